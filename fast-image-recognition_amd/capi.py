@@ -1,0 +1,224 @@
+"""ctypes binding of include/fir_amd.h (plumbing only: argument marshalling, error mapping)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+METRIC_L2, METRIC_CHI2, METRIC_KL = 0, 1, 2
+KEY_NONE = 0xFFFFFFFFFFFFFFFF
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def lib_path():
+    return os.path.join(_HERE, "libfir_amd.so")
+
+
+class FirError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"fir_amd error {code}: {msg}")
+        self.code = code
+
+
+# Every symbol include/fir_amd.h declares: (name, restype, argtypes).
+_f32p = C.POINTER(C.c_float)
+_i32p = C.POINTER(C.c_int32)
+_i64p = C.POINTER(C.c_int64)
+_u64p = C.POINTER(C.c_uint64)
+_vp = C.c_void_p
+SYMBOLS = [
+    ("fir_last_error", C.c_char_p, []),
+    ("fir_version", C.c_int, []),
+    ("fir_device_count", C.c_int, []),
+    ("fir_device_info", C.c_int, [C.c_int32, C.c_char_p, C.c_int32, _i32p, _i64p]),
+    ("fir_gallery_create", C.c_int, [_vp, C.c_int64, C.c_int32, _vp, C.c_int32, C.c_int32, C.POINTER(_vp)]),
+    ("fir_gallery_create_dev", C.c_int, [_vp, C.c_int64, C.c_int32, _vp, C.c_int32, C.c_int32, _vp, C.POINTER(_vp)]),
+    ("fir_gallery_destroy", C.c_int, [_vp]),
+    ("fir_gallery_info", C.c_int, [_vp, _i64p, _i32p, _i32p, _i32p]),
+    ("fir_gallery_set_metric", C.c_int, [_vp, C.c_int32]),
+    ("fir_gallery_set_row_offset", C.c_int, [_vp, C.c_int64]),
+    ("fir_feature_distance", C.c_int, [_vp, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f32p]),
+    ("fir_search_top1", C.c_int, [_vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp]),
+    ("fir_search_top1_keys_dev", C.c_int, [_vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp]),
+    ("fir_keys_unpack", C.c_int, [_vp, C.c_int32, _vp, _vp]),
+    ("fir_key_pack", C.c_uint64, [C.c_float, C.c_int32]),
+    ("fir_gallery_classes_of", C.c_int, [_vp, _vp, C.c_int32, _vp]),
+    ("fir_search_topk", C.c_int, [_vp, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp, _vp]),
+    ("fir_search_topk_keys_dev", C.c_int, [_vp, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp, _vp]),
+    ("fir_range_distances", C.c_int, [_vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp]),
+    ("fir_range_distances_dev", C.c_int, [_vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp]),
+    ("fir_profile_enable", C.c_int, [_vp, C.c_int32]),
+    ("fir_profile_read", C.c_int, [_vp, _vp, C.c_int32, _i32p, C.POINTER(C.c_double)]),
+    ("fir_gallery_sync", C.c_int, [_vp]),
+    ("fir_gallery_set_tuning", C.c_int, [_vp, C.c_int32, C.c_int32]),
+    ("fir_gallery_get_tuning", C.c_int, [_vp, _i32p, _i32p, _i32p]),
+]
+
+_lib = None
+
+
+def lib():
+    """Load libfir_amd.so (once). Raises if it has not been built: there is no fallback."""
+    global _lib
+    if _lib is None:
+        p = lib_path()
+        if not os.path.exists(p):
+            raise FirError(-100, f"{p} not built (run __graft_entry__.build())")
+        L = C.CDLL(p)
+        for name, res, args in SYMBOLS:
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise FirError(rc, lib().fir_last_error().decode(errors="replace"))
+
+
+def _f32(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(_vp)
+
+
+def device_count():
+    return lib().fir_device_count()
+
+
+def device_info(device=0):
+    name = C.create_string_buffer(64)
+    cus = C.c_int32()
+    hbm = C.c_int64()
+    _check(lib().fir_device_info(device, name, 64, C.byref(cus), C.byref(hbm)))
+    return {"arch": name.value.decode(), "cus": cus.value, "hbm_bytes": hbm.value}
+
+
+def feature_distance(lhs, rhs, start=0, end=None, metric=METRIC_L2, device=0):
+    lhs, pl = _f32(lhs)
+    rhs, pr = _f32(rhs)
+    if end is None:
+        end = lhs.size
+    out = C.c_float()
+    _check(lib().fir_feature_distance(pl, pr, lhs.size, start, end, metric, device, C.byref(out)))
+    return np.float32(out.value)
+
+
+def key_pack(dist, idx):
+    return int(lib().fir_key_pack(float(dist), int(idx)))
+
+
+def keys_unpack(keys):
+    keys = np.ascontiguousarray(keys, dtype=np.uint64)
+    idx = np.empty(keys.shape, np.int32)
+    dist = np.empty(keys.shape, np.float32)
+    _check(lib().fir_keys_unpack(keys.ctypes.data_as(_vp), keys.size, idx.ctypes.data_as(_vp), dist.ctypes.data_as(_vp)))
+    return idx, dist
+
+
+class Gallery:
+    """Owns one fir_gallery handle. Host arrays in, host arrays out, unless the *_dev methods
+    are used with raw device pointers (ints, e.g. torch.Tensor.data_ptr())."""
+
+    def __init__(self, rows=None, class_no=None, metric=METRIC_L2, device=0, *, dev_ptr=None, n=None, d=None,
+                 dev_class_ptr=None, stream=None):
+        self._h = _vp()
+        if dev_ptr is not None:
+            _check(lib().fir_gallery_create_dev(_vp(dev_ptr), n, d, _vp(dev_class_ptr) if dev_class_ptr else None, metric,
+                                                device, _vp(stream) if stream else None, C.byref(self._h)))
+            self.n, self.d = int(n), int(d)
+        else:
+            rows = np.ascontiguousarray(rows, dtype=np.float32)
+            if rows.ndim != 2:
+                raise ValueError("rows must be [n, d]")
+            cls_p = None
+            if class_no is not None:
+                class_no = np.ascontiguousarray(class_no, dtype=np.int32)
+                cls_p = class_no.ctypes.data_as(_vp)
+            _check(lib().fir_gallery_create(rows.ctypes.data_as(_vp), rows.shape[0], rows.shape[1], cls_p, metric, device,
+                                            C.byref(self._h)))
+            self.n, self.d = rows.shape
+        self.device = device
+
+    def close(self):
+        if self._h:
+            lib().fir_gallery_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def set_metric(self, metric):
+        _check(lib().fir_gallery_set_metric(self._h, metric))
+
+    def set_row_offset(self, off):
+        _check(lib().fir_gallery_set_row_offset(self._h, off))
+
+    def set_tuning(self, queries_per_pass=0, waves=0):
+        _check(lib().fir_gallery_set_tuning(self._h, queries_per_pass, waves))
+
+    def get_tuning(self):
+        a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+        _check(lib().fir_gallery_get_tuning(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"queries_per_pass": a.value, "waves": b.value, "max_waves": c.value}
+
+    def search_top1(self, queries, start=0, end=0):
+        q, pq = _f32(queries)
+        q = q.reshape(-1, self.d)
+        idx = np.empty(q.shape[0], np.int32)
+        dist = np.empty(q.shape[0], np.float32)
+        _check(lib().fir_search_top1(self._h, pq, q.shape[0], start, end, idx.ctypes.data_as(_vp), dist.ctypes.data_as(_vp)))
+        return idx, dist
+
+    def search_top1_keys_dev(self, q_ptr, qb, keys_ptr, start=0, end=0, stream=None):
+        _check(lib().fir_search_top1_keys_dev(self._h, _vp(q_ptr), qb, start, end, _vp(keys_ptr), _vp(stream) if stream else None))
+
+    def search_topk(self, queries, k, start=0, end=0):
+        q, pq = _f32(queries)
+        q = q.reshape(-1, self.d)
+        idx = np.empty((q.shape[0], k), np.int32)
+        dist = np.empty((q.shape[0], k), np.float32)
+        _check(lib().fir_search_topk(self._h, pq, q.shape[0], start, end, k, idx.ctypes.data_as(_vp), dist.ctypes.data_as(_vp)))
+        return idx, dist
+
+    def search_topk_keys_dev(self, q_ptr, qb, k, keys_ptr, start=0, end=0, stream=None):
+        _check(lib().fir_search_topk_keys_dev(self._h, _vp(q_ptr), qb, start, end, k, _vp(keys_ptr), _vp(stream) if stream else None))
+
+    def range_distances(self, queries, start=0, end=0):
+        q, pq = _f32(queries)
+        q = q.reshape(-1, self.d)
+        out = np.empty((q.shape[0], self.n), np.float32)
+        _check(lib().fir_range_distances(self._h, pq, q.shape[0], start, end, out.ctypes.data_as(_vp)))
+        return out
+
+    def range_distances_dev(self, q_ptr, qb, out_ptr, start=0, end=0, stream=None):
+        _check(lib().fir_range_distances_dev(self._h, _vp(q_ptr), qb, start, end, _vp(out_ptr), _vp(stream) if stream else None))
+
+    def classes_of(self, idx):
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        out = np.empty(idx.shape, np.int32)
+        _check(lib().fir_gallery_classes_of(self._h, idx.ctypes.data_as(_vp), idx.size, out.ctypes.data_as(_vp)))
+        return out
+
+    def profile_enable(self, on=True):
+        _check(lib().fir_profile_enable(self._h, 1 if on else 0))
+
+    def profile_read(self, cap=65536):
+        ms = np.empty(cap, np.float32)
+        cnt = C.c_int32()
+        nbytes = C.c_double()
+        _check(lib().fir_profile_read(self._h, ms.ctypes.data_as(_vp), cap, C.byref(cnt), C.byref(nbytes)))
+        return ms[: min(cnt.value, cap)].copy(), nbytes.value
+
+    def sync(self):
+        _check(lib().fir_gallery_sync(self._h))

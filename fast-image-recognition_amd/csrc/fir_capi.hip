@@ -1,0 +1,611 @@
+// fir_capi.hip -- the C ABI (include/fir_amd.h) over the gfx950 kernels in fir_kernels.h.
+//
+// Host side of the drop-in boundary: owns device buffers, streams and launch geometry.
+// Nothing here computes a distance on the host; without a HIP device every entry point fails.
+#include "fir_kernels.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/fir_amd.h"
+
+using namespace fir;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define FIR_HIP(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) return fail(e_ == hipErrorOutOfMemory ? FIR_ERR_NOMEM : FIR_ERR_HIP,     \
+                                          "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+constexpr int kU = 8;        // float4 chunks per lane per load group (8 KiB per wave in flight per group)
+constexpr int kWps = 4;      // waves per SIMD the scan kernels are register-budgeted for (<= 128 VGPRs)
+constexpr int kKMax = 8;     // per-lane candidate list length of the top-K scan
+
+}  // namespace
+
+struct fir_gallery {
+    int device = 0;
+    int cus = 0;
+    int64_t n = 0;
+    int d = 0, dp4 = 0;
+    int64_t tiles = 0;
+    int metric = FIR_METRIC_L2;
+    int64_t row_offset = 0;
+    float4* gal4 = nullptr;
+    int32_t* cls = nullptr;
+    hipStream_t stream = nullptr;
+
+    // workspaces (grown on demand, never inside a *_dev call once large enough)
+    float* qt = nullptr;      size_t qt_cap = 0;      // transposed query tiles
+    float* dq = nullptr;      size_t dq_cap = 0;      // staged host queries
+    uint64_t* dkeys = nullptr; size_t dkeys_cap = 0;  // keys for the host-pointer API
+    uint64_t* part = nullptr; size_t part_cap = 0;    // top-K per-wave partials
+    float* dout = nullptr;    size_t dout_cap = 0;    // range distances for the host-pointer API
+    int32_t* didx = nullptr;  size_t didx_cap = 0;
+
+    int qpp = 8;              // queries per gallery pass
+    int waves_req = 0;        // 0 = automatic
+    int max_waves = 0;
+
+    bool profiling = false;
+    std::vector<hipEvent_t> ev;   // pairs
+    size_t ev_used = 0;
+    double last_bytes = 0.0;
+};
+
+namespace {
+
+template <typename T>
+int grow(T*& p, size_t& cap, size_t need) {
+    if (need <= cap) return FIR_OK;
+    if (p) FIR_HIP(hipFree(p));
+    p = nullptr; cap = 0;
+    size_t want = std::max(need, (size_t)4096);
+    FIR_HIP(hipMalloc((void**)&p, want * sizeof(T)));
+    cap = want;
+    return FIR_OK;
+}
+
+typedef void (*scan_fn)(const ScanArgs);
+
+template <int EPI>
+scan_fn pick_kernel(int qb, int metric) {
+#define FIR_CASE(QB, M) if (qb == QB && metric == M) return (scan_fn)k_scan<QB, M, kU, EPI, kKMax, kWps>;
+    FIR_CASE(1, 0) FIR_CASE(2, 0) FIR_CASE(4, 0)
+    FIR_CASE(1, 1) FIR_CASE(2, 1) FIR_CASE(4, 1)
+    FIR_CASE(1, 2) FIR_CASE(2, 2) FIR_CASE(4, 2)
+    if constexpr (EPI != kEpiTopK) {   // the top-K scan keeps 2*kKMax registers per query: 4 queries at most
+        FIR_CASE(8, 0) FIR_CASE(8, 1) FIR_CASE(8, 2)
+    }
+#undef FIR_CASE
+    return nullptr;
+}
+
+scan_fn pick(int epi, int qb, int metric) {
+    switch (epi) {
+        case kEpiTop1: return pick_kernel<kEpiTop1>(qb, metric);
+        case kEpiTopK: return pick_kernel<kEpiTopK>(qb, metric);
+        default: return pick_kernel<kEpiStore>(qb, metric);
+    }
+}
+
+// Number of waves for `tiles` tiles: every wave gets ceil(tiles / waves) or one fewer tile and
+// all waves are resident at once, so the grid drains together (no ragged last round).
+int pick_waves(int64_t tiles, int max_waves) {
+    if (tiles <= 0) return 4;
+    if (tiles <= max_waves) return (int)((tiles + 3) / 4 * 4);
+    const int64_t rounds = (tiles + max_waves - 1) / max_waves;
+    const int64_t w = (tiles + rounds - 1) / rounds;
+    return (int)std::min<int64_t>((w + 3) / 4 * 4, max_waves);
+}
+
+int check_range(const fir_gallery* g, int32_t& start, int32_t& end) {
+    if (end == 0) end = g->d;   // db_features.cpp:320-321
+    if (start < 0 || end > g->d || start >= end)
+        return fail(FIR_ERR_ARG, "feature range [%d,%d) not inside [0,%d)", start, end, g->d);
+    return FIR_OK;
+}
+
+int largest_pow2_le(int x, int cap) {
+    int p = 1;
+    while (p * 2 <= x && p * 2 <= cap) p *= 2;
+    return p;
+}
+
+// Queue: transpose (+ key init) of one query tile, then one gallery pass.
+int run_pass(fir_gallery* g, hipStream_t st, int epi, const float* d_queries, int q0, int qb_tile, int32_t start,
+             int32_t end, uint64_t* keys, float* out, int64_t out_stride, int k) {
+    const int kk = g->dp4 * 4;
+    float* qt = g->qt + (size_t)q0 * kk;
+    {
+        const int64_t total = (int64_t)kk * qb_tile;
+        const int blocks = (int)((total + kBlock - 1) / kBlock);
+        hipLaunchKernelGGL(k_transpose_queries, dim3(blocks), dim3(kBlock), 0, st, d_queries + (size_t)q0 * g->d, qb_tile,
+                           g->d, g->dp4, qb_tile, qt);
+    }
+    scan_fn fn = pick(epi, qb_tile, g->metric);
+    if (!fn) return fail(FIR_ERR_ARG, "no kernel for qb=%d metric=%d", qb_tile, g->metric);
+    const int waves = g->waves_req > 0 ? std::min(g->waves_req, g->max_waves) : pick_waves(g->tiles, g->max_waves);
+    ScanArgs a;
+    a.gal4 = g->gal4;
+    a.qt = qt;
+    a.n = g->n;
+    a.tiles = (int32_t)g->tiles;
+    a.dp4 = g->dp4;
+    a.start = start;
+    a.end = end;
+    a.waves = waves;
+    a.row_offset = g->row_offset;
+    a.keys = keys;
+    a.out = out;
+    a.out_stride = out_stride;
+    a.nq = qb_tile;
+    a.k = k;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (g->profiling) {
+        if (g->ev_used + 2 > g->ev.size()) {
+            for (int i = 0; i < 64; ++i) {
+                hipEvent_t e;
+                FIR_HIP(hipEventCreate(&e));
+                g->ev.push_back(e);
+            }
+        }
+        e0 = g->ev[g->ev_used++];
+        e1 = g->ev[g->ev_used++];
+        FIR_HIP(hipEventRecord(e0, st));
+    }
+    hipLaunchKernelGGL(fn, dim3(waves / 4), dim3(kBlock), 0, st, a);
+    if (g->profiling) {
+        FIR_HIP(hipEventRecord(e1, st));
+        // algorithmic bytes of one pass: the gallery range once, the query tile, the keys
+        g->last_bytes = (double)g->n * (end - start) * 4.0 + (double)qb_tile * (end - start) * 4.0 + qb_tile * 8.0;
+    }
+    FIR_HIP(hipGetLastError());
+    return FIR_OK;
+}
+
+__global__ void k_fill_keys(uint64_t* keys, int n) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) keys[i] = kKeyNone;
+}
+
+int top1_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start, int32_t end, uint64_t* d_keys,
+             hipStream_t st) {
+    int rc = grow(g->qt, g->qt_cap, (size_t)qb * g->dp4 * 4);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_fill_keys, dim3((qb + kBlock - 1) / kBlock), dim3(kBlock), 0, st, d_keys, qb);
+    int q0 = 0;
+    while (q0 < qb) {
+        const int t = largest_pow2_le(qb - q0, g->qpp);
+        rc = run_pass(g, st, kEpiTop1, d_queries, q0, t, start, end, d_keys + q0, nullptr, 0, 0);
+        if (rc) return rc;
+        q0 += t;
+    }
+    return FIR_OK;
+}
+
+int topk_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start, int32_t end, int32_t k, uint64_t* d_keys,
+             hipStream_t st) {
+    int rc = grow(g->qt, g->qt_cap, (size_t)qb * g->dp4 * 4);
+    if (rc) return rc;
+    const int qcap = std::min(g->qpp, 4);   // 2*kKMax registers per query per lane
+    rc = grow(g->part, g->part_cap, (size_t)g->max_waves * qcap * k);
+    if (rc) return rc;
+    int q0 = 0;
+    while (q0 < qb) {
+        const int t = largest_pow2_le(qb - q0, qcap);
+        rc = run_pass(g, st, kEpiTopK, d_queries, q0, t, start, end, g->part, nullptr, 0, k);
+        if (rc) return rc;
+        const int waves = g->waves_req > 0 ? std::min(g->waves_req, g->max_waves) : pick_waves(g->tiles, g->max_waves);
+        hipLaunchKernelGGL(k_topk_merge, dim3(t), dim3(kBlock), 0, st, g->part, waves, t, q0, t, k, d_keys);
+        q0 += t;
+    }
+    FIR_HIP(hipGetLastError());
+    return FIR_OK;
+}
+
+int range_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start, int32_t end, float* d_out, hipStream_t st) {
+    int rc = grow(g->qt, g->qt_cap, (size_t)qb * g->dp4 * 4);
+    if (rc) return rc;
+    int q0 = 0;
+    while (q0 < qb) {
+        const int t = largest_pow2_le(qb - q0, g->qpp);
+        rc = run_pass(g, st, kEpiStore, d_queries, q0, t, start, end, nullptr, d_out + (size_t)q0 * g->n, g->n, 0);
+        if (rc) return rc;
+        q0 += t;
+    }
+    return FIR_OK;
+}
+
+int set_device(int device) {
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) return fail(FIR_ERR_NODEVICE, "no HIP device visible");
+    if (device < 0 || device >= cnt) return fail(FIR_ERR_NODEVICE, "device %d out of range (%d visible)", device, cnt);
+    FIR_HIP(hipSetDevice(device));
+    return FIR_OK;
+}
+
+int gallery_alloc(int64_t n, int32_t d, int32_t metric, int32_t device, fir_gallery** out) {
+    if (!out) return fail(FIR_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (n < 0 || d <= 0) return fail(FIR_ERR_ARG, "bad gallery shape n=%lld d=%d", (long long)n, d);
+    if (n >= ((int64_t)1 << 31) - 64) return fail(FIR_ERR_ARG, "n=%lld does not fit 32-bit row indices", (long long)n);
+    if (metric < 0 || metric > 2) return fail(FIR_ERR_ARG, "bad metric %d", metric);
+    int rc = set_device(device);
+    if (rc) return rc;
+    hipDeviceProp_t prop;
+    FIR_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(FIR_ERR_NODEVICE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+    fir_gallery* g = new (std::nothrow) fir_gallery();
+    if (!g) return fail(FIR_ERR_NOMEM, "host allocation failed");
+    g->device = device;
+    g->cus = prop.multiProcessorCount;
+    g->n = n;
+    g->d = d;
+    g->dp4 = (d + 3) / 4;
+    g->tiles = (n + kTileRows - 1) / kTileRows;
+    g->metric = metric;
+    int nb = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_scan<8, 0, kU, kEpiTop1, kKMax, kWps>, kBlock, 0);
+    if (e != hipSuccess || nb <= 0) nb = 4;
+    nb = std::min(nb, 8);
+    g->max_waves = g->cus * nb * (kBlock / 64);
+    e = hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete g; return fail(FIR_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    const size_t f4 = (size_t)std::max<int64_t>(g->tiles, 1) * g->dp4 * 64;
+    e = hipMalloc((void**)&g->gal4, f4 * sizeof(float4));
+    if (e != hipSuccess) {
+        (void)hipStreamDestroy(g->stream);
+        delete g;
+        return fail(FIR_ERR_NOMEM, "hipMalloc of %zu gallery bytes: %s", f4 * sizeof(float4), hipGetErrorString(e));
+    }
+    *out = g;
+    return FIR_OK;
+}
+
+int retile_slab(fir_gallery* g, const float* d_rows, int64_t slab_rows, int64_t row0, hipStream_t st) {
+    const int64_t slab_tiles = (slab_rows + kTileRows - 1) / kTileRows;
+    const int64_t total = slab_tiles * g->dp4 * 64;
+    if (total == 0) return FIR_OK;
+    const int64_t blocks = (total + kBlock - 1) / kBlock;
+    if (blocks > 0x7FFFFFFF) return fail(FIR_ERR_ARG, "slab too large");
+    hipLaunchKernelGGL(k_retile, dim3((unsigned)blocks), dim3(kBlock), 0, st, d_rows, slab_rows, row0, g->n, g->d, g->dp4, g->gal4);
+    FIR_HIP(hipGetLastError());
+    return FIR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* fir_last_error(void) { return g_err; }
+int fir_version(void) { return 100; }
+
+int fir_device_count(void) {
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess) return 0;
+    return cnt;
+}
+
+int fir_device_info(int32_t device, char* name, int32_t cap, int32_t* cus, int64_t* hbm_bytes) {
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || device < 0 || device >= cnt)
+        return fail(FIR_ERR_NODEVICE, "device %d not available", device);
+    hipDeviceProp_t prop;
+    FIR_HIP(hipGetDeviceProperties(&prop, device));
+    if (name && cap > 0) { strncpy(name, prop.gcnArchName, (size_t)cap - 1); name[cap - 1] = 0; }
+    if (cus) *cus = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+    return FIR_OK;
+}
+
+int fir_gallery_create(const float* rows, int64_t n, int32_t d, const int32_t* class_no, int32_t metric, int32_t device,
+                       fir_gallery** out) {
+    if (n > 0 && !rows) return fail(FIR_ERR_ARG, "rows is NULL");
+    fir_gallery* g = nullptr;
+    int rc = gallery_alloc(n, d, metric, device, &g);
+    if (rc) return rc;
+    // upload in slabs of whole tiles (<= 256 MiB of rows each) and re-tile on the device
+    int64_t slab = std::max<int64_t>(kTileRows, ((int64_t)(256u << 20) / ((int64_t)d * 4)) / kTileRows * kTileRows);
+    slab = std::min<int64_t>(slab, std::max<int64_t>(g->tiles, 1) * kTileRows);
+    float* stage = nullptr;
+    hipError_t e = hipMalloc((void**)&stage, (size_t)slab * d * sizeof(float));
+    if (e != hipSuccess) { fir_gallery_destroy(g); return fail(FIR_ERR_NOMEM, "staging hipMalloc: %s", hipGetErrorString(e)); }
+    for (int64_t r0 = 0; r0 < std::max<int64_t>(g->tiles, 1) * kTileRows && rc == FIR_OK; r0 += slab) {
+        const int64_t have = std::max<int64_t>(0, std::min<int64_t>(slab, n - r0));
+        if (have > 0) {
+            e = hipMemcpyAsync(stage, rows + r0 * d, (size_t)have * d * sizeof(float), hipMemcpyHostToDevice, g->stream);
+            if (e != hipSuccess) { rc = fail(FIR_ERR_HIP, "gallery upload: %s", hipGetErrorString(e)); break; }
+        }
+        if (have > 0) rc = retile_slab(g, stage, have, r0, g->stream);
+        e = hipStreamSynchronize(g->stream);   // the staging buffer is reused by the next slab
+        if (e != hipSuccess && rc == FIR_OK) rc = fail(FIR_ERR_HIP, "gallery retile: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(stage);
+    if (rc == FIR_OK && class_no && n > 0) {
+        e = hipMalloc((void**)&g->cls, (size_t)n * sizeof(int32_t));
+        if (e == hipSuccess) e = hipMemcpy(g->cls, class_no, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice);
+        if (e != hipSuccess) rc = fail(FIR_ERR_HIP, "class upload: %s", hipGetErrorString(e));
+    }
+    if (rc) { fir_gallery_destroy(g); return rc; }
+    *out = g;
+    return FIR_OK;
+}
+
+int fir_gallery_create_dev(const float* d_rows, int64_t n, int32_t d, const int32_t* d_class_no, int32_t metric,
+                           int32_t device, void* stream, fir_gallery** out) {
+    if (n > 0 && !d_rows) return fail(FIR_ERR_ARG, "d_rows is NULL");
+    fir_gallery* g = nullptr;
+    int rc = gallery_alloc(n, d, metric, device, &g);
+    if (rc) return rc;
+    hipStream_t st = stream ? (hipStream_t)stream : g->stream;
+    // slabs keep the launch grid inside 2^31 blocks
+    const int64_t slab = std::max<int64_t>(kTileRows, ((int64_t)1 << 30) / ((int64_t)g->dp4 * 4) / kTileRows * kTileRows);
+    for (int64_t r0 = 0; r0 < g->tiles * kTileRows && rc == FIR_OK; r0 += slab) {
+        const int64_t span = std::min<int64_t>(slab, g->tiles * kTileRows - r0);
+        rc = retile_slab(g, d_rows + r0 * d, span, r0, st);
+    }
+    if (rc == FIR_OK && d_class_no && n > 0) {
+        hipError_t e = hipMalloc((void**)&g->cls, (size_t)n * sizeof(int32_t));
+        if (e == hipSuccess) e = hipMemcpyAsync(g->cls, d_class_no, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) rc = fail(FIR_ERR_HIP, "class copy: %s", hipGetErrorString(e));
+    }
+    if (rc == FIR_OK) {
+        hipError_t e = hipStreamSynchronize(st);
+        if (e != hipSuccess) rc = fail(FIR_ERR_HIP, "gallery retile: %s", hipGetErrorString(e));
+    }
+    if (rc) { fir_gallery_destroy(g); return rc; }
+    *out = g;
+    return FIR_OK;
+}
+
+int fir_gallery_destroy(fir_gallery* g) {
+    if (!g) return FIR_OK;
+    (void)hipSetDevice(g->device);
+    if (g->stream) (void)hipStreamSynchronize(g->stream);
+    for (hipEvent_t e : g->ev) (void)hipEventDestroy(e);
+    (void)hipFree(g->gal4); (void)hipFree(g->cls); (void)hipFree(g->qt); (void)hipFree(g->dq); (void)hipFree(g->dkeys);
+    (void)hipFree(g->part); (void)hipFree(g->dout); (void)hipFree(g->didx);
+    if (g->stream) (void)hipStreamDestroy(g->stream);
+    delete g;
+    return FIR_OK;
+}
+
+int fir_gallery_info(const fir_gallery* g, int64_t* n, int32_t* d, int32_t* metric, int32_t* device) {
+    if (!g) return fail(FIR_ERR_ARG, "gallery is NULL");
+    if (n) *n = g->n;
+    if (d) *d = g->d;
+    if (metric) *metric = g->metric;
+    if (device) *device = g->device;
+    return FIR_OK;
+}
+
+int fir_gallery_set_metric(fir_gallery* g, int32_t metric) {
+    if (!g) return fail(FIR_ERR_ARG, "gallery is NULL");
+    if (metric < 0 || metric > 2) return fail(FIR_ERR_ARG, "bad metric %d", metric);
+    g->metric = metric;
+    return FIR_OK;
+}
+
+int fir_gallery_set_row_offset(fir_gallery* g, int64_t first_global_row) {
+    if (!g) return fail(FIR_ERR_ARG, "gallery is NULL");
+    if (first_global_row < 0 || first_global_row + g->n >= ((int64_t)1 << 31))
+        return fail(FIR_ERR_ARG, "row offset %lld + n does not fit 32-bit indices", (long long)first_global_row);
+    g->row_offset = first_global_row;
+    return FIR_OK;
+}
+
+int fir_feature_distance(const float* lhs, const float* rhs, int32_t len, int32_t start_pos, int32_t end_pos,
+                         int32_t metric, int32_t device, float* out) {
+    if (!lhs || !rhs || !out) return fail(FIR_ERR_ARG, "NULL argument");
+    if (start_pos < 0 || end_pos > len || start_pos >= end_pos) return fail(FIR_ERR_ARG, "bad range [%d,%d) of %d", start_pos, end_pos, len);
+    if (metric < 0 || metric > 2) return fail(FIR_ERR_ARG, "bad metric %d", metric);
+    int rc = set_device(device);
+    if (rc) return rc;
+    float* buf = nullptr;
+    FIR_HIP(hipMalloc((void**)&buf, (size_t)(2 * len + 1) * sizeof(float)));
+    hipError_t e = hipMemcpy(buf, lhs, (size_t)len * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(buf + len, rhs, (size_t)len * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        if (metric == 0) hipLaunchKernelGGL(k_pair_distance<0>, dim3(1), dim3(64), 0, 0, buf, buf + len, start_pos, end_pos, buf + 2 * len);
+        else if (metric == 1) hipLaunchKernelGGL(k_pair_distance<1>, dim3(1), dim3(64), 0, 0, buf, buf + len, start_pos, end_pos, buf + 2 * len);
+        else hipLaunchKernelGGL(k_pair_distance<2>, dim3(1), dim3(64), 0, 0, buf, buf + len, start_pos, end_pos, buf + 2 * len);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(out, buf + 2 * len, sizeof(float), hipMemcpyDeviceToHost);
+    (void)hipFree(buf);
+    if (e != hipSuccess) return fail(FIR_ERR_HIP, "pair distance: %s", hipGetErrorString(e));
+    return FIR_OK;
+}
+
+int fir_search_top1_keys_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start_pos, int32_t end_pos,
+                             uint64_t* d_keys, void* stream) {
+    if (!g || !d_keys || (qb > 0 && !d_queries)) return fail(FIR_ERR_ARG, "NULL argument");
+    if (qb < 0) return fail(FIR_ERR_ARG, "qb < 0");
+    if (qb == 0) return FIR_OK;
+    int rc = check_range(g, start_pos, end_pos);
+    if (rc) return rc;
+    FIR_HIP(hipSetDevice(g->device));
+    return top1_dev(g, d_queries, qb, start_pos, end_pos, d_keys, stream ? (hipStream_t)stream : g->stream);
+}
+
+int fir_search_top1(fir_gallery* g, const float* queries, int32_t qb, int32_t start_pos, int32_t end_pos, int32_t* idx,
+                    float* dist) {
+    if (!g || (qb > 0 && !queries)) return fail(FIR_ERR_ARG, "NULL argument");
+    if (qb < 0) return fail(FIR_ERR_ARG, "qb < 0");
+    if (qb == 0) return FIR_OK;
+    int rc = check_range(g, start_pos, end_pos);
+    if (rc) return rc;
+    FIR_HIP(hipSetDevice(g->device));
+    if ((rc = grow(g->dq, g->dq_cap, (size_t)qb * g->d))) return rc;
+    if ((rc = grow(g->dkeys, g->dkeys_cap, (size_t)qb))) return rc;
+    FIR_HIP(hipMemcpyAsync(g->dq, queries, (size_t)qb * g->d * sizeof(float), hipMemcpyHostToDevice, g->stream));
+    if ((rc = top1_dev(g, g->dq, qb, start_pos, end_pos, g->dkeys, g->stream))) return rc;
+    std::vector<uint64_t> keys((size_t)qb);
+    FIR_HIP(hipMemcpyAsync(keys.data(), g->dkeys, (size_t)qb * sizeof(uint64_t), hipMemcpyDeviceToHost, g->stream));
+    FIR_HIP(hipStreamSynchronize(g->stream));
+    return fir_keys_unpack(keys.data(), qb, idx, dist);
+}
+
+uint64_t fir_key_pack(float dist, int32_t idx) {
+    if (idx < 0) return kKeyNone;
+    return key_pack(dist, (uint32_t)idx);
+}
+
+int fir_keys_unpack(const uint64_t* keys, int32_t n, int32_t* idx, float* dist) {
+    if (!keys && n > 0) return fail(FIR_ERR_ARG, "keys is NULL");
+    for (int32_t i = 0; i < n; ++i) {
+        if (keys[i] == kKeyNone) {
+            if (idx) idx[i] = -1;
+            if (dist) dist[i] = kNotFound;
+        } else {
+            if (idx) idx[i] = (int32_t)(uint32_t)(keys[i] & 0xFFFFFFFFull);
+            if (dist) dist[i] = f32_from_orderable((uint32_t)(keys[i] >> 32));
+        }
+    }
+    return FIR_OK;
+}
+
+int fir_gallery_classes_of(fir_gallery* g, const int32_t* idx, int32_t n, int32_t* class_out) {
+    if (!g || !idx || !class_out) return fail(FIR_ERR_ARG, "NULL argument");
+    if (!g->cls) return fail(FIR_ERR_STATE, "gallery was created without class labels");
+    if (n <= 0) return FIR_OK;
+    FIR_HIP(hipSetDevice(g->device));
+    int rc = grow(g->didx, g->didx_cap, (size_t)2 * n);
+    if (rc) return rc;
+    FIR_HIP(hipMemcpyAsync(g->didx, idx, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, g->stream));
+    hipLaunchKernelGGL(k_classes_of, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, g->stream, g->cls, g->n, g->row_offset,
+                       g->didx, n, g->didx + n);
+    FIR_HIP(hipGetLastError());
+    FIR_HIP(hipMemcpyAsync(class_out, g->didx + n, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, g->stream));
+    FIR_HIP(hipStreamSynchronize(g->stream));
+    return FIR_OK;
+}
+
+int fir_search_topk_keys_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start_pos, int32_t end_pos,
+                             int32_t k, uint64_t* d_keys, void* stream) {
+    if (!g || !d_keys || (qb > 0 && !d_queries)) return fail(FIR_ERR_ARG, "NULL argument");
+    if (qb < 0) return fail(FIR_ERR_ARG, "qb < 0");
+    if (k < 1 || k > kKMax) return fail(FIR_ERR_ARG, "k=%d outside [1,%d]", k, kKMax);
+    if (qb == 0) return FIR_OK;
+    int rc = check_range(g, start_pos, end_pos);
+    if (rc) return rc;
+    FIR_HIP(hipSetDevice(g->device));
+    return topk_dev(g, d_queries, qb, start_pos, end_pos, k, d_keys, stream ? (hipStream_t)stream : g->stream);
+}
+
+int fir_search_topk(fir_gallery* g, const float* queries, int32_t qb, int32_t start_pos, int32_t end_pos, int32_t k,
+                    int32_t* idx, float* dist) {
+    if (!g || (qb > 0 && !queries)) return fail(FIR_ERR_ARG, "NULL argument");
+    if (qb < 0) return fail(FIR_ERR_ARG, "qb < 0");
+    if (k < 1 || k > kKMax) return fail(FIR_ERR_ARG, "k=%d outside [1,%d]", k, kKMax);
+    if (qb == 0) return FIR_OK;
+    int rc = check_range(g, start_pos, end_pos);
+    if (rc) return rc;
+    FIR_HIP(hipSetDevice(g->device));
+    if ((rc = grow(g->dq, g->dq_cap, (size_t)qb * g->d))) return rc;
+    if ((rc = grow(g->dkeys, g->dkeys_cap, (size_t)qb * k))) return rc;
+    FIR_HIP(hipMemcpyAsync(g->dq, queries, (size_t)qb * g->d * sizeof(float), hipMemcpyHostToDevice, g->stream));
+    if ((rc = topk_dev(g, g->dq, qb, start_pos, end_pos, k, g->dkeys, g->stream))) return rc;
+    std::vector<uint64_t> keys((size_t)qb * k);
+    FIR_HIP(hipMemcpyAsync(keys.data(), g->dkeys, keys.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, g->stream));
+    FIR_HIP(hipStreamSynchronize(g->stream));
+    return fir_keys_unpack(keys.data(), qb * k, idx, dist);
+}
+
+int fir_range_distances_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start_pos, int32_t end_pos,
+                            float* d_out, void* stream) {
+    if (!g || !d_out || (qb > 0 && !d_queries)) return fail(FIR_ERR_ARG, "NULL argument");
+    if (qb < 0) return fail(FIR_ERR_ARG, "qb < 0");
+    if (qb == 0) return FIR_OK;
+    int rc = check_range(g, start_pos, end_pos);
+    if (rc) return rc;
+    FIR_HIP(hipSetDevice(g->device));
+    return range_dev(g, d_queries, qb, start_pos, end_pos, d_out, stream ? (hipStream_t)stream : g->stream);
+}
+
+int fir_range_distances(fir_gallery* g, const float* queries, int32_t qb, int32_t start_pos, int32_t end_pos, float* out) {
+    if (!g || !out || (qb > 0 && !queries)) return fail(FIR_ERR_ARG, "NULL argument");
+    if (qb < 0) return fail(FIR_ERR_ARG, "qb < 0");
+    if (qb == 0 || g->n == 0) return FIR_OK;
+    int rc = check_range(g, start_pos, end_pos);
+    if (rc) return rc;
+    FIR_HIP(hipSetDevice(g->device));
+    if ((rc = grow(g->dq, g->dq_cap, (size_t)qb * g->d))) return rc;
+    if ((rc = grow(g->dout, g->dout_cap, (size_t)qb * g->n))) return rc;
+    FIR_HIP(hipMemcpyAsync(g->dq, queries, (size_t)qb * g->d * sizeof(float), hipMemcpyHostToDevice, g->stream));
+    if ((rc = range_dev(g, g->dq, qb, start_pos, end_pos, g->dout, g->stream))) return rc;
+    FIR_HIP(hipMemcpyAsync(out, g->dout, (size_t)qb * g->n * sizeof(float), hipMemcpyDeviceToHost, g->stream));
+    FIR_HIP(hipStreamSynchronize(g->stream));
+    return FIR_OK;
+}
+
+int fir_profile_enable(fir_gallery* g, int32_t on) {
+    if (!g) return fail(FIR_ERR_ARG, "gallery is NULL");
+    g->profiling = on != 0;
+    g->ev_used = 0;
+    return FIR_OK;
+}
+
+int fir_profile_read(fir_gallery* g, float* ms, int32_t cap, int32_t* count, double* bytes_per_launch) {
+    if (!g) return fail(FIR_ERR_ARG, "gallery is NULL");
+    FIR_HIP(hipSetDevice(g->device));
+    const int32_t launches = (int32_t)(g->ev_used / 2);
+    for (int32_t i = 0; i < launches; ++i) {
+        FIR_HIP(hipEventSynchronize(g->ev[2 * i + 1]));
+        float t = 0.f;
+        FIR_HIP(hipEventElapsedTime(&t, g->ev[2 * i], g->ev[2 * i + 1]));
+        if (ms && i < cap) ms[i] = t;
+    }
+    if (count) *count = launches;
+    if (bytes_per_launch) *bytes_per_launch = g->last_bytes;
+    g->ev_used = 0;
+    return FIR_OK;
+}
+
+int fir_gallery_sync(fir_gallery* g) {
+    if (!g) return fail(FIR_ERR_ARG, "gallery is NULL");
+    FIR_HIP(hipSetDevice(g->device));
+    FIR_HIP(hipStreamSynchronize(g->stream));
+    return FIR_OK;
+}
+
+int fir_gallery_set_tuning(fir_gallery* g, int32_t queries_per_pass, int32_t waves) {
+    if (!g) return fail(FIR_ERR_ARG, "gallery is NULL");
+    if (queries_per_pass != 0) {
+        if (queries_per_pass != 1 && queries_per_pass != 2 && queries_per_pass != 4 && queries_per_pass != 8)
+            return fail(FIR_ERR_ARG, "queries_per_pass must be 1, 2, 4 or 8");
+        g->qpp = queries_per_pass;
+    }
+    if (waves < 0 || (waves % 4) != 0) return fail(FIR_ERR_ARG, "waves must be a non-negative multiple of 4");
+    g->waves_req = waves;
+    return FIR_OK;
+}
+
+int fir_gallery_get_tuning(const fir_gallery* g, int32_t* queries_per_pass, int32_t* waves, int32_t* max_waves) {
+    if (!g) return fail(FIR_ERR_ARG, "gallery is NULL");
+    if (queries_per_pass) *queries_per_pass = g->qpp;
+    if (waves) *waves = g->waves_req > 0 ? std::min(g->waves_req, g->max_waves) : pick_waves(g->tiles, g->max_waves);
+    if (max_waves) *max_waves = g->max_waves;
+    return FIR_OK;
+}
+
+}  // extern "C"

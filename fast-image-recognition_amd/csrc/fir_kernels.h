@@ -1,0 +1,356 @@
+// fir_kernels.h -- gfx950 (MI355X / CDNA4) device code of the gallery matcher.
+//
+// One idea carries every kernel here: the gallery is re-tiled ONCE, at create time, into
+//
+//     tile t (64 consecutive rows)  x  chunk c (4 consecutive features)  x  lane r (row in tile)
+//     float4 at  gal4[(t * dp4 + c) * 64 + r]            dp4 = ceil(d / 4)
+//
+// so that a wavefront owns 64 rows, lane r owns row 64 t + r, and the wave's
+// `global_load_dwordx4` for chunk c reads one contiguous, perfectly coalesced KiB.
+// A tile is one linear 64*dp4*16-byte stream (128 KiB at d = 512) that goes straight into
+// VGPRs: no LDS staging, no transposition, no cross-lane reduction per row. Each lane then
+// accumulates ITS row's distance to QB queries feature by feature, in ascending feature order,
+// with one IEEE rounding per operation -- exactly the evaluation order of the reference's scalar
+// loop (qt_cpp/db_features.cpp:22-42), which makes L2 and chi-square results bit-identical to
+// the reference, not merely close. The query values are wave-uniform and are fetched through the
+// scalar cache (s_load from a [feature][QB] transposed tile) as SGPR operands of the VALU ops.
+//
+// Roofline: the scan reads n*d*4 gallery bytes once per pass for QB queries; it is HBM-bound
+// while 3*QB VALU ops per gallery float (L2, un-fused sub/mul/add) fit under the HBM time
+// (QB <= 8 at d = 512 on MI355X); chi-square / KL are VALU-bound (IEEE division / log per
+// element) and are priced against the vector-ALU roof instead.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fir {
+
+constexpr int kTileRows = 64;   // rows per tile == lanes per wavefront (gfx950 wave64)
+constexpr int kBlock = 256;     // 4 waves per workgroup, one per SIMD
+constexpr float kNotFound = 100000.0f;  // db_features.cpp:323, ann.cpp:116
+constexpr uint64_t kKeyNone = 0xFFFFFFFFFFFFFFFFull;
+
+enum { kL2 = 0, kChi2 = 1, kKL = 2 };
+enum { kEpiTop1 = 0, kEpiTopK = 1, kEpiStore = 2 };
+
+typedef const float __attribute__((address_space(4)))* sfloat_p;  // constant AS => s_load when uniform
+
+// float bits -> uint32 whose unsigned order equals the float order (negatives included).
+__host__ __device__ __forceinline__ uint32_t f32_orderable(float f) {
+    uint32_t b;
+    __builtin_memcpy(&b, &f, 4);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__host__ __device__ __forceinline__ float f32_from_orderable(uint32_t o) {
+    uint32_t b = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
+    float f;
+    __builtin_memcpy(&f, &b, 4);
+    return f;
+}
+__host__ __device__ __forceinline__ uint64_t key_pack(float dist, uint32_t idx) {
+    return ((uint64_t)f32_orderable(dist + 0.0f) << 32) | (uint64_t)idx;  // +0.0f: -0 -> +0
+}
+
+// One feature of the reference's distance loop, lhs = query (test image), rhs = gallery row
+// (ImageInfo::distance, db_features.h:24-26). The translation unit is compiled with
+// -ffp-contract=off: sub, mul, add (and the chi-square divide) each round once, like the
+// reference's SSE scalar code.
+template <int METRIC>
+__device__ __forceinline__ float accum(float acc, float l, float r) {
+    if constexpr (METRIC == kL2) {
+        const float df = l - r;
+        return acc + df * df;                                   // db_features.cpp:26
+    } else if constexpr (METRIC == kChi2) {
+        const float s = l + r;
+        const float df = l - r;
+        const float term = df * df / s;                         // db_features.cpp:31
+        return (s > 0.0f) ? acc + term : acc;                   // db_features.cpp:29
+    } else {
+        const float s = l + r;                                  // db_features.cpp:29,33-36
+        float a = acc;
+        if (s > 0.0f) {
+            if (l > 0.0f) a = a + l * logf(2.0f * l / s);
+            if (r > 0.0f) a = a + r * logf(2.0f * r / s);
+        }
+        return a;
+    }
+}
+
+struct ScanArgs {
+    const float4* gal4;   // tiled gallery
+    const float* qt;      // query tile, transposed: qt[k * QB + q], k in [0, dp4*4)
+    int64_t n;            // rows in this gallery (shard)
+    int32_t tiles;        // ceil(n / 64)
+    int32_t dp4;          // float4 chunks per row
+    int32_t start, end;   // feature range [start, end)
+    int32_t waves;        // total waves in the grid
+    int64_t row_offset;   // global index of local row 0
+    uint64_t* keys;       // kEpiTop1: [QB] packed keys (pre-set to kKeyNone); kEpiTopK: partials [waves][QB][K]
+    float* out;           // kEpiStore: out[q * out_stride + row]
+    int64_t out_stride;
+    int32_t nq;           // live queries in this tile (<= QB); only kEpiStore needs it
+    int32_t k;            // kEpiTopK
+};
+
+// 64-bit wave-wide minimum (all lanes end with the result).
+__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const uint64_t o = __shfl_xor((unsigned long long)v, off, 64);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+template <int QB, int METRIC, int U>
+struct TileAcc {
+    static constexpr int kSq = 4 * QB;   // query values one chunk needs: 4 features x QB queries
+
+    static __device__ __forceinline__ void load_sq(float (&sq)[kSq], sfloat_p qc, int c) {
+#pragma unroll
+        for (int i = 0; i < kSq; ++i) sq[i] = qc[c * kSq + i];   // uniform address, constant AS: s_load_dwordx8/x16
+    }
+    static __device__ __forceinline__ void chunk(float (&acc)[QB], const float4 g, const float (&sq)[kSq]) {
+        const float gv[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int q = 0; q < QB; ++q) acc[q] = accum<METRIC>(acc[q], sq[j * QB + q], gv[j]);
+        }
+    }
+    // acc[q] += contribution of one group of U chunks starting at chunk c. The schedule barrier
+    // after each chunk keeps the compiler from hoisting a whole group's scalar loads at once
+    // (4*QB SGPRs per chunk; hoisting them all spills SGPRs).
+    static __device__ __forceinline__ void group(float (&acc)[QB], const float4 (&g)[U], sfloat_p qc, int c) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float cur[kSq];
+            load_sq(cur, qc, c + u);
+            chunk(acc, g[u], cur);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // One chunk with a feature mask [k0, k1) (range edges that are not multiples of 4).
+    static __device__ __forceinline__ void masked(float (&acc)[QB], const float4 g, sfloat_p qc, int c, int k0, int k1) {
+        const float gv[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = c * 4 + j;
+            if (k >= k0 && k < k1) {   // wave-uniform
+#pragma unroll
+                for (int q = 0; q < QB; ++q) acc[q] = accum<METRIC>(acc[q], qc[k * QB + q], gv[j]);
+            }
+        }
+    }
+};
+
+// Streams whole tiles; lane r of a wave owns row 64 t + r. EPI selects what happens to the
+// finished distances: running first-minimum (top-1), running K smallest (top-K), or store.
+template <int QB, int METRIC, int U, int EPI, int KMAX, int WPS>
+__global__ void __launch_bounds__(kBlock, WPS) k_scan(const ScanArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    sfloat_p qc = (sfloat_p)(uintptr_t)a.qt;
+
+    const int c_lo = (a.start + 3) >> 2;          // first whole chunk
+    const int c_hi = a.end >> 2;                  // one past the last whole chunk
+    const float fcount = (float)(a.end - a.start);  // db_features.cpp:40 divides by (end_pos-start_pos)
+
+    float best_d[EPI == kEpiTop1 ? QB : 1];
+    int32_t best_i[EPI == kEpiTop1 ? QB : 1];
+    float kd[EPI == kEpiTopK ? QB : 1][EPI == kEpiTopK ? KMAX : 1];
+    int32_t ki[EPI == kEpiTopK ? QB : 1][EPI == kEpiTopK ? KMAX : 1];
+    if constexpr (EPI == kEpiTop1) {
+#pragma unroll
+        for (int q = 0; q < QB; ++q) { best_d[q] = kNotFound; best_i[q] = -1; }
+    }
+    if constexpr (EPI == kEpiTopK) {
+#pragma unroll
+        for (int q = 0; q < QB; ++q)
+#pragma unroll
+            for (int i = 0; i < KMAX; ++i) { kd[q][i] = kNotFound; ki[q][i] = -1; }
+    }
+
+    const int ng = c_lo <= c_hi ? (c_hi - c_lo) / U : 0;   // whole groups of U chunks
+    const int c_end = c_lo + ng * U;
+
+    for (int t = gw; t < a.tiles; t += a.waves) {
+        const float4* tile = a.gal4 + (size_t)t * a.dp4 * 64 + lane;
+        float acc[QB];
+#pragma unroll
+        for (int q = 0; q < QB; ++q) acc[q] = 0.0f;
+
+        if (c_lo > c_hi) {
+            // the whole range lies inside one chunk
+            TileAcc<QB, METRIC, U>::masked(acc, tile[(size_t)(a.start >> 2) * 64], qc, a.start >> 2, a.start, a.end);
+        } else {
+            if ((a.start & 3) != 0)
+                TileAcc<QB, METRIC, U>::masked(acc, tile[(size_t)(c_lo - 1) * 64], qc, c_lo - 1, a.start, a.end);
+
+            const float4* p = tile + (size_t)c_lo * 64;
+            for (int gi = 0; gi < ng; ++gi) {
+                float4 g[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) g[u] = p[(size_t)(gi * U + u) * 64];
+                TileAcc<QB, METRIC, U>::group(acc, g, qc, c_lo + gi * U);
+            }
+            for (int c = c_end; c < c_hi; ++c)
+                TileAcc<QB, METRIC, U>::masked(acc, tile[(size_t)c * 64], qc, c, a.start, a.end);
+            if ((a.end & 3) != 0)
+                TileAcc<QB, METRIC, U>::masked(acc, tile[(size_t)c_hi * 64], qc, c_hi, a.start, a.end);
+        }
+
+        const int64_t row = (int64_t)t * kTileRows + lane;
+        if (row < a.n) {
+#pragma unroll
+            for (int q = 0; q < QB; ++q) {
+                const float dist = acc[q] / fcount;                      // db_features.cpp:40
+                if constexpr (EPI == kEpiTop1) {
+                    if (dist < best_d[q]) { best_d[q] = dist; best_i[q] = (int32_t)row; }   // db_features.cpp:329-332
+                } else if constexpr (EPI == kEpiTopK) {
+                    if (dist < kd[q][KMAX - 1]) {
+                        // insert keeping ascending order; strict '<' keeps earlier rows first on ties
+                        float cd = dist; int32_t ci = (int32_t)row;
+#pragma unroll
+                        for (int i = 0; i < KMAX; ++i) {
+                            const bool sw = cd < kd[q][i];
+                            const float td = kd[q][i]; const int32_t ti = ki[q][i];
+                            kd[q][i] = sw ? cd : td; ki[q][i] = sw ? ci : ti;
+                            cd = sw ? td : cd; ci = sw ? ti : ci;
+                        }
+                    }
+                } else {
+                    if (q < a.nq) a.out[(size_t)q * a.out_stride + row] = dist;
+                }
+            }
+        }
+    }
+
+    if constexpr (EPI == kEpiTop1) {
+#pragma unroll
+        for (int q = 0; q < QB; ++q) {
+            uint64_t key = best_i[q] >= 0 ? key_pack(best_d[q], (uint32_t)((int64_t)best_i[q] + a.row_offset)) : kKeyNone;
+            key = wave_min_u64(key);
+            if (lane == 0 && key != kKeyNone) {
+                // most waves lose against what is already there: read first, contend only to win
+                const uint64_t cur = __hip_atomic_load(a.keys + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (key < cur) atomicMin((unsigned long long*)(a.keys + q), (unsigned long long)key);
+            }
+        }
+    }
+    if constexpr (EPI == kEpiTopK) {
+        // K rounds: the wave's next smallest key strictly greater than the previous winner.
+        // Keys are unique (the row index is part of the key), so "greater than" removes exactly one.
+#pragma unroll
+        for (int q = 0; q < QB; ++q) {
+            uint64_t lk[KMAX];
+#pragma unroll
+            for (int i = 0; i < KMAX; ++i)
+                lk[i] = ki[q][i] >= 0 ? key_pack(kd[q][i], (uint32_t)((int64_t)ki[q][i] + a.row_offset)) : kKeyNone;
+            uint64_t prev = 0;
+            bool first = true;
+            for (int r = 0; r < a.k; ++r) {
+                uint64_t cand = kKeyNone;
+#pragma unroll
+                for (int i = KMAX - 1; i >= 0; --i)
+                    if (first || lk[i] > prev) cand = lk[i] < cand ? lk[i] : cand;
+                const uint64_t w = wave_min_u64(cand);
+                if (lane == 0) a.keys[((size_t)gw * QB + q) * a.k + r] = w;
+                prev = w;
+                first = false;
+                if (w == kKeyNone) {
+                    for (int r2 = r + 1; r2 < a.k; ++r2)
+                        if (lane == 0) a.keys[((size_t)gw * QB + q) * a.k + r2] = kKeyNone;
+                    break;
+                }
+            }
+        }
+    }
+}
+
+// Final merge of the per-wave top-K partials: one block per query. K rounds of
+// "smallest key greater than the previous winner" over waves*K candidates.
+__global__ void __launch_bounds__(kBlock) k_topk_merge(const uint64_t* part, int waves, int QB, int q0, int nq, int K,
+                                                        uint64_t* out /* [nq_total][K] */) {
+    __shared__ uint64_t red[kBlock / 64];
+    const int q = blockIdx.x;   // query inside the tile
+    if (q >= nq) return;
+    uint64_t prev = 0;
+    bool first = true;
+    for (int r = 0; r < K; ++r) {
+        uint64_t cand = kKeyNone;
+        for (int i = threadIdx.x; i < waves * K; i += kBlock) {
+            const int w = i / K, j = i - w * K;
+            const uint64_t v = part[((size_t)w * QB + q) * K + j];
+            if ((first || v > prev) && v < cand) cand = v;
+        }
+        cand = wave_min_u64(cand);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cand;
+        __syncthreads();
+        uint64_t m = red[0];
+#pragma unroll
+        for (int i = 1; i < kBlock / 64; ++i) m = red[i] < m ? red[i] : m;
+        __syncthreads();
+        if (threadIdx.x == 0) out[(size_t)(q0 + q) * K + r] = m;
+        prev = m;
+        first = false;
+    }
+}
+
+// rows[n][d] row-major  ->  tiled layout (see top of file). One thread per output float4.
+// row0 = first row of this slab (multiple of 64); rows beyond n and features beyond d are zero.
+__global__ void __launch_bounds__(kBlock) k_retile(const float* __restrict__ rows, int64_t slab_rows, int64_t row0,
+                                                    int64_t n, int d, int dp4, float4* __restrict__ gal4) {
+    const int64_t o = (int64_t)blockIdx.x * kBlock + threadIdx.x;   // float4 index inside the slab's tiles
+    const int64_t slab_tiles = (slab_rows + kTileRows - 1) / kTileRows;
+    if (o >= slab_tiles * dp4 * 64) return;
+    const int r = (int)(o & 63);
+    const int64_t tc = o >> 6;
+    const int c = (int)(tc % dp4);
+    const int64_t tl = tc / dp4;
+    const int64_t lrow = tl * kTileRows + r;       // row inside the slab
+    const int64_t grow = row0 + lrow;              // row inside the gallery
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (lrow < slab_rows && grow < n) {
+        const float* src = rows + lrow * d + (int64_t)c * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (c * 4 + j < d) v[j] = src[j];
+    }
+    gal4[((row0 / kTileRows + tl) * dp4 + c) * 64 + r] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// queries[nq][d] row-major -> tiles of QB queries, transposed: qt[tile][k][QB], k < dp4*4.
+// Queries past nq and features past d are zero.
+__global__ void __launch_bounds__(kBlock) k_transpose_queries(const float* __restrict__ q, int nq, int d, int dp4, int QB,
+                                                               float* __restrict__ qt) {
+    const int kk = dp4 * 4;
+    const int64_t total = (int64_t)((nq + QB - 1) / QB) * kk * QB;
+    const int64_t o = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (o >= total) return;
+    const int qi = (int)(o % QB);
+    const int64_t r = o / QB;
+    const int k = (int)(r % kk);
+    const int tile = (int)(r / kk);
+    const int qq = tile * QB + qi;
+    qt[o] = (qq < nq && k < d) ? q[(int64_t)qq * d + k] : 0.0f;
+}
+
+// feature_distance for one pair (db_features.cpp:22-42): one lane, sequential, exact order.
+template <int METRIC>
+__global__ void k_pair_distance(const float* __restrict__ l, const float* __restrict__ r, int start, int end, float* out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float acc = 0.0f;
+    for (int i = start; i < end; ++i) acc = accum<METRIC>(acc, l[i], r[i]);
+    *out = acc / (float)(end - start);
+}
+
+__global__ void __launch_bounds__(kBlock) k_classes_of(const int32_t* __restrict__ cls, int64_t n, int64_t row_offset,
+                                                        const int32_t* __restrict__ idx, int m, int32_t* __restrict__ out) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= m) return;
+    const int64_t l = (int64_t)idx[i] - row_offset;
+    out[i] = (idx[i] >= 0 && l >= 0 && l < n) ? cls[l] : -1;
+}
+
+}  // namespace fir

@@ -1,0 +1,141 @@
+/*
+ * fir_amd.h -- C ABI of the MI355X (gfx950) gallery matcher.
+ *
+ * Drop-in boundary for the brute-force / probabilistic match path of
+ * av-savchenko/fast-image-recognition (qt_cpp). The reference has no FFI of its own -- the path
+ * is plain C++ called in-process -- so each entry point below names the reference function it
+ * replaces (path:line under the reference checkout); the C++ host shim in
+ * fast-image-recognition_amd/host/ re-creates the reference's classes on top of these calls.
+ *
+ * Conventions
+ *   - plain C types only; `fir_gallery` is an opaque handle; no exceptions cross the boundary;
+ *   - every function returns FIR_OK (0) or a negative FIR_ERR_* code; fir_last_error() gives
+ *     the message of the calling thread's last failure;
+ *   - "not found" is reported the reference's way: index -1 and distance 100000
+ *     (qt_cpp/db_features.cpp:322-323, qt_cpp/ann.cpp:115-116);
+ *   - the gallery rows are COPIED at create time (the reference only borrows them,
+ *     qt_cpp/ImageTesting.cpp:40, qt_cpp/ann.h:28): the caller may free its rows afterwards;
+ *   - one handle is used by one host thread at a time (the reference is single threaded);
+ *   - `*_dev` variants take DEVICE pointers and a HIP stream (void* = hipStream_t, NULL = the
+ *     handle's own stream) and are asynchronous; the others take host pointers and return
+ *     when the results are in the caller's buffers;
+ *   - there is no CPU fallback: without a usable gfx950 device every call fails.
+ */
+#ifndef FIR_AMD_H
+#define FIR_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fir_gallery fir_gallery;
+
+/* The reference's compile-time metric switch (qt_cpp/db_features.h:12,
+ * qt_cpp/db_features.cpp:25-39) as a runtime value. */
+enum {
+    FIR_METRIC_L2 = 0,   /* sum (a-b)^2 / n                          db_features.cpp:26,40  */
+    FIR_METRIC_CHI2 = 1, /* sum_{a+b>0} (a-b)^2/(a+b) / n            db_features.cpp:29-31  */
+    FIR_METRIC_KL = 2    /* sum a ln(2a/(a+b)) + b ln(2b/(a+b)) / n  db_features.cpp:33-36  */
+};
+
+enum {
+    FIR_OK = 0,
+    FIR_ERR_ARG = -1,      /* bad argument                                   */
+    FIR_ERR_HIP = -2,      /* a HIP runtime call failed                      */
+    FIR_ERR_NOMEM = -3,    /* host or device allocation failed               */
+    FIR_ERR_NODEVICE = -4, /* no gfx950 device / device index out of range   */
+    FIR_ERR_STATE = -5     /* call not valid for this handle (e.g. no labels) */
+};
+
+#define FIR_NOT_FOUND_DIST 100000.0f
+#define FIR_KEY_NONE 0xFFFFFFFFFFFFFFFFull
+
+const char* fir_last_error(void);
+int fir_version(void);
+
+/* Number of visible HIP devices (does not initialise a device context). */
+int fir_device_count(void);
+/* name[cap] <- gcnArchName; *cus, *hbm_bytes as reported by the runtime. */
+int fir_device_info(int32_t device, char* name, int32_t cap, int32_t* cus, int64_t* hbm_bytes);
+
+/* ---- gallery ------------------------------------------------------------------------------
+ * Replaces the `std::vector<ImageInfo>` gallery that Classifier::train (ImageTesting.cpp:40)
+ * and ClassificationMethod's constructor (ann.h:11) borrow. rows[n][d] float32 row-major,
+ * class_no[n] (may be NULL: then class lookups fail with FIR_ERR_STATE). */
+int fir_gallery_create(const float* rows, int64_t n, int32_t d, const int32_t* class_no, int32_t metric,
+                       int32_t device, fir_gallery** out);
+/* Same, rows/class_no already in this device's memory (row-major); async on `stream`. */
+int fir_gallery_create_dev(const float* d_rows, int64_t n, int32_t d, const int32_t* d_class_no, int32_t metric,
+                           int32_t device, void* stream, fir_gallery** out);
+int fir_gallery_destroy(fir_gallery* g);
+int fir_gallery_info(const fir_gallery* g, int64_t* n, int32_t* d, int32_t* metric, int32_t* device);
+int fir_gallery_set_metric(fir_gallery* g, int32_t metric);
+/* Row-sharded galleries: global index of this shard's row 0 (added to every reported index). */
+int fir_gallery_set_row_offset(fir_gallery* g, int64_t first_global_row);
+
+/* ---- single pair ----------------------------------------------------------------------------
+ * feature_distance(lhs, rhs, start_pos, end_pos), db_features.cpp:22-42 (ImageInfo::distance,
+ * db_features.h:24). len = number of floats in each vector. Computed on the device. */
+int fir_feature_distance(const float* lhs, const float* rhs, int32_t len, int32_t start_pos, int32_t end_pos,
+                         int32_t metric, int32_t device, float* out);
+
+/* ---- nearest row ---------------------------------------------------------------------------
+ * Batched recognize_image_bf (db_features.cpp:319-335) / BruteForce::recognize
+ * (ann.cpp:113-126): for each of qb queries, the row with the smallest distance over features
+ * [start_pos, end_pos) -- first minimum in row order, strict `<` from 100000. end_pos = 0 means d
+ * (the reference's max_features == 0 rule, db_features.cpp:320-321).
+ * idx[qb] <- row index (+ row offset) or -1, dist[qb] <- its distance (either may be NULL). */
+int fir_search_top1(fir_gallery* g, const float* queries, int32_t qb, int32_t start_pos, int32_t end_pos,
+                    int32_t* idx, float* dist);
+
+/* Device-resident form. d_keys[qb] receives one packed key per query:
+ *   (orderable(float bits of distance) << 32) | uint32(row index + row offset),
+ * FIR_KEY_NONE when no row qualifies. Keys order exactly like (distance, index), so the minimum
+ * of the keys of several row shards is the reference's answer on the whole gallery: reduce them
+ * with an integer MIN (RCCL all-reduce on uint64/int64), then unpack. */
+int fir_search_top1_keys_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start_pos, int32_t end_pos,
+                             uint64_t* d_keys, void* stream);
+/* Host-side unpack of packed keys (pure integer work, no device). */
+int fir_keys_unpack(const uint64_t* keys, int32_t n, int32_t* idx, float* dist);
+uint64_t fir_key_pack(float dist, int32_t idx);
+/* classNo of each index (BruteForceClassifier::recognize, ImageTesting.cpp:61-67): -1 stays -1.
+ * idx are LOCAL+offset indices as returned above. */
+int fir_gallery_classes_of(fir_gallery* g, const int32_t* idx, int32_t n, int32_t* class_out);
+
+/* ---- K nearest rows -------------------------------------------------------------------------
+ * The K smallest entries of the distance vector of db_features.cpp:325-333, ascending, equal
+ * distances by ascending row index; unused slots idx -1 / dist 100000. idx[qb*k], dist[qb*k]. */
+int fir_search_topk(fir_gallery* g, const float* queries, int32_t qb, int32_t start_pos, int32_t end_pos, int32_t k,
+                    int32_t* idx, float* dist);
+int fir_search_topk_keys_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start_pos, int32_t end_pos,
+                             int32_t k, uint64_t* d_keys /* [qb*k] ascending */, void* stream);
+
+/* ---- all distances of a feature sub-range ---------------------------------------------------
+ * out[qb][n] <- distance(query, row j) over [start_pos,end_pos): the per-row loops of
+ * ConventionalTWDClassifier / ProposedTWDClassifier (ImageTesting.cpp:117,174,243). */
+int fir_range_distances(fir_gallery* g, const float* queries, int32_t qb, int32_t start_pos, int32_t end_pos,
+                        float* out);
+int fir_range_distances_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start_pos, int32_t end_pos,
+                            float* d_out, void* stream);
+
+/* ---- profiling ------------------------------------------------------------------------------
+ * When enabled, every gallery-scan kernel launch is bracketed by HIP events on the stream it
+ * is launched on. fir_profile_read waits for them and returns the launch durations (ms) in
+ * launch order since the previous read; *bytes_per_launch is the algorithmic byte count of the
+ * LAST launch (gallery range + query tile + keys). */
+int fir_profile_enable(fir_gallery* g, int32_t on);
+int fir_profile_read(fir_gallery* g, float* ms, int32_t cap, int32_t* count, double* bytes_per_launch);
+
+/* Block until all work queued by this handle is done. */
+int fir_gallery_sync(fir_gallery* g);
+
+/* Tunables (for experiments; defaults are chosen at create time). */
+int fir_gallery_set_tuning(fir_gallery* g, int32_t queries_per_pass, int32_t waves);
+int fir_gallery_get_tuning(const fir_gallery* g, int32_t* queries_per_pass, int32_t* waves, int32_t* max_waves);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FIR_AMD_H */

@@ -1,0 +1,545 @@
+/*
+ * oracle.c -- CPU restatement of the reference's gallery-match hot path, in plain C.
+ *
+ * TEST INFRASTRUCTURE ONLY. Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg may load this library, and only as the checker. The product (libfir_amd.so and the C++
+ * host shim) never includes, links, loads or calls anything in oracle/.
+ *
+ * Parity status: PINNED. Every function here is checked (tests/test_oracle_vs_ref.py, run in
+ * the build container) against the real reference code compiled from /root/reference by
+ * oracle/build_ref.sh, and against the committed fixtures in tests/golden/ that the same
+ * reference build generated (tests/golden/make_golden.py). The reference ships no tests,
+ * golden vectors or data files of its own.
+ *
+ * Arithmetic contract: the reference is built for baseline x86-64 (no FMA), so every
+ * float expression below is evaluated in the reference's order with one IEEE rounding per
+ * operation. Build with -ffp-contract=off and without -ffast-math (oracle/Makefile).
+ *
+ * All reference citations are path:line under /root/reference/.
+ */
+#define _POSIX_C_SOURCE 200809L
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <float.h>
+
+#define ORC_L2 0
+#define ORC_CHI2 1
+#define ORC_KL 2
+
+/* qt_cpp/db_features.cpp:22-42  feature_distance(lhs, rhs, start_pos, end_pos).
+ * L2 arm :26, chi-square arm :29-31, KL/JS arm :33-36, mean over the range :40. */
+float orc_feature_distance(const float* lhs, const float* rhs, int start_pos, int end_pos, int metric) {
+    float dist = 0;
+    for (int i = start_pos; i < end_pos; ++i) {
+        if (metric == ORC_L2) {
+            dist += (lhs[i] - rhs[i]) * (lhs[i] - rhs[i]);
+        } else if ((lhs[i] + rhs[i]) > 0) {
+            if (metric == ORC_CHI2) {
+                dist += (lhs[i] - rhs[i]) * (lhs[i] - rhs[i]) / (lhs[i] + rhs[i]);
+            } else {
+                if (lhs[i] > 0) dist += lhs[i] * logf(2 * lhs[i] / (lhs[i] + rhs[i]));
+                if (rhs[i] > 0) dist += rhs[i] * logf(2 * rhs[i] / (lhs[i] + rhs[i]));
+            }
+        }
+    }
+    dist /= (end_pos - start_pos);
+    return dist;
+}
+
+/* The per-row loop body of qt_cpp/db_features.cpp:325-328 for all rows: out[j] = distance(q, row j). */
+void orc_all_distances(const float* rows, int64_t n, int d, const float* query, int start_pos, int end_pos,
+                       int metric, float* out) {
+    for (int64_t j = 0; j < n; ++j) out[j] = orc_feature_distance(query, rows + j * d, start_pos, end_pos, metric);
+}
+
+/* qt_cpp/db_features.cpp:319-335 recognize_image_bf (and the identical scan of
+ * qt_cpp/ann.cpp:113-126 BruteForce::recognize): strict `<` running minimum from 100000 in row
+ * order, -1 when nothing beats it. start_pos is 0 in the reference; it is a parameter here for
+ * the sub-range scans of ImageTesting.cpp:174,243. */
+int64_t orc_recognize_bf(const float* rows, int64_t n, int d, const float* query, int start_pos, int end_pos,
+                         int metric, float* best_dist_out) {
+    int64_t bestInd = -1;
+    double bestDist = 100000;
+    float bestF = 100000.0f;
+    for (int64_t j = 0; j < n; ++j) {
+        float dj = orc_feature_distance(query, rows + j * d, start_pos, end_pos, metric);
+        double dist = dj; /* vector<double> distances, db_features.cpp:324 */
+        if (dist < bestDist) {
+            bestDist = dist;
+            bestF = dj;
+            bestInd = j;
+        }
+    }
+    if (best_dist_out) *best_dist_out = bestF;
+    return bestInd;
+}
+
+/* K smallest rows of the reference's distance vector (db_features.cpp:325-333 generalised from
+ * 1 to K winners): ascending distance, equal distances in ascending row order, only rows with
+ * distance < 100000, unused slots idx = -1 / dist = 100000. K = 1 equals orc_recognize_bf. */
+void orc_topk(const float* rows, int64_t n, int d, const float* query, int start_pos, int end_pos, int metric,
+              int k, int64_t* idx_out, float* dist_out) {
+    for (int i = 0; i < k; ++i) { idx_out[i] = -1; dist_out[i] = 100000.0f; }
+    for (int64_t j = 0; j < n; ++j) {
+        float dj = orc_feature_distance(query, rows + j * d, start_pos, end_pos, metric);
+        if (!(dj < dist_out[k - 1])) continue; /* strict: a later equal row never displaces an earlier one */
+        int p = k - 1;
+        while (p > 0 && dj < dist_out[p - 1]) { dist_out[p] = dist_out[p - 1]; idx_out[p] = idx_out[p - 1]; --p; }
+        dist_out[p] = dj;
+        idx_out[p] = j;
+    }
+}
+
+/* qt_cpp/ImageTesting.cpp:58-71 BruteForceClassifier::recognize -> classNo of the best row or -1. */
+int orc_bf_classifier(const float* rows, int64_t n, int d, const int32_t* class_no, const float* query,
+                      int max_features, int metric) {
+    int64_t b = orc_recognize_bf(rows, n, d, query, 0, max_features, metric, 0);
+    return b == -1 ? -1 : class_no[b];
+}
+
+static int cmp_desc_double(const void* a, const void* b) {
+    double x = *(const double*)a, y = *(const double*)b;
+    return (x < y) - (x > y);
+}
+
+/* qt_cpp/ImageTesting.cpp:108-186 ConventionalTWDClassifier::recognize.
+ * type 0 Posteriors (:118-122,141-149), 1 DistDiff (:157-159), 2 DistRatio (:160-162);
+ * second stage :165-180 (last_feature = 256). The sum of the 5 largest class posteriors is
+ * taken in descending order here; the reference sums them in the order std::nth_element
+ * leaves them (:141-146), which can differ in the last bit of `sum`. */
+int orc_twd_conventional(const float* rows, int64_t n, int d, const int32_t* class_no, const float* query,
+                         int num_of_classes, int type, double threshold, int reduced_features_count, int metric,
+                         int* unreliable_out) {
+    int64_t bestInd = -1;
+    double bestDist = 100000, secondBestDist = 100000;
+    double* distances = (double*)calloc((size_t)(n > 0 ? n : 1), sizeof(double));
+    const int DIST_WEIGHT = 100;
+    double* probabs = (double*)calloc((size_t)(num_of_classes > 5 ? num_of_classes : 5), sizeof(double));
+    double max_probab = 0, probab = 0;
+    for (int64_t j = 0; j < n; ++j) {
+        distances[j] = orc_feature_distance(query, rows + j * d, 0, reduced_features_count, metric);
+        if (type == 0) {
+            probab = exp(-distances[j] * DIST_WEIGHT);
+            if (probab > probabs[class_no[j]]) probabs[class_no[j]] = probab;
+        }
+        if (distances[j] < bestDist) {
+            if (bestInd != -1 && class_no[bestInd] != class_no[j]) secondBestDist = bestDist;
+            bestDist = distances[j];
+            bestInd = j;
+            if (type == 0) max_probab = probab;
+        }
+    }
+    int is_reliable = 0;
+    if (type == 0) {
+        const int MAX_PROBABS_COUNT = 5;
+        qsort(probabs, (size_t)num_of_classes, sizeof(double), cmp_desc_double);
+        double sum = 0;
+        for (int i = 0; i < MAX_PROBABS_COUNT; ++i) sum += probabs[i];
+        max_probab /= sum;
+        is_reliable = max_probab > threshold;
+    } else if (type == 1) {
+        is_reliable = (secondBestDist - bestDist) > threshold;
+    } else {
+        is_reliable = (bestDist / secondBestDist) < threshold;
+    }
+    if (unreliable_out) *unreliable_out = !is_reliable;
+    if (!is_reliable) {
+        bestInd = -1;
+        bestDist = 100000;
+        int last_feature = 256;
+        for (int64_t j = 0; j < n; ++j) {
+            distances[j] = (distances[j] * reduced_features_count +
+                            orc_feature_distance(query, rows + j * d, reduced_features_count, last_feature, metric) *
+                                (last_feature - reduced_features_count)) / last_feature;
+            if (distances[j] < bestDist) { bestDist = distances[j]; bestInd = j; }
+        }
+    }
+    int bestClassInd = -1;
+    if (bestInd != -1) bestClassInd = class_no[bestInd];
+    free(distances);
+    free(probabs);
+    return bestClassInd;
+}
+
+/* qt_cpp/ImageTesting.cpp:207-288 ProposedTWDClassifier::recognize (CHECK_ALL_INSTANCES build,
+ * :206): chunks of reduced_features_count dims up to 256 (:227,229), running per-row sums :243,
+ * pruning by bestDist * (1/th) :254-266, stop when one class is left :278. */
+int orc_twd_proposed(const float* rows, int64_t n, int d, const int32_t* class_no, const float* query,
+                     int reduced_features_count, double th, int metric, int* unreliable_out, int* chunks_out) {
+    double threshold = 1.0 / th; /* ImageTesting.cpp:191 */
+    int64_t bestInd = -1;
+    double* distances = (double*)calloc((size_t)(n > 0 ? n : 1), sizeof(double));
+    int* instances_to_check = (int*)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+    for (int64_t j = 0; j < n; ++j) instances_to_check[j] = 1;
+    int last_feature = 256;
+    int unreliable = 0, chunks = 0;
+    for (int cur_features = 0; cur_features < last_feature; cur_features += reduced_features_count) {
+        double bestDist = 100000;
+        ++chunks;
+        for (int64_t j = 0; j < n; ++j) {
+            if (!instances_to_check[j]) continue;
+            distances[j] += orc_feature_distance(query, rows + j * d, cur_features,
+                                                 cur_features + reduced_features_count, metric);
+            if (distances[j] < bestDist) { bestDist = distances[j]; bestInd = j; }
+        }
+        int num_of_variants = 0;
+        double dist_threshold = bestDist * threshold;
+        ++num_of_variants;
+        int bestClass = class_no[bestInd];
+        for (int64_t j = 0; j < n; ++j) {
+            if (instances_to_check[j]) {
+                if (distances[j] > dist_threshold) instances_to_check[j] = 0;
+                else if (class_no[j] != bestClass) ++num_of_variants;
+            }
+        }
+        if (num_of_variants == 1) break;
+        if (cur_features == 0) ++unreliable;
+    }
+    if (unreliable_out) *unreliable_out = unreliable;
+    if (chunks_out) *chunks_out = chunks;
+    int bestClassInd = -1;
+    if (bestInd != -1) bestClassInd = class_no[bestInd];
+    free(distances);
+    free(instances_to_check);
+    return bestClassInd;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Double-precision classifiers of qt_cpp/classification.cpp. The training rows are given in the
+ * reference's scan order: class 0's training_set rows, then class 1's, ... (:121-122,195-198):
+ * train_rows[nt][d], train_class[nt] non-decreasing, avg[d] = avgValues (:984).
+ * ------------------------------------------------------------------------------------------ */
+
+/* Mean squared distance of classification.cpp:123-143 (KNN) for one training row. */
+static double cls_dist_sum(const double* g, const double* q, const double* avg, int d) {
+    double dist = 0;
+    for (int fi = 0; fi < d; ++fi) {
+        double diff = g[fi] - avg[fi]; /* normalize(), :103-105 */
+        double val = q[fi] - avg[fi];
+        diff -= val;
+        dist += diff * diff;
+    }
+    return dist;
+}
+
+/* classification.cpp:116-170 KNNClassifier::predict. dist_out (nullable) receives the nt mean
+ * distances (:143). Equal distances are visited in scan order here (the reference's std::sort
+ * :151 leaves their order unspecified). */
+typedef struct { double d; int64_t i; } orc_di;
+static int cmp_di(const void* a, const void* b) {
+    const orc_di* x = (const orc_di*)a; const orc_di* y = (const orc_di*)b;
+    if (x->d < y->d) return -1;
+    if (x->d > y->d) return 1;
+    return (x->i > y->i) - (x->i < y->i);
+}
+int orc_knn_predict(const double* train_rows, const int32_t* train_class, int64_t nt, int d, const double* avg,
+                    int num_of_classes, const double* q, int K, double* dist_out) {
+    float* outputs = (float*)calloc((size_t)num_of_classes, sizeof(float));
+    orc_di* di = (orc_di*)malloc(sizeof(orc_di) * (size_t)(nt > 0 ? nt : 1));
+    for (int64_t t = 0; t < nt; ++t) {
+        double dist = cls_dist_sum(train_rows + t * d, q, avg, d);
+        dist /= d;
+        di[t].d = dist; di[t].i = t;
+        if (dist_out) dist_out[t] = dist;
+    }
+    qsort(di, (size_t)nt, sizeof(orc_di), cmp_di);
+    for (int64_t i = 0; i < nt; ++i) {
+        int c = train_class[di[i].i];
+        ++outputs[c];
+        if (outputs[c] >= K) break;
+    }
+    float max_output = -DBL_MAX; /* float max_output=-DBL_MAX -> -inf, :161 */
+    int bestClass = -1;
+    for (int i = 0; i < num_of_classes; ++i)
+        if (max_output < outputs[i]) { max_output = outputs[i]; bestClass = i; }
+    free(outputs);
+    free(di);
+    return bestClass;
+}
+
+/* classification.cpp:188-226 PNNClassifier::predict_bf. total_training_size = nt (:189 is
+ * dataset.size()-test_set.size()). scores_out (nullable) receives the num_of_classes outputs. */
+int orc_pnn_predict(const double* train_rows, const int32_t* train_class, int64_t nt, int d, const double* avg,
+                    int num_of_classes, const double* q, double* scores_out) {
+    double var = 0.00002;
+    if (d > 2000) var /= 10;
+    double* outputs = (double*)calloc((size_t)num_of_classes, sizeof(double));
+    double den = (double)nt;
+    for (int64_t t = 0; t < nt; ++t) {
+        double dist = cls_dist_sum(train_rows + t * d, q, avg, d);
+        outputs[train_class[t]] += exp(-dist / (2 * (size_t)d * var));
+    }
+    for (int i = 0; i < num_of_classes; ++i) outputs[i] /= den;
+    double max_output = -DBL_MAX;
+    int bestClass = -1;
+    for (int i = 0; i < num_of_classes; ++i)
+        if (max_output < outputs[i]) { max_output = outputs[i]; bestClass = i; }
+    if (scores_out) memcpy(scores_out, outputs, sizeof(double) * (size_t)num_of_classes);
+    free(outputs);
+    return bestClass;
+}
+
+/* classification.cpp:228-295 PNNClassifier::predict_sequentional: 32-feature chunks (:182),
+ * per-row running sums, class outputs with 2*var*max_fi (:266), classes below
+ * max/1e9 dropped (:280-289, float threshold), stop when one class is left. */
+int orc_pnn_predict_seq(const double* train_rows, const int32_t* train_class, int64_t nt, int d, const double* avg,
+                        int num_of_classes, const double* q, int* chunks_out) {
+    const int delta_features_count = 32;
+    const int output_dividor = 1000000000;
+    double var = 0.00002;
+    if (d > 2000) var /= 10;
+    int bestClass = -1;
+    int* classes_to_check = (int*)malloc(sizeof(int) * (size_t)num_of_classes);
+    for (int i = 0; i < num_of_classes; ++i) classes_to_check[i] = 1;
+    double* distances = (double*)calloc((size_t)(nt > 0 ? nt : 1), sizeof(double));
+    double* outputs = (double*)calloc((size_t)num_of_classes, sizeof(double));
+    double den = (double)nt;
+    int chunks = 0;
+    for (int cur_features = 0; cur_features < d; cur_features += delta_features_count) {
+        int max_fi = cur_features + delta_features_count;
+        if (max_fi > d) max_fi = d;
+        ++chunks;
+        for (int i = 0; i < num_of_classes; ++i) if (classes_to_check[i]) outputs[i] = 0;
+        for (int64_t t = 0; t < nt; ++t) {
+            int c = train_class[t];
+            if (!classes_to_check[c]) continue;
+            const double* g = train_rows + t * d;
+            for (int fi = cur_features; fi < max_fi; ++fi) {
+                double diff = g[fi] - avg[fi];
+                double val = q[fi] - avg[fi];
+                diff -= val;
+                distances[t] += diff * diff;
+            }
+            outputs[c] += exp(-distances[t] / (2 * var * max_fi));
+        }
+        for (int i = 0; i < num_of_classes; ++i) if (classes_to_check[i]) outputs[i] = outputs[i] / den;
+        double max_output = -DBL_MAX;
+        for (int i = 0; i < num_of_classes; ++i)
+            if (classes_to_check[i] && max_output < outputs[i]) { max_output = outputs[i]; bestClass = i; }
+        int num_of_variants = 0;
+        float output_threshold = max_output / output_dividor;
+        for (int i = 0; i < num_of_classes; ++i) {
+            if (classes_to_check[i]) {
+                if (outputs[i] < output_threshold) classes_to_check[i] = 0;
+                else ++num_of_variants;
+            }
+        }
+        if (num_of_variants == 1) break;
+    }
+    if (chunks_out) *chunks_out = chunks;
+    free(classes_to_check); free(distances); free(outputs);
+    return bestClass;
+}
+
+/* classification.cpp:969-989: per-feature min / max / mean / std over the training rows
+ * (std = sqrt((sum x^2 - mean^2 * count) / (count - 1))). */
+void orc_train_stats(const double* train_rows, int64_t nt, int d, double* mn, double* mx, double* avg, double* sd) {
+    for (int fi = 0; fi < d; ++fi) {
+        mn[fi] = FLT_MAX; mx[fi] = -FLT_MAX; avg[fi] = sd[fi] = 0;
+        int count = 0;
+        for (int64_t t = 0; t < nt; ++t) {
+            ++count;
+            double feature = train_rows[t * d + fi];
+            if (feature < mn[fi]) mn[fi] = feature;
+            if (mx[fi] < feature) mx[fi] = feature;
+            avg[fi] += feature;
+            sd[fi] += feature * feature;
+        }
+        avg[fi] /= count;
+        sd[fi] = sqrt((sd[fi] - avg[fi] * avg[fi] * count) / (count - 1));
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Feature-file format (producer qt_cpp/dnn_feature_extractor.py:58-64; consumers
+ * qt_cpp/db_features.cpp:44-116 and qt_cpp/classification.cpp:795-862).
+ * ------------------------------------------------------------------------------------------ */
+
+static char* orc_getline(FILE* f, char** buf, size_t* cap) {
+    size_t len = 0;
+    int c;
+    while ((c = fgetc(f)) != EOF) {
+        if (len + 2 > *cap) { *cap = *cap ? *cap * 2 : 1 << 16; *buf = (char*)realloc(*buf, *cap); }
+        if (c == '\n') { (*buf)[len] = 0; return *buf; }
+        (*buf)[len++] = (char)c;
+    }
+    if (len == 0) return 0;
+    (*buf)[len] = 0;
+    return *buf;
+}
+
+/* db_features.cpp:44-116 loadImages with d in place of FEATURES_COUNT. Rows come out in
+ * ImagesDatabase order (class by first appearance :65-73, then file order). metric selects
+ * the normalisation: L2 norm (:88,95) or plain sum (:91) for chi2/KL. Pass rows_out == NULL
+ * to count. Returns the number of images (or -1 if rows_out is too small); 0 when the file
+ * cannot be opened (:49,115). */
+int64_t orc_load_images(const char* path, int d, int metric, float* rows_out, int32_t* class_out, int64_t cap_rows,
+                        int* n_classes_out) {
+    FILE* f = fopen(path, "r");
+    if (n_classes_out) *n_classes_out = 0;
+    if (!f) return 0;
+    char *l1 = 0, *l2 = 0, *l3 = 0;
+    size_t c1 = 0, c2 = 0, c3 = 0;
+    char** names = 0; int n_names = 0, cap_names = 0;
+    /* pass 1: class ids and per-class counts */
+    int32_t* rec_class = 0; int64_t n_rec = 0, cap_rec = 0;
+    long* rec_pos = 0;
+    for (;;) {
+        if (!orc_getline(f, &l1, &c1)) break;
+        if (!orc_getline(f, &l2, &c2)) break;
+        long pos = ftell(f);
+        if (!orc_getline(f, &l3, &c3)) break;
+        char* person = l2 + strspn(l2, " \t\n\r\f\v");
+        if (strstr(person, "BACKGROUND_Google") || strstr(person, "257.clutter")) continue; /* :60-64 */
+        int cls = -1;
+        for (int i = 0; i < n_names; ++i) if (!strcmp(names[i], person)) { cls = i; break; }
+        if (cls < 0) {
+            if (n_names == cap_names) { cap_names = cap_names ? cap_names * 2 : 64; names = (char**)realloc(names, sizeof(char*) * (size_t)cap_names); }
+            names[n_names] = strdup(person);
+            cls = n_names++;
+        }
+        if (n_rec == cap_rec) {
+            cap_rec = cap_rec ? cap_rec * 2 : 1024;
+            rec_class = (int32_t*)realloc(rec_class, sizeof(int32_t) * (size_t)cap_rec);
+            rec_pos = (long*)realloc(rec_pos, sizeof(long) * (size_t)cap_rec);
+        }
+        rec_class[n_rec] = cls; rec_pos[n_rec] = pos; ++n_rec;
+    }
+    if (n_classes_out) *n_classes_out = n_names;
+    int64_t ret = n_rec;
+    if (rows_out) {
+        if (n_rec > cap_rows) ret = -1;
+        else {
+            /* class-major output offsets */
+            int64_t* start = (int64_t*)calloc((size_t)n_names + 1, sizeof(int64_t));
+            for (int64_t r = 0; r < n_rec; ++r) start[rec_class[r] + 1]++;
+            for (int i = 0; i < n_names; ++i) start[i + 1] += start[i];
+            for (int64_t r = 0; r < n_rec; ++r) {
+                fseek(f, rec_pos[r], SEEK_SET);
+                orc_getline(f, &l3, &c3);
+                int64_t o = start[rec_class[r]]++;
+                float* feat = rows_out + o * d;
+                char* p = l3;
+                float dfeature = 0, sum = 0;
+                for (int i = 0; i < d; ++i) {
+                    char* e;
+                    float v = strtof(p, &e);
+                    if (e != p) { dfeature = v; p = e; } else dfeature = 0; /* failed extraction stores 0 (C++11) */
+                    if (fabsf(dfeature) < 0.0001) dfeature = 0;           /* :85-86 (compared in double) */
+                    feat[i] = dfeature;
+                    if (metric == ORC_L2) sum += dfeature * dfeature;       /* :88 */
+                    else sum += dfeature;                                  /* :91 */
+                }
+                if (metric == ORC_L2) sum = sqrtf(sum);                     /* :95-96 */
+                for (int i = 0; i < d; ++i) feat[i] /= sum;                 /* :98-99 */
+                if (class_out) class_out[o] = rec_class[r];
+            }
+            free(start);
+        }
+    }
+    for (int i = 0; i < n_names; ++i) free(names[i]);
+    free(names); free(rec_class); free(rec_pos); free(l1); free(l2); free(l3);
+    fclose(f);
+    return ret;
+}
+
+/* classification.cpp:795-862 load_image_dataset with d in place of FEATURES_COUNT: doubles,
+ * no zero-clip, L2 normalisation in double (:829-847), rows kept in FILE order, class by first
+ * appearance (:817-823). Returns the number of rows. */
+int64_t orc_load_dataset_f64(const char* path, int d, double* rows_out, int32_t* labels_out, int64_t cap_rows,
+                             int* n_classes_out) {
+    FILE* f = fopen(path, "r");
+    if (n_classes_out) *n_classes_out = 0;
+    if (!f) return 0;
+    char *l1 = 0, *l2 = 0, *l3 = 0;
+    size_t c1 = 0, c2 = 0, c3 = 0;
+    char** names = 0; int n_names = 0, cap_names = 0;
+    int64_t n_rec = 0, ret = 0;
+    for (;;) {
+        if (!orc_getline(f, &l1, &c1)) break;
+        if (!orc_getline(f, &l2, &c2)) break;
+        if (!orc_getline(f, &l3, &c3)) break;
+        char* person = l2 + strspn(l2, " \t\n\r\f\v");
+        if (strstr(person, "BACKGROUND_Google") || strstr(person, "257.clutter")) continue;
+        int cls = -1;
+        for (int i = 0; i < n_names; ++i) if (!strcmp(names[i], person)) { cls = i; break; }
+        if (cls < 0) {
+            if (n_names == cap_names) { cap_names = cap_names ? cap_names * 2 : 64; names = (char**)realloc(names, sizeof(char*) * (size_t)cap_names); }
+            names[n_names] = strdup(person);
+            cls = n_names++;
+        }
+        if (rows_out) {
+            if (n_rec >= cap_rows) { ret = -1; break; }
+            double* feat = rows_out + n_rec * d;
+            char* p = l3;
+            double sum = 0;
+            for (int i = 0; i < d; ++i) {
+                char* e;
+                double v = strtod(p, &e);
+                if (e != p) p = e; else v = 0;
+                sum += v * v;
+                feat[i] = v;
+            }
+            sum = sqrt(sum);
+            for (int i = 0; i < d; ++i) feat[i] /= sum;
+            if (labels_out) labels_out[n_rec] = cls;
+        }
+        ++n_rec;
+    }
+    if (n_classes_out) *n_classes_out = n_names;
+    for (int i = 0; i < n_names; ++i) free(names[i]);
+    free(names); free(l1); free(l2); free(l3);
+    fclose(f);
+    return ret < 0 ? ret : n_rec;
+}
+
+/* db_features.cpp:117-162 getTrainingAndTestImages. perm[400] is the content of `indices`
+ * after the (optional) shuffle (:119-124) -- identity for randomize=false. caltech_rule != 0
+ * takes 30 gallery images per class (:132-133); otherwise ceil(count*fraction) clamped to
+ * [1, count-1] (:135-142). Outputs indexInDatabase (:146,150,159) and classNo per view. */
+int64_t orc_split(const int32_t* class_counts, int n_classes, const int32_t* perm, int caltech_rule, double fraction,
+                  int32_t* db_index, int32_t* db_class, int32_t* test_index, int32_t* test_class, int64_t* n_test_out) {
+    const int INDICES_COUNT = 400;
+    int64_t ndb = 0, ntest = 0;
+    int indexInDatabase = 0;
+    for (int class_ind = 0; class_ind < n_classes; ++class_ind) {
+        int currentFaceCount = class_counts[class_ind];
+        int db_size;
+        if (caltech_rule) db_size = 30;
+        else {
+            float size_f = currentFaceCount * fraction;
+            db_size = (int)(ceil(size_f));
+            if (db_size == currentFaceCount) db_size = currentFaceCount - 1;
+            if (db_size == 0) db_size = 1;
+        }
+        int ind = 0;
+        for (int i = 0; i < INDICES_COUNT; ++i) {
+            if (perm[i] < currentFaceCount) {
+                if (ind < db_size) { db_index[ndb] = indexInDatabase + perm[i]; db_class[ndb] = class_ind; ++ndb; }
+                else { test_index[ntest] = indexInDatabase + perm[i]; test_class[ntest] = class_ind; ++ntest; }
+                ++ind;
+            }
+        }
+        indexInDatabase += currentFaceCount;
+    }
+    if (n_test_out) *n_test_out = ntest;
+    return ndb;
+}
+
+/* ann.cpp:84-93 ClassificationMethod::getThreshold: the value at rank (int)(n*rate). */
+static int cmp_float(const void* a, const void* b) {
+    float x = *(const float*)a, y = *(const float*)b;
+    return (x > y) - (x < y);
+}
+float orc_get_threshold(const float* dists, int n, float false_accept_rate) {
+    float* v = (float*)malloc(sizeof(float) * (size_t)n);
+    memcpy(v, dists, sizeof(float) * (size_t)n);
+    qsort(v, (size_t)n, sizeof(float), cmp_float);
+    int ind = (int)(n * false_accept_rate);
+    float t = v[ind];
+    free(v);
+    return t;
+}
