@@ -1,0 +1,251 @@
+#!/usr/bin/env python3
+"""bench.py -- query-vectors/sec of brute-force L2 top-1 over a 1M x 512 float32 gallery.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` (N > 1 is launched by
+torch.distributed.run, one rank per GPU). A "step" is one batch of `--batch` query vectors
+matched against the whole gallery: ceil(batch / queries_per_pass) gallery passes of the scan
+kernel plus, for N > 1, one RCCL all-reduce(MIN) over the packed (distance, index) keys.
+Queries and gallery are resident in HBM before the timed region starts.
+
+Multi-GPU: the SAME 1M x 512 gallery is sharded by rows over the N ranks ("scaling":
+"strong"); every rank scans its shard for all queries and the global nearest neighbour is the
+integer minimum of the ranks' packed keys (exact first-minimum tie-break).
+
+Rank 0 prints ONE JSON line. `roofline` is measured live with HIP events around every scan
+launch on the stream the kernel runs on; `cpu_baseline` (N = 1 only) times the reference's own
+recognize_image_bf (oracle/_ref, built from /root/reference in the build container) on the
+host cores over a bounded sample of the same queries, and cross-checks the GPU answers.
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import __graft_entry__ as ge  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 achievable)
+CHUNK_ROWS = 15625      # generation granule: 64 chunks make the 1M-row gallery, any 1/2/4/8 sharding is whole chunks
+
+
+def gen_chunk(chunk, rows, d, device):
+    """Rows [chunk*CHUNK_ROWS, ...) of the global synthetic gallery: Uniform[0,1), |x|<1e-4 -> 0,
+    L2-normalised (qt_cpp/db_features.cpp:85-101). Depends only on the chunk id."""
+    g = torch.Generator(device=device)
+    g.manual_seed(1_000_003 * 13 + chunk)
+    x = torch.rand((rows, d), generator=g, device=device, dtype=torch.float32)
+    x = torch.where(x.abs() < 1e-4, torch.zeros_like(x), x)
+    return x / x.norm(dim=1, keepdim=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rows", type=int, default=1_000_000)
+    ap.add_argument("--dim", type=int, default=512)
+    ap.add_argument("--batch", type=int, default=64, help="query vectors per step")
+    ap.add_argument("--qpp", type=int, default=0, help="queries per gallery pass (0 = library default)")
+    ap.add_argument("--waves", type=int, default=0)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    fir = ge.load_package()
+
+    n, d, qb = args.rows, args.dim, args.batch
+    n_chunks = (n + CHUNK_ROWS - 1) // CHUNK_ROWS
+    per = (n_chunks + world - 1) // world
+    c_lo, c_hi = min(rank * per, n_chunks), min((rank + 1) * per, n_chunks)
+    row_lo, row_hi = min(c_lo * CHUNK_ROWS, n), min(c_hi * CHUNK_ROWS, n)
+
+    # ---- gallery shard, generated on the device, re-tiled by the library, source freed ----
+    shard = torch.empty((row_hi - row_lo, d), device=dev, dtype=torch.float32)
+    for c in range(c_lo, c_hi):
+        r0 = c * CHUNK_ROWS
+        rows = min(CHUNK_ROWS, n - r0)
+        shard[r0 - row_lo: r0 - row_lo + rows] = gen_chunk(c, rows, d, dev)
+    torch.cuda.synchronize()
+    # all timed work runs on one explicit (non-default) stream: the library launches on it and torch
+    # orders the RCCL all-reduce after it
+    work_stream = torch.cuda.Stream(device=dev)
+    stream = work_stream.cuda_stream
+    g = fir.Gallery(dev_ptr=shard.data_ptr(), n=shard.shape[0], d=d, metric=fir.METRIC_L2, device=local_rank, stream=stream)
+    g.set_row_offset(row_lo)
+    if args.qpp or args.waves:
+        g.set_tuning(args.qpp, args.waves)
+    tuning = g.get_tuning()
+
+    # ---- queries: even = fresh draws, odd = perturbed copies of known gallery rows of chunk 0 ----
+    c0 = gen_chunk(0, min(CHUNK_ROWS, n), d, dev)
+    gq = torch.Generator(device=dev)
+    gq.manual_seed(424243)
+    fresh = torch.rand((qb, d), generator=gq, device=dev)
+    planted_rows = (torch.arange(qb, device=dev) * 977 + 11) % c0.shape[0]
+    noise = (torch.rand((qb, d), generator=gq, device=dev) - 0.5) * 0.05 * c0.mean()
+    pert = (c0[planted_rows] + noise).clamp_min(0)
+    q = torch.where((torch.arange(qb, device=dev) % 2 == 0)[:, None], fresh, pert)
+    q = (q / q.norm(dim=1, keepdim=True)).contiguous()
+    del c0, fresh, pert, noise
+    keys = torch.empty(qb, device=dev, dtype=torch.int64)   # packed u64 keys; < 2^63 because distances are >= 0
+    host_shard = None
+    if world == 1 and args.cpu_seconds > 0:
+        host_shard = shard.cpu().numpy()
+    del shard
+    torch.cuda.empty_cache()
+
+    torch.cuda.synchronize()
+
+    def step():
+        with torch.cuda.stream(work_stream):
+            g.search_top1_keys_dev(q.data_ptr(), qb, keys.data_ptr(), stream=stream)
+            if dist is not None:
+                dist.all_reduce(keys, op=dist.ReduceOp.MIN)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    g.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    t1 = time.perf_counter()
+    kernel_ms, bytes_alg = g.profile_read()
+    g.profile_enable(False)
+    elapsed = t1 - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    idx, dd = fir.keys_unpack(keys.cpu().numpy().view(np.uint64))
+    # size-independent property at full size: every planted query finds its source row, closer than any fresh one does
+    planted = planted_rows.cpu().numpy()
+    odd = np.arange(qb) % 2 == 1
+    planted_ok = bool(np.all(idx[odd] == planted[odd])) if n >= CHUNK_ROWS else None
+
+    out = None
+    if rank == 0:
+        passes_per_step = len(kernel_ms) / max(args.steps, 1)
+        avg_ms = float(np.mean(kernel_ms)) if len(kernel_ms) else float("nan")
+        achieved = bytes_alg / (avg_ms * 1e-3) / 1e9 if len(kernel_ms) else float("nan")
+        out = {
+            "metric": "query-vectors/sec brute-force L2 top-1, 1Mx512 gallery",
+            "value": qb * args.steps / elapsed,
+            "unit": "queries/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{n}x{d} f32 gallery, batched L2 top-1 (configs[1] kernel at the metric's 1Mx512 size)",
+                "query_batch": qb,
+                "queries_per_pass": tuning["queries_per_pass"],
+                "passes_per_step": passes_per_step,
+                "waves": tuning["waves"],
+                "row_sharding": f"{world} shard(s) of {row_hi - row_lo} rows",
+                "planted_queries_found": planted_ok,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "kernel": "fir::k_scan<8,L2,top1>",
+                "kernel_avg_ms": avg_ms,
+                "bytes_per_launch": bytes_alg,
+            },
+        }
+        if host_shard is not None:
+            out["cpu_baseline"] = cpu_baseline(host_shard, q.cpu().numpy(), idx, dd, args.cpu_seconds)
+    g.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+def cpu_baseline(rows, queries, gpu_idx, gpu_dist, budget_s):
+    """The reference's recognize_image_bf (qt_cpp/db_features.cpp:319-335) on the host cores:
+    one query per thread at a time (the reference itself is single threaded; queries are
+    independent). Falls back to the C restatement when oracle/_ref is not present."""
+    import oracle_lib
+
+    cores = max(1, min(len(os.sched_getaffinity(0)), 16))
+    d = rows.shape[1]
+    kind = "reference" if oracle_lib.have_ref() else "port"
+    if kind == "reference":
+        db = oracle_lib.load_ref("l2").db(rows, None, 0)
+        fn = lambda qv: db.recognize_image_bf(qv, d)  # noqa: E731
+    else:
+        orc = oracle_lib.load_oracle()
+        fn = lambda qv: orc.recognize_bf(rows, qv, 0, d, 0)[0]  # noqa: E731
+    # calibrate with one query, then run whole rounds of `cores` queries inside the budget
+    t0 = time.perf_counter()
+    first = fn(queries[0])
+    t_one = time.perf_counter() - t0
+    rounds = max(1, int(budget_s / max(t_one * 1.3, 1e-6)))
+    nq = min(queries.shape[0], rounds * cores)
+    res = [None] * nq
+    res[0] = first
+
+    def work(tid):
+        for i in range(tid, nq, cores):
+            res[i] = fn(queries[i])
+
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=work, args=(t,)) for t in range(cores)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    dt = time.perf_counter() - t0
+    agree = int(sum(int(res[i]) == int(gpu_idx[i]) for i in range(nq)))
+    return {
+        "value": nq / dt,
+        "unit": "queries/s",
+        "cores": cores,
+        "kind": kind,
+        "sample": f"{nq} of the step's {queries.shape[0]} queries against the full {rows.shape[0]}x{d} gallery, "
+                  f"{cores} threads x recognize_image_bf ({t_one:.2f} s/query/thread); GPU index identical on {agree}/{nq}",
+    }
+
+
+if __name__ == "__main__":
+    main()
