@@ -73,12 +73,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     fir = ge.load_package()
+    from fast_image_recognition_amd import sharding
 
     n, d, qb = args.rows, args.dim, args.batch
-    n_chunks = (n + CHUNK_ROWS - 1) // CHUNK_ROWS
-    per = (n_chunks + world - 1) // world
-    c_lo, c_hi = min(rank * per, n_chunks), min((rank + 1) * per, n_chunks)
-    row_lo, row_hi = min(c_lo * CHUNK_ROWS, n), min(c_hi * CHUNK_ROWS, n)
+    row_lo, row_hi = sharding.shard_bounds(n, world, rank, granule=CHUNK_ROWS)
+    c_lo, c_hi = row_lo // CHUNK_ROWS, (row_hi + CHUNK_ROWS - 1) // CHUNK_ROWS
 
     # ---- gallery shard, generated on the device, re-tiled by the library, source freed ----
     shard = torch.empty((row_hi - row_lo, d), device=dev, dtype=torch.float32)
@@ -108,7 +107,7 @@ def main():
     q = torch.where((torch.arange(qb, device=dev) % 2 == 0)[:, None], fresh, pert)
     q = (q / q.norm(dim=1, keepdim=True)).contiguous()
     del c0, fresh, pert, noise
-    keys = torch.empty(qb, device=dev, dtype=torch.int64)   # packed u64 keys; < 2^63 because distances are >= 0
+    keys = torch.empty(qb, device=dev, dtype=torch.int64)   # packed u64 keys (viewed int64 for torch)
     host_shard = None
     if world == 1 and args.cpu_seconds > 0:
         host_shard = shard.cpu().numpy()
@@ -121,7 +120,9 @@ def main():
         with torch.cuda.stream(work_stream):
             g.search_top1_keys_dev(q.data_ptr(), qb, keys.data_ptr(), stream=stream)
             if dist is not None:
-                dist.all_reduce(keys, op=dist.ReduceOp.MIN)
+                k = sharding.keys_as_int64(keys)           # order-preserving u64 -> i64 (x ^ 2^63)
+                sharding.allreduce_min_keys(k)             # RCCL all-reduce(MIN) over xGMI
+                keys.copy_(sharding.keys_from_int64(k))
 
     def fence():
         torch.cuda.synchronize()

@@ -1,0 +1,92 @@
+"""Input builders shared by tests/golden/make_golden.py (which asks the REAL reference for the
+expected outputs) and the tests that replay the fixtures. Inputs are regenerated from seeds
+(tests/synth.py); only expected outputs live in tests/golden/*.npz."""
+import numpy as np
+
+import synth
+
+L2, CHI2, KL = 0, 1, 2
+METRIC_NAMES = {L2: "l2", CHI2: "chi2", KL: "kl"}
+
+# (seed, n, d): SURVEY.md section 8c
+MATCH_SHAPES = [(13, 257, 64), (17, 1000, 256), (101, 4099, 512), (13, 600, 1280), (17, 500, 1536)]
+N_QUERIES = 6
+
+
+def match_case(seed, n, d, metric):
+    rows = synth.make_gallery(seed, n, d, metric)
+    q, _ = synth.make_queries(seed, rows, N_QUERIES, metric)
+    return rows, q
+
+
+def special_cases():
+    """name -> (rows, queries, metric): ties, 1-ulp near ties, zero rows, NaN rows, nothing-found."""
+    out = {}
+    rows = synth.make_gallery(21, 1500, 64, L2)
+    q, pick = synth.make_queries(21, rows, 4, L2)
+    for i in range(4):
+        src = rows[int(pick[i])].copy()
+        q[i] = src
+        for dup in (17 + i, 64 * 5 + 3, 1499 - i):
+            rows[dup] = src
+    out["ties"] = (rows, q, L2)
+
+    rows = synth.make_gallery(22, 1200, 128, L2)
+    q, _ = synth.make_queries(22, rows, 3, L2)
+    base = rows[100].copy()
+    for j, r in enumerate((200, 900, 1199)):
+        v = base.copy()
+        v[j] = np.nextafter(v[j], np.float32(2), dtype=np.float32)
+        rows[r] = v
+    q[:] = base
+    out["near_ties"] = (rows, q, L2)
+
+    rows = synth.make_gallery(23, 300, 32, CHI2)
+    rows[3] = 0
+    rows[200] = 0
+    q, _ = synth.make_queries(23, rows, 3, CHI2)
+    q[0, :8] = 0
+    out["zero_rows_chi2"] = (rows, q, CHI2)
+
+    rows = synth.make_gallery(24, 300, 32, L2)
+    rows[5, 3] = np.nan
+    rows[77] = np.nan
+    q, _ = synth.make_queries(24, rows, 3, L2)
+    out["nan_rows"] = (rows, q, L2)
+
+    rows = np.full((130, 8), 1.0e4, np.float32)
+    out["nothing_found"] = (rows, np.zeros((2, 8), np.float32), L2)
+    return out
+
+
+def twd_case(seed=13, n=1515, d=300, n_classes=101):
+    rows = synth.make_gallery(seed, n, d, L2)
+    cls = synth.make_labels(n, n_classes)
+    q, _ = synth.make_queries(seed, rows, 12, L2, noise=0.4)
+    return rows, cls, q, n_classes
+
+
+TWD_CONVENTIONAL = [(0, 0.24), (1, 0.003), (2, 0.7), (0, 0.5), (1, 1e-5), (2, 0.999)]   # ImageTesting.cpp:531-533 + both outcomes
+TWD_PROPOSED = [(32, 0.7), (64, 0.7), (32, 0.95)]                                      # ImageTesting.cpp:534-535
+
+
+def cls_case(seed=17, n=360, d=96, n_classes=12):
+    """Double-precision dataset for classification.cpp (already L2-normalised like :829-847)."""
+    x = synth.uniform01(n * d, seed).reshape(n, d).astype(np.float64)
+    lab = (np.arange(n) % n_classes).astype(np.int32)
+    x += 0.5 * synth.uniform01(n_classes * d, seed + 1).reshape(n_classes, d).astype(np.float64)[lab]
+    x /= np.sqrt((x * x).sum(axis=1))[:, None]
+    return x, lab, n_classes
+
+
+def loader_case():
+    """A small feature file in the producer's format (dnn_feature_extractor.py:58-64) with
+    FEATURES_COUNT = 1536 columns, classes out of order, a skipped class and sub-1e-4 values."""
+    d = 1536
+    classes = ["accordion", "BACKGROUND_Google", "airplanes", "accordion", "anchor", "airplanes", "257.clutter", "anchor", "accordion"]
+    feats = synth.uniform01(len(classes) * d, 909).reshape(len(classes), d).astype(np.float32)
+    feats[:, 5] = 0.00004      # below the 1e-4 clip
+    feats[2, 7] = 0.0001       # printed as 0.000100: parses back just above/below the clip
+    feats[4, :50] = 0.0
+    names = [f"/data/101_ObjectCategories/{c}/image_{i:04d}.jpg" for i, c in enumerate(classes)]
+    return names, classes, feats, d

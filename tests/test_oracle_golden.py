@@ -1,0 +1,123 @@
+"""Pins the oracle (oracle/oracle.c) to the reference: every fixture in
+tests/golden/reference_outputs.npz was produced by the REAL reference code
+(tests/golden/make_golden.py over oracle/_ref); the C restatement must reproduce it exactly.
+Runs anywhere (no GPU, no /root/reference)."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+
+import golden_cases as gc
+import synth
+
+GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_outputs.npz"))
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def topk_all(oracle, rows, q, s, e, k, metric):
+    idx, dd = [], []
+    for qi in q:
+        i, d_ = oracle.topk(rows, qi, s, e, k, metric)
+        idx.append(i)
+        dd.append(d_)
+    return np.array(idx, np.int32), np.array(dd, np.float32)
+
+
+@pytest.mark.parametrize("metric", [gc.L2, gc.CHI2, gc.KL])
+@pytest.mark.parametrize("shape", gc.MATCH_SHAPES)
+def test_match_path_matches_reference(oracle, metric, shape):
+    seed, n, d = shape
+    rows, q = gc.match_case(seed, n, d, metric)
+    ranges = [(0, d)] + ([(0, 64), (64, 256)] if d >= 256 else [(0, 32), (5, 39)])
+    for (s, e) in ranges:
+        pre = f"match/{gc.METRIC_NAMES[metric]}/{seed}_{n}_{d}/{s}_{e}/"
+        idx, dist = oracle.top1_batch(rows, q, s, e, metric)
+        assert np.array_equal(idx, GOLD[pre + "best_idx"])
+        assert np.array_equal(bits(dist), bits(GOLD[pre + "best_dist"]))   # KL too: same libm on both sides
+        ti, td = topk_all(oracle, rows, q, s, e, 5, metric)
+        assert np.array_equal(ti, GOLD[pre + "top5_idx"])
+        assert np.array_equal(bits(td), bits(GOLD[pre + "top5_dist"]))
+
+
+@pytest.mark.parametrize("name", sorted(gc.special_cases().keys()))
+def test_special_cases_match_reference(oracle, name):
+    rows, q, metric = gc.special_cases()[name]
+    d = rows.shape[1]
+    idx, dist = oracle.top1_batch(rows, q, 0, d, metric)
+    assert np.array_equal(idx, GOLD[f"special/{name}/best_idx"])
+    assert np.array_equal(bits(dist), bits(GOLD[f"special/{name}/best_dist"]))
+    ti, td = topk_all(oracle, rows, q, 0, d, 5, metric)
+    assert np.array_equal(ti, GOLD[f"special/{name}/top5_idx"])
+    assert np.array_equal(bits(td), bits(GOLD[f"special/{name}/top5_dist"]))
+
+
+def test_bruteforce_classifier_and_twd_match_reference(oracle):
+    rows, cls, q, ncls = gc.twd_case()
+    for maxf in (300, 64, 256):
+        got = [oracle.bf_classifier(rows, cls, qi, maxf) for qi in q]
+        assert got == list(GOLD[f"bfclass/{maxf}/class"])
+    assert str(GOLD["bfclass/64/name"]) == "BF, 64"
+    both = set()
+    for (typ, th) in gc.TWD_CONVENTIONAL:
+        got = [oracle.twd_conventional(rows, cls, qi, ncls, typ, th, 64) for qi in q]
+        assert [g[0] for g in got] == list(GOLD[f"twd_conv/{typ}_{th}/class"])
+        assert [g[1] for g in got] == list(GOLD[f"twd_conv/{typ}_{th}/unreliable"])
+        both.update(g[1] for g in got)
+    assert both == {0, 1}, "fixtures must exercise both the reliable and the second-stage outcome"
+    for (fc, th) in gc.TWD_PROPOSED:
+        got = [oracle.twd_proposed(rows, cls, qi, fc, th) for qi in q]
+        assert [g[0] for g in got] == list(GOLD[f"twd_prop/{fc}_{th}/class"])
+        assert [g[1] for g in got] == list(GOLD[f"twd_prop/{fc}_{th}/unreliable"])
+
+
+def test_ann_bruteforce_and_threshold_match_reference(oracle):
+    rows, q = gc.match_case(17, 500, 1536, gc.L2)
+    idx, _ = oracle.top1_batch(rows, q, 0, 1536, gc.L2)
+    assert np.array_equal(idx, GOLD["ann_bf/idx"])
+    dists = synth.uniform01(1000, 55)
+    for rate in (0.0, 0.01, 0.1, 0.5):
+        assert bits(oracle.get_threshold(dists, rate)) == bits(GOLD[f"threshold/{rate}"])
+
+
+def test_loader_and_split_match_reference(oracle):
+    names, classes, feats, d = gc.loader_case()
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "feats.txt")
+        synth.write_feature_file(path, names, classes, feats)
+        for metric in (gc.L2, gc.CHI2):
+            rows, cls, ncls = oracle.load_images(path, d, metric)
+            pre = f"loader/{gc.METRIC_NAMES[metric]}/"
+            assert ncls == int(GOLD[pre + "n_classes"]) == 3
+            assert np.array_equal(cls, GOLD[pre + "class"])
+            assert np.array_equal(bits(rows), bits(GOLD[pre + "rows"]))
+        r64, lab, ncls = oracle.load_dataset_f64(path, d)
+        assert np.array_equal(lab, GOLD["loader/f64/labels"])
+        assert np.array_equal(r64.view(np.uint64), GOLD["loader/f64/rows"].view(np.uint64))
+        assert oracle.load_images(os.path.join(td, "missing.txt"), d, gc.L2)[0].shape[0] == 0   # db_features.cpp:49,115
+    counts = np.array([45, 31, 30, 29, 1, 400, 120], np.int32)
+    dbi, dbc, ti, tc = oracle.split(counts, None, True)
+    assert np.array_equal(dbi, GOLD["split/db_index"]) and np.array_equal(dbc, GOLD["split/db_class"])
+    assert np.array_equal(ti, GOLD["split/test_index"]) and np.array_equal(tc, GOLD["split/test_class"])
+
+
+def test_classification_knn_pnn_match_reference(oracle):
+    x, lab, ncls = gc.cls_case()
+    train, tcls, test = GOLD["cls/train"], GOLD["cls/train_class"], GOLD["cls/test"]
+    tr = x[train]
+    mn, mx, avg, sd = oracle.train_stats(tr)
+    for got, nm in ((mn, "min"), (mx, "max"), (avg, "avg"), (sd, "std")):
+        assert np.array_equal(got.view(np.uint64), GOLD[f"cls/{nm}"].view(np.uint64)), nm
+    knn1 = [oracle.knn_predict(tr, tcls, avg, ncls, x[r], 1)[0] for r in test]
+    knn3 = [oracle.knn_predict(tr, tcls, avg, ncls, x[r], 3)[0] for r in test]
+    pnn = [oracle.pnn_predict(tr, tcls, avg, ncls, x[r])[0] for r in test]
+    seq = [oracle.pnn_predict_seq(tr, tcls, avg, ncls, x[r])[0] for r in test]
+    assert knn1 == list(GOLD["cls/knn1"])
+    assert knn3 == list(GOLD["cls/knn3"])
+    assert pnn == list(GOLD["cls/pnn"])
+    assert seq == list(GOLD["cls/pnn_seq"])
+    acc = np.mean(np.array(knn1) == lab[test])
+    assert acc > 0.5, "the synthetic classes should be separable enough for the fixture to mean something"

@@ -1,0 +1,97 @@
+"""N > 1 path on CPU: two gloo ranks, each with a row shard. The per-shard packed keys come from
+the oracle here (no GPU in this container); the sharding arithmetic, the int64 view of the
+keys and the MIN all-reduce are the product's (fast-image-recognition_amd/sharding.py)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n, d, qb, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    import torch.distributed as dist
+
+    import __graft_entry__ as ge
+    import oracle_lib
+    import synth
+
+    fir = ge.load_package()
+    from fast_image_recognition_amd import sharding
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    rows = synth.make_gallery(77, n, d, 0)
+    q, _ = synth.make_queries(77, rows, qb, 0)
+    rows[n - 3] = rows[5]
+    q[1] = rows[5]                        # a tie across shards
+    q[2] = np.float32(1e4)                # nothing within 100000 -> FIR_KEY_NONE everywhere
+    lo, hi = sharding.shard_bounds(n, world, rank, granule=64)
+    orc = oracle_lib.load_oracle()
+    keys = np.empty(qb, np.uint64)
+    for i in range(qb):
+        if hi > lo:
+            li, ld = orc.recognize_bf(rows[lo:hi], q[i], 0, d, 0)
+        else:
+            li, ld = -1, np.float32(100000.0)
+        keys[i] = fir.key_pack(ld, li + lo if li >= 0 else -1)
+    t = sharding.keys_as_int64(torch.from_numpy(keys.view(np.int64)).clone())
+    sharding.allreduce_min_keys(t)
+    merged = sharding.keys_from_int64(t).numpy().view(np.uint64)
+    idx, dd = fir.keys_unpack(merged)
+    np.savez(os.path.join(out_dir, f"r{rank}.npz"), idx=idx, dist=dd, lo=lo, hi=hi)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n", [(2, 1000), (2, 70), (3, 129)])
+def test_sharded_top1_equals_unsharded(tmp_path, oracle, world, n):
+    import synth
+
+    d, qb = 48, 6
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, n, d, qb, str(tmp_path)), nprocs=world, join=True)
+    rows = synth.make_gallery(77, n, d, 0)
+    q, _ = synth.make_queries(77, rows, qb, 0)
+    rows[n - 3] = rows[5]
+    q[1] = rows[5]
+    q[2] = np.float32(1e4)
+    eidx, edist = oracle.top1_batch(rows, q, 0, d, 0)
+    assert eidx[1] == 5 and eidx[2] == -1
+    cover = []
+    for r in range(world):
+        z = np.load(tmp_path / f"r{r}.npz")
+        assert np.array_equal(z["idx"], eidx), (r, z["idx"], eidx)
+        assert np.array_equal(z["dist"].view(np.uint32), edist.view(np.uint32))
+        cover.append((int(z["lo"]), int(z["hi"])))
+    assert cover[0][0] == 0 and cover[-1][1] == n
+    assert all(cover[i][1] == cover[i + 1][0] for i in range(world - 1))
+
+
+def test_shard_bounds_partition():
+    import __graft_entry__ as ge
+
+    ge.load_package()
+    from fast_image_recognition_amd import sharding
+
+    for n in (0, 1, 63, 64, 65, 1000, 15625 * 64, 10_000_000):
+        for world in (1, 2, 3, 4, 8):
+            for gran in (1, 64, 15625):
+                b = [sharding.shard_bounds(n, world, r, gran) for r in range(world)]
+                assert b[0][0] == 0 and b[-1][1] == n
+                assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+                assert all(lo <= hi for lo, hi in b)
+                assert all(lo % gran == 0 for lo, hi in b if lo < n)
