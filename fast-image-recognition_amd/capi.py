@@ -11,7 +11,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def lib_path():
-    return os.path.join(_HERE, "libfir_amd.so")
+    # FIR_AMD_LIB: an alternative build of the same library (kernel-variant experiments in tools/)
+    return os.environ.get("FIR_AMD_LIB") or os.path.join(_HERE, "libfir_amd.so")
 
 
 class FirError(RuntimeError):

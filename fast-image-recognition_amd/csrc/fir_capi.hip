@@ -34,8 +34,14 @@ int fail(int code, const char* fmt, ...) {
                                           "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
-constexpr int kU = 8;        // float4 chunks per lane per load group (8 KiB per wave in flight per group)
-constexpr int kWps = 4;      // waves per SIMD the scan kernels are register-budgeted for (<= 128 VGPRs)
+#ifndef FIR_U
+#define FIR_U 8
+#endif
+#ifndef FIR_WPS
+#define FIR_WPS 4
+#endif
+constexpr int kU = FIR_U;    // float4 chunks per lane per load group (FIR_U KiB per wave in flight per group)
+constexpr int kWps = FIR_WPS;     // waves per SIMD the scan kernels are register-budgeted for (<= 128 VGPRs)
 constexpr int kKMax = 8;     // per-lane candidate list length of the top-K scan
 
 }  // namespace
@@ -62,7 +68,11 @@ struct fir_gallery {
 
     int qpp = 8;              // queries per gallery pass
     int waves_req = 0;        // 0 = automatic
-    int max_waves = 0;
+    int max_waves = 0;        // upper bound over all scan kernels (8 blocks per CU)
+    int last_waves = 0;       // waves of the most recent scan launch
+
+    struct Occ { const void* fn; size_t lds; int waves; };
+    std::vector<Occ> occ;     // resident-wave capacity per scan kernel
 
     bool profiling = false;
     std::vector<hipEvent_t> ev;   // pairs
@@ -88,6 +98,10 @@ typedef void (*scan_fn)(const ScanArgs);
 template <int EPI>
 scan_fn pick_kernel(int qb, int metric) {
 #define FIR_CASE(QB, M) if (qb == QB && metric == M) return (scan_fn)k_scan<QB, M, kU, EPI, kKMax, kWps>;
+#ifdef FIR_MINIMAL   // experiment builds: only the L2 top-1 kernels
+    if constexpr (EPI == kEpiTop1) { FIR_CASE(8, 0) FIR_CASE(4, 0) FIR_CASE(2, 0) FIR_CASE(1, 0) }
+    return nullptr;
+#endif
     FIR_CASE(1, 0) FIR_CASE(2, 0) FIR_CASE(4, 0)
     FIR_CASE(1, 1) FIR_CASE(2, 1) FIR_CASE(4, 1)
     FIR_CASE(1, 2) FIR_CASE(2, 2) FIR_CASE(4, 2)
@@ -95,6 +109,39 @@ scan_fn pick_kernel(int qb, int metric) {
         FIR_CASE(8, 0) FIR_CASE(8, 1) FIR_CASE(8, 2)
     }
 #undef FIR_CASE
+    return nullptr;
+}
+
+#ifndef FIR_FAST
+#define FIR_FAST 1
+#endif
+#ifndef FIR_FAST_U
+#define FIR_FAST_U 8
+#endif
+#ifndef FIR_FAST_WPS
+#define FIR_FAST_WPS 4
+#endif
+#ifndef FIR_FAST_MODE
+#define FIR_FAST_MODE 2   // 1: query tile through the scalar cache (SGPR operands), 2: staged in LDS
+#endif
+// The hand-scheduled L2 top-1 kernels cover whole-chunk feature ranges with 8 or 16 queries.
+// *lds_bytes receives the dynamic LDS size the kernel must be launched with.
+scan_fn pick_fast(int epi, int qb, int metric, int start, int end, int dp4, size_t* lds_bytes) {
+    if (lds_bytes) *lds_bytes = 0;
+#if FIR_FAST
+    if (epi != kEpiTop1 || metric != kL2 || (start & 3) || (end & 3)) return nullptr;
+    if (qb != 8 && qb != 16) return nullptr;
+#if FIR_FAST_MODE == 2
+    const size_t need = (size_t)(dp4 + 1) * qb * 16;     // query tile + one zero chunk of slack
+    if (need <= 64 * 1024) {
+        if (lds_bytes) *lds_bytes = need;
+        if (qb == 8) return (scan_fn)k_scan_l2_lds<1, FIR_FAST_U, FIR_FAST_WPS>;
+        return (scan_fn)k_scan_l2_lds<2, FIR_FAST_U, FIR_FAST_WPS>;
+    }
+#endif
+    if (qb == 8) return (scan_fn)k_scan_l2_fast<1, FIR_FAST_U, FIR_FAST_WPS>;
+    return (scan_fn)k_scan_l2_fast<2, FIR_FAST_U, FIR_FAST_WPS>;
+#endif
     return nullptr;
 }
 
@@ -106,14 +153,16 @@ scan_fn pick(int epi, int qb, int metric) {
     }
 }
 
-// Number of waves for `tiles` tiles: every wave gets ceil(tiles / waves) or one fewer tile and
-// all waves are resident at once, so the grid drains together (no ragged last round).
-int pick_waves(int64_t tiles, int max_waves) {
+// Number of waves for `tiles` tiles. All waves are resident at once (waves <= capacity) and each
+// gets ceil(tiles / waves) or one fewer tile. Large galleries use a whole number of waves per
+// SIMD -- 3 measured best on MI355X for the HBM-bound L2 scan (profiles/r01_sweep_notes.md):
+// with a fractional count the SIMDs that hold one wave more finish late.
+int pick_waves(int64_t tiles, int max_waves, int simds) {
     if (tiles <= 0) return 4;
-    if (tiles <= max_waves) return (int)((tiles + 3) / 4 * 4);
-    const int64_t rounds = (tiles + max_waves - 1) / max_waves;
-    const int64_t w = (tiles + rounds - 1) / rounds;
-    return (int)std::min<int64_t>((w + 3) / 4 * 4, max_waves);
+    const int per_simd = std::max(1, std::min(3, max_waves / std::max(simds, 1)));
+    const int w = per_simd * simds;
+    if (tiles <= w) return (int)((tiles + 3) / 4 * 4);
+    return w;
 }
 
 int check_range(const fir_gallery* g, int32_t& start, int32_t& end) {
@@ -129,9 +178,22 @@ int largest_pow2_le(int x, int cap) {
     return p;
 }
 
+// Resident-wave capacity of one scan kernel on this device (cached per kernel / LDS size).
+int max_waves_for(fir_gallery* g, scan_fn fn, size_t lds_bytes) {
+    for (const auto& e : g->occ)
+        if (e.fn == (const void*)fn && e.lds == lds_bytes) return e.waves;
+    int nb = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)fn, kBlock, lds_bytes);
+    if (e != hipSuccess || nb <= 0) nb = 2;
+    nb = std::min(nb, 8);
+    const int waves = g->cus * nb * (kBlock / 64);
+    g->occ.push_back({(const void*)fn, lds_bytes, waves});
+    return waves;
+}
+
 // Queue: transpose (+ key init) of one query tile, then one gallery pass.
 int run_pass(fir_gallery* g, hipStream_t st, int epi, const float* d_queries, int q0, int qb_tile, int32_t start,
-             int32_t end, uint64_t* keys, float* out, int64_t out_stride, int k) {
+             int32_t end, uint64_t* keys, float* out, int64_t out_stride, int k, int* waves_used = nullptr) {
     const int kk = g->dp4 * 4;
     float* qt = g->qt + (size_t)q0 * kk;
     {
@@ -140,9 +202,14 @@ int run_pass(fir_gallery* g, hipStream_t st, int epi, const float* d_queries, in
         hipLaunchKernelGGL(k_transpose_queries, dim3(blocks), dim3(kBlock), 0, st, d_queries + (size_t)q0 * g->d, qb_tile,
                            g->d, g->dp4, qb_tile, qt);
     }
-    scan_fn fn = pick(epi, qb_tile, g->metric);
+    size_t lds_bytes = 0;
+    scan_fn fn = pick_fast(epi, qb_tile, g->metric, start, end, g->dp4, &lds_bytes);
+    if (!fn) fn = pick(epi, qb_tile, g->metric);
     if (!fn) return fail(FIR_ERR_ARG, "no kernel for qb=%d metric=%d", qb_tile, g->metric);
-    const int waves = g->waves_req > 0 ? std::min(g->waves_req, g->max_waves) : pick_waves(g->tiles, g->max_waves);
+    const int max_waves = max_waves_for(g, fn, lds_bytes);
+    const int waves = g->waves_req > 0 ? std::min(g->waves_req, max_waves) : pick_waves(g->tiles, max_waves, g->cus * 4);
+    g->last_waves = waves;
+    if (waves_used) *waves_used = waves;
     ScanArgs a;
     a.gal4 = g->gal4;
     a.qt = qt;
@@ -171,7 +238,7 @@ int run_pass(fir_gallery* g, hipStream_t st, int epi, const float* d_queries, in
         e1 = g->ev[g->ev_used++];
         FIR_HIP(hipEventRecord(e0, st));
     }
-    hipLaunchKernelGGL(fn, dim3(waves / 4), dim3(kBlock), 0, st, a);
+    hipLaunchKernelGGL(fn, dim3(waves / 4), dim3(kBlock), lds_bytes, st, a);
     if (g->profiling) {
         FIR_HIP(hipEventRecord(e1, st));
         // algorithmic bytes of one pass: the gallery range once, the query tile, the keys
@@ -188,12 +255,14 @@ __global__ void k_fill_keys(uint64_t* keys, int n) {
 
 int top1_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start, int32_t end, uint64_t* d_keys,
              hipStream_t st) {
-    int rc = grow(g->qt, g->qt_cap, (size_t)qb * g->dp4 * 4);
+    int rc = grow(g->qt, g->qt_cap, (size_t)qb * g->dp4 * 4 + 64);   // +64: the fast kernel prefetches one unit past the tile
     if (rc) return rc;
     hipLaunchKernelGGL(k_fill_keys, dim3((qb + kBlock - 1) / kBlock), dim3(kBlock), 0, st, d_keys, qb);
+    // 16 queries per pass exist only in the hand-scheduled kernel (whole-chunk L2 ranges)
+    const int cap = pick_fast(kEpiTop1, 16, g->metric, start, end, g->dp4, nullptr) ? g->qpp : std::min(g->qpp, 8);
     int q0 = 0;
     while (q0 < qb) {
-        const int t = largest_pow2_le(qb - q0, g->qpp);
+        const int t = largest_pow2_le(qb - q0, cap);
         rc = run_pass(g, st, kEpiTop1, d_queries, q0, t, start, end, d_keys + q0, nullptr, 0, 0);
         if (rc) return rc;
         q0 += t;
@@ -211,9 +280,9 @@ int topk_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start, 
     int q0 = 0;
     while (q0 < qb) {
         const int t = largest_pow2_le(qb - q0, qcap);
-        rc = run_pass(g, st, kEpiTopK, d_queries, q0, t, start, end, g->part, nullptr, 0, k);
+        int waves = 0;
+        rc = run_pass(g, st, kEpiTopK, d_queries, q0, t, start, end, g->part, nullptr, 0, k, &waves);
         if (rc) return rc;
-        const int waves = g->waves_req > 0 ? std::min(g->waves_req, g->max_waves) : pick_waves(g->tiles, g->max_waves);
         hipLaunchKernelGGL(k_topk_merge, dim3(t), dim3(kBlock), 0, st, g->part, waves, t, q0, t, k, d_keys);
         q0 += t;
     }
@@ -226,7 +295,7 @@ int range_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start,
     if (rc) return rc;
     int q0 = 0;
     while (q0 < qb) {
-        const int t = largest_pow2_le(qb - q0, g->qpp);
+        const int t = largest_pow2_le(qb - q0, std::min(g->qpp, 8));
         rc = run_pass(g, st, kEpiStore, d_queries, q0, t, start, end, nullptr, d_out + (size_t)q0 * g->n, g->n, 0);
         if (rc) return rc;
         q0 += t;
@@ -263,11 +332,8 @@ int gallery_alloc(int64_t n, int32_t d, int32_t metric, int32_t device, fir_gall
     g->dp4 = (d + 3) / 4;
     g->tiles = (n + kTileRows - 1) / kTileRows;
     g->metric = metric;
-    int nb = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_scan<8, 0, kU, kEpiTop1, kKMax, kWps>, kBlock, 0);
-    if (e != hipSuccess || nb <= 0) nb = 4;
-    nb = std::min(nb, 8);
-    g->max_waves = g->cus * nb * (kBlock / 64);
+    g->max_waves = g->cus * 8 * (kBlock / 64);
+    hipError_t e;
     e = hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete g; return fail(FIR_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
     const size_t f4 = (size_t)std::max<int64_t>(g->tiles, 1) * g->dp4 * 64;
@@ -591,8 +657,9 @@ int fir_gallery_sync(fir_gallery* g) {
 int fir_gallery_set_tuning(fir_gallery* g, int32_t queries_per_pass, int32_t waves) {
     if (!g) return fail(FIR_ERR_ARG, "gallery is NULL");
     if (queries_per_pass != 0) {
-        if (queries_per_pass != 1 && queries_per_pass != 2 && queries_per_pass != 4 && queries_per_pass != 8)
-            return fail(FIR_ERR_ARG, "queries_per_pass must be 1, 2, 4 or 8");
+        if (queries_per_pass != 1 && queries_per_pass != 2 && queries_per_pass != 4 && queries_per_pass != 8 &&
+            queries_per_pass != 16)
+            return fail(FIR_ERR_ARG, "queries_per_pass must be 1, 2, 4, 8 or 16");
         g->qpp = queries_per_pass;
     }
     if (waves < 0 || (waves % 4) != 0) return fail(FIR_ERR_ARG, "waves must be a non-negative multiple of 4");
@@ -603,7 +670,7 @@ int fir_gallery_set_tuning(fir_gallery* g, int32_t queries_per_pass, int32_t wav
 int fir_gallery_get_tuning(const fir_gallery* g, int32_t* queries_per_pass, int32_t* waves, int32_t* max_waves) {
     if (!g) return fail(FIR_ERR_ARG, "gallery is NULL");
     if (queries_per_pass) *queries_per_pass = g->qpp;
-    if (waves) *waves = g->waves_req > 0 ? std::min(g->waves_req, g->max_waves) : pick_waves(g->tiles, g->max_waves);
+    if (waves) *waves = g->last_waves;   // waves of the most recent scan launch (0 before the first)
     if (max_waves) *max_waves = g->max_waves;
     return FIR_OK;
 }

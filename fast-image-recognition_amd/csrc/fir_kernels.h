@@ -76,6 +76,23 @@ __device__ __forceinline__ float accum(float acc, float l, float r) {
     }
 }
 
+#ifndef FIR_PIPE
+#define FIR_PIPE 0
+#endif
+#ifndef FIR_NT
+#define FIR_NT 1   // +6 % on the 1M x 512 scan (profiles/r01_sweep_notes.md)
+#endif
+// One lane's float4 of a gallery tile. FIR_NT: non-temporal hint (the gallery is streamed once per pass).
+__device__ __forceinline__ float4 ld_gallery(const float4* p) {
+#if FIR_NT
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f v = __builtin_nontemporal_load((const v4f*)p);
+    return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return *p;
+#endif
+}
+
 struct ScanArgs {
     const float4* gal4;   // tiled gallery
     const float* qt;      // query tile, transposed: qt[k * QB + q], k in [0, dp4*4)
@@ -188,12 +205,30 @@ __global__ void __launch_bounds__(kBlock, WPS) k_scan(const ScanArgs a) {
                 TileAcc<QB, METRIC, U>::masked(acc, tile[(size_t)(c_lo - 1) * 64], qc, c_lo - 1, a.start, a.end);
 
             const float4* p = tile + (size_t)c_lo * 64;
+#if FIR_PIPE == 0
             for (int gi = 0; gi < ng; ++gi) {
                 float4 g[U];
 #pragma unroll
-                for (int u = 0; u < U; ++u) g[u] = p[(size_t)(gi * U + u) * 64];
+                for (int u = 0; u < U; ++u) g[u] = ld_gallery(p + (size_t)(gi * U + u) * 64);
                 TileAcc<QB, METRIC, U>::group(acc, g, qc, c_lo + gi * U);
             }
+#else
+            // register double buffer: group gi+1 is in flight while group gi is consumed
+            float4 g[U];
+            if (ng > 0) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) g[u] = ld_gallery(p + (size_t)u * 64);
+            }
+            for (int gi = 0; gi < ng; ++gi) {
+                float4 nx[U];
+                const int gn = gi + 1 < ng ? gi + 1 : gi;   // the last group re-reads itself (cache hit, keeps the loop branch-free)
+#pragma unroll
+                for (int u = 0; u < U; ++u) nx[u] = ld_gallery(p + (size_t)(gn * U + u) * 64);
+                TileAcc<QB, METRIC, U>::group(acc, g, qc, c_lo + gi * U);
+#pragma unroll
+                for (int u = 0; u < U; ++u) g[u] = nx[u];
+            }
+#endif
             for (int c = c_end; c < c_hi; ++c)
                 TileAcc<QB, METRIC, U>::masked(acc, tile[(size_t)c * 64], qc, c, a.start, a.end);
             if ((a.end & 3) != 0)
@@ -264,6 +299,307 @@ __global__ void __launch_bounds__(kBlock, WPS) k_scan(const ScanArgs a) {
                     break;
                 }
             }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Hand-scheduled L2 top-1 scan (the headline kernel): same tile streaming, same arithmetic and
+// therefore the same bits as k_scan<QB, kL2, ..., kEpiTop1>, for feature ranges made of whole
+// chunks (start % 4 == 0 && end % 4 == 0). The per-chunk body is one inline-asm block of 48
+// packed-f32 VALU instructions for 8 queries (v_pk_add_f32 with an SGPR query pair and the lane's
+// gallery value broadcast by op_sel, v_pk_mul_f32, v_pk_add_f32): packed f32 ops issue at the
+// same rate as scalar ones on gfx950 (profiles/r01_ubench_valu_issue_rate.txt), i.e. two queries
+// per issue slot, and four independent accumulator pairs are interleaved so no dependent pair is
+// closer than four instructions (no hazard nops). IEEE-wise each half of a packed op is the plain
+// f32 op, un-fused: sub, mul, add -- the reference's own three roundings.
+// ---------------------------------------------------------------------------------------------
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef const f2 __attribute__((address_space(4)))* sf2_p;
+
+#define FIR_SUB_LO(t, s, g) "v_pk_add_f32 %[" #t "], %[" #s "], %[" #g "] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+#define FIR_SUB_HI(t, s, g) "v_pk_add_f32 %[" #t "], %[" #s "], %[" #g "] op_sel:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+#define FIR_SQR(t) "v_pk_mul_f32 %[" #t "], %[" #t "], %[" #t "]\n\t"
+#define FIR_ACC(a, t) "v_pk_add_f32 %[" #a "], %[" #a "], %[" #t "]\n\t"
+
+// One pipeline unit: acc[0..3] (4 query pairs = 8 queries) += (q - g)^2 for TWO features held in
+// the register pair g (lo = feature 2h, hi = feature 2h+1 of the chunk); s[jj*4+p] = queries
+// (2p, 2p+1) of feature jj. 24 packed instructions, dependent ones >= 4 apart.
+__device__ __forceinline__ void l2_half8(f2 (&a)[4], const f2 g, const f2 (&s)[8]) {
+    f2 t0, t1, t2, t3, u0, u1, u2, u3;
+    asm volatile(
+        FIR_SUB_LO(t0, s0, g) FIR_SUB_LO(t1, s1, g) FIR_SUB_LO(t2, s2, g) FIR_SUB_LO(t3, s3, g)
+        FIR_SUB_HI(u0, s4, g) FIR_SUB_HI(u1, s5, g) FIR_SUB_HI(u2, s6, g) FIR_SUB_HI(u3, s7, g)
+        FIR_SQR(t0) FIR_SQR(t1) FIR_SQR(t2) FIR_SQR(t3)
+        FIR_ACC(a0, t0) FIR_ACC(a1, t1) FIR_ACC(a2, t2) FIR_ACC(a3, t3)
+        FIR_SQR(u0) FIR_SQR(u1) FIR_SQR(u2) FIR_SQR(u3)
+        FIR_ACC(a0, u0) FIR_ACC(a1, u1) FIR_ACC(a2, u2) FIR_ACC(a3, u3)
+        : [a0] "+v"(a[0]), [a1] "+v"(a[1]), [a2] "+v"(a[2]), [a3] "+v"(a[3]),
+          [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3),
+          [u0] "=&v"(u0), [u1] "=&v"(u1), [u2] "=&v"(u2), [u3] "=&v"(u3)
+        : [g] "v"(g),
+          [s0] "s"(s[0]), [s1] "s"(s[1]), [s2] "s"(s[2]), [s3] "s"(s[3]),
+          [s4] "s"(s[4]), [s5] "s"(s[5]), [s6] "s"(s[6]), [s7] "s"(s[7]));
+}
+
+// Query values of unit (chunk c, half h, query block b): 2 features x 8 queries = 8 f2 (16 SGPRs).
+template <int NB>
+__device__ __forceinline__ void load_unit(f2 (&s)[8], sf2_p q2, int c, int h, int b) {
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp) s[jj * 4 + pp] = q2[((c * 4 + 2 * h + jj) * 4 * NB) + 4 * b + pp];
+}
+
+// One chunk (4 features) of one lane against 8*NB queries; the scalar loads run one unit ahead
+// of the VALU work (cur = this unit's query values on entry, next unit's on exit).
+template <int NB>
+__device__ __forceinline__ void l2_chunk(f2 (&acc)[NB][4], const float4 g, f2 (&cur)[8], sf2_p q2, int c) {
+    const f2 gp[2] = {f2{g.x, g.y}, f2{g.z, g.w}};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            f2 nx[8];
+            // the unit after (c, h, b); past the last chunk this reads the slack behind the query tile
+            const int nb = b + 1 < NB ? b + 1 : 0;
+            const int nh = b + 1 < NB ? h : (h + 1) & 1;
+            const int nc = (b + 1 < NB || h == 0) ? c : c + 1;
+            // SMEM returns out of order, so a wait for `cur` is lgkmcnt(0): take it BEFORE the next
+            // unit's loads are issued (an empty asm that reads cur pins the wait here), then let
+            // those loads fly under this unit's 24 VALU instructions.
+            asm volatile("" ::"s"(cur[0]), "s"(cur[1]), "s"(cur[2]), "s"(cur[3]), "s"(cur[4]), "s"(cur[5]), "s"(cur[6]), "s"(cur[7]));
+            __builtin_amdgcn_sched_barrier(0);
+            load_unit<NB>(nx, q2, nc, nh, nb);
+            l2_half8(acc[b], gp[h], cur);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) cur[i] = nx[i];
+        }
+    }
+}
+
+// NB blocks of 8 queries per pass (QB = 8 * NB). qt layout as everywhere: qt[k * QB + q]; the
+// query tile must be followed by >= 64 readable floats (prefetch of the unit past the end).
+template <int NB, int U, int WPS>
+__global__ void __launch_bounds__(kBlock, WPS) k_scan_l2_fast(const ScanArgs a) {
+    constexpr int QB = 8 * NB;
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    sf2_p q2 = (sf2_p)(uintptr_t)a.qt;            // f2 index of (feature k, query pair p of block b): k*4*NB + 4*b + p
+    const int c_lo = a.start >> 2, c_hi = a.end >> 2;
+    const float fcount = (float)(a.end - a.start);
+
+    float best_d[QB];
+    int32_t best_i[QB];
+#pragma unroll
+    for (int q = 0; q < QB; ++q) { best_d[q] = kNotFound; best_i[q] = -1; }
+
+    for (int t = gw; t < a.tiles; t += a.waves) {
+        const float4* p = a.gal4 + ((size_t)t * a.dp4 + c_lo) * 64 + lane;
+        f2 acc[NB][4];
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[b][i] = f2{0.0f, 0.0f};
+        f2 cur[8];
+        load_unit<NB>(cur, q2, c_lo, 0, 0);
+
+        int c = c_lo;
+        for (; c + U <= c_hi; c += U) {
+            float4 g[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) g[u] = ld_gallery(p + (size_t)(c - c_lo + u) * 64);
+#pragma unroll
+            for (int u = 0; u < U; ++u) l2_chunk<NB>(acc, g[u], cur, q2, c + u);
+        }
+        for (; c < c_hi; ++c)      // (c_hi - c_lo) % U leftover chunks
+            l2_chunk<NB>(acc, ld_gallery(p + (size_t)(c - c_lo) * 64), cur, q2, c);
+
+        const int64_t row = (int64_t)t * kTileRows + lane;
+        if (row < a.n) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float d0 = acc[b][i].x / fcount, d1 = acc[b][i].y / fcount;   // db_features.cpp:40
+                    const int q0 = b * 8 + 2 * i;
+                    if (d0 < best_d[q0]) { best_d[q0] = d0; best_i[q0] = (int32_t)row; }           // db_features.cpp:329-332
+                    if (d1 < best_d[q0 + 1]) { best_d[q0 + 1] = d1; best_i[q0 + 1] = (int32_t)row; }
+                }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < QB; ++q) {
+        uint64_t key = best_i[q] >= 0 ? key_pack(best_d[q], (uint32_t)((int64_t)best_i[q] + a.row_offset)) : kKeyNone;
+        key = wave_min_u64(key);
+        if (lane == 0 && key != kKeyNone) {
+            const uint64_t cur_key = __hip_atomic_load(a.keys + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (key < cur_key) atomicMin((unsigned long long*)(a.keys + q), (unsigned long long)key);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Same kernel with the query tile staged in LDS. Why: the SGPR form above fetches 16 query
+// dwords per 24 VALU instructions through the scalar cache; an 8-query tile at d = 512 is 16 KiB
+// -- the whole scalar cache -- and every wave walks it at its own phase, so the s_loads miss to L2
+// (~800 cycles each, measured: 0.7 us per chunk per wave, profiles/r01_sweep_notes.md) and SMEM
+// returns out of order, so only one batch can be in flight per wave: the wave becomes latency
+// bound. LDS reads are in-order, counted (lgkmcnt(N)) and ~100 cycles: every lane reads the same
+// address (a broadcast, no bank conflict), 4 x ds_read_b128 per unit, issued one unit ahead.
+// ---------------------------------------------------------------------------------------------
+// One feature of one lane against 8 queries: acc[0..3] += (q - g)^2, g = lo or hi half of the
+// register pair, s[p] = queries (2p, 2p+1). 12 packed instructions, dependent ones 4 apart.
+template <int HI>
+__device__ __forceinline__ void l2_feat8_v(f2 (&a)[4], const f2 g, const f2 (&s)[4]) {
+    f2 t0, t1, t2, t3;
+    if constexpr (HI == 0) {
+        asm volatile(FIR_SUB_LO(t0, s0, g) FIR_SUB_LO(t1, s1, g) FIR_SUB_LO(t2, s2, g) FIR_SUB_LO(t3, s3, g)
+                     FIR_SQR(t0) FIR_SQR(t1) FIR_SQR(t2) FIR_SQR(t3)
+                     FIR_ACC(a0, t0) FIR_ACC(a1, t1) FIR_ACC(a2, t2) FIR_ACC(a3, t3)
+                     : [a0] "+v"(a[0]), [a1] "+v"(a[1]), [a2] "+v"(a[2]), [a3] "+v"(a[3]),
+                       [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
+                     : [g] "v"(g), [s0] "v"(s[0]), [s1] "v"(s[1]), [s2] "v"(s[2]), [s3] "v"(s[3]));
+    } else {
+        asm volatile(FIR_SUB_HI(t0, s0, g) FIR_SUB_HI(t1, s1, g) FIR_SUB_HI(t2, s2, g) FIR_SUB_HI(t3, s3, g)
+                     FIR_SQR(t0) FIR_SQR(t1) FIR_SQR(t2) FIR_SQR(t3)
+                     FIR_ACC(a0, t0) FIR_ACC(a1, t1) FIR_ACC(a2, t2) FIR_ACC(a3, t3)
+                     : [a0] "+v"(a[0]), [a1] "+v"(a[1]), [a2] "+v"(a[2]), [a3] "+v"(a[3]),
+                       [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
+                     : [g] "v"(g), [s0] "v"(s[0]), [s1] "v"(s[1]), [s2] "v"(s[2]), [s3] "v"(s[3]));
+    }
+}
+
+// Query values of unit (feature k, block b) from the LDS copy of the tile (float4 view:
+// index of (feature k, queries 4i..4i+3) = k * 2 * NB + i): 2 x ds_read_b128, a broadcast.
+template <int NB>
+__device__ __forceinline__ void lds_unit(f2 (&s)[4], const float4* lq, int k, int b) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float4 v = lq[k * 2 * NB + 2 * b + i];
+        s[2 * i] = f2{v.x, v.y};
+        s[2 * i + 1] = f2{v.z, v.w};
+    }
+}
+
+// One chunk (4 features) of one lane against 8*NB queries; the LDS reads run one unit (one
+// feature x 8 queries) ahead of the VALU work: cur = this unit's query values on entry, the next
+// unit's on exit (past the last feature: the zeroed slack chunk).
+template <int NB>
+__device__ __forceinline__ void l2_chunk_lds(f2 (&acc)[NB][4], const float4 g, f2 (&cur)[4], const float4* lq, int c) {
+    const f2 gp[2] = {f2{g.x, g.y}, f2{g.z, g.w}};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            f2 nx[4];
+            const int nb = b + 1 < NB ? b + 1 : 0;
+            const int nk = c * 4 + j + (b + 1 < NB ? 0 : 1);
+            lds_unit<NB>(nx, lq, nk, nb);
+            if (j & 1) l2_feat8_v<1>(acc[b], gp[j >> 1], cur);
+            else l2_feat8_v<0>(acc[b], gp[j >> 1], cur);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) cur[i] = nx[i];
+        }
+    }
+}
+
+// Dynamic LDS: (dp4 + 1) * 4 * QB floats (the query tile + one zero chunk of slack).
+template <int NB, int U, int WPS>
+__global__ void __launch_bounds__(kBlock, WPS) k_scan_l2_lds(const ScanArgs a) {
+    constexpr int QB = 8 * NB;
+    extern __shared__ __attribute__((aligned(16))) float4 lq[];
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const int c_lo = a.start >> 2, c_hi = a.end >> 2;
+    const float fcount = (float)(a.end - a.start);
+    {
+        const float4* src = reinterpret_cast<const float4*>(a.qt);
+        const int n4 = a.dp4 * QB;                       // float4s in the tile: dp4*4 features * QB / 4
+        for (int i = threadIdx.x; i < n4 + QB; i += kBlock) lq[i] = i < n4 ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        __syncthreads();
+    }
+    // LDS base held in a VGPR the compiler cannot prove uniform: the reads then use one per-group
+    // address register + immediate offsets (ds_read_b128 v, vaddr offset:N) instead of one
+    // s_add + v_mov per read. All lanes still read the same address (hardware broadcast).
+    int zero_v;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(zero_v));
+    const float4* lqv = lq + zero_v;
+
+    float best_d[QB];
+    int32_t best_i[QB];
+#pragma unroll
+    for (int q = 0; q < QB; ++q) { best_d[q] = kNotFound; best_i[q] = -1; }
+
+    for (int t = gw; t < a.tiles; t += a.waves) {
+#ifdef FIR_DEBUG_TILEMOD   // timing experiments only: every tile reads one of the first few (cache-resident stream)
+        const float4* p = a.gal4 + ((size_t)(t % FIR_DEBUG_TILEMOD) * a.dp4 + c_lo) * 64 + lane;
+#else
+        const float4* p = a.gal4 + ((size_t)t * a.dp4 + c_lo) * 64 + lane;
+#endif
+        f2 acc[NB][4];
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[b][i] = f2{0.0f, 0.0f};
+        f2 cur[4];
+        lds_unit<NB>(cur, lqv, c_lo * 4, 0);
+
+        int c = c_lo;
+#if FIR_PIPE == 0
+        for (; c + U <= c_hi; c += U) {
+            float4 g[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) g[u] = ld_gallery(p + (size_t)(c - c_lo + u) * 64);
+#pragma unroll
+            for (int u = 0; u < U; ++u) l2_chunk_lds<NB>(acc, g[u], cur, lqv, c + u);
+        }
+#else
+        // register double buffer: the next group's loads are in flight while this group is consumed
+        {
+            const int ng = (c_hi - c_lo) / U;
+            float4 g[U];
+            if (ng > 0) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) g[u] = ld_gallery(p + (size_t)u * 64);
+            }
+            for (int gi = 0; gi < ng; ++gi, c += U) {
+                float4 nxg[U];
+                const int gn = gi + 1 < ng ? gi + 1 : gi;   // the last group re-reads itself (L2 hit; keeps the loop branch-free)
+#pragma unroll
+                for (int u = 0; u < U; ++u) nxg[u] = ld_gallery(p + (size_t)(gn * U + u) * 64);
+#pragma unroll
+                for (int u = 0; u < U; ++u) l2_chunk_lds<NB>(acc, g[u], cur, lqv, c + u);
+#pragma unroll
+                for (int u = 0; u < U; ++u) g[u] = nxg[u];
+            }
+        }
+#endif
+        for (; c < c_hi; ++c)
+            l2_chunk_lds<NB>(acc, ld_gallery(p + (size_t)(c - c_lo) * 64), cur, lqv, c);
+
+        const int64_t row = (int64_t)t * kTileRows + lane;
+        if (row < a.n) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float d0 = acc[b][i].x / fcount, d1 = acc[b][i].y / fcount;   // db_features.cpp:40
+                    const int q0 = b * 8 + 2 * i;
+                    if (d0 < best_d[q0]) { best_d[q0] = d0; best_i[q0] = (int32_t)row; }           // db_features.cpp:329-332
+                    if (d1 < best_d[q0 + 1]) { best_d[q0 + 1] = d1; best_i[q0 + 1] = (int32_t)row; }
+                }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < QB; ++q) {
+        uint64_t key = best_i[q] >= 0 ? key_pack(best_d[q], (uint32_t)((int64_t)best_i[q] + a.row_offset)) : kKeyNone;
+        key = wave_min_u64(key);
+        if (lane == 0 && key != kKeyNone) {
+            const uint64_t cur_key = __hip_atomic_load(a.keys + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (key < cur_key) atomicMin((unsigned long long*)(a.keys + q), (unsigned long long)key);
         }
     }
 }
