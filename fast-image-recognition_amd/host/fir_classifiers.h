@@ -1,0 +1,126 @@
+// fir_classifiers.h -- the reference's two classifier interfaces on top of the GPU matcher:
+//   Classifier / BruteForceClassifier              qt_cpp/ImageTesting.cpp:35-71   (-> class id)
+//   ClassificationMethod / BruteForce              qt_cpp/ann.h:9-47, ann.cpp:84-126 (-> gallery row)
+// Same constructors, virtuals, names and -1 conventions, so the reference's drivers
+// (testRecognitionMethod ImageTesting.cpp:439, testSetRecognition ann.cpp:94) compile against
+// them unchanged. Added: batched recognize_batch() -- one gallery pass per 8 test images.
+#ifndef FIR_CLASSIFIERS_H
+#define FIR_CLASSIFIERS_H
+
+#include <chrono>
+#include <iostream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "fir_db.h"
+
+// ---- ImageTesting.cpp:35-49 ----
+class Classifier {
+public:
+    Classifier(std::string n) : name(n), pDbImages(nullptr) {}
+    virtual ~Classifier() {}
+    // The reference only stores the pointer (ImageTesting.cpp:40); the upload happens lazily on
+    // the first recognize and is redone when a new split arrives through the same vector.
+    virtual void train(std::vector<ImageInfo>* pDb) { pDbImages = pDb; if (pDb) fir::invalidate(*pDb); }
+    virtual int recognize(ImageInfo& testImageInfo) = 0;
+    // Batched extension: class id (or -1) for every test image.
+    virtual std::vector<int> recognize_batch(const std::vector<ImageInfo>& tests) {
+        std::vector<int> out;
+        out.reserve(tests.size());
+        for (ImageInfo t : tests) out.push_back(recognize(t));
+        return out;
+    }
+    std::string get_name() { return name; }
+
+private:
+    std::string name;
+
+protected:
+    std::vector<ImageInfo>* pDbImages;
+    static std::string build_name(std::string prefix, int param) {   // ImageTesting.cpp:51-55
+        std::ostringstream os;
+        os << prefix << ", " << param;
+        return os.str();
+    }
+};
+
+// ---- ImageTesting.cpp:58-71 ----
+class BruteForceClassifier : public Classifier {
+public:
+    BruteForceClassifier(int max_feats = FEATURES_COUNT) : Classifier(Classifier::build_name("BF", max_feats)), max_features(max_feats) {}
+    int recognize(ImageInfo& testImageInfo) override {
+        const int best = recognize_image_bf(*pDbImages, testImageInfo, max_features);
+        return best == -1 ? -1 : (*pDbImages)[best].classNo;
+    }
+    std::vector<int> recognize_batch(const std::vector<ImageInfo>& tests) override {
+        std::vector<int> rows = fir::recognize_images_bf(*pDbImages, tests, max_features);
+        for (int& r : rows) r = (r == -1) ? -1 : (*pDbImages)[r].classNo;
+        return rows;
+    }
+
+private:
+    int max_features;
+};
+
+// ---- ann.h:9-39 ----
+class ClassificationMethod {
+public:
+    ClassificationMethod(std::string name, std::vector<ImageInfo>& db) : method_name(name), dbImages(db), distanceCalcCount(0), avgCheckedPercent(0) {
+        imageCountToCheck = (int)dbImages.size();
+    }
+    virtual ~ClassificationMethod() {}
+    virtual int recognize(ImageInfo& testImageInfo) = 0;
+    virtual std::vector<int> recognize_batch(const std::vector<ImageInfo>& tests) {
+        std::vector<int> out;
+        out.reserve(tests.size());
+        for (ImageInfo t : tests) out.push_back(recognize(t));
+        return out;
+    }
+    // ann.cpp:94-109: error rate and ms per query over a test set (batched underneath).
+    void testSetRecognition(std::vector<ImageInfo>& testImages) {
+        int errorsCount = 0;
+        avgCheckedPercent = 0;
+        auto t1 = std::chrono::high_resolution_clock::now();
+        std::vector<int> best = recognize_batch(testImages);
+        for (size_t i = 0; i < testImages.size(); ++i)
+            if (best[i] == -1 || testImages[i].classNo != dbImages[best[i]].classNo) ++errorsCount;
+        auto t2 = std::chrono::high_resolution_clock::now();
+        double total_time = (double)std::chrono::duration_cast<std::chrono::milliseconds>(t2 - t1).count();
+        double errorRate = 100. * errorsCount / testImages.size();
+        std::cout << method_name.c_str() << " error=" << errorRate << "% total_time (ms)" << total_time / testImages.size()
+                  << " checkedPercent=" << (avgCheckedPercent > 0 ? avgCheckedPercent / testImages.size() : -1) << std::endl;
+    }
+    virtual void setImageCountToCheck(int count) {                    // ann.h:20-22
+        imageCountToCheck = (count > 0 && count < (int)dbImages.size()) ? count : (int)dbImages.size();
+    }
+    // ann.cpp:84-93: the distance at rank (int)(n * rate).
+    static float getThreshold(std::vector<float>& otherClassesDists, float falseAcceptRate);
+
+protected:
+    std::string method_name;
+    std::vector<ImageInfo>& dbImages;
+    int distanceCalcCount;
+    float avgCheckedPercent;
+    int imageCountToCheck;
+    float distance(ImageInfo& testImage, int modelInd, bool updateCounters = true) {   // ann.h:33-38
+        if (updateCounters) ++distanceCalcCount;
+        return testImage.distance(dbImages[modelInd]);
+    }
+};
+
+// ---- ann.h:42-47, ann.cpp:113-126: exhaustive nearest neighbour over all FEATURES_COUNT features ----
+class BruteForce : public ClassificationMethod {
+public:
+    BruteForce(std::vector<ImageInfo>& db) : ClassificationMethod("BF", db) {}
+    int recognize(ImageInfo& testImage) override {
+        distanceCalcCount = (int)dbImages.size();                    // every row is evaluated once (ann.cpp:114,118)
+        return recognize_image_bf(dbImages, testImage, FEATURES_COUNT);
+    }
+    std::vector<int> recognize_batch(const std::vector<ImageInfo>& tests) override {
+        distanceCalcCount = (int)dbImages.size();
+        return fir::recognize_images_bf(dbImages, tests, FEATURES_COUNT);
+    }
+};
+
+#endif  // FIR_CLASSIFIERS_H

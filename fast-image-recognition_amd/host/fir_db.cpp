@@ -1,0 +1,204 @@
+// fir_db.cpp -- host side of the drop-in (see fir_db.h). IO, packing and handle caching only:
+// every distance is computed by libfir_amd.so on the GPU.
+#include "fir_db.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
+#include <tuple>
+
+namespace fir {
+
+namespace {
+int g_device = 0;
+int g_metric = FIR_DEFAULT_METRIC;
+
+struct CacheKey {
+    const void* vec;
+    size_t n;
+    const float* first;
+    const float* last;
+    int dim;
+    int metric;
+    bool operator<(const CacheKey& o) const {
+        return std::tie(vec, n, first, last, dim, metric) < std::tie(o.vec, o.n, o.first, o.last, o.dim, o.metric);
+    }
+};
+std::map<CacheKey, fir_gallery*> g_cache;
+
+CacheKey key_of(const std::vector<ImageInfo>& db, int dim) {
+    CacheKey k;
+    k.vec = &db;
+    k.n = db.size();
+    k.first = db.empty() ? nullptr : db.front().features.data();
+    k.last = db.empty() ? nullptr : db.back().features.data();
+    k.dim = dim;
+    k.metric = g_metric;
+    return k;
+}
+}  // namespace
+
+void set_device(int device) { g_device = device; }
+int device() { return g_device; }
+int metric() { return g_metric; }
+void set_metric(int m) { g_metric = m; }
+void log_error(const char* where) { std::fprintf(stderr, "fir: %s: %s\n", where, fir_last_error()); }
+
+fir_gallery* GalleryCache::get(const std::vector<ImageInfo>& db, int dim) {
+    const CacheKey k = key_of(db, dim);
+    auto it = g_cache.find(k);
+    if (it != g_cache.end()) return it->second;
+    // a different split presented through the same vector object replaces the old upload
+    for (auto i = g_cache.begin(); i != g_cache.end();) {
+        if (i->first.vec == k.vec) { fir_gallery_destroy(i->second); i = g_cache.erase(i); } else ++i;
+    }
+    std::vector<float> rows((size_t)db.size() * dim);
+    std::vector<int32_t> cls(db.size());
+    for (size_t j = 0; j < db.size(); ++j) {
+        const FeaturesVector& f = db[j].features;
+        const size_t have = std::min<size_t>(f.size(), (size_t)dim);
+        std::memcpy(&rows[j * dim], f.data(), have * sizeof(float));   // rows shorter than dim are zero padded
+        cls[j] = db[j].classNo;
+    }
+    fir_gallery* g = nullptr;
+    if (fir_gallery_create(rows.data(), (int64_t)db.size(), dim, cls.data(), g_metric, g_device, &g) != FIR_OK) {
+        log_error("gallery upload");
+        return nullptr;
+    }
+    g_cache[k] = g;
+    return g;
+}
+
+void GalleryCache::invalidate(const std::vector<ImageInfo>& db) {
+    for (auto i = g_cache.begin(); i != g_cache.end();) {
+        if (i->first.vec == (const void*)&db) { fir_gallery_destroy(i->second); i = g_cache.erase(i); } else ++i;
+    }
+}
+
+void GalleryCache::clear() {
+    for (auto& kv : g_cache) fir_gallery_destroy(kv.second);
+    g_cache.clear();
+}
+
+std::vector<int> recognize_images_bf(const std::vector<ImageInfo>& dbImages, const std::vector<ImageInfo>& tests,
+                                     int max_features, std::vector<float>* best_dist) {
+    if (max_features == 0) max_features = FEATURES_COUNT;          // db_features.cpp:320-321
+    std::vector<int> out(tests.size(), -1);
+    if (best_dist) best_dist->assign(tests.size(), FIR_NOT_FOUND_DIST);
+    if (tests.empty() || dbImages.empty()) return out;
+    // the gallery is uploaded with as many features as the scan reads
+    const int dim = max_features;
+    fir_gallery* g = GalleryCache::get(dbImages, dim);
+    if (!g) return out;
+    std::vector<float> q((size_t)tests.size() * dim, 0.0f);
+    for (size_t i = 0; i < tests.size(); ++i) {
+        const FeaturesVector& f = tests[i].features;
+        std::memcpy(&q[i * dim], f.data(), std::min<size_t>(f.size(), (size_t)dim) * sizeof(float));
+    }
+    std::vector<int32_t> idx(tests.size());
+    std::vector<float> dist(tests.size());
+    if (fir_search_top1(g, q.data(), (int32_t)tests.size(), 0, max_features, idx.data(), dist.data()) != FIR_OK) {
+        log_error("search_top1");
+        return out;
+    }
+    for (size_t i = 0; i < tests.size(); ++i) out[i] = idx[i];
+    if (best_dist) *best_dist = dist;
+    return out;
+}
+
+}  // namespace fir
+
+float feature_distance(const FeaturesVector& lhs, const FeaturesVector& rhs, int start_pos, int end_pos) {
+    float d = 0.0f;
+    const int len = (int)std::min(lhs.size(), rhs.size());
+    if (fir_feature_distance(lhs.data(), rhs.data(), len, start_pos, end_pos, fir::metric(), fir::device(), &d) != FIR_OK) {
+        fir::log_error("feature_distance");
+        return std::nanf("");
+    }
+    return d;
+}
+
+int recognize_image_bf(const std::vector<ImageInfo>& dbImages, const ImageInfo& testImageInfo, int max_features) {
+    std::vector<ImageInfo> one(1, testImageInfo);
+    return fir::recognize_images_bf(dbImages, one, max_features)[0];
+}
+
+// ---- feature file: "<path>\n<class>\n<f0> <f1> ... \n" per image (dnn_feature_extractor.py:58-64) ----
+int loadImages(ImagesDatabase& imagesDb, std::string features_file, std::unordered_map<std::string, int>& person2indexMap,
+               bool /*early_stop*/) {
+    person2indexMap.clear();
+    std::ifstream in(features_file);
+    int total = 0;
+    if (!in) return 0;                                               // silently empty, db_features.cpp:49,115
+    const bool l2 = fir::metric() == FIR_METRIC_L2;
+    std::string path_line, class_line, feat_line;
+    while (std::getline(in, path_line) && std::getline(in, class_line) && std::getline(in, feat_line)) {
+        class_line.erase(0, class_line.find_first_not_of(" \t\n\r\f\v"));
+        if (class_line.find("BACKGROUND_Google") != std::string::npos || class_line.find("257.clutter") != std::string::npos)
+            continue;                                                // db_features.cpp:60-64
+        auto it = person2indexMap.find(class_line);
+        if (it == person2indexMap.end()) {                           // class id = order of first appearance, :65-73
+            it = person2indexMap.emplace(class_line, (int)person2indexMap.size()).first;
+            imagesDb.emplace_back();
+        }
+        std::vector<FeaturesVector>& bucket = imagesDb[it->second];
+        bucket.emplace_back(FEATURES_COUNT);
+        FeaturesVector& f = bucket.back();
+        const char* p = feat_line.c_str();
+        float norm = 0.0f, v = 0.0f;
+        for (int i = 0; i < FEATURES_COUNT; ++i) {
+            char* end = nullptr;
+            const float parsed = std::strtof(p, &end);
+            v = (end != p) ? parsed : 0.0f;                          // a failed extraction stores 0 (C++11 num_get)
+            if (end != p) p = end;
+            if (std::fabs(v) < 0.0001) v = 0.0f;                     // :85-86
+            f[i] = v;
+            norm += l2 ? v * v : v;                                  // :88 / :91
+        }
+        if (l2) norm = std::sqrt(norm);                              // :95
+        for (int i = 0; i < FEATURES_COUNT; ++i) f[i] /= norm;       // :98-99
+        ++total;
+    }
+    return total;
+}
+
+void getTrainingAndTestImages(const ImagesDatabase& totalImages, std::vector<ImageInfo>& dbImages,
+                              std::vector<ImageInfo>& testImages, bool randomize) {
+    const int kIndices = 400;                                        // db_features.cpp:119
+    int order[kIndices];
+    for (int i = 0; i < kIndices; ++i) order[i] = i;
+    if (randomize) {
+        // what std::random_shuffle(first, last) does in libstdc++ (removed from C++17): rand()-driven swaps
+        for (int i = 1; i < kIndices; ++i) {
+            const int j = std::rand() % (i + 1);
+            if (i != j) std::swap(order[i], order[j]);
+        }
+    }
+    dbImages.clear();
+    testImages.clear();
+    int base = 0;
+    for (size_t c = 0; c < totalImages.size(); ++c) {
+        const int count = (int)totalImages[c].size();
+#ifndef FIR_SPLIT_BY_FRACTION
+        int gallery_size = 30;                                       // Caltech rule, :132-133
+#else
+        float want = count * FRACTION;                               // :135-142
+        int gallery_size = (int)std::ceil(want);
+        if (gallery_size == count) gallery_size = count - 1;
+        if (gallery_size == 0) gallery_size = 1;
+#endif
+        int taken = 0;
+        for (int i = 0; i < kIndices; ++i) {
+            if (order[i] >= count) continue;
+            ImageInfo view((int)c, base + order[i], totalImages[c][order[i]]);
+            (taken < gallery_size ? dbImages : testImages).push_back(view);
+            ++taken;
+        }
+        base += count;
+    }
+}

@@ -1,0 +1,98 @@
+// fir_db.h -- host-side mirror of the reference's data model and match entry points
+// (qt_cpp/db_features.h, qt_cpp/db.h), backed by the MI355X library through its C ABI
+// (include/fir_amd.h). Source-compatible with the reference's callers: the same type names,
+// function names, argument order and defaults, the same "-1 means not found" convention.
+//
+// What differs, by design:
+//   * distances are computed on the GPU: recognize_image_bf packs the borrowed gallery views into
+//     one row-major block, uploads it (cached per gallery vector, see GalleryCache) and runs the
+//     scan kernel; feature_distance runs a one-lane kernel. There is no host arithmetic path.
+//   * batched overloads (recognize_images_bf) are added: one gallery pass serves 8 queries.
+#ifndef FIR_DB_H
+#define FIR_DB_H
+
+#include <cstdint>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/fir_amd.h"
+
+// qt_cpp/db.h:79-91 -- the reference fixes the feature dimension at compile time.
+#ifndef FEATURES_COUNT
+#define FEATURES_COUNT 1536
+#endif
+// qt_cpp/db.h:71-78 (Caltech build)
+#ifndef FIR_FRACTION
+#define FIR_FRACTION 0.03
+#endif
+const double FRACTION = FIR_FRACTION;
+
+// qt_cpp/db_features.h:12 -- compile-time metric switch, kept as a macro and mapped to the
+// runtime enum: define FIR_USE_CHI2 or FIR_USE_KL to get the other arms of db_features.cpp:25-39.
+#if defined(FIR_USE_KL)
+#define FIR_DEFAULT_METRIC FIR_METRIC_KL
+#elif defined(FIR_USE_CHI2)
+#define FIR_DEFAULT_METRIC FIR_METRIC_CHI2
+#else
+#define USE_L2_DISTANCE
+#define FIR_DEFAULT_METRIC FIR_METRIC_L2
+#endif
+
+typedef std::vector<float> FeaturesVector;                              // db_features.h:14
+typedef std::vector<std::vector<FeaturesVector> > ImagesDatabase;       // db_features.h:15
+
+// db_features.h:17, db_features.cpp:22-42
+float feature_distance(const FeaturesVector& lhs, const FeaturesVector& rhs, int start_pos = 0, int end_pos = FEATURES_COUNT);
+
+// db_features.h:19-29 -- a non-owning view of one image's features.
+class ImageInfo {
+public:
+    ImageInfo(int no, int ind, const FeaturesVector& feat) : classNo(no), indexInDatabase(ind), features(feat) {}
+    float distance(const ImageInfo& rhs, int start_pos = 0, int end_pos = FEATURES_COUNT) const {
+        return feature_distance(features, rhs.features, start_pos, end_pos);
+    }
+    const int classNo, indexInDatabase;
+    const FeaturesVector& features;
+};
+
+// db_features.h:31, db_features.cpp:44-116 -- text feature file -> database (class-major).
+int loadImages(ImagesDatabase& imagesDb, std::string features_file, std::unordered_map<std::string, int>& person2indexMap,
+               bool early_stop = false);
+// db_features.h:32, db_features.cpp:117-162
+void getTrainingAndTestImages(const ImagesDatabase& totalImages, std::vector<ImageInfo>& dbImages,
+                              std::vector<ImageInfo>& testImages, bool randomize = true);
+// db_features.h:33, db_features.cpp:319-335 -- row index of the nearest gallery image or -1.
+int recognize_image_bf(const std::vector<ImageInfo>& dbImages, const ImageInfo& testImageInfo, int max_features = 0);
+
+namespace fir {
+
+// Batched form of recognize_image_bf: out[i] = row index for tests[i] (or -1). One call costs
+// ceil(n / 8) gallery passes instead of n.
+std::vector<int> recognize_images_bf(const std::vector<ImageInfo>& dbImages, const std::vector<ImageInfo>& tests,
+                                     int max_features = 0, std::vector<float>* best_dist = nullptr);
+
+// The device copy of one `std::vector<ImageInfo>` gallery. The reference's classifiers only keep
+// a pointer to the caller's vector (ImageTesting.cpp:40, ann.h:28); here the rows are packed and
+// uploaded on first use and the handle is reused while the SAME vector object (address, size,
+// first/last feature pointers) is presented again. Call fir::invalidate(dbImages) after
+// mutating a gallery in place.
+class GalleryCache {
+public:
+    static fir_gallery* get(const std::vector<ImageInfo>& dbImages, int dim);
+    static void invalidate(const std::vector<ImageInfo>& dbImages);
+    static void clear();
+};
+inline void invalidate(const std::vector<ImageInfo>& dbImages) { GalleryCache::invalidate(dbImages); }
+
+void set_device(int device);   // default 0
+int device();
+int metric();                  // FIR_DEFAULT_METRIC unless set_metric was called
+void set_metric(int metric);
+
+// Thrown by nothing: errors are reported the reference's way (-1 / empty) and logged to stderr.
+void log_error(const char* where);
+
+}  // namespace fir
+
+#endif  // FIR_DB_H

@@ -1,0 +1,57 @@
+// host_driver.cpp -- exercises the drop-in C++ surface the way the reference's harnesses do
+// (testRecognitionMethod ImageTesting.cpp:439-501, testANN ann.cpp:24-81) and prints the
+// per-query answers as JSON for tests/test_gpu_host_shim.py to compare with the oracle.
+//   host_driver <features.txt> [max_features ...]
+#include <cstdio>
+#include <cstdlib>
+
+#include "compat/ann.h"
+#include "compat/db_features.h"
+
+static void print_vec(const char* key, const std::vector<int>& v, bool comma) {
+    std::printf("\"%s\": [", key);
+    for (size_t i = 0; i < v.size(); ++i) std::printf("%s%d", i ? ", " : "", v[i]);
+    std::printf("]%s\n", comma ? "," : "");
+}
+
+int main(int argc, char** argv) {
+    if (argc < 2) { std::fprintf(stderr, "usage: host_driver <features.txt> [max_features ...]\n"); return 2; }
+    ImagesDatabase total;
+    std::unordered_map<std::string, int> person2index;
+    const int n = loadImages(total, argv[1], person2index);
+    std::vector<ImageInfo> dbImages, testImages;
+    getTrainingAndTestImages(total, dbImages, testImages, /*randomize=*/false);
+    std::printf("{\n\"images\": %d, \"classes\": %zu, \"gallery\": %zu, \"queries\": %zu,\n", n, total.size(), dbImages.size(), testImages.size());
+
+    std::vector<int> truth, dbidx, dbcls;
+    for (const ImageInfo& t : testImages) truth.push_back(t.classNo);
+    for (const ImageInfo& g : dbImages) { dbidx.push_back(g.indexInDatabase); dbcls.push_back(g.classNo); }
+    print_vec("query_class", truth, true);
+    print_vec("gallery_index", dbidx, true);
+    print_vec("gallery_class", dbcls, true);
+
+    for (int a = 2; a < argc; ++a) {                       // BruteForceClassifier(max_features), one query at a time
+        const int maxf = std::atoi(argv[a]);
+        BruteForceClassifier bf(maxf);
+        bf.train(&dbImages);
+        std::vector<int> one, batch = bf.recognize_batch(testImages);
+        for (ImageInfo t : testImages) one.push_back(bf.recognize(t));
+        char key[64];
+        std::snprintf(key, sizeof key, "bf_%d_single", maxf);
+        print_vec(key, one, true);
+        std::snprintf(key, sizeof key, "bf_%d_batch", maxf);
+        print_vec(key, batch, true);
+        std::printf("\"bf_%d_name\": \"%s\",\n", maxf, bf.get_name().c_str());
+    }
+    BruteForce ann(dbImages);                               // ann.h BruteForce -> gallery rows
+    std::vector<int> rows = ann.recognize_batch(testImages);
+    print_vec("ann_rows", rows, true);
+    std::vector<int> raw;
+    for (const ImageInfo& t : testImages) raw.push_back(recognize_image_bf(dbImages, t));
+    print_vec("recognize_image_bf", raw, true);
+    const float d01 = testImages.empty() ? 0.f : testImages[0].distance(dbImages[0]);
+    const float d64 = testImages.empty() ? 0.f : testImages[0].distance(dbImages[0], 0, 64);
+    std::printf("\"dist_q0_g0\": %.9g, \"dist_q0_g0_64\": %.9g\n}\n", d01, d64);
+    fir::GalleryCache::clear();
+    return 0;
+}
