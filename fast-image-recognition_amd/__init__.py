@@ -8,6 +8,7 @@ The directory name is not an importable identifier; load it with
 ``__graft_entry__.load_package()`` (importlib by path) as ``fast_image_recognition_amd``.
 """
 from .capi import (  # noqa: F401
+    ClsModel,
     FirError,
     Gallery,
     METRIC_CHI2,

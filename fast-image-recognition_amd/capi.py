@@ -48,6 +48,11 @@ SYMBOLS = [
     ("fir_search_topk_keys_dev", C.c_int, [_vp, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp, _vp]),
     ("fir_range_distances", C.c_int, [_vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp]),
     ("fir_range_distances_dev", C.c_int, [_vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp]),
+    ("fir_cls_create", C.c_int, [_vp, C.c_int64, C.c_int32, _vp, C.c_int32, _vp, C.c_int32, C.POINTER(_vp)]),
+    ("fir_cls_destroy", C.c_int, [_vp]),
+    ("fir_cls_distance_sums", C.c_int, [_vp, _vp, C.c_int32, _vp]),
+    ("fir_cls_pnn_predict", C.c_int, [_vp, _vp, C.c_int32, C.c_double, _vp, _vp]),
+    ("fir_cls_knn_predict", C.c_int, [_vp, _vp, C.c_int32, C.c_int32, _vp]),
     ("fir_profile_enable", C.c_int, [_vp, C.c_int32]),
     ("fir_profile_read", C.c_int, [_vp, _vp, C.c_int32, _i32p, C.POINTER(C.c_double)]),
     ("fir_gallery_sync", C.c_int, [_vp]),
@@ -223,3 +228,58 @@ class Gallery:
 
     def sync(self):
         _check(lib().fir_gallery_sync(self._h))
+
+
+class ClsModel:
+    """Owns one fir_cls handle: the training set of the double-precision kNN / PNN classifiers
+    (qt_cpp/classification.cpp:116-226) in the reference's class-major scan order."""
+
+    def __init__(self, train_rows, train_class, num_classes, avg, device=0):
+        tr = np.ascontiguousarray(train_rows, dtype=np.float64)
+        tc = np.ascontiguousarray(train_class, dtype=np.int32)
+        av = np.ascontiguousarray(avg, dtype=np.float64)
+        self._h = _vp()
+        self.nt, self.d = tr.shape
+        self.num_classes = int(num_classes)
+        _check(lib().fir_cls_create(tr.ctypes.data_as(_vp), tr.shape[0], tr.shape[1], tc.ctypes.data_as(_vp), num_classes,
+                                    av.ctypes.data_as(_vp), device, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().fir_cls_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _q(self, queries):
+        q = np.ascontiguousarray(queries, dtype=np.float64).reshape(-1, self.d)
+        return q, q.ctypes.data_as(_vp)
+
+    def distance_sums(self, queries):
+        q, pq = self._q(queries)
+        out = np.empty((q.shape[0], self.nt), np.float64)
+        _check(lib().fir_cls_distance_sums(self._h, pq, q.shape[0], out.ctypes.data_as(_vp)))
+        return out
+
+    def pnn_predict(self, queries, var=0.0):
+        q, pq = self._q(queries)
+        scores = np.empty((q.shape[0], self.num_classes), np.float64)
+        best = np.empty(q.shape[0], np.int32)
+        _check(lib().fir_cls_pnn_predict(self._h, pq, q.shape[0], var, scores.ctypes.data_as(_vp), best.ctypes.data_as(_vp)))
+        return best, scores
+
+    def knn_predict(self, queries, k):
+        q, pq = self._q(queries)
+        best = np.empty(q.shape[0], np.int32)
+        _check(lib().fir_cls_knn_predict(self._h, pq, q.shape[0], k, best.ctypes.data_as(_vp)))
+        return best

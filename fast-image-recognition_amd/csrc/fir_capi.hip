@@ -363,6 +363,11 @@ int retile_slab(fir_gallery* g, const float* d_rows, int64_t slab_rows, int64_t 
 extern "C" {
 
 const char* fir_last_error(void) { return g_err; }
+// internal: lets the library's other translation units (fir_cls.hip) report through fir_last_error()
+void fir_set_last_error_(const char* msg) {
+    strncpy(g_err, msg ? msg : "", sizeof(g_err) - 1);
+    g_err[sizeof(g_err) - 1] = 0;
+}
 int fir_version(void) { return 100; }
 
 int fir_device_count(void) {

@@ -1,0 +1,407 @@
+// fir_cls.hip -- double-precision kNN / PNN classifiers of qt_cpp/classification.cpp on gfx950.
+//
+// Same design as the f32 matcher (fir_kernels.h): the training rows are re-tiled once into
+//   tile t (64 rows) x chunk c (2 features) x lane r  ->  double2 at gal2[(t*dp2 + c)*64 + r]
+// holding (g - avg) -- Classifier::normalize of the training side (classification.cpp:103-105,
+// 132) evaluated once instead of per query: same double subtraction, same bits. A wave owns a
+// tile, a lane owns a row and accumulates  diff = (g-avg) - (q-avg);  dist += diff*diff  in
+// feature order with un-fused mul/add (translation unit built -ffp-contract=off), i.e. the
+// reference's evaluation order (classification.cpp:123-141, 199-211): the distance sums are
+// bit-identical to the reference's doubles. exp() and the per-class sums of PNN are a parallel
+// reduction (device exp, different summation order): scores agree to ~1e-13 relative, the
+// arg-max class is what is compared.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <cfloat>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/fir_amd.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kTileRows = 64;
+constexpr int kQB = 4;       // queries per pass of the f64 scan
+constexpr int kKMax = 8;
+
+int cls_fail(int code, const char* fmt, ...);   // defined with the C ABI below
+
+typedef const double __attribute__((address_space(4)))* sdouble_p;
+
+// rows[slab][d] row-major -> tiled (g - avg). One thread per output double2.
+__global__ void __launch_bounds__(kBlock) k_cls_retile(const double* __restrict__ rows, int64_t slab_rows, int64_t row0, int64_t nt,
+                                                        int d, int dp2, const double* __restrict__ avg, double2* __restrict__ gal2) {
+    const int64_t o = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t slab_tiles = (slab_rows + kTileRows - 1) / kTileRows;
+    if (o >= slab_tiles * dp2 * 64) return;
+    const int r = (int)(o & 63);
+    const int64_t tc = o >> 6;
+    const int c = (int)(tc % dp2);
+    const int64_t tl = tc / dp2;
+    const int64_t lrow = tl * kTileRows + r, grow = row0 + lrow;
+    double v[2] = {0.0, 0.0};
+    if (lrow < slab_rows && grow < nt) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int k = c * 2 + j;
+            if (k < d) v[j] = rows[lrow * d + k] - avg[k];          // normalize(), classification.cpp:103-105
+        }
+    }
+    gal2[((row0 / kTileRows + tl) * dp2 + c) * 64 + r] = make_double2(v[0], v[1]);
+}
+
+// queries[nq][d] -> qn[k][QB] = q[k] - avg[k] (the query side of normalize(), :135), zero padded.
+__global__ void __launch_bounds__(kBlock) k_cls_prep_queries(const double* __restrict__ q, int nq, int d, int dp2,
+                                                              const double* __restrict__ avg, double* __restrict__ qn) {
+    const int kk = dp2 * 2;
+    const int64_t o = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (o >= (int64_t)kk * kQB) return;
+    const int qi = (int)(o % kQB);
+    const int k = (int)(o / kQB);
+    qn[o] = (qi < nq && k < d) ? q[(int64_t)qi * d + k] - avg[k] : 0.0;
+}
+
+// sums[q][row] = sum_k ((g-avg) - (q-avg))^2, sequential in k.
+__global__ void __launch_bounds__(kBlock) k_cls_scan(const double2* __restrict__ gal2, const double* __restrict__ qn, int64_t nt,
+                                                      int tiles, int dp2, int d, int waves, int nq, double* __restrict__ sums) {
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    sdouble_p qc = (sdouble_p)(uintptr_t)qn;
+    for (int t = gw; t < tiles; t += waves) {
+        const double2* p = gal2 + (size_t)t * dp2 * 64 + lane;
+        double acc[kQB];
+#pragma unroll
+        for (int q = 0; q < kQB; ++q) acc[q] = 0.0;
+        int c = 0;
+        for (; c + 4 <= dp2; c += 4) {
+            double2 g[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) g[u] = p[(size_t)(c + u) * 64];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double gv[2] = {g[u].x, g[u].y};
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int k = (c + u) * 2 + j;
+                    if (k < d) {
+#pragma unroll
+                        for (int q = 0; q < kQB; ++q) {
+                            const double diff = gv[j] - qc[k * kQB + q];       // :132-137
+                            acc[q] = acc[q] + diff * diff;                      // :141
+                        }
+                    }
+                }
+            }
+        }
+        for (; c < dp2; ++c) {
+            const double2 g = p[(size_t)c * 64];
+            const double gv[2] = {g.x, g.y};
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int k = c * 2 + j;
+                if (k < d) {
+#pragma unroll
+                    for (int q = 0; q < kQB; ++q) {
+                        const double diff = gv[j] - qc[k * kQB + q];
+                        acc[q] = acc[q] + diff * diff;
+                    }
+                }
+            }
+        }
+        const int64_t row = (int64_t)t * kTileRows + lane;
+        if (row < nt) {
+#pragma unroll
+            for (int q = 0; q < kQB; ++q)
+                if (q < nq) sums[(size_t)q * nt + row] = acc[q];
+        }
+    }
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// PNN class outputs, classification.cpp:195-216: scores[q][c] = sum_{t in class c} exp(-dist/(2 d var)) / nt.
+// grid (num_classes, qb), one wave per (class, query).
+__global__ void __launch_bounds__(64) k_cls_pnn(const double* __restrict__ sums, const int32_t* __restrict__ class_off, int64_t nt,
+                                                 int num_classes, double denom /* 2*d*var */, double* __restrict__ scores) {
+    const int c = blockIdx.x, q = blockIdx.y;
+    const double* s = sums + (size_t)q * nt;
+    double acc = 0.0;
+    for (int t = class_off[c] + threadIdx.x; t < class_off[c + 1]; t += 64) acc += exp(-s[t] / denom);
+    acc = wave_sum(acc);
+    if (threadIdx.x == 0) scores[(size_t)q * num_classes + c] = acc / (double)nt;
+}
+
+// kNN: the class that first collects k votes in the globally sorted order (classification.cpp:151-160)
+// is the class whose k-th nearest member is nearest. kth[q][c] = k-th smallest mean distance of
+// class c (+inf when the class has fewer than k rows). One wave per (class, query).
+__global__ void __launch_bounds__(64) k_cls_knn_kth(const double* __restrict__ sums, const int32_t* __restrict__ class_off, int64_t nt,
+                                                     int num_classes, int d, int k, double* __restrict__ kth) {
+    const int c = blockIdx.x, q = blockIdx.y;
+    const double* s = sums + (size_t)q * nt;
+    double best[kKMax];
+#pragma unroll
+    for (int i = 0; i < kKMax; ++i) best[i] = DBL_MAX;
+    for (int t = class_off[c] + threadIdx.x; t < class_off[c + 1]; t += 64) {
+        double v = s[t] / (double)d;                                              // :143
+#pragma unroll
+        for (int i = 0; i < kKMax; ++i) {
+            const bool sw = v < best[i];
+            const double tmp = best[i];
+            best[i] = sw ? v : tmp;
+            v = sw ? tmp : v;
+        }
+    }
+    // k rounds of wave-min with removal (each lane pops its own head when it wins; ties pop one lane)
+    double res = DBL_MAX;
+    for (int r = 0; r < k; ++r) {
+        double m = best[0];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const double o = __shfl_xor(m, off, 64);
+            m = o < m ? o : m;
+        }
+        res = m;
+        const unsigned long long who = __ballot(best[0] == m);
+        const int winner = __ffsll((long long)who) - 1;
+        if ((int)threadIdx.x == winner) {
+#pragma unroll
+            for (int i = 0; i + 1 < kKMax; ++i) best[i] = best[i + 1];
+            best[kKMax - 1] = DBL_MAX;
+        }
+    }
+    if (threadIdx.x == 0) kth[(size_t)q * num_classes + c] = (class_off[c + 1] - class_off[c] >= k) ? res : DBL_MAX;
+}
+
+// mode 0: PNN arg-max, first maximum from -DBL_MAX (classification.cpp:217-224).
+// mode 1: kNN arg-min of kth; when no class has k rows the reference's loop ends without a
+//         break and the arg-max of the vote counts = the largest class (first) wins (:161-168).
+__global__ void __launch_bounds__(64) k_cls_argbest(const double* __restrict__ v, const int32_t* __restrict__ class_off, int num_classes,
+                                                     int mode, int32_t* __restrict__ best_class) {
+    const int q = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    const double* s = v + (size_t)q * num_classes;
+    int best = -1;
+    if (mode == 0) {
+        double mx = -DBL_MAX;
+        for (int i = 0; i < num_classes; ++i)
+            if (mx < s[i]) { mx = s[i]; best = i; }
+    } else {
+        double mn = DBL_MAX;
+        for (int i = 0; i < num_classes; ++i)
+            if (s[i] < mn) { mn = s[i]; best = i; }
+        if (best < 0) {
+            int mc = -1;
+            for (int i = 0; i < num_classes; ++i) {
+                const int cnt = class_off[i + 1] - class_off[i];
+                if (cnt > mc) { mc = cnt; best = i; }
+            }
+        }
+    }
+    best_class[q] = best;
+}
+
+}  // namespace
+
+struct fir_cls {
+    int device = 0, cus = 0;
+    int64_t nt = 0;
+    int d = 0, dp2 = 0, num_classes = 0;
+    int64_t tiles = 0;
+    double2* gal2 = nullptr;
+    double* avg = nullptr;
+    int32_t* class_off = nullptr;
+    hipStream_t stream = nullptr;
+    double* dq = nullptr; size_t dq_cap = 0;
+    double* qn = nullptr;
+    double* sums = nullptr; size_t sums_cap = 0;
+    double* scores = nullptr; size_t scores_cap = 0;
+    int32_t* best = nullptr; size_t best_cap = 0;
+};
+
+extern "C" void fir_set_last_error_(const char* msg);   // fir_capi.hip: feeds fir_last_error()
+
+namespace {
+
+thread_local char g_cls_err[512];
+
+int cls_fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_cls_err, sizeof(g_cls_err), fmt, ap);
+    va_end(ap);
+    fir_set_last_error_(g_cls_err);
+    return code;
+}
+
+#define CLS_HIP(expr)                                                                                          \
+    do {                                                                                                       \
+        hipError_t e_ = (expr);                                                                                \
+        if (e_ != hipSuccess) return cls_fail(e_ == hipErrorOutOfMemory ? FIR_ERR_NOMEM : FIR_ERR_HIP,        \
+                                              "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+template <typename T>
+int cls_grow(T*& p, size_t& cap, size_t need) {
+    if (need <= cap) return FIR_OK;
+    if (p) CLS_HIP(hipFree(p));
+    p = nullptr; cap = 0;
+    CLS_HIP(hipMalloc((void**)&p, std::max<size_t>(need, 1024) * sizeof(T)));
+    cap = std::max<size_t>(need, 1024);
+    return FIR_OK;
+}
+
+// distance sums of all qb queries into c->sums (device), in passes of kQB queries
+int cls_scan(fir_cls* c, const double* queries, int32_t qb) {
+    int rc;
+    if ((rc = cls_grow(c->dq, c->dq_cap, (size_t)qb * c->d))) return rc;
+    if ((rc = cls_grow(c->sums, c->sums_cap, (size_t)qb * std::max<int64_t>(c->nt, 1)))) return rc;
+    CLS_HIP(hipMemcpyAsync(c->dq, queries, (size_t)qb * c->d * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    const int kk = c->dp2 * 2;
+    const int waves = (int)std::min<int64_t>(std::max<int64_t>((c->tiles + 3) / 4 * 4, 4), (int64_t)c->cus * 16);
+    for (int q0 = 0; q0 < qb; q0 += kQB) {
+        const int nq = std::min(kQB, qb - q0);
+        hipLaunchKernelGGL(k_cls_prep_queries, dim3((kk * kQB + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream,
+                           c->dq + (size_t)q0 * c->d, nq, c->d, c->dp2, c->avg, c->qn);
+        hipLaunchKernelGGL(k_cls_scan, dim3(waves / 4), dim3(kBlock), 0, c->stream, c->gal2, c->qn, c->nt, (int)c->tiles, c->dp2,
+                           c->d, waves, nq, c->sums + (size_t)q0 * c->nt);
+    }
+    CLS_HIP(hipGetLastError());
+    return FIR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fir_cls_create(const double* train_rows, int64_t nt, int32_t d, const int32_t* train_class, int32_t num_classes,
+                   const double* avg, int32_t device, fir_cls** out) {
+    if (!out) return cls_fail(FIR_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (nt < 0 || d <= 0 || num_classes <= 0 || !avg || (nt > 0 && (!train_rows || !train_class)))
+        return cls_fail(FIR_ERR_ARG, "bad arguments (nt=%lld d=%d classes=%d)", (long long)nt, d, num_classes);
+    if (nt >= ((int64_t)1 << 31) - 64) return cls_fail(FIR_ERR_ARG, "nt too large");
+    std::vector<int32_t> off((size_t)num_classes + 1, 0);
+    for (int64_t t = 0; t < nt; ++t) {
+        const int32_t cl = train_class[t];
+        if (cl < 0 || cl >= num_classes || (t > 0 && cl < train_class[t - 1]))
+            return cls_fail(FIR_ERR_ARG, "train_class must be non-decreasing in [0,%d) (row %lld)", num_classes, (long long)t);
+        off[(size_t)cl + 1]++;
+    }
+    for (int i = 0; i < num_classes; ++i) off[(size_t)i + 1] += off[(size_t)i];
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) return cls_fail(FIR_ERR_NODEVICE, "no HIP device visible");
+    if (device < 0 || device >= cnt) return cls_fail(FIR_ERR_NODEVICE, "device %d out of range (%d visible)", device, cnt);
+    CLS_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    CLS_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return cls_fail(FIR_ERR_NODEVICE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+    fir_cls* c = new (std::nothrow) fir_cls();
+    if (!c) return cls_fail(FIR_ERR_NOMEM, "host allocation failed");
+    c->device = device;
+    c->cus = prop.multiProcessorCount;
+    c->nt = nt;
+    c->d = d;
+    c->dp2 = (d + 1) / 2;
+    c->num_classes = num_classes;
+    c->tiles = (nt + kTileRows - 1) / kTileRows;
+    int rc = FIR_OK;
+    double* stage = nullptr;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    const size_t g2 = (size_t)std::max<int64_t>(c->tiles, 1) * c->dp2 * 64;
+    if (e == hipSuccess) e = hipMalloc((void**)&c->gal2, g2 * sizeof(double2));
+    if (e == hipSuccess) e = hipMalloc((void**)&c->avg, (size_t)d * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&c->qn, (size_t)c->dp2 * 2 * kQB * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&c->class_off, ((size_t)num_classes + 1) * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMemcpy(c->avg, avg, (size_t)d * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(c->class_off, off.data(), off.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+    const int64_t slab = std::max<int64_t>(kTileRows, ((int64_t)(256u << 20) / ((int64_t)d * 8)) / kTileRows * kTileRows);
+    if (e == hipSuccess && nt > 0) e = hipMalloc((void**)&stage, (size_t)std::min<int64_t>(slab, c->tiles * kTileRows) * d * sizeof(double));
+    for (int64_t r0 = 0; e == hipSuccess && r0 < nt; r0 += slab) {
+        const int64_t have = std::min<int64_t>(slab, nt - r0);
+        e = hipMemcpyAsync(stage, train_rows + r0 * d, (size_t)have * d * sizeof(double), hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) break;
+        const int64_t total = ((have + kTileRows - 1) / kTileRows) * c->dp2 * 64;
+        hipLaunchKernelGGL(k_cls_retile, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, stage, have, r0, nt, d,
+                           c->dp2, c->avg, c->gal2);
+        e = hipStreamSynchronize(c->stream);
+    }
+    if (stage) (void)hipFree(stage);
+    if (e != hipSuccess) rc = cls_fail(e == hipErrorOutOfMemory ? FIR_ERR_NOMEM : FIR_ERR_HIP, "training-set upload: %s", hipGetErrorString(e));
+    if (rc) { fir_cls_destroy(c); return rc; }
+    *out = c;
+    return FIR_OK;
+}
+
+int fir_cls_destroy(fir_cls* c) {
+    if (!c) return FIR_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(c->gal2); (void)hipFree(c->avg); (void)hipFree(c->class_off); (void)hipFree(c->dq); (void)hipFree(c->qn);
+    (void)hipFree(c->sums); (void)hipFree(c->scores); (void)hipFree(c->best);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return FIR_OK;
+}
+
+int fir_cls_distance_sums(fir_cls* c, const double* queries, int32_t qb, double* sums) {
+    if (!c || !sums || (qb > 0 && !queries)) return cls_fail(FIR_ERR_ARG, "NULL argument");
+    if (qb < 0) return cls_fail(FIR_ERR_ARG, "qb < 0");
+    if (qb == 0 || c->nt == 0) return FIR_OK;
+    CLS_HIP(hipSetDevice(c->device));
+    int rc = cls_scan(c, queries, qb);
+    if (rc) return rc;
+    CLS_HIP(hipMemcpyAsync(sums, c->sums, (size_t)qb * c->nt * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    CLS_HIP(hipStreamSynchronize(c->stream));
+    return FIR_OK;
+}
+
+int fir_cls_pnn_predict(fir_cls* c, const double* queries, int32_t qb, double var, double* scores, int32_t* best_class) {
+    if (!c || (qb > 0 && !queries)) return cls_fail(FIR_ERR_ARG, "NULL argument");
+    if (qb < 0) return cls_fail(FIR_ERR_ARG, "qb < 0");
+    if (qb == 0) return FIR_OK;
+    CLS_HIP(hipSetDevice(c->device));
+    if (var <= 0) { var = 0.00002; if (c->d > 2000) var /= 10; }                // classification.cpp:190-193
+    int rc = cls_scan(c, queries, qb);
+    if (rc) return rc;
+    if ((rc = cls_grow(c->scores, c->scores_cap, (size_t)qb * c->num_classes))) return rc;
+    if ((rc = cls_grow(c->best, c->best_cap, (size_t)qb))) return rc;
+    const double denom = (double)(2 * (size_t)c->d) * var;                       // 2*num_of_cont_features*var, :213
+    hipLaunchKernelGGL(k_cls_pnn, dim3(c->num_classes, qb), dim3(64), 0, c->stream, c->sums, c->class_off, c->nt, c->num_classes, denom, c->scores);
+    hipLaunchKernelGGL(k_cls_argbest, dim3(qb), dim3(64), 0, c->stream, c->scores, c->class_off, c->num_classes, 0, c->best);
+    CLS_HIP(hipGetLastError());
+    if (scores) CLS_HIP(hipMemcpyAsync(scores, c->scores, (size_t)qb * c->num_classes * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (best_class) CLS_HIP(hipMemcpyAsync(best_class, c->best, (size_t)qb * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    CLS_HIP(hipStreamSynchronize(c->stream));
+    return FIR_OK;
+}
+
+int fir_cls_knn_predict(fir_cls* c, const double* queries, int32_t qb, int32_t k, int32_t* best_class) {
+    if (!c || !best_class || (qb > 0 && !queries)) return cls_fail(FIR_ERR_ARG, "NULL argument");
+    if (qb < 0) return cls_fail(FIR_ERR_ARG, "qb < 0");
+    if (k < 1 || k > kKMax) return cls_fail(FIR_ERR_ARG, "k=%d outside [1,%d]", k, kKMax);
+    if (qb == 0) return FIR_OK;
+    CLS_HIP(hipSetDevice(c->device));
+    int rc = cls_scan(c, queries, qb);
+    if (rc) return rc;
+    if ((rc = cls_grow(c->scores, c->scores_cap, (size_t)qb * c->num_classes))) return rc;
+    if ((rc = cls_grow(c->best, c->best_cap, (size_t)qb))) return rc;
+    hipLaunchKernelGGL(k_cls_knn_kth, dim3(c->num_classes, qb), dim3(64), 0, c->stream, c->sums, c->class_off, c->nt, c->num_classes, c->d, k, c->scores);
+    hipLaunchKernelGGL(k_cls_argbest, dim3(qb), dim3(64), 0, c->stream, c->scores, c->class_off, c->num_classes, 1, c->best);
+    CLS_HIP(hipGetLastError());
+    CLS_HIP(hipMemcpyAsync(best_class, c->best, (size_t)qb * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    CLS_HIP(hipStreamSynchronize(c->stream));
+    return FIR_OK;
+}
+
+}  // extern "C"

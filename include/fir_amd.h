@@ -120,6 +120,27 @@ int fir_range_distances(fir_gallery* g, const float* queries, int32_t qb, int32_
 int fir_range_distances_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start_pos, int32_t end_pos,
                             float* d_out, void* stream);
 
+/* ---- double-precision classifiers (qt_cpp/classification.cpp) ---------------------------------
+ * The training set of KNNClassifier / PNNClassifier (classification.cpp:116-226): train_rows[nt][d]
+ * float64 in the reference's scan order -- class 0's training rows, then class 1's, ...
+ * (classification.cpp:121-122,195-198), train_class[nt] non-decreasing in [0, num_classes),
+ * avg[d] = avgValues (classification.cpp:984; Classifier::normalize subtracts it, :103-105).
+ * Rows are copied. */
+typedef struct fir_cls fir_cls;
+int fir_cls_create(const double* train_rows, int64_t nt, int32_t d, const int32_t* train_class, int32_t num_classes,
+                   const double* avg, int32_t device, fir_cls** out);
+int fir_cls_destroy(fir_cls* c);
+/* sums[qb][nt] <- sum_f ((g_f - avg_f) - (q_f - avg_f))^2 per training row, accumulated in feature
+ * order in double (classification.cpp:123-141 before the division, :199-211). */
+int fir_cls_distance_sums(fir_cls* c, const double* queries, int32_t qb, double* sums);
+/* PNNClassifier::predict_bf, classification.cpp:188-226. var <= 0 selects the reference's value
+ * (2e-5, divided by 10 when d > 2000, :190-193). scores[qb][num_classes] (may be NULL) <-
+ * sum_t exp(-dist / (2 d var)) / nt per class; best_class[qb] <- first maximum. */
+int fir_cls_pnn_predict(fir_cls* c, const double* queries, int32_t qb, double var, double* scores, int32_t* best_class);
+/* KNNClassifier::predict, classification.cpp:116-170: rows sorted by mean distance vote for their
+ * class until one class has k votes. 1 <= k <= 8. best_class[qb]. */
+int fir_cls_knn_predict(fir_cls* c, const double* queries, int32_t qb, int32_t k, int32_t* best_class);
+
 /* ---- profiling ------------------------------------------------------------------------------
  * When enabled, every gallery-scan kernel launch is bracketed by HIP events on the stream it
  * is launched on. fir_profile_read waits for them and returns the launch durations (ms) in

@@ -1,0 +1,74 @@
+"""GPU parity of the double-precision kNN / PNN path (qt_cpp/classification.cpp:116-226):
+distance sums bit-identical to the oracle; predicted classes identical to the oracle and to the
+REAL reference's predictions recorded in tests/golden; PNN class scores within 1e-12 relative."""
+import os
+
+import numpy as np
+import pytest
+
+import golden_cases as gc
+
+pytestmark = pytest.mark.gpu
+
+GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_outputs.npz"))
+
+
+def test_reference_predictions_reproduced(fir, oracle):
+    x, lab, ncls = gc.cls_case()
+    train, tcls, test = GOLD["cls/train"], GOLD["cls/train_class"], GOLD["cls/test"]
+    tr, avg = x[train], GOLD["cls/avg"]
+    q = x[test]
+    with fir.ClsModel(tr, tcls, ncls, avg, 0) as m:
+        sums = m.distance_sums(q)
+        knn1, knn3 = m.knn_predict(q, 1), m.knn_predict(q, 3)
+        pnn, scores = m.pnn_predict(q)
+    assert np.array_equal(knn1, GOLD["cls/knn1"])
+    assert np.array_equal(knn3, GOLD["cls/knn3"])
+    assert np.array_equal(pnn, GOLD["cls/pnn"])
+    d = tr.shape[1]
+    for i in (0, 7, len(test) - 1):
+        _, dist = oracle.knn_predict(tr, tcls, avg, ncls, q[i], 1)          # mean distances (sum / d)
+        assert np.array_equal((sums[i] / d).view(np.uint64), dist.view(np.uint64))
+        _, es = oracle.pnn_predict(tr, tcls, avg, ncls, q[i])
+        np.testing.assert_allclose(scores[i], es, rtol=1e-12, atol=0)
+
+
+@pytest.mark.parametrize("seed,n,d,ncls,frac", [(3, 500, 64, 10, 0.5), (4, 1200, 257, 25, 0.4), (5, 200, 3, 4, 0.7), (6, 130, 2100, 5, 0.5)])
+def test_matches_oracle_on_fresh_data(fir, oracle, seed, n, d, ncls, frac):
+    x, lab, _ = gc.cls_case(seed=seed, n=n, d=d, n_classes=ncls)
+    rng = np.random.default_rng(seed)
+    is_train = rng.random(n) < frac
+    order = np.argsort(lab[is_train], kind="stable")
+    tr, tcls = x[is_train][order], lab[is_train][order]
+    q = x[~is_train][:23]
+    _, _, avg, _ = oracle.train_stats(tr)
+    with fir.ClsModel(tr, tcls, ncls, avg, 0) as m:
+        sums = m.distance_sums(q)
+        knn = {k: m.knn_predict(q, k) for k in (1, 3, 5)}
+        pnn, scores = m.pnn_predict(q)
+    for i in range(q.shape[0]):
+        e1, dist = oracle.knn_predict(tr, tcls, avg, ncls, q[i], 1)
+        assert np.array_equal((sums[i] / d).view(np.uint64), dist.view(np.uint64))
+        assert knn[1][i] == e1
+        assert knn[3][i] == oracle.knn_predict(tr, tcls, avg, ncls, q[i], 3)[0]
+        assert knn[5][i] == oracle.knn_predict(tr, tcls, avg, ncls, q[i], 5)[0]
+        ep, es = oracle.pnn_predict(tr, tcls, avg, ncls, q[i])       # d > 2000 exercises var/10 (classification.cpp:192-193)
+        np.testing.assert_allclose(scores[i], es, rtol=1e-12, atol=1e-300)
+        if np.sort(es)[-1] > 0 and np.sort(es)[-1] > np.sort(es)[-2] * (1 + 1e-9):
+            assert pnn[i] == ep
+
+
+def test_classes_smaller_than_k_and_bad_arguments(fir, oracle):
+    x, lab, ncls = gc.cls_case(seed=9, n=40, d=16, n_classes=8)        # 5 rows per class, k = 8 never reached
+    order = np.argsort(lab, kind="stable")
+    tr, tcls = x[order][:-3], lab[order][:-3]                          # last class has 2 rows
+    _, _, avg, _ = oracle.train_stats(tr)
+    q = x[:6]
+    with fir.ClsModel(tr, tcls, ncls, avg, 0) as m:
+        got = m.knn_predict(q, 8)
+        for i in range(6):
+            assert got[i] == oracle.knn_predict(tr, tcls, avg, ncls, q[i], 8)[0]
+        with pytest.raises(fir.FirError):
+            m.knn_predict(q, 9)
+    with pytest.raises(fir.FirError):
+        fir.ClsModel(tr, tcls[::-1].copy(), ncls, avg, 0)               # classes must be non-decreasing
