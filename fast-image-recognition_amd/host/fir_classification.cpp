@@ -1,0 +1,176 @@
+// fir_classification.cpp -- see fir_classification.h. Dataset IO / split bookkeeping on the host,
+// every distance, exp and vote on the GPU (fir_cls_*).
+#include "fir_classification.h"
+
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <map>
+#include <sstream>
+
+namespace fir {
+namespace {
+ClassificationState g_state;
+int g_cls_device = 0;
+}  // namespace
+ClassificationState& classification_state() { return g_state; }
+int classification_device() { return g_cls_device; }
+void set_classification_device(int device) { g_cls_device = device; }
+}  // namespace fir
+
+using fir::classification_state;
+
+void load_image_dataset(const std::string& features_file, int features_count) {
+    fir::ClassificationState& st = classification_state();
+    st.dataset.clear(); st.tmp_dataset.clear(); st.indices.clear(); st.training_set.clear(); st.test_set.clear();
+    st.num_of_cont_features = (size_t)features_count;
+    st.num_of_classes = 0;
+    std::ifstream in(features_file);
+    if (!in) return;
+    std::map<std::string, int> class_id;                                   // classification.cpp:803
+    std::string path_line, class_line, feat_line;
+    while (std::getline(in, path_line) && std::getline(in, class_line) && std::getline(in, feat_line)) {
+        class_line.erase(0, class_line.find_first_not_of(" \t\n\r\f\v"));
+        if (class_line.find("BACKGROUND_Google") != std::string::npos || class_line.find("257.clutter") != std::string::npos)
+            continue;                                                      // :813-817
+        auto it = class_id.find(class_line);
+        if (it == class_id.end()) it = class_id.emplace(class_line, (int)class_id.size()).first;
+        std::vector<FEATURE_TYPE> f((size_t)features_count);
+        const char* p = feat_line.c_str();
+        FEATURE_TYPE norm = 0;
+        for (int i = 0; i < features_count; ++i) {
+            char* end = nullptr;
+            double v = std::strtod(p, &end);
+            if (end == p) v = 0; else p = end;
+            norm += v * v;                                                 // :833
+            f[(size_t)i] = v;
+        }
+        norm = std::sqrt(norm);                                            // :842
+        for (double& v : f) v /= norm;                                     // :845-847
+        st.dataset.push_back(Feature_vector(f, it->second));
+    }
+    st.num_of_classes = class_id.size();
+    st.indices.assign(st.num_of_classes, std::vector<size_t>());
+    for (size_t i = 0; i < st.dataset.size(); ++i) st.indices[(size_t)st.dataset[i].output].push_back(i);
+    st.num_of_cont_features_orig = st.num_of_cont_features;               // classification.cpp:995
+}
+
+void split_train_test(double fraction, bool shuffle) {
+    fir::ClassificationState& st = classification_state();
+    const size_t C = st.num_of_classes, D = st.num_of_cont_features_orig;
+    st.training_set.assign(C, std::vector<size_t>());
+    st.test_set.clear();
+    for (size_t c = 0; c < C; ++c) {
+        std::vector<size_t>& idx = st.indices[c];
+        if (shuffle)                                                       // std::random_shuffle, :952
+            for (size_t i = 1; i < idx.size(); ++i) { const size_t j = (size_t)std::rand() % (i + 1); if (i != j) std::swap(idx[i], idx[j]); }
+        int end = fraction >= 1 ? (int)fraction : (int)std::ceil(fraction * idx.size());   // :953
+        if (end == 0 && !idx.empty()) end = 1;
+        else if (end >= (int)idx.size()) end = (int)idx.size();
+        st.training_set[c].assign(idx.begin(), idx.begin() + end);
+        st.test_set.insert(st.test_set.end(), idx.begin() + end, idx.end());
+    }
+    st.tmp_dataset = st.dataset;
+    st.num_of_cont_features = D;
+    st.minValues.assign(D, 0); st.maxValues.assign(D, 0); st.avgValues.assign(D, 0); st.stdValues.assign(D, 0);
+    for (size_t f = 0; f < D; ++f) {                                       // :969-989
+        double mn = FLT_MAX, mx = -FLT_MAX, sum = 0, sq = 0;
+        int count = 0;
+        for (size_t c = 0; c < C; ++c)
+            for (size_t t : st.training_set[c]) {
+                const double v = st.dataset[t].features[f];
+                ++count;
+                if (v < mn) mn = v;
+                if (mx < v) mx = v;
+                sum += v;
+                sq += v * v;
+            }
+        st.minValues[f] = mn; st.maxValues[f] = mx;
+        st.avgValues[f] = sum / count;
+        st.stdValues[f] = std::sqrt((sq - st.avgValues[f] * st.avgValues[f] * count) / (count - 1));
+    }
+    ++st.split_serial;
+}
+
+fir_cls* Classifier::device_model() {
+    fir::ClassificationState& st = classification_state();
+    if (st.model && st.model_serial == st.split_serial) return st.model;
+    if (st.model) { fir_cls_destroy(st.model); st.model = nullptr; }
+    const size_t D = st.num_of_cont_features;
+    std::vector<double> rows;
+    std::vector<int32_t> cls;
+    for (size_t c = 0; c < st.num_of_classes; ++c)
+        for (size_t t : st.training_set[c]) {                              // the reference's scan order, :121-122
+            const std::vector<double>& f = st.tmp_dataset[t].features;
+            rows.insert(rows.end(), f.begin(), f.begin() + D);
+            cls.push_back((int32_t)c);
+        }
+    if (fir_cls_create(rows.data(), (int64_t)cls.size(), (int32_t)D, cls.data(), (int32_t)st.num_of_classes, st.avgValues.data(),
+                       fir::classification_device(), &st.model) != FIR_OK) {
+        std::fprintf(stderr, "fir: training-set upload: %s\n", fir_last_error());
+        st.model = nullptr;
+    }
+    st.model_serial = st.split_serial;
+    return st.model;
+}
+
+std::vector<int> Classifier::predict_batch(const std::vector<const Feature_vector*>& inputs) {
+    std::vector<int> out;
+    for (const Feature_vector* fv : inputs) out.push_back(predict(*fv));
+    return out;
+}
+
+namespace {
+std::vector<double> pack(const std::vector<const Feature_vector*>& inputs, size_t D) {
+    std::vector<double> q(inputs.size() * D);
+    for (size_t i = 0; i < inputs.size(); ++i)
+        for (size_t f = 0; f < D; ++f) q[i * D + f] = inputs[i]->features[f];
+    return q;
+}
+template <typename T>
+std::string named(const std::string& prefix, T param) {                    // classification.cpp:97-102
+    std::ostringstream os;
+    os << prefix << ", " << param;
+    return os.str();
+}
+}  // namespace
+
+KNNClassifier::KNNClassifier(int k) : Classifier(named("k-NN", k)), K(k) {}
+
+std::vector<int> KNNClassifier::predict_batch(const std::vector<const Feature_vector*>& inputs) {
+    std::vector<int> out(inputs.size(), -1);
+    fir_cls* m = device_model();
+    if (!m || inputs.empty()) return out;
+    std::vector<double> q = pack(inputs, classification_state().num_of_cont_features);
+    std::vector<int32_t> best(inputs.size());
+    if (fir_cls_knn_predict(m, q.data(), (int32_t)inputs.size(), K, best.data()) != FIR_OK) {
+        std::fprintf(stderr, "fir: knn_predict: %s\n", fir_last_error());
+        return out;
+    }
+    out.assign(best.begin(), best.end());
+    return out;
+}
+int KNNClassifier::predict(const Feature_vector& inputFeatures) {
+    return predict_batch(std::vector<const Feature_vector*>(1, &inputFeatures))[0];
+}
+
+PNNClassifier::PNNClassifier(bool bf, std::string name) : Classifier(name + (bf ? "" : " (seq)")), bruteforce(bf) {}
+
+std::vector<int> PNNClassifier::predict_batch(const std::vector<const Feature_vector*>& inputs) {
+    std::vector<int> out(inputs.size(), -1);
+    fir_cls* m = device_model();
+    if (!m || inputs.empty()) return out;
+    std::vector<double> q = pack(inputs, classification_state().num_of_cont_features);
+    std::vector<int32_t> best(inputs.size());
+    if (fir_cls_pnn_predict(m, q.data(), (int32_t)inputs.size(), /*reference var*/ 0.0, nullptr, best.data()) != FIR_OK) {
+        std::fprintf(stderr, "fir: pnn_predict: %s\n", fir_last_error());
+        return out;
+    }
+    out.assign(best.begin(), best.end());
+    return out;
+}
+int PNNClassifier::predict(const Feature_vector& inputFeatures) {
+    return predict_batch(std::vector<const Feature_vector*>(1, &inputFeatures))[0];
+}

@@ -53,3 +53,35 @@ def test_host_shim_matches_oracle_end_to_end(tmp_path, oracle):
     assert np.float32(got["dist_q0_g0_64"]) == oracle.feature_distance(q[0], gal[0], 0, 64, 0)
     acc = np.mean(np.array(got["bf_1536_batch"]) == np.array(got["query_class"]))
     assert acc > 0.9
+
+
+def test_classification_shim_matches_oracle_end_to_end(tmp_path, oracle):
+    """classification.cpp-side API (load_image_dataset, split_train_test, KNNClassifier, PNNClassifier)."""
+    import golden_cases as gc
+
+    cls_driver = os.path.join(ROOT, "fast-image-recognition_amd", "host", "cls_driver")
+    d, ncls = 96, 7
+    x, lab, _ = gc.cls_case(seed=23, n=210, d=d, n_classes=ncls)
+    names = [f"/data/c{int(c)}/i{i}.jpg" for i, c in enumerate(lab)]
+    classes = [f"class_{int(c)}" for c in lab]
+    path = str(tmp_path / "features.txt")
+    synth.write_feature_file(path, names, classes, x.astype(np.float32))
+    out = subprocess.run([cls_driver, path, str(d), "12"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    got = json.loads(out.stdout)
+
+    rows, labels, nc = oracle.load_dataset_f64(path, d)
+    assert (got["classes"], got["features"], got["rows"]) == (nc, d, rows.shape[0]) == (ncls, d, 210)
+    train = np.concatenate([np.nonzero(labels == c)[0][:12] for c in range(nc)])      # fraction >= 1: that many per class (:953)
+    test = np.concatenate([np.nonzero(labels == c)[0][12:] for c in range(nc)])
+    assert got["train_rows"] == list(train) and got["test_rows"] == list(test)
+    tr, tcls = rows[train], labels[train]
+    _, _, avg, _ = oracle.train_stats(tr)
+    assert got["avg0"] == avg[0]
+    e1 = [oracle.knn_predict(tr, tcls, avg, nc, rows[r], 1)[0] for r in test]
+    e3 = [oracle.knn_predict(tr, tcls, avg, nc, rows[r], 3)[0] for r in test]
+    ep = [oracle.pnn_predict(tr, tcls, avg, nc, rows[r])[0] for r in test]
+    assert got["knn1_single"] == e1 and got["knn1_batch"] == e1 and got["knn1_name"] == "k-NN, 1"
+    assert got["knn3_single"] == e3 and got["knn3_batch"] == e3
+    assert got["pnn_single"] == ep and got["pnn_batch"] == ep and got["pnn_name"] == "PNN"
+    assert np.mean(np.array(e1) == np.array(got["truth"])) > 0.5
