@@ -48,6 +48,8 @@ SYMBOLS = [
     ("fir_search_topk_keys_dev", C.c_int, [_vp, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp, _vp]),
     ("fir_range_distances", C.c_int, [_vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp]),
     ("fir_range_distances_dev", C.c_int, [_vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp]),
+    ("fir_twd_conventional", C.c_int, [_vp, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_int32, _vp, _vp]),
+    ("fir_twd_proposed", C.c_int, [_vp, _vp, C.c_int32, C.c_int32, C.c_double, _vp, _vp, _vp]),
     ("fir_cls_create", C.c_int, [_vp, C.c_int64, C.c_int32, _vp, C.c_int32, _vp, C.c_int32, C.POINTER(_vp)]),
     ("fir_cls_destroy", C.c_int, [_vp]),
     ("fir_cls_distance_sums", C.c_int, [_vp, _vp, C.c_int32, _vp]),
@@ -209,6 +211,25 @@ class Gallery:
 
     def range_distances_dev(self, q_ptr, qb, out_ptr, start=0, end=0, stream=None):
         _check(lib().fir_range_distances_dev(self._h, _vp(q_ptr), qb, start, end, _vp(out_ptr), _vp(stream) if stream else None))
+
+    def twd_conventional(self, queries, num_classes, typ, threshold, reduced_features_count=64):
+        q, pq = _f32(queries)
+        q = q.reshape(-1, self.d)
+        cls = np.empty(q.shape[0], np.int32)
+        unrel = np.empty(q.shape[0], np.int32)
+        _check(lib().fir_twd_conventional(self._h, pq, q.shape[0], num_classes, typ, threshold, reduced_features_count,
+                                          cls.ctypes.data_as(_vp), unrel.ctypes.data_as(_vp)))
+        return cls, unrel
+
+    def twd_proposed(self, queries, reduced_features_count, threshold):
+        q, pq = _f32(queries)
+        q = q.reshape(-1, self.d)
+        cls = np.empty(q.shape[0], np.int32)
+        unrel = np.empty(q.shape[0], np.int32)
+        chunks = np.empty(q.shape[0], np.int32)
+        _check(lib().fir_twd_proposed(self._h, pq, q.shape[0], reduced_features_count, threshold, cls.ctypes.data_as(_vp),
+                                      unrel.ctypes.data_as(_vp), chunks.ctypes.data_as(_vp)))
+        return cls, unrel, chunks
 
     def classes_of(self, idx):
         idx = np.ascontiguousarray(idx, dtype=np.int32)

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/fir_amd.h"
+#include "fir_internal.h"
 
 using namespace fir;
 
@@ -363,6 +364,12 @@ int retile_slab(fir_gallery* g, const float* d_rows, int64_t slab_rows, int64_t 
 extern "C" {
 
 const char* fir_last_error(void) { return g_err; }
+int fir_gallery_view_(fir_gallery* g, fir_gallery_view* out) {
+    if (!g || !out) return FIR_ERR_ARG;
+    out->device = g->device; out->cus = g->cus; out->n = g->n; out->d = g->d; out->row_offset = g->row_offset;
+    out->cls = g->cls; out->stream = g->stream;
+    return FIR_OK;
+}
 // internal: lets the library's other translation units (fir_cls.hip) report through fir_last_error()
 void fir_set_last_error_(const char* msg) {
     strncpy(g_err, msg ? msg : "", sizeof(g_err) - 1);

@@ -120,6 +120,21 @@ int fir_range_distances(fir_gallery* g, const float* queries, int32_t qb, int32_
 int fir_range_distances_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start_pos, int32_t end_pos,
                             float* d_out, void* stream);
 
+/* ---- three-way-decision classifiers -----------------------------------------------------------
+ * ConventionalTWDClassifier::recognize, ImageTesting.cpp:108-186. type 0 = Posteriors
+ * (exp(-100 d) per class, best / sum of the 5 largest class posteriors > threshold, :118-122,141-149),
+ * 1 = DistDiff (:157-159), 2 = DistRatio (:160-162). First stage over features
+ * [0, reduced_features_count); unreliable queries get the second stage over [.., 256) (:165-180).
+ * The gallery needs class labels and d >= 256. class_out[qb] <- class id or -1,
+ * unreliable_out[qb] (may be NULL) <- 1 when the second stage ran (num_of_unreliable, :167). */
+int fir_twd_conventional(fir_gallery* g, const float* queries, int32_t qb, int32_t num_classes, int32_t type,
+                         double threshold, int32_t reduced_features_count, int32_t* class_out, int32_t* unreliable_out);
+/* ProposedTWDClassifier::recognize, ImageTesting.cpp:207-288 (CHECK_ALL_INSTANCES build):
+ * chunks of reduced_features_count features up to 256, running per-row sums, rows further than
+ * best * (1 / threshold) dropped, stop when one class is left. chunks_out (may be NULL) <- chunks used. */
+int fir_twd_proposed(fir_gallery* g, const float* queries, int32_t qb, int32_t reduced_features_count, double threshold,
+                     int32_t* class_out, int32_t* unreliable_out, int32_t* chunks_out);
+
 /* ---- double-precision classifiers (qt_cpp/classification.cpp) ---------------------------------
  * The training set of KNNClassifier / PNNClassifier (classification.cpp:116-226): train_rows[nt][d]
  * float64 in the reference's scan order -- class 0's training rows, then class 1's, ...
