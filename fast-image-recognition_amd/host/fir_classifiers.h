@@ -63,6 +63,56 @@ private:
     int max_features;
 };
 
+// ---- ImageTesting.cpp:33: how many queries needed the second stage / a second chunk ----
+namespace fir {
+int& num_of_unreliable();
+fir_gallery* twd_gallery(const std::vector<ImageInfo>& dbImages);   // the 256-feature upload the TWD classifiers scan
+}  // namespace fir
+
+// ---- ImageTesting.cpp:74-186 ----
+class ConventionalTWDClassifier : public Classifier {
+public:
+    enum class TWD_Type { Posteriors, DistDiff, DistRatio };
+    ConventionalTWDClassifier(int cls_num, TWD_Type t, double th, int feat_count = 64)
+        : Classifier(build_name(t, th)), num_of_classes(cls_num), reduced_features_count(feat_count), threshold(th), type(t) {}
+    int recognize(ImageInfo& testImageInfo) override {
+        return recognize_batch(std::vector<ImageInfo>(1, testImageInfo))[0];
+    }
+    std::vector<int> recognize_batch(const std::vector<ImageInfo>& tests) override;
+
+private:
+    int num_of_classes;
+    int reduced_features_count;
+    double threshold;
+    TWD_Type type;
+    static std::string build_name(TWD_Type type, double threshold) {   // ImageTesting.cpp:91-106
+        const char* prefix = type == TWD_Type::Posteriors ? "TWD posteriors" : type == TWD_Type::DistDiff ? "TWD diff" : "TWD ratio";
+        std::ostringstream os;
+        os << prefix << ", " << threshold;
+        return os.str();
+    }
+};
+
+// ---- ImageTesting.cpp:188-288 ----
+class ProposedTWDClassifier : public Classifier {
+public:
+    ProposedTWDClassifier(int cls_num, int feat_count, double th)
+        : Classifier(build_name(feat_count, th)), num_of_classes(cls_num), reduced_features_count(feat_count), th_(th) {}
+    int recognize(ImageInfo& testImageInfo) override {
+        return recognize_batch(std::vector<ImageInfo>(1, testImageInfo))[0];
+    }
+    std::vector<int> recognize_batch(const std::vector<ImageInfo>& tests) override;
+
+private:
+    int num_of_classes, reduced_features_count;
+    double th_;
+    static std::string build_name(int feat_count, double threshold) {  // ImageTesting.cpp:199-203
+        std::ostringstream os;
+        os << "Proposed TWD, " << feat_count << ", " << threshold;
+        return os.str();
+    }
+};
+
 // ---- ann.h:9-39 ----
 class ClassificationMethod {
 public:

@@ -43,6 +43,29 @@ int main(int argc, char** argv) {
         print_vec(key, batch, true);
         std::printf("\"bf_%d_name\": \"%s\",\n", maxf, bf.get_name().c_str());
     }
+    {   // the TWD classifiers of testRecognition (ImageTesting.cpp:530-535), batched and one at a time
+        const int C = (int)total.size();
+        ConventionalTWDClassifier post(C, ConventionalTWDClassifier::TWD_Type::Posteriors, 0.24);
+        ConventionalTWDClassifier diff(C, ConventionalTWDClassifier::TWD_Type::DistDiff, 0.003);
+        ConventionalTWDClassifier ratio(C, ConventionalTWDClassifier::TWD_Type::DistRatio, 0.7);
+        ProposedTWDClassifier p32(C, 32, 0.7), p64(C, 64, 0.7);
+        Classifier* twd[5] = {&post, &diff, &ratio, &p32, &p64};
+        const char* keys[5] = {"twd_post", "twd_diff", "twd_ratio", "twd_p32", "twd_p64"};
+        for (int i = 0; i < 5; ++i) {
+            twd[i]->train(&dbImages);
+            fir::num_of_unreliable() = 0;
+            std::vector<int> b = twd[i]->recognize_batch(testImages);
+            const int unrel = fir::num_of_unreliable();
+            std::vector<int> one;
+            for (size_t k = 0; k < testImages.size() && k < 6; ++k) { ImageInfo t = testImages[k]; one.push_back(twd[i]->recognize(t)); }
+            char key[64];
+            std::snprintf(key, sizeof key, "%s_batch", keys[i]);
+            print_vec(key, b, true);
+            std::snprintf(key, sizeof key, "%s_first6", keys[i]);
+            print_vec(key, one, true);
+            std::printf("\"%s_unreliable\": %d, \"%s_name\": \"%s\",\n", keys[i], unrel, keys[i], twd[i]->get_name().c_str());
+        }
+    }
     BruteForce ann(dbImages);                               // ann.h BruteForce -> gallery rows
     std::vector<int> rows = ann.recognize_batch(testImages);
     print_vec("ann_rows", rows, true);

@@ -53,6 +53,18 @@ def test_host_shim_matches_oracle_end_to_end(tmp_path, oracle):
     assert np.float32(got["dist_q0_g0_64"]) == oracle.feature_distance(q[0], gal[0], 0, 64, 0)
     acc = np.mean(np.array(got["bf_1536_batch"]) == np.array(got["query_class"]))
     assert acc > 0.9
+    # the TWD classifiers of testRecognition (ImageTesting.cpp:530-535)
+    ncls = len(counts)
+    for key, fn in (("twd_post", lambda qi: oracle.twd_conventional(gal, dbc, qi, ncls, 0, 0.24, 64)),
+                    ("twd_diff", lambda qi: oracle.twd_conventional(gal, dbc, qi, ncls, 1, 0.003, 64)),
+                    ("twd_ratio", lambda qi: oracle.twd_conventional(gal, dbc, qi, ncls, 2, 0.7, 64)),
+                    ("twd_p32", lambda qi: oracle.twd_proposed(gal, dbc, qi, 32, 0.7)[:2]),
+                    ("twd_p64", lambda qi: oracle.twd_proposed(gal, dbc, qi, 64, 0.7)[:2])):
+        exp = [fn(qi) for qi in q]
+        assert got[key + "_batch"] == [e[0] for e in exp], key
+        assert got[key + "_first6"] == [e[0] for e in exp][:6], key
+        assert got[key + "_unreliable"] == sum(e[1] for e in exp), key
+    assert got["twd_post_name"] == "TWD posteriors, 0.24" and got["twd_p32_name"] == "Proposed TWD, 32, 0.7"
 
 
 def test_classification_shim_matches_oracle_end_to_end(tmp_path, oracle):
