@@ -54,6 +54,7 @@ SYMBOLS = [
     ("fir_cls_destroy", C.c_int, [_vp]),
     ("fir_cls_distance_sums", C.c_int, [_vp, _vp, C.c_int32, _vp]),
     ("fir_cls_pnn_predict", C.c_int, [_vp, _vp, C.c_int32, C.c_double, _vp, _vp]),
+    ("fir_cls_pnn_predict_seq", C.c_int, [_vp, _vp, C.c_int32, C.c_double, _vp, _vp]),
     ("fir_cls_knn_predict", C.c_int, [_vp, _vp, C.c_int32, C.c_int32, _vp]),
     ("fir_profile_enable", C.c_int, [_vp, C.c_int32]),
     ("fir_profile_read", C.c_int, [_vp, _vp, C.c_int32, _i32p, C.POINTER(C.c_double)]),
@@ -298,6 +299,13 @@ class ClsModel:
         best = np.empty(q.shape[0], np.int32)
         _check(lib().fir_cls_pnn_predict(self._h, pq, q.shape[0], var, scores.ctypes.data_as(_vp), best.ctypes.data_as(_vp)))
         return best, scores
+
+    def pnn_predict_seq(self, queries, var=0.0):
+        q, pq = self._q(queries)
+        best = np.empty(q.shape[0], np.int32)
+        chunks = np.empty(q.shape[0], np.int32)
+        _check(lib().fir_cls_pnn_predict_seq(self._h, pq, q.shape[0], var, best.ctypes.data_as(_vp), chunks.ctypes.data_as(_vp)))
+        return best, chunks
 
     def knn_predict(self, queries, k):
         q, pq = self._q(queries)

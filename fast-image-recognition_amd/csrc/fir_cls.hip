@@ -68,8 +68,10 @@ __global__ void __launch_bounds__(kBlock) k_cls_prep_queries(const double* __res
 }
 
 // sums[q][row] = sum_k ((g-avg) - (q-avg))^2, sequential in k.
+// c0, c1: double2-chunk range [c0, c1) of the features to sum (whole scan: 0, dp2).
 __global__ void __launch_bounds__(kBlock) k_cls_scan(const double2* __restrict__ gal2, const double* __restrict__ qn, int64_t nt,
-                                                      int tiles, int dp2, int d, int waves, int nq, double* __restrict__ sums) {
+                                                      int tiles, int dp2, int d, int waves, int nq, int c0, int c1,
+                                                      double* __restrict__ sums) {
     const int lane = threadIdx.x & 63;
     const int gw = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     sdouble_p qc = (sdouble_p)(uintptr_t)qn;
@@ -78,8 +80,8 @@ __global__ void __launch_bounds__(kBlock) k_cls_scan(const double2* __restrict__
         double acc[kQB];
 #pragma unroll
         for (int q = 0; q < kQB; ++q) acc[q] = 0.0;
-        int c = 0;
-        for (; c + 4 <= dp2; c += 4) {
+        int c = c0;
+        for (; c + 4 <= c1; c += 4) {
             double2 g[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) g[u] = p[(size_t)(c + u) * 64];
@@ -99,7 +101,7 @@ __global__ void __launch_bounds__(kBlock) k_cls_scan(const double2* __restrict__
                 }
             }
         }
-        for (; c < dp2; ++c) {
+        for (; c < c1; ++c) {
             const double2 g = p[(size_t)c * 64];
             const double gv[2] = {g.x, g.y};
 #pragma unroll
@@ -180,6 +182,62 @@ __global__ void __launch_bounds__(64) k_cls_knn_kth(const double* __restrict__ s
         }
     }
     if (threadIdx.x == 0) kth[(size_t)q * num_classes + c] = (class_off[c + 1] - class_off[c] >= k) ? res : DBL_MAX;
+}
+
+// PNNClassifier::predict_sequentional, classification.cpp:228-295. cs[chunk][q][nt]: per-row sums of
+// 32-feature chunk `chunk`; dist[q][nt] workspace. One workgroup per query; wave w owns classes
+// w, w+4, ... (rows of a class are contiguous), so every class output is summed in a fixed order.
+// Dynamic LDS: num_classes doubles (outputs) + num_classes ints (classes_to_check).
+__global__ void __launch_bounds__(kBlock) k_cls_pnn_seq(const double* __restrict__ cs, int nq, int nchunks, double* __restrict__ dist,
+                                                         const int32_t* __restrict__ class_off, int64_t nt, int num_classes, int d,
+                                                         double var, int32_t* __restrict__ best_class, int32_t* __restrict__ chunks_out) {
+    extern __shared__ __attribute__((aligned(16))) double outputs[];
+    int* checked = (int*)(outputs + num_classes);
+    __shared__ int best_s, stop_s;
+    const int q = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double* dq = dist + (size_t)q * nt;
+    for (int64_t t = threadIdx.x; t < nt; t += kBlock) dq[t] = 0.0;                 // distances[i][t] = 0 (:238-241)
+    for (int c = threadIdx.x; c < num_classes; c += kBlock) { checked[c] = 1; outputs[c] = 0.0; }
+    if (threadIdx.x == 0) { best_s = -1; stop_s = 0; }
+    __syncthreads();
+    const double den = (double)nt;                                                  // total_training_size (:244)
+    int used = 0;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        ++used;
+        int max_fi = (ch + 1) * 32;                                                 // delta_features_count = 32 (:182,247-249)
+        if (max_fi > d) max_fi = d;
+        const double* csq = cs + ((size_t)ch * nq + q) * nt;
+        for (int c = wave; c < num_classes; c += kBlock / 64) {
+            if (!checked[c]) continue;                                              // :251
+            double acc = 0.0;
+            for (int t = class_off[c] + lane; t < class_off[c + 1]; t += 64) {
+                const double v = dq[t] + csq[t];                                    // distances[i][t] += diff*diff ... (:264)
+                dq[t] = v;
+                acc += exp(-v / (2 * var * max_fi));                                // :266
+            }
+            acc = wave_sum(acc);
+            if (lane == 0) outputs[c] = acc / den;                                  // :268
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double max_output = -DBL_MAX;
+            int best = best_s;
+            for (int i = 0; i < num_classes; ++i)
+                if (checked[i] && max_output < outputs[i]) { max_output = outputs[i]; best = i; }   // :272-279
+            best_s = best;
+            const float output_threshold = (float)(max_output / 1000000000);        // output_dividor = 1E9 (:186,282)
+            int variants = 0;
+            for (int i = 0; i < num_classes; ++i)
+                if (checked[i]) {
+                    if (outputs[i] < output_threshold) checked[i] = 0;              // :285-286
+                    else ++variants;
+                }
+            stop_s = variants == 1;                                                 // :291
+        }
+        __syncthreads();
+        if (stop_s) break;
+    }
+    if (threadIdx.x == 0) { best_class[q] = best_s; chunks_out[q] = used; }
 }
 
 // mode 0: PNN arg-max, first maximum from -DBL_MAX (classification.cpp:217-224).
@@ -273,7 +331,7 @@ int cls_scan(fir_cls* c, const double* queries, int32_t qb) {
         hipLaunchKernelGGL(k_cls_prep_queries, dim3((kk * kQB + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream,
                            c->dq + (size_t)q0 * c->d, nq, c->d, c->dp2, c->avg, c->qn);
         hipLaunchKernelGGL(k_cls_scan, dim3(waves / 4), dim3(kBlock), 0, c->stream, c->gal2, c->qn, c->nt, (int)c->tiles, c->dp2,
-                           c->d, waves, nq, c->sums + (size_t)q0 * c->nt);
+                           c->d, waves, nq, 0, c->dp2, c->sums + (size_t)q0 * c->nt);
     }
     CLS_HIP(hipGetLastError());
     return FIR_OK;
@@ -382,6 +440,40 @@ int fir_cls_pnn_predict(fir_cls* c, const double* queries, int32_t qb, double va
     CLS_HIP(hipGetLastError());
     if (scores) CLS_HIP(hipMemcpyAsync(scores, c->scores, (size_t)qb * c->num_classes * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (best_class) CLS_HIP(hipMemcpyAsync(best_class, c->best, (size_t)qb * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    CLS_HIP(hipStreamSynchronize(c->stream));
+    return FIR_OK;
+}
+
+int fir_cls_pnn_predict_seq(fir_cls* c, const double* queries, int32_t qb, double var, int32_t* best_class, int32_t* chunks_out) {
+    if (!c || !best_class || (qb > 0 && !queries)) return cls_fail(FIR_ERR_ARG, "NULL argument");
+    if (qb < 0) return cls_fail(FIR_ERR_ARG, "qb < 0");
+    if ((size_t)c->num_classes * 12 > 60 * 1024) return cls_fail(FIR_ERR_ARG, "num_classes=%d too large for the LDS tables", c->num_classes);
+    if (qb == 0) return FIR_OK;
+    CLS_HIP(hipSetDevice(c->device));
+    if (var <= 0) { var = 0.00002; if (c->d > 2000) var /= 10; }                // classification.cpp:229-233
+    const int nchunks = (c->d + 31) / 32;
+    const int64_t ntp = std::max<int64_t>(c->nt, 1);
+    int rc;
+    if ((rc = cls_grow(c->dq, c->dq_cap, (size_t)qb * c->d))) return rc;
+    if ((rc = cls_grow(c->sums, c->sums_cap, (size_t)(nchunks + 1) * kQB * ntp))) return rc;   // chunk sums + running sums
+    if ((rc = cls_grow(c->best, c->best_cap, (size_t)2 * std::max(qb, kQB)))) return rc;
+    CLS_HIP(hipMemcpyAsync(c->dq, queries, (size_t)qb * c->d * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    const int kk = c->dp2 * 2;
+    const int waves = (int)std::min<int64_t>(std::max<int64_t>((c->tiles + 3) / 4 * 4, 4), (int64_t)c->cus * 16);
+    double* run = c->sums + (size_t)nchunks * kQB * ntp;
+    for (int q0 = 0; q0 < qb; q0 += kQB) {
+        const int nq = std::min(kQB, qb - q0);
+        hipLaunchKernelGGL(k_cls_prep_queries, dim3((kk * kQB + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream,
+                           c->dq + (size_t)q0 * c->d, nq, c->d, c->dp2, c->avg, c->qn);
+        for (int ch = 0; ch < nchunks; ++ch)
+            hipLaunchKernelGGL(k_cls_scan, dim3(waves / 4), dim3(kBlock), 0, c->stream, c->gal2, c->qn, c->nt, (int)c->tiles, c->dp2,
+                               c->d, waves, nq, ch * 16, std::min(c->dp2, (ch + 1) * 16), c->sums + (size_t)ch * nq * c->nt);
+        hipLaunchKernelGGL(k_cls_pnn_seq, dim3(nq), dim3(kBlock), (size_t)c->num_classes * 12, c->stream, c->sums, nq, nchunks, run,
+                           c->class_off, c->nt, c->num_classes, c->d, var, c->best + q0, c->best + std::max(qb, kQB) + q0);
+    }
+    CLS_HIP(hipGetLastError());
+    CLS_HIP(hipMemcpyAsync(best_class, c->best, (size_t)qb * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    if (chunks_out) CLS_HIP(hipMemcpyAsync(chunks_out, c->best + std::max(qb, kQB), (size_t)qb * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     CLS_HIP(hipStreamSynchronize(c->stream));
     return FIR_OK;
 }

@@ -152,6 +152,10 @@ int fir_cls_distance_sums(fir_cls* c, const double* queries, int32_t qb, double*
  * (2e-5, divided by 10 when d > 2000, :190-193). scores[qb][num_classes] (may be NULL) <-
  * sum_t exp(-dist / (2 d var)) / nt per class; best_class[qb] <- first maximum. */
 int fir_cls_pnn_predict(fir_cls* c, const double* queries, int32_t qb, double var, double* scores, int32_t* best_class);
+/* PNNClassifier::predict_sequentional, classification.cpp:228-295: 32-feature chunks, running per-row
+ * sums, class outputs with 2*var*max_fi, classes below max/1e9 dropped, stop when one class is left.
+ * chunks_out[qb] (may be NULL) <- chunks used. */
+int fir_cls_pnn_predict_seq(fir_cls* c, const double* queries, int32_t qb, double var, int32_t* best_class, int32_t* chunks_out);
 /* KNNClassifier::predict, classification.cpp:116-170: rows sorted by mean distance vote for their
  * class until one class has k votes. 1 <= k <= 8. best_class[qb]. */
 int fir_cls_knn_predict(fir_cls* c, const double* queries, int32_t qb, int32_t k, int32_t* best_class);

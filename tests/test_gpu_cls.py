@@ -22,6 +22,8 @@ def test_reference_predictions_reproduced(fir, oracle):
         sums = m.distance_sums(q)
         knn1, knn3 = m.knn_predict(q, 1), m.knn_predict(q, 3)
         pnn, scores = m.pnn_predict(q)
+        seq, _ = m.pnn_predict_seq(q)
+    assert np.array_equal(seq, GOLD["cls/pnn_seq"])
     assert np.array_equal(knn1, GOLD["cls/knn1"])
     assert np.array_equal(knn3, GOLD["cls/knn3"])
     assert np.array_equal(pnn, GOLD["cls/pnn"])
@@ -46,7 +48,10 @@ def test_matches_oracle_on_fresh_data(fir, oracle, seed, n, d, ncls, frac):
         sums = m.distance_sums(q)
         knn = {k: m.knn_predict(q, k) for k in (1, 3, 5)}
         pnn, scores = m.pnn_predict(q)
+        seq, seq_chunks = m.pnn_predict_seq(q)
     for i in range(q.shape[0]):
+        es_, ec_ = oracle.pnn_predict_seq(tr, tcls, avg, ncls, q[i])
+        assert (seq[i], seq_chunks[i]) == (es_, ec_)
         e1, dist = oracle.knn_predict(tr, tcls, avg, ncls, q[i], 1)
         assert np.array_equal((sums[i] / d).view(np.uint64), dist.view(np.uint64))
         assert knn[1][i] == e1
