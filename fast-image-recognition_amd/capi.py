@@ -52,6 +52,7 @@ SYMBOLS = [
     ("fir_twd_proposed", C.c_int, [_vp, _vp, C.c_int32, C.c_int32, C.c_double, _vp, _vp, _vp]),
     ("fir_cls_create", C.c_int, [_vp, C.c_int64, C.c_int32, _vp, C.c_int32, _vp, C.c_int32, C.POINTER(_vp)]),
     ("fir_cls_destroy", C.c_int, [_vp]),
+    ("fir_cls_set_total_training_size", C.c_int, [_vp, C.c_int64]),
     ("fir_cls_distance_sums", C.c_int, [_vp, _vp, C.c_int32, _vp]),
     ("fir_cls_pnn_predict", C.c_int, [_vp, _vp, C.c_int32, C.c_double, _vp, _vp]),
     ("fir_cls_pnn_predict_seq", C.c_int, [_vp, _vp, C.c_int32, C.c_double, _vp, _vp]),
@@ -286,6 +287,9 @@ class ClsModel:
     def _q(self, queries):
         q = np.ascontiguousarray(queries, dtype=np.float64).reshape(-1, self.d)
         return q, q.ctypes.data_as(_vp)
+
+    def set_total_training_size(self, total):
+        _check(lib().fir_cls_set_total_training_size(self._h, int(total)))
 
     def distance_sums(self, queries):
         q, pq = self._q(queries)

@@ -134,13 +134,14 @@ __device__ __forceinline__ double wave_sum(double v) {
 // PNN class outputs, classification.cpp:195-216: scores[q][c] = sum_{t in class c} exp(-dist/(2 d var)) / nt.
 // grid (num_classes, qb), one wave per (class, query).
 __global__ void __launch_bounds__(64) k_cls_pnn(const double* __restrict__ sums, const int32_t* __restrict__ class_off, int64_t nt,
-                                                 int num_classes, double denom /* 2*d*var */, double* __restrict__ scores) {
+                                                 int num_classes, double denom /* 2*d*var */, double den /* total_training_size */,
+                                                 double* __restrict__ scores) {
     const int c = blockIdx.x, q = blockIdx.y;
     const double* s = sums + (size_t)q * nt;
     double acc = 0.0;
     for (int t = class_off[c] + threadIdx.x; t < class_off[c + 1]; t += 64) acc += exp(-s[t] / denom);
     acc = wave_sum(acc);
-    if (threadIdx.x == 0) scores[(size_t)q * num_classes + c] = acc / (double)nt;
+    if (threadIdx.x == 0) scores[(size_t)q * num_classes + c] = acc / den;
 }
 
 // kNN: the class that first collects k votes in the globally sorted order (classification.cpp:151-160)
@@ -284,6 +285,7 @@ struct fir_cls {
     double* sums = nullptr; size_t sums_cap = 0;
     double* scores = nullptr; size_t scores_cap = 0;
     int32_t* best = nullptr; size_t best_cap = 0;
+    double total_training_size = 0;   // 0: nt. PNNwithClustering keeps the full size as denominator (classification.cpp:390,393)
 };
 
 extern "C" void fir_set_last_error_(const char* msg);   // fir_capi.hip: feeds fir_last_error()
@@ -401,6 +403,12 @@ int fir_cls_create(const double* train_rows, int64_t nt, int32_t d, const int32_
     return FIR_OK;
 }
 
+int fir_cls_set_total_training_size(fir_cls* c, int64_t total) {
+    if (!c || total < 0) return cls_fail(FIR_ERR_ARG, "bad argument");
+    c->total_training_size = (double)total;
+    return FIR_OK;
+}
+
 int fir_cls_destroy(fir_cls* c) {
     if (!c) return FIR_OK;
     (void)hipSetDevice(c->device);
@@ -435,7 +443,8 @@ int fir_cls_pnn_predict(fir_cls* c, const double* queries, int32_t qb, double va
     if ((rc = cls_grow(c->scores, c->scores_cap, (size_t)qb * c->num_classes))) return rc;
     if ((rc = cls_grow(c->best, c->best_cap, (size_t)qb))) return rc;
     const double denom = (double)(2 * (size_t)c->d) * var;                       // 2*num_of_cont_features*var, :213
-    hipLaunchKernelGGL(k_cls_pnn, dim3(c->num_classes, qb), dim3(64), 0, c->stream, c->sums, c->class_off, c->nt, c->num_classes, denom, c->scores);
+    hipLaunchKernelGGL(k_cls_pnn, dim3(c->num_classes, qb), dim3(64), 0, c->stream, c->sums, c->class_off, c->nt, c->num_classes, denom,
+                       c->total_training_size > 0 ? c->total_training_size : (double)c->nt, c->scores);
     hipLaunchKernelGGL(k_cls_argbest, dim3(qb), dim3(64), 0, c->stream, c->scores, c->class_off, c->num_classes, 0, c->best);
     CLS_HIP(hipGetLastError());
     if (scores) CLS_HIP(hipMemcpyAsync(scores, c->scores, (size_t)qb * c->num_classes * sizeof(double), hipMemcpyDeviceToHost, c->stream));

@@ -26,10 +26,11 @@ int main(int argc, char** argv) {
     print_vec("test_rows", test_rows, true);
     print_vec("train_rows", train_rows, true);
     KNNClassifier knn1(1), knn3(3);
-    PNNClassifier pnn(true);
-    Classifier* all[3] = {&knn1, &knn3, &pnn};
-    const char* keys[3] = {"knn1", "knn3", "pnn"};
-    for (int i = 0; i < 3; ++i) {
+    PNNClassifier pnn(true), pnn_seq(false);
+    PNNwithClusteringClassifier clust(5);
+    Classifier* all[5] = {&knn1, &knn3, &pnn, &pnn_seq, &clust};
+    const char* keys[5] = {"knn1", "knn3", "pnn", "pnn_seq", "pnn_clust5"};
+    for (int i = 0; i < 5; ++i) {
         all[i]->train();
         std::vector<int> one;
         for (const Feature_vector* fv : inputs) one.push_back(all[i]->predict(*fv));
@@ -41,6 +42,9 @@ int main(int argc, char** argv) {
         print_vec(key, batch, true);
         std::printf("\"%s_name\": \"%s\",\n", keys[i], all[i]->get_name().c_str());
     }
+    std::vector<int> medoids;
+    for (const auto& c : clust.clusters()) for (size_t t : c) medoids.push_back((int)t);
+    print_vec("medoid_rows", medoids, true);
     std::printf("\"avg0\": %.17g\n}\n", st.avgValues.empty() ? 0.0 : st.avgValues[0]);
     if (st.model) fir_cls_destroy(st.model);
     return 0;

@@ -164,7 +164,9 @@ std::vector<int> PNNClassifier::predict_batch(const std::vector<const Feature_ve
     if (!m || inputs.empty()) return out;
     std::vector<double> q = pack(inputs, classification_state().num_of_cont_features);
     std::vector<int32_t> best(inputs.size());
-    if (fir_cls_pnn_predict(m, q.data(), (int32_t)inputs.size(), /*reference var*/ 0.0, nullptr, best.data()) != FIR_OK) {
+    const int rc = bruteforce ? fir_cls_pnn_predict(m, q.data(), (int32_t)inputs.size(), /*reference var*/ 0.0, nullptr, best.data())
+                              : fir_cls_pnn_predict_seq(m, q.data(), (int32_t)inputs.size(), 0.0, best.data(), nullptr);   // :297-307
+    if (rc != FIR_OK) {
         std::fprintf(stderr, "fir: pnn_predict: %s\n", fir_last_error());
         return out;
     }
@@ -172,5 +174,98 @@ std::vector<int> PNNClassifier::predict_batch(const std::vector<const Feature_ve
     return out;
 }
 int PNNClassifier::predict(const Feature_vector& inputFeatures) {
+    return predict_batch(std::vector<const Feature_vector*>(1, &inputFeatures))[0];
+}
+
+PNNwithClusteringClassifier::PNNwithClusteringClassifier(int no_clusters)
+    : Classifier(named("PNN with clustering", no_clusters)), num_clusters(no_clusters) {}
+PNNwithClusteringClassifier::~PNNwithClusteringClassifier() { if (medoid_model) fir_cls_destroy(medoid_model); }
+
+void PNNwithClusteringClassifier::train() {
+    fir::ClassificationState& st = classification_state();
+    const size_t D = st.num_of_cont_features;
+    clustered_training_set.assign(st.num_of_classes, std::vector<size_t>());
+    const std::vector<double> zero_mean(D, 0.0);
+    for (size_t i = 0; i < st.num_of_classes; ++i) {
+        const std::vector<size_t>& members = st.training_set[i];
+        const size_t n = members.size();
+        if (n <= (size_t)num_clusters) { clustered_training_set[i] = members; continue; }   // :381-385
+        // n x n table of mean squared distances between the class's raw rows (:339-343, 360-365), from the GPU
+        std::vector<double> rows(n * D);
+        for (size_t t = 0; t < n; ++t)
+            for (size_t f = 0; f < D; ++f) rows[t * D + f] = st.dataset[members[t]].features[f];
+        std::vector<int32_t> one_class(n, 0);
+        std::vector<double> table(n * n);
+        fir_cls* pair = nullptr;
+        if (fir_cls_create(rows.data(), (int64_t)n, (int32_t)D, one_class.data(), 1, zero_mean.data(), fir::classification_device(), &pair) != FIR_OK ||
+            fir_cls_distance_sums(pair, rows.data(), (int32_t)n, table.data()) != FIR_OK) {
+            std::fprintf(stderr, "fir: clustering distances: %s\n", fir_last_error());
+            if (pair) fir_cls_destroy(pair);
+            clustered_training_set[i] = members;
+            continue;
+        }
+        fir_cls_destroy(pair);
+        for (double& v : table) v /= (double)D;                                           // dist /= num_of_cont_features
+        std::vector<long> centroid((size_t)num_clusters), assign(n);
+        for (int c = 0; c < num_clusters; ++c) centroid[(size_t)c] = c;
+        for (int step = 0; step < 100; ++step) {
+            for (size_t t = 0; t < n; ++t) {                                              // nearest medoid, first on ties (:331-350)
+                assign[t] = -1;
+                double best = DBL_MAX;
+                for (int c = 0; c < num_clusters; ++c) {
+                    if (centroid[(size_t)c] < 0) continue;
+                    const double dist = table[(size_t)centroid[(size_t)c] * n + t];
+                    if (dist < best) { best = dist; assign[t] = c; }
+                }
+            }
+            for (int c = 0; c < num_clusters; ++c) {                                      // member with the smallest summed distance (:351-375)
+                double best = DBL_MAX;
+                centroid[(size_t)c] = -1;
+                for (size_t t = 0; t < n; ++t) {
+                    if (assign[t] != c) continue;
+                    double sum = 0;
+                    for (size_t t1 = 0; t1 < n; ++t1)
+                        if (assign[t1] == c) sum += table[t * n + t1];
+                    if (sum < best) { best = sum; centroid[(size_t)c] = (long)t; }
+                }
+            }
+        }
+        for (int c = 0; c < num_clusters; ++c)
+            if (centroid[(size_t)c] >= 0) clustered_training_set[i].push_back(members[(size_t)centroid[(size_t)c]]);
+    }
+    // device model over the medoids; the PNN denominator stays the full training size (:390,393)
+    if (medoid_model) { fir_cls_destroy(medoid_model); medoid_model = nullptr; }
+    std::vector<double> rows;
+    std::vector<int32_t> cls;
+    size_t total = 0;
+    for (size_t c = 0; c < st.num_of_classes; ++c) {
+        total += st.training_set[c].size();
+        for (size_t t : clustered_training_set[c]) {
+            const std::vector<double>& f = st.tmp_dataset[t].features;
+            rows.insert(rows.end(), f.begin(), f.begin() + D);
+            cls.push_back((int32_t)c);
+        }
+    }
+    if (fir_cls_create(rows.data(), (int64_t)cls.size(), (int32_t)D, cls.data(), (int32_t)st.num_of_classes, st.avgValues.data(),
+                       fir::classification_device(), &medoid_model) != FIR_OK ||
+        fir_cls_set_total_training_size(medoid_model, (int64_t)total) != FIR_OK) {
+        std::fprintf(stderr, "fir: medoid upload: %s\n", fir_last_error());
+        if (medoid_model) { fir_cls_destroy(medoid_model); medoid_model = nullptr; }
+    }
+}
+
+std::vector<int> PNNwithClusteringClassifier::predict_batch(const std::vector<const Feature_vector*>& inputs) {
+    std::vector<int> out(inputs.size(), -1);
+    if (!medoid_model || inputs.empty()) return out;
+    std::vector<double> q = pack(inputs, classification_state().num_of_cont_features);
+    std::vector<int32_t> best(inputs.size());
+    if (fir_cls_pnn_predict(medoid_model, q.data(), (int32_t)inputs.size(), 0.0, nullptr, best.data()) != FIR_OK) {
+        std::fprintf(stderr, "fir: pnn_predict: %s\n", fir_last_error());
+        return out;
+    }
+    out.assign(best.begin(), best.end());
+    return out;
+}
+int PNNwithClusteringClassifier::predict(const Feature_vector& inputFeatures) {
     return predict_batch(std::vector<const Feature_vector*>(1, &inputFeatures))[0];
 }

@@ -90,4 +90,22 @@ private:
     bool bruteforce;
 };
 
+// classification.cpp:311-428: k-medoids (100 rounds) inside every class, then the PNN over the medoids only.
+// The pairwise within-class distances come from the GPU (fir_cls_distance_sums with a zero mean vector);
+// the assign / re-pick bookkeeping of the 100 rounds runs on the host over that n x n table.
+class PNNwithClusteringClassifier : public Classifier {
+public:
+    PNNwithClusteringClassifier(int no_clusters);
+    ~PNNwithClusteringClassifier();
+    void train() override;
+    int predict(const Feature_vector& inputFeatures) override;
+    std::vector<int> predict_batch(const std::vector<const Feature_vector*>& inputs) override;
+    const std::vector<std::vector<size_t> >& clusters() const { return clustered_training_set; }
+
+private:
+    const int num_clusters;
+    std::vector<std::vector<size_t> > clustered_training_set;
+    fir_cls* medoid_model = nullptr;
+};
+
 #endif  // FIR_CLASSIFICATION_H

@@ -145,6 +145,9 @@ typedef struct fir_cls fir_cls;
 int fir_cls_create(const double* train_rows, int64_t nt, int32_t d, const int32_t* train_class, int32_t num_classes,
                    const double* avg, int32_t device, fir_cls** out);
 int fir_cls_destroy(fir_cls* c);
+/* PNNwithClusteringClassifier::predict (classification.cpp:389-428) runs the PNN over the medoid rows
+ * only but still divides by the FULL training size: set it here (0 = the number of rows held). */
+int fir_cls_set_total_training_size(fir_cls* c, int64_t total);
 /* sums[qb][nt] <- sum_f ((g_f - avg_f) - (q_f - avg_f))^2 per training row, accumulated in feature
  * order in double (classification.cpp:123-141 before the division, :199-211). */
 int fir_cls_distance_sums(fir_cls* c, const double* queries, int32_t qb, double* sums);

@@ -282,6 +282,88 @@ int orc_pnn_predict(const double* train_rows, const int32_t* train_class, int64_
     return bestClass;
 }
 
+/* classification.cpp:320-388 PNNwithClusteringClassifier::train for ONE class: rows[n][d] are the class's
+ * training rows (raw dataset features, no mean subtraction, :339-342) in training_set order. 100 rounds of
+ * assign-to-nearest-medoid (:331-350) / re-pick the member with the smallest summed distance (:351-375).
+ * medoids_out[num_clusters] <- positions inside the class (or -1 for an emptied cluster); returns how many
+ * were written. Classes with n <= num_clusters keep every row (:381-385): medoids 0..n-1. */
+int orc_pnn_cluster_class(const double* rows, int n, int d, int num_clusters, int* medoids_out) {
+    if (n <= num_clusters) {
+        for (int j = 0; j < n; ++j) medoids_out[j] = j;
+        return n;
+    }
+    long* centroid = (long*)malloc(sizeof(long) * (size_t)num_clusters);
+    long* assign = (long*)malloc(sizeof(long) * (size_t)n);
+    for (int c = 0; c < num_clusters; ++c) centroid[c] = c;
+    for (int step = 0; step < 100; ++step) {
+        for (int t = 0; t < n; ++t) {
+            assign[t] = -1;
+            double bestDist = DBL_MAX;
+            for (int c = 0; c < num_clusters; ++c) {
+                if (centroid[c] < 0) continue; /* the reference's size_t compare is always true; an emptied cluster is UB there */
+                double dist = 0;
+                const double* a = rows + centroid[c] * d;
+                const double* b = rows + (long)t * d;
+                for (int f = 0; f < d; ++f) dist += (a[f] - b[f]) * (a[f] - b[f]);
+                dist /= d;
+                if (dist < bestDist) { bestDist = dist; assign[t] = c; }
+            }
+        }
+        for (int c = 0; c < num_clusters; ++c) {
+            double bestClustDist = DBL_MAX;
+            centroid[c] = -1;
+            for (int t = 0; t < n; ++t) {
+                if (assign[t] != c) continue;
+                double clustDist = 0;
+                for (int t1 = 0; t1 < n; ++t1) {
+                    if (assign[t1] != c) continue;
+                    double dist = 0;
+                    const double* a = rows + (long)t * d;
+                    const double* b = rows + (long)t1 * d;
+                    for (int f = 0; f < d; ++f) dist += (a[f] - b[f]) * (a[f] - b[f]);
+                    dist /= d;
+                    clustDist += dist;
+                }
+                if (clustDist < bestClustDist) { bestClustDist = clustDist; centroid[c] = t; }
+            }
+        }
+    }
+    int m = 0;
+    for (int c = 0; c < num_clusters; ++c)
+        if (centroid[c] >= 0) medoids_out[m++] = (int)centroid[c];
+    free(centroid);
+    free(assign);
+    return m;
+}
+
+/* classification.cpp:389-428 PNNwithClusteringClassifier::predict: predict_bf over the medoid rows, but the
+ * denominator stays the FULL training size (:390,393). */
+int orc_pnn_predict_den(const double* train_rows, const int32_t* train_class, int64_t nt, int d, const double* avg,
+                        int num_of_classes, const double* q, double total_training_size, double* scores_out) {
+    double var = 0.00002;
+    if (d > 2000) var /= 10;
+    double* outputs = (double*)calloc((size_t)num_of_classes, sizeof(double));
+    for (int64_t t = 0; t < nt; ++t) {
+        double dist = 0;
+        const double* g = train_rows + t * d;
+        for (int fi = 0; fi < d; ++fi) {
+            double diff = g[fi] - avg[fi];
+            double val = q[fi] - avg[fi];
+            diff -= val;
+            dist += diff * diff;
+        }
+        outputs[train_class[t]] += exp(-dist / (2 * (size_t)d * var));
+    }
+    for (int i = 0; i < num_of_classes; ++i) outputs[i] /= total_training_size;
+    double max_output = -DBL_MAX;
+    int bestClass = -1;
+    for (int i = 0; i < num_of_classes; ++i)
+        if (max_output < outputs[i]) { max_output = outputs[i]; bestClass = i; }
+    if (scores_out) memcpy(scores_out, outputs, sizeof(double) * (size_t)num_of_classes);
+    free(outputs);
+    return bestClass;
+}
+
 /* classification.cpp:228-295 PNNClassifier::predict_sequentional: 32-feature chunks (:182),
  * per-row running sums, class outputs with 2*var*max_fi (:266), classes below
  * max/1e9 dropped (:280-289, float threshold), stop when one class is left. */

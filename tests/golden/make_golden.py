@@ -144,7 +144,7 @@ def main():
     fx["cls/train"], fx["cls/train_class"], fx["cls/test"] = train, tcls, test
     mn, mx, avg, sd = rc.stats()
     fx["cls/min"], fx["cls/max"], fx["cls/avg"], fx["cls/std"] = mn, mx, avg, sd
-    for kind, param, nm in ((0, 1, "knn1"), (0, 3, "knn3"), (1, 0, "pnn"), (2, 0, "pnn_seq")):
+    for kind, param, nm in ((0, 1, "knn1"), (0, 3, "knn3"), (1, 0, "pnn"), (2, 0, "pnn_seq"), (3, 5, "pnn_clust5"), (3, 2, "pnn_clust2")):
         fx[f"cls/{nm}"] = np.array([rc.predict_row(kind, param, int(r)) for r in test], np.int32)
 
     out = os.path.join(HERE, "reference_outputs.npz")

@@ -42,6 +42,10 @@ class Oracle:
         L.orc_pnn_predict.argtypes = [_vp, _vp, C.c_int64, C.c_int, _vp, C.c_int, _vp, _vp]
         L.orc_pnn_predict_seq.restype = C.c_int
         L.orc_pnn_predict_seq.argtypes = [_vp, _vp, C.c_int64, C.c_int, _vp, C.c_int, _vp, C.POINTER(C.c_int)]
+        L.orc_pnn_cluster_class.restype = C.c_int
+        L.orc_pnn_cluster_class.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp]
+        L.orc_pnn_predict_den.restype = C.c_int
+        L.orc_pnn_predict_den.argtypes = [_vp, _vp, C.c_int64, C.c_int, _vp, C.c_int, _vp, C.c_double, _vp]
         L.orc_train_stats.restype = None
         L.orc_train_stats.argtypes = [_vp, C.c_int64, C.c_int, _vp, _vp, _vp, _vp]
         L.orc_load_images.restype = C.c_int64
@@ -142,6 +146,31 @@ class Oracle:
         chunks = C.c_int()
         r = self.L.orc_pnn_predict_seq(_p(tr), _p(tc), tr.shape[0], tr.shape[1], _p(avg), num_classes, _p(q), C.byref(chunks))
         return int(r), int(chunks.value)
+
+    def pnn_cluster_class(self, rows, num_clusters):
+        r = np.ascontiguousarray(rows, np.float64)
+        out = np.full(max(num_clusters, r.shape[0]), -1, np.int32)
+        m = self.L.orc_pnn_cluster_class(_p(r), r.shape[0], r.shape[1], num_clusters, _p(out))
+        return out[:m].copy()
+
+    def pnn_cluster_train(self, train_rows, train_class, num_classes, num_clusters):
+        """medoid rows (positions in train_rows) of every class, class-major."""
+        tc = np.asarray(train_class)
+        keep = []
+        for c in range(num_classes):
+            pos = np.nonzero(tc == c)[0]
+            if pos.size:
+                keep.extend(pos[self.pnn_cluster_class(train_rows[pos], num_clusters)])
+        return np.array(keep, np.int64)
+
+    def pnn_predict_den(self, train_rows, train_class, avg, num_classes, q, total):
+        tr = np.ascontiguousarray(train_rows, np.float64)
+        tc = np.ascontiguousarray(train_class, np.int32)
+        avg = np.ascontiguousarray(avg, np.float64)
+        q = np.ascontiguousarray(q, np.float64)
+        scores = np.empty(num_classes, np.float64)
+        r = self.L.orc_pnn_predict_den(_p(tr), _p(tc), tr.shape[0], tr.shape[1], _p(avg), num_classes, _p(q), float(total), _p(scores))
+        return int(r), scores
 
     def train_stats(self, train_rows):
         tr = np.ascontiguousarray(train_rows, np.float64)

@@ -97,3 +97,9 @@ def test_classification_shim_matches_oracle_end_to_end(tmp_path, oracle):
     assert got["knn3_single"] == e3 and got["knn3_batch"] == e3
     assert got["pnn_single"] == ep and got["pnn_batch"] == ep and got["pnn_name"] == "PNN"
     assert np.mean(np.array(e1) == np.array(got["truth"])) > 0.5
+    es = [oracle.pnn_predict_seq(tr, tcls, avg, nc, rows[r])[0] for r in test]
+    assert got["pnn_seq_single"] == es and got["pnn_seq_batch"] == es and got["pnn_seq_name"] == "PNN (seq)"
+    keep = oracle.pnn_cluster_train(tr, tcls, nc, 5)            # positions in the class-major training list
+    assert got["medoid_rows"] == list(train[keep])
+    ec = [oracle.pnn_predict_den(tr[keep], tcls[keep], avg, nc, rows[r], tr.shape[0])[0] for r in test]
+    assert got["pnn_clust5_single"] == ec and got["pnn_clust5_batch"] == ec and got["pnn_clust5_name"] == "PNN with clustering, 5"

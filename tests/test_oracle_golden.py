@@ -119,5 +119,10 @@ def test_classification_knn_pnn_match_reference(oracle):
     assert knn3 == list(GOLD["cls/knn3"])
     assert pnn == list(GOLD["cls/pnn"])
     assert seq == list(GOLD["cls/pnn_seq"])
+    for k in (5, 2):        # PNNwithClusteringClassifier (classification.cpp:311-428): k-medoids per class, PNN over the medoids
+        keep = oracle.pnn_cluster_train(tr, tcls, ncls, k)
+        assert keep.size == ncls * k
+        got = [oracle.pnn_predict_den(tr[keep], tcls[keep], avg, ncls, x[r], tr.shape[0])[0] for r in test]
+        assert got == list(GOLD[f"cls/pnn_clust{k}"])
     acc = np.mean(np.array(knn1) == lab[test])
     assert acc > 0.5, "the synthetic classes should be separable enough for the fixture to mean something"
