@@ -53,10 +53,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rows", type=int, default=1_000_000)
     ap.add_argument("--dim", type=int, default=512)
-    ap.add_argument("--batch", type=int, default=64, help="query vectors per step")
+    ap.add_argument("--batch", type=int, default=256, help="query vectors per step")
     ap.add_argument("--qpp", type=int, default=0, help="queries per gallery pass (0 = library default)")
     ap.add_argument("--waves", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' rehearses the N>1 path with all ranks on ONE GPU")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -69,7 +70,11 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:   # rehearsal: ranks may share a GPU, the key exchange goes through host memory
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
+            local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     fir = ge.load_package()
@@ -120,7 +125,12 @@ def main():
             g.search_top1_keys_dev(q.data_ptr(), qb, keys.data_ptr(), stream=stream)
             if dist is not None:
                 k = sharding.keys_as_int64(keys)           # order-preserving u64 -> i64 (x ^ 2^63)
-                sharding.allreduce_min_keys(k)             # RCCL all-reduce(MIN) over xGMI
+                if args.backend == "nccl":
+                    sharding.allreduce_min_keys(k)         # RCCL all-reduce(MIN) over xGMI
+                else:
+                    kh = k.cpu()
+                    sharding.allreduce_min_keys(kh)
+                    k = kh.to(dev)
                 keys.copy_(sharding.keys_from_int64(k))
 
     def fence():
@@ -143,7 +153,7 @@ def main():
     tuning = g.get_tuning()
     elapsed = t1 - t0
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
