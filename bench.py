@@ -165,7 +165,7 @@ def main():
 
     out = None
     if rank == 0:
-        passes_per_step = len(kernel_ms) / max(args.steps, 1)
+        launches_per_step = len(kernel_ms) / max(args.steps, 1)
         avg_ms = float(np.mean(kernel_ms)) if len(kernel_ms) else float("nan")
         achieved = bytes_alg / (avg_ms * 1e-3) / 1e9 if len(kernel_ms) else float("nan")
         out = {
@@ -185,7 +185,8 @@ def main():
                 "workload": f"{n}x{d} f32 gallery, batched L2 top-1 (configs[1] kernel at the metric's 1Mx512 size)",
                 "query_batch": qb,
                 "queries_per_pass": tuning["queries_per_pass"],
-                "passes_per_step": passes_per_step,
+                "gallery_passes_per_step": -(-qb // max(tuning["queries_per_pass"], 1)),
+                "scan_launches_per_step": launches_per_step,
                 "waves": tuning["waves"],
                 "row_sharding": f"{world} shard(s) of {row_hi - row_lo} rows",
                 "planted_queries_found": planted_ok,

@@ -71,6 +71,7 @@ struct fir_gallery {
     int waves_req = 0;        // 0 = automatic
     int max_waves = 0;        // upper bound over all scan kernels (8 blocks per CU)
     int last_waves = 0;       // waves of the most recent scan launch
+    int max_tiles_per_launch = 64;   // query tiles (gallery passes) folded into one launch of the hand-scheduled kernels
 
     struct Occ { const void* fn; size_t lds; int waves; };
     std::vector<Occ> occ;     // resident-wave capacity per scan kernel
@@ -194,13 +195,14 @@ int max_waves_for(fir_gallery* g, scan_fn fn, size_t lds_bytes) {
 
 // Queue: transpose (+ key init) of one query tile, then one gallery pass.
 int run_pass(fir_gallery* g, hipStream_t st, int epi, const float* d_queries, int q0, int qb_tile, int32_t start,
-             int32_t end, uint64_t* keys, float* out, int64_t out_stride, int k, int* waves_used = nullptr) {
+             int32_t end, uint64_t* keys, float* out, int64_t out_stride, int k, int* waves_used = nullptr, int ny = 1) {
+    // ny > 1 (hand-scheduled top-1 kernels only): ny consecutive query tiles of qb_tile queries in ONE launch
     const int kk = g->dp4 * 4;
     float* qt = g->qt + (size_t)q0 * kk;
     {
-        const int64_t total = (int64_t)kk * qb_tile;
+        const int64_t total = (int64_t)kk * qb_tile * ny;
         const int blocks = (int)((total + kBlock - 1) / kBlock);
-        hipLaunchKernelGGL(k_transpose_queries, dim3(blocks), dim3(kBlock), 0, st, d_queries + (size_t)q0 * g->d, qb_tile,
+        hipLaunchKernelGGL(k_transpose_queries, dim3(blocks), dim3(kBlock), 0, st, d_queries + (size_t)q0 * g->d, qb_tile * ny,
                            g->d, g->dp4, qb_tile, qt);
     }
     size_t lds_bytes = 0;
@@ -226,6 +228,7 @@ int run_pass(fir_gallery* g, hipStream_t st, int epi, const float* d_queries, in
     a.out_stride = out_stride;
     a.nq = qb_tile;
     a.k = k;
+    a.qt_stride = (int64_t)kk * qb_tile;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (g->profiling) {
         if (g->ev_used + 2 > g->ev.size()) {
@@ -239,11 +242,11 @@ int run_pass(fir_gallery* g, hipStream_t st, int epi, const float* d_queries, in
         e1 = g->ev[g->ev_used++];
         FIR_HIP(hipEventRecord(e0, st));
     }
-    hipLaunchKernelGGL(fn, dim3(waves / 4), dim3(kBlock), lds_bytes, st, a);
+    hipLaunchKernelGGL(fn, dim3(waves / 4, ny), dim3(kBlock), lds_bytes, st, a);
     if (g->profiling) {
         FIR_HIP(hipEventRecord(e1, st));
         // algorithmic bytes of one pass: the gallery range once, the query tile, the keys
-        g->last_bytes = (double)g->n * (end - start) * 4.0 + (double)qb_tile * (end - start) * 4.0 + qb_tile * 8.0;
+        g->last_bytes = ny * ((double)g->n * (end - start) * 4.0 + (double)qb_tile * (end - start) * 4.0 + qb_tile * 8.0);
     }
     FIR_HIP(hipGetLastError());
     return FIR_OK;
@@ -264,9 +267,11 @@ int top1_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start, 
     int q0 = 0;
     while (q0 < qb) {
         const int t = largest_pow2_le(qb - q0, cap);
-        rc = run_pass(g, st, kEpiTop1, d_queries, q0, t, start, end, d_keys + q0, nullptr, 0, 0);
+        // all the whole tiles of t queries go into one launch (blockIdx.y) when the hand-scheduled kernel takes them
+        const int ny = pick_fast(kEpiTop1, t, g->metric, start, end, g->dp4, nullptr) ? std::min((qb - q0) / t, g->max_tiles_per_launch) : 1;
+        rc = run_pass(g, st, kEpiTop1, d_queries, q0, t, start, end, d_keys + q0, nullptr, 0, 0, nullptr, ny);
         if (rc) return rc;
-        q0 += t;
+        q0 += t * ny;
     }
     return FIR_OK;
 }

@@ -107,6 +107,7 @@ struct ScanArgs {
     int64_t out_stride;
     int32_t nq;           // live queries in this tile (<= QB); only kEpiStore needs it
     int32_t k;            // kEpiTopK
+    int64_t qt_stride;    // hand-scheduled kernels: floats between the query tiles of consecutive blockIdx.y
 };
 
 // 64-bit wave-wide minimum (all lanes end with the result).
@@ -386,7 +387,10 @@ __global__ void __launch_bounds__(kBlock, WPS) k_scan_l2_fast(const ScanArgs a) 
     constexpr int QB = 8 * NB;
     const int lane = threadIdx.x & 63;
     const int gw = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-    sf2_p q2 = (sf2_p)(uintptr_t)a.qt;            // f2 index of (feature k, query pair p of block b): k*4*NB + 4*b + p
+    // blockIdx.y = query tile: one launch runs several gallery passes back to back (no launch gaps, the
+    // tail of one pass overlaps the head of the next; small galleries fill the chip with concurrent passes)
+    sf2_p q2 = (sf2_p)(uintptr_t)(a.qt + (size_t)blockIdx.y * a.qt_stride);   // f2 index of (feature k, pair p of block b): k*4*NB + 4*b + p
+    uint64_t* keys = a.keys + (size_t)blockIdx.y * QB;
     const int c_lo = a.start >> 2, c_hi = a.end >> 2;
     const float fcount = (float)(a.end - a.start);
 
@@ -434,8 +438,8 @@ __global__ void __launch_bounds__(kBlock, WPS) k_scan_l2_fast(const ScanArgs a) 
         uint64_t key = best_i[q] >= 0 ? key_pack(best_d[q], (uint32_t)((int64_t)best_i[q] + a.row_offset)) : kKeyNone;
         key = wave_min_u64(key);
         if (lane == 0 && key != kKeyNone) {
-            const uint64_t cur_key = __hip_atomic_load(a.keys + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (key < cur_key) atomicMin((unsigned long long*)(a.keys + q), (unsigned long long)key);
+            const uint64_t cur_key = __hip_atomic_load(keys + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (key < cur_key) atomicMin((unsigned long long*)(keys + q), (unsigned long long)key);
         }
     }
 }
@@ -516,7 +520,8 @@ __global__ void __launch_bounds__(kBlock, WPS) k_scan_l2_lds(const ScanArgs a) {
     const int c_lo = a.start >> 2, c_hi = a.end >> 2;
     const float fcount = (float)(a.end - a.start);
     {
-        const float4* src = reinterpret_cast<const float4*>(a.qt);
+        // blockIdx.y = query tile (see k_scan_l2_fast)
+        const float4* src = reinterpret_cast<const float4*>(a.qt + (size_t)blockIdx.y * a.qt_stride);
         const int n4 = a.dp4 * QB;                       // float4s in the tile: dp4*4 features * QB / 4
         for (int i = threadIdx.x; i < n4 + QB; i += kBlock) lq[i] = i < n4 ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         __syncthreads();
@@ -527,6 +532,7 @@ __global__ void __launch_bounds__(kBlock, WPS) k_scan_l2_lds(const ScanArgs a) {
     int zero_v;
     asm volatile("v_mov_b32 %0, 0" : "=v"(zero_v));
     const float4* lqv = lq + zero_v;
+    uint64_t* keys = a.keys + (size_t)blockIdx.y * QB;
 
     float best_d[QB];
     int32_t best_i[QB];
@@ -598,8 +604,8 @@ __global__ void __launch_bounds__(kBlock, WPS) k_scan_l2_lds(const ScanArgs a) {
         uint64_t key = best_i[q] >= 0 ? key_pack(best_d[q], (uint32_t)((int64_t)best_i[q] + a.row_offset)) : kKeyNone;
         key = wave_min_u64(key);
         if (lane == 0 && key != kKeyNone) {
-            const uint64_t cur_key = __hip_atomic_load(a.keys + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (key < cur_key) atomicMin((unsigned long long*)(a.keys + q), (unsigned long long)key);
+            const uint64_t cur_key = __hip_atomic_load(keys + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (key < cur_key) atomicMin((unsigned long long*)(keys + q), (unsigned long long)key);
         }
     }
 }

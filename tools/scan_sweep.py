@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--dim", type=int, default=512)
     ap.add_argument("--waves", default="0")
     ap.add_argument("--qpp", default="8")
+    ap.add_argument("--batch", type=int, default=0, help="queries per call (0 = queries per pass): > qpp folds passes into one launch")
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--launches", type=int, default=10)
     ap.add_argument("--tag", default=os.path.basename(os.environ.get("FIR_AMD_LIB", "default")))
@@ -32,7 +33,7 @@ def main():
     del x
     torch.cuda.empty_cache()
     configs = [(int(q), int(w)) for q in a.qpp.split(",") for w in a.waves.split(",")]
-    qmax = max(c[0] for c in configs)
+    qmax = max(max(c[0] for c in configs), a.batch)
     q = torch.rand((qmax, a.dim), device=dev)
     q = (q / q.norm(dim=1, keepdim=True)).contiguous()
     keys = torch.empty(qmax, device=dev, dtype=torch.int64)
@@ -43,7 +44,7 @@ def main():
             g.set_tuning(c[0], c[1])
             g.profile_enable(True)
             for _ in range(a.launches):
-                g.search_top1_keys_dev(q.data_ptr(), c[0], keys.data_ptr(), stream=st.cuda_stream)
+                g.search_top1_keys_dev(q.data_ptr(), a.batch or c[0], keys.data_ptr(), stream=st.cuda_stream)
             ms, nbytes = g.profile_read()
             if r > 0:
                 res[c].append((float(np.median(ms)), float(ms.min()), nbytes))
@@ -52,8 +53,9 @@ def main():
         mn = min(v[1] for v in res[c])
         nb = res[c][0][2]
         g.set_tuning(c[0], c[1])
-        print(f"{a.tag:22s} qpp={c[0]:2d} waves={c[1]:5d} median {med*1e3:7.1f} us  min {mn*1e3:7.1f} us  "
-              f"{nb/med/1e6:7.1f} GB/s (median)  {c[0]/med*1e3:8.0f} q/s", flush=True)
+        nqs = a.batch or c[0]
+        print(f"{a.tag:22s} qpp={c[0]:2d} batch={nqs:4d} waves={c[1]:5d} median {med*1e3:8.1f} us  min {mn*1e3:8.1f} us  "
+              f"{nb/med/1e6:7.1f} GB/s (median)  {nqs/med*1e3:8.0f} q/s", flush=True)
     g.close()
 
 
