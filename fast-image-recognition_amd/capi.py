@@ -57,6 +57,10 @@ SYMBOLS = [
     ("fir_cls_pnn_predict", C.c_int, [_vp, _vp, C.c_int32, C.c_double, _vp, _vp]),
     ("fir_cls_pnn_predict_seq", C.c_int, [_vp, _vp, C.c_int32, C.c_double, _vp, _vp]),
     ("fir_cls_knn_predict", C.c_int, [_vp, _vp, C.c_int32, C.c_int32, _vp]),
+    ("fir_gemm_create", C.c_int, [_vp, C.POINTER(_vp)]),
+    ("fir_gemm_destroy", C.c_int, [_vp]),
+    ("fir_gemm_search_top1_keys_dev", C.c_int, [_vp, _vp, C.c_int32, _vp, _vp]),
+    ("fir_gemm_stats", C.c_int, [_vp, _i64p, _i64p]),
     ("fir_profile_enable", C.c_int, [_vp, C.c_int32]),
     ("fir_profile_read", C.c_int, [_vp, _vp, C.c_int32, _i32p, C.POINTER(C.c_double)]),
     ("fir_gallery_sync", C.c_int, [_vp]),
@@ -251,6 +255,40 @@ class Gallery:
 
     def sync(self):
         _check(lib().fir_gallery_sync(self._h))
+
+
+class GemmSearch:
+    """Large-batch L2 top-1 through the matrix cores (fir_gemm_*): same answers as Gallery.search_top1."""
+
+    def __init__(self, gallery):
+        self._g = gallery           # keeps the gallery alive
+        self._h = _vp()
+        _check(lib().fir_gemm_create(gallery._h, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().fir_gemm_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def search_top1_keys_dev(self, q_ptr, qb, keys_ptr, stream=None):
+        _check(lib().fir_gemm_search_top1_keys_dev(self._h, _vp(q_ptr), qb, _vp(keys_ptr), _vp(stream) if stream else None))
+
+    def stats(self):
+        a, b = C.c_int64(), C.c_int64()
+        _check(lib().fir_gemm_stats(self._h, C.byref(a), C.byref(b)))
+        return {"passes": a.value, "fallback_queries": b.value}
 
 
 class ClsModel:

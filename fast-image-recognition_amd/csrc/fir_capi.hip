@@ -375,6 +375,12 @@ int fir_gallery_view_(fir_gallery* g, fir_gallery_view* out) {
     out->cls = g->cls; out->stream = g->stream;
     return FIR_OK;
 }
+int fir_gallery_tiled_(fir_gallery* g, const void** gal4, int* dp4) {
+    if (!g || !gal4 || !dp4) return FIR_ERR_ARG;
+    *gal4 = g->gal4;
+    *dp4 = g->dp4;
+    return FIR_OK;
+}
 // internal: lets the library's other translation units (fir_cls.hip) report through fir_last_error()
 void fir_set_last_error_(const char* msg) {
     strncpy(g_err, msg ? msg : "", sizeof(g_err) - 1);

@@ -1,0 +1,527 @@
+// fir_gemm.hip -- large-batch L2 top-1 through the matrix cores, with the reference's exact answer.
+//
+// The streaming scan (fir_kernels.h) is HBM-bound at 8 queries per gallery pass and VALU-bound
+// beyond. For big query batches the N x Qb x d work is a GEMM: p(q, g) = |g|^2 - 2 q.g orders the
+// rows of one query exactly like the squared distance does, and q.g runs on MFMA. gfx950 has an
+// f32-input MFMA (v_mfma_f32_32x32x2_f32: exact products, f32 fma chain) at the f32 vector peak
+// (157 TF), i.e. ONE matrix op per (row, query, feature) instead of the scan's three VALU ops.
+//
+// The GEMM only NOMINATES rows; the answer is still the reference's:
+//   1. proxies of a row sample give, per query, an upper bound tau of its C-th smallest proxy;
+//   2. the full pass appends every row with p < tau to the query's candidate list;
+//   3. the C best candidates are re-ranked with the reference's own arithmetic (sequential,
+//      un-fused f32: fir::accum<kL2>), first-minimum tie-break on (distance, row);
+//   4. a rigorous bound certifies the winner: every non-candidate row has p >= p_C, hence a
+//      reference distance >= (|q|^2 + p_C)/d - E, with E covering every rounding on both sides;
+//      if that does not exceed the winner's exact distance (near ties beyond C candidates,
+//      candidate overflow), the query is re-run through the exact streaming scan.
+// So results are bit-identical to the scan path's -- index and distance -- by construction.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <vector>
+
+#include "../../include/fir_amd.h"
+#include "fir_internal.h"
+#include "fir_common.h"
+
+namespace {
+
+using fir::kKeyNone;
+
+constexpr int kGemmBlock = 512;        // 8 waves: 2 per SIMD
+constexpr int kQT = 64;                // queries per pass (2 accumulator tiles of 32 per wave)
+constexpr int kRowsPerWave = 32;
+constexpr int kRowsPerBlock = kRowsPerWave * (kGemmBlock / 64);   // 256
+constexpr int kCand = 8;               // candidates re-ranked exactly per query
+constexpr int kListCap = 4096;         // appended (proxy, row) entries per query before "overflow"
+constexpr int kMinSampleRows = 8192;   // rows whose proxies seed tau: max(8192, n / 64) -> ~512 appended rows per query
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+thread_local char g_gemm_err[512];
+int gemm_fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_gemm_err, sizeof(g_gemm_err), fmt, ap);
+    va_end(ap);
+    fir_set_last_error_(g_gemm_err);
+    return code;
+}
+#define GEMM_HIP(expr)                                                                                         \
+    do {                                                                                                       \
+        hipError_t e_ = (expr);                                                                                \
+        if (e_ != hipSuccess) return gemm_fail(e_ == hipErrorOutOfMemory ? FIR_ERR_NOMEM : FIR_ERR_HIP,       \
+                                               "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+// MFMA operand layout shared by gallery and queries ("fragment order"): for a block of 32 vectors
+// and a group kq of 8 features, lane l holds the float4
+//   ( v[l&31][8kq+0+h], v[l&31][8kq+2+h], v[l&31][8kq+4+h], v[l&31][8kq+6+h] ),  h = l >> 5,
+// so component i is the A (or B) operand of the MFMA that contracts features 8kq+2i, 8kq+2i+1
+// (v_mfma_f32_32x32x2_f32: A[i = l&31][k = l>>5], B[k = l>>5][j = l&31]).
+// tiled gallery (fir_kernels.h layout) -> fragment order + squared row norms.
+__global__ void __launch_bounds__(256) k_gemm_pack_gallery(const float4* __restrict__ gal4, int64_t n, int dp4, int dq8,
+                                                            float4* __restrict__ gm, float* __restrict__ gnorm) {
+    const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;      // float4 index in gm
+    const int64_t rblocks = (n + 31) / 32;
+    if (o >= rblocks * dq8 * 64) return;
+    const int l = (int)(o & 63);
+    const int64_t t = o >> 6;
+    const int kq = (int)(t % dq8);
+    const int64_t rb = t / dq8;
+    const int64_t row = rb * 32 + (l & 31);
+    const int h = l >> 5;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (row < n) {
+        const int64_t tile = row >> 6;
+        const int r = (int)(row & 63);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = 8 * kq + 2 * i + h;
+            if (k < dp4 * 4) {
+                const float4 g = gal4[(tile * dp4 + (k >> 2)) * 64 + r];
+                v[i] = (k & 3) == 0 ? g.x : (k & 3) == 1 ? g.y : (k & 3) == 2 ? g.z : g.w;
+            }
+        }
+    }
+    gm[o] = make_float4(v[0], v[1], v[2], v[3]);
+    if (kq == 0 && h == 0 && row < n) {      // one thread per row: its squared norm (any summation order: covered by E)
+        const int64_t tile = row >> 6;
+        const int r = (int)(row & 63);
+        float s = 0.f;
+        for (int c = 0; c < dp4; ++c) {
+            const float4 g = gal4[(tile * dp4 + c) * 64 + r];
+            s += g.x * g.x + g.y * g.y + g.z * g.z + g.w * g.w;
+        }
+        gnorm[row] = s;
+    }
+}
+
+// queries[nq][d] -> fragment order qm[jb][kq][lane] (float4), zero padded to kQT queries; qnorm[q] = |q|^2.
+__global__ void __launch_bounds__(256) k_gemm_pack_queries(const float* __restrict__ q, int nq, int d, int dq8, float4* __restrict__ qm) {
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o < (kQT / 32) * dq8 * 64) {
+        const int l = o & 63;
+        const int t = o >> 6;
+        const int kq = t % dq8, jb = t / dq8;
+        const int qi = jb * 32 + (l & 31), h = l >> 5;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (qi < nq) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int k = 8 * kq + 2 * i + h;
+                if (k < d) v[i] = q[(size_t)qi * d + k];
+            }
+        }
+        qm[o] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+// qnorm[q] = |q|^2 (one wave per query; any summation order is covered by the certificate's E).
+__global__ void __launch_bounds__(64) k_gemm_qnorm(const float* __restrict__ q, int nq, int d, float* __restrict__ qnorm) {
+    const int qi = blockIdx.x;
+    float s = 0.f;
+    if (qi < nq)
+        for (int k = threadIdx.x; k < d; k += 64) s += q[(size_t)qi * d + k] * q[(size_t)qi * d + k];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (threadIdx.x == 0) qnorm[qi] = s;
+}
+
+// One wave: 32 gallery rows x 64 queries; p = |g|^2 - 2 q.g.
+// MODE 0: store the proxies of rows < sample_rows into sample[q][row] (seeding tau).
+// MODE 1: append (p, row) with p < tau[q] to the query's list.
+// Dynamic LDS: the query tile in fragment order, 2 * dq8 * 64 float4.
+template <int MODE>
+__global__ void __launch_bounds__(kGemmBlock, 2) k_gemm_proxy(const float4* __restrict__ gm, const float* __restrict__ gnorm,
+                                                               const float4* __restrict__ qm, int64_t n, int64_t row_begin,
+                                                               int64_t row_end, int dq8, const float* __restrict__ tau,
+                                                               unsigned long long* __restrict__ lists, int* __restrict__ counts,
+                                                               float* __restrict__ sample, int sample_rows) {
+    extern __shared__ __attribute__((aligned(16))) float4 lq[];
+    __shared__ float tau_s[kQT];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < (kQT / 32) * dq8 * 64; i += kGemmBlock) lq[i] = qm[i];
+    if (MODE == 1 && threadIdx.x < kQT) tau_s[threadIdx.x] = tau[threadIdx.x];
+    __syncthreads();
+    const int64_t rb_begin = row_begin / 32, rb_end = (row_end + 31) / 32;
+    for (int64_t rb = rb_begin + (int64_t)blockIdx.x * (kGemmBlock / 64) + wave; rb < rb_end; rb += (int64_t)gridDim.x * (kGemmBlock / 64)) {
+        const float4* a = gm + (size_t)rb * dq8 * 64 + lane;
+        f32x16 acc0 = {0.f}, acc1 = {0.f};
+        // dq8 is a multiple of 4: EIGHT gallery fragments in flight (named registers, no runtime indexing), each
+        // re-issued right after its 8 MFMAs, i.e. 7 steps = 3 584 MFMA cycles (x2 with two waves per SIMD) ahead of
+        // its use -- with 2 waves per SIMD the loads must cover the HBM latency on their own.
+        const int last = dq8 - 1;
+        float4 a0 = a[0], a1 = a[(size_t)(1 < last ? 1 : last) * 64], a2 = a[(size_t)(2 < last ? 2 : last) * 64],
+               a3 = a[(size_t)(3 < last ? 3 : last) * 64], a4 = a[(size_t)(4 < last ? 4 : last) * 64],
+               a5 = a[(size_t)(5 < last ? 5 : last) * 64], a6 = a[(size_t)(6 < last ? 6 : last) * 64],
+               a7 = a[(size_t)(7 < last ? 7 : last) * 64];
+        // this wave's 32 squared row norms, one per lane (both halves), handed out by shuffles in the epilogue
+        const int64_t nrow = rb * 32 + (lane & 31);
+        const float gn_lane = nrow < n ? gnorm[nrow] : 0.0f;
+#define FIR_GEMM_STEP(AV, KQ)                                                          \
+        {                                                                              \
+            const float4 b0 = lq[(size_t)(KQ) * 64 + lane];                            \
+            const float4 b1 = lq[(size_t)(dq8 + (KQ)) * 64 + lane];                    \
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(AV.x, b0.x, acc0, 0, 0, 0);    \
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(AV.x, b1.x, acc1, 0, 0, 0);    \
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(AV.y, b0.y, acc0, 0, 0, 0);    \
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(AV.y, b1.y, acc1, 0, 0, 0);    \
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(AV.z, b0.z, acc0, 0, 0, 0);    \
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(AV.z, b1.z, acc1, 0, 0, 0);    \
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(AV.w, b0.w, acc0, 0, 0, 0);    \
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(AV.w, b1.w, acc1, 0, 0, 0);    \
+        }
+        for (int kq = 0; kq < dq8; kq += 8) {
+            // (the tail re-loads clamp to the last fragment: harmless L2 hits, keeps the loop branch-free)
+#define FIR_GEMM_NEXT(AV, OFF) AV = a[(size_t)(kq + (OFF) + 8 < dq8 ? kq + (OFF) + 8 : last) * 64];
+            FIR_GEMM_STEP(a0, kq)
+            FIR_GEMM_NEXT(a0, 0)
+            FIR_GEMM_STEP(a1, kq + 1)
+            FIR_GEMM_NEXT(a1, 1)
+            FIR_GEMM_STEP(a2, kq + 2)
+            FIR_GEMM_NEXT(a2, 2)
+            FIR_GEMM_STEP(a3, kq + 3)
+            FIR_GEMM_NEXT(a3, 3)
+            if (kq + 4 < dq8) {     // dq8 is a multiple of 4, not necessarily of 8
+                FIR_GEMM_STEP(a4, kq + 4)
+                FIR_GEMM_NEXT(a4, 4)
+                FIR_GEMM_STEP(a5, kq + 5)
+                FIR_GEMM_NEXT(a5, 5)
+                FIR_GEMM_STEP(a6, kq + 6)
+                FIR_GEMM_NEXT(a6, 6)
+                FIR_GEMM_STEP(a7, kq + 7)
+                FIR_GEMM_NEXT(a7, 7)
+            }
+#undef FIR_GEMM_NEXT
+        }
+#undef FIR_GEMM_STEP
+        // C/D layout of the 32x32 MFMA: column (query) = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) {
+            const int q = jb * 32 + (lane & 31);
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int roff = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                const int64_t row = rb * 32 + roff;
+                const float gn = __shfl(gn_lane, roff, 64);     // every lane takes part (before any divergence)
+                if (row >= n || row < row_begin || row >= row_end) continue;
+                const float dot = jb == 0 ? acc0[reg] : acc1[reg];
+                const float p = gn - 2.0f * dot;
+                if (MODE == 0) {
+                    if (row < sample_rows) sample[(size_t)q * sample_rows + row] = p;
+                } else if (p < tau_s[q]) {
+                    const int slot = atomicAdd(&counts[q], 1);
+                    if (slot < kListCap) lists[(size_t)q * kListCap + slot] = fir::key_pack(p, (uint32_t)row);
+                }
+            }
+        }
+    }
+}
+
+// tau[q] = kCand-th smallest sampled proxy, nudged up so that ties with it are appended too. One block per
+// query, ONE pass over the samples: every thread keeps its kCand smallest keys sorted in registers, then kCand
+// rounds of block-min pop the global order statistics.
+__global__ void __launch_bounds__(256) k_gemm_tau(const float* __restrict__ sample, int sample_rows, float* __restrict__ tau) {
+    __shared__ unsigned long long red[4];
+    const int q = blockIdx.x;
+    const float* s = sample + (size_t)q * sample_rows;
+    unsigned long long best[kCand];
+#pragma unroll
+    for (int i = 0; i < kCand; ++i) best[i] = kKeyNone;
+    for (int i = threadIdx.x; i < sample_rows; i += 256) {
+        unsigned long long v = fir::key_pack(s[i], (uint32_t)i);
+        if (v < best[kCand - 1]) {
+#pragma unroll
+            for (int j = 0; j < kCand; ++j) {
+                const bool sw = v < best[j];
+                const unsigned long long t = best[j];
+                best[j] = sw ? v : t;
+                v = sw ? t : v;
+            }
+        }
+    }
+    unsigned long long m = kKeyNone;
+    for (int r = 0; r < kCand; ++r) {
+        unsigned long long c = fir::wave_min_u64(best[0]);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+        __syncthreads();
+        m = red[0];
+        for (int i = 1; i < 4; ++i) m = red[i] < m ? red[i] : m;
+        if (m == kKeyNone) break;
+        if (best[0] == m) {     // keys are unique (row index): exactly one thread pops
+#pragma unroll
+            for (int j = 0; j + 1 < kCand; ++j) best[j] = best[j + 1];
+            best[kCand - 1] = kKeyNone;
+        }
+    }
+    if (threadIdx.x == 0) {
+        // fewer than kCand sampled rows: no bound -> +inf appends everything (the list cap then decides)
+        float t = __builtin_huge_valf();
+        if (m != kKeyNone) {
+            const float v = fir::f32_from_orderable((uint32_t)(m >> 32));
+            t = v + fabsf(v) * 1e-6f + 1e-30f;
+        }
+        tau[q] = t;
+    }
+}
+
+// Per query: the kCand best appended entries, re-ranked with the reference's arithmetic; certificate.
+// One wave per query. out_key[q] = exact packed key; ok[q] = 1 when the certificate holds.
+__global__ void __launch_bounds__(64) k_gemm_rerank(const unsigned long long* __restrict__ lists, const int* __restrict__ counts,
+                                                     const float* __restrict__ tau, const float4* __restrict__ gal4,
+                                                     const float* __restrict__ queries, const float* __restrict__ qnorm,
+                                                     const float* __restrict__ gnorm_max_p, int64_t n, int d, int dp4, int64_t row_offset,
+                                                     unsigned long long* __restrict__ out_key, int* __restrict__ ok) {
+    const int q = blockIdx.x, lane = threadIdx.x;
+    const int cnt = counts[q];
+    const int have = cnt < kListCap ? cnt : kListCap;
+    const unsigned long long* L = lists + (size_t)q * kListCap;
+    // kCand rounds of wave-min over the list ("smallest key greater than the previous winner")
+    unsigned long long pick[kCand];
+    unsigned long long prev = 0;
+    bool first = true;
+    int got = 0;
+#pragma unroll
+    for (int r = 0; r < kCand; ++r) {
+        unsigned long long cand = kKeyNone;
+        if (first || prev != kKeyNone) {
+            for (int i = lane; i < have; i += 64) {
+                const unsigned long long v = L[i];
+                if ((first || v > prev) && v < cand) cand = v;
+            }
+        }
+        cand = fir::wave_min_u64(cand);
+        pick[r] = cand;
+        if (cand != kKeyNone) ++got;
+        prev = cand;
+        first = false;
+    }
+    unsigned long long last_pick = pick[0];
+#pragma unroll
+    for (int r = 1; r < kCand; ++r) last_pick = pick[r] != kKeyNone ? pick[r] : last_pick;
+    // the picked rows go to LDS with all 64 lanes loading (kCand x dp4 float4), then lane c re-computes candidate c's
+    // distance from there: db_features.cpp:22-42 order, un-fused (fir::accum<kL2>)
+    extern __shared__ __attribute__((aligned(16))) float4 crow[];     // [kCand][dp4]
+    for (int i = lane; i < kCand * dp4; i += 64) {
+        const int cnd = i / dp4, c = i - cnd * dp4;
+        unsigned long long pk = pick[0];
+#pragma unroll
+        for (int r = 1; r < kCand; ++r) pk = cnd == r ? pick[r] : pk;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (pk != kKeyNone) {
+            const int64_t row = (int64_t)(uint32_t)(pk & 0xFFFFFFFFull);
+            v = gal4[((row >> 6) * dp4 + c) * 64 + (row & 63)];
+        }
+        crow[i] = v;
+    }
+    __syncthreads();
+    unsigned long long key = kKeyNone;
+    if (lane < got) {
+        unsigned long long mine = pick[0];
+#pragma unroll
+        for (int r = 1; r < kCand; ++r) mine = lane == r ? pick[r] : mine;
+        const int64_t row = (int64_t)(uint32_t)(mine & 0xFFFFFFFFull);
+        const float* qv = queries + (size_t)q * d;
+        const float4* my = crow + (size_t)lane * dp4;
+        float acc = 0.0f;
+        for (int c = 0; c < dp4; ++c) {
+            const float4 g = my[c];
+            const float gv[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = c * 4 + j;
+                if (k < d) acc = fir::accum<fir::kL2>(acc, qv[k], gv[j]);
+            }
+        }
+        const float dist = acc / (float)d;
+        if (dist < fir::kNotFound) key = fir::key_pack(dist, (uint32_t)(row + row_offset));
+    }
+    key = fir::wave_min_u64(key);
+    if (lane == 0) {
+        out_key[q] = key;
+        // Certificate. Every row NOT re-ranked has proxy >= p_excl: the kCand-th picked proxy when the list held more,
+        // else tau (nothing below tau was left out). Its reference distance is then >= (|q|^2 + p_excl)/d - E.
+        bool certified = false;
+        if (cnt <= kListCap) {                      // nothing below tau was dropped from the list
+            // rows not re-ranked: never appended (p >= tau) or appended but beyond the kCand picks (p >= last pick's)
+            const float p_excl = have > got ? fir::f32_from_orderable((uint32_t)(last_pick >> 32)) : tau[q];
+            const float qn = qnorm[q], gmax = gnorm_max_p[0];
+            // E bounds every rounding on both sides, in distance units: the f32 fma chain of the dot product
+            // (<= d u |q||g|, doubled), the two float norms (<= d u each), the reference's own d+3 roundings of the
+            // (q-g)^2 sum and its divide: (4d + 11) u (|q|^2 + |g|^2) / d in total; 8 d u (...) / d is used.  u = 2^-24.
+            const float E = 8.0f * (float)d * 5.9604645e-8f * (qn + gmax) / (float)d;
+            const float lower = (qn + p_excl) / (float)d - E;
+            const float best = key != kKeyNone ? fir::f32_from_orderable((uint32_t)(key >> 32)) : fir::kNotFound;
+            certified = lower > best;               // false for NaN
+            if (n <= got) certified = true;         // every row was re-ranked
+        }
+        ok[q] = certified ? 1 : 0;
+    }
+}
+
+__global__ void k_gemm_max(const float* __restrict__ gnorm, int64_t n, float* __restrict__ out) {
+    __shared__ float red[4];
+    float m = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 256) m = fmaxf(m, gnorm[i]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+}  // namespace
+
+struct fir_gemm {
+    fir_gallery* g = nullptr;
+    fir_gallery_view v;
+    const float4* gal4 = nullptr;
+    int dp4 = 0, dq8 = 0;
+    float4* gm = nullptr;
+    float* gnorm = nullptr;
+    float* gmax = nullptr;
+    float4* qm = nullptr;
+    float* qnorm = nullptr;
+    float* tau = nullptr;
+    float* sample = nullptr;
+    unsigned long long* lists = nullptr;
+    int* counts = nullptr;
+    int* ok = nullptr; size_t ok_cap = 0;  // certificate flags of one call
+    int sample_rows = 0;
+    float* fbq = nullptr;                 // fallback queries (device)
+    unsigned long long* fbkeys = nullptr;
+    int64_t passes = 0, fallbacks = 0;
+};
+
+
+
+extern "C" {
+
+int fir_gemm_create(fir_gallery* g, fir_gemm** out) {
+    if (!g || !out) return gemm_fail(FIR_ERR_ARG, "NULL argument");
+    *out = nullptr;
+    fir_gemm* m = new (std::nothrow) fir_gemm();
+    if (!m) return gemm_fail(FIR_ERR_NOMEM, "host allocation failed");
+    m->g = g;
+    const void* gp = nullptr;
+    if (fir_gallery_view_(g, &m->v) != FIR_OK || fir_gallery_tiled_(g, &gp, &m->dp4) != FIR_OK) { delete m; return gemm_fail(FIR_ERR_ARG, "bad gallery"); }
+    m->gal4 = (const float4*)gp;
+    m->dq8 = (m->v.d + 31) / 32 * 4;     // feature groups of 8, padded to a multiple of 4 groups (zeros)
+    if ((size_t)(kQT / 32) * m->dq8 * 64 * 16 > 150 * 1024) { delete m; return gemm_fail(FIR_ERR_ARG, "d=%d too large for the LDS query tile of the GEMM path", m->v.d); }
+    hipError_t e = hipSetDevice(m->v.device);
+    const int64_t rblocks = (std::max<int64_t>(m->v.n, 1) + 31) / 32;
+    const int64_t np = std::max<int64_t>(m->v.n, 1);
+    if (e == hipSuccess) e = hipMalloc((void**)&m->gm, (size_t)rblocks * m->dq8 * 64 * sizeof(float4));
+    if (e == hipSuccess) e = hipMalloc((void**)&m->gnorm, (size_t)np * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&m->gmax, 16);
+    if (e == hipSuccess) e = hipMalloc((void**)&m->qm, (size_t)(kQT / 32) * m->dq8 * 64 * sizeof(float4));
+    if (e == hipSuccess) e = hipMalloc((void**)&m->qnorm, kQT * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&m->tau, kQT * sizeof(float));
+    m->sample_rows = (int)std::min<int64_t>(np, std::max<int64_t>(kMinSampleRows, np / 64));
+    if (e == hipSuccess) e = hipMalloc((void**)&m->sample, (size_t)kQT * m->sample_rows * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&m->lists, (size_t)kQT * kListCap * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void**)&m->counts, kQT * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void**)&m->fbq, (size_t)kQT * m->v.d * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&m->fbkeys, kQT * sizeof(unsigned long long));
+    const int lds_bytes = (kQT / 32) * m->dq8 * 64 * (int)sizeof(float4);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (e == hipSuccess && m->v.n > 0) {
+        const int64_t total = rblocks * m->dq8 * 64;
+        hipLaunchKernelGGL(k_gemm_pack_gallery, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, m->v.stream, m->gal4, m->v.n, m->dp4, m->dq8,
+                           m->gm, m->gnorm);
+        hipLaunchKernelGGL(k_gemm_max, dim3(1), dim3(256), 0, m->v.stream, m->gnorm, m->v.n, m->gmax);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(m->v.stream);
+    }
+    if (e != hipSuccess) {
+        const int rc = gemm_fail(e == hipErrorOutOfMemory ? FIR_ERR_NOMEM : FIR_ERR_HIP, "GEMM-path setup: %s", hipGetErrorString(e));
+        fir_gemm_destroy(m);
+        return rc;
+    }
+    *out = m;
+    return FIR_OK;
+}
+
+int fir_gemm_destroy(fir_gemm* m) {
+    if (!m) return FIR_OK;
+    (void)hipSetDevice(m->v.device);
+    (void)hipStreamSynchronize(m->v.stream);
+    (void)hipFree(m->gm); (void)hipFree(m->gnorm); (void)hipFree(m->gmax); (void)hipFree(m->qm); (void)hipFree(m->qnorm);
+    (void)hipFree(m->tau); (void)hipFree(m->sample); (void)hipFree(m->lists); (void)hipFree(m->counts); (void)hipFree(m->ok);
+    (void)hipFree(m->fbq); (void)hipFree(m->fbkeys);
+    delete m;
+    return FIR_OK;
+}
+
+int fir_gemm_stats(const fir_gemm* m, int64_t* passes, int64_t* fallback_queries) {
+    if (!m) return gemm_fail(FIR_ERR_ARG, "NULL argument");
+    if (passes) *passes = m->passes;
+    if (fallback_queries) *fallback_queries = m->fallbacks;
+    return FIR_OK;
+}
+
+// d_queries / d_keys: device pointers. All passes are queued first; the certificates of the whole batch are read
+// back with ONE stream synchronisation, then the uncertified queries (if any) go through the exact scan.
+int fir_gemm_search_top1_keys_dev(fir_gemm* m, const float* d_queries, int32_t qb, uint64_t* d_keys, void* stream) {
+    if (!m || !d_keys || (qb > 0 && !d_queries)) return gemm_fail(FIR_ERR_ARG, "NULL argument");
+    if (qb < 0) return gemm_fail(FIR_ERR_ARG, "qb < 0");
+    if (qb == 0) return FIR_OK;
+    GEMM_HIP(hipSetDevice(m->v.device));
+    hipStream_t st = stream ? (hipStream_t)stream : m->v.stream;
+    const int d = m->v.d;
+    const int64_t n = m->v.n;
+    if (n == 0) return fir_search_top1_keys_dev(m->g, d_queries, qb, 0, 0, d_keys, st);
+    if ((size_t)qb > m->ok_cap) {
+        if (m->ok) GEMM_HIP(hipFree(m->ok));
+        m->ok = nullptr;
+        m->ok_cap = 0;
+        GEMM_HIP(hipMalloc((void**)&m->ok, (size_t)std::max(qb, 1024) * sizeof(int)));
+        m->ok_cap = (size_t)std::max(qb, 1024);
+    }
+    const size_t lds = (size_t)(kQT / 32) * m->dq8 * 64 * sizeof(float4);
+    const int grid = m->v.cus;      // one 512-thread workgroup per CU
+    const int sample_rows = m->sample_rows;
+    for (int q0 = 0; q0 < qb; q0 += kQT) {
+        const int nq = std::min(kQT, qb - q0);
+        const float* dq = d_queries + (size_t)q0 * d;
+        hipLaunchKernelGGL(k_gemm_pack_queries, dim3(((kQT / 32) * m->dq8 * 64 + 255) / 256), dim3(256), 0, st, dq, nq, d, m->dq8, m->qm);
+        hipLaunchKernelGGL(k_gemm_qnorm, dim3(kQT), dim3(64), 0, st, dq, nq, d, m->qnorm);
+        GEMM_HIP(hipMemsetAsync(m->counts, 0, kQT * sizeof(int), st));
+        hipLaunchKernelGGL(k_gemm_proxy<0>, dim3(std::min(grid, (sample_rows + kRowsPerBlock - 1) / kRowsPerBlock)), dim3(kGemmBlock), lds, st, m->gm,
+                           m->gnorm, m->qm, n, (int64_t)0, (int64_t)sample_rows, m->dq8, m->tau, m->lists, m->counts, m->sample, sample_rows);
+        hipLaunchKernelGGL(k_gemm_tau, dim3(kQT), dim3(256), 0, st, m->sample, sample_rows, m->tau);
+        hipLaunchKernelGGL(k_gemm_proxy<1>, dim3(grid), dim3(kGemmBlock), lds, st, m->gm, m->gnorm, m->qm, n, (int64_t)0, n, m->dq8, m->tau, m->lists,
+                           m->counts, m->sample, sample_rows);
+        hipLaunchKernelGGL(k_gemm_rerank, dim3(nq), dim3(64), (size_t)kCand * m->dp4 * sizeof(float4), st, m->lists, m->counts, m->tau, m->gal4, dq,
+                           m->qnorm, m->gmax, n, d, m->dp4, m->v.row_offset, (unsigned long long*)d_keys + q0, m->ok + q0);
+        ++m->passes;
+    }
+    GEMM_HIP(hipGetLastError());
+    std::vector<int> h_ok((size_t)qb);
+    GEMM_HIP(hipMemcpyAsync(h_ok.data(), m->ok, (size_t)qb * sizeof(int), hipMemcpyDeviceToHost, st));
+    GEMM_HIP(hipStreamSynchronize(st));
+    // uncertified queries: the exact streaming scan answers them, kQT at a time
+    std::vector<int> which;
+    for (int i = 0; i < qb; ++i)
+        if (!h_ok[(size_t)i]) which.push_back(i);
+    m->fallbacks += (int64_t)which.size();
+    for (size_t f0 = 0; f0 < which.size(); f0 += kQT) {
+        const int nf = (int)std::min<size_t>(kQT, which.size() - f0);
+        for (int i = 0; i < nf; ++i)
+            GEMM_HIP(hipMemcpyAsync(m->fbq + (size_t)i * d, d_queries + (size_t)which[f0 + i] * d, (size_t)d * sizeof(float), hipMemcpyDeviceToDevice, st));
+        int rc = fir_search_top1_keys_dev(m->g, m->fbq, nf, 0, 0, (uint64_t*)m->fbkeys, st);
+        if (rc) return rc;
+        for (int i = 0; i < nf; ++i)
+            GEMM_HIP(hipMemcpyAsync(d_keys + which[f0 + i], m->fbkeys + i, sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
+    }
+    return FIR_OK;
+}
+
+}  // extern "C"

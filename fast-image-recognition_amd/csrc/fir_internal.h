@@ -17,3 +17,4 @@ struct fir_gallery_view {
 };
 extern "C" int fir_gallery_view_(fir_gallery* g, fir_gallery_view* out);
 extern "C" void fir_set_last_error_(const char* msg);
+extern "C" int fir_gallery_tiled_(fir_gallery* g, const void** gal4, int* dp4);   // the tiled f32 gallery (fir_kernels.h layout)

@@ -163,6 +163,18 @@ int fir_cls_pnn_predict_seq(fir_cls* c, const double* queries, int32_t qb, doubl
  * class until one class has k votes. 1 <= k <= 8. best_class[qb]. */
 int fir_cls_knn_predict(fir_cls* c, const double* queries, int32_t qb, int32_t k, int32_t* best_class);
 
+/* ---- large query batches through the matrix cores (L2, whole feature range) ------------------------
+ * Same answers as fir_search_top1 -- bit-identical index and distance: an f32-MFMA GEMM only nominates
+ * candidate rows, the reference's arithmetic re-ranks them, a rounding-error certificate proves no other
+ * row can win, and uncertified queries are re-run through the exact streaming scan (fir_gemm.hip).
+ * Costs one extra copy of the gallery in MFMA fragment order. The gallery handle must outlive it. */
+typedef struct fir_gemm fir_gemm;
+int fir_gemm_create(fir_gallery* g, fir_gemm** out);
+int fir_gemm_destroy(fir_gemm* m);
+int fir_gemm_search_top1_keys_dev(fir_gemm* m, const float* d_queries, int32_t qb, uint64_t* d_keys, void* stream);
+/* passes = 64-query GEMM passes run so far, fallback_queries = queries answered by the exact scan instead. */
+int fir_gemm_stats(const fir_gemm* m, int64_t* passes, int64_t* fallback_queries);
+
 /* ---- profiling ------------------------------------------------------------------------------
  * When enabled, every gallery-scan kernel launch is bracketed by HIP events on the stream it
  * is launched on. fir_profile_read waits for them and returns the launch durations (ms) in

@@ -1,0 +1,71 @@
+"""The matrix-core path (fir_gemm_*) must return exactly what the exact scan returns -- index and
+distance bit-for-bit -- on easy data, on adversarial data (many near ties: more than the re-ranked
+candidates), with duplicates, NaN rows and odd shapes; the certificate / fallback makes it so."""
+import numpy as np
+import pytest
+import torch
+
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def run_both(fir, rows, q):
+    dev = torch.device("cuda", 0)
+    with fir.Gallery(rows, None, 0, 0) as g:
+        eidx, edist = g.search_top1(q)
+        tq = torch.from_numpy(np.ascontiguousarray(q, np.float32)).to(dev)
+        keys = torch.empty(q.shape[0], dtype=torch.int64, device=dev)
+        with fir.GemmSearch(g) as m:
+            m.search_top1_keys_dev(tq.data_ptr(), q.shape[0], keys.data_ptr())
+            torch.cuda.synchronize()
+            st = m.stats()
+        idx, dist = fir.keys_unpack(keys.cpu().numpy().view(np.uint64))
+    return (idx, dist), (eidx, edist), st
+
+
+@pytest.mark.parametrize("seed,n,d,qb", [(1, 5000, 512, 70), (2, 40000, 512, 64), (3, 1000, 256, 5), (4, 333, 100, 130), (5, 7, 64, 3), (6, 70000, 128, 200)])
+def test_gemm_equals_scan(fir, oracle, seed, n, d, qb):
+    rows = synth.make_gallery(seed, n, d, 0)
+    q, _ = synth.make_queries(seed, rows, qb, 0)
+    (idx, dist), (eidx, edist), st = run_both(fir, rows, q)
+    assert np.array_equal(idx, eidx)
+    assert np.array_equal(dist.view(np.uint32), edist.view(np.uint32))
+    for i in (0, qb - 1):
+        assert (idx[i], dist[i]) == oracle.recognize_bf(rows, q[i], 0, d, 0)
+    assert st["fallback_queries"] <= qb // 4 + 2, st      # the certificate normally holds on random data
+
+
+def test_gemm_adversarial_near_ties_and_duplicates(fir, oracle):
+    """20 rows within a few ulps of the best (more than the 8 re-ranked candidates), exact duplicates of the best,
+    a NaN row and unnormalised rows: the certificate must refuse and the exact scan must answer."""
+    n, d = 30000, 512
+    rows = synth.make_gallery(9, n, d, 0)
+    q, pick = synth.make_queries(9, rows, 12, 0)
+    base = rows[777].copy()
+    for j in range(20):                       # near-duplicates of one row, spread over the gallery
+        v = base.copy()
+        v[j] = np.nextafter(v[j], np.float32(2), dtype=np.float32)
+        rows[1000 + 1400 * j] = v
+    q[0] = base
+    q[1] = base * np.float32(1.0000001)
+    for r in (5, 29999, 12345):               # exact duplicates: the lowest row must win
+        rows[r] = rows[4242]
+    q[2] = rows[4242]
+    rows[100] = np.nan
+    rows[200] *= np.float32(50.0)             # a long row: |g|^2 enters the proxy and the error bound
+    q[3] = rows[200]
+    (idx, dist), (eidx, edist), st = run_both(fir, rows, q)
+    assert np.array_equal(idx, eidx)
+    assert np.array_equal(dist.view(np.uint32), edist.view(np.uint32))
+    assert idx[2] == 5 and dist[2] == 0
+    assert st["fallback_queries"] >= 1        # the near-tie queries cannot be certified with 8 candidates
+    for i in range(4):
+        assert (idx[i], dist[i]) == oracle.recognize_bf(rows, q[i], 0, d, 0)
+
+
+def test_gemm_nothing_found(fir):
+    rows = np.full((300, 64), 1.0e4, np.float32)
+    q = np.zeros((3, 64), np.float32)
+    (idx, dist), (eidx, edist), _ = run_both(fir, rows, q)
+    assert np.all(idx == -1) and np.array_equal(idx, eidx) and np.array_equal(dist, edist)
