@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--qpp", type=int, default=0, help="queries per gallery pass (0 = library default)")
     ap.add_argument("--waves", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--no-mfma", action="store_true", help="skip the (untimed) matrix-core cross-check of the same step")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' rehearses the N>1 path with all ranks on ONE GPU")
     args = ap.parse_args()
 
@@ -157,6 +158,24 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # outside the timed region: the same step through the matrix-core path (fir_gemm_*), which must return the same keys
+    mfma = None
+    if world == 1 and not args.no_mfma:
+        gm = fir.GemmSearch(g)
+        k2 = torch.empty_like(keys)
+        with torch.cuda.stream(work_stream):
+            gm.search_top1_keys_dev(q.data_ptr(), qb, k2.data_ptr(), stream=stream)
+            torch.cuda.synchronize()
+            tg0 = time.perf_counter()
+            for _ in range(5):
+                gm.search_top1_keys_dev(q.data_ptr(), qb, k2.data_ptr(), stream=stream)
+            torch.cuda.synchronize()
+            tg = (time.perf_counter() - tg0) / 5
+        mfma = {"queries_per_s": qb / tg, "ms_per_step": tg * 1e3, "tflops_dot_products": 2.0 * n * d * qb / tg / 1e12,
+                "peak_tflops_f32_mfma": 157.3, "identical_keys_to_scan": bool(torch.equal(keys, k2)),
+                "fallback_queries": gm.stats()["fallback_queries"]}
+        gm.close()
+
     idx, dd = fir.keys_unpack(keys.cpu().numpy().view(np.uint64))
     # size-independent property at full size: every planted query finds its source row, closer than any fresh one does
     planted = planted_rows.cpu().numpy()
@@ -190,6 +209,7 @@ def main():
                 "waves": tuning["waves"],
                 "row_sharding": f"{world} shard(s) of {row_hi - row_lo} rows",
                 "planted_queries_found": planted_ok,
+                "same_step_through_mfma_path": mfma,
             },
             "roofline": {
                 "bound": "hbm",

@@ -34,8 +34,6 @@ using fir::kKeyNone;
 
 constexpr int kGemmBlock = 512;        // 8 waves: 2 per SIMD
 constexpr int kQT = 64;                // queries per pass (2 accumulator tiles of 32 per wave)
-constexpr int kRowsPerWave = 32;
-constexpr int kRowsPerBlock = kRowsPerWave * (kGemmBlock / 64);   // 256
 constexpr int kCand = 8;               // candidates re-ranked exactly per query
 constexpr int kListCap = 4096;         // appended (proxy, row) entries per query before "overflow"
 constexpr int kMinSampleRows = 8192;   // rows whose proxies seed tau: max(8192, n / 64) -> ~512 appended rows per query
@@ -145,11 +143,12 @@ __global__ void __launch_bounds__(kGemmBlock, 2) k_gemm_proxy(const float4* __re
     extern __shared__ __attribute__((aligned(16))) float4 lq[];
     __shared__ float tau_s[kQT];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < (kQT / 32) * dq8 * 64; i += kGemmBlock) lq[i] = qm[i];
+    const int wpb = blockDim.x >> 6;      // 8 waves for the full pass, 2 for the (short) sample pass so that it covers every CU
+    for (int i = threadIdx.x; i < (kQT / 32) * dq8 * 64; i += blockDim.x) lq[i] = qm[i];
     if (MODE == 1 && threadIdx.x < kQT) tau_s[threadIdx.x] = tau[threadIdx.x];
     __syncthreads();
     const int64_t rb_begin = row_begin / 32, rb_end = (row_end + 31) / 32;
-    for (int64_t rb = rb_begin + (int64_t)blockIdx.x * (kGemmBlock / 64) + wave; rb < rb_end; rb += (int64_t)gridDim.x * (kGemmBlock / 64)) {
+    for (int64_t rb = rb_begin + (int64_t)blockIdx.x * wpb + wave; rb < rb_end; rb += (int64_t)gridDim.x * wpb) {
         const float4* a = gm + (size_t)rb * dq8 * 64 + lane;
         f32x16 acc0 = {0.f}, acc1 = {0.f};
         // dq8 is a multiple of 4: EIGHT gallery fragments in flight (named registers, no runtime indexing), each
@@ -163,10 +162,15 @@ __global__ void __launch_bounds__(kGemmBlock, 2) k_gemm_proxy(const float4* __re
         // this wave's 32 squared row norms, one per lane (both halves), handed out by shuffles in the epilogue
         const int64_t nrow = rb * 32 + (lane & 31);
         const float gn_lane = nrow < n ? gnorm[nrow] : 0.0f;
+        // query fragments come from LDS one step AHEAD of the MFMAs that use them (b0/b1 = this step, n0/n1 = next):
+        // issued back to back with the matrix ops, an un-prefetched ds_read leaves the matrix pipe idle ~25 % of the time
+        float4 b0 = lq[lane], b1 = lq[(size_t)dq8 * 64 + lane];
 #define FIR_GEMM_STEP(AV, KQ)                                                          \
         {                                                                              \
-            const float4 b0 = lq[(size_t)(KQ) * 64 + lane];                            \
-            const float4 b1 = lq[(size_t)(dq8 + (KQ)) * 64 + lane];                    \
+            const int kn = (KQ) + 1 < dq8 ? (KQ) + 1 : (KQ);                           \
+            const float4 n0 = lq[(size_t)kn * 64 + lane];                              \
+            const float4 n1 = lq[(size_t)(dq8 + kn) * 64 + lane];                      \
+            __builtin_amdgcn_sched_barrier(0); /* keep the two ds_reads up here */    \
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(AV.x, b0.x, acc0, 0, 0, 0);    \
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(AV.x, b1.x, acc1, 0, 0, 0);    \
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(AV.y, b0.y, acc0, 0, 0, 0);    \
@@ -175,6 +179,8 @@ __global__ void __launch_bounds__(kGemmBlock, 2) k_gemm_proxy(const float4* __re
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(AV.z, b1.z, acc1, 0, 0, 0);    \
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(AV.w, b0.w, acc0, 0, 0, 0);    \
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(AV.w, b1.w, acc1, 0, 0, 0);    \
+            b0 = n0;                                                                   \
+            b1 = n1;                                                                   \
         }
         for (int kq = 0; kq < dq8; kq += 8) {
             // (the tail re-loads clamp to the last fragment: harmless L2 hits, keeps the loop branch-free)
@@ -386,12 +392,15 @@ struct fir_gemm {
     float4* gm = nullptr;
     float* gnorm = nullptr;
     float* gmax = nullptr;
-    float4* qm = nullptr;
-    float* qnorm = nullptr;
-    float* tau = nullptr;
+    // two sets of per-pass scratch: the re-rank of pass i runs on a side stream while pass i+1 is computed
+    float4* qm[2] = {nullptr, nullptr};
+    float* qnorm[2] = {nullptr, nullptr};
+    float* tau[2] = {nullptr, nullptr};
     float* sample = nullptr;
-    unsigned long long* lists = nullptr;
-    int* counts = nullptr;
+    unsigned long long* lists[2] = {nullptr, nullptr};
+    int* counts[2] = {nullptr, nullptr};
+    hipStream_t side = nullptr;
+    hipEvent_t main_done[2] = {nullptr, nullptr}, rerank_done[2] = {nullptr, nullptr};
     int* ok = nullptr; size_t ok_cap = 0;  // certificate flags of one call
     int sample_rows = 0;
     float* fbq = nullptr;                 // fallback queries (device)
@@ -420,13 +429,18 @@ int fir_gemm_create(fir_gallery* g, fir_gemm** out) {
     if (e == hipSuccess) e = hipMalloc((void**)&m->gm, (size_t)rblocks * m->dq8 * 64 * sizeof(float4));
     if (e == hipSuccess) e = hipMalloc((void**)&m->gnorm, (size_t)np * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&m->gmax, 16);
-    if (e == hipSuccess) e = hipMalloc((void**)&m->qm, (size_t)(kQT / 32) * m->dq8 * 64 * sizeof(float4));
-    if (e == hipSuccess) e = hipMalloc((void**)&m->qnorm, kQT * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc((void**)&m->tau, kQT * sizeof(float));
+    for (int b = 0; b < 2; ++b) {
+        if (e == hipSuccess) e = hipMalloc((void**)&m->qm[b], (size_t)(kQT / 32) * m->dq8 * 64 * sizeof(float4));
+        if (e == hipSuccess) e = hipMalloc((void**)&m->qnorm[b], kQT * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc((void**)&m->tau[b], kQT * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc((void**)&m->lists[b], (size_t)kQT * kListCap * sizeof(unsigned long long));
+        if (e == hipSuccess) e = hipMalloc((void**)&m->counts[b], kQT * sizeof(int));
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&m->main_done[b], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&m->rerank_done[b], hipEventDisableTiming);
+    }
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking);
     m->sample_rows = (int)std::min<int64_t>(np, std::max<int64_t>(kMinSampleRows, np / 64));
     if (e == hipSuccess) e = hipMalloc((void**)&m->sample, (size_t)kQT * m->sample_rows * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc((void**)&m->lists, (size_t)kQT * kListCap * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMalloc((void**)&m->counts, kQT * sizeof(int));
     if (e == hipSuccess) e = hipMalloc((void**)&m->fbq, (size_t)kQT * m->v.d * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&m->fbkeys, kQT * sizeof(unsigned long long));
     const int lds_bytes = (kQT / 32) * m->dq8 * 64 * (int)sizeof(float4);
@@ -453,8 +467,13 @@ int fir_gemm_destroy(fir_gemm* m) {
     if (!m) return FIR_OK;
     (void)hipSetDevice(m->v.device);
     (void)hipStreamSynchronize(m->v.stream);
-    (void)hipFree(m->gm); (void)hipFree(m->gnorm); (void)hipFree(m->gmax); (void)hipFree(m->qm); (void)hipFree(m->qnorm);
-    (void)hipFree(m->tau); (void)hipFree(m->sample); (void)hipFree(m->lists); (void)hipFree(m->counts); (void)hipFree(m->ok);
+    if (m->side) { (void)hipStreamSynchronize(m->side); (void)hipStreamDestroy(m->side); }
+    for (int b = 0; b < 2; ++b) {
+        (void)hipFree(m->qm[b]); (void)hipFree(m->qnorm[b]); (void)hipFree(m->tau[b]); (void)hipFree(m->lists[b]); (void)hipFree(m->counts[b]);
+        if (m->main_done[b]) (void)hipEventDestroy(m->main_done[b]);
+        if (m->rerank_done[b]) (void)hipEventDestroy(m->rerank_done[b]);
+    }
+    (void)hipFree(m->gm); (void)hipFree(m->gnorm); (void)hipFree(m->gmax); (void)hipFree(m->sample); (void)hipFree(m->ok);
     (void)hipFree(m->fbq); (void)hipFree(m->fbkeys);
     delete m;
     return FIR_OK;
@@ -488,21 +507,29 @@ int fir_gemm_search_top1_keys_dev(fir_gemm* m, const float* d_queries, int32_t q
     const size_t lds = (size_t)(kQT / 32) * m->dq8 * 64 * sizeof(float4);
     const int grid = m->v.cus;      // one 512-thread workgroup per CU
     const int sample_rows = m->sample_rows;
-    for (int q0 = 0; q0 < qb; q0 += kQT) {
+    int pass = 0;
+    for (int q0 = 0; q0 < qb; q0 += kQT, ++pass) {
         const int nq = std::min(kQT, qb - q0);
+        const int b = pass & 1;
         const float* dq = d_queries + (size_t)q0 * d;
-        hipLaunchKernelGGL(k_gemm_pack_queries, dim3(((kQT / 32) * m->dq8 * 64 + 255) / 256), dim3(256), 0, st, dq, nq, d, m->dq8, m->qm);
-        hipLaunchKernelGGL(k_gemm_qnorm, dim3(kQT), dim3(64), 0, st, dq, nq, d, m->qnorm);
-        GEMM_HIP(hipMemsetAsync(m->counts, 0, kQT * sizeof(int), st));
-        hipLaunchKernelGGL(k_gemm_proxy<0>, dim3(std::min(grid, (sample_rows + kRowsPerBlock - 1) / kRowsPerBlock)), dim3(kGemmBlock), lds, st, m->gm,
-                           m->gnorm, m->qm, n, (int64_t)0, (int64_t)sample_rows, m->dq8, m->tau, m->lists, m->counts, m->sample, sample_rows);
-        hipLaunchKernelGGL(k_gemm_tau, dim3(kQT), dim3(256), 0, st, m->sample, sample_rows, m->tau);
-        hipLaunchKernelGGL(k_gemm_proxy<1>, dim3(grid), dim3(kGemmBlock), lds, st, m->gm, m->gnorm, m->qm, n, (int64_t)0, n, m->dq8, m->tau, m->lists,
-                           m->counts, m->sample, sample_rows);
-        hipLaunchKernelGGL(k_gemm_rerank, dim3(nq), dim3(64), (size_t)kCand * m->dp4 * sizeof(float4), st, m->lists, m->counts, m->tau, m->gal4, dq,
-                           m->qnorm, m->gmax, n, d, m->dp4, m->v.row_offset, (unsigned long long*)d_keys + q0, m->ok + q0);
+        if (pass >= 2) GEMM_HIP(hipStreamWaitEvent(st, m->rerank_done[b], 0));     // scratch set b is free again
+        hipLaunchKernelGGL(k_gemm_pack_queries, dim3(((kQT / 32) * m->dq8 * 64 + 255) / 256), dim3(256), 0, st, dq, nq, d, m->dq8, m->qm[b]);
+        hipLaunchKernelGGL(k_gemm_qnorm, dim3(kQT), dim3(64), 0, st, dq, nq, d, m->qnorm[b]);
+        GEMM_HIP(hipMemsetAsync(m->counts[b], 0, kQT * sizeof(int), st));
+        hipLaunchKernelGGL(k_gemm_proxy<0>, dim3((sample_rows + 63) / 64), dim3(128), lds, st, m->gm, m->gnorm, m->qm[b], n, (int64_t)0,
+                           (int64_t)sample_rows, m->dq8, m->tau[b], m->lists[b], m->counts[b], m->sample, sample_rows);
+        hipLaunchKernelGGL(k_gemm_tau, dim3(kQT), dim3(256), 0, st, m->sample, sample_rows, m->tau[b]);
+        hipLaunchKernelGGL(k_gemm_proxy<1>, dim3(grid), dim3(kGemmBlock), lds, st, m->gm, m->gnorm, m->qm[b], n, (int64_t)0, n, m->dq8, m->tau[b],
+                           m->lists[b], m->counts[b], m->sample, sample_rows);
+        GEMM_HIP(hipEventRecord(m->main_done[b], st));
+        // exact re-rank + certificate of this pass on the side stream, under the next pass's GEMM
+        GEMM_HIP(hipStreamWaitEvent(m->side, m->main_done[b], 0));
+        hipLaunchKernelGGL(k_gemm_rerank, dim3(nq), dim3(64), (size_t)kCand * m->dp4 * sizeof(float4), m->side, m->lists[b], m->counts[b], m->tau[b],
+                           m->gal4, dq, m->qnorm[b], m->gmax, n, d, m->dp4, m->v.row_offset, (unsigned long long*)d_keys + q0, m->ok + q0);
+        GEMM_HIP(hipEventRecord(m->rerank_done[b], m->side));
         ++m->passes;
     }
+    for (int b = 0; b < 2 && b < pass; ++b) GEMM_HIP(hipStreamWaitEvent(st, m->rerank_done[b], 0));   // join the side stream
     GEMM_HIP(hipGetLastError());
     std::vector<int> h_ok((size_t)qb);
     GEMM_HIP(hipMemcpyAsync(h_ok.data(), m->ok, (size_t)qb * sizeof(int), hipMemcpyDeviceToHost, st));
