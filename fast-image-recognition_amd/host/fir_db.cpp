@@ -1,6 +1,7 @@
 // fir_db.cpp -- host side of the drop-in (see fir_db.h). IO, packing and handle caching only:
 // every distance is computed by libfir_amd.so on the GPU.
 #include "fir_db.h"
+#include "fir_loader.h"
 
 #include <algorithm>
 #include <cmath>
@@ -129,42 +130,23 @@ int recognize_image_bf(const std::vector<ImageInfo>& dbImages, const ImageInfo& 
 }
 
 // ---- feature file: "<path>\n<class>\n<f0> <f1> ... \n" per image (dnn_feature_extractor.py:58-64) ----
+// db_features.cpp:44-116 through the fast packed loader (fir_loader.cpp: memory-mapped, threaded, exact float
+// parsing; rows bit-identical to the reference's -- tests/test_host_loader.py), then scattered into the
+// reference's ImagesDatabase shape.
 int loadImages(ImagesDatabase& imagesDb, std::string features_file, std::unordered_map<std::string, int>& person2indexMap,
                bool /*early_stop*/) {
     person2indexMap.clear();
-    std::ifstream in(features_file);
-    int total = 0;
-    if (!in) return 0;                                               // silently empty, db_features.cpp:49,115
-    const bool l2 = fir::metric() == FIR_METRIC_L2;
-    std::string path_line, class_line, feat_line;
-    while (std::getline(in, path_line) && std::getline(in, class_line) && std::getline(in, feat_line)) {
-        class_line.erase(0, class_line.find_first_not_of(" \t\n\r\f\v"));
-        if (class_line.find("BACKGROUND_Google") != std::string::npos || class_line.find("257.clutter") != std::string::npos)
-            continue;                                                // db_features.cpp:60-64
-        auto it = person2indexMap.find(class_line);
-        if (it == person2indexMap.end()) {                           // class id = order of first appearance, :65-73
-            it = person2indexMap.emplace(class_line, (int)person2indexMap.size()).first;
-            imagesDb.emplace_back();
-        }
-        std::vector<FeaturesVector>& bucket = imagesDb[it->second];
-        bucket.emplace_back(FEATURES_COUNT);
-        FeaturesVector& f = bucket.back();
-        const char* p = feat_line.c_str();
-        float norm = 0.0f, v = 0.0f;
-        for (int i = 0; i < FEATURES_COUNT; ++i) {
-            char* end = nullptr;
-            const float parsed = std::strtof(p, &end);
-            v = (end != p) ? parsed : 0.0f;                          // a failed extraction stores 0 (C++11 num_get)
-            if (end != p) p = end;
-            if (std::fabs(v) < 0.0001) v = 0.0f;                     // :85-86
-            f[i] = v;
-            norm += l2 ? v * v : v;                                  // :88 / :91
-        }
-        if (l2) norm = std::sqrt(norm);                              // :95
-        for (int i = 0; i < FEATURES_COUNT; ++i) f[i] /= norm;       // :98-99
-        ++total;
+    fir::PackedFeatures packed;
+    const int64_t total = fir::load_features_packed(features_file, FEATURES_COUNT, fir::metric(), packed);
+    if (total <= 0) return 0;                                        // silently empty, db_features.cpp:49,115
+    const size_t first_new = imagesDb.size();                        // the reference appends to whatever the caller passed
+    imagesDb.resize(first_new + packed.class_names.size());
+    for (size_t c = 0; c < packed.class_names.size(); ++c) person2indexMap.emplace(packed.class_names[c], (int)c);
+    for (int64_t r = 0; r < packed.n; ++r) {
+        const float* src = &packed.rows[(size_t)r * FEATURES_COUNT];
+        imagesDb[first_new + (size_t)packed.class_no[(size_t)r]].emplace_back(src, src + FEATURES_COUNT);
     }
-    return total;
+    return (int)total;
 }
 
 void getTrainingAndTestImages(const ImagesDatabase& totalImages, std::vector<ImageInfo>& dbImages,

@@ -1,0 +1,93 @@
+"""The fast feature-file loader (fast-image-recognition_amd/host/fir_loader.cpp): packed rows
+bit-identical to the oracle's restatement of loadImages (which the fixtures pin to the reference), for any thread
+count, through the binary cache; and its float parser agrees with the C library's strtof on every token form."""
+import ctypes
+import json
+import os
+import random
+import subprocess
+
+import numpy as np
+import pytest
+
+import golden_cases as gc
+import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DRIVER = os.path.join(ROOT, "fast-image-recognition_amd", "host", "loader_driver")
+
+pytestmark = pytest.mark.skipif(not os.path.exists(DRIVER), reason="loader_driver not built (run __graft_entry__.build())")
+
+
+def test_parse_float_exact_equals_strtof(tmp_path):
+    libc = ctypes.CDLL("libc.so.6")
+    libc.strtof.restype = ctypes.c_float
+    libc.strtof.argtypes = [ctypes.c_char_p, ctypes.c_void_p]
+    rnd = random.Random(7)
+    toks = ["0.000000", "1.000000", "-0.000001", "0.000100", "0.000099", "123456.789012", "0.1", "-12.5", "3", ".5", "5.",
+            "1e-3", "2.5E+4", "nan", "inf", "-inf", "0.00000000000000000001", "123456789012345678", "16777217.0", "0.333333",
+            "8388608.5", "8388609.5", "4194304.25", "1.00000005960464477539", "0.99999997019767761230"]
+    for _ in range(4000):
+        toks.append("{:f}".format(rnd.uniform(-3, 3) if rnd.random() < 0.8 else rnd.uniform(-1e5, 1e5)))
+    for _ in range(1000):      # exact float midpoints and their neighbours in 7-17 digits
+        f = np.float32(rnd.uniform(0.001, 100.0))
+        mid = (float(f) + float(np.nextafter(f, np.float32(1e9)))) / 2
+        toks.append(repr(mid))
+        toks.append("{:.10f}".format(mid))
+    path = tmp_path / "tokens.txt"
+    path.write_text(" ".join(toks) + "\n")
+    out = subprocess.run([DRIVER, "--tokens", str(path)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0
+    got = out.stdout.split()
+    assert len(got) == len(toks) and "FAIL" not in got
+    for t, g in zip(toks, got):
+        exp = np.float32(libc.strtof(t.encode(), None))
+        assert int(g) == int(exp.view(np.uint32)) or (np.isnan(exp) and np.isnan(np.uint32(int(g)).view(np.float32))), t
+
+
+@pytest.mark.parametrize("metric", [gc.L2, gc.CHI2])
+@pytest.mark.parametrize("threads", [1, 5])
+def test_fast_loader_matches_oracle_bit_for_bit(tmp_path, oracle, metric, threads):
+    d = 96
+    rng = np.random.default_rng(3)
+    n = 233
+    classes = [f"class_{int(c)}" for c in rng.integers(0, 9, n)]
+    classes[5] = "BACKGROUND_Google"
+    classes[77] = "  257.clutter"
+    classes[9] = "\tclass_3"                 # leading blanks are stripped (db_features.cpp:57)
+    feats = synth.uniform01(n * d, 41).reshape(n, d).astype(np.float32) * np.float32(3.0) - np.float32(0.2)
+    feats[:, 3] = 0.00004
+    names = [f"/x/{i}.jpg" for i in range(n)]
+    path = str(tmp_path / "f.txt")
+    synth.write_feature_file(path, names, classes, feats)
+    with open(path, "a") as f:               # a short feature line: the remaining features read as 0 (failed extraction)
+        f.write("/x/short.jpg\nclass_1\n0.500000 0.250000 \n")
+        f.write("/x/incomplete.jpg\nclass_2\n")      # an incomplete trailing record is dropped (db_features.cpp:52-57)
+    out_bin = str(tmp_path / "rows.bin")
+    out = subprocess.run([DRIVER, path, str(d), str(metric), out_bin, str(threads)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    info = json.loads(out.stdout)
+    rows, cls, ncls = oracle.load_images(path, d, metric)
+    assert info["images"] == rows.shape[0] == n - 2 + 1 and info["classes"] == ncls
+    raw = np.fromfile(out_bin, dtype=np.uint8)
+    got_rows = raw[: rows.size * 4].view(np.float32).reshape(rows.shape)
+    got_cls = raw[rows.size * 4:].view(np.int32)
+    assert np.array_equal(got_cls, cls)
+    assert np.array_equal(got_rows.view(np.uint32), rows.view(np.uint32))
+
+
+def test_fast_loader_reproduces_reference_fixture(tmp_path):
+    """The loader fixture of tests/golden was produced by the REAL reference's loadImages."""
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "reference_outputs.npz"))
+    names, classes, feats, d = gc.loader_case()
+    path = str(tmp_path / "feats.txt")
+    synth.write_feature_file(path, names, classes, feats)
+    for metric in (gc.L2, gc.CHI2):
+        out_bin = str(tmp_path / f"rows{metric}.bin")
+        out = subprocess.run([DRIVER, path, str(d), str(metric), out_bin, "3"], capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr
+        exp = gold[f"loader/{gc.METRIC_NAMES[metric]}/rows"]
+        raw = np.fromfile(out_bin, dtype=np.uint8)
+        assert np.array_equal(raw[: exp.size * 4].view(np.uint32), exp.view(np.uint32).ravel())
+        assert np.array_equal(raw[exp.size * 4:].view(np.int32), gold[f"loader/{gc.METRIC_NAMES[metric]}/class"])
+    assert subprocess.run([DRIVER, str(tmp_path / "missing.txt"), "8", "0", str(tmp_path / "m.bin")], capture_output=True, text=True).stdout.startswith('{"images": 0')
