@@ -67,7 +67,7 @@ struct fir_gallery {
     float* dout = nullptr;    size_t dout_cap = 0;    // range distances for the host-pointer API
     int32_t* didx = nullptr;  size_t didx_cap = 0;
 
-    int qpp = 8;              // queries per gallery pass
+    int qpp = 0;              // queries per gallery pass; 0 = automatic (effective_qpp)
     int waves_req = 0;        // 0 = automatic
     int max_waves = 0;        // upper bound over all scan kernels (8 blocks per CU)
     int last_waves = 0;       // waves of the most recent scan launch
@@ -167,6 +167,16 @@ int pick_waves(int64_t tiles, int max_waves, int simds) {
     return w;
 }
 
+// Queries per gallery pass. Galleries larger than the 256 MiB Infinity Cache are streamed from HBM and the
+// L2 scan stays HBM-bound up to 8 queries per pass (profiles/r01_sweep_notes.md); a gallery (shard) that stays
+// cache-resident is VALU-bound either way, and 16 queries per pass halve its cache traffic
+// (profiles/r01_qb_table_100kx512.txt: 295k vs 175k queries/s at 100k x 512).
+int effective_qpp(const fir_gallery* g) {
+    if (g->qpp > 0) return g->qpp;
+    const double bytes = (double)g->tiles * 64.0 * g->dp4 * 16.0;
+    return bytes <= 384.0 * 1024 * 1024 ? 16 : 8;
+}
+
 int check_range(const fir_gallery* g, int32_t& start, int32_t& end) {
     if (end == 0) end = g->d;   // db_features.cpp:320-321
     if (start < 0 || end > g->d || start >= end)
@@ -263,7 +273,7 @@ int top1_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start, 
     if (rc) return rc;
     hipLaunchKernelGGL(k_fill_keys, dim3((qb + kBlock - 1) / kBlock), dim3(kBlock), 0, st, d_keys, qb);
     // 16 queries per pass exist only in the hand-scheduled kernel (whole-chunk L2 ranges)
-    const int cap = pick_fast(kEpiTop1, 16, g->metric, start, end, g->dp4, nullptr) ? g->qpp : std::min(g->qpp, 8);
+    const int cap = pick_fast(kEpiTop1, 16, g->metric, start, end, g->dp4, nullptr) ? effective_qpp(g) : std::min(effective_qpp(g), 8);
     int q0 = 0;
     while (q0 < qb) {
         const int t = largest_pow2_le(qb - q0, cap);
@@ -280,7 +290,7 @@ int topk_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start, 
              hipStream_t st) {
     int rc = grow(g->qt, g->qt_cap, (size_t)qb * g->dp4 * 4);
     if (rc) return rc;
-    const int qcap = std::min(g->qpp, 4);   // 2*kKMax registers per query per lane
+    const int qcap = std::min(effective_qpp(g), 4);   // 2*kKMax registers per query per lane
     rc = grow(g->part, g->part_cap, (size_t)g->max_waves * qcap * k);
     if (rc) return rc;
     int q0 = 0;
@@ -301,7 +311,7 @@ int range_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start,
     if (rc) return rc;
     int q0 = 0;
     while (q0 < qb) {
-        const int t = largest_pow2_le(qb - q0, std::min(g->qpp, 8));
+        const int t = largest_pow2_le(qb - q0, std::min(effective_qpp(g), 8));
         rc = run_pass(g, st, kEpiStore, d_queries, q0, t, start, end, nullptr, d_out + (size_t)q0 * g->n, g->n, 0);
         if (rc) return rc;
         q0 += t;
@@ -679,7 +689,8 @@ int fir_gallery_sync(fir_gallery* g) {
 
 int fir_gallery_set_tuning(fir_gallery* g, int32_t queries_per_pass, int32_t waves) {
     if (!g) return fail(FIR_ERR_ARG, "gallery is NULL");
-    if (queries_per_pass != 0) {
+    if (queries_per_pass < 0) g->qpp = 0;   // back to automatic
+    if (queries_per_pass > 0) {
         if (queries_per_pass != 1 && queries_per_pass != 2 && queries_per_pass != 4 && queries_per_pass != 8 &&
             queries_per_pass != 16)
             return fail(FIR_ERR_ARG, "queries_per_pass must be 1, 2, 4, 8 or 16");
@@ -692,7 +703,7 @@ int fir_gallery_set_tuning(fir_gallery* g, int32_t queries_per_pass, int32_t wav
 
 int fir_gallery_get_tuning(const fir_gallery* g, int32_t* queries_per_pass, int32_t* waves, int32_t* max_waves) {
     if (!g) return fail(FIR_ERR_ARG, "gallery is NULL");
-    if (queries_per_pass) *queries_per_pass = g->qpp;
+    if (queries_per_pass) *queries_per_pass = effective_qpp(g);
     if (waves) *waves = g->last_waves;   // waves of the most recent scan launch (0 before the first)
     if (max_waves) *max_waves = g->max_waves;
     return FIR_OK;
