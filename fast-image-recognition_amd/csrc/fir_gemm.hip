@@ -34,6 +34,7 @@ using fir::kKeyNone;
 
 constexpr int kGemmBlock = 512;        // 8 waves: 2 per SIMD
 constexpr int kQT = 64;                // queries per pass (2 accumulator tiles of 32 per wave)
+constexpr int kSlab8 = 64;             // query features staged in LDS at a time, in groups of 8 (512 features)
 constexpr int kCand = 8;               // candidates re-ranked exactly per query
 constexpr int kListCap = 4096;         // appended (proxy, row) entries per query before "overflow"
 constexpr int kMinSampleRows = 8192;   // rows whose proxies seed tau: max(8192, n / 64) -> ~512 appended rows per query
@@ -144,68 +145,88 @@ __global__ void __launch_bounds__(kGemmBlock, 2) k_gemm_proxy(const float4* __re
     __shared__ float tau_s[kQT];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wpb = blockDim.x >> 6;      // 8 waves for the full pass, 2 for the (short) sample pass so that it covers every CU
-    for (int i = threadIdx.x; i < (kQT / 32) * dq8 * 64; i += blockDim.x) lq[i] = qm[i];
+    // The query tile is staged in LDS one SLAB of features at a time (<= kSlab8 groups of 8 = 512 features, 128 KiB for
+    // 64 queries); d <= 512 needs one slab, loaded once; longer vectors (d = 1280: 3 slabs) re-stage per row group.
+    const int sq8 = dq8 < kSlab8 ? dq8 : kSlab8;
+    const int nslab = (dq8 + sq8 - 1) / sq8;
     if (MODE == 1 && threadIdx.x < kQT) tau_s[threadIdx.x] = tau[threadIdx.x];
-    __syncthreads();
     const int64_t rb_begin = row_begin / 32, rb_end = (row_end + 31) / 32;
-    for (int64_t rb = rb_begin + (int64_t)blockIdx.x * wpb + wave; rb < rb_end; rb += (int64_t)gridDim.x * wpb) {
-        const float4* a = gm + (size_t)rb * dq8 * 64 + lane;
+    const int64_t nrg = (rb_end - rb_begin + wpb - 1) / wpb;            // row groups of wpb x 32 rows; uniform trip count per block
+    bool staged = false;
+    for (int64_t rg = blockIdx.x; rg < nrg; rg += gridDim.x) {
+        const int64_t rb = rb_begin + rg * wpb + wave;
+        const bool active = rb < rb_end;
         f32x16 acc0 = {0.f}, acc1 = {0.f};
-        // dq8 is a multiple of 4: EIGHT gallery fragments in flight (named registers, no runtime indexing), each
-        // re-issued right after its 8 MFMAs, i.e. 7 steps = 3 584 MFMA cycles (x2 with two waves per SIMD) ahead of
-        // its use -- with 2 waves per SIMD the loads must cover the HBM latency on their own.
-        const int last = dq8 - 1;
-        float4 a0 = a[0], a1 = a[(size_t)(1 < last ? 1 : last) * 64], a2 = a[(size_t)(2 < last ? 2 : last) * 64],
-               a3 = a[(size_t)(3 < last ? 3 : last) * 64], a4 = a[(size_t)(4 < last ? 4 : last) * 64],
-               a5 = a[(size_t)(5 < last ? 5 : last) * 64], a6 = a[(size_t)(6 < last ? 6 : last) * 64],
-               a7 = a[(size_t)(7 < last ? 7 : last) * 64];
+        for (int sl = 0; sl < nslab; ++sl) {
+            const int k0 = sl * sq8;
+            const int kw = dq8 - k0 < sq8 ? dq8 - k0 : sq8;            // groups in this slab (a multiple of 4)
+            if (nslab > 1 || !staged) {
+                __syncthreads();                                          // everyone is done with the previous slab
+                for (int i = threadIdx.x; i < 2 * kw * 64; i += blockDim.x) {
+                    const int jb = i / (kw * 64), r = i - jb * kw * 64;
+                    lq[(size_t)jb * sq8 * 64 + r] = qm[((size_t)jb * dq8 + k0) * 64 + r];
+                }
+                __syncthreads();
+                staged = true;
+            }
+            if (!active) continue;
+            const float4* a = gm + ((size_t)rb * dq8 + k0) * 64 + lane;
+            // kw is a multiple of 4: EIGHT gallery fragments in flight (named registers, no runtime indexing), each
+            // re-issued right after its 8 MFMAs, i.e. 7 steps = 3 584 MFMA cycles (x2 with two waves per SIMD) ahead of
+            // its use -- with 2 waves per SIMD the loads must cover the HBM latency on their own.
+            const int last = kw - 1;
+            float4 a0 = a[0], a1 = a[(size_t)(1 < last ? 1 : last) * 64], a2 = a[(size_t)(2 < last ? 2 : last) * 64],
+                   a3 = a[(size_t)(3 < last ? 3 : last) * 64], a4 = a[(size_t)(4 < last ? 4 : last) * 64],
+                   a5 = a[(size_t)(5 < last ? 5 : last) * 64], a6 = a[(size_t)(6 < last ? 6 : last) * 64],
+                   a7 = a[(size_t)(7 < last ? 7 : last) * 64];
+            // query fragments come from LDS one step AHEAD of the MFMAs that use them (b0/b1 = this step, n0/n1 = next)
+            float4 b0 = lq[lane], b1 = lq[(size_t)sq8 * 64 + lane];
+#define FIR_GEMM_STEP(AV, KQ)                                                              \
+            {                                                                              \
+                const int kn = (KQ) + 1 < kw ? (KQ) + 1 : (KQ);                            \
+                const float4 n0 = lq[(size_t)kn * 64 + lane];                              \
+                const float4 n1 = lq[(size_t)(sq8 + kn) * 64 + lane];                      \
+                __builtin_amdgcn_sched_barrier(0); /* keep the two ds_reads up here */    \
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(AV.x, b0.x, acc0, 0, 0, 0);    \
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(AV.x, b1.x, acc1, 0, 0, 0);    \
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(AV.y, b0.y, acc0, 0, 0, 0);    \
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(AV.y, b1.y, acc1, 0, 0, 0);    \
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(AV.z, b0.z, acc0, 0, 0, 0);    \
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(AV.z, b1.z, acc1, 0, 0, 0);    \
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(AV.w, b0.w, acc0, 0, 0, 0);    \
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(AV.w, b1.w, acc1, 0, 0, 0);    \
+                b0 = n0;                                                                   \
+                b1 = n1;                                                                   \
+            }
+            for (int kq = 0; kq < kw; kq += 8) {
+                // (the tail re-loads clamp to the last fragment: harmless L2 hits, keeps the loop branch-free)
+#define FIR_GEMM_NEXT(AV, OFF) AV = a[(size_t)(kq + (OFF) + 8 < kw ? kq + (OFF) + 8 : last) * 64];
+                FIR_GEMM_STEP(a0, kq)
+                FIR_GEMM_NEXT(a0, 0)
+                FIR_GEMM_STEP(a1, kq + 1)
+                FIR_GEMM_NEXT(a1, 1)
+                FIR_GEMM_STEP(a2, kq + 2)
+                FIR_GEMM_NEXT(a2, 2)
+                FIR_GEMM_STEP(a3, kq + 3)
+                FIR_GEMM_NEXT(a3, 3)
+                if (kq + 4 < kw) {     // kw is a multiple of 4, not necessarily of 8
+                    FIR_GEMM_STEP(a4, kq + 4)
+                    FIR_GEMM_NEXT(a4, 4)
+                    FIR_GEMM_STEP(a5, kq + 5)
+                    FIR_GEMM_NEXT(a5, 5)
+                    FIR_GEMM_STEP(a6, kq + 6)
+                    FIR_GEMM_NEXT(a6, 6)
+                    FIR_GEMM_STEP(a7, kq + 7)
+                    FIR_GEMM_NEXT(a7, 7)
+                }
+#undef FIR_GEMM_NEXT
+            }
+#undef FIR_GEMM_STEP
+        }
+        if (!active) continue;
         // this wave's 32 squared row norms, one per lane (both halves), handed out by shuffles in the epilogue
         const int64_t nrow = rb * 32 + (lane & 31);
         const float gn_lane = nrow < n ? gnorm[nrow] : 0.0f;
-        // query fragments come from LDS one step AHEAD of the MFMAs that use them (b0/b1 = this step, n0/n1 = next):
-        // issued back to back with the matrix ops, an un-prefetched ds_read leaves the matrix pipe idle ~25 % of the time
-        float4 b0 = lq[lane], b1 = lq[(size_t)dq8 * 64 + lane];
-#define FIR_GEMM_STEP(AV, KQ)                                                          \
-        {                                                                              \
-            const int kn = (KQ) + 1 < dq8 ? (KQ) + 1 : (KQ);                           \
-            const float4 n0 = lq[(size_t)kn * 64 + lane];                              \
-            const float4 n1 = lq[(size_t)(dq8 + kn) * 64 + lane];                      \
-            __builtin_amdgcn_sched_barrier(0); /* keep the two ds_reads up here */    \
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(AV.x, b0.x, acc0, 0, 0, 0);    \
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(AV.x, b1.x, acc1, 0, 0, 0);    \
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(AV.y, b0.y, acc0, 0, 0, 0);    \
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(AV.y, b1.y, acc1, 0, 0, 0);    \
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(AV.z, b0.z, acc0, 0, 0, 0);    \
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(AV.z, b1.z, acc1, 0, 0, 0);    \
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(AV.w, b0.w, acc0, 0, 0, 0);    \
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(AV.w, b1.w, acc1, 0, 0, 0);    \
-            b0 = n0;                                                                   \
-            b1 = n1;                                                                   \
-        }
-        for (int kq = 0; kq < dq8; kq += 8) {
-            // (the tail re-loads clamp to the last fragment: harmless L2 hits, keeps the loop branch-free)
-#define FIR_GEMM_NEXT(AV, OFF) AV = a[(size_t)(kq + (OFF) + 8 < dq8 ? kq + (OFF) + 8 : last) * 64];
-            FIR_GEMM_STEP(a0, kq)
-            FIR_GEMM_NEXT(a0, 0)
-            FIR_GEMM_STEP(a1, kq + 1)
-            FIR_GEMM_NEXT(a1, 1)
-            FIR_GEMM_STEP(a2, kq + 2)
-            FIR_GEMM_NEXT(a2, 2)
-            FIR_GEMM_STEP(a3, kq + 3)
-            FIR_GEMM_NEXT(a3, 3)
-            if (kq + 4 < dq8) {     // dq8 is a multiple of 4, not necessarily of 8
-                FIR_GEMM_STEP(a4, kq + 4)
-                FIR_GEMM_NEXT(a4, 4)
-                FIR_GEMM_STEP(a5, kq + 5)
-                FIR_GEMM_NEXT(a5, 5)
-                FIR_GEMM_STEP(a6, kq + 6)
-                FIR_GEMM_NEXT(a6, 6)
-                FIR_GEMM_STEP(a7, kq + 7)
-                FIR_GEMM_NEXT(a7, 7)
-            }
-#undef FIR_GEMM_NEXT
-        }
-#undef FIR_GEMM_STEP
         // C/D layout of the 32x32 MFMA: column (query) = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
 #pragma unroll
         for (int jb = 0; jb < 2; ++jb) {
@@ -422,7 +443,6 @@ int fir_gemm_create(fir_gallery* g, fir_gemm** out) {
     if (fir_gallery_view_(g, &m->v) != FIR_OK || fir_gallery_tiled_(g, &gp, &m->dp4) != FIR_OK) { delete m; return gemm_fail(FIR_ERR_ARG, "bad gallery"); }
     m->gal4 = (const float4*)gp;
     m->dq8 = (m->v.d + 31) / 32 * 4;     // feature groups of 8, padded to a multiple of 4 groups (zeros)
-    if ((size_t)(kQT / 32) * m->dq8 * 64 * 16 > 150 * 1024) { delete m; return gemm_fail(FIR_ERR_ARG, "d=%d too large for the LDS query tile of the GEMM path", m->v.d); }
     hipError_t e = hipSetDevice(m->v.device);
     const int64_t rblocks = (std::max<int64_t>(m->v.n, 1) + 31) / 32;
     const int64_t np = std::max<int64_t>(m->v.n, 1);
@@ -443,7 +463,7 @@ int fir_gemm_create(fir_gallery* g, fir_gemm** out) {
     if (e == hipSuccess) e = hipMalloc((void**)&m->sample, (size_t)kQT * m->sample_rows * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&m->fbq, (size_t)kQT * m->v.d * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&m->fbkeys, kQT * sizeof(unsigned long long));
-    const int lds_bytes = (kQT / 32) * m->dq8 * 64 * (int)sizeof(float4);
+    const int lds_bytes = (kQT / 32) * std::min(m->dq8, kSlab8) * 64 * (int)sizeof(float4);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e == hipSuccess && m->v.n > 0) {
@@ -504,7 +524,7 @@ int fir_gemm_search_top1_keys_dev(fir_gemm* m, const float* d_queries, int32_t q
         GEMM_HIP(hipMalloc((void**)&m->ok, (size_t)std::max(qb, 1024) * sizeof(int)));
         m->ok_cap = (size_t)std::max(qb, 1024);
     }
-    const size_t lds = (size_t)(kQT / 32) * m->dq8 * 64 * sizeof(float4);
+    const size_t lds = (size_t)(kQT / 32) * std::min(m->dq8, kSlab8) * 64 * sizeof(float4);
     const int grid = m->v.cus;      // one 512-thread workgroup per CU
     const int sample_rows = m->sample_rows;
     int pass = 0;

@@ -24,7 +24,7 @@ def run_both(fir, rows, q):
     return (idx, dist), (eidx, edist), st
 
 
-@pytest.mark.parametrize("seed,n,d,qb", [(1, 5000, 512, 70), (2, 40000, 512, 64), (3, 1000, 256, 5), (4, 333, 100, 130), (5, 7, 64, 3), (6, 70000, 128, 200)])
+@pytest.mark.parametrize("seed,n,d,qb", [(1, 5000, 512, 70), (2, 40000, 512, 64), (3, 1000, 256, 5), (4, 333, 100, 130), (5, 7, 64, 3), (6, 70000, 128, 200), (7, 3000, 1280, 70), (8, 900, 1536, 9), (9, 2000, 520, 33)])
 def test_gemm_equals_scan(fir, oracle, seed, n, d, qb):
     rows = synth.make_gallery(seed, n, d, 0)
     q, _ = synth.make_queries(seed, rows, qb, 0)
