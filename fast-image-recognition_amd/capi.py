@@ -58,6 +58,7 @@ SYMBOLS = [
     ("fir_cls_pnn_predict_seq", C.c_int, [_vp, _vp, C.c_int32, C.c_double, _vp, _vp]),
     ("fir_cls_knn_predict", C.c_int, [_vp, _vp, C.c_int32, C.c_int32, _vp]),
     ("fir_gemm_create", C.c_int, [_vp, C.POINTER(_vp)]),
+    ("fir_gemm_create_ex", C.c_int, [_vp, C.c_int32, C.POINTER(_vp)]),
     ("fir_gemm_destroy", C.c_int, [_vp]),
     ("fir_gemm_search_top1_keys_dev", C.c_int, [_vp, _vp, C.c_int32, _vp, _vp]),
     ("fir_gemm_stats", C.c_int, [_vp, _i64p, _i64p]),
@@ -260,10 +261,12 @@ class Gallery:
 class GemmSearch:
     """Large-batch L2 top-1 through the matrix cores (fir_gemm_*): same answers as Gallery.search_top1."""
 
-    def __init__(self, gallery):
+    F32, BF16_SPLIT = 0, 1
+
+    def __init__(self, gallery, precision=1):
         self._g = gallery           # keeps the gallery alive
         self._h = _vp()
-        _check(lib().fir_gemm_create(gallery._h, C.byref(self._h)))
+        _check(lib().fir_gemm_create_ex(gallery._h, precision, C.byref(self._h)))
 
     def close(self):
         if self._h:

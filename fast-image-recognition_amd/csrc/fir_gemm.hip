@@ -35,6 +35,7 @@ using fir::kKeyNone;
 constexpr int kGemmBlock = 512;        // 8 waves: 2 per SIMD
 constexpr int kQT = 64;                // queries per pass (2 accumulator tiles of 32 per wave)
 constexpr int kSlab8 = 64;             // query features staged in LDS at a time, in groups of 8 (512 features)
+constexpr int kSlab16 = 32;            // bf16 variant: k-blocks of 16 features staged at a time (512 features)
 constexpr int kCand = 8;               // candidates re-ranked exactly per query
 constexpr int kListCap = 4096;         // appended (proxy, row) entries per query before "overflow"
 constexpr int kMinSampleRows = 8192;   // rows whose proxies seed tau: max(8192, n / 64) -> ~512 appended rows per query
@@ -250,6 +251,183 @@ __global__ void __launch_bounds__(kGemmBlock, 2) k_gemm_proxy(const float4* __re
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// bf16-split variant. x = hi + lo + r with hi = bf16(x), lo = bf16(x - hi), |r| <= 2^-18 |x|: the dot product
+// is taken as hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_bf16 (bf16 products are exact in f32; 16x the f32-MFMA
+// rate, so three of them are still 5.3x faster); the dropped lo.lo and r terms are <= 3 * 2^-18 |g||q| and go
+// into the certificate's E. Fragment order for this MFMA: lane l (r = l & 31, h = l >> 5) holds the 8 features
+// 16 kb + 8 h .. + 7 of vector r of its 32-block as 8 bf16 (one uint4); hi and lo fragments are stored side by side.
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split_bf16(float x, unsigned short& hi, unsigned short& lo) {
+    const __bf16 h = (__bf16)x;                    // round to nearest even
+    const __bf16 l = (__bf16)(x - (float)h);
+    __builtin_memcpy(&hi, &h, 2);
+    __builtin_memcpy(&lo, &l, 2);
+}
+
+// tiled f32 gallery -> gb[(rb * dk16 + kb) * 2 + {hi, lo}][lane] (uint4 = 8 bf16)
+__global__ void __launch_bounds__(256) k_gemm_pack_gallery_bf16(const float4* __restrict__ gal4, int64_t n, int dp4, int dk16,
+                                                                 uint4* __restrict__ gb) {
+    const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;      // (rb, kb, lane)
+    const int64_t rblocks = (n + 31) / 32;
+    if (o >= rblocks * dk16 * 64) return;
+    const int l = (int)(o & 63);
+    const int64_t t = o >> 6;
+    const int kb = (int)(t % dk16);
+    const int64_t rb = t / dk16;
+    const int64_t row = rb * 32 + (l & 31);
+    const int h = l >> 5;
+    unsigned short hi[8], lo[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = 16 * kb + 8 * h + j;
+        float x = 0.f;
+        if (row < n && k < dp4 * 4) {
+            const float4 g = gal4[((row >> 6) * dp4 + (k >> 2)) * 64 + (row & 63)];
+            x = (k & 3) == 0 ? g.x : (k & 3) == 1 ? g.y : (k & 3) == 2 ? g.z : g.w;
+        }
+        split_bf16(x, hi[j], lo[j]);
+    }
+    uint4 vh, vl;
+    __builtin_memcpy(&vh, hi, 16);
+    __builtin_memcpy(&vl, lo, 16);
+    gb[(size_t)(t * 2) * 64 + l] = vh;
+    gb[(size_t)(t * 2 + 1) * 64 + l] = vl;
+}
+
+// queries -> qb[(jb * dk16 + kb) * 2 + {hi, lo}][lane], zero padded to kQT queries
+__global__ void __launch_bounds__(256) k_gemm_pack_queries_bf16(const float* __restrict__ q, int nq, int d, int dk16, uint4* __restrict__ qbf) {
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= (kQT / 32) * dk16 * 64) return;
+    const int l = o & 63;
+    const int t = o >> 6;
+    const int kb = t % dk16, jb = t / dk16;
+    const int qi = jb * 32 + (l & 31), h = l >> 5;
+    unsigned short hi[8], lo[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = 16 * kb + 8 * h + j;
+        const float x = (qi < nq && k < d) ? q[(size_t)qi * d + k] : 0.f;
+        split_bf16(x, hi[j], lo[j]);
+    }
+    uint4 vh, vl;
+    __builtin_memcpy(&vh, hi, 16);
+    __builtin_memcpy(&vl, lo, 16);
+    qbf[(size_t)(t * 2) * 64 + l] = vh;
+    qbf[(size_t)(t * 2 + 1) * 64 + l] = vl;
+}
+
+__device__ __forceinline__ bf16x8 as_bf16x8(const uint4 v) {
+    bf16x8 r;
+    __builtin_memcpy(&r, &v, 16);
+    return r;
+}
+
+// Same contract as k_gemm_proxy (one wave: 32 rows x 64 queries, MODE 0 sample / MODE 1 append), bf16-split operands.
+// Dynamic LDS: one slab of the query tile: 2 query blocks x sk16 k-blocks x {hi, lo} x 64 uint4 (128 KiB at 512 features).
+template <int MODE>
+__global__ void __launch_bounds__(kGemmBlock, 2) k_gemm_proxy_bf16(const uint4* __restrict__ gb, const float* __restrict__ gnorm,
+                                                                    const uint4* __restrict__ qbf, int64_t n, int64_t row_begin,
+                                                                    int64_t row_end, int dk16, const float* __restrict__ tau,
+                                                                    unsigned long long* __restrict__ lists, int* __restrict__ counts,
+                                                                    float* __restrict__ sample, int sample_rows) {
+    extern __shared__ __attribute__((aligned(16))) uint4 lqb[];
+    __shared__ float tau_s[kQT];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wpb = blockDim.x >> 6;
+    const int sk16 = dk16 < kSlab16 ? dk16 : kSlab16;
+    const int nslab = (dk16 + sk16 - 1) / sk16;
+    if (MODE == 1 && threadIdx.x < kQT) tau_s[threadIdx.x] = tau[threadIdx.x];
+    const int64_t rb_begin = row_begin / 32, rb_end = (row_end + 31) / 32;
+    const int64_t nrg = (rb_end - rb_begin + wpb - 1) / wpb;
+    bool staged = false;
+    for (int64_t rg = blockIdx.x; rg < nrg; rg += gridDim.x) {
+        const int64_t rb = rb_begin + rg * wpb + wave;
+        const bool active = rb < rb_end;
+        f32x16 acc0 = {0.f}, acc1 = {0.f};
+        for (int sl = 0; sl < nslab; ++sl) {
+            const int k0 = sl * sk16;
+            const int kw = dk16 - k0 < sk16 ? dk16 - k0 : sk16;            // k-blocks in this slab (a multiple of 4)
+            if (nslab > 1 || !staged) {
+                __syncthreads();
+                for (int i = threadIdx.x; i < 2 * kw * 128; i += blockDim.x) {
+                    const int jb = i / (kw * 128), r = i - jb * kw * 128;
+                    lqb[(size_t)jb * sk16 * 128 + r] = qbf[((size_t)jb * dk16 + k0) * 128 + r];
+                }
+                __syncthreads();
+                staged = true;
+            }
+            if (!active) continue;
+            const uint4* a = gb + ((size_t)rb * dk16 + k0) * 128 + lane;      // +0: hi fragment, +64: lo fragment of a k-block
+            const int last = kw - 1;
+            // four k-blocks (hi + lo = 2 KiB per wave each) in flight, re-issued right after use
+            uint4 h0 = a[0], l0 = a[64];
+            uint4 h1 = a[(size_t)(1 < last ? 1 : last) * 128], l1 = a[(size_t)(1 < last ? 1 : last) * 128 + 64];
+            uint4 h2 = a[(size_t)(2 < last ? 2 : last) * 128], l2 = a[(size_t)(2 < last ? 2 : last) * 128 + 64];
+            uint4 h3 = a[(size_t)(3 < last ? 3 : last) * 128], l3 = a[(size_t)(3 < last ? 3 : last) * 128 + 64];
+            // query fragments one step ahead: block 0 hi/lo, block 1 hi/lo
+            uint4 b0h = lqb[lane], b0l = lqb[64 + lane], b1h = lqb[(size_t)sk16 * 128 + lane], b1l = lqb[(size_t)sk16 * 128 + 64 + lane];
+#define FIR_BF_STEP(AH, AL, KB)                                                                                  \
+            {                                                                                                    \
+                const int kn = (KB) + 1 < kw ? (KB) + 1 : (KB);                                                  \
+                const uint4 n0h = lqb[(size_t)kn * 128 + lane], n0l = lqb[(size_t)kn * 128 + 64 + lane];         \
+                const uint4 n1h = lqb[(size_t)(sk16 + kn) * 128 + lane], n1l = lqb[(size_t)(sk16 + kn) * 128 + 64 + lane]; \
+                __builtin_amdgcn_sched_barrier(0);                                                               \
+                const bf16x8 ah = as_bf16x8(AH), al = as_bf16x8(AL);                                             \
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, as_bf16x8(b0h), acc0, 0, 0, 0);               \
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, as_bf16x8(b1h), acc1, 0, 0, 0);               \
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, as_bf16x8(b0l), acc0, 0, 0, 0);               \
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, as_bf16x8(b1l), acc1, 0, 0, 0);               \
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, as_bf16x8(b0h), acc0, 0, 0, 0);               \
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, as_bf16x8(b1h), acc1, 0, 0, 0);               \
+                b0h = n0h; b0l = n0l; b1h = n1h; b1l = n1l;                                                      \
+            }
+#define FIR_BF_NEXT(AH, AL, OFF)                                                        \
+            {                                                                           \
+                const size_t nx = (size_t)(kb + (OFF) + 4 < kw ? kb + (OFF) + 4 : last) * 128; \
+                AH = a[nx];                                                             \
+                AL = a[nx + 64];                                                        \
+            }
+            for (int kb = 0; kb < kw; kb += 4) {
+                FIR_BF_STEP(h0, l0, kb)
+                FIR_BF_NEXT(h0, l0, 0)
+                FIR_BF_STEP(h1, l1, kb + 1)
+                FIR_BF_NEXT(h1, l1, 1)
+                FIR_BF_STEP(h2, l2, kb + 2)
+                FIR_BF_NEXT(h2, l2, 2)
+                FIR_BF_STEP(h3, l3, kb + 3)
+                FIR_BF_NEXT(h3, l3, 3)
+            }
+#undef FIR_BF_NEXT
+#undef FIR_BF_STEP
+        }
+        if (!active) continue;
+        const int64_t nrow = rb * 32 + (lane & 31);
+        const float gn_lane = nrow < n ? gnorm[nrow] : 0.0f;
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) {
+            const int q = jb * 32 + (lane & 31);
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int roff = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                const int64_t row = rb * 32 + roff;
+                const float gn = __shfl(gn_lane, roff, 64);
+                if (row >= n || row < row_begin || row >= row_end) continue;
+                const float dot = jb == 0 ? acc0[reg] : acc1[reg];
+                const float p = gn - 2.0f * dot;
+                if (MODE == 0) {
+                    if (row < sample_rows) sample[(size_t)q * sample_rows + row] = p;
+                } else if (p < tau_s[q]) {
+                    const int slot = atomicAdd(&counts[q], 1);
+                    if (slot < kListCap) lists[(size_t)q * kListCap + slot] = fir::key_pack(p, (uint32_t)row);
+                }
+            }
+        }
+    }
+}
+
 // tau[q] = kCand-th smallest sampled proxy, nudged up so that ties with it are appended too. One block per
 // query, ONE pass over the samples: every thread keeps its kCand smallest keys sorted in registers, then kCand
 // rounds of block-min pop the global order statistics.
@@ -303,7 +481,7 @@ __global__ void __launch_bounds__(256) k_gemm_tau(const float* __restrict__ samp
 __global__ void __launch_bounds__(64) k_gemm_rerank(const unsigned long long* __restrict__ lists, const int* __restrict__ counts,
                                                      const float* __restrict__ tau, const float4* __restrict__ gal4,
                                                      const float* __restrict__ queries, const float* __restrict__ qnorm,
-                                                     const float* __restrict__ gnorm_max_p, int64_t n, int d, int dp4, int64_t row_offset,
+                                                     const float* __restrict__ gnorm_max_p, int64_t n, int d, int dp4, int64_t row_offset, float e_rel,
                                                      unsigned long long* __restrict__ out_key, int* __restrict__ ok) {
     const int q = blockIdx.x, lane = threadIdx.x;
     const int cnt = counts[q];
@@ -382,7 +560,8 @@ __global__ void __launch_bounds__(64) k_gemm_rerank(const unsigned long long* __
             // E bounds every rounding on both sides, in distance units: the f32 fma chain of the dot product
             // (<= d u |q||g|, doubled), the two float norms (<= d u each), the reference's own d+3 roundings of the
             // (q-g)^2 sum and its divide: (4d + 11) u (|q|^2 + |g|^2) / d in total; 8 d u (...) / d is used.  u = 2^-24.
-            const float E = 8.0f * (float)d * 5.9604645e-8f * (qn + gmax) / (float)d;
+            // e_rel = 8 d u, plus 2^-14 for the bf16-split variant (dropped lo.lo / residual terms, 3 * 2^-18 |g||q|, doubled in p)
+            const float E = e_rel * (qn + gmax) / (float)d;
             const float lower = (qn + p_excl) / (float)d - E;
             const float best = key != kKeyNone ? fir::f32_from_orderable((uint32_t)(key >> 32)) : fir::kNotFound;
             certified = lower > best;               // false for NaN
@@ -390,6 +569,18 @@ __global__ void __launch_bounds__(64) k_gemm_rerank(const unsigned long long* __
         }
         ok[q] = certified ? 1 : 0;
     }
+}
+
+// gnorm[row] = |g|^2 (one thread per row; any summation order is covered by the certificate's E).
+__global__ void __launch_bounds__(256) k_gemm_row_norms(const float4* __restrict__ gal4, int64_t n, int dp4, float* __restrict__ gnorm) {
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (row >= n) return;
+    float s = 0.f;
+    for (int c = 0; c < dp4; ++c) {
+        const float4 g = gal4[((row >> 6) * dp4 + c) * 64 + (row & 63)];
+        s += g.x * g.x + g.y * g.y + g.z * g.z + g.w * g.w;
+    }
+    gnorm[row] = s;
 }
 
 __global__ void k_gemm_max(const float* __restrict__ gnorm, int64_t n, float* __restrict__ out) {
@@ -410,7 +601,11 @@ struct fir_gemm {
     fir_gallery_view v;
     const float4* gal4 = nullptr;
     int dp4 = 0, dq8 = 0;
-    float4* gm = nullptr;
+    int precision = 0;          // 0: f32 MFMA, 1: bf16 split (hi.hi + hi.lo + lo.hi)
+    int dk16 = 0;               // bf16 variant: k-blocks of 16 features (padded to a multiple of 4)
+    float4* gm = nullptr;       // f32 fragments
+    uint4* gb = nullptr;        // bf16 hi/lo fragments
+    uint4* qbf[2] = {nullptr, nullptr};
     float* gnorm = nullptr;
     float* gmax = nullptr;
     // two sets of per-pass scratch: the re-rank of pass i runs on a side stream while pass i+1 is computed
@@ -433,8 +628,11 @@ struct fir_gemm {
 
 extern "C" {
 
-int fir_gemm_create(fir_gallery* g, fir_gemm** out) {
+int fir_gemm_create(fir_gallery* g, fir_gemm** out) { return fir_gemm_create_ex(g, FIR_GEMM_BF16_SPLIT, out); }
+
+int fir_gemm_create_ex(fir_gallery* g, int32_t precision, fir_gemm** out) {
     if (!g || !out) return gemm_fail(FIR_ERR_ARG, "NULL argument");
+    if (precision != FIR_GEMM_F32 && precision != FIR_GEMM_BF16_SPLIT) return gemm_fail(FIR_ERR_ARG, "bad precision %d", precision);
     *out = nullptr;
     fir_gemm* m = new (std::nothrow) fir_gemm();
     if (!m) return gemm_fail(FIR_ERR_NOMEM, "host allocation failed");
@@ -442,15 +640,19 @@ int fir_gemm_create(fir_gallery* g, fir_gemm** out) {
     const void* gp = nullptr;
     if (fir_gallery_view_(g, &m->v) != FIR_OK || fir_gallery_tiled_(g, &gp, &m->dp4) != FIR_OK) { delete m; return gemm_fail(FIR_ERR_ARG, "bad gallery"); }
     m->gal4 = (const float4*)gp;
+    m->precision = precision;
     m->dq8 = (m->v.d + 31) / 32 * 4;     // feature groups of 8, padded to a multiple of 4 groups (zeros)
+    m->dk16 = (m->v.d + 63) / 64 * 4;    // k-blocks of 16, padded to a multiple of 4
     hipError_t e = hipSetDevice(m->v.device);
     const int64_t rblocks = (std::max<int64_t>(m->v.n, 1) + 31) / 32;
     const int64_t np = std::max<int64_t>(m->v.n, 1);
-    if (e == hipSuccess) e = hipMalloc((void**)&m->gm, (size_t)rblocks * m->dq8 * 64 * sizeof(float4));
+    if (e == hipSuccess && precision == FIR_GEMM_F32) e = hipMalloc((void**)&m->gm, (size_t)rblocks * m->dq8 * 64 * sizeof(float4));
+    if (e == hipSuccess && precision == FIR_GEMM_BF16_SPLIT) e = hipMalloc((void**)&m->gb, (size_t)rblocks * m->dk16 * 128 * sizeof(uint4));
     if (e == hipSuccess) e = hipMalloc((void**)&m->gnorm, (size_t)np * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&m->gmax, 16);
     for (int b = 0; b < 2; ++b) {
         if (e == hipSuccess) e = hipMalloc((void**)&m->qm[b], (size_t)(kQT / 32) * m->dq8 * 64 * sizeof(float4));
+        if (e == hipSuccess) e = hipMalloc((void**)&m->qbf[b], (size_t)(kQT / 32) * m->dk16 * 128 * sizeof(uint4));
         if (e == hipSuccess) e = hipMalloc((void**)&m->qnorm[b], kQT * sizeof(float));
         if (e == hipSuccess) e = hipMalloc((void**)&m->tau[b], kQT * sizeof(float));
         if (e == hipSuccess) e = hipMalloc((void**)&m->lists[b], (size_t)kQT * kListCap * sizeof(unsigned long long));
@@ -463,11 +665,22 @@ int fir_gemm_create(fir_gallery* g, fir_gemm** out) {
     if (e == hipSuccess) e = hipMalloc((void**)&m->sample, (size_t)kQT * m->sample_rows * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&m->fbq, (size_t)kQT * m->v.d * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&m->fbkeys, kQT * sizeof(unsigned long long));
-    const int lds_bytes = (kQT / 32) * std::min(m->dq8, kSlab8) * 64 * (int)sizeof(float4);
+    const int lds_bytes = precision == FIR_GEMM_F32 ? (kQT / 32) * std::min(m->dq8, kSlab8) * 64 * (int)sizeof(float4)
+                                                    : (kQT / 32) * std::min(m->dk16, kSlab16) * 128 * (int)sizeof(uint4);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy_bf16<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy_bf16<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e == hipSuccess && m->v.n > 0) {
-        const int64_t total = rblocks * m->dq8 * 64;
+        // row norms come from the f32 packer (run on a one-group scratch when only the bf16 fragments are kept)
+        if (precision == FIR_GEMM_BF16_SPLIT) {
+            const int64_t totalb = rblocks * m->dk16 * 64;
+            hipLaunchKernelGGL(k_gemm_pack_gallery_bf16, dim3((unsigned)((totalb + 255) / 256)), dim3(256), 0, m->v.stream, m->gal4, m->v.n, m->dp4,
+                               m->dk16, m->gb);
+            hipLaunchKernelGGL(k_gemm_row_norms, dim3((unsigned)((m->v.n + 255) / 256)), dim3(256), 0, m->v.stream, m->gal4, m->v.n, m->dp4, m->gnorm);
+        }
+        const int64_t total = precision == FIR_GEMM_F32 ? rblocks * m->dq8 * 64 : 0;
+        if (total > 0)
         hipLaunchKernelGGL(k_gemm_pack_gallery, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, m->v.stream, m->gal4, m->v.n, m->dp4, m->dq8,
                            m->gm, m->gnorm);
         hipLaunchKernelGGL(k_gemm_max, dim3(1), dim3(256), 0, m->v.stream, m->gnorm, m->v.n, m->gmax);
@@ -489,11 +702,11 @@ int fir_gemm_destroy(fir_gemm* m) {
     (void)hipStreamSynchronize(m->v.stream);
     if (m->side) { (void)hipStreamSynchronize(m->side); (void)hipStreamDestroy(m->side); }
     for (int b = 0; b < 2; ++b) {
-        (void)hipFree(m->qm[b]); (void)hipFree(m->qnorm[b]); (void)hipFree(m->tau[b]); (void)hipFree(m->lists[b]); (void)hipFree(m->counts[b]);
+        (void)hipFree(m->qm[b]); (void)hipFree(m->qbf[b]); (void)hipFree(m->qnorm[b]); (void)hipFree(m->tau[b]); (void)hipFree(m->lists[b]); (void)hipFree(m->counts[b]);
         if (m->main_done[b]) (void)hipEventDestroy(m->main_done[b]);
         if (m->rerank_done[b]) (void)hipEventDestroy(m->rerank_done[b]);
     }
-    (void)hipFree(m->gm); (void)hipFree(m->gnorm); (void)hipFree(m->gmax); (void)hipFree(m->sample); (void)hipFree(m->ok);
+    (void)hipFree(m->gm); (void)hipFree(m->gb); (void)hipFree(m->gnorm); (void)hipFree(m->gmax); (void)hipFree(m->sample); (void)hipFree(m->ok);
     (void)hipFree(m->fbq); (void)hipFree(m->fbkeys);
     delete m;
     return FIR_OK;
@@ -524,7 +737,9 @@ int fir_gemm_search_top1_keys_dev(fir_gemm* m, const float* d_queries, int32_t q
         GEMM_HIP(hipMalloc((void**)&m->ok, (size_t)std::max(qb, 1024) * sizeof(int)));
         m->ok_cap = (size_t)std::max(qb, 1024);
     }
-    const size_t lds = (size_t)(kQT / 32) * std::min(m->dq8, kSlab8) * 64 * sizeof(float4);
+    const size_t lds = m->precision == FIR_GEMM_F32 ? (size_t)(kQT / 32) * std::min(m->dq8, kSlab8) * 64 * sizeof(float4)
+                                                    : (size_t)(kQT / 32) * std::min(m->dk16, kSlab16) * 128 * sizeof(uint4);
+    const float e_rel = 8.0f * (float)d * 5.9604645e-8f + (m->precision == FIR_GEMM_BF16_SPLIT ? 6.1035156e-5f : 0.0f);
     const int grid = m->v.cus;      // one 512-thread workgroup per CU
     const int sample_rows = m->sample_rows;
     int pass = 0;
@@ -533,19 +748,29 @@ int fir_gemm_search_top1_keys_dev(fir_gemm* m, const float* d_queries, int32_t q
         const int b = pass & 1;
         const float* dq = d_queries + (size_t)q0 * d;
         if (pass >= 2) GEMM_HIP(hipStreamWaitEvent(st, m->rerank_done[b], 0));     // scratch set b is free again
-        hipLaunchKernelGGL(k_gemm_pack_queries, dim3(((kQT / 32) * m->dq8 * 64 + 255) / 256), dim3(256), 0, st, dq, nq, d, m->dq8, m->qm[b]);
         hipLaunchKernelGGL(k_gemm_qnorm, dim3(kQT), dim3(64), 0, st, dq, nq, d, m->qnorm[b]);
         GEMM_HIP(hipMemsetAsync(m->counts[b], 0, kQT * sizeof(int), st));
-        hipLaunchKernelGGL(k_gemm_proxy<0>, dim3((sample_rows + 63) / 64), dim3(128), lds, st, m->gm, m->gnorm, m->qm[b], n, (int64_t)0,
-                           (int64_t)sample_rows, m->dq8, m->tau[b], m->lists[b], m->counts[b], m->sample, sample_rows);
-        hipLaunchKernelGGL(k_gemm_tau, dim3(kQT), dim3(256), 0, st, m->sample, sample_rows, m->tau[b]);
-        hipLaunchKernelGGL(k_gemm_proxy<1>, dim3(grid), dim3(kGemmBlock), lds, st, m->gm, m->gnorm, m->qm[b], n, (int64_t)0, n, m->dq8, m->tau[b],
-                           m->lists[b], m->counts[b], m->sample, sample_rows);
+        const int sample_grid = (sample_rows + 63) / 64;
+        if (m->precision == FIR_GEMM_F32) {
+            hipLaunchKernelGGL(k_gemm_pack_queries, dim3(((kQT / 32) * m->dq8 * 64 + 255) / 256), dim3(256), 0, st, dq, nq, d, m->dq8, m->qm[b]);
+            hipLaunchKernelGGL(k_gemm_proxy<0>, dim3(sample_grid), dim3(128), lds, st, m->gm, m->gnorm, m->qm[b], n, (int64_t)0,
+                               (int64_t)sample_rows, m->dq8, m->tau[b], m->lists[b], m->counts[b], m->sample, sample_rows);
+            hipLaunchKernelGGL(k_gemm_tau, dim3(kQT), dim3(256), 0, st, m->sample, sample_rows, m->tau[b]);
+            hipLaunchKernelGGL(k_gemm_proxy<1>, dim3(grid), dim3(kGemmBlock), lds, st, m->gm, m->gnorm, m->qm[b], n, (int64_t)0, n, m->dq8, m->tau[b],
+                               m->lists[b], m->counts[b], m->sample, sample_rows);
+        } else {
+            hipLaunchKernelGGL(k_gemm_pack_queries_bf16, dim3(((kQT / 32) * m->dk16 * 64 + 255) / 256), dim3(256), 0, st, dq, nq, d, m->dk16, m->qbf[b]);
+            hipLaunchKernelGGL(k_gemm_proxy_bf16<0>, dim3(sample_grid), dim3(128), lds, st, m->gb, m->gnorm, m->qbf[b], n, (int64_t)0,
+                               (int64_t)sample_rows, m->dk16, m->tau[b], m->lists[b], m->counts[b], m->sample, sample_rows);
+            hipLaunchKernelGGL(k_gemm_tau, dim3(kQT), dim3(256), 0, st, m->sample, sample_rows, m->tau[b]);
+            hipLaunchKernelGGL(k_gemm_proxy_bf16<1>, dim3(grid), dim3(kGemmBlock), lds, st, m->gb, m->gnorm, m->qbf[b], n, (int64_t)0, n, m->dk16,
+                               m->tau[b], m->lists[b], m->counts[b], m->sample, sample_rows);
+        }
         GEMM_HIP(hipEventRecord(m->main_done[b], st));
         // exact re-rank + certificate of this pass on the side stream, under the next pass's GEMM
         GEMM_HIP(hipStreamWaitEvent(m->side, m->main_done[b], 0));
         hipLaunchKernelGGL(k_gemm_rerank, dim3(nq), dim3(64), (size_t)kCand * m->dp4 * sizeof(float4), m->side, m->lists[b], m->counts[b], m->tau[b],
-                           m->gal4, dq, m->qnorm[b], m->gmax, n, d, m->dp4, m->v.row_offset, (unsigned long long*)d_keys + q0, m->ok + q0);
+                           m->gal4, dq, m->qnorm[b], m->gmax, n, d, m->dp4, m->v.row_offset, e_rel, (unsigned long long*)d_keys + q0, m->ok + q0);
         GEMM_HIP(hipEventRecord(m->rerank_done[b], m->side));
         ++m->passes;
     }

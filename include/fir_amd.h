@@ -169,7 +169,12 @@ int fir_cls_knn_predict(fir_cls* c, const double* queries, int32_t qb, int32_t k
  * row can win, and uncertified queries are re-run through the exact streaming scan (fir_gemm.hip).
  * Costs one extra copy of the gallery in MFMA fragment order. The gallery handle must outlive it. */
 typedef struct fir_gemm fir_gemm;
-int fir_gemm_create(fir_gallery* g, fir_gemm** out);
+enum {
+    FIR_GEMM_F32 = 0,        /* v_mfma_f32_32x32x2_f32: exact products (157 TF peak)                                */
+    FIR_GEMM_BF16_SPLIT = 1  /* x = hi + lo in bf16, hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_bf16 (default) */
+};
+int fir_gemm_create(fir_gallery* g, fir_gemm** out);   /* = fir_gemm_create_ex(g, FIR_GEMM_BF16_SPLIT, out) */
+int fir_gemm_create_ex(fir_gallery* g, int32_t precision, fir_gemm** out);
 int fir_gemm_destroy(fir_gemm* m);
 int fir_gemm_search_top1_keys_dev(fir_gemm* m, const float* d_queries, int32_t qb, uint64_t* d_keys, void* stream);
 /* passes = 64-query GEMM passes run so far, fallback_queries = queries answered by the exact scan instead. */

@@ -10,13 +10,13 @@ import synth
 pytestmark = pytest.mark.gpu
 
 
-def run_both(fir, rows, q):
+def run_both(fir, rows, q, precision=1):
     dev = torch.device("cuda", 0)
     with fir.Gallery(rows, None, 0, 0) as g:
         eidx, edist = g.search_top1(q)
         tq = torch.from_numpy(np.ascontiguousarray(q, np.float32)).to(dev)
         keys = torch.empty(q.shape[0], dtype=torch.int64, device=dev)
-        with fir.GemmSearch(g) as m:
+        with fir.GemmSearch(g, precision) as m:
             m.search_top1_keys_dev(tq.data_ptr(), q.shape[0], keys.data_ptr())
             torch.cuda.synchronize()
             st = m.stats()
@@ -25,10 +25,11 @@ def run_both(fir, rows, q):
 
 
 @pytest.mark.parametrize("seed,n,d,qb", [(1, 5000, 512, 70), (2, 40000, 512, 64), (3, 1000, 256, 5), (4, 333, 100, 130), (5, 7, 64, 3), (6, 70000, 128, 200), (7, 3000, 1280, 70), (8, 900, 1536, 9), (9, 2000, 520, 33)])
-def test_gemm_equals_scan(fir, oracle, seed, n, d, qb):
+@pytest.mark.parametrize("precision", [0, 1])
+def test_gemm_equals_scan(fir, oracle, seed, n, d, qb, precision):
     rows = synth.make_gallery(seed, n, d, 0)
     q, _ = synth.make_queries(seed, rows, qb, 0)
-    (idx, dist), (eidx, edist), st = run_both(fir, rows, q)
+    (idx, dist), (eidx, edist), st = run_both(fir, rows, q, precision)
     assert np.array_equal(idx, eidx)
     assert np.array_equal(dist.view(np.uint32), edist.view(np.uint32))
     for i in (0, qb - 1):
@@ -36,7 +37,8 @@ def test_gemm_equals_scan(fir, oracle, seed, n, d, qb):
     assert st["fallback_queries"] <= qb // 4 + 2, st      # the certificate normally holds on random data
 
 
-def test_gemm_adversarial_near_ties_and_duplicates(fir, oracle):
+@pytest.mark.parametrize("precision", [0, 1])
+def test_gemm_adversarial_near_ties_and_duplicates(fir, oracle, precision):
     """20 rows within a few ulps of the best (more than the 8 re-ranked candidates), exact duplicates of the best,
     a NaN row and unnormalised rows: the certificate must refuse and the exact scan must answer."""
     n, d = 30000, 512
@@ -55,7 +57,7 @@ def test_gemm_adversarial_near_ties_and_duplicates(fir, oracle):
     rows[100] = np.nan
     rows[200] *= np.float32(50.0)             # a long row: |g|^2 enters the proxy and the error bound
     q[3] = rows[200]
-    (idx, dist), (eidx, edist), st = run_both(fir, rows, q)
+    (idx, dist), (eidx, edist), st = run_both(fir, rows, q, precision)
     assert np.array_equal(idx, eidx)
     assert np.array_equal(dist.view(np.uint32), edist.view(np.uint32))
     assert idx[2] == 5 and dist[2] == 0
