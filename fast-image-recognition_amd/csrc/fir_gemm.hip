@@ -36,6 +36,7 @@ constexpr int kGemmBlock = 512;        // 8 waves: 2 per SIMD
 constexpr int kQT = 64;                // queries per pass (2 accumulator tiles of 32 per wave)
 constexpr int kSlab8 = 64;             // query features staged in LDS at a time, in groups of 8 (512 features)
 constexpr int kSlab16 = 32;            // bf16 variant: k-blocks of 16 features staged at a time (512 features)
+constexpr int kPasses = 4;             // 64-query passes folded into one launch (blockIdx.y): their tails overlap
 constexpr int kCand = 8;               // candidates re-ranked exactly per query
 constexpr int kListCap = 4096;         // appended (proxy, row) entries per query before "overflow"
 constexpr int kMinSampleRows = 8192;   // rows whose proxies seed tau: max(8192, n / 64) -> ~512 appended rows per query
@@ -102,7 +103,11 @@ __global__ void __launch_bounds__(256) k_gemm_pack_gallery(const float4* __restr
 }
 
 // queries[nq][d] -> fragment order qm[jb][kq][lane] (float4), zero padded to kQT queries; qnorm[q] = |q|^2.
-__global__ void __launch_bounds__(256) k_gemm_pack_queries(const float* __restrict__ q, int nq, int d, int dq8, float4* __restrict__ qm) {
+__global__ void __launch_bounds__(256) k_gemm_pack_queries(const float* q, int nq, int d, int dq8, float4* qm) {
+    // blockIdx.y = pass: 64 queries each, packed back to back
+    q += (size_t)blockIdx.y * kQT * d;
+    nq -= (int)blockIdx.y * kQT;
+    qm += (size_t)blockIdx.y * (kQT / 32) * dq8 * 64;
     const int o = blockIdx.x * 256 + threadIdx.x;
     if (o < (kQT / 32) * dq8 * 64) {
         const int l = o & 63;
@@ -138,12 +143,19 @@ __global__ void __launch_bounds__(64) k_gemm_qnorm(const float* __restrict__ q, 
 // Dynamic LDS: the query tile in fragment order, 2 * dq8 * 64 float4.
 template <int MODE>
 __global__ void __launch_bounds__(kGemmBlock, 2) k_gemm_proxy(const float4* __restrict__ gm, const float* __restrict__ gnorm,
-                                                               const float4* __restrict__ qm, int64_t n, int64_t row_begin,
-                                                               int64_t row_end, int dq8, const float* __restrict__ tau,
-                                                               unsigned long long* __restrict__ lists, int* __restrict__ counts,
-                                                               float* __restrict__ sample, int sample_rows) {
+                                                               const float4* qm, int64_t n, int64_t row_begin,
+                                                               int64_t row_end, int dq8, const float* tau, unsigned long long* lists, int* counts, float* sample,
+                                                               int sample_rows) {
     extern __shared__ __attribute__((aligned(16))) float4 lq[];
     __shared__ float tau_s[kQT];
+    {   // blockIdx.y = pass (64 queries each); every per-pass buffer is laid out pass-major
+        const size_t ps = blockIdx.y;
+        qm += ps * (kQT / 32) * dq8 * 64;
+        tau += ps * kQT;
+        lists += ps * kQT * kListCap;
+        counts += ps * kQT;
+        sample += ps * kQT * sample_rows;
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wpb = blockDim.x >> 6;      // 8 waves for the full pass, 2 for the (short) sample pass so that it covers every CU
     // The query tile is staged in LDS one SLAB of features at a time (<= kSlab8 groups of 8 = 512 features, 128 KiB for
@@ -298,7 +310,10 @@ __global__ void __launch_bounds__(256) k_gemm_pack_gallery_bf16(const float4* __
 }
 
 // queries -> qb[(jb * dk16 + kb) * 2 + {hi, lo}][lane], zero padded to kQT queries
-__global__ void __launch_bounds__(256) k_gemm_pack_queries_bf16(const float* __restrict__ q, int nq, int d, int dk16, uint4* __restrict__ qbf) {
+__global__ void __launch_bounds__(256) k_gemm_pack_queries_bf16(const float* q, int nq, int d, int dk16, uint4* qbf) {
+    q += (size_t)blockIdx.y * kQT * d;       // blockIdx.y = pass
+    nq -= (int)blockIdx.y * kQT;
+    qbf += (size_t)blockIdx.y * (kQT / 32) * dk16 * 128;
     const int o = blockIdx.x * 256 + threadIdx.x;
     if (o >= (kQT / 32) * dk16 * 64) return;
     const int l = o & 63;
@@ -319,6 +334,11 @@ __global__ void __launch_bounds__(256) k_gemm_pack_queries_bf16(const float* __r
     qbf[(size_t)(t * 2 + 1) * 64 + l] = vl;
 }
 
+__device__ __forceinline__ uint4 ld_nt(const uint4* p) {      // non-temporal: the gallery fragments are streamed once per pass
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    const v4u v = __builtin_nontemporal_load((const v4u*)p);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
 __device__ __forceinline__ bf16x8 as_bf16x8(const uint4 v) {
     bf16x8 r;
     __builtin_memcpy(&r, &v, 16);
@@ -329,20 +349,30 @@ __device__ __forceinline__ bf16x8 as_bf16x8(const uint4 v) {
 // Dynamic LDS: one slab of the query tile: 2 query blocks x sk16 k-blocks x {hi, lo} x 64 uint4 (128 KiB at 512 features).
 template <int MODE>
 __global__ void __launch_bounds__(kGemmBlock, 2) k_gemm_proxy_bf16(const uint4* __restrict__ gb, const float* __restrict__ gnorm,
-                                                                    const uint4* __restrict__ qbf, int64_t n, int64_t row_begin,
-                                                                    int64_t row_end, int dk16, const float* __restrict__ tau,
-                                                                    unsigned long long* __restrict__ lists, int* __restrict__ counts,
-                                                                    float* __restrict__ sample, int sample_rows) {
+                                                                    const uint4* qbf, int64_t n, int64_t row_begin,
+                                                                    int64_t row_end, int dk16, const float* tau, unsigned long long* lists, int* counts, float* sample,
+                                                                    int sample_rows) {
     extern __shared__ __attribute__((aligned(16))) uint4 lqb[];
     __shared__ float tau_s[kQT];
+    {   // blockIdx.y = pass (64 queries each); every per-pass buffer is laid out pass-major
+        const size_t ps = blockIdx.y;
+        qbf += ps * (kQT / 32) * dk16 * 128;
+        tau += ps * kQT;
+        lists += ps * kQT * kListCap;
+        counts += ps * kQT;
+        sample += ps * kQT * sample_rows;
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wpb = blockDim.x >> 6;
-    const int sk16 = dk16 < kSlab16 ? dk16 : kSlab16;
+    // MODE 0 (the short sample pass) reads the query fragments straight from global memory (L2-resident) and is launched
+    // WITHOUT dynamic LDS, so its small workgroups fit next to the full pass's 128-KiB workgroups on the same CUs.
+    const int sk16 = MODE == 0 ? dk16 : (dk16 < kSlab16 ? dk16 : kSlab16);
     const int nslab = (dk16 + sk16 - 1) / sk16;
+    const uint4* bsrc = MODE == 0 ? qbf : lqb;
     if (MODE == 1 && threadIdx.x < kQT) tau_s[threadIdx.x] = tau[threadIdx.x];
     const int64_t rb_begin = row_begin / 32, rb_end = (row_end + 31) / 32;
     const int64_t nrg = (rb_end - rb_begin + wpb - 1) / wpb;
-    bool staged = false;
+    bool staged = MODE == 0;
     for (int64_t rg = blockIdx.x; rg < nrg; rg += gridDim.x) {
         const int64_t rb = rb_begin + rg * wpb + wave;
         const bool active = rb < rb_end;
@@ -350,7 +380,7 @@ __global__ void __launch_bounds__(kGemmBlock, 2) k_gemm_proxy_bf16(const uint4* 
         for (int sl = 0; sl < nslab; ++sl) {
             const int k0 = sl * sk16;
             const int kw = dk16 - k0 < sk16 ? dk16 - k0 : sk16;            // k-blocks in this slab (a multiple of 4)
-            if (nslab > 1 || !staged) {
+            if (MODE == 1 && (nslab > 1 || !staged)) {
                 __syncthreads();
                 for (int i = threadIdx.x; i < 2 * kw * 128; i += blockDim.x) {
                     const int jb = i / (kw * 128), r = i - jb * kw * 128;
@@ -362,18 +392,22 @@ __global__ void __launch_bounds__(kGemmBlock, 2) k_gemm_proxy_bf16(const uint4* 
             if (!active) continue;
             const uint4* a = gb + ((size_t)rb * dk16 + k0) * 128 + lane;      // +0: hi fragment, +64: lo fragment of a k-block
             const int last = kw - 1;
-            // four k-blocks (hi + lo = 2 KiB per wave each) in flight, re-issued right after use
-            uint4 h0 = a[0], l0 = a[64];
-            uint4 h1 = a[(size_t)(1 < last ? 1 : last) * 128], l1 = a[(size_t)(1 < last ? 1 : last) * 128 + 64];
-            uint4 h2 = a[(size_t)(2 < last ? 2 : last) * 128], l2 = a[(size_t)(2 < last ? 2 : last) * 128 + 64];
-            uint4 h3 = a[(size_t)(3 < last ? 3 : last) * 128], l3 = a[(size_t)(3 < last ? 3 : last) * 128 + 64];
+            // EIGHT k-blocks (hi + lo = 2 KiB per wave each, 16 KiB per wave) in flight, non-temporal, re-issued right after use:
+            // this kernel is HBM-bound (the six MFMAs of a k-block take 192 cycles, its 2 KiB take longer to arrive)
+#define FIR_BF_LD(IDX) ld_nt(a + (size_t)((IDX) < last ? (IDX) : last) * 128)
+#define FIR_BF_LDL(IDX) ld_nt(a + (size_t)((IDX) < last ? (IDX) : last) * 128 + 64)
+            uint4 h0 = FIR_BF_LD(0), l0 = FIR_BF_LDL(0), h1 = FIR_BF_LD(1), l1 = FIR_BF_LDL(1), h2 = FIR_BF_LD(2), l2 = FIR_BF_LDL(2),
+                  h3 = FIR_BF_LD(3), l3 = FIR_BF_LDL(3), h4 = FIR_BF_LD(4), l4 = FIR_BF_LDL(4), h5 = FIR_BF_LD(5), l5 = FIR_BF_LDL(5),
+                  h6 = FIR_BF_LD(6), l6 = FIR_BF_LDL(6), h7 = FIR_BF_LD(7), l7 = FIR_BF_LDL(7);
             // query fragments one step ahead: block 0 hi/lo, block 1 hi/lo
-            uint4 b0h = lqb[lane], b0l = lqb[64 + lane], b1h = lqb[(size_t)sk16 * 128 + lane], b1l = lqb[(size_t)sk16 * 128 + 64 + lane];
+            const uint4* bq0 = bsrc + (size_t)(MODE == 0 ? k0 : 0) * 128 + lane;
+            const uint4* bq1 = bq0 + (size_t)sk16 * 128;
+            uint4 b0h = bq0[0], b0l = bq0[64], b1h = bq1[0], b1l = bq1[64];
 #define FIR_BF_STEP(AH, AL, KB)                                                                                  \
             {                                                                                                    \
                 const int kn = (KB) + 1 < kw ? (KB) + 1 : (KB);                                                  \
-                const uint4 n0h = lqb[(size_t)kn * 128 + lane], n0l = lqb[(size_t)kn * 128 + 64 + lane];         \
-                const uint4 n1h = lqb[(size_t)(sk16 + kn) * 128 + lane], n1l = lqb[(size_t)(sk16 + kn) * 128 + 64 + lane]; \
+                const uint4 n0h = bq0[(size_t)kn * 128], n0l = bq0[(size_t)kn * 128 + 64];                       \
+                const uint4 n1h = bq1[(size_t)kn * 128], n1l = bq1[(size_t)kn * 128 + 64];                       \
                 __builtin_amdgcn_sched_barrier(0);                                                               \
                 const bf16x8 ah = as_bf16x8(AH), al = as_bf16x8(AL);                                             \
                 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, as_bf16x8(b0h), acc0, 0, 0, 0);               \
@@ -384,13 +418,12 @@ __global__ void __launch_bounds__(kGemmBlock, 2) k_gemm_proxy_bf16(const uint4* 
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, as_bf16x8(b1h), acc1, 0, 0, 0);               \
                 b0h = n0h; b0l = n0l; b1h = n1h; b1l = n1l;                                                      \
             }
-#define FIR_BF_NEXT(AH, AL, OFF)                                                        \
-            {                                                                           \
-                const size_t nx = (size_t)(kb + (OFF) + 4 < kw ? kb + (OFF) + 4 : last) * 128; \
-                AH = a[nx];                                                             \
-                AL = a[nx + 64];                                                        \
+#define FIR_BF_NEXT(AH, AL, OFF)                \
+            {                                   \
+                AH = FIR_BF_LD(kb + (OFF) + 8); \
+                AL = FIR_BF_LDL(kb + (OFF) + 8);\
             }
-            for (int kb = 0; kb < kw; kb += 4) {
+            for (int kb = 0; kb < kw; kb += 8) {
                 FIR_BF_STEP(h0, l0, kb)
                 FIR_BF_NEXT(h0, l0, 0)
                 FIR_BF_STEP(h1, l1, kb + 1)
@@ -399,9 +432,21 @@ __global__ void __launch_bounds__(kGemmBlock, 2) k_gemm_proxy_bf16(const uint4* 
                 FIR_BF_NEXT(h2, l2, 2)
                 FIR_BF_STEP(h3, l3, kb + 3)
                 FIR_BF_NEXT(h3, l3, 3)
+                if (kb + 4 < kw) {      // kw is a multiple of 4, not necessarily of 8
+                    FIR_BF_STEP(h4, l4, kb + 4)
+                    FIR_BF_NEXT(h4, l4, 4)
+                    FIR_BF_STEP(h5, l5, kb + 5)
+                    FIR_BF_NEXT(h5, l5, 5)
+                    FIR_BF_STEP(h6, l6, kb + 6)
+                    FIR_BF_NEXT(h6, l6, 6)
+                    FIR_BF_STEP(h7, l7, kb + 7)
+                    FIR_BF_NEXT(h7, l7, 7)
+                }
             }
 #undef FIR_BF_NEXT
 #undef FIR_BF_STEP
+#undef FIR_BF_LD
+#undef FIR_BF_LDL
         }
         if (!active) continue;
         const int64_t nrow = rb * 32 + (lane & 31);
@@ -651,18 +696,18 @@ int fir_gemm_create_ex(fir_gallery* g, int32_t precision, fir_gemm** out) {
     if (e == hipSuccess) e = hipMalloc((void**)&m->gnorm, (size_t)np * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&m->gmax, 16);
     for (int b = 0; b < 2; ++b) {
-        if (e == hipSuccess) e = hipMalloc((void**)&m->qm[b], (size_t)(kQT / 32) * m->dq8 * 64 * sizeof(float4));
-        if (e == hipSuccess) e = hipMalloc((void**)&m->qbf[b], (size_t)(kQT / 32) * m->dk16 * 128 * sizeof(uint4));
-        if (e == hipSuccess) e = hipMalloc((void**)&m->qnorm[b], kQT * sizeof(float));
-        if (e == hipSuccess) e = hipMalloc((void**)&m->tau[b], kQT * sizeof(float));
-        if (e == hipSuccess) e = hipMalloc((void**)&m->lists[b], (size_t)kQT * kListCap * sizeof(unsigned long long));
-        if (e == hipSuccess) e = hipMalloc((void**)&m->counts[b], kQT * sizeof(int));
+        if (e == hipSuccess) e = hipMalloc((void**)&m->qm[b], (size_t)kPasses * (kQT / 32) * m->dq8 * 64 * sizeof(float4));
+        if (e == hipSuccess) e = hipMalloc((void**)&m->qbf[b], (size_t)kPasses * (kQT / 32) * m->dk16 * 128 * sizeof(uint4));
+        if (e == hipSuccess) e = hipMalloc((void**)&m->qnorm[b], kPasses * kQT * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc((void**)&m->tau[b], kPasses * kQT * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc((void**)&m->lists[b], (size_t)kPasses * kQT * kListCap * sizeof(unsigned long long));
+        if (e == hipSuccess) e = hipMalloc((void**)&m->counts[b], kPasses * kQT * sizeof(int));
         if (e == hipSuccess) e = hipEventCreateWithFlags(&m->main_done[b], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&m->rerank_done[b], hipEventDisableTiming);
     }
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking);
     m->sample_rows = (int)std::min<int64_t>(np, std::max<int64_t>(kMinSampleRows, np / 64));
-    if (e == hipSuccess) e = hipMalloc((void**)&m->sample, (size_t)kQT * m->sample_rows * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&m->sample, (size_t)kPasses * kQT * m->sample_rows * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&m->fbq, (size_t)kQT * m->v.d * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&m->fbkeys, kQT * sizeof(unsigned long long));
     const int lds_bytes = precision == FIR_GEMM_F32 ? (kQT / 32) * std::min(m->dq8, kSlab8) * 64 * (int)sizeof(float4)
@@ -742,39 +787,41 @@ int fir_gemm_search_top1_keys_dev(fir_gemm* m, const float* d_queries, int32_t q
     const float e_rel = 8.0f * (float)d * 5.9604645e-8f + (m->precision == FIR_GEMM_BF16_SPLIT ? 6.1035156e-5f : 0.0f);
     const int grid = m->v.cus;      // one 512-thread workgroup per CU
     const int sample_rows = m->sample_rows;
-    int pass = 0;
-    for (int q0 = 0; q0 < qb; q0 += kQT, ++pass) {
-        const int nq = std::min(kQT, qb - q0);
-        const int b = pass & 1;
+    int sb = 0;      // super-batch = up to kPasses passes of 64 queries in ONE set of launches
+    for (int q0 = 0; q0 < qb; q0 += kPasses * kQT, ++sb) {
+        const int nq = std::min(kPasses * kQT, qb - q0);
+        const int np = (nq + kQT - 1) / kQT;
+        const int b = sb & 1;
         const float* dq = d_queries + (size_t)q0 * d;
-        if (pass >= 2) GEMM_HIP(hipStreamWaitEvent(st, m->rerank_done[b], 0));     // scratch set b is free again
-        hipLaunchKernelGGL(k_gemm_qnorm, dim3(kQT), dim3(64), 0, st, dq, nq, d, m->qnorm[b]);
-        GEMM_HIP(hipMemsetAsync(m->counts[b], 0, kQT * sizeof(int), st));
+        if (sb >= 2) GEMM_HIP(hipStreamWaitEvent(st, m->rerank_done[b], 0));     // scratch set b is free again
+        hipLaunchKernelGGL(k_gemm_qnorm, dim3(np * kQT), dim3(64), 0, st, dq, nq, d, m->qnorm[b]);
+        GEMM_HIP(hipMemsetAsync(m->counts[b], 0, (size_t)np * kQT * sizeof(int), st));
         const int sample_grid = (sample_rows + 63) / 64;
         if (m->precision == FIR_GEMM_F32) {
-            hipLaunchKernelGGL(k_gemm_pack_queries, dim3(((kQT / 32) * m->dq8 * 64 + 255) / 256), dim3(256), 0, st, dq, nq, d, m->dq8, m->qm[b]);
-            hipLaunchKernelGGL(k_gemm_proxy<0>, dim3(sample_grid), dim3(128), lds, st, m->gm, m->gnorm, m->qm[b], n, (int64_t)0,
+            hipLaunchKernelGGL(k_gemm_pack_queries, dim3(((kQT / 32) * m->dq8 * 64 + 255) / 256, np), dim3(256), 0, st, dq, nq, d, m->dq8, m->qm[b]);
+            hipLaunchKernelGGL(k_gemm_proxy<0>, dim3(sample_grid, np), dim3(128), lds, st, m->gm, m->gnorm, m->qm[b], n, (int64_t)0,
                                (int64_t)sample_rows, m->dq8, m->tau[b], m->lists[b], m->counts[b], m->sample, sample_rows);
-            hipLaunchKernelGGL(k_gemm_tau, dim3(kQT), dim3(256), 0, st, m->sample, sample_rows, m->tau[b]);
-            hipLaunchKernelGGL(k_gemm_proxy<1>, dim3(grid), dim3(kGemmBlock), lds, st, m->gm, m->gnorm, m->qm[b], n, (int64_t)0, n, m->dq8, m->tau[b],
-                               m->lists[b], m->counts[b], m->sample, sample_rows);
-        } else {
-            hipLaunchKernelGGL(k_gemm_pack_queries_bf16, dim3(((kQT / 32) * m->dk16 * 64 + 255) / 256), dim3(256), 0, st, dq, nq, d, m->dk16, m->qbf[b]);
-            hipLaunchKernelGGL(k_gemm_proxy_bf16<0>, dim3(sample_grid), dim3(128), lds, st, m->gb, m->gnorm, m->qbf[b], n, (int64_t)0,
-                               (int64_t)sample_rows, m->dk16, m->tau[b], m->lists[b], m->counts[b], m->sample, sample_rows);
-            hipLaunchKernelGGL(k_gemm_tau, dim3(kQT), dim3(256), 0, st, m->sample, sample_rows, m->tau[b]);
-            hipLaunchKernelGGL(k_gemm_proxy_bf16<1>, dim3(grid), dim3(kGemmBlock), lds, st, m->gb, m->gnorm, m->qbf[b], n, (int64_t)0, n, m->dk16,
+            hipLaunchKernelGGL(k_gemm_tau, dim3(np * kQT), dim3(256), 0, st, m->sample, sample_rows, m->tau[b]);
+            hipLaunchKernelGGL(k_gemm_proxy<1>, dim3(grid, np), dim3(kGemmBlock), lds, st, m->gm, m->gnorm, m->qm[b], n, (int64_t)0, n, m->dq8,
                                m->tau[b], m->lists[b], m->counts[b], m->sample, sample_rows);
+        } else {
+            hipLaunchKernelGGL(k_gemm_pack_queries_bf16, dim3(((kQT / 32) * m->dk16 * 64 + 255) / 256, np), dim3(256), 0, st, dq, nq, d, m->dk16,
+                               m->qbf[b]);
+            hipLaunchKernelGGL(k_gemm_proxy_bf16<0>, dim3(sample_grid, np), dim3(128), 0, st, m->gb, m->gnorm, m->qbf[b], n, (int64_t)0,
+                               (int64_t)sample_rows, m->dk16, m->tau[b], m->lists[b], m->counts[b], m->sample, sample_rows);
+            hipLaunchKernelGGL(k_gemm_tau, dim3(np * kQT), dim3(256), 0, st, m->sample, sample_rows, m->tau[b]);
+            hipLaunchKernelGGL(k_gemm_proxy_bf16<1>, dim3(grid, np), dim3(kGemmBlock), lds, st, m->gb, m->gnorm, m->qbf[b], n, (int64_t)0, n,
+                               m->dk16, m->tau[b], m->lists[b], m->counts[b], m->sample, sample_rows);
         }
         GEMM_HIP(hipEventRecord(m->main_done[b], st));
-        // exact re-rank + certificate of this pass on the side stream, under the next pass's GEMM
+        // exact re-rank + certificate of this super-batch on the side stream, under the next one's GEMM
         GEMM_HIP(hipStreamWaitEvent(m->side, m->main_done[b], 0));
         hipLaunchKernelGGL(k_gemm_rerank, dim3(nq), dim3(64), (size_t)kCand * m->dp4 * sizeof(float4), m->side, m->lists[b], m->counts[b], m->tau[b],
                            m->gal4, dq, m->qnorm[b], m->gmax, n, d, m->dp4, m->v.row_offset, e_rel, (unsigned long long*)d_keys + q0, m->ok + q0);
         GEMM_HIP(hipEventRecord(m->rerank_done[b], m->side));
-        ++m->passes;
+        m->passes += np;
     }
-    for (int b = 0; b < 2 && b < pass; ++b) GEMM_HIP(hipStreamWaitEvent(st, m->rerank_done[b], 0));   // join the side stream
+    for (int b = 0; b < 2 && b < sb; ++b) GEMM_HIP(hipStreamWaitEvent(st, m->rerank_done[b], 0));   // join the side stream
     GEMM_HIP(hipGetLastError());
     std::vector<int> h_ok((size_t)qb);
     GEMM_HIP(hipMemcpyAsync(h_ok.data(), m->ok, (size_t)qb * sizeof(int), hipMemcpyDeviceToHost, st));
