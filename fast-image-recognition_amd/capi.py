@@ -38,6 +38,7 @@ SYMBOLS = [
     ("fir_gallery_info", C.c_int, [_vp, _i64p, _i32p, _i32p, _i32p]),
     ("fir_gallery_set_metric", C.c_int, [_vp, C.c_int32]),
     ("fir_gallery_set_row_offset", C.c_int, [_vp, C.c_int64]),
+    ("fir_gallery_set_large_batch_mfma", C.c_int, [_vp, C.c_int32]),
     ("fir_feature_distance", C.c_int, [_vp, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f32p]),
     ("fir_search_top1", C.c_int, [_vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp]),
     ("fir_search_top1_keys_dev", C.c_int, [_vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp]),
@@ -178,6 +179,9 @@ class Gallery:
 
     def set_row_offset(self, off):
         _check(lib().fir_gallery_set_row_offset(self._h, off))
+
+    def set_large_batch_mfma(self, min_queries):
+        _check(lib().fir_gallery_set_large_batch_mfma(self._h, min_queries))
 
     def set_tuning(self, queries_per_pass=0, waves=0):
         _check(lib().fir_gallery_set_tuning(self._h, queries_per_pass, waves))

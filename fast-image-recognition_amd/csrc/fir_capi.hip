@@ -71,6 +71,8 @@ struct fir_gallery {
     int waves_req = 0;        // 0 = automatic
     int max_waves = 0;        // upper bound over all scan kernels (8 blocks per CU)
     int last_waves = 0;       // waves of the most recent scan launch
+    int large_batch_min = 0;  // > 0: fir_search_top1 sends L2 whole-range batches of at least this many queries through fir_gemm_*
+    fir_gemm* gemm = nullptr; // created on first use
     int max_tiles_per_launch = 64;   // query tiles (gallery passes) folded into one launch of the hand-scheduled kernels
 
     struct Occ { const void* fn; size_t lds; int waves; };
@@ -480,6 +482,7 @@ int fir_gallery_destroy(fir_gallery* g) {
     if (!g) return FIR_OK;
     (void)hipSetDevice(g->device);
     if (g->stream) (void)hipStreamSynchronize(g->stream);
+    if (g->gemm) { fir_gemm_destroy(g->gemm); g->gemm = nullptr; }
     for (hipEvent_t e : g->ev) (void)hipEventDestroy(e);
     (void)hipFree(g->gal4); (void)hipFree(g->cls); (void)hipFree(g->qt); (void)hipFree(g->dq); (void)hipFree(g->dkeys);
     (void)hipFree(g->part); (void)hipFree(g->dout); (void)hipFree(g->didx);
@@ -504,11 +507,20 @@ int fir_gallery_set_metric(fir_gallery* g, int32_t metric) {
     return FIR_OK;
 }
 
+int fir_gallery_set_large_batch_mfma(fir_gallery* g, int32_t min_queries) {
+    if (!g) return fail(FIR_ERR_ARG, "gallery is NULL");
+    if (min_queries < 0) return fail(FIR_ERR_ARG, "min_queries < 0");
+    g->large_batch_min = min_queries;
+    if (min_queries == 0 && g->gemm) { fir_gemm_destroy(g->gemm); g->gemm = nullptr; }
+    return FIR_OK;
+}
+
 int fir_gallery_set_row_offset(fir_gallery* g, int64_t first_global_row) {
     if (!g) return fail(FIR_ERR_ARG, "gallery is NULL");
     if (first_global_row < 0 || first_global_row + g->n >= ((int64_t)1 << 31))
         return fail(FIR_ERR_ARG, "row offset %lld + n does not fit 32-bit indices", (long long)first_global_row);
     g->row_offset = first_global_row;
+    if (g->gemm) { fir_gemm_destroy(g->gemm); g->gemm = nullptr; }   // it caches the offset; rebuilt on next use
     return FIR_OK;
 }
 
@@ -557,7 +569,14 @@ int fir_search_top1(fir_gallery* g, const float* queries, int32_t qb, int32_t st
     if ((rc = grow(g->dq, g->dq_cap, (size_t)qb * g->d))) return rc;
     if ((rc = grow(g->dkeys, g->dkeys_cap, (size_t)qb))) return rc;
     FIR_HIP(hipMemcpyAsync(g->dq, queries, (size_t)qb * g->d * sizeof(float), hipMemcpyHostToDevice, g->stream));
-    if ((rc = top1_dev(g, g->dq, qb, start_pos, end_pos, g->dkeys, g->stream))) return rc;
+    // opt-in: large L2 whole-range batches go through the matrix cores (same keys, fir_gemm.hip)
+    if (g->large_batch_min > 0 && qb >= g->large_batch_min && g->metric == FIR_METRIC_L2 && start_pos == 0 && end_pos == g->d && g->n > 0) {
+        if (!g->gemm && (rc = fir_gemm_create(g, &g->gemm))) return rc;
+        rc = fir_gemm_search_top1_keys_dev(g->gemm, g->dq, qb, g->dkeys, g->stream);
+    } else {
+        rc = top1_dev(g, g->dq, qb, start_pos, end_pos, g->dkeys, g->stream);
+    }
+    if (rc) return rc;
     std::vector<uint64_t> keys((size_t)qb);
     FIR_HIP(hipMemcpyAsync(keys.data(), g->dkeys, (size_t)qb * sizeof(uint64_t), hipMemcpyDeviceToHost, g->stream));
     FIR_HIP(hipStreamSynchronize(g->stream));

@@ -18,6 +18,7 @@ namespace fir {
 namespace {
 int g_device = 0;
 int g_metric = FIR_DEFAULT_METRIC;
+int g_large_batch = 0;
 
 struct CacheKey {
     const void* vec;
@@ -44,6 +45,7 @@ CacheKey key_of(const std::vector<ImageInfo>& db, int dim) {
 }
 }  // namespace
 
+void set_large_batch_mfma(int min_queries) { g_large_batch = min_queries; }
 void set_device(int device) { g_device = device; }
 int device() { return g_device; }
 int metric() { return g_metric; }
@@ -71,6 +73,7 @@ fir_gallery* GalleryCache::get(const std::vector<ImageInfo>& db, int dim) {
         log_error("gallery upload");
         return nullptr;
     }
+    if (g_large_batch > 0) fir_gallery_set_large_batch_mfma(g, g_large_batch);
     g_cache[k] = g;
     return g;
 }

@@ -177,6 +177,9 @@ int fir_gemm_create(fir_gallery* g, fir_gemm** out);   /* = fir_gemm_create_ex(g
 int fir_gemm_create_ex(fir_gallery* g, int32_t precision, fir_gemm** out);
 int fir_gemm_destroy(fir_gemm* m);
 int fir_gemm_search_top1_keys_dev(fir_gemm* m, const float* d_queries, int32_t qb, uint64_t* d_keys, void* stream);
+/* Opt-in for the host-pointer call: fir_search_top1 sends L2 whole-range batches of >= min_queries queries through
+ * the matrix-core path (created on first use, costs the extra gallery copy); 0 switches it off and frees the copy. */
+int fir_gallery_set_large_batch_mfma(fir_gallery* g, int32_t min_queries);
 /* passes = 64-query GEMM passes run so far, fallback_queries = queries answered by the exact scan instead. */
 int fir_gemm_stats(const fir_gemm* m, int64_t* passes, int64_t* fallback_queries);
 

@@ -71,3 +71,22 @@ def test_gemm_nothing_found(fir):
     q = np.zeros((3, 64), np.float32)
     (idx, dist), (eidx, edist), _ = run_both(fir, rows, q)
     assert np.all(idx == -1) and np.array_equal(idx, eidx) and np.array_equal(dist, edist)
+
+
+def test_host_call_auto_dispatch(fir):
+    """fir_gallery_set_large_batch_mfma: the plain host-pointer search uses the matrix cores for big batches -- same answers."""
+    rows = synth.make_gallery(21, 20000, 256, 0)
+    q, _ = synth.make_queries(21, rows, 300, 0)
+    with fir.Gallery(rows, None, 0, 0) as g:
+        a = g.search_top1(q)
+        g.set_large_batch_mfma(128)
+        b = g.search_top1(q)             # 300 >= 128: GEMM path
+        c = g.search_top1(q[:50])        # below the threshold: exact scan
+        d = g.search_top1(q, 0, 64)      # a sub-range: exact scan
+        g.set_row_offset(1000)           # the cached GEMM state follows the offset
+        e = g.search_top1(q)
+        g.set_large_batch_mfma(0)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+    assert np.array_equal(a[0][:50], c[0])
+    assert d[0].shape == (300,)
+    assert np.array_equal(e[0], a[0] + 1000) and np.array_equal(e[1].view(np.uint32), a[1].view(np.uint32))
