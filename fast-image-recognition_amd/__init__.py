@@ -11,6 +11,7 @@ from .capi import (  # noqa: F401
     ClsModel,
     FirError,
     Gallery,
+    Dem,
     GemmSearch,
     METRIC_CHI2,
     METRIC_KL,

@@ -63,6 +63,13 @@ SYMBOLS = [
     ("fir_gemm_destroy", C.c_int, [_vp]),
     ("fir_gemm_search_top1_keys_dev", C.c_int, [_vp, _vp, C.c_int32, _vp, _vp]),
     ("fir_gemm_stats", C.c_int, [_vp, _i64p, _i64p]),
+    ("fir_dem_pivot_table", C.c_int, [_vp, C.c_int32, C.c_int32, _vp, _vp, _vp, _i32p]),
+    ("fir_dem_create", C.c_int, [_vp, C.c_int32, C.c_int32, C.POINTER(_vp)]),
+    ("fir_dem_destroy", C.c_int, [_vp]),
+    ("fir_dem_info", C.c_int, [_vp, _i32p, _i32p, _i32p, _i64p]),
+    ("fir_dem_get", C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    ("fir_dem_likelihoods", C.c_int, [_vp, _vp, C.c_int32, _vp, _vp]),
+    ("fir_rows_distances", C.c_int, [_vp, _vp, C.c_int32, _vp, C.c_int32, C.c_int32, C.c_int32, _vp]),
     ("fir_profile_enable", C.c_int, [_vp, C.c_int32]),
     ("fir_profile_read", C.c_int, [_vp, _vp, C.c_int32, _i32p, C.POINTER(C.c_double)]),
     ("fir_gallery_sync", C.c_int, [_vp]),
@@ -220,6 +227,25 @@ class Gallery:
         _check(lib().fir_range_distances(self._h, pq, q.shape[0], start, end, out.ctypes.data_as(_vp)))
         return out
 
+    def rows_distances(self, queries, rows, start=0, end=0):
+        """out[q][k] = distance(query q, gallery row rows[q][k]) (fir_rows_distances)."""
+        q, pq = _f32(queries)
+        q = q.reshape(-1, self.d)
+        rows = np.ascontiguousarray(rows, np.int32).reshape(q.shape[0], -1)
+        out = np.empty(rows.shape, np.float32)
+        _check(lib().fir_rows_distances(self._h, pq, q.shape[0], rows.ctypes.data_as(_vp), rows.shape[1], start, end, out.ctypes.data_as(_vp)))
+        return out
+
+    def dem_pivot_table(self, first_pivot, n_pivots, want_table=True):
+        """DirectedEnumeration's PIVOT build (ann.cpp:302-331): (pivots, table or None, min_other, n_built)."""
+        piv = np.empty(n_pivots, np.int32)
+        mo = np.empty(n_pivots, np.float32)
+        table = np.empty((n_pivots, self.n), np.float32) if want_table else None
+        built = C.c_int32()
+        _check(lib().fir_dem_pivot_table(self._h, first_pivot, n_pivots, piv.ctypes.data_as(_vp),
+                                         table.ctypes.data_as(_vp) if want_table else None, mo.ctypes.data_as(_vp), C.byref(built)))
+        return piv, table, mo, built.value
+
     def range_distances_dev(self, q_ptr, qb, out_ptr, start=0, end=0, stream=None):
         _check(lib().fir_range_distances_dev(self._h, _vp(q_ptr), qb, start, end, _vp(out_ptr), _vp(stream) if stream else None))
 
@@ -296,6 +322,46 @@ class GemmSearch:
         a, b = C.c_int64(), C.c_int64()
         _check(lib().fir_gemm_stats(self._h, C.byref(a), C.byref(b)))
         return {"passes": a.value, "fallback_queries": b.value}
+
+
+class Dem:
+    """DirectedEnumeration's device state (fir_dem_*): pivot table + kept pivots, likelihoods at query time."""
+
+    def __init__(self, gallery, first_pivot, n_pivots):
+        self._g = gallery
+        self._h = _vp()
+        _check(lib().fir_dem_create(gallery._h, first_pivot, n_pivots, C.byref(self._h)))
+        a, b, c, n = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int64()
+        _check(lib().fir_dem_info(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(n)))
+        self.n_pivots, self.n_built, self.n_used, self.n = a.value, b.value, c.value, n.value
+
+    def close(self):
+        if self._h:
+            lib().fir_dem_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def get(self, want_table=True):
+        piv = np.empty(self.n_pivots, np.int32)
+        mo = np.empty(self.n_pivots, np.float32)
+        table = np.empty((self.n_used, self.n), np.float32) if want_table else None
+        order = np.empty(self.n, np.int32)
+        _check(lib().fir_dem_get(self._h, piv.ctypes.data_as(_vp), mo.ctypes.data_as(_vp),
+                                 table.ctypes.data_as(_vp) if want_table else None, order.ctypes.data_as(_vp)))
+        return piv, mo, table, order
+
+    def likelihoods(self, queries, want_lik=True):
+        q, pq = _f32(queries)
+        q = q.reshape(-1, self._g.d)
+        pd = np.empty((q.shape[0], self.n_used), np.float32)
+        lik = np.empty((q.shape[0], self.n), np.float32) if want_lik else None
+        _check(lib().fir_dem_likelihoods(self._h, pq, q.shape[0], pd.ctypes.data_as(_vp), lik.ctypes.data_as(_vp) if want_lik else None))
+        return pd, lik
 
 
 class ClsModel:

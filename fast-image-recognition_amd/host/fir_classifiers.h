@@ -173,4 +173,37 @@ public:
     }
 };
 
+// ---- ann.h:64-100, ann.cpp:270-507 (PIVOT build): maximum-likelihood directed enumeration ----
+// The constructor's pivot table (n_pivots gallery scans), the per-query likelihood update over the table and the
+// candidate distance checks run on the GPU (fir_dem_*, fir_rows_distances); the walk itself -- the index
+// bookkeeping, std::partial_sort, the early exit below `threshold` -- is the reference's sequential logic on the
+// host, so row, bestDistance, isFoundLessThreshold and the checked-percent counter come out the same.
+class DirectedEnumeration : public ClassificationMethod {
+public:
+    DirectedEnumeration(std::vector<ImageInfo>& faceImages, float falseAcceptRate = 0.01f, float threshold = 0, int imageCountToCheck = 0);
+    ~DirectedEnumeration();
+    DirectedEnumeration(const DirectedEnumeration&) = delete;
+    DirectedEnumeration& operator=(const DirectedEnumeration&) = delete;
+
+    int recognize(ImageInfo& testImage) override;
+    std::vector<int> recognize_batch(const std::vector<ImageInfo>& tests) override;
+
+    bool isFoundLessThreshold;
+    float bestDistance;
+
+    // added: what the constructor built (tests, diagnostics)
+    float getThresholdValue() const { return threshold; }
+    const std::vector<int>& getStartIndices() const { return startIndices; }
+    int getDistanceCalcCount() const { return distanceCalcCount; }
+
+private:
+    int finish_walk(const float* query, const float* pivot_dist, const float* likelihoods);
+    float threshold;
+    std::vector<int> startIndices;            // <= 32 kept (ann.cpp:333-334)
+    std::vector<int> order0;                  // likelihood_indices after the pivot loop (ann.cpp:427-432)
+    std::vector<int> likelihood_indices;
+    fir_gallery* gallery;                     // owned: all FEATURES_COUNT features of dbImages
+    fir_dem* dem;
+};
+
 #endif  // FIR_CLASSIFIERS_H

@@ -4,6 +4,7 @@
 //   host_driver <features.txt> [max_features ...]
 #include <cstdio>
 #include <cstdlib>
+#include <iostream>
 
 #include "compat/ann.h"
 #include "compat/db_features.h"
@@ -64,6 +65,33 @@ int main(int argc, char** argv) {
             std::snprintf(key, sizeof key, "%s_first6", keys[i]);
             print_vec(key, one, true);
             std::printf("\"%s_unreliable\": %d, \"%s_name\": \"%s\",\n", keys[i], unrel, keys[i], twd[i]->get_name().c_str());
+        }
+    }
+    {   // DirectedEnumeration the way testANN drives it (ann.cpp:62-72): one build, several imageCountToCheck
+        std::streambuf* old = std::cout.rdbuf(nullptr);     // the constructor prints like the reference's; keep stdout JSON
+        std::srand(13);
+        DirectedEnumeration dem(dbImages);
+        std::cout.rdbuf(old);
+        print_vec("dem_pivots", dem.getStartIndices(), true);
+        std::printf("\"dem_threshold\": %.9g,\n", dem.getThresholdValue());
+        const int counts[3] = {0, 40, 100};
+        for (int c = 0; c < 3; ++c) {
+            dem.setImageCountToCheck(counts[c]);
+            std::vector<int> batch = dem.recognize_batch(testImages), one, calc, found;
+            for (ImageInfo t : testImages) {
+                one.push_back(dem.recognize(t));
+                calc.push_back(dem.getDistanceCalcCount());
+                found.push_back(dem.isFoundLessThreshold ? 1 : 0);
+            }
+            char key[64];
+            std::snprintf(key, sizeof key, "dem_%d_batch", counts[c]);
+            print_vec(key, batch, true);
+            std::snprintf(key, sizeof key, "dem_%d_single", counts[c]);
+            print_vec(key, one, true);
+            std::snprintf(key, sizeof key, "dem_%d_calc", counts[c]);
+            print_vec(key, calc, true);
+            std::snprintf(key, sizeof key, "dem_%d_found", counts[c]);
+            print_vec(key, found, true);
         }
     }
     BruteForce ann(dbImages);                               // ann.h BruteForce -> gallery rows

@@ -163,6 +163,39 @@ int fir_cls_pnn_predict_seq(fir_cls* c, const double* queries, int32_t qb, doubl
  * class until one class has k votes. 1 <= k <= 8. best_class[qb]. */
 int fir_cls_knn_predict(fir_cls* c, const double* queries, int32_t qb, int32_t k, int32_t* best_class);
 
+/* ---- DirectedEnumeration (maximum-likelihood directed enumeration, ann.h:64-100) -------------------
+ * The PIVOT build of the constructor, ann.cpp:302-331: for ii = 0..n_pivots-1, table row ii = distance(gallery row j,
+ * pivot ii) over all d features (ann.h:33-38), min_other[ii] = smallest distance from pivot ii to a row of another class
+ * (:309-311,325 -> otherClassesDists, the input of getThreshold :341-343), and pivot ii+1 = the first row whose summed
+ * distance to the pivots so far (-1000000 restart at a pivot, :313-318) is largest and > 0 (:319-322).
+ * pivots[0] = first_pivot (the reference draws it with random_shuffle, :366-376). The gallery needs class labels.
+ * pivots_out[n_pivots], table_out[n_pivots][n] (may be NULL), min_other_out[n_pivots] (may be NULL).
+ * *n_built_out (may be NULL) < n_pivots when no row had a positive sum (identical rows): the reference would index
+ * dbImages[-1] there; the remaining pivots are -1 and their table rows unspecified. */
+int fir_dem_pivot_table(fir_gallery* g, int32_t first_pivot, int32_t n_pivots, int32_t* pivots_out, float* table_out,
+                        float* min_other_out, int32_t* n_built_out);
+
+/* The same build kept on the device for query time: the table rows of the first min(n_built, 32) pivots
+ * (ann.cpp:333-334 keeps 32) and those pivots as a small gallery of their own. The gallery handle must outlive it. */
+typedef struct fir_dem fir_dem;
+int fir_dem_create(fir_gallery* g, int32_t first_pivot, int32_t n_pivots, fir_dem** out);
+int fir_dem_destroy(fir_dem* h);
+int fir_dem_info(const fir_dem* h, int32_t* n_pivots, int32_t* n_built, int32_t* n_used, int64_t* n);
+/* pivots_out[n_pivots], min_other_out[n_pivots], table_out[n_used][n], order_out[n] = the state of
+ * `likelihood_indices` after the pivot loop of recognize (ann.cpp:427-432; identity except near the front). Any may be NULL. */
+int fir_dem_get(fir_dem* h, int32_t* pivots_out, float* min_other_out, float* table_out, int32_t* order_out);
+/* The data-parallel part of DirectedEnumeration::recognize (ann.cpp:427-447) for qb queries:
+ * pivot_dist_out[qb][n_used] = distance(query, pivot i) (CHECK_FOR_BEST_DIST's tmpDist), and
+ * lik_out[qb][n] = `likelihoods` after all n_used pivots: sum over i, in order, of (tmpDist_i - table[i][nu])^2 in
+ * float, each row visited as often as the reference's index bookkeeping visits it. Either may be NULL. */
+int fir_dem_likelihoods(fir_dem* h, const float* queries, int32_t qb, float* pivot_dist_out, float* lik_out);
+
+/* out[qb][m] = distance(query q, gallery row rows[q][m]) over [start_pos, end_pos) (end_pos 0 = d): the candidate
+ * checks of an enumeration (CHECK_FOR_BEST_DIST, ann.cpp:389-399) as one gather. Rows are LOCAL indices; a row
+ * outside the gallery yields 100000. */
+int fir_rows_distances(fir_gallery* g, const float* queries, int32_t qb, const int32_t* rows, int32_t m, int32_t start_pos,
+                       int32_t end_pos, float* out);
+
 /* ---- large query batches through the matrix cores (L2, whole feature range) ------------------------
  * Same answers as fir_search_top1 -- bit-identical index and distance: an f32-MFMA GEMM only nominates
  * candidate rows, the reference's arithmetic re-ranks them, a rounding-error certificate proves no other

@@ -18,6 +18,9 @@
 #   libref_kl.so    same, and the `#if 1` at db_features.cpp:30 read as `#if 0` -> the reference's
 #                   own (otherwise dead) KL / Jensen-Shannon arm, lines 33-36
 # plus libref_cls.so from classification.cpp (double-precision kNN / PNN).
+# The match TU also carries ann.h:1-47,61-100 and ann.cpp:2-22,84-126,268-507 (ClassificationMethod, BruteForce,
+# DirectedEnumeration); the class bodies are read with `private`/`protected` defined to `public` so that the
+# marshalling code can copy the pivot table and counters out -- the reference's lines themselves are untouched.
 #
 # Flags follow the reference's qmake project (recognition_testing.pro: c++11, release -O2).
 set -euo pipefail
@@ -43,8 +46,13 @@ match_tu() {   # $1 = metric id (0 l2, 1 chi2, 2 kl)
         sed -n '1,162p;319,335p' "$REF/db_features.cpp"
     fi
     sed -n '1,288p' "$REF/ImageTesting.cpp"
-    sed -n '1,47p' "$REF/ann.h"; echo '#endif'
-    sed -n '2,22p;84,126p' "$REF/ann.cpp"
+    echo '#define private public     /* the wrapper reads DirectedEnumeration::P_matrix / startIndices / threshold (ann.h:93-96) */'
+    echo '#define protected public   /* ... and ClassificationMethod::distanceCalcCount (ann.h:30) */'
+    sed -n '1,47p;61,100p' "$REF/ann.h"
+    echo '#undef private'
+    echo '#undef protected'
+    echo '#endif'
+    sed -n '2,22p;84,126p;268,507p' "$REF/ann.cpp"
     echo '#include "ref_wrap_match.inc"'
 }
 

@@ -611,6 +611,91 @@ int64_t orc_split(const int32_t* class_counts, int n_classes, const int32_t* per
     return ndb;
 }
 
+/* qt_cpp/ann.cpp:302-331 (PIVOT build of DirectedEnumeration's constructor): the pivot x gallery distance table and
+ * the greedy farthest-point choice of the next pivot. pivots[0] is given (the reference draws it with random_shuffle,
+ * :366-376); table[ii][j] = distance(dbImages[j], pivot ii) over all d features (ann.h:33-38: lhs = row j, rhs = the
+ * pivot); min_other[ii] = smallest distance to a row of another class (:309-311, pushed to otherClassesDists :325);
+ * pivots[ii+1] = the first row whose sum of distances to the pivots so far (-1000000 restarts at a pivot, :313-318)
+ * is largest and > 0 (:319-322), or -1. */
+void orc_dem_pivot_table(const float* rows, int64_t n, int d, const int32_t* class_no, int metric, int n_pivots, int32_t* pivots,
+                         float* table, float* min_other) {
+    for (int ii = 0; ii < n_pivots; ++ii) {
+        const int i = pivots[ii];
+        int mostFarModel = -1;
+        double maxFarDist = 0;
+        float min_other_dist = FLT_MAX;
+        for (int64_t j = 0; j < n; ++j) {
+            const float dist = orc_feature_distance(rows + j * d, rows + (int64_t)i * d, 0, d, metric);
+            table[(int64_t)ii * n + j] = dist;
+            if (class_no[i] != class_no[j] && dist < min_other_dist) min_other_dist = dist;
+            double currentFarDist = 0;
+            for (int ind = 0; ind <= ii; ++ind) {
+                if (pivots[ind] == j) currentFarDist = -1000000;
+                else currentFarDist += table[(int64_t)ind * n + j];
+            }
+            if (currentFarDist > maxFarDist) { maxFarDist = currentFarDist; mostFarModel = (int)j; }
+        }
+        min_other[ii] = min_other_dist;
+        if (ii < n_pivots - 1) pivots[ii + 1] = mostFarModel;
+    }
+}
+
+/* qt_cpp/ann.cpp:411-507 DirectedEnumeration::recognize (PIVOT build): walk the `used` kept pivots (early exit when a
+ * distance drops below `threshold`, :389-399), accumulating likelihoods[nu] += (tmpDist - table[i][nu])^2 in float
+ * over the index positions behind the front (:427-447, the two-write "swap" of :431-432 replayed literally); order the
+ * rest by likelihood up to position image_count_to_check (:455-456) and check candidates in that order until
+ * distanceCalcCount reaches image_count_to_check (:458-462). Equal likelihoods: std::partial_sort leaves their order
+ * unspecified; here they keep their array order (callers avoid ties). Returns the row index or -1. */
+typedef struct { float lik; int pos; int row; } orc_dem_cand;
+static int orc_dem_cmp(const void* a, const void* b) {
+    const orc_dem_cand* x = (const orc_dem_cand*)a; const orc_dem_cand* y = (const orc_dem_cand*)b;
+    if (x->lik < y->lik) return -1;
+    if (y->lik < x->lik) return 1;
+    return x->pos - y->pos;
+}
+int orc_dem_recognize(const float* rows, int64_t n, int d, int metric, const int32_t* pivots, int used, const float* table,
+                      float threshold, int image_count_to_check, const float* query, float* best_dist, int* found,
+                      int* calc_count, float* lik_out) {
+    float* likelihoods = (float*)calloc((size_t)n, sizeof(float));
+    int* likelihood_indices = (int*)malloc((size_t)n * sizeof(int));
+    int bestIndex = -1, start_index = 0, distanceCalcCount = 0, isFound = 0;
+    float bestDistance = FLT_MAX, tmpDist;
+    if (image_count_to_check <= 0 || image_count_to_check >= n) image_count_to_check = (int)n;   /* ann.h:20-22 */
+    for (int64_t i = 0; i < n; ++i) likelihood_indices[i] = (int)i;
+    for (int i = 0; i < used; ++i) {
+        const int imageNum = pivots[i];
+        tmpDist = orc_feature_distance(query, rows + (int64_t)imageNum * d, 0, d, metric); ++distanceCalcCount;
+        if (tmpDist < bestDistance) { bestDistance = tmpDist; bestIndex = imageNum; if (bestDistance < threshold) { isFound = 1; goto end; } }
+        likelihood_indices[imageNum] = likelihood_indices[start_index];
+        likelihood_indices[start_index++] = imageNum;
+        for (int64_t ii = start_index; ii < n; ++ii) {
+            const int nu = likelihood_indices[ii];
+            const float modelsDist = table[(int64_t)i * n + nu];
+            if (modelsDist >= 0) { const float tmp = tmpDist - modelsDist; likelihoods[nu] += tmp * tmp; }
+        }
+    }
+    if (lik_out) memcpy(lik_out, likelihoods, (size_t)n * sizeof(float));
+    if (image_count_to_check > start_index) {
+        const int64_t m = n - start_index;
+        orc_dem_cand* c = (orc_dem_cand*)malloc((size_t)(m > 0 ? m : 1) * sizeof(orc_dem_cand));
+        for (int64_t k = 0; k < m; ++k) { c[k].pos = (int)k; c[k].row = likelihood_indices[start_index + k]; c[k].lik = likelihoods[c[k].row]; }
+        qsort(c, (size_t)m, sizeof(orc_dem_cand), orc_dem_cmp);
+        for (int64_t k = 0; k < m; ++k) likelihood_indices[start_index + k] = c[k].row;
+        free(c);
+    }
+    while (distanceCalcCount < image_count_to_check) {
+        const int imageNum = likelihood_indices[start_index++];
+        tmpDist = orc_feature_distance(query, rows + (int64_t)imageNum * d, 0, d, metric); ++distanceCalcCount;
+        if (tmpDist < bestDistance) { bestDistance = tmpDist; bestIndex = imageNum; if (bestDistance < threshold) { isFound = 1; goto end; } }
+    }
+end:
+    if (best_dist) *best_dist = bestDistance;
+    if (found) *found = isFound;
+    if (calc_count) *calc_count = distanceCalcCount;
+    free(likelihoods); free(likelihood_indices);
+    return bestIndex;
+}
+
 /* ann.cpp:84-93 ClassificationMethod::getThreshold: the value at rank (int)(n*rate). */
 static int cmp_float(const void* a, const void* b) {
     float x = *(const float*)a, y = *(const float*)b;

@@ -104,6 +104,21 @@ def main():
     db = refs[gc.L2].db(rows, None, 1536)
     fx["ann_bf/idx"] = np.array([db.ann_bruteforce(qi) for qi in q], np.int32)
     db.close()
+    # ---- DirectedEnumeration pivot table (ann.cpp:302-331): rows of FEATURES_COUNT features, class labels ----
+    rows, dcls, dq = gc.dem_case()
+    db = refs[gc.L2].db(rows, dcls, 1536)
+    dem = db.dem(0.01, seed=13)
+    piv, table, th = dem.get()
+    fx["dem/pivots"], fx["dem/table"], fx["dem/threshold"] = piv, table, np.array(th, np.float32)
+    for m in gc.DEM_IMAGE_COUNTS:      # DirectedEnumeration::recognize (ann.cpp:411-507) at several imageCountToCheck
+        dem.set_image_count(m)
+        res = [dem.recognize(q) for q in dq]
+        fx[f"dem/recognize/{m}/row"] = np.array([r[0] for r in res], np.int32)
+        fx[f"dem/recognize/{m}/dist"] = np.array([r[1] for r in res], np.float32)
+        fx[f"dem/recognize/{m}/found"] = np.array([r[2] for r in res], np.int32)
+        fx[f"dem/recognize/{m}/calc"] = np.array([r[3] for r in res], np.int32)
+    dem.close()
+    db.close()
     dists = synth.uniform01(1000, 55)
     for rate in (0.0, 0.01, 0.1, 0.5):
         fx[f"threshold/{rate}"] = np.array(refs[gc.L2].get_threshold(dists, rate), np.float32)

@@ -19,6 +19,15 @@ def match_case(seed, n, d, metric):
     return rows, q
 
 
+DEM_IMAGE_COUNTS = (0, 40, 150)
+
+
+def dem_case():
+    """DirectedEnumeration (ann.cpp:270-507): rows of FEATURES_COUNT features, class labels, queries."""
+    rows, q = match_case(17, 500, 1536, L2)
+    return rows, synth.make_labels(500, 25), q
+
+
 def special_cases():
     """name -> (rows, queries, metric): ties, 1-ulp near ties, zero rows, NaN rows, nothing-found."""
     out = {}

@@ -54,6 +54,11 @@ class Oracle:
         L.orc_load_dataset_f64.argtypes = [C.c_char_p, C.c_int, _vp, _vp, C.c_int64, C.POINTER(C.c_int)]
         L.orc_split.restype = C.c_int64
         L.orc_split.argtypes = [_vp, C.c_int, _vp, C.c_int, C.c_double, _vp, _vp, _vp, _vp, C.POINTER(C.c_int64)]
+        L.orc_dem_pivot_table.restype = None
+        L.orc_dem_pivot_table.argtypes = [_vp, C.c_int64, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp, _vp]
+        L.orc_dem_recognize.restype = C.c_int
+        L.orc_dem_recognize.argtypes = [_vp, C.c_int64, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_float, C.c_int, _vp,
+                                        _f32p, C.POINTER(C.c_int), C.POINTER(C.c_int), _vp]
         L.orc_get_threshold.restype = C.c_float
         L.orc_get_threshold.argtypes = [_vp, C.c_int, C.c_float]
 
@@ -212,6 +217,30 @@ class Oracle:
         d = np.ascontiguousarray(dists, np.float32)
         return np.float32(self.L.orc_get_threshold(_p(d), d.size, rate))
 
+    def dem_pivot_table(self, rows, cls, first_pivot, n_pivots, metric=0):
+        rows, n, d = self._rows(rows)
+        cls = np.ascontiguousarray(cls, np.int32)
+        piv = np.full(n_pivots, -1, np.int32)
+        piv[0] = first_pivot
+        table = np.empty((n_pivots, n), np.float32)
+        mo = np.empty(n_pivots, np.float32)
+        self.L.orc_dem_pivot_table(_p(rows), n, d, _p(cls), metric, n_pivots, _p(piv), _p(table), _p(mo))
+        return piv, table, mo
+
+
+    def dem_recognize(self, rows, pivots, table, threshold, image_count, query, metric=0, want_lik=False):
+        """-> (row, best_dist, found, calc_count[, likelihoods])"""
+        rows, n, d = self._rows(rows)
+        pivots = np.ascontiguousarray(pivots, np.int32)
+        table = np.ascontiguousarray(table, np.float32)
+        q = np.ascontiguousarray(query, np.float32)
+        bd, fo, cc = C.c_float(), C.c_int(), C.c_int()
+        lik = np.zeros(n, np.float32) if want_lik else None
+        r = self.L.orc_dem_recognize(_p(rows), n, d, metric, _p(pivots), pivots.size, _p(table), float(threshold), image_count, _p(q),
+                                     C.byref(bd), C.byref(fo), C.byref(cc), _p(lik) if want_lik else None)
+        out = (r, np.float32(bd.value), fo.value, cc.value)
+        return out + (lik,) if want_lik else out
+
 
 class RefMatch:
     """oracle/_ref/libref_{l2,chi2,kl}.so -- the reference's own code (oracle/ref_wrap_match.inc)."""
@@ -239,6 +268,14 @@ class RefMatch:
         L.ref_db_ann_bruteforce.argtypes = [_vp, _vp]
         L.ref_get_threshold.restype = C.c_float
         L.ref_get_threshold.argtypes = [_vp, C.c_int, C.c_float]
+        L.ref_dem_create.restype = _vp
+        L.ref_dem_create.argtypes = [_vp, C.c_float, C.c_float, C.c_int, C.c_uint]
+        L.ref_dem_destroy.argtypes = [_vp]
+        L.ref_dem_get.restype = C.c_int
+        L.ref_dem_get.argtypes = [_vp, _vp, _vp, _f32p]
+        L.ref_dem_set_image_count.argtypes = [_vp, C.c_int]
+        L.ref_dem_recognize.restype = C.c_int
+        L.ref_dem_recognize.argtypes = [_vp, _vp, _vp, _f32p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.ref_load_images.restype = C.c_int
         L.ref_load_images.argtypes = [C.c_char_p, _vp, _vp, C.c_int64, C.POINTER(C.c_int)]
         L.ref_split_noshuffle.restype = C.c_int
@@ -324,9 +361,50 @@ class RefDb:
         r = self.ref.L.ref_db_twd_proposed(self.h, _p(q), num_classes, feat_count, th, C.byref(u))
         return int(r), int(u.value)
 
+    def dem(self, false_accept_rate=0.01, threshold=0.0, image_count=0, seed=13):
+        """The reference's DirectedEnumeration over this gallery (ann.cpp:270-507)."""
+        return RefDem(self, false_accept_rate, threshold, image_count, seed)
+
+    def dem_build(self, false_accept_rate=0.01, seed=13):
+        """DirectedEnumeration's constructor (ann.cpp:270-348): (pivots, table[np][n], threshold)."""
+        dem = self.dem(false_accept_rate, seed=seed)
+        out = dem.get()
+        dem.close()
+        return out
+
     def ann_bruteforce(self, q):
         q = np.ascontiguousarray(q, np.float32)
         return int(self.ref.L.ref_db_ann_bruteforce(self.h, _p(q)))
+
+
+class RefDem:
+    def __init__(self, db, false_accept_rate, threshold, image_count, seed):
+        self.db, self.L = db, db.ref.L
+        self.h = self.L.ref_dem_create(db.h, false_accept_rate, threshold, image_count, seed)
+        assert self.h, "gallery must hold FEATURES_COUNT features"
+
+    def get(self):
+        npiv = min(32, max(5, int(self.db.n * 0.015)))
+        piv = np.empty(npiv, np.int32)
+        table = np.empty((npiv, self.db.n), np.float32)
+        th = C.c_float()
+        got = self.L.ref_dem_get(self.h, _p(piv), _p(table), C.byref(th))
+        assert got == npiv, got
+        return piv, table, np.float32(th.value)
+
+    def set_image_count(self, m):
+        self.L.ref_dem_set_image_count(self.h, m)
+
+    def recognize(self, query):
+        q = np.ascontiguousarray(query, np.float32)
+        bd, fo, cc = C.c_float(), C.c_int(), C.c_int()
+        r = self.L.ref_dem_recognize(self.h, self.db.h, _p(q), C.byref(bd), C.byref(fo), C.byref(cc))
+        return r, np.float32(bd.value), fo.value, cc.value
+
+    def close(self):
+        if self.h:
+            self.L.ref_dem_destroy(self.h)
+            self.h = None
 
 
 class RefCls:

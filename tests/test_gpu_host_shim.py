@@ -65,6 +65,18 @@ def test_host_shim_matches_oracle_end_to_end(tmp_path, oracle):
         assert got[key + "_first6"] == [e[0] for e in exp][:6], key
         assert got[key + "_unreliable"] == sum(e[1] for e in exp), key
     assert got["twd_post_name"] == "TWD posteriors, 0.24" and got["twd_p32_name"] == "Proposed TWD, 32, 0.7"
+    # DirectedEnumeration (ann.cpp:270-507): the greedy pivots, the false-accept threshold and the walk
+    npiv = max(5, int(len(gal) * 0.015))
+    piv, table, mo = oracle.dem_pivot_table(gal, dbc, got["dem_pivots"][0], npiv, 0)
+    assert got["dem_pivots"] == list(piv)
+    th = oracle.get_threshold(mo, 0.01)
+    assert np.float32(got["dem_threshold"]) == th
+    for m in (0, 40, 100):
+        exp = [oracle.dem_recognize(gal, piv, table, th, m, qi, 0) for qi in q]
+        assert got[f"dem_{m}_batch"] == [e[0] for e in exp], m
+        assert got[f"dem_{m}_single"] == [e[0] for e in exp], m
+        assert got[f"dem_{m}_calc"] == [e[3] for e in exp], m
+        assert got[f"dem_{m}_found"] == [e[2] for e in exp], m
 
 
 def test_classification_shim_matches_oracle_end_to_end(tmp_path, oracle):

@@ -83,6 +83,32 @@ def test_ann_bruteforce_and_threshold_match_reference(oracle):
         assert bits(oracle.get_threshold(dists, rate)) == bits(GOLD[f"threshold/{rate}"])
 
 
+def test_dem_pivot_table_matches_reference(oracle):
+    """DirectedEnumeration's constructor (ann.cpp:270-348): table, greedy pivots, false-accept threshold."""
+    rows, cls, _ = gc.dem_case()
+    gp, gt, gth = GOLD["dem/pivots"], GOLD["dem/table"], GOLD["dem/threshold"]
+    assert gp.size == max(5, int(500 * 0.015)) == 7
+    piv, table, mo = oracle.dem_pivot_table(rows, cls, int(gp[0]), gp.size, gc.L2)
+    assert np.array_equal(piv, gp)
+    assert np.array_equal(bits(table), bits(gt))
+    assert bits(oracle.get_threshold(mo, 0.01)) == bits(gth)      # otherClassesDists -> getThreshold (ann.cpp:341-343)
+
+
+def test_dem_recognize_matches_reference(oracle):
+    """DirectedEnumeration::recognize (ann.cpp:411-507): row, bestDistance, isFoundLessThreshold, distanceCalcCount."""
+    rows, cls, queries = gc.dem_case()
+    gp, gt, gth = GOLD["dem/pivots"], GOLD["dem/table"], GOLD["dem/threshold"]
+    seen_found = seen_full = 0
+    for m in gc.DEM_IMAGE_COUNTS:
+        for i, q in enumerate(queries):
+            r, bd, fo, cc = oracle.dem_recognize(rows, gp, gt, gth, m, q, gc.L2)
+            want = tuple(GOLD[f"dem/recognize/{m}/{k}"][i] for k in ("row", "dist", "found", "calc"))
+            assert (r, bits(bd), fo, cc) == (want[0], bits(want[1]), want[2], want[3]), (m, i)
+            seen_found += fo
+            seen_full += (cc == (m or len(rows)))
+    assert seen_found and seen_full       # both exits of the walk are exercised
+
+
 def test_loader_and_split_match_reference(oracle):
     names, classes, feats, d = gc.loader_case()
     with tempfile.TemporaryDirectory() as td:
