@@ -10,6 +10,7 @@ The directory name is not an importable identifier; load it with
 from .capi import (  # noqa: F401
     ClsModel,
     FirError,
+    Fpnn,
     Gallery,
     Dem,
     GemmSearch,

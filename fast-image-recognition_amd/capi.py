@@ -70,6 +70,12 @@ SYMBOLS = [
     ("fir_dem_get", C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     ("fir_dem_likelihoods", C.c_int, [_vp, _vp, C.c_int32, _vp, _vp]),
     ("fir_rows_distances", C.c_int, [_vp, _vp, C.c_int32, _vp, C.c_int32, C.c_int32, C.c_int32, _vp]),
+    ("fir_fpnn_train", C.c_int, [_vp, C.c_int64, C.c_int32, _vp, C.c_int32, _vp, _vp, C.c_double, C.c_int32, C.POINTER(_vp)]),
+    ("fir_fpnn_destroy", C.c_int, [_vp]),
+    ("fir_fpnn_info", C.c_int, [_vp, _i32p, _i32p, _i32p]),
+    ("fir_fpnn_get_model", C.c_int, [_vp, _vp]),
+    ("fir_fpnn_predict", C.c_int, [_vp, _vp, C.c_int32, _vp, _vp]),
+    ("fir_fpnn_predict_seq", C.c_int, [_vp, _vp, C.c_int32, C.c_float, _vp, _vp]),
     ("fir_profile_enable", C.c_int, [_vp, C.c_int32]),
     ("fir_profile_read", C.c_int, [_vp, _vp, C.c_int32, _i32p, C.POINTER(C.c_double)]),
     ("fir_gallery_sync", C.c_int, [_vp]),
@@ -362,6 +368,54 @@ class Dem:
         lik = np.empty((q.shape[0], self.n), np.float32) if want_lik else None
         _check(lib().fir_dem_likelihoods(self._h, pq, q.shape[0], pd.ctypes.data_as(_vp), lik.ctypes.data_as(_vp) if want_lik else None))
         return pd, lik
+
+
+class Fpnn:
+    """FPNNClassifier (classification.cpp:618-791): trained trigonometric-series model on the device."""
+
+    def __init__(self, train_rows, train_class, num_classes, avg, sd, scale=1.0, device=0):
+        rows = np.ascontiguousarray(train_rows, np.float64)
+        cls = np.ascontiguousarray(train_class, np.int32)
+        avg = np.ascontiguousarray(avg, np.float64)
+        sd = np.ascontiguousarray(sd, np.float64)
+        self.d, self.num_classes = rows.shape[1], num_classes
+        self._h = _vp()
+        _check(lib().fir_fpnn_train(rows.ctypes.data_as(_vp), rows.shape[0], self.d, cls.ctypes.data_as(_vp), num_classes,
+                                    avg.ctypes.data_as(_vp), sd.ctypes.data_as(_vp), scale, device, C.byref(self._h)))
+        j = C.c_int32()
+        _check(lib().fir_fpnn_info(self._h, C.byref(j), None, None))
+        self.J = j.value
+
+    def close(self):
+        if self._h:
+            lib().fir_fpnn_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def model(self):
+        a = np.empty(self.d * self.num_classes * (2 * self.J + 1), np.float64)
+        _check(lib().fir_fpnn_get_model(self._h, a.ctypes.data_as(_vp)))
+        return a
+
+    def predict(self, queries):
+        q = np.ascontiguousarray(queries, np.float64).reshape(-1, self.d)
+        best = np.empty(q.shape[0], np.int32)
+        outs = np.empty((q.shape[0], self.num_classes), np.float32)
+        _check(lib().fir_fpnn_predict(self._h, q.ctypes.data_as(_vp), q.shape[0], best.ctypes.data_as(_vp), outs.ctypes.data_as(_vp)))
+        return best, outs
+
+    def predict_seq(self, queries, output_ratio=0.9):
+        q = np.ascontiguousarray(queries, np.float64).reshape(-1, self.d)
+        best = np.empty(q.shape[0], np.int32)
+        chunks = np.empty(q.shape[0], np.int32)
+        _check(lib().fir_fpnn_predict_seq(self._h, q.ctypes.data_as(_vp), q.shape[0], output_ratio, best.ctypes.data_as(_vp),
+                                          chunks.ctypes.data_as(_vp)))
+        return best, chunks
 
 
 class ClsModel:

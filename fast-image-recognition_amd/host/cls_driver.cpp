@@ -28,9 +28,10 @@ int main(int argc, char** argv) {
     KNNClassifier knn1(1), knn3(3);
     PNNClassifier pnn(true), pnn_seq(false);
     PNNwithClusteringClassifier clust(5);
-    Classifier* all[5] = {&knn1, &knn3, &pnn, &pnn_seq, &clust};
-    const char* keys[5] = {"knn1", "knn3", "pnn", "pnn_seq", "pnn_clust5"};
-    for (int i = 0; i < 5; ++i) {
+    FPNNClassifier fpnn(1.0, true), fpnn033(0.33, true), fpnn_seq(1.0, false), fpnn033_seq(0.33, false, 0.99f);   // :1002-1007
+    Classifier* all[9] = {&knn1, &knn3, &pnn, &pnn_seq, &clust, &fpnn, &fpnn033, &fpnn_seq, &fpnn033_seq};
+    const char* keys[9] = {"knn1", "knn3", "pnn", "pnn_seq", "pnn_clust5", "fpnn", "fpnn033", "fpnn_seq", "fpnn033_seq"};
+    for (int i = 0; i < 9; ++i) {
         all[i]->train();
         std::vector<int> one;
         for (const Feature_vector* fv : inputs) one.push_back(all[i]->predict(*fv));
@@ -45,6 +46,7 @@ int main(int argc, char** argv) {
     std::vector<int> medoids;
     for (const auto& c : clust.clusters()) for (size_t t : c) medoids.push_back((int)t);
     print_vec("medoid_rows", medoids, true);
+    std::printf("\"fpnn_J\": %d,\n", fpnn.harmonics());
     std::printf("\"avg0\": %.17g\n}\n", st.avgValues.empty() ? 0.0 : st.avgValues[0]);
     if (st.model) fir_cls_destroy(st.model);
     return 0;

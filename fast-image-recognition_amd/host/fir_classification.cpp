@@ -269,3 +269,50 @@ std::vector<int> PNNwithClusteringClassifier::predict_batch(const std::vector<co
 int PNNwithClusteringClassifier::predict(const Feature_vector& inputFeatures) {
     return predict_batch(std::vector<const Feature_vector*>(1, &inputFeatures))[0];
 }
+
+// ---- FPNNClassifier (classification.cpp:618-791) ----
+FPNNClassifier::FPNNClassifier(double scale, bool bf, float output_ratio)
+    : PNNClassifier(bf, named("FPNN", scale)), features_scale(scale), exhaustive(bf), ratio(output_ratio) {}
+FPNNClassifier::~FPNNClassifier() {
+    if (model) fir_fpnn_destroy(model);
+}
+int FPNNClassifier::harmonics() const {
+    int32_t J = 0;
+    if (model) fir_fpnn_info(model, &J, nullptr, nullptr);
+    return J;
+}
+void FPNNClassifier::train() {
+    fir::ClassificationState& st = classification_state();
+    if (model) { fir_fpnn_destroy(model); model = nullptr; }
+    const size_t D = st.num_of_cont_features;
+    std::vector<double> rows;
+    std::vector<int32_t> cls;
+    for (size_t c = 0; c < st.num_of_classes; ++c)
+        for (size_t t : st.training_set[c]) {                              // :680: tmp_dataset[training_set[i][t]]
+            const std::vector<double>& f = st.tmp_dataset[t].features;
+            rows.insert(rows.end(), f.begin(), f.begin() + D);
+            cls.push_back((int32_t)c);
+        }
+    if (fir_fpnn_train(rows.data(), (int64_t)cls.size(), (int32_t)D, cls.data(), (int32_t)st.num_of_classes, st.avgValues.data(),
+                       st.stdValues.data(), features_scale, fir::classification_device(), &model) != FIR_OK) {
+        std::fprintf(stderr, "fir: fpnn_train: %s\n", fir_last_error());
+        model = nullptr;
+    }
+}
+std::vector<int> FPNNClassifier::predict_batch(const std::vector<const Feature_vector*>& inputs) {
+    std::vector<int> out(inputs.size(), -1);
+    if (!model || inputs.empty()) return out;
+    std::vector<double> q = pack(inputs, classification_state().num_of_cont_features);
+    std::vector<int32_t> best(inputs.size());
+    const int rc = exhaustive ? fir_fpnn_predict(model, q.data(), (int32_t)inputs.size(), best.data(), nullptr)
+                              : fir_fpnn_predict_seq(model, q.data(), (int32_t)inputs.size(), ratio, best.data(), nullptr);
+    if (rc != FIR_OK) {
+        std::fprintf(stderr, "fir: fpnn_predict: %s\n", fir_last_error());
+        return out;
+    }
+    out.assign(best.begin(), best.end());
+    return out;
+}
+int FPNNClassifier::predict(const Feature_vector& inputFeatures) {
+    return predict_batch(std::vector<const Feature_vector*>(1, &inputFeatures))[0];
+}

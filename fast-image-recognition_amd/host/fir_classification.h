@@ -108,4 +108,23 @@ private:
     fir_cls* medoid_model = nullptr;
 };
 
+// classification.cpp:618-791: orthogonal-series (trigonometric) PNN. train() builds the D x C x (2J+1) coefficient
+// model on the GPU (fir_fpnn_train); predict() is predict_bf or, with bf = false, predict_sequentional with the
+// class-pruning threshold fastlog(output_ratio) per feature seen.
+class FPNNClassifier : public PNNClassifier {
+public:
+    FPNNClassifier(double scale = 1.0, bool bf = true, float output_ratio = 0.9f);
+    ~FPNNClassifier();
+    void train() override;
+    int predict(const Feature_vector& inputFeatures) override;
+    std::vector<int> predict_batch(const std::vector<const Feature_vector*>& inputs) override;
+    int harmonics() const;                                     // J (classification.cpp:669-676)
+
+private:
+    double features_scale;
+    bool exhaustive;
+    float ratio;
+    fir_fpnn* model = nullptr;
+};
+
 #endif  // FIR_CLASSIFICATION_H

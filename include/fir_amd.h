@@ -163,6 +163,24 @@ int fir_cls_pnn_predict_seq(fir_cls* c, const double* queries, int32_t qb, doubl
  * class until one class has k votes. 1 <= k <= 8. best_class[qb]. */
 int fir_cls_knn_predict(fir_cls* c, const double* queries, int32_t qb, int32_t k, int32_t* best_class);
 
+/* ---- FPNNClassifier: orthogonal-series (trigonometric) PNN, classification.cpp:618-791 ----------
+ * train() (:661-696): train_rows[nt][d] float64, class-major like fir_cls_create (train_class non-decreasing), avg[d] /
+ * sd[d] = avgValues / stdValues of split_train_test (:969-989), scale = features_scale. J = max(3, ceil(cbrt(nt /
+ * num_classes))) harmonics; the model has d * num_classes * (2J+1) doubles. */
+typedef struct fir_fpnn fir_fpnn;
+int fir_fpnn_train(const double* train_rows, int64_t nt, int32_t d, const int32_t* train_class, int32_t num_classes,
+                   const double* avg, const double* sd, double scale, int32_t device, fir_fpnn** out);
+int fir_fpnn_destroy(fir_fpnn* h);
+int fir_fpnn_info(const fir_fpnn* h, int32_t* J, int32_t* d, int32_t* num_classes);
+/* a_out[(f * num_classes + c) * (2J+1) + k]: the reference's `a` (:676-690). */
+int fir_fpnn_get_model(fir_fpnn* h, double* a_out);
+/* predict_bf (:698-735): best_class[qb]; outputs[qb][num_classes] (may be NULL) = the float log-scores. */
+int fir_fpnn_predict(fir_fpnn* h, const double* queries, int32_t qb, int32_t* best_class, float* outputs);
+/* predict_sequentional (:736-791): 32-feature chunks, classes below max + fastlog(output_ratio) * features_seen are
+ * dropped, stop when one is left. chunks_out[qb] (may be NULL) = chunks evaluated. */
+int fir_fpnn_predict_seq(fir_fpnn* h, const double* queries, int32_t qb, float output_ratio, int32_t* best_class,
+                         int32_t* chunks_out);
+
 /* ---- DirectedEnumeration (maximum-likelihood directed enumeration, ann.h:64-100) -------------------
  * The PIVOT build of the constructor, ann.cpp:302-331: for ii = 0..n_pivots-1, table row ii = distance(gallery row j,
  * pivot ii) over all d features (ann.h:33-38), min_other[ii] = smallest distance from pivot ii to a row of another class

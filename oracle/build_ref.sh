@@ -57,7 +57,11 @@ match_tu() {   # $1 = metric id (0 l2, 1 chi2, 2 kl)
 }
 
 cls_tu() {
-    sed -n '1,10p;19,428p;617,862p;942,990p' "$REF/classification.cpp"
+    sed -n '1,10p;19,428p' "$REF/classification.cpp"
+    echo '#define private public     /* the wrapper reads FPNNClassifier::a / J (classification.cpp:630-632) */'
+    sed -n '617,791p' "$REF/classification.cpp"
+    echo '#undef private'
+    sed -n '792,862p;942,990p' "$REF/classification.cpp"
     echo '#include "ref_wrap_cls.inc"'
 }
 

@@ -416,6 +416,106 @@ int orc_pnn_predict_seq(const double* train_rows, const int32_t* train_class, in
     return bestClass;
 }
 
+/* ---- FPNNClassifier, classification.cpp:618-791 ---- */
+/* fasterlog2, classification.cpp:64-73 */
+static float orc_fasterlog2(float x) {
+    union { float f; uint32_t i; } vx = { x };
+    union { uint32_t i; float f; } mx = { (vx.i & 0x007FFFFF) | (0x7e << 23) };
+    float y = vx.i;
+    y *= 1.0 / (1 << 23);
+    return y - 124.22544637f - 1.498030302f * mx.f - 1.72587999f / (0.3520887068f + mx.f);
+}
+float orc_fastlog(float x) { return orc_fasterlog2(x); }
+/* FPNNClassifier::normalize, :637-659 (the `#elif 1` arm) */
+static double orc_fpnn_normalize(double x, double avg, double sd, double features_scale) {
+    double val = (sd != 0) ? features_scale * (x - avg) / sd : 0;
+    const double max_val = 0.5;
+    if (val < -max_val) val = -max_val;
+    else if (val > max_val) val = max_val;
+    return val;
+}
+/* :669-676 */
+int orc_fpnn_J(int64_t num_of_training_data, int num_of_classes) {
+    int J = (int)ceil(pow(1.0 * num_of_training_data / num_of_classes, 1.0 / 3));
+    const int min_J = 3;
+    if (J <= min_J) J = min_J;
+    return J;
+}
+/* FPNNClassifier::train, :661-696. train_rows class-major ([nt][d], train_class non-decreasing) = tmp_dataset rows in
+ * training_set order. a[(fi*C + i)*(2J+1) + ...]. */
+void orc_fpnn_train(const double* train_rows, const int32_t* train_class, int64_t nt, int d, int num_of_classes, const double* avg,
+                    const double* sd, double features_scale, int J, double* a) {
+    const double PI = atan(1.0) * 4;
+    int64_t* start = (int64_t*)calloc((size_t)num_of_classes + 1, sizeof(int64_t));
+    for (int64_t t = 0; t < nt; ++t) start[train_class[t] + 1]++;
+    for (int i = 0; i < num_of_classes; ++i) start[i + 1] += start[i];
+    for (int64_t k = 0; k < (int64_t)num_of_classes * d * (2 * J + 1); ++k) a[k] = 0;
+    for (int fi = 0; fi < d; ++fi)
+        for (int i = 0; i < num_of_classes; ++i) {
+            const size_t model_ind = ((size_t)fi * num_of_classes + i) * (2 * J + 1);
+            a[model_ind] = 0.5;
+            const size_t sz = (size_t)(start[i + 1] - start[i]);
+            const double cur_mult = 1.0 / sz;
+            for (size_t t = 0; t < sz; ++t) {
+                const double val = orc_fpnn_normalize(train_rows[(start[i] + (int64_t)t) * d + fi], avg[fi], sd[fi], features_scale);
+                for (size_t j = 0; j < (size_t)J; ++j) {
+                    a[model_ind + 2 * j + 1] += cos(PI * (j + 1) * val) * cur_mult * ((size_t)J - j) / ((size_t)J * ((size_t)J + 1));
+                    a[model_ind + 2 * j + 2] += sin(PI * (j + 1) * val) * cur_mult * ((size_t)J - j) / ((size_t)J * ((size_t)J + 1));
+                }
+            }
+        }
+    free(start);
+}
+/* predict_bf :698-735 (seq = 0) and predict_sequentional :736-791 (seq = 1). outputs_out[C] and chunks_out nullable. */
+int orc_fpnn_predict(const double* a, int J, int d, int num_of_classes, const double* avg, const double* sd, double features_scale,
+                     const double* q, int seq, float output_ratio, float* outputs_out, int* chunks_out) {
+    const double PI = atan(1.0) * 4;
+    const float output_delta = orc_fasterlog2(output_ratio);
+    const int delta_features_count = 32;
+    float* outputs = (float*)calloc((size_t)num_of_classes, sizeof(float));
+    int* classes_to_check = (int*)malloc(sizeof(int) * (size_t)num_of_classes);
+    double* cos_vals = (double*)malloc(sizeof(double) * (size_t)J);
+    double* sin_vals = (double*)malloc(sizeof(double) * (size_t)J);
+    for (int i = 0; i < num_of_classes; ++i) classes_to_check[i] = 1;
+    int bestClass = -1, chunks = 0;
+    for (int cur_features = 0; cur_features < d; cur_features += seq ? delta_features_count : d) {
+        int max_fi = seq ? cur_features + delta_features_count : d;
+        if (max_fi > d) max_fi = d;
+        ++chunks;
+        for (int fi = cur_features; fi < max_fi; ++fi) {
+            const double val = orc_fpnn_normalize(q[fi], avg[fi], sd[fi], features_scale);
+            cos_vals[0] = cos(PI * val);
+            sin_vals[0] = sin(PI * val);
+            for (int j = 1; j < J; ++j) {
+                cos_vals[j] = cos_vals[j - 1] * cos_vals[0] - sin_vals[j - 1] * sin_vals[0];
+                sin_vals[j] = cos_vals[j - 1] * sin_vals[0] + sin_vals[j - 1] * cos_vals[0];
+            }
+            for (int i = 0; i < num_of_classes; ++i) {
+                if (!classes_to_check[i]) continue;
+                const size_t model_ind = ((size_t)fi * num_of_classes + i) * (2 * J + 1);
+                double probab = a[model_ind];
+                for (int j = 0; j < J; ++j) probab += (a[model_ind + 2 * j + 1] * cos_vals[j] + a[model_ind + 2 * j + 2] * sin_vals[j]);
+                outputs[i] += orc_fasterlog2(probab);
+            }
+        }
+        float max_output = -FLT_MAX;
+        for (int i = 0; i < num_of_classes; ++i)
+            if (classes_to_check[i] && max_output < outputs[i]) { max_output = outputs[i]; bestClass = i; }
+        if (!seq) break;
+        int num_of_variants = 0;
+        const float output_threshold = max_output + output_delta * (size_t)max_fi;
+        for (int i = 0; i < num_of_classes; ++i) {
+            if (outputs[i] < output_threshold) classes_to_check[i] = 0;
+            else ++num_of_variants;
+        }
+        if (num_of_variants == 1) break;
+    }
+    if (outputs_out) memcpy(outputs_out, outputs, sizeof(float) * (size_t)num_of_classes);
+    if (chunks_out) *chunks_out = chunks;
+    free(outputs); free(classes_to_check); free(cos_vals); free(sin_vals);
+    return bestClass;
+}
+
 /* classification.cpp:969-989: per-feature min / max / mean / std over the training rows
  * (std = sqrt((sum x^2 - mean^2 * count) / (count - 1))). */
 void orc_train_stats(const double* train_rows, int64_t nt, int d, double* mn, double* mx, double* avg, double* sd) {

@@ -162,6 +162,25 @@ def main():
     for kind, param, nm in ((0, 1, "knn1"), (0, 3, "knn3"), (1, 0, "pnn"), (2, 0, "pnn_seq"), (3, 5, "pnn_clust5"), (3, 2, "pnn_clust2")):
         fx[f"cls/{nm}"] = np.array([rc.predict_row(kind, param, int(r)) for r in test], np.int32)
 
+    # ---- FPNNClassifier (classification.cpp:618-791) on the same split (J = 3) and on a second one (J = 4) ----
+    def fpnn_golden(tag, test_rows):
+        for sc in gc.FPNN_SCALES:
+            J, a = rc.fpnn_model(sc)
+            fx[f"{tag}/{sc}/J"], fx[f"{tag}/{sc}/a"] = np.array(J, np.int32), a
+            fx[f"{tag}/{sc}/bf"] = np.array([rc.fpnn_predict(sc, True, 0.9, row=int(r)) for r in test_rows], np.int32)
+            for ratio in gc.FPNN_RATIOS:
+                fx[f"{tag}/{sc}/seq_{ratio}"] = np.array([rc.fpnn_predict(sc, False, ratio, row=int(r)) for r in test_rows], np.int32)
+    fpnn_golden("fpnn", test)
+    fx["fpnn/fastlog_in"] = np.array([0.9, 0.99, 1.0, 0.5, 1e-3, 3.75, 1e-30, 7e8], np.float32)
+    fx["fpnn/fastlog_out"] = np.array([rc.fastlog(v) for v in fx["fpnn/fastlog_in"]], np.float32)
+    x2, lab2, ncls2 = gc.fpnn_case2()
+    rc.set_dataset(x2, lab2, ncls2)
+    train2, tcls2, test2 = rc.split(40.0, seed=29)
+    fx["fpnn2/train"], fx["fpnn2/train_class"], fx["fpnn2/test"] = train2, tcls2, test2
+    _, _, avg2, sd2 = rc.stats()
+    fx["fpnn2/avg"], fx["fpnn2/std"] = avg2, sd2
+    fpnn_golden("fpnn2", test2)
+
     out = os.path.join(HERE, "reference_outputs.npz")
     np.savez_compressed(out, **fx)
     print(f"wrote {out}: {len(fx)} arrays, {os.path.getsize(out) / 1024:.0f} KiB")

@@ -88,6 +88,15 @@ def cls_case(seed=17, n=360, d=96, n_classes=12):
     return x, lab, n_classes
 
 
+FPNN_SCALES = (1.0, 0.33)                 # classification.cpp:1002-1007
+FPNN_RATIOS = (0.9, 0.99)                 # output_ratio: the default (:620) and a tighter pruning threshold
+
+
+def fpnn_case2():
+    """A second dataset for FPNN: 40 training rows per class -> J = 4 harmonics; 70 features -> a ragged last chunk."""
+    return cls_case(seed=19, n=480, d=70, n_classes=8)
+
+
 def loader_case():
     """A small feature file in the producer's format (dnn_feature_extractor.py:58-64) with
     FEATURES_COUNT = 1536 columns, classes out of order, a skipped class and sub-1e-4 values."""

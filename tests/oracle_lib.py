@@ -59,6 +59,14 @@ class Oracle:
         L.orc_dem_recognize.restype = C.c_int
         L.orc_dem_recognize.argtypes = [_vp, C.c_int64, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_float, C.c_int, _vp,
                                         _f32p, C.POINTER(C.c_int), C.POINTER(C.c_int), _vp]
+        L.orc_fastlog.restype = C.c_float
+        L.orc_fastlog.argtypes = [C.c_float]
+        L.orc_fpnn_J.restype = C.c_int
+        L.orc_fpnn_J.argtypes = [C.c_int64, C.c_int]
+        L.orc_fpnn_train.restype = None
+        L.orc_fpnn_train.argtypes = [_vp, _vp, C.c_int64, C.c_int, C.c_int, _vp, _vp, C.c_double, C.c_int, _vp]
+        L.orc_fpnn_predict.restype = C.c_int
+        L.orc_fpnn_predict.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_double, _vp, C.c_int, C.c_float, _vp, C.POINTER(C.c_int)]
         L.orc_get_threshold.restype = C.c_float
         L.orc_get_threshold.argtypes = [_vp, C.c_int, C.c_float]
 
@@ -227,6 +235,32 @@ class Oracle:
         self.L.orc_dem_pivot_table(_p(rows), n, d, _p(cls), metric, n_pivots, _p(piv), _p(table), _p(mo))
         return piv, table, mo
 
+
+    def fastlog(self, x):
+        return np.float32(self.L.orc_fastlog(float(x)))
+
+    def fpnn_train(self, train_rows, train_class, num_classes, avg, sd, scale):
+        """FPNNClassifier::train (classification.cpp:661-696) -> (J, a)"""
+        rows = np.ascontiguousarray(train_rows, np.float64)
+        cls = np.ascontiguousarray(train_class, np.int32)
+        avg = np.ascontiguousarray(avg, np.float64)
+        sd = np.ascontiguousarray(sd, np.float64)
+        nt, d = rows.shape
+        J = self.L.orc_fpnn_J(nt, num_classes)
+        a = np.empty(d * num_classes * (2 * J + 1), np.float64)
+        self.L.orc_fpnn_train(_p(rows), _p(cls), nt, d, num_classes, _p(avg), _p(sd), scale, J, _p(a))
+        return J, a
+
+    def fpnn_predict(self, a, J, num_classes, avg, sd, scale, q, seq=False, output_ratio=0.9):
+        """predict_bf / predict_sequentional (:698-791) -> (class, outputs[C], chunks)"""
+        a = np.ascontiguousarray(a, np.float64)
+        avg = np.ascontiguousarray(avg, np.float64)
+        sd = np.ascontiguousarray(sd, np.float64)
+        q = np.ascontiguousarray(q, np.float64)
+        outs = np.empty(num_classes, np.float32)
+        ch = C.c_int()
+        r = self.L.orc_fpnn_predict(_p(a), J, q.size, num_classes, _p(avg), _p(sd), scale, _p(q), 1 if seq else 0, output_ratio, _p(outs), C.byref(ch))
+        return r, outs, ch.value
 
     def dem_recognize(self, rows, pivots, table, threshold, image_count, query, metric=0, want_lik=False):
         """-> (row, best_dist, found, calc_count[, likelihoods])"""
@@ -427,6 +461,12 @@ class RefCls:
         L.ref_cls_predict_row.argtypes = [C.c_int, C.c_int, C.c_int64]
         L.ref_cls_predict_vec.restype = C.c_int
         L.ref_cls_predict_vec.argtypes = [C.c_int, C.c_int, _vp]
+        L.ref_cls_fpnn_predict.restype = C.c_int
+        L.ref_cls_fpnn_predict.argtypes = [C.c_double, C.c_int, C.c_float, _vp, C.c_int64]
+        L.ref_cls_fpnn_model.restype = C.c_int
+        L.ref_cls_fpnn_model.argtypes = [C.c_double, _vp]
+        L.ref_cls_fastlog.restype = C.c_float
+        L.ref_cls_fastlog.argtypes = [C.c_float]
 
     def set_dataset(self, rows, labels, n_classes):
         rows = np.ascontiguousarray(rows, np.float64)
@@ -451,6 +491,20 @@ class RefCls:
 
     def predict_row(self, kind, param, row):
         return int(self.L.ref_cls_predict_row(kind, param, row))
+
+    def fpnn_predict(self, scale, bf, output_ratio, q=None, row=-1):
+        if q is not None:
+            q = np.ascontiguousarray(q, np.float64)
+        return int(self.L.ref_cls_fpnn_predict(scale, 1 if bf else 0, output_ratio, _p(q) if q is not None else None, row))
+
+    def fpnn_model(self, scale):
+        J = self.L.ref_cls_fpnn_model(scale, None)
+        a = np.empty(self.L.ref_cls_num_features() * self.L.ref_cls_num_classes() * (2 * J + 1), np.float64)
+        self.L.ref_cls_fpnn_model(scale, _p(a))
+        return J, a
+
+    def fastlog(self, x):
+        return np.float32(self.L.ref_cls_fastlog(float(x)))
 
     def predict_vec(self, kind, param, q):
         q = np.ascontiguousarray(q, np.float64)

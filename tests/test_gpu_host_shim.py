@@ -100,7 +100,7 @@ def test_classification_shim_matches_oracle_end_to_end(tmp_path, oracle):
     test = np.concatenate([np.nonzero(labels == c)[0][12:] for c in range(nc)])
     assert got["train_rows"] == list(train) and got["test_rows"] == list(test)
     tr, tcls = rows[train], labels[train]
-    _, _, avg, _ = oracle.train_stats(tr)
+    _, _, avg, sd = oracle.train_stats(tr)
     assert got["avg0"] == avg[0]
     e1 = [oracle.knn_predict(tr, tcls, avg, nc, rows[r], 1)[0] for r in test]
     e3 = [oracle.knn_predict(tr, tcls, avg, nc, rows[r], 3)[0] for r in test]
@@ -115,3 +115,11 @@ def test_classification_shim_matches_oracle_end_to_end(tmp_path, oracle):
     assert got["medoid_rows"] == list(train[keep])
     ec = [oracle.pnn_predict_den(tr[keep], tcls[keep], avg, nc, rows[r], tr.shape[0])[0] for r in test]
     assert got["pnn_clust5_single"] == ec and got["pnn_clust5_batch"] == ec and got["pnn_clust5_name"] == "PNN with clustering, 5"
+    # FPNNClassifier (classification.cpp:618-791), the four instances of testClassification1 (:1002-1007)
+    for key, sc, seq, ratio, name in (("fpnn", 1.0, False, 0.9, "FPNN, 1"), ("fpnn033", 0.33, False, 0.9, "FPNN, 0.33"),
+                                      ("fpnn_seq", 1.0, True, 0.9, "FPNN, 1 (seq)"), ("fpnn033_seq", 0.33, True, 0.99, "FPNN, 0.33 (seq)")):
+        J, a = oracle.fpnn_train(tr, tcls, nc, avg, sd, sc)
+        assert got["fpnn_J"] == J
+        ef = [oracle.fpnn_predict(a, J, nc, avg, sd, sc, rows[r], seq, ratio)[0] for r in test]
+        assert got[key + "_single"] == ef and got[key + "_batch"] == ef, key
+        assert got[key + "_name"] == name

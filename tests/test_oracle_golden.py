@@ -83,6 +83,29 @@ def test_ann_bruteforce_and_threshold_match_reference(oracle):
         assert bits(oracle.get_threshold(dists, rate)) == bits(GOLD[f"threshold/{rate}"])
 
 
+def test_fpnn_matches_reference(oracle):
+    """FPNNClassifier (classification.cpp:618-791): fasterlog2, the trained coefficients and both predict forms."""
+    for vin, vout in zip(GOLD["fpnn/fastlog_in"], GOLD["fpnn/fastlog_out"]):
+        assert bits(oracle.fastlog(vin)) == bits(vout)
+    x, lab, ncls = gc.cls_case()
+    x2, lab2, ncls2 = gc.fpnn_case2()
+    cases = (("fpnn", x, ncls, GOLD["cls/train"], GOLD["cls/train_class"], GOLD["cls/test"], GOLD["cls/avg"], GOLD["cls/std"], 3),
+             ("fpnn2", x2, ncls2, GOLD["fpnn2/train"], GOLD["fpnn2/train_class"], GOLD["fpnn2/test"], GOLD["fpnn2/avg"], GOLD["fpnn2/std"], 4))
+    for tag, xx, nc, train, tcls, test, avg, sd, wantJ in cases:
+        pruned = 0
+        for sc in gc.FPNN_SCALES:
+            J, a = oracle.fpnn_train(xx[train], tcls, nc, avg, sd, sc)
+            assert J == int(GOLD[f"{tag}/{sc}/J"]) == wantJ
+            assert np.array_equal(a.view(np.uint64), GOLD[f"{tag}/{sc}/a"].view(np.uint64)), (tag, sc)
+            bf = [oracle.fpnn_predict(a, J, nc, avg, sd, sc, xx[r])[0] for r in test]
+            assert bf == list(GOLD[f"{tag}/{sc}/bf"]), (tag, sc)
+            for ratio in gc.FPNN_RATIOS:
+                res = [oracle.fpnn_predict(a, J, nc, avg, sd, sc, xx[r], True, ratio) for r in test]
+                assert [r[0] for r in res] == list(GOLD[f"{tag}/{sc}/seq_{ratio}"]), (tag, sc, ratio)
+                pruned += sum(r[2] < -(-xx.shape[1] // 32) for r in res)
+        assert pruned > 0, "the sequential form should stop early for some queries"
+
+
 def test_dem_pivot_table_matches_reference(oracle):
     """DirectedEnumeration's constructor (ann.cpp:270-348): table, greedy pivots, false-accept threshold."""
     rows, cls, _ = gc.dem_case()
