@@ -1,8 +1,10 @@
 // cls_driver.cpp -- drives the classification.cpp-side API the way testClassification1 does
 // (classification.cpp:991-1060: load, split, train, predict every test item) and prints JSON.
 //   cls_driver <features.txt> <features_count> <fraction>
+//   cls_driver --dump <features.txt> <features_count> <out.bin>   (load_image_dataset only; runs without a GPU)
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 #include "fir_classification.h"
 
@@ -13,6 +15,17 @@ static void print_vec(const char* key, const std::vector<int>& v, bool comma) {
 }
 
 int main(int argc, char** argv) {
+    if (argc >= 5 && !std::strcmp(argv[1], "--dump")) {       // --dump <features.txt> <features_count> <out.bin>: loader only, no GPU
+        load_image_dataset(argv[2], std::atoi(argv[3]));
+        fir::ClassificationState& st = fir::classification_state();
+        FILE* fp = std::fopen(argv[4], "wb");
+        for (const Feature_vector& fv : st.dataset) std::fwrite(fv.features.data(), sizeof(double), fv.features.size(), fp);
+        std::fclose(fp);
+        std::printf("{\"rows\": %zu, \"classes\": %zu, \"labels\": [", st.dataset.size(), st.num_of_classes);
+        for (size_t i = 0; i < st.dataset.size(); ++i) std::printf("%s%d", i ? ", " : "", (int)st.dataset[i].output);
+        std::printf("]}\n");
+        return 0;
+    }
     if (argc < 4) { std::fprintf(stderr, "usage: cls_driver <features.txt> <features_count> <fraction>\n"); return 2; }
     load_image_dataset(argv[1], std::atoi(argv[2]));
     split_train_test(std::atof(argv[3]), /*shuffle=*/false);

@@ -5,6 +5,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <fstream>
 #include <map>
@@ -40,10 +41,35 @@ void load_image_dataset(const std::string& features_file, int features_count) {
         std::vector<FEATURE_TYPE> f((size_t)features_count);
         const char* p = feat_line.c_str();
         FEATURE_TYPE norm = 0;
+        double v = 0;
+        bool failed = false;
         for (int i = 0; i < features_count; ++i) {
-            char* end = nullptr;
-            double v = std::strtod(p, &end);
-            if (end == p) v = 0; else p = end;
+            // `iss >> feature` (:832): nothing is extracted once the line is exhausted (the value read then is the previous
+            // one in practice -- the reference's variable is uninitialised); a malformed field stores 0 and fails the stream
+            if (!failed) {
+                const char* q = p;
+                while (*q && std::strchr(" \t\n\r\f\v", *q)) ++q;
+                if (!*q) failed = true;
+                else {
+                    const char* fe = q;
+                    if (*fe == '+' || *fe == '-') ++fe;
+                    bool digits = false, point = false;
+                    for (;; ++fe) {
+                        if (*fe >= '0' && *fe <= '9') digits = true;
+                        else if (*fe == '.' && !point) point = true;
+                        else break;
+                    }
+                    if (digits && (*fe == 'e' || *fe == 'E')) {
+                        const char* x = fe + 1;
+                        if (*x == '+' || *x == '-') ++x;
+                        const char* xd = x;
+                        while (*x >= '0' && *x <= '9') ++x;
+                        if (x == xd) digits = false; else fe = x;
+                    }
+                    if (!digits) { failed = true; v = 0; }
+                    else { v = std::strtod(std::string(q, fe).c_str(), nullptr); p = fe; }
+                }
+            }
             norm += v * v;                                                 // :833
             f[(size_t)i] = v;
         }

@@ -1,6 +1,8 @@
 // fir_db.cpp -- host side of the drop-in (see fir_db.h). IO, packing and handle caching only:
 // every distance is computed by libfir_amd.so on the GPU.
 #include "fir_db.h"
+
+#include <iostream>
 #include "fir_loader.h"
 
 #include <algorithm>
@@ -150,6 +152,23 @@ int loadImages(ImagesDatabase& imagesDb, std::string features_file, std::unorder
         imagesDb[first_new + (size_t)packed.class_no[(size_t)r]].emplace_back(src, src + FEATURES_COUNT);
     }
     return (int)total;
+}
+
+// video.cpp:35-96 through fir_loader's exact parser. Entries are (re)built the way the reference's map ends up:
+// a repeated person name re-sizes and overwrites the earlier entry's videos.
+void loadVideos(MapOfVideos& dbVideos, const std::string& video_features_file) {
+    fir::PackedVideos pv;
+    if (fir::load_videos_packed(video_features_file, FEATURES_COUNT, fir::metric(), pv) <= 0) return;
+    for (size_t p = 0; p < pv.person.size(); ++p) {
+        std::vector<std::vector<FeaturesVector> >& videos = dbVideos[pv.person[p]];
+        videos.clear();
+        for (int32_t v = pv.video_first[p]; v < pv.video_first[p + 1]; ++v) {
+            videos.emplace_back();
+            for (int64_t r = pv.frame_first[(size_t)v]; r < pv.frame_first[(size_t)v + 1]; ++r)
+                videos.back().emplace_back(&pv.rows[(size_t)r * FEATURES_COUNT], &pv.rows[(size_t)(r + 1) * FEATURES_COUNT]);
+        }
+    }
+    std::cout << "total size=" << dbVideos.size() << " totalVideos=" << pv.total_videos << " totalImages=" << pv.total_images << std::endl;   // :92
 }
 
 void getTrainingAndTestImages(const ImagesDatabase& totalImages, std::vector<ImageInfo>& dbImages,

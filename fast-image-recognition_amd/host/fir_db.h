@@ -12,6 +12,7 @@
 #define FIR_DB_H
 
 #include <cstdint>
+#include <map>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -64,6 +65,11 @@ void getTrainingAndTestImages(const ImagesDatabase& totalImages, std::vector<Ima
                               std::vector<ImageInfo>& testImages, bool randomize = true);
 // db_features.h:33, db_features.cpp:319-335 -- row index of the nearest gallery image or -1.
 int recognize_image_bf(const std::vector<ImageInfo>& dbImages, const ImageInfo& testImageInfo, int max_features = 0);
+
+// video.cpp:21,35-96 -- person -> videos -> frames of the YouTube-Faces feature file. The reference hard-wires the
+// file name (video.cpp:23-33); it is a defaulted argument here.
+typedef std::map<std::string, std::vector<std::vector<FeaturesVector> > > MapOfVideos;
+void loadVideos(MapOfVideos& dbVideos, const std::string& video_features_file = "vgg_mean_dnn_features.txt");
 
 namespace fir {
 

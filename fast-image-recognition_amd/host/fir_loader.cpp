@@ -19,14 +19,32 @@ namespace {
 const double kPow10[23] = {1e0,  1e1,  1e2,  1e3,  1e4,  1e5,  1e6,  1e7,  1e8,  1e9,  1e10, 1e11,
                            1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
 
+// The general case: the characters `istream >> float` (libstdc++ num_get) would accept -- sign, digits, one decimal
+// point, one exponent with optional sign -- converted by strtof. No "nan" / "inf" / hex forms: the stream rejects them.
 float slow_path(const char* p, const char* limit, const char** end) {
-    // strtof needs a terminated string: copy the token
     char buf[128];
     const char* q = p;
     while (q < limit && (*q == ' ' || *q == '\t')) ++q;
     size_t len = 0;
-    while (q + len < limit && len < sizeof(buf) - 1 && q[len] != ' ' && q[len] != '\t' && q[len] != '\n' && q[len] != '\r') ++len;
-    std::memcpy(buf, q, len);
+    bool digits = false, point = false;
+    if (q < limit && (*q == '+' || *q == '-')) buf[len++] = *q;
+    while (q + len < limit && len < sizeof(buf) - 2) {
+        const char c = q[len];
+        if (c >= '0' && c <= '9') digits = true;
+        else if (c == '.' && !point) point = true;
+        else break;
+        buf[len++] = c;
+    }
+    if (!digits) { *end = p; return 0.0f; }
+    if (q + len < limit && (q[len] == 'e' || q[len] == 'E')) {
+        size_t l2 = len;
+        buf[l2++] = q[len];
+        if (q + l2 < limit && (q[l2] == '+' || q[l2] == '-')) { buf[l2] = q[l2]; ++l2; }
+        bool ed = false;
+        while (q + l2 < limit && l2 < sizeof(buf) - 1 && q[l2] >= '0' && q[l2] <= '9') { buf[l2] = q[l2]; ++l2; ed = true; }
+        if (!ed) { *end = p; return 0.0f; }                            // "1e": the stream fails the whole field
+        len = l2;
+    }
     buf[len] = 0;
     char* e = nullptr;
     const float v = std::strtof(buf, &e);
@@ -56,9 +74,8 @@ float parse_float_exact(const char* p, const char* limit, const char** end) {
             any = true;
         }
     }
-    if (!any) { (void)tok; return slow_path(p, limit, end); }          // nan / inf / garbage: let strtof decide
-    if (s < limit && (*s == 'e' || *s == 'E' || *s == 'x' || *s == 'X' || *s == 'n' || *s == 'N' || *s == 'i' || *s == 'I'))
-        return slow_path(p, limit, end);                               // exponent / hex forms
+    if (!any) { (void)tok; *end = p; return 0.0f; }                    // nan / inf / garbage: the stream extracts nothing
+    if (s < limit && (*s == 'e' || *s == 'E')) return slow_path(p, limit, end);   // exponent form
     if (digits > 15 || frac > 22) return slow_path(p, limit, end);     // (double)mant must be exact, 10^frac too
     *end = s;
     if (mant == 0) return neg ? -0.0f : 0.0f;
@@ -88,13 +105,20 @@ void parse_range(const std::vector<Record>& recs, size_t lo, size_t hi, const st
         const char* p = recs[r].feat;
         const char* limit = recs[r].feat_end;
         float norm = 0.0f;
+        float v = 0.0f;                                                // `dfeature` lives across the loop (db_features.cpp:81)
         bool failed = false;
         for (int i = 0; i < d; ++i) {
-            float v = 0.0f;
             if (!failed) {
-                const char* e = p;
-                v = parse_float_exact(p, limit, &e);
-                if (e == p) { failed = true; v = 0.0f; } else p = e;   // a failed extraction stores 0 and fails the stream (C++11)
+                // `iss >> dfeature`: at the end of the line nothing is extracted and dfeature keeps its (clipped) value;
+                // a malformed token stores 0 (C++11); either way the stream stays failed for the rest of the row
+                const char* q = p;
+                while (q < limit && std::strchr(" \t\n\r\f\v", *q)) ++q;
+                if (q >= limit) failed = true;
+                else {
+                    const char* e = q;
+                    const float parsed = parse_float_exact(q, limit, &e);
+                    if (e == q) { failed = true; v = 0.0f; } else { v = parsed; p = e; }
+                }
             }
             if (std::fabs(v) < 0.0001) v = 0.0f;                       // db_features.cpp:85-86
             f[i] = v;
@@ -224,6 +248,118 @@ int load_feature_cache(const std::string& cache_file, PackedFeatures& out) {
     std::fclose(fp);
     if (!ok) out = PackedFeatures();
     return ok ? 0 : -1;
+}
+
+// ---- video.cpp:35-96 ----
+namespace {
+struct Cursor {                                  // the reference's ifstream, over the mapped file
+    const char* p;
+    const char* limit;
+    bool fail = false;
+    bool getline(const char*& b, const char*& e) {                     // std::getline: fails only when nothing is left
+        if (fail || p >= limit) { fail = true; return false; }
+        b = p;
+        const char* nl = (const char*)std::memchr(p, '\n', (size_t)(limit - p));
+        e = nl ? nl : limit;
+        p = nl ? nl + 1 : limit;
+        return true;
+    }
+    bool read_int(int& v) {                                            // ifs >> int
+        if (fail) return false;
+        while (p < limit && std::strchr(" \t\n\r\f\v", *p)) ++p;
+        const char* s = p;
+        bool neg = false;
+        if (s < limit && (*s == '-' || *s == '+')) { neg = *s == '-'; ++s; }
+        long long acc = 0;
+        const char* digits = s;
+        while (s < limit && *s >= '0' && *s <= '9' && acc < (1ll << 40)) acc = acc * 10 + (*s++ - '0');
+        if (s == digits) { fail = true; v = 0; return false; }         // num_get failure stores 0
+        p = s;
+        v = (int)(neg ? -acc : acc);
+        return true;
+    }
+};
+}  // namespace
+
+int64_t load_videos_packed(const std::string& video_features_file, int d, int metric, PackedVideos& out) {
+    out = PackedVideos();
+    out.d = d;
+    const int fd = ::open(video_features_file.c_str(), O_RDONLY);
+    if (fd < 0) return 0;
+    struct stat st;
+    if (::fstat(fd, &st) != 0 || st.st_size == 0) { ::close(fd); return 0; }
+    const size_t size = (size_t)st.st_size;
+    const char* base = (const char*)::mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+    ::close(fd);
+    if (base == MAP_FAILED) return 0;
+    Cursor in{base, base + size};
+    const bool l2 = metric == 0;
+    // person -> videos -> frames (rows), exactly the reference's MapOfVideos while reading
+    std::map<std::string, std::vector<std::vector<std::vector<float> > > > db;
+    while (!in.fail) {
+        const char *b, *e;
+        if (!in.getline(b, e)) break;                                  // :42-43
+        while (b < e && std::strchr(" \t\n\r\f\v", *b)) ++b;           // :44
+        const std::string personName(b, e);
+        int videos_count = 0;
+        in.read_int(videos_count);                                     // :46
+        if (videos_count < 0) videos_count = 0;
+        std::vector<std::vector<std::vector<float> > >& person_videos = db[personName];   // :49-50
+        person_videos.resize((size_t)videos_count);                    // :51 (a repeated name re-sizes the earlier entry)
+        for (int i = 0; i < videos_count; ++i) {
+            int frames_count = 0;
+            in.read_int(frames_count);                                 // :55
+            if (frames_count < 0) frames_count = 0;
+            person_videos[(size_t)i].assign((size_t)frames_count, std::vector<float>());   // :57
+            if (!in.getline(b, e)) break;                              // rest of the count line, :59-60
+            for (int j = 0; j < frames_count; ++j) {
+                const char *fb, *fe;
+                if (!in.getline(b, e)) break;                          // file name, :63
+                if (!in.getline(fb, fe)) break;                        // features, :65
+                std::vector<float>& f = person_videos[(size_t)i][(size_t)j];
+                f.assign((size_t)d, 0.0f);
+                float dfeature = 0.0f, sum = 0.0f;                     // dfeature is uninitialised in the reference (:70)
+                bool stream_failed = false;
+                const char* p = fb;
+                for (int k = 0; k < d; ++k) {
+                    if (!stream_failed) {
+                        const char* q = p;
+                        while (q < fe && std::strchr(" \t\n\r\f\v", *q)) ++q;
+                        if (q >= fe) stream_failed = true;             // end of line: the extraction leaves dfeature as it was
+                        else {
+                            const char* endp = q;
+                            const float v = parse_float_exact(q, fe, &endp);
+                            if (endp == q) { stream_failed = true; dfeature = 0.0f; }   // malformed token: 0 is stored
+                            else { dfeature = v; p = endp; }
+                        }
+                    }
+                    if (std::fabs(dfeature) < 0.0001) dfeature = 0;    // :74-75
+                    f[(size_t)k] = dfeature;
+                    sum += dfeature * dfeature;                        // :78
+                }
+                if (l2) sum = std::sqrt(sum);                          // :81-83
+                for (int k = 0; k < d; ++k) f[(size_t)k] /= sum;       // :84-85
+                ++out.total_images;
+            }
+        }
+        out.total_videos += videos_count;                              // :91
+    }
+    ::munmap((void*)base, size);
+    out.video_first.push_back(0);
+    out.frame_first.push_back(0);
+    for (auto& kv : db) {
+        out.person.push_back(kv.first);
+        for (auto& video : kv.second) {
+            for (auto& frame : video) {
+                const size_t at = out.rows.size();
+                out.rows.resize(at + (size_t)d, 0.0f);
+                if (frame.size() == (size_t)d) std::memcpy(&out.rows[at], frame.data(), sizeof(float) * (size_t)d);
+            }
+            out.frame_first.push_back(out.frame_first.back() + (int64_t)video.size());
+        }
+        out.video_first.push_back((int32_t)(out.frame_first.size() - 1));
+    }
+    return (int64_t)out.person.size();
 }
 
 }  // namespace fir

@@ -36,7 +36,23 @@ int64_t load_features_packed(const std::string& features_file, int d, int metric
 int save_feature_cache(const std::string& cache_file, const PackedFeatures& f);
 int load_feature_cache(const std::string& cache_file, PackedFeatures& out);
 
-// One token -> float exactly as strtof would convert it; *end is set past the token (== p when nothing parsed).
+// The video-feature file of qt_cpp/video.cpp:35-96 (loadVideos): per person a name line, the number of videos, per
+// video the number of frames and per frame a file-name line and a "%f " x D line. Same clip (|x| < 1e-4 -> 0) as the
+// image files; the row is divided by its L2 norm (L2 metric) or -- as the reference does here, unlike loadImages --
+// by its sum of squares (other metrics), video.cpp:74-83. Persons come back sorted by name (the reference's std::map).
+struct PackedVideos {
+    int d = 0;
+    std::vector<std::string> person;            // sorted, unique
+    std::vector<int32_t> video_first;           // [persons + 1]: videos of person p are video_first[p] .. video_first[p+1]
+    std::vector<int64_t> frame_first;           // [videos + 1]: rows of video v are frame_first[v] .. frame_first[v+1]
+    std::vector<float> rows;                    // [frames][d]
+    int64_t total_images = 0, total_videos = 0; // the counters loadVideos prints (video.cpp:92)
+};
+// Returns the number of persons (0 when the file cannot be opened, video.cpp:38).
+int64_t load_videos_packed(const std::string& video_features_file, int d, int metric, PackedVideos& out);
+
+// One token -> float exactly as `istream >> float` converts it (strtof on the characters num_get accepts: no nan / inf /
+// hex); *end is set past the token (== p when nothing could be extracted).
 float parse_float_exact(const char* p, const char* limit, const char** end);
 
 }  // namespace fir

@@ -1,6 +1,7 @@
 // loader_driver.cpp -- loader_driver <features.txt> <d> <metric> <out.bin> [threads] : parse with the fast loader,
 // round-trip through the binary cache, dump rows + classes for tests/test_host_loader.py (no GPU involved).
-// loader_driver --tokens <file> : parse every whitespace-separated token with parse_float_exact, print the float bits.
+// loader_driver --videos <file> <d> <metric> <out.bin> : the video-feature file of video.cpp:35-96.
+// loader_driver --tokens <file> : parse every whitespace-separated token with parse_float_exact, print the float bits (REJECT for what `istream >> float` refuses).
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -23,12 +24,32 @@ int main(int argc, char** argv) {
             if (p >= limit) break;
             const char* e = p;
             const float v = fir::parse_float_exact(p, limit, &e);
-            if (e == p) { std::printf("FAIL\n"); break; }
+            if (e == p) {                                   // not a number for `istream >> float`: skip the token
+                std::printf("REJECT\n");
+                while (p < limit && *p != ' ' && *p != '\n') ++p;
+                continue;
+            }
             uint32_t bits;
             std::memcpy(&bits, &v, 4);
             std::printf("%u\n", bits);
             p = e;
         }
+        return 0;
+    }
+    if (argc >= 6 && !std::strcmp(argv[1], "--videos")) {       // --videos <file> <d> <metric> <out.bin>: video.cpp:35-96
+        fir::PackedVideos v;
+        const int64_t persons = fir::load_videos_packed(argv[2], std::atoi(argv[3]), std::atoi(argv[4]), v);
+        FILE* fp = std::fopen(argv[5], "wb");
+        std::fwrite(v.rows.data(), sizeof(float), v.rows.size(), fp);
+        std::fclose(fp);
+        std::printf("{\"persons\": %lld, \"total_images\": %lld, \"total_videos\": %lld, \"names\": [", (long long)persons,
+                    (long long)v.total_images, (long long)v.total_videos);
+        for (size_t i = 0; i < v.person.size(); ++i) std::printf("%s\"%s\"", i ? ", " : "", v.person[i].c_str());
+        std::printf("], \"video_first\": [");
+        for (size_t i = 0; i < v.video_first.size(); ++i) std::printf("%s%d", i ? ", " : "", v.video_first[i]);
+        std::printf("], \"frame_first\": [");
+        for (size_t i = 0; i < v.frame_first.size(); ++i) std::printf("%s%lld", i ? ", " : "", (long long)v.frame_first[i]);
+        std::printf("]}\n");
         return 0;
     }
     if (argc < 5) { std::fprintf(stderr, "usage: loader_driver <features.txt> <d> <metric> <out.bin> [threads]\n"); return 2; }

@@ -19,7 +19,7 @@
 #                   own (otherwise dead) KL / Jensen-Shannon arm, lines 33-36
 # plus libref_cls.so from classification.cpp (double-precision kNN / PNN).
 # The match TU also carries ann.h:1-47,61-100 and ann.cpp:2-22,84-126,268-507 (ClassificationMethod, BruteForce,
-# DirectedEnumeration); the class bodies are read with `private`/`protected` defined to `public` so that the
+# DirectedEnumeration) and video.cpp:21-155 (loadVideos); the class bodies are read with `private`/`protected` defined to `public` so that the
 # marshalling code can copy the pivot table and counters out -- the reference's lines themselves are untouched.
 #
 # Flags follow the reference's qmake project (recognition_testing.pro: c++11, release -O2).
@@ -53,6 +53,10 @@ match_tu() {   # $1 = metric id (0 l2, 1 chi2, 2 kl)
     echo '#undef protected'
     echo '#endif'
     sed -n '2,22p;84,126p;268,507p' "$REF/ann.cpp"
+    echo '#include <fstream>'
+    echo '#include <sstream>'
+    echo '#include <map>'
+    sed -n '21,155p' "$REF/video.cpp"         # MapOfVideos, the feature file names, loadVideos (:98-154 is an '#if 0' block)
     echo '#include "ref_wrap_match.inc"'
 }
 

@@ -540,6 +540,52 @@ void orc_train_stats(const double* train_rows, int64_t nt, int d, double* mn, do
  * qt_cpp/db_features.cpp:44-116 and qt_cpp/classification.cpp:795-862).
  * ------------------------------------------------------------------------------------------ */
 
+/* `istream >> value` (libstdc++): once the stream has failed nothing is extracted; at the end of the line nothing is
+ * extracted and the value is left as it was; a field that is not a number stores 0 and fails the stream. The field is
+ * sign, digits, one decimal point, one exponent -- no nan / inf / hex. */
+static int orc_numfield(const char* p, char* buf, size_t cap) {
+    size_t len = 0; int digits = 0, point = 0;
+    if (*p == '+' || *p == '-') buf[len++] = *p;
+    while (len < cap - 2) {
+        const char c = p[len];
+        if (c >= '0' && c <= '9') digits = 1;
+        else if (c == '.' && !point) point = 1;
+        else break;
+        buf[len++] = c;
+    }
+    if (!digits) return 0;
+    if (p[len] == 'e' || p[len] == 'E') {
+        size_t l2 = len; int ed = 0;
+        buf[l2] = p[l2]; ++l2;
+        if (p[l2] == '+' || p[l2] == '-') { buf[l2] = p[l2]; ++l2; }
+        while (l2 < cap - 1 && p[l2] >= '0' && p[l2] <= '9') { buf[l2] = p[l2]; ++l2; ed = 1; }
+        if (!ed) return 0;
+        len = l2;
+    }
+    buf[len] = 0;
+    return (int)len;
+}
+static void orc_extract_f32(char** pp, int* failed, float* value) {
+    char buf[128];
+    if (*failed) return;
+    char* p = *pp + strspn(*pp, " \t\n\r\f\v");
+    if (!*p) { *failed = 1; return; }
+    const int len = orc_numfield(p, buf, sizeof buf);
+    if (!len) { *failed = 1; *value = 0; return; }
+    *value = strtof(buf, 0);
+    *pp = p + len;
+}
+static void orc_extract_f64(char** pp, int* failed, double* value) {
+    char buf[128];
+    if (*failed) return;
+    char* p = *pp + strspn(*pp, " \t\n\r\f\v");
+    if (!*p) { *failed = 1; return; }
+    const int len = orc_numfield(p, buf, sizeof buf);
+    if (!len) { *failed = 1; *value = 0; return; }
+    *value = strtod(buf, 0);
+    *pp = p + len;
+}
+
 static char* orc_getline(FILE* f, char** buf, size_t* cap) {
     size_t len = 0;
     int c;
@@ -606,10 +652,9 @@ int64_t orc_load_images(const char* path, int d, int metric, float* rows_out, in
                 float* feat = rows_out + o * d;
                 char* p = l3;
                 float dfeature = 0, sum = 0;
+                int failed = 0;
                 for (int i = 0; i < d; ++i) {
-                    char* e;
-                    float v = strtof(p, &e);
-                    if (e != p) { dfeature = v; p = e; } else dfeature = 0; /* failed extraction stores 0 (C++11) */
+                    orc_extract_f32(&p, &failed, &dfeature);               /* iss >> dfeature, :83 */
                     if (fabsf(dfeature) < 0.0001) dfeature = 0;           /* :85-86 (compared in double) */
                     feat[i] = dfeature;
                     if (metric == ORC_L2) sum += dfeature * dfeature;       /* :88 */
@@ -658,10 +703,11 @@ int64_t orc_load_dataset_f64(const char* path, int d, double* rows_out, int32_t*
             double* feat = rows_out + n_rec * d;
             char* p = l3;
             double sum = 0;
+            double v = 0;   /* `FEATURE_TYPE feature;` is declared inside the loop, uninitialised (:831): a short line reads an
+                             * indeterminate value there; the same storage is reused in practice, which is what is modelled */
+            int failed = 0;
             for (int i = 0; i < d; ++i) {
-                char* e;
-                double v = strtod(p, &e);
-                if (e != p) p = e; else v = 0;
+                orc_extract_f64(&p, &failed, &v);
                 sum += v * v;
                 feat[i] = v;
             }
@@ -794,6 +840,118 @@ end:
     if (calc_count) *calc_count = distanceCalcCount;
     free(likelihoods); free(likelihood_indices);
     return bestIndex;
+}
+
+/* qt_cpp/video.cpp:35-96 loadVideos: per person a name line (:42-44), `ifs >> videos_count` (:46), per video
+ * `ifs >> frames_count` and the rest of that line (:55-60), per frame a file-name line and a feature line (:63-66);
+ * |x| < 1e-4 -> 0 (:74-75), sum of squares (:78), sqrt for the L2 metric only (:80-82), divide (:84-85). Persons are
+ * kept sorted by name (std::map); a repeated name re-sizes and overwrites the earlier entry (:49-51).
+ * Flattened like oracle/ref_wrap_match.inc::ref_load_videos_cwd. Returns the number of persons. */
+typedef struct { char* name; int n_videos; int* n_frames; float*** frames; /* [video][frame] -> d floats or NULL */ } orc_person;
+static void orc_skip_ws(const char** p, const char* limit) { while (*p < limit && strchr(" \t\n\r\f\v", **p)) ++*p; }
+static int orc_stream_int(const char** p, const char* limit, int* fail, int* v) {
+    if (*fail) return 0;
+    orc_skip_ws(p, limit);
+    const char* s = *p; int neg = 0; long long acc = 0;
+    if (s < limit && (*s == '-' || *s == '+')) { neg = *s == '-'; ++s; }
+    const char* d0 = s;
+    while (s < limit && *s >= '0' && *s <= '9') acc = acc * 10 + (*s++ - '0');
+    if (s == d0) { *fail = 1; *v = 0; return 0; }
+    *p = s; *v = (int)(neg ? -acc : acc);
+    return 1;
+}
+static int orc_stream_line(const char** p, const char* limit, int* fail, const char** b, const char** e) {
+    if (*fail || *p >= limit) { *fail = 1; return 0; }
+    *b = *p;
+    const char* nl = (const char*)memchr(*p, '\n', (size_t)(limit - *p));
+    *e = nl ? nl : limit;
+    *p = nl ? nl + 1 : limit;
+    return 1;
+}
+int orc_load_videos(const char* path, int d, int metric, char* names_out, int names_cap, int32_t* videos_per_person,
+                    int32_t* frames_per_video, float* rows_out, int* n_videos, int* n_frames) {
+    FILE* f = fopen(path, "rb");
+    if (n_videos) *n_videos = 0;
+    if (n_frames) *n_frames = 0;
+    if (!f) return 0;
+    fseek(f, 0, SEEK_END); long size = ftell(f); fseek(f, 0, SEEK_SET);
+    char* text = (char*)malloc((size_t)size + 1);
+    if (fread(text, 1, (size_t)size, f) != (size_t)size) { fclose(f); free(text); return 0; }
+    fclose(f); text[size] = 0;
+    const char* p = text; const char* limit = text + size;
+    orc_person* persons = 0; int np = 0, cap = 0, fail = 0;
+    while (!fail) {
+        const char *b, *e;
+        if (!orc_stream_line(&p, limit, &fail, &b, &e)) break;
+        while (b < e && strchr(" \t\n\r\f\v", *b)) ++b;
+        char* name = (char*)malloc((size_t)(e - b) + 1); memcpy(name, b, (size_t)(e - b)); name[e - b] = 0;
+        int videos_count = 0;
+        orc_stream_int(&p, limit, &fail, &videos_count);
+        if (videos_count < 0) videos_count = 0;
+        int at = 0;                                   /* sorted insert / find */
+        while (at < np && strcmp(persons[at].name, name) < 0) ++at;
+        if (at == np || strcmp(persons[at].name, name) != 0) {
+            if (np == cap) { cap = cap ? cap * 2 : 16; persons = (orc_person*)realloc(persons, sizeof(orc_person) * (size_t)cap); }
+            memmove(persons + at + 1, persons + at, sizeof(orc_person) * (size_t)(np - at));
+            persons[at].name = name; persons[at].n_videos = 0; persons[at].n_frames = 0; persons[at].frames = 0; ++np;
+        } else free(name);
+        orc_person* P = &persons[at];
+        /* resize(videos_count): existing videos beyond the new size are dropped, new ones are empty */
+        P->n_frames = (int*)realloc(P->n_frames, sizeof(int) * (size_t)(videos_count > 0 ? videos_count : 1));
+        P->frames = (float***)realloc(P->frames, sizeof(float**) * (size_t)(videos_count > 0 ? videos_count : 1));
+        for (int i = P->n_videos; i < videos_count; ++i) { P->n_frames[i] = 0; P->frames[i] = 0; }
+        P->n_videos = videos_count;
+        for (int i = 0; i < videos_count; ++i) {
+            int frames_count = 0;
+            orc_stream_int(&p, limit, &fail, &frames_count);
+            if (frames_count < 0) frames_count = 0;
+            P->frames[i] = (float**)realloc(P->frames[i], sizeof(float*) * (size_t)(frames_count > 0 ? frames_count : 1));
+            for (int j = 0; j < frames_count; ++j) P->frames[i][j] = 0;      /* resize(): the earlier frames are replaced */
+            P->n_frames[i] = frames_count;
+            if (!orc_stream_line(&p, limit, &fail, &b, &e)) break;
+            for (int j = 0; j < frames_count; ++j) {
+                const char *fb, *fe;
+                if (!orc_stream_line(&p, limit, &fail, &b, &e)) break;
+                if (!orc_stream_line(&p, limit, &fail, &fb, &fe)) break;
+                char* line = (char*)malloc((size_t)(fe - fb) + 1); memcpy(line, fb, (size_t)(fe - fb)); line[fe - fb] = 0;
+                char* lp = line;
+                float* feat = (float*)malloc(sizeof(float) * (size_t)d);
+                float dfeature = 0, sum = 0; int sfail = 0;
+                for (int k = 0; k < d; ++k) {
+                    orc_extract_f32(&lp, &sfail, &dfeature);
+                    if (fabsf(dfeature) < 0.0001) dfeature = 0;
+                    feat[k] = dfeature;
+                    sum += dfeature * dfeature;
+                }
+                if (metric == ORC_L2) sum = sqrtf(sum);
+                for (int k = 0; k < d; ++k) feat[k] /= sum;
+                P->frames[i][j] = feat;
+                free(line);
+            }
+        }
+    }
+    int nv = 0, nf = 0; size_t off = 0;
+    for (int a = 0; a < np; ++a) {
+        const size_t len = strlen(persons[a].name);
+        if (names_out && off + len + 2 < (size_t)names_cap) { memcpy(names_out + off, persons[a].name, len); names_out[off + len] = '\n'; off += len + 1; names_out[off] = 0; }
+        if (videos_per_person) videos_per_person[a] = persons[a].n_videos;
+        for (int i = 0; i < persons[a].n_videos; ++i, ++nv) {
+            if (frames_per_video) frames_per_video[nv] = persons[a].n_frames[i];
+            for (int j = 0; j < persons[a].n_frames[i]; ++j, ++nf) {
+                if (rows_out) {
+                    if (persons[a].frames[i][j]) memcpy(rows_out + (size_t)nf * d, persons[a].frames[i][j], sizeof(float) * (size_t)d);
+                    else memset(rows_out + (size_t)nf * d, 0, sizeof(float) * (size_t)d);
+                }
+                free(persons[a].frames[i][j]);
+            }
+            free(persons[a].frames[i]);
+        }
+        free(persons[a].frames); free(persons[a].n_frames); free(persons[a].name);
+    }
+    free(persons); free(text);
+    if (n_videos) *n_videos = nv;
+    if (n_frames) *n_frames = nf;
+    return np;
 }
 
 /* ann.cpp:84-93 ClassificationMethod::getThreshold: the value at rank (int)(n*rate). */

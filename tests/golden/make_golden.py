@@ -148,6 +148,36 @@ def main():
         rc.L.ref_cls_get_dataset(r.ctypes.data, lab.ctypes.data)
         fx["loader/f64/rows"] = r
         fx["loader/f64/labels"] = lab
+        # damaged rows: what `iss >> dfeature` leaves behind on short / malformed lines
+        dpath = os.path.join(td, "damaged.txt")
+        with open(dpath, "w") as fh:
+            fh.write(gc.damaged_loader_text())
+        for metric in (gc.L2, gc.CHI2):
+            r, c, nc = refs[metric].load_images(dpath)
+            fx[f"loader_damaged/{gc.METRIC_NAMES[metric]}/rows"] = r
+        with open(os.path.join(td, fname), "w") as fh:
+            fh.write(gc.damaged_loader_text())
+        os.chdir(td)
+        try:
+            n = rc.L.ref_cls_load_dataset_cwd()
+        finally:
+            os.chdir(cwd)
+        r = np.empty((n, rc.L.ref_cls_num_features()), np.float64)
+        lab = np.empty(n, np.int32)
+        rc.L.ref_cls_get_dataset(r.ctypes.data, lab.ctypes.data)
+        fx["loader_damaged/f64/rows"] = r
+        # loadVideos (video.cpp:35-96): reads VIDEO_FEATURES_FILE from the CWD
+        with open(os.path.join(td, refs[gc.L2].video_features_file()), "w") as fh:
+            fh.write(gc.video_text())
+        os.chdir(td)
+        try:
+            for metric in (gc.L2, gc.CHI2):
+                names, vpp, fpv, rows = refs[metric].load_videos_cwd()
+                pre = f"videos/{gc.METRIC_NAMES[metric]}/"
+                fx[pre + "names"] = np.array(names)
+                fx[pre + "videos_per_person"], fx[pre + "frames_per_video"], fx[pre + "rows"] = vpp, fpv, rows
+        finally:
+            os.chdir(cwd)
     counts = np.array([45, 31, 30, 29, 1, 400, 120], np.int32)
     dbi, dbc, ti, tc = refs[gc.L2].split_noshuffle(counts)
     fx["split/db_index"], fx["split/db_class"], fx["split/test_index"], fx["split/test_class"] = dbi, dbc, ti, tc

@@ -88,6 +88,42 @@ def cls_case(seed=17, n=360, d=96, n_classes=12):
     return x, lab, n_classes
 
 
+def _fmt(row):
+    return "".join("{:f} ".format(float(v)) for v in row)
+
+
+def damaged_loader_text():
+    """A feature file (FEATURES_COUNT = 1536) whose rows exercise `iss >> dfeature` (db_features.cpp:83) off the happy
+    path: a line that ends early (the last value repeats), a malformed field (0 from there on), exponent notation, and
+    tokens the stream does not take for numbers (nan)."""
+    d = 1536
+    f = synth.uniform01(4 * d, 911).reshape(4, d).astype(np.float32)
+    lines = []
+    lines += ["/data/a/0.jpg", "alpha", _fmt(f[0])]
+    lines += ["/data/a/1.jpg", "alpha", _fmt(f[1][:100])]                                   # short line
+    lines += ["/data/b/2.jpg", "beta", _fmt(f[2][:50]) + "abc " + _fmt(f[2][51:])]          # malformed field
+    lines += ["/data/b/3.jpg", "beta", "1.5e-1 2E0 -3.25e+0 .5 7. +0.25 " + _fmt(f[3][6:700]) + "nan " + _fmt(f[3][701:])]
+    return "\n".join(lines) + "\n"
+
+
+def video_text():
+    """A video-feature file in the layout loadVideos reads (video.cpp:35-96): person, #videos, per video #frames, per
+    frame a name line and a feature line. Persons out of order, a name with leading blanks, one short frame line."""
+    d = 1536
+    f = synth.uniform01(7 * d, 913).reshape(7, d).astype(np.float32)
+    f[:, 3] = 0.00005
+    out, k = [], 0
+    for person, videos in (("zeta", (2, 1)), ("  alpha beta", (1,)), ("mid", (1, 2))):
+        out += [person, str(len(videos))]
+        for nframes in videos:
+            out.append(str(nframes))
+            for _ in range(nframes):
+                out += [f"frame_{k}.jpg", _fmt(f[k]) if k != 4 else _fmt(f[k][:900])]
+                k += 1
+    assert k == 7
+    return "\n".join(out) + "\n"
+
+
 FPNN_SCALES = (1.0, 0.33)                 # classification.cpp:1002-1007
 FPNN_RATIOS = (0.9, 0.99)                 # output_ratio: the default (:620) and a tighter pruning threshold
 

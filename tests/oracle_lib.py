@@ -14,6 +14,17 @@ def _p(a):
     return a.ctypes.data_as(_vp)
 
 
+def _load_videos(call, d):
+    names = C.create_string_buffer(1 << 16)
+    nv, nf = C.c_int(), C.c_int()
+    npersons = call(names, len(names), None, None, None, C.byref(nv), C.byref(nf))
+    vpp = np.empty(npersons, np.int32)
+    fpv = np.empty(nv.value, np.int32)
+    rows = np.empty((nf.value, d), np.float32)
+    call(names, len(names), _p(vpp), _p(fpv), _p(rows), C.byref(nv), C.byref(nf))
+    return names.value.decode().split("\n")[:-1], vpp, fpv, rows
+
+
 class Oracle:
     """oracle/oracle.c"""
 
@@ -67,6 +78,8 @@ class Oracle:
         L.orc_fpnn_train.argtypes = [_vp, _vp, C.c_int64, C.c_int, C.c_int, _vp, _vp, C.c_double, C.c_int, _vp]
         L.orc_fpnn_predict.restype = C.c_int
         L.orc_fpnn_predict.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_double, _vp, C.c_int, C.c_float, _vp, C.POINTER(C.c_int)]
+        L.orc_load_videos.restype = C.c_int
+        L.orc_load_videos.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_int, _vp, _vp, _vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.orc_get_threshold.restype = C.c_float
         L.orc_get_threshold.argtypes = [_vp, C.c_int, C.c_float]
 
@@ -201,6 +214,10 @@ class Oracle:
         assert n2 == n
         return rows, cls, int(ncls.value)
 
+    def load_videos(self, path, d, metric=0):
+        """loadVideos (video.cpp:35-96) -> (names, videos_per_person, frames_per_video, rows)"""
+        return _load_videos(lambda *a: self.L.orc_load_videos(path.encode(), d, metric, *a), d)
+
     def load_dataset_f64(self, path, d):
         ncls = C.c_int()
         n = self.L.orc_load_dataset_f64(path.encode(), d, None, None, 0, C.byref(ncls))
@@ -310,6 +327,9 @@ class RefMatch:
         L.ref_dem_set_image_count.argtypes = [_vp, C.c_int]
         L.ref_dem_recognize.restype = C.c_int
         L.ref_dem_recognize.argtypes = [_vp, _vp, _vp, _f32p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.ref_video_features_file.restype = C.c_char_p
+        L.ref_load_videos_cwd.restype = C.c_int
+        L.ref_load_videos_cwd.argtypes = [C.c_char_p, C.c_int, _vp, _vp, _vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.ref_load_images.restype = C.c_int
         L.ref_load_images.argtypes = [C.c_char_p, _vp, _vp, C.c_int64, C.POINTER(C.c_int)]
         L.ref_split_noshuffle.restype = C.c_int
@@ -337,6 +357,13 @@ class RefMatch:
         n2 = self.L.ref_load_images(path.encode(), _p(rows), _p(cls), n, C.byref(ncls))
         assert n2 == n
         return rows, cls, int(ncls.value)
+
+    def load_videos_cwd(self):
+        """loadVideos over VIDEO_FEATURES_FILE in the current directory."""
+        return _load_videos(self.L.ref_load_videos_cwd, self.features_count)
+
+    def video_features_file(self):
+        return self.L.ref_video_features_file().decode()
 
     def split_noshuffle(self, class_counts):
         cc = np.ascontiguousarray(class_counts, np.int32)

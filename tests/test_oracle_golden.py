@@ -147,6 +147,25 @@ def test_loader_and_split_match_reference(oracle):
         assert np.array_equal(lab, GOLD["loader/f64/labels"])
         assert np.array_equal(r64.view(np.uint64), GOLD["loader/f64/rows"].view(np.uint64))
         assert oracle.load_images(os.path.join(td, "missing.txt"), d, gc.L2)[0].shape[0] == 0   # db_features.cpp:49,115
+        # short / malformed feature lines: the stream's leftovers (db_features.cpp:83, classification.cpp:832)
+        dpath = os.path.join(td, "damaged.txt")
+        with open(dpath, "w") as fh:
+            fh.write(gc.damaged_loader_text())
+        for metric in (gc.L2, gc.CHI2):
+            rows, _, _ = oracle.load_images(dpath, d, metric)
+            assert np.array_equal(bits(rows), bits(GOLD[f"loader_damaged/{gc.METRIC_NAMES[metric]}/rows"])), metric
+        r64, _, _ = oracle.load_dataset_f64(dpath, d)
+        assert np.array_equal(r64.view(np.uint64), GOLD["loader_damaged/f64/rows"].view(np.uint64))
+        # loadVideos (video.cpp:35-96)
+        vpath = os.path.join(td, "videos.txt")
+        with open(vpath, "w") as fh:
+            fh.write(gc.video_text())
+        for metric in (gc.L2, gc.CHI2):
+            names, vpp, fpv, rows = oracle.load_videos(vpath, d, metric)
+            pre = f"videos/{gc.METRIC_NAMES[metric]}/"
+            assert names == list(GOLD[pre + "names"]) == ["alpha beta", "mid", "zeta"]
+            assert np.array_equal(vpp, GOLD[pre + "videos_per_person"]) and np.array_equal(fpv, GOLD[pre + "frames_per_video"])
+            assert np.array_equal(bits(rows), bits(GOLD[pre + "rows"])), metric
     counts = np.array([45, 31, 30, 29, 1, 400, 120], np.int32)
     dbi, dbc, ti, tc = oracle.split(counts, None, True)
     assert np.array_equal(dbi, GOLD["split/db_index"]) and np.array_equal(dbc, GOLD["split/db_class"])
