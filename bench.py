@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--waves", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-mfma", action="store_true", help="skip the (untimed) matrix-core cross-check of the same step")
+    ap.add_argument("--force-dist", action="store_true", help="initialise the process group even for one rank (exercises the RCCL key exchange on a 1-GPU box)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' rehearses the N>1 path with all ranks on ONE GPU")
     args = ap.parse_args()
 
@@ -68,9 +69,10 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:   # rehearsal: ranks may share a GPU, the key exchange goes through host memory
