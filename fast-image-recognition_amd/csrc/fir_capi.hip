@@ -66,6 +66,9 @@ struct fir_gallery {
     uint64_t* part = nullptr; size_t part_cap = 0;    // top-K per-wave partials
     float* dout = nullptr;    size_t dout_cap = 0;    // range distances for the host-pointer API
     int32_t* didx = nullptr;  size_t didx_cap = 0;
+    // pinned, device-visible host staging of the small host-pointer calls: queries go in, packed keys come out, with
+    // no copy engine in between (the kernels read / write it over PCIe) and one stream synchronisation per call
+    void* pin = nullptr;
 
     int qpp = 0;              // queries per gallery pass; 0 = automatic (effective_qpp)
     int waves_req = 0;        // 0 = automatic
@@ -130,6 +133,7 @@ scan_fn pick_kernel(int qb, int metric) {
 #endif
 // The hand-scheduled L2 top-1 kernels cover whole-chunk feature ranges with 8 or 16 queries.
 // *lds_bytes receives the dynamic LDS size the kernel must be launched with.
+constexpr size_t kMaxQueryTileLds = 144 * 1024;   // of the CU's 160 KiB; one workgroup per CU above 80 KiB
 scan_fn pick_fast(int epi, int qb, int metric, int start, int end, int dp4, size_t* lds_bytes) {
     if (lds_bytes) *lds_bytes = 0;
 #if FIR_FAST
@@ -137,7 +141,7 @@ scan_fn pick_fast(int epi, int qb, int metric, int start, int end, int dp4, size
     if (qb != 8 && qb != 16) return nullptr;
 #if FIR_FAST_MODE == 2
     const size_t need = (size_t)(dp4 + 1) * qb * 16;     // query tile + one zero chunk of slack
-    if (need <= 64 * 1024) {
+    if (need <= kMaxQueryTileLds) {                        // above 64 KiB the launch opts in (run_pass)
         if (lds_bytes) *lds_bytes = need;
         if (qb == 8) return (scan_fn)k_scan_l2_lds<1, FIR_FAST_U, FIR_FAST_WPS>;
         return (scan_fn)k_scan_l2_lds<2, FIR_FAST_U, FIR_FAST_WPS>;
@@ -145,6 +149,22 @@ scan_fn pick_fast(int epi, int qb, int metric, int start, int end, int dp4, size
 #endif
     if (qb == 8) return (scan_fn)k_scan_l2_fast<1, FIR_FAST_U, FIR_FAST_WPS>;
     return (scan_fn)k_scan_l2_fast<2, FIR_FAST_U, FIR_FAST_WPS>;
+#endif
+    return nullptr;
+}
+
+// Few tiles (a gallery of a few thousand rows): every wave owns a whole tile and streams it alone, so what limits a
+// single-query call is how many gallery loads the wave keeps in flight. One- and two-query tiles have the registers
+// for 16 chunks (16 KiB per wave) per load group.
+constexpr int kUDeep = 16;
+scan_fn pick_deep(int epi, int qb, int metric, int dp4, size_t* lds_bytes) {
+    const size_t need = (size_t)dp4 * 4 * qb * sizeof(float);
+    if (need > 64 * 1024) return nullptr;
+#ifndef FIR_MINIMAL
+#define FIR_DEEP(QB, M, E) if (epi == E && qb == QB && metric == M) { *lds_bytes = need; return (scan_fn)k_scan<QB, M, kUDeep, E, kKMax, kWps, 1>; }
+    FIR_DEEP(1, 0, kEpiTop1) FIR_DEEP(1, 1, kEpiTop1) FIR_DEEP(1, 2, kEpiTop1)
+    FIR_DEEP(1, 0, kEpiStore) FIR_DEEP(1, 1, kEpiStore) FIR_DEEP(1, 2, kEpiStore)
+#undef FIR_DEEP
 #endif
     return nullptr;
 }
@@ -173,10 +193,26 @@ int pick_waves(int64_t tiles, int max_waves, int simds) {
 // L2 scan stays HBM-bound up to 8 queries per pass (profiles/r01_sweep_notes.md); a gallery (shard) that stays
 // cache-resident is VALU-bound either way, and 16 queries per pass halve its cache traffic
 // (profiles/r01_qb_table_100kx512.txt: 295k vs 175k queries/s at 100k x 512).
+double gallery_bytes(const fir_gallery* g) { return (double)g->tiles * 64.0 * g->dp4 * 16.0; }
+// Galleries up to this size are read with plain loads instead of the non-temporal hint. 0: measured no gain from
+// plain loads even for an 18 MB gallery that fits the L2s (one-query calls unchanged, multi-pass calls slower --
+// profiles/r01_small_gallery_sweep.txt), so every gallery is streamed.
+constexpr double kL2ResidentBytes = 0.0;
+
 int effective_qpp(const fir_gallery* g) {
     if (g->qpp > 0) return g->qpp;
-    const double bytes = (double)g->tiles * 64.0 * g->dp4 * 16.0;
-    return bytes <= 384.0 * 1024 * 1024 ? 16 : 8;
+    return gallery_bytes(g) <= 384.0 * 1024 * 1024 ? 16 : 8;
+}
+
+// Queries per pass of one top-1 call of qb queries. A wave owns whole 64-row tiles, so a gallery of few tiles gives
+// few waves per pass: the automatic choice halves the query tile until the launch (tiles x passes) has a wave for
+// every SIMD (profiles/r01_small_gallery_sweep.txt).
+int top1_qpp(const fir_gallery* g, int qb, int cap) {
+    if (g->qpp > 0) return cap;
+    const int64_t simds = (int64_t)g->cus * 4;
+    int q = cap;
+    while (q > 1 && g->tiles * ((qb + q - 1) / q) < simds) q /= 2;
+    return q;
 }
 
 int check_range(const fir_gallery* g, int32_t& start, int32_t& end) {
@@ -207,20 +243,27 @@ int max_waves_for(fir_gallery* g, scan_fn fn, size_t lds_bytes) {
 
 // Queue: transpose (+ key init) of one query tile, then one gallery pass.
 int run_pass(fir_gallery* g, hipStream_t st, int epi, const float* d_queries, int q0, int qb_tile, int32_t start,
-             int32_t end, uint64_t* keys, float* out, int64_t out_stride, int k, int* waves_used = nullptr, int ny = 1) {
+             int32_t end, uint64_t* keys, float* out, int64_t out_stride, int k, int* waves_used = nullptr, int ny = 1,
+             int init_keys = 0) {
     // ny > 1 (hand-scheduled top-1 kernels only): ny consecutive query tiles of qb_tile queries in ONE launch
     const int kk = g->dp4 * 4;
     float* qt = g->qt + (size_t)q0 * kk;
     {
-        const int64_t total = (int64_t)kk * qb_tile * ny;
+        const int64_t total = std::max<int64_t>((int64_t)kk * qb_tile * ny, init_keys);
         const int blocks = (int)((total + kBlock - 1) / kBlock);
         hipLaunchKernelGGL(k_transpose_queries, dim3(blocks), dim3(kBlock), 0, st, d_queries + (size_t)q0 * g->d, qb_tile * ny,
-                           g->d, g->dp4, qb_tile, qt);
+                           g->d, g->dp4, qb_tile, qt, init_keys > 0 ? keys : nullptr, init_keys);
     }
     size_t lds_bytes = 0;
     scan_fn fn = pick_fast(epi, qb_tile, g->metric, start, end, g->dp4, &lds_bytes);
+    if (!fn && g->tiles <= (int64_t)g->cus * 4) fn = pick_deep(epi, qb_tile, g->metric, g->dp4, &lds_bytes);
     if (!fn) fn = pick(epi, qb_tile, g->metric);
     if (!fn) return fail(FIR_ERR_ARG, "no kernel for qb=%d metric=%d", qb_tile, g->metric);
+    if (lds_bytes > 64 * 1024) {   // more than the default dynamic LDS limit: opt in once per kernel
+        bool known = false;
+        for (const auto& e : g->occ) known = known || (e.fn == (const void*)fn && e.lds == lds_bytes);
+        if (!known) FIR_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxQueryTileLds));
+    }
     const int max_waves = max_waves_for(g, fn, lds_bytes);
     const int waves = g->waves_req > 0 ? std::min(g->waves_req, max_waves) : pick_waves(g->tiles, max_waves, g->cus * 4);
     g->last_waves = waves;
@@ -241,6 +284,7 @@ int run_pass(fir_gallery* g, hipStream_t st, int epi, const float* d_queries, in
     a.nq = qb_tile;
     a.k = k;
     a.qt_stride = (int64_t)kk * qb_tile;
+    a.nt = gallery_bytes(g) > kL2ResidentBytes ? 1 : 0;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (g->profiling) {
         if (g->ev_used + 2 > g->ev.size()) {
@@ -264,24 +308,22 @@ int run_pass(fir_gallery* g, hipStream_t st, int epi, const float* d_queries, in
     return FIR_OK;
 }
 
-__global__ void k_fill_keys(uint64_t* keys, int n) {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i < n) keys[i] = kKeyNone;
-}
-
 int top1_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start, int32_t end, uint64_t* d_keys,
              hipStream_t st) {
     int rc = grow(g->qt, g->qt_cap, (size_t)qb * g->dp4 * 4 + 64);   // +64: the fast kernel prefetches one unit past the tile
     if (rc) return rc;
-    hipLaunchKernelGGL(k_fill_keys, dim3((qb + kBlock - 1) / kBlock), dim3(kBlock), 0, st, d_keys, qb);
     // 16 queries per pass exist only in the hand-scheduled kernel (whole-chunk L2 ranges)
-    const int cap = pick_fast(kEpiTop1, 16, g->metric, start, end, g->dp4, nullptr) ? effective_qpp(g) : std::min(effective_qpp(g), 8);
+    int cap = pick_fast(kEpiTop1, 16, g->metric, start, end, g->dp4, nullptr) ? effective_qpp(g) : std::min(effective_qpp(g), 8);
+    // 16 queries per pass only while their tile fits the default 64 KiB of LDS (d <= 1020): a larger tile leaves one
+    // workgroup per CU, and the 8-query tile then does better
+    if (cap > 8 && (size_t)(g->dp4 + 1) * 16 * 16 > 64 * 1024) cap = 8;
+    cap = top1_qpp(g, qb, cap);
     int q0 = 0;
     while (q0 < qb) {
         const int t = largest_pow2_le(qb - q0, cap);
-        // all the whole tiles of t queries go into one launch (blockIdx.y) when the hand-scheduled kernel takes them
-        const int ny = pick_fast(kEpiTop1, t, g->metric, start, end, g->dp4, nullptr) ? std::min((qb - q0) / t, g->max_tiles_per_launch) : 1;
-        rc = run_pass(g, st, kEpiTop1, d_queries, q0, t, start, end, d_keys + q0, nullptr, 0, 0, nullptr, ny);
+        // all the whole tiles of t queries go into one launch (blockIdx.y)
+        const int ny = std::min((qb - q0) / t, g->max_tiles_per_launch);
+        rc = run_pass(g, st, kEpiTop1, d_queries, q0, t, start, end, d_keys + q0, nullptr, 0, 0, nullptr, ny, /*init_keys=*/t * ny);
         if (rc) return rc;
         q0 += t * ny;
     }
@@ -486,6 +528,7 @@ int fir_gallery_destroy(fir_gallery* g) {
     for (hipEvent_t e : g->ev) (void)hipEventDestroy(e);
     (void)hipFree(g->gal4); (void)hipFree(g->cls); (void)hipFree(g->qt); (void)hipFree(g->dq); (void)hipFree(g->dkeys);
     (void)hipFree(g->part); (void)hipFree(g->dout); (void)hipFree(g->didx);
+    if (g->pin) (void)hipHostFree(g->pin);
     if (g->stream) (void)hipStreamDestroy(g->stream);
     delete g;
     return FIR_OK;
@@ -558,6 +601,20 @@ int fir_search_top1_keys_dev(fir_gallery* g, const float* d_queries, int32_t qb,
     return top1_dev(g, d_queries, qb, start_pos, end_pos, d_keys, stream ? (hipStream_t)stream : g->stream);
 }
 
+namespace {
+constexpr size_t kPinQueryBytes = 256 * 1024;    // host-pointer calls up to this many query bytes take the pinned path
+constexpr size_t kPinKeys = 4096;                // and up to this many result keys
+__global__ void __launch_bounds__(kBlock) k_publish_keys(const uint64_t* __restrict__ keys, int n, uint64_t* __restrict__ host_keys) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) host_keys[i] = keys[i];
+}
+int ensure_pin(fir_gallery* g) {
+    if (g->pin) return FIR_OK;
+    FIR_HIP(hipHostMalloc(&g->pin, kPinQueryBytes + kPinKeys * sizeof(uint64_t), hipHostMallocDefault));
+    return FIR_OK;
+}
+}  // namespace
+
 int fir_search_top1(fir_gallery* g, const float* queries, int32_t qb, int32_t start_pos, int32_t end_pos, int32_t* idx,
                     float* dist) {
     if (!g || (qb > 0 && !queries)) return fail(FIR_ERR_ARG, "NULL argument");
@@ -566,6 +623,20 @@ int fir_search_top1(fir_gallery* g, const float* queries, int32_t qb, int32_t st
     int rc = check_range(g, start_pos, end_pos);
     if (rc) return rc;
     FIR_HIP(hipSetDevice(g->device));
+    const bool mfma = g->large_batch_min > 0 && qb >= g->large_batch_min && g->metric == FIR_METRIC_L2 && start_pos == 0 && end_pos == g->d && g->n > 0;
+    if (!mfma && (size_t)qb * g->d * sizeof(float) <= kPinQueryBytes && (size_t)qb <= kPinKeys) {
+        // small call: queries are read from, and keys written to, pinned host memory by the kernels themselves
+        if ((rc = ensure_pin(g))) return rc;
+        if ((rc = grow(g->dkeys, g->dkeys_cap, (size_t)qb))) return rc;
+        float* hq = (float*)g->pin;
+        uint64_t* hk = (uint64_t*)((char*)g->pin + kPinQueryBytes);
+        std::memcpy(hq, queries, (size_t)qb * g->d * sizeof(float));
+        if ((rc = top1_dev(g, hq, qb, start_pos, end_pos, g->dkeys, g->stream))) return rc;
+        hipLaunchKernelGGL(k_publish_keys, dim3((qb + kBlock - 1) / kBlock), dim3(kBlock), 0, g->stream, g->dkeys, qb, hk);
+        FIR_HIP(hipGetLastError());
+        FIR_HIP(hipStreamSynchronize(g->stream));
+        return fir_keys_unpack(hk, qb, idx, dist);
+    }
     if ((rc = grow(g->dq, g->dq_cap, (size_t)qb * g->d))) return rc;
     if ((rc = grow(g->dkeys, g->dkeys_cap, (size_t)qb))) return rc;
     FIR_HIP(hipMemcpyAsync(g->dq, queries, (size_t)qb * g->d * sizeof(float), hipMemcpyHostToDevice, g->stream));

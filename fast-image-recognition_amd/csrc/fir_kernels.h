@@ -20,6 +20,8 @@
 // (QB <= 8 at d = 512 on MI355X); chi-square / KL are VALU-bound (IEEE division / log per
 // element) and are priced against the vector-ALU roof instead.
 #pragma once
+#include <type_traits>
+
 #include "fir_common.h"
 
 namespace fir {
@@ -30,15 +32,35 @@ namespace fir {
 #ifndef FIR_NT
 #define FIR_NT 1   // +6 % on the 1M x 512 scan (profiles/r01_sweep_notes.md)
 #endif
-// One lane's float4 of a gallery tile. FIR_NT: non-temporal hint (the gallery is streamed once per pass).
-__device__ __forceinline__ float4 ld_gallery(const float4* p) {
+// One lane's float4 of a gallery tile. nt: non-temporal hint -- a gallery that is streamed from HBM once per pass
+// should not displace anything in L2; a gallery small enough to live in the L2s keeps the plain load so that the
+// next call finds it there (ScanArgs::nt, set per gallery by its size).
+__device__ __forceinline__ float4 ld_gallery(const float4* p, bool nt) {
 #if FIR_NT
-    typedef float v4f __attribute__((ext_vector_type(4)));
-    const v4f v = __builtin_nontemporal_load((const v4f*)p);
-    return make_float4(v.x, v.y, v.z, v.w);
-#else
-    return *p;
+    if (nt) {
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const v4f v = __builtin_nontemporal_load((const v4f*)p);
+        return make_float4(v.x, v.y, v.z, v.w);
+    }
 #endif
+    return *p;
+}
+// U chunks of one lane, `stride` float4 apart; one uniform branch for the whole group.
+template <int U>
+__device__ __forceinline__ void ld_gallery_group(float4 (&g)[U], const float4* p, bool nt) {
+#if FIR_NT
+    if (nt) {
+        typedef float v4f __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const v4f v = __builtin_nontemporal_load((const v4f*)(p + (size_t)u * 64));
+            g[u] = make_float4(v.x, v.y, v.z, v.w);
+        }
+        return;
+    }
+#endif
+#pragma unroll
+    for (int u = 0; u < U; ++u) g[u] = p[(size_t)u * 64];
 }
 
 struct ScanArgs {
@@ -55,14 +77,16 @@ struct ScanArgs {
     int64_t out_stride;
     int32_t nq;           // live queries in this tile (<= QB); only kEpiStore needs it
     int32_t k;            // kEpiTopK
-    int64_t qt_stride;    // hand-scheduled kernels: floats between the query tiles of consecutive blockIdx.y
+    int64_t qt_stride;    // floats between the query tiles of consecutive blockIdx.y (top-1 kernels)
+    int32_t nt;           // non-temporal gallery loads (galleries that do not fit the L2s)
 };
 
 template <int QB, int METRIC, int U>
 struct TileAcc {
     static constexpr int kSq = 4 * QB;   // query values one chunk needs: 4 features x QB queries
 
-    static __device__ __forceinline__ void load_sq(float (&sq)[kSq], sfloat_p qc, int c) {
+    template <typename QP>
+    static __device__ __forceinline__ void load_sq(float (&sq)[kSq], QP qc, int c) {
 #pragma unroll
         for (int i = 0; i < kSq; ++i) sq[i] = qc[c * kSq + i];   // uniform address, constant AS: s_load_dwordx8/x16
     }
@@ -74,20 +98,23 @@ struct TileAcc {
             for (int q = 0; q < QB; ++q) acc[q] = accum<METRIC>(acc[q], sq[j * QB + q], gv[j]);
         }
     }
-    // acc[q] += contribution of one group of U chunks starting at chunk c. The schedule barrier
-    // after each chunk keeps the compiler from hoisting a whole group's scalar loads at once
-    // (4*QB SGPRs per chunk; hoisting them all spills SGPRs).
-    static __device__ __forceinline__ void group(float (&acc)[QB], const float4 (&g)[U], sfloat_p qc, int c) {
+    // acc[q] += contribution of one group of U chunks starting at chunk c. QP = constant-address-space pointer: the
+    // query values come through the scalar cache (s_load); the schedule barrier after each chunk keeps the compiler
+    // from hoisting a whole group's scalar loads at once (4*QB SGPRs per chunk; hoisting them all spills SGPRs).
+    // QP = plain pointer into LDS: broadcast ds_reads, in-order and counted, scheduled by the compiler.
+    template <typename QP>
+    static __device__ __forceinline__ void group(float (&acc)[QB], const float4 (&g)[U], QP qc, int c) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             float cur[kSq];
             load_sq(cur, qc, c + u);
             chunk(acc, g[u], cur);
-            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (sizeof(QP) == sizeof(sfloat_p) && __is_same(QP, sfloat_p)) __builtin_amdgcn_sched_barrier(0);
         }
     }
     // One chunk with a feature mask [k0, k1) (range edges that are not multiples of 4).
-    static __device__ __forceinline__ void masked(float (&acc)[QB], const float4 g, sfloat_p qc, int c, int k0, int k1) {
+    template <typename QP>
+    static __device__ __forceinline__ void masked(float (&acc)[QB], const float4 g, QP qc, int c, int k0, int k1) {
         const float gv[4] = {g.x, g.y, g.z, g.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -102,11 +129,25 @@ struct TileAcc {
 
 // Streams whole tiles; lane r of a wave owns row 64 t + r. EPI selects what happens to the
 // finished distances: running first-minimum (top-1), running K smallest (top-K), or store.
-template <int QB, int METRIC, int U, int EPI, int KMAX, int WPS>
+// LDSQ = 1: the query tile is staged in (dynamic) LDS first -- dp4*4*QB floats -- and read from there; used for
+// one- and two-query tiles over galleries of few tiles, where a wave streams a whole tile alone and the per-chunk
+// scalar-load latency of the default form is what it waits for.
+template <int QB, int METRIC, int U, int EPI, int KMAX, int WPS, int LDSQ = 0>
 __global__ void __launch_bounds__(kBlock, WPS) k_scan(const ScanArgs a) {
     const int lane = threadIdx.x & 63;
     const int gw = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-    sfloat_p qc = (sfloat_p)(uintptr_t)a.qt;
+    // blockIdx.y = query tile (top-1 only): several tiles of QB queries share one launch
+    const float* qsrc = a.qt + (EPI == kEpiTop1 ? (size_t)blockIdx.y * a.qt_stride : 0);
+    extern __shared__ __attribute__((aligned(16))) float lds_q[];
+    if constexpr (LDSQ) {
+        const int nf = a.dp4 * 4 * QB;
+        for (int i = threadIdx.x; i < nf; i += kBlock) lds_q[i] = qsrc[i];
+        __syncthreads();
+    }
+    typedef typename std::conditional<LDSQ != 0, const float*, sfloat_p>::type QP;
+    QP qc;
+    if constexpr (LDSQ) qc = lds_q;
+    else qc = (sfloat_p)(uintptr_t)qsrc;
 
     const int c_lo = (a.start + 3) >> 2;          // first whole chunk
     const int c_hi = a.end >> 2;                  // one past the last whole chunk
@@ -147,22 +188,19 @@ __global__ void __launch_bounds__(kBlock, WPS) k_scan(const ScanArgs a) {
 #if FIR_PIPE == 0
             for (int gi = 0; gi < ng; ++gi) {
                 float4 g[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) g[u] = ld_gallery(p + (size_t)(gi * U + u) * 64);
+                ld_gallery_group<U>(g, p + (size_t)(gi * U) * 64, a.nt != 0);
                 TileAcc<QB, METRIC, U>::group(acc, g, qc, c_lo + gi * U);
             }
 #else
             // register double buffer: group gi+1 is in flight while group gi is consumed
             float4 g[U];
             if (ng > 0) {
-#pragma unroll
-                for (int u = 0; u < U; ++u) g[u] = ld_gallery(p + (size_t)u * 64);
+                ld_gallery_group<U>(g, p, a.nt != 0);
             }
             for (int gi = 0; gi < ng; ++gi) {
                 float4 nx[U];
                 const int gn = gi + 1 < ng ? gi + 1 : gi;   // the last group re-reads itself (cache hit, keeps the loop branch-free)
-#pragma unroll
-                for (int u = 0; u < U; ++u) nx[u] = ld_gallery(p + (size_t)(gn * U + u) * 64);
+                ld_gallery_group<U>(nx, p + (size_t)(gn * U) * 64, a.nt != 0);
                 TileAcc<QB, METRIC, U>::group(acc, g, qc, c_lo + gi * U);
 #pragma unroll
                 for (int u = 0; u < U; ++u) g[u] = nx[u];
@@ -201,14 +239,15 @@ __global__ void __launch_bounds__(kBlock, WPS) k_scan(const ScanArgs a) {
     }
 
     if constexpr (EPI == kEpiTop1) {
+        uint64_t* keys = a.keys + (size_t)blockIdx.y * QB;
 #pragma unroll
         for (int q = 0; q < QB; ++q) {
             uint64_t key = best_i[q] >= 0 ? key_pack(best_d[q], (uint32_t)((int64_t)best_i[q] + a.row_offset)) : kKeyNone;
             key = wave_min_u64(key);
             if (lane == 0 && key != kKeyNone) {
                 // most waves lose against what is already there: read first, contend only to win
-                const uint64_t cur = __hip_atomic_load(a.keys + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (key < cur) atomicMin((unsigned long long*)(a.keys + q), (unsigned long long)key);
+                const uint64_t cur = __hip_atomic_load(keys + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (key < cur) atomicMin((unsigned long long*)(keys + q), (unsigned long long)key);
             }
         }
     }
@@ -350,13 +389,12 @@ __global__ void __launch_bounds__(kBlock, WPS) k_scan_l2_fast(const ScanArgs a) 
         int c = c_lo;
         for (; c + U <= c_hi; c += U) {
             float4 g[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) g[u] = ld_gallery(p + (size_t)(c - c_lo + u) * 64);
+            ld_gallery_group<U>(g, p + (size_t)(c - c_lo) * 64, a.nt != 0);
 #pragma unroll
             for (int u = 0; u < U; ++u) l2_chunk<NB>(acc, g[u], cur, q2, c + u);
         }
         for (; c < c_hi; ++c)      // (c_hi - c_lo) % U leftover chunks
-            l2_chunk<NB>(acc, ld_gallery(p + (size_t)(c - c_lo) * 64), cur, q2, c);
+            l2_chunk<NB>(acc, ld_gallery(p + (size_t)(c - c_lo) * 64, a.nt != 0), cur, q2, c);
 
         const int64_t row = (int64_t)t * kTileRows + lane;
         if (row < a.n) {
@@ -495,8 +533,7 @@ __global__ void __launch_bounds__(kBlock, WPS) k_scan_l2_lds(const ScanArgs a) {
 #if FIR_PIPE == 0
         for (; c + U <= c_hi; c += U) {
             float4 g[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) g[u] = ld_gallery(p + (size_t)(c - c_lo + u) * 64);
+            ld_gallery_group<U>(g, p + (size_t)(c - c_lo) * 64, a.nt != 0);
 #pragma unroll
             for (int u = 0; u < U; ++u) l2_chunk_lds<NB>(acc, g[u], cur, lqv, c + u);
         }
@@ -506,14 +543,12 @@ __global__ void __launch_bounds__(kBlock, WPS) k_scan_l2_lds(const ScanArgs a) {
             const int ng = (c_hi - c_lo) / U;
             float4 g[U];
             if (ng > 0) {
-#pragma unroll
-                for (int u = 0; u < U; ++u) g[u] = ld_gallery(p + (size_t)u * 64);
+                ld_gallery_group<U>(g, p, a.nt != 0);
             }
             for (int gi = 0; gi < ng; ++gi, c += U) {
                 float4 nxg[U];
                 const int gn = gi + 1 < ng ? gi + 1 : gi;   // the last group re-reads itself (L2 hit; keeps the loop branch-free)
-#pragma unroll
-                for (int u = 0; u < U; ++u) nxg[u] = ld_gallery(p + (size_t)(gn * U + u) * 64);
+                ld_gallery_group<U>(nxg, p + (size_t)(gn * U) * 64, a.nt != 0);
 #pragma unroll
                 for (int u = 0; u < U; ++u) l2_chunk_lds<NB>(acc, g[u], cur, lqv, c + u);
 #pragma unroll
@@ -522,7 +557,7 @@ __global__ void __launch_bounds__(kBlock, WPS) k_scan_l2_lds(const ScanArgs a) {
         }
 #endif
         for (; c < c_hi; ++c)
-            l2_chunk_lds<NB>(acc, ld_gallery(p + (size_t)(c - c_lo) * 64), cur, lqv, c);
+            l2_chunk_lds<NB>(acc, ld_gallery(p + (size_t)(c - c_lo) * 64, a.nt != 0), cur, lqv, c);
 
         const int64_t row = (int64_t)t * kTileRows + lane;
         if (row < a.n) {
@@ -601,19 +636,23 @@ __global__ void __launch_bounds__(kBlock) k_retile(const float* __restrict__ row
 }
 
 // queries[nq][d] row-major -> tiles of QB queries, transposed: qt[tile][k][QB], k < dp4*4.
-// Queries past nq and features past d are zero.
+// Queries past nq and features past d are zero. keys[0..nkeys) (may be NULL) are preset to "no row yet" on the way:
+// the top-1 scans that follow only ever lower them.
 __global__ void __launch_bounds__(kBlock) k_transpose_queries(const float* __restrict__ q, int nq, int d, int dp4, int QB,
-                                                               float* __restrict__ qt) {
+                                                               float* __restrict__ qt, uint64_t* __restrict__ keys, int nkeys) {
     const int kk = dp4 * 4;
     const int64_t total = (int64_t)((nq + QB - 1) / QB) * kk * QB;
     const int64_t o = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (keys && o < nkeys) keys[o] = kKeyNone;
     if (o >= total) return;
-    const int qi = (int)(o % QB);
-    const int64_t r = o / QB;
-    const int k = (int)(r % kk);
-    const int tile = (int)(r / kk);
+    // consecutive threads read consecutive features of one query (the source may be pinned host memory read over
+    // PCIe: coalesced reads matter there); the strided side is the write into device memory
+    const int k = (int)(o % kk);
+    const int64_t r = o / kk;
+    const int qi = (int)(r % QB);
+    const int tile = (int)(r / QB);
     const int qq = tile * QB + qi;
-    qt[o] = (qq < nq && k < d) ? q[(int64_t)qq * d + k] : 0.0f;
+    qt[((int64_t)tile * kk + k) * QB + qi] = (qq < nq && k < d) ? q[(int64_t)qq * d + k] : 0.0f;
 }
 
 // feature_distance for one pair (db_features.cpp:22-42): one lane, sequential, exact order.
