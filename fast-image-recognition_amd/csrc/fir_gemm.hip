@@ -32,7 +32,11 @@ namespace {
 
 using fir::kKeyNone;
 
-constexpr int kGemmBlock = 512;        // 8 waves: 2 per SIMD
+#ifndef FIR_GEMM_BLOCK
+#define FIR_GEMM_BLOCK 512
+#endif
+constexpr int kGemmBlock = FIR_GEMM_BLOCK;   // 512 = 8 waves: 2 per SIMD (one workgroup per CU: the query slab takes 128 KiB of LDS)
+constexpr int kGemmMinBlocks = kGemmBlock <= 512 ? 2 : 1;
 constexpr int kQT = 64;                // queries per pass (2 accumulator tiles of 32 per wave)
 constexpr int kSlab8 = 64;             // query features staged in LDS at a time, in groups of 8 (512 features)
 constexpr int kSlab16 = 32;            // bf16 variant: k-blocks of 16 features staged at a time (512 features)
@@ -142,7 +146,7 @@ __global__ void __launch_bounds__(64) k_gemm_qnorm(const float* __restrict__ q, 
 // MODE 1: append (p, row) with p < tau[q] to the query's list.
 // Dynamic LDS: the query tile in fragment order, 2 * dq8 * 64 float4.
 template <int MODE>
-__global__ void __launch_bounds__(kGemmBlock, 2) k_gemm_proxy(const float4* __restrict__ gm, const float* __restrict__ gnorm,
+__global__ void __launch_bounds__(kGemmBlock, kGemmMinBlocks) k_gemm_proxy(const float4* __restrict__ gm, const float* __restrict__ gnorm,
                                                                const float4* qm, int64_t n, int64_t row_begin,
                                                                int64_t row_end, int dq8, const float* tau, unsigned long long* lists, int* counts, float* sample,
                                                                int sample_rows) {
@@ -348,7 +352,7 @@ __device__ __forceinline__ bf16x8 as_bf16x8(const uint4 v) {
 // Same contract as k_gemm_proxy (one wave: 32 rows x 64 queries, MODE 0 sample / MODE 1 append), bf16-split operands.
 // Dynamic LDS: one slab of the query tile: 2 query blocks x sk16 k-blocks x {hi, lo} x 64 uint4 (128 KiB at 512 features).
 template <int MODE>
-__global__ void __launch_bounds__(kGemmBlock, 2) k_gemm_proxy_bf16(const uint4* __restrict__ gb, const float* __restrict__ gnorm,
+__global__ void __launch_bounds__(kGemmBlock, kGemmMinBlocks) k_gemm_proxy_bf16(const uint4* __restrict__ gb, const float* __restrict__ gnorm,
                                                                     const uint4* qbf, int64_t n, int64_t row_begin,
                                                                     int64_t row_end, int dk16, const float* tau, unsigned long long* lists, int* counts, float* sample,
                                                                     int sample_rows) {

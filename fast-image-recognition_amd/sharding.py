@@ -5,7 +5,10 @@ neighbour of each query is the integer minimum over ranks of the packed (distanc
 which orders exactly like the reference's first-minimum rule (qt_cpp/db_features.cpp:329-332)
 because the low word is the GLOBAL row index. One all-reduce(MIN) of qb x 8 bytes is the only
 exchange step of the path; RCCL carries it over xGMI (torch.distributed backend "nccl"), gloo in
-the CPU tests. Plumbing only: no distance is computed here.
+the CPU tests. The K nearest rows are an all-gather of every rank's K packed keys plus an integer
+K-way merge; the PNN class scores (qt_cpp/classification.cpp:188-226, partial sums over the rank's
+training rows divided by the GLOBAL training-set size) are one all-reduce(SUM) of qb x C doubles.
+Plumbing only: no distance is computed here.
 """
 import torch
 
@@ -38,3 +41,36 @@ def allreduce_min_keys(keys_i64, group=None, async_op=False):
 def keys_from_int64(keys_i64):
     """Inverse of keys_as_int64 (still an int64 tensor; view it as uint64 on the host)."""
     return keys_i64 ^ _SIGN
+
+
+def merge_topk_keys(parts_i64, k):
+    """parts_i64[P, qb, k] (order-preserving int64 views of each shard's ascending packed keys) -> [qb, k]: the k
+    smallest of the P*k candidates per query, ascending. Keys are unique (the low word is the global row index) and
+    FIR_KEY_NONE sorts last, so this is exactly fir_search_topk over the whole gallery."""
+    p, qb, kk = parts_i64.shape
+    cat = parts_i64.permute(1, 0, 2).reshape(qb, p * kk)
+    return torch.sort(cat, dim=1).values[:, :k].contiguous()
+
+
+def allgather_merge_topk(keys_i64, k, group=None):
+    """Every rank contributes its [qb, k] keys (keys_as_int64 view); every rank gets the merged [qb, k]."""
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    buf = [torch.empty_like(keys_i64) for _ in range(world)]
+    dist.all_gather(buf, keys_i64.contiguous(), group=group)
+    return merge_topk_keys(torch.stack(buf), k)
+
+
+def allreduce_sum_scores(scores_f64, group=None, async_op=False):
+    """In-place SUM all-reduce of the PNN class scores [qb, C] (float64). Each rank computes them over its own
+    training rows with the global training-set size as the divisor (fir_cls_set_total_training_size)."""
+    import torch.distributed as dist
+
+    return dist.all_reduce(scores_f64, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+
+
+def first_max_class(scores_f64):
+    """The reference's arg-max (strict '<' from -DBL_MAX in class order, classification.cpp:217-224): first maximum."""
+    mx = scores_f64.max(dim=1, keepdim=True).values
+    return (scores_f64 == mx).to(torch.int8).argmax(dim=1).to(torch.int32)

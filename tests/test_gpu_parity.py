@@ -253,6 +253,53 @@ def test_row_offset_and_shard_merge(fir, oracle):
         assert_bits_equal(mdist, edist)
 
 
+def test_sharded_topk_merge_and_pnn_partial_sums(fir, oracle):
+    """SURVEY 8e beyond top-1: the K nearest rows over row shards = K-way merge of the shards' packed keys; the PNN
+    class scores = sum of the shards' partial scores (each over its training rows, divided by the global size)."""
+    import torch
+
+    import golden_cases as gc
+    from fast_image_recognition_amd import sharding
+
+    rows = synth.make_gallery(52, 9000, 96, CHI2)
+    q, _ = synth.make_queries(52, rows, 7, CHI2)
+    rows[8000] = rows[77]
+    q[2] = rows[77]
+    k = 5
+    with fir.Gallery(rows, None, CHI2, 0) as g:
+        widx, wdist = g.search_topk(q, k)
+    for parts in (2, 3):
+        per = (9000 + parts - 1) // parts
+        stack = []
+        for r in range(parts):
+            lo, hi = r * per, min(9000, (r + 1) * per)
+            with fir.Gallery(rows[lo:hi], None, CHI2, 0) as g:
+                g.set_row_offset(lo)
+                idx, dist = g.search_topk(q, k)
+            keys = np.array([[fir.key_pack(dist[i, j], idx[i, j]) for j in range(k)] for i in range(len(q))], np.uint64)
+            stack.append(sharding.keys_as_int64(torch.from_numpy(keys.view(np.int64))))
+        merged = sharding.keys_from_int64(sharding.merge_topk_keys(torch.stack(stack), k)).numpy().view(np.uint64)
+        midx, mdist = fir.keys_unpack(merged.reshape(-1))
+        assert np.array_equal(midx.reshape(-1, k), widx)
+        assert_bits_equal(mdist.reshape(-1, k), wdist)
+
+    x, lab, ncls = gc.cls_case(seed=53, n=700, d=64, n_classes=9)
+    order = np.argsort(lab, kind="stable")
+    tr, tcls, qs = x[order][:600], lab[order][:600], x[order][600:640]
+    avg = tr.mean(0)
+    whole = fir.ClsModel(tr, tcls, ncls, avg, 0)
+    wbest, wscores = whole.pnn_predict(qs)
+    whole.close()
+    total = np.zeros_like(wscores)
+    for lo, hi in ((0, 250), (250, 251), (251, 600)):
+        m = fir.ClsModel(tr[lo:hi], tcls[lo:hi], ncls, avg, 0)
+        m.set_total_training_size(600)
+        total += m.pnn_predict(qs)[1]
+        m.close()
+    assert np.allclose(total, wscores, rtol=1e-12, atol=1e-300)
+    assert np.array_equal(sharding.first_max_class(torch.from_numpy(total)).numpy(), wbest)
+
+
 def test_errors_are_reported_not_crashed(fir):
     rows = synth.make_gallery(61, 100, 32, L2)
     with fir.Gallery(rows, None, L2, 0) as g:

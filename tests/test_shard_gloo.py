@@ -57,6 +57,84 @@ def _worker(rank, world, port, n, d, qb, out_dir):
     dist.destroy_process_group()
 
 
+def _worker_topk_pnn(rank, world, port, n, d, qb, k, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    import torch.distributed as dist
+
+    import __graft_entry__ as ge
+    import golden_cases as gc
+    import oracle_lib
+    import synth
+
+    fir = ge.load_package()
+    from fast_image_recognition_amd import sharding
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    orc = oracle_lib.load_oracle()
+    # ---- K nearest rows: all-gather of each shard's K keys + integer merge ----
+    rows = synth.make_gallery(78, n, d, 1)
+    q, _ = synth.make_queries(78, rows, qb, 1)
+    rows[n - 2] = rows[3]
+    q[0] = rows[3]                                        # equal distances in different shards: ordered by global row
+    lo, hi = sharding.shard_bounds(n, world, rank, granule=64)
+    keys = np.full((qb, k), np.uint64(0xFFFFFFFFFFFFFFFF), np.uint64)
+    for i in range(qb):
+        if hi > lo:
+            li, ld = orc.topk(rows[lo:hi], q[i], 0, d, k, 1)
+            for j in range(k):
+                if li[j] >= 0:
+                    keys[i, j] = fir.key_pack(ld[j], int(li[j]) + lo)
+    t = sharding.keys_as_int64(torch.from_numpy(keys.view(np.int64)).clone())
+    merged = sharding.keys_from_int64(sharding.allgather_merge_topk(t, k)).numpy().view(np.uint64)
+    idx, dd = fir.keys_unpack(merged.reshape(-1))
+    # ---- PNN class scores: partial sums over the shard's training rows, all-reduce(SUM) ----
+    x, lab, ncls = gc.cls_case(seed=31, n=240, d=40, n_classes=6)
+    order = np.argsort(lab, kind="stable")
+    tr, tcls = x[order][:200], lab[order][:200]
+    _, _, avg, _ = orc.train_stats(tr)
+    tlo, thi = sharding.shard_bounds(tr.shape[0], world, rank)
+    qs = x[order][200:]
+    part = np.zeros((qs.shape[0], ncls))
+    if thi > tlo:
+        for i, qi in enumerate(qs):
+            part[i] = orc.pnn_predict_den(tr[tlo:thi], tcls[tlo:thi], avg, ncls, qi, tr.shape[0])[1]
+    st = torch.from_numpy(part)
+    sharding.allreduce_sum_scores(st)
+    best = sharding.first_max_class(st).numpy()
+    np.savez(os.path.join(out_dir, f"k{rank}.npz"), idx=idx.reshape(qb, k), dist=dd.reshape(qb, k), scores=st.numpy(), best=best)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n", [(2, 500), (3, 130)])
+def test_sharded_topk_and_pnn_equal_unsharded(tmp_path, oracle, world, n):
+    """top-K = all-gather of K keys per rank + K-way merge; PNN = all-reduce(SUM) of the class scores."""
+    import golden_cases as gc
+    import synth
+
+    d, qb, k = 32, 5, 5
+    port = _free_port()
+    mp.spawn(_worker_topk_pnn, args=(world, port, n, d, qb, k, str(tmp_path)), nprocs=world, join=True)
+    rows = synth.make_gallery(78, n, d, 1)
+    q, _ = synth.make_queries(78, rows, qb, 1)
+    rows[n - 2] = rows[3]
+    q[0] = rows[3]
+    exp = [oracle.topk(rows, qi, 0, d, k, 1) for qi in q]
+    assert list(exp[0][0][:2]) == [3, n - 2]
+    x, lab, ncls = gc.cls_case(seed=31, n=240, d=40, n_classes=6)
+    order = np.argsort(lab, kind="stable")
+    tr, tcls = x[order][:200], lab[order][:200]
+    _, _, avg, _ = oracle.train_stats(tr)
+    pe = [oracle.pnn_predict(tr, tcls, avg, ncls, qi) for qi in x[order][200:]]
+    for r in range(world):
+        z = np.load(tmp_path / f"k{r}.npz")
+        for i in range(qb):
+            assert np.array_equal(z["idx"][i], exp[i][0]), (r, i)
+            assert np.array_equal(z["dist"][i].view(np.uint32), exp[i][1].view(np.uint32))
+        assert np.allclose(z["scores"], np.array([e[1] for e in pe]), rtol=1e-12, atol=1e-300)    # summation order differs
+        assert list(z["best"]) == [e[0] for e in pe]
+
+
 @pytest.mark.parametrize("world,n", [(2, 1000), (2, 70), (3, 129)])
 def test_sharded_top1_equals_unsharded(tmp_path, oracle, world, n):
     import synth
