@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "../../include/fir_amd.h"
@@ -40,7 +41,7 @@ constexpr int kGemmMinBlocks = kGemmBlock <= 512 ? 2 : 1;
 constexpr int kQT = 64;                // queries per pass (2 accumulator tiles of 32 per wave)
 constexpr int kSlab8 = 64;             // query features staged in LDS at a time, in groups of 8 (512 features)
 constexpr int kSlab16 = 32;            // bf16 variant: k-blocks of 16 features staged at a time (512 features)
-constexpr int kPasses = 4;             // 64-query passes folded into one launch (blockIdx.y): their tails overlap
+constexpr int kPasses = 8;             // 64-query passes folded into one set of launches (blockIdx.y): their tails overlap
 constexpr int kCand = 8;               // candidates re-ranked exactly per query
 constexpr int kListCap = 4096;         // appended (proxy, row) entries per query before "overflow"
 constexpr int kMinSampleRows = 8192;   // rows whose proxies seed tau: max(8192, n / 64) -> ~512 appended rows per query
@@ -477,6 +478,138 @@ __global__ void __launch_bounds__(kGemmBlock, kGemmMinBlocks) k_gemm_proxy_bf16(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The append pass for TWO 64-query passes at once: one wave = 32 rows x 128 queries (four accumulator tiles, twelve
+// MFMAs per k-block). The gallery stream -- what bounds k_gemm_proxy_bf16 (5.7 TB/s, MFMA pipe ~25 % busy) -- is read
+// once per 128 queries instead of once per 64. The query fragments of 128 queries only fit LDS 256 features at a time
+// (4 query blocks x 16 k-blocks x {hi, lo} x 1 KiB = 128 KiB), so every row group of a workgroup re-stages the slabs;
+// the gallery fragments keep streaming through the staging barriers (their register ring is indexed by the global
+// k-block, not by the slab). blockIdx.y = pair of passes; the per-pass scratch (tau, lists, counts, query fragments) is
+// laid out pass-major, so the pair's 128 queries are simply consecutive.
+// ---------------------------------------------------------------------------------------------
+constexpr int kSlabW = 16;             // k-blocks (of 16 features) of the 128-query slab
+constexpr int kWideLds = 4 * kSlabW * 128 * (int)sizeof(uint4);   // 128 KiB
+__global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_bf16_wide(const uint4* __restrict__ gb, const float* __restrict__ gnorm,
+                                                                         const uint4* qbf, int64_t n, int dk16, const float* tau,
+                                                                         unsigned long long* lists, int* counts) {
+    extern __shared__ __attribute__((aligned(16))) uint4 lqb[];
+    __shared__ float tau_s[2 * kQT];
+    {
+        const size_t pr = blockIdx.y;
+        qbf += pr * 4 * dk16 * 128;
+        tau += pr * 2 * kQT;
+        lists += pr * 2 * kQT * kListCap;
+        counts += pr * 2 * kQT;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wpb = blockDim.x >> 6;
+    if (threadIdx.x < 2 * kQT) tau_s[threadIdx.x] = tau[threadIdx.x];
+    const int64_t rb_end = (n + 31) / 32;
+    const int64_t nrg = (rb_end + wpb - 1) / wpb;
+    const int nslab = (dk16 + kSlabW - 1) / kSlabW;
+    const int klast = dk16 - 1;
+    for (int64_t rg = blockIdx.x; rg < nrg; rg += gridDim.x) {
+        const int64_t rb = rg * wpb + wave;
+        const bool active = rb < rb_end;
+        const uint4* a = gb + (size_t)(active ? rb : rb_end - 1) * dk16 * 128 + lane;    // inactive waves stream a valid block and drop it
+        f32x16 acc0 = {0.f}, acc1 = {0.f}, acc2 = {0.f}, acc3 = {0.f};
+#define FIR_W_LD(KG) ld_nt(a + (size_t)((KG) < klast ? (KG) : klast) * 128)
+#define FIR_W_LDL(KG) ld_nt(a + (size_t)((KG) < klast ? (KG) : klast) * 128 + 64)
+        uint4 h0 = FIR_W_LD(0), l0 = FIR_W_LDL(0), h1 = FIR_W_LD(1), l1 = FIR_W_LDL(1), h2 = FIR_W_LD(2), l2 = FIR_W_LDL(2),
+              h3 = FIR_W_LD(3), l3 = FIR_W_LDL(3), h4 = FIR_W_LD(4), l4 = FIR_W_LDL(4), h5 = FIR_W_LD(5), l5 = FIR_W_LDL(5),
+              h6 = FIR_W_LD(6), l6 = FIR_W_LDL(6), h7 = FIR_W_LD(7), l7 = FIR_W_LDL(7);
+        for (int sl = 0; sl < nslab; ++sl) {
+            const int k0 = sl * kSlabW;
+            const int kw = dk16 - k0 < kSlabW ? dk16 - k0 : kSlabW;        // k-blocks in this slab (a multiple of 4)
+            __syncthreads();                                                // everyone is done with the previous slab
+            for (int i = threadIdx.x; i < 4 * kw * 128; i += blockDim.x) {
+                const int jb = i / (kw * 128), r = i - jb * kw * 128;
+                lqb[(size_t)jb * kSlabW * 128 + r] = qbf[((size_t)jb * dk16 + k0) * 128 + r];
+            }
+            __syncthreads();
+            const uint4* bq = lqb + lane;
+            // query fragments one k-block ahead: blocks 0..3, hi and lo
+            uint4 b0h = bq[0], b0l = bq[64], b1h = bq[kSlabW * 128], b1l = bq[kSlabW * 128 + 64], b2h = bq[2 * kSlabW * 128],
+                  b2l = bq[2 * kSlabW * 128 + 64], b3h = bq[3 * kSlabW * 128], b3l = bq[3 * kSlabW * 128 + 64];
+#define FIR_W_STEP(AH, AL, KB)                                                                                   \
+            {                                                                                                    \
+                const int kn = (KB) + 1 < kw ? (KB) + 1 : (KB);                                                  \
+                const uint4* nq = bq + (size_t)kn * 128;                                                         \
+                const uint4 n0h = nq[0], n0l = nq[64], n1h = nq[kSlabW * 128], n1l = nq[kSlabW * 128 + 64];      \
+                const uint4 n2h = nq[2 * kSlabW * 128], n2l = nq[2 * kSlabW * 128 + 64];                         \
+                const uint4 n3h = nq[3 * kSlabW * 128], n3l = nq[3 * kSlabW * 128 + 64];                         \
+                __builtin_amdgcn_sched_barrier(0);                                                               \
+                const bf16x8 ah = as_bf16x8(AH), al = as_bf16x8(AL);                                             \
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, as_bf16x8(b0h), acc0, 0, 0, 0);               \
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, as_bf16x8(b1h), acc1, 0, 0, 0);               \
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, as_bf16x8(b2h), acc2, 0, 0, 0);               \
+                acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, as_bf16x8(b3h), acc3, 0, 0, 0);               \
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, as_bf16x8(b0l), acc0, 0, 0, 0);               \
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, as_bf16x8(b1l), acc1, 0, 0, 0);               \
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, as_bf16x8(b2l), acc2, 0, 0, 0);               \
+                acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, as_bf16x8(b3l), acc3, 0, 0, 0);               \
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, as_bf16x8(b0h), acc0, 0, 0, 0);               \
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, as_bf16x8(b1h), acc1, 0, 0, 0);               \
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, as_bf16x8(b2h), acc2, 0, 0, 0);               \
+                acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, as_bf16x8(b3h), acc3, 0, 0, 0);               \
+                b0h = n0h; b0l = n0l; b1h = n1h; b1l = n1l; b2h = n2h; b2l = n2l; b3h = n3h; b3l = n3l;          \
+            }
+#define FIR_W_NEXT(AH, AL, OFF)                     \
+            {                                       \
+                AH = FIR_W_LD(k0 + kb + (OFF) + 8); \
+                AL = FIR_W_LDL(k0 + kb + (OFF) + 8);\
+            }
+            for (int kb = 0; kb < kw; kb += 8) {
+                FIR_W_STEP(h0, l0, kb)
+                FIR_W_NEXT(h0, l0, 0)
+                FIR_W_STEP(h1, l1, kb + 1)
+                FIR_W_NEXT(h1, l1, 1)
+                FIR_W_STEP(h2, l2, kb + 2)
+                FIR_W_NEXT(h2, l2, 2)
+                FIR_W_STEP(h3, l3, kb + 3)
+                FIR_W_NEXT(h3, l3, 3)
+                if (kb + 4 < kw) {      // kw is a multiple of 4, not necessarily of 8
+                    FIR_W_STEP(h4, l4, kb + 4)
+                    FIR_W_NEXT(h4, l4, 4)
+                    FIR_W_STEP(h5, l5, kb + 5)
+                    FIR_W_NEXT(h5, l5, 5)
+                    FIR_W_STEP(h6, l6, kb + 6)
+                    FIR_W_NEXT(h6, l6, 6)
+                    FIR_W_STEP(h7, l7, kb + 7)
+                    FIR_W_NEXT(h7, l7, 7)
+                } else {
+                    // a 4-block tail: registers 4..7 hold the NEXT slab's first blocks only if the ring stays aligned, and
+                    // dk16 % 8 == 4 happens in the last slab only, where nothing follows
+                }
+            }
+#undef FIR_W_NEXT
+#undef FIR_W_STEP
+        }
+#undef FIR_W_LD
+#undef FIR_W_LDL
+        if (!active) continue;
+        const int64_t nrow = rb * 32 + (lane & 31);
+        const float gn_lane = nrow < n ? gnorm[nrow] : 0.0f;
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) {
+            const int q = jb * 32 + (lane & 31);
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int roff = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                const int64_t row = rb * 32 + roff;
+                const float gn = __shfl(gn_lane, roff, 64);
+                if (row >= n) continue;
+                const float dot = jb == 0 ? acc0[reg] : jb == 1 ? acc1[reg] : jb == 2 ? acc2[reg] : acc3[reg];
+                const float p = gn - 2.0f * dot;
+                if (p < tau_s[q]) {
+                    const int slot = atomicAdd(&counts[q], 1);
+                    if (slot < kListCap) lists[(size_t)q * kListCap + slot] = fir::key_pack(p, (uint32_t)row);
+                }
+            }
+        }
+    }
+}
+
 // tau[q] = kCand-th smallest sampled proxy, nudged up so that ties with it are appended too. One block per
 // query, ONE pass over the samples: every thread keeps its kCand smallest keys sorted in registers, then kCand
 // rounds of block-min pop the global order statistics.
@@ -671,6 +804,7 @@ struct fir_gemm {
     float* fbq = nullptr;                 // fallback queries (device)
     unsigned long long* fbkeys = nullptr;
     int64_t passes = 0, fallbacks = 0;
+    bool wide = true;                     // bf16: pairs of passes through k_gemm_proxy_bf16_wide (FIR_GEMM_WIDE=0 turns it off)
 };
 
 
@@ -690,6 +824,7 @@ int fir_gemm_create_ex(fir_gallery* g, int32_t precision, fir_gemm** out) {
     if (fir_gallery_view_(g, &m->v) != FIR_OK || fir_gallery_tiled_(g, &gp, &m->dp4) != FIR_OK) { delete m; return gemm_fail(FIR_ERR_ARG, "bad gallery"); }
     m->gal4 = (const float4*)gp;
     m->precision = precision;
+    if (const char* w = std::getenv("FIR_GEMM_WIDE")) m->wide = std::atoi(w) != 0;   // experiments: 0 = one pass per gallery read
     m->dq8 = (m->v.d + 31) / 32 * 4;     // feature groups of 8, padded to a multiple of 4 groups (zeros)
     m->dk16 = (m->v.d + 63) / 64 * 4;    // k-blocks of 16, padded to a multiple of 4
     hipError_t e = hipSetDevice(m->v.device);
@@ -720,6 +855,7 @@ int fir_gemm_create_ex(fir_gallery* g, int32_t precision, fir_gemm** out) {
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy_bf16<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy_bf16<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy_bf16_wide, hipFuncAttributeMaxDynamicSharedMemorySize, kWideLds);
     if (e == hipSuccess && m->v.n > 0) {
         // row norms come from the f32 packer (run on a one-group scratch when only the bf16 fragments are kept)
         if (precision == FIR_GEMM_BF16_SPLIT) {
@@ -814,8 +950,17 @@ int fir_gemm_search_top1_keys_dev(fir_gemm* m, const float* d_queries, int32_t q
             hipLaunchKernelGGL(k_gemm_proxy_bf16<0>, dim3(sample_grid, np), dim3(128), 0, st, m->gb, m->gnorm, m->qbf[b], n, (int64_t)0,
                                (int64_t)sample_rows, m->dk16, m->tau[b], m->lists[b], m->counts[b], m->sample, sample_rows);
             hipLaunchKernelGGL(k_gemm_tau, dim3(np * kQT), dim3(256), 0, st, m->sample, sample_rows, m->tau[b]);
-            hipLaunchKernelGGL(k_gemm_proxy_bf16<1>, dim3(grid, np), dim3(kGemmBlock), lds, st, m->gb, m->gnorm, m->qbf[b], n, (int64_t)0, n,
-                               m->dk16, m->tau[b], m->lists[b], m->counts[b], m->sample, sample_rows);
+            // pairs of passes share one read of the gallery (128 queries per wave); an odd last pass goes alone
+            const int pairs = m->wide ? np / 2 : 0;
+            if (pairs > 0)
+                hipLaunchKernelGGL(k_gemm_proxy_bf16_wide, dim3(grid, pairs), dim3(kGemmBlock), kWideLds, st, m->gb, m->gnorm, m->qbf[b], n, m->dk16,
+                                   m->tau[b], m->lists[b], m->counts[b]);
+            if (np > 2 * pairs) {
+                const size_t p0 = (size_t)2 * pairs;
+                hipLaunchKernelGGL(k_gemm_proxy_bf16<1>, dim3(grid, np - 2 * pairs), dim3(kGemmBlock), lds, st, m->gb, m->gnorm,
+                                   m->qbf[b] + p0 * (kQT / 32) * m->dk16 * 128, n, (int64_t)0, n, m->dk16, m->tau[b] + p0 * kQT,
+                                   m->lists[b] + p0 * kQT * kListCap, m->counts[b] + p0 * kQT, m->sample + p0 * kQT * sample_rows, sample_rows);
+            }
         }
         GEMM_HIP(hipEventRecord(m->main_done[b], st));
         // exact re-rank + certificate of this super-batch on the side stream, under the next one's GEMM
