@@ -246,8 +246,9 @@ int fir_profile_read(fir_gallery* g, float* ms, int32_t cap, int32_t* count, dou
 int fir_gallery_sync(fir_gallery* g);
 
 /* Tunables (for experiments). queries_per_pass: 1, 2, 4, 8 or 16; 0 keeps the current setting, < 0 returns to the
- * automatic choice (8 for galleries streamed from HBM, 16 for galleries that stay resident in the 256 MiB
- * Infinity Cache). waves: waves per gallery pass, 0 = automatic. */
+ * automatic choice: at most 8 for galleries streamed from HBM and 16 for galleries that stay resident in the 256 MiB
+ * Infinity Cache (8 when a 16-query tile would not fit 64 KiB of LDS, d > 1020), halved per call until
+ * tiles x passes gives every SIMD a wave (small galleries, small batches). waves: waves per gallery pass, 0 = automatic. */
 int fir_gallery_set_tuning(fir_gallery* g, int32_t queries_per_pass, int32_t waves);
 int fir_gallery_get_tuning(const fir_gallery* g, int32_t* queries_per_pass, int32_t* waves, int32_t* max_waves);
 
