@@ -69,6 +69,7 @@ struct fir_gallery {
     // pinned, device-visible host staging of the small host-pointer calls: queries go in, packed keys come out, with
     // no copy engine in between (the kernels read / write it over PCIe) and one stream synchronisation per call
     void* pin = nullptr;
+    void* scratch[16] = {};   size_t scratch_cap[16] = {};   // fir_gallery_scratch_ (classifier entry points in the other translation units)
 
     int qpp = 0;              // queries per gallery pass; 0 = automatic (effective_qpp)
     int waves_req = 0;        // 0 = automatic
@@ -363,6 +364,60 @@ int range_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start,
     return FIR_OK;
 }
 
+constexpr int kUSub = 8;      // chunks per load group of k_scan_subranges: sub-ranges are multiples of 32 features
+scan_fn pick_subranges(int qb, int metric) {
+#ifndef FIR_MINIMAL
+#define FIR_SUB(QB, M) if (qb == QB && metric == M) return (scan_fn)k_scan_subranges<QB, M, kUSub, kWps>;
+    FIR_SUB(1, 0) FIR_SUB(2, 0) FIR_SUB(4, 0) FIR_SUB(8, 0)
+    FIR_SUB(1, 1) FIR_SUB(2, 1) FIR_SUB(4, 1) FIR_SUB(8, 1)
+    FIR_SUB(1, 2) FIR_SUB(2, 2) FIR_SUB(4, 2) FIR_SUB(8, 2)
+#undef FIR_SUB
+#endif
+    return nullptr;
+}
+
+int subranges_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start, int32_t end, int32_t step, float* d_out, hipStream_t st) {
+    const int nsub = (end - start) / step;
+    if (step % (4 * kUSub) != 0 || start % 4 != 0) {   // one pass per sub-range (any step)
+        for (int ci = 0; ci < nsub; ++ci) {
+            const int rc = range_dev(g, d_queries, qb, start + ci * step, start + (ci + 1) * step, d_out + (size_t)ci * qb * g->n, st);
+            if (rc) return rc;
+        }
+        return FIR_OK;
+    }
+    int rc = grow(g->qt, g->qt_cap, (size_t)8 * g->dp4 * 4);
+    if (rc) return rc;
+    const int kk = g->dp4 * 4;
+    for (int q0 = 0; q0 < qb; q0 += 8) {
+        const int live = std::min(8, qb - q0);
+        const int qbt = live <= 1 ? 1 : live <= 2 ? 2 : live <= 4 ? 4 : 8;   // kernel tile: the next power of two (extra queries are zero padding)
+        scan_fn fn = pick_subranges(qbt, g->metric);
+        if (!fn) return fail(FIR_ERR_ARG, "no sub-range kernel for qb=%d metric=%d", qbt, g->metric);
+        hipLaunchKernelGGL(k_transpose_queries, dim3((unsigned)(((int64_t)kk * qbt + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
+                           d_queries + (size_t)q0 * g->d, live, g->d, g->dp4, qbt, g->qt, (uint64_t*)nullptr, 0);
+        const int max_waves = max_waves_for(g, fn, 0);
+        ScanArgs a{};
+        a.gal4 = g->gal4;
+        a.qt = g->qt;
+        a.n = g->n;
+        a.tiles = (int32_t)g->tiles;
+        a.dp4 = g->dp4;
+        a.start = start;
+        a.end = end;
+        a.step = step;
+        a.waves = pick_waves(g->tiles, max_waves, g->cus * 4);
+        a.row_offset = g->row_offset;
+        a.out = d_out + (size_t)q0 * g->n;
+        a.out_stride = g->n;
+        a.nq = live;
+        a.k = qb;
+        a.nt = gallery_bytes(g) > kL2ResidentBytes ? 1 : 0;
+        hipLaunchKernelGGL(fn, dim3(a.waves / 4), dim3(kBlock), 0, st, a);
+        FIR_HIP(hipGetLastError());
+    }
+    return FIR_OK;
+}
+
 int set_device(int device) {
     int cnt = 0;
     if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) return fail(FIR_ERR_NODEVICE, "no HIP device visible");
@@ -428,6 +483,29 @@ int fir_gallery_view_(fir_gallery* g, fir_gallery_view* out) {
     out->device = g->device; out->cus = g->cus; out->n = g->n; out->d = g->d; out->row_offset = g->row_offset;
     out->cls = g->cls; out->stream = g->stream;
     return FIR_OK;
+}
+int fir_gallery_scratch_(fir_gallery* g, int slot, size_t bytes, void** out) {
+    if (!g || !out || slot < 0 || slot >= 16) return fail(FIR_ERR_ARG, "bad scratch request");
+    if (bytes > g->scratch_cap[slot]) {
+        if (g->scratch[slot]) FIR_HIP(hipFree(g->scratch[slot]));
+        g->scratch[slot] = nullptr;
+        g->scratch_cap[slot] = 0;
+        const size_t want = std::max<size_t>(bytes + bytes / 4, 4096);
+        FIR_HIP(hipMalloc(&g->scratch[slot], want));
+        g->scratch_cap[slot] = want;
+    }
+    *out = g->scratch[slot];
+    return FIR_OK;
+}
+int fir_subrange_distances_dev_(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start, int32_t end, int32_t step, float* d_out,
+                                void* stream) {
+    if (!g || !d_queries || !d_out) return fail(FIR_ERR_ARG, "NULL argument");
+    if (qb <= 0) return fail(FIR_ERR_ARG, "qb=%d must be positive", qb);
+    if (step <= 0 || start < 0 || end > g->d || start >= end || (end - start) % step != 0)
+        return fail(FIR_ERR_ARG, "sub-ranges of %d features do not tile [%d,%d) inside [0,%d)", step, start, end, g->d);
+    if (g->n == 0) return FIR_OK;
+    FIR_HIP(hipSetDevice(g->device));
+    return subranges_dev(g, d_queries, qb, start, end, step, d_out, stream ? (hipStream_t)stream : g->stream);
 }
 int fir_gallery_tiled_(fir_gallery* g, const void** gal4, int* dp4) {
     if (!g || !gal4 || !dp4) return FIR_ERR_ARG;
@@ -529,6 +607,7 @@ int fir_gallery_destroy(fir_gallery* g) {
     (void)hipFree(g->gal4); (void)hipFree(g->cls); (void)hipFree(g->qt); (void)hipFree(g->dq); (void)hipFree(g->dkeys);
     (void)hipFree(g->part); (void)hipFree(g->dout); (void)hipFree(g->didx);
     if (g->pin) (void)hipHostFree(g->pin);
+    for (void* p : g->scratch) if (p) (void)hipFree(p);
     if (g->stream) (void)hipStreamDestroy(g->stream);
     delete g;
     return FIR_OK;

@@ -18,3 +18,14 @@ struct fir_gallery_view {
 extern "C" int fir_gallery_view_(fir_gallery* g, fir_gallery_view* out);
 extern "C" void fir_set_last_error_(const char* msg);
 extern "C" int fir_gallery_tiled_(fir_gallery* g, const void** gal4, int* dp4);   // the tiled f32 gallery (fir_kernels.h layout)
+
+// Device scratch owned by the gallery handle: `slot` in [0, 16), grown on demand, kept until the gallery is destroyed
+// (the per-call hipMalloc / hipFree pairs of the classifier entry points cost more than their kernels on small galleries).
+// Slots 0-7: fir_twd.hip, 8-11: fir_dem.hip.
+extern "C" int fir_gallery_scratch_(fir_gallery* g, int slot, size_t bytes, void** out);
+
+// d_out[(ci * qb + q) * n + row] = distance(query q, row) over sub-range ci = [start + ci*step, start + (ci+1)*step), for
+// every sub-range of [start, end): ONE gallery pass (k_scan_subranges) when step is a multiple of 32 features, one
+// range-distance pass per sub-range otherwise. Device pointers; asynchronous on `stream`.
+extern "C" int fir_subrange_distances_dev_(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start, int32_t end, int32_t step,
+                                           float* d_out, void* stream);

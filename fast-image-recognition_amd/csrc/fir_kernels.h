@@ -79,6 +79,7 @@ struct ScanArgs {
     int32_t k;            // kEpiTopK
     int64_t qt_stride;    // floats between the query tiles of consecutive blockIdx.y (top-1 kernels)
     int32_t nt;           // non-temporal gallery loads (galleries that do not fit the L2s)
+    int32_t step;         // k_scan_subranges: features per sub-range
 };
 
 template <int QB, int METRIC, int U>
@@ -276,6 +277,40 @@ __global__ void __launch_bounds__(kBlock, WPS) k_scan(const ScanArgs a) {
                         if (lane == 0) a.keys[((size_t)gw * QB + q) * a.k + r2] = kKeyNone;
                     break;
                 }
+            }
+        }
+    }
+}
+
+// All distances of CONSECUTIVE feature sub-ranges in one gallery pass: sub-range ci = [start + ci*step, start + (ci+1)*step),
+// each a fresh sum divided by `step` (the reference's distance(row, cur, cur + delta) of ProposedTWDClassifier,
+// ImageTesting.cpp:243-250, and of the second TWD stage) -- out[(ci * k + q) * out_stride + row], k = queries of the whole
+// call (this launch handles nq of them; `out` already points at its first one). start, end and step are multiples of
+// 4*U features. One read of [start, end) per tile instead of one launch per sub-range.
+template <int QB, int METRIC, int U, int WPS>
+__global__ void __launch_bounds__(kBlock, WPS) k_scan_subranges(const ScanArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    sfloat_p qc = (sfloat_p)(uintptr_t)a.qt;
+    const float fcount = (float)a.step;                               // db_features.cpp:40
+    const int cstep = a.step >> 2;
+    for (int t = gw; t < a.tiles; t += a.waves) {
+        const float4* tile = a.gal4 + (size_t)t * a.dp4 * 64 + lane;
+        const int64_t row = (int64_t)t * kTileRows + lane;
+        int ci = 0;
+        for (int c0 = a.start >> 2; c0 < (a.end >> 2); c0 += cstep, ++ci) {
+            float acc[QB];
+#pragma unroll
+            for (int q = 0; q < QB; ++q) acc[q] = 0.0f;
+            for (int c = c0; c < c0 + cstep; c += U) {
+                float4 g[U];
+                ld_gallery_group<U>(g, tile + (size_t)c * 64, a.nt != 0);
+                TileAcc<QB, METRIC, U>::group(acc, g, qc, c);
+            }
+            if (row < a.n) {
+#pragma unroll
+                for (int q = 0; q < QB; ++q)
+                    if (q < a.nq) a.out[((size_t)ci * a.k + q) * a.out_stride + row] = acc[q] / fcount;
             }
         }
     }

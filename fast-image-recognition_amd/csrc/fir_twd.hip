@@ -25,7 +25,8 @@
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kBatch = 8;          // queries per internal batch (one range-distance pass serves 8)
+constexpr int kBatch = 64;         // queries per internal batch at most: all their scans and decision workgroups are queued
+                                   // before ONE synchronisation (a range-distance pass serves 8 of them)
 constexpr int kLastFeature = 256;  // ImageTesting.cpp:169-171, 226-228
 
 thread_local char g_twd_err[512];
@@ -89,19 +90,42 @@ __global__ void __launch_bounds__(kBlock) k_twd_conv_stage1(const float* __restr
     for (int c = threadIdx.x; c < num_classes; c += kBlock) probabs[c] = 0ull;     // vector<double> probabs(num_of_classes) = 0
     if (threadIdx.x == 0) { carry_s.d = 100000.0; carry_s.i = -1; }                // bestDist = 100000, bestInd = -1 (:110-111)
     __syncthreads();
+    // The rows are taken kSpan = 256 x kPer at a time: loaded coalesced into LDS, then thread t owns the CONTIGUOUS rows
+    // [t*kPer, (t+1)*kPer) of the span, so the reference's scan order holds inside a thread, across the threads and
+    // across spans, with one block-wide scan per span (not per 256 rows). kPer is odd: conflict-free LDS reads.
+    constexpr int kPer = 15, kSpan = kBlock * kPer;
+    __shared__ float sd[kSpan];
+    __shared__ int32_t sc[kSpan];
     int last_change_row = -1;          // last record row whose class differs from the previous record's class
     double second_at_change = 0.0;     // what secondBestDist was set to at that row (:124-125)
-    for (int base = 0; base < n; base += kBlock) {
-        const int row = base + threadIdx.x;
+    for (int base = 0; base < n; base += kSpan) {
+        const int live = min(kSpan, n - base);
+        for (int i = threadIdx.x; i < live; i += kBlock) { sd[i] = d1[base + i]; sc[i] = cls[base + i]; }
+        __syncthreads();
+        const int r0 = min(threadIdx.x * kPer, live), r1 = min(r0 + kPer, live);
+        // pass 1: the segment's first minimum; class posteriors (order independent: a maximum), one LDS atomic per run of
+        // equal labels (galleries are class-major, ImageTesting.cpp:446)
         DI own;
-        own.d = row < n ? (double)d1[row] : __builtin_huge_val();                  // distances[j] (double) (:117)
-        own.i = row;
-        if (type == 0 && row < n) {
-            const double probab = exp(-own.d * 100);                               // DIST_WEIGHT = 100 (:113,119)
-            const int cl = cls[row];
-            if (cl >= 0 && cl < num_classes) atomicMax(&probabs[cl], (unsigned long long)__double_as_longlong(probab));   // :120-121
+        own.d = __builtin_huge_val();
+        own.i = -1;
+        int run_class = -1;
+        double run_max = 0.0;
+        for (int r = r0; r < r1; ++r) {
+            const double d = (double)sd[r];                                         // distances[j] (double) (:117)
+            if (d < own.d) { own.d = d; own.i = base + r; }
+            if (type == 0) {
+                const double probab = exp(-d * 100);                                // DIST_WEIGHT = 100 (:113,119)
+                const int cl = sc[r];
+                if (cl != run_class) {
+                    if (run_class >= 0 && run_class < num_classes) atomicMax(&probabs[run_class], (unsigned long long)__double_as_longlong(run_max));
+                    run_class = cl;
+                    run_max = probab;
+                } else if (run_max < probab) run_max = probab;                      // :120-121
+            }
         }
-        DI inc = own;                                                               // inclusive scan inside the wave
+        if (type == 0 && run_class >= 0 && run_class < num_classes) atomicMax(&probabs[run_class], (unsigned long long)__double_as_longlong(run_max));
+        // exclusive scan of the segment minima, seeded with what the earlier spans left behind
+        DI inc = own;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             const DI o = shfl_up_di(inc, off);
@@ -109,12 +133,22 @@ __global__ void __launch_bounds__(kBlock) k_twd_conv_stage1(const float* __restr
         }
         if (lane == 63) wave_tot[wave] = inc;
         __syncthreads();
-        DI pre = carry_s;                                                           // everything before this wave
+        DI pre = carry_s;
         for (int w = 0; w < wave; ++w) pre = later_wins_if_smaller(pre, wave_tot[w]);
         DI excl = shfl_up_di(inc, 1);
         excl = lane == 0 ? pre : later_wins_if_smaller(pre, excl);
-        if (row < n && own.d < excl.d) {                                            // a new best (:123)
-            if (excl.i != -1 && cls[excl.i] != cls[row]) { last_change_row = row; second_at_change = excl.d; }   // :124-125
+        // pass 2: the reference's loop over this thread's rows, entered with the state the earlier rows left behind
+        if (own.i >= 0 && own.d < excl.d) {      // otherwise no row of this segment sets a record
+            DI cur = excl;
+            int cur_class = cur.i >= 0 ? cls[cur.i] : -1;
+            for (int r = r0; r < r1; ++r) {
+                const double d = (double)sd[r];
+                if (d < cur.d) {                                                     // a new best (:123)
+                    const int cl = sc[r];
+                    if (cur.i != -1 && cur_class != cl) { last_change_row = base + r; second_at_change = cur.d; }   // :124-125
+                    cur.d = d; cur.i = base + r; cur_class = cl;
+                }
+            }
         }
         __syncthreads();
         if (threadIdx.x == kBlock - 1) carry_s = later_wins_if_smaller(pre, inc);
@@ -167,14 +201,16 @@ __global__ void __launch_bounds__(kBlock) k_twd_conv_stage1(const float* __restr
 }
 
 // ---- second stage (ImageTesting.cpp:165-180) for the unreliable queries ----
-// which[u] = query slot inside the batch; dist1[slot][n] first-stage distances, dist2[u][n] over [reduced, 256).
+// One workgroup per query of the batch; the reliable ones (unreliable[slot] == 0) return at once, so the host does not
+// have to look at the first stage's verdicts before queueing this. dist1 / dist2: [slot][n] over [0, reduced) / [reduced, 256).
 __global__ void __launch_bounds__(kBlock) k_twd_conv_stage2(const float* __restrict__ dist1, const float* __restrict__ dist2,
-                                                             const int32_t* __restrict__ which, const int32_t* __restrict__ cls, int n,
+                                                             const int32_t* __restrict__ unreliable, const int32_t* __restrict__ cls, int n,
                                                              int reduced, int32_t* __restrict__ class_out) {
     __shared__ DI red[kBlock / 64];
-    const int u = blockIdx.x, slot = which[u];
+    const int slot = blockIdx.x;
+    if (!unreliable[slot]) return;
     const float* d1 = dist1 + (size_t)slot * n;
-    const float* d2 = dist2 + (size_t)u * n;
+    const float* d2 = dist2 + (size_t)slot * n;
     DI m;
     m.d = 100000.0;      // bestDist = 100000 (:168); only strictly smaller rows qualify
     m.i = -1;
@@ -240,12 +276,21 @@ __global__ void __launch_bounds__(kBlock) k_twd_proposed(const float* __restrict
     }
 }
 
-struct Buf {
+// Queries per internal batch: as many as keep the per-batch distance tables under `budget` bytes (a multiple of 8, <= kBatch).
+int batch_for(int64_t n, size_t bytes_per_query_row, size_t budget = (size_t)512 << 20) {
+    const size_t per_query = (size_t)std::max<int64_t>(n, 1) * bytes_per_query_row;
+    const size_t fit = budget / std::max<size_t>(per_query, 1);
+    return (int)std::max<size_t>(8, std::min<size_t>(kBatch, fit / 8 * 8));
+}
+
+// A slot of the gallery handle's scratch pool (fir_gallery_scratch_): grown on demand, reused by every later call.
+struct Slot {
     void* p = nullptr;
-    ~Buf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, std::max<size_t>(bytes, 16)); }
     template <typename T> T* as() { return (T*)p; }
 };
+#define TWD_SLOT(var, slot, bytes)                                                       \
+    Slot var;                                                                            \
+    if ((rc = fir_gallery_scratch_(g, slot, std::max<size_t>(bytes, 16), &var.p))) return rc
 
 int check_common(fir_gallery* g, const float* queries, int32_t qb, int32_t reduced, fir_gallery_view* v) {
     if (!g || (qb > 0 && !queries)) return twd_fail(FIR_ERR_ARG, "NULL argument");
@@ -274,49 +319,36 @@ int fir_twd_conventional(fir_gallery* g, const float* queries, int32_t qb, int32
     if (qb == 0) return FIR_OK;
     TWD_HIP(hipSetDevice(v.device));
     const int n = (int)v.n;
-    Buf dq, d1, d2, dsub, dcls, dunrel, dwhich;
-    TWD_HIP(dq.alloc((size_t)kBatch * v.d * 4));
-    TWD_HIP(dsub.alloc((size_t)kBatch * v.d * 4));
-    TWD_HIP(d1.alloc((size_t)kBatch * std::max(n, 1) * 4));
-    TWD_HIP(d2.alloc((size_t)kBatch * std::max(n, 1) * 4));
-    TWD_HIP(dcls.alloc(kBatch * 4));
-    TWD_HIP(dunrel.alloc(kBatch * 4));
-    TWD_HIP(dwhich.alloc(kBatch * 4));
-    for (int q0 = 0; q0 < qb; q0 += kBatch) {
-        const int nq = std::min(kBatch, qb - q0);
-        TWD_HIP(hipMemcpyAsync(dq.p, queries + (size_t)q0 * v.d, (size_t)nq * v.d * 4, hipMemcpyHostToDevice, v.stream));
-        int32_t h_cls[kBatch], h_unrel[kBatch];
+    const int batch = std::min(batch_for(n, 8), std::max(8, (qb + 7) / 8 * 8));
+    TWD_SLOT(dq, 0, (size_t)batch * v.d * 4);
+    TWD_SLOT(d1, 1, (size_t)batch * std::max(n, 1) * 4);
+    TWD_SLOT(d2, 2, (size_t)batch * std::max(n, 1) * 4);
+    TWD_SLOT(dres, 3, (size_t)2 * kBatch * 4);                 // class[kBatch], unreliable[kBatch]
+    int32_t* dcls = dres.as<int32_t>();
+    int32_t* dunrel = dcls + kBatch;
+    for (int q0 = 0; q0 < qb; q0 += batch) {
+        const int nq = std::min(batch, qb - q0);
+        int32_t h_res[2 * kBatch];
         if (n == 0) {
-            for (int i = 0; i < nq; ++i) { h_cls[i] = -1; h_unrel[i] = 1; }
+            for (int i = 0; i < nq; ++i) { h_res[i] = -1; h_res[kBatch + i] = 1; }
         } else {
+            // both stages are queued back to back -- the second one decides on the device which queries it concerns -- and
+            // the verdicts come back with ONE copy and ONE synchronisation per batch
+            TWD_HIP(hipMemcpyAsync(dq.p, queries + (size_t)q0 * v.d, (size_t)nq * v.d * 4, hipMemcpyHostToDevice, v.stream));
             if ((rc = fir_range_distances_dev(g, dq.as<float>(), nq, 0, reduced_features_count, d1.as<float>(), v.stream))) return rc;
             hipLaunchKernelGGL(k_twd_conv_stage1, dim3(nq), dim3(kBlock), (size_t)num_classes * 8, v.stream, d1.as<float>(), v.cls, n,
-                               num_classes, type, threshold, dcls.as<int32_t>(), dunrel.as<int32_t>());
+                               num_classes, type, threshold, dcls, dunrel);
             TWD_HIP(hipGetLastError());
-            TWD_HIP(hipMemcpyAsync(h_unrel, dunrel.p, nq * 4, hipMemcpyDeviceToHost, v.stream));
-            TWD_HIP(hipStreamSynchronize(v.stream));
-            int32_t which[kBatch];
-            int nu = 0;
-            for (int i = 0; i < nq; ++i)
-                if (h_unrel[i]) {
-                    which[nu] = i;
-                    TWD_HIP(hipMemcpyAsync(dsub.as<float>() + (size_t)nu * v.d, dq.as<float>() + (size_t)i * v.d, (size_t)v.d * 4,
-                                           hipMemcpyDeviceToDevice, v.stream));
-                    ++nu;
-                }
-            if (nu > 0) {
-                TWD_HIP(hipMemcpyAsync(dwhich.p, which, nu * 4, hipMemcpyHostToDevice, v.stream));
-                if ((rc = fir_range_distances_dev(g, dsub.as<float>(), nu, reduced_features_count, kLastFeature, d2.as<float>(), v.stream))) return rc;
-                hipLaunchKernelGGL(k_twd_conv_stage2, dim3(nu), dim3(kBlock), 0, v.stream, d1.as<float>(), d2.as<float>(), dwhich.as<int32_t>(),
-                                   v.cls, n, reduced_features_count, dcls.as<int32_t>());
-                TWD_HIP(hipGetLastError());
-            }
-            TWD_HIP(hipMemcpyAsync(h_cls, dcls.p, nq * 4, hipMemcpyDeviceToHost, v.stream));
+            if ((rc = fir_range_distances_dev(g, dq.as<float>(), nq, reduced_features_count, kLastFeature, d2.as<float>(), v.stream))) return rc;
+            hipLaunchKernelGGL(k_twd_conv_stage2, dim3(nq), dim3(kBlock), 0, v.stream, d1.as<float>(), d2.as<float>(), dunrel, v.cls, n,
+                               reduced_features_count, dcls);
+            TWD_HIP(hipGetLastError());
+            TWD_HIP(hipMemcpyAsync(h_res, dres.p, sizeof(h_res), hipMemcpyDeviceToHost, v.stream));
             TWD_HIP(hipStreamSynchronize(v.stream));
         }
         for (int i = 0; i < nq; ++i) {
-            class_out[q0 + i] = h_cls[i];
-            if (unreliable_out) unreliable_out[q0 + i] = h_unrel[i];
+            class_out[q0 + i] = h_res[i];
+            if (unreliable_out) unreliable_out[q0 + i] = h_res[kBatch + i];
         }
     }
     return FIR_OK;
@@ -337,31 +369,31 @@ int fir_twd_proposed(fir_gallery* g, const float* queries, int32_t qb, int32_t r
     if (kLastFeature % reduced_features_count != 0)
         return twd_fail(FIR_ERR_ARG, "reduced_features_count=%d must divide %d", reduced_features_count, kLastFeature);
     const int nchunks = kLastFeature / reduced_features_count;
-    Buf dq, cd, acc, alive, dcls, dunrel, dchunks;
-    TWD_HIP(dq.alloc((size_t)kBatch * v.d * 4));
-    TWD_HIP(cd.alloc((size_t)nchunks * kBatch * std::max(n, 1) * 4));
-    TWD_HIP(acc.alloc((size_t)kBatch * std::max(n, 1) * 8));
-    TWD_HIP(alive.alloc((size_t)kBatch * std::max(n, 1)));
-    TWD_HIP(dcls.alloc(kBatch * 4));
-    TWD_HIP(dunrel.alloc(kBatch * 4));
-    TWD_HIP(dchunks.alloc(kBatch * 4));
-    for (int q0 = 0; q0 < qb; q0 += kBatch) {
-        const int nq = std::min(kBatch, qb - q0);
-        int32_t h_cls[kBatch], h_unrel[kBatch], h_chunks[kBatch];
+    const int batch = std::min(batch_for(n, (size_t)nchunks * 4 + 9, (size_t)1 << 30), std::max(8, (qb + 7) / 8 * 8));
+    TWD_SLOT(dq, 0, (size_t)batch * v.d * 4);
+    TWD_SLOT(cd, 4, (size_t)nchunks * batch * std::max(n, 1) * 4);
+    TWD_SLOT(acc, 5, (size_t)batch * std::max(n, 1) * 8);
+    TWD_SLOT(alive, 6, (size_t)batch * std::max(n, 1));
+    TWD_SLOT(dres, 3, (size_t)3 * kBatch * 4);                 // class, unreliable, chunks
+    int32_t* dcls = dres.as<int32_t>();
+    int32_t* dunrel = dcls + kBatch;
+    int32_t* dchunks = dcls + 2 * kBatch;
+    for (int q0 = 0; q0 < qb; q0 += batch) {
+        const int nq = std::min(batch, qb - q0);
+        int32_t h_res[3 * kBatch];
+        int32_t* h_cls = h_res;
+        int32_t* h_unrel = h_res + kBatch;
+        int32_t* h_chunks = h_res + 2 * kBatch;
         if (n == 0) {
             for (int i = 0; i < nq; ++i) { h_cls[i] = -1; h_unrel[i] = 0; h_chunks[i] = 0; }
         } else {
             TWD_HIP(hipMemcpyAsync(dq.p, queries + (size_t)q0 * v.d, (size_t)nq * v.d * 4, hipMemcpyHostToDevice, v.stream));
-            for (int c = 0; c < nchunks; ++c)
-                if ((rc = fir_range_distances_dev(g, dq.as<float>(), nq, c * reduced_features_count, (c + 1) * reduced_features_count,
-                                                  cd.as<float>() + (size_t)c * nq * n, v.stream)))
-                    return rc;
+            // all chunk distances cd[c][slot][n] from ONE pass over features [0, 256)
+            if ((rc = fir_subrange_distances_dev_(g, dq.as<float>(), nq, 0, kLastFeature, reduced_features_count, cd.as<float>(), v.stream))) return rc;
             hipLaunchKernelGGL(k_twd_proposed, dim3(nq), dim3(kBlock), 0, v.stream, cd.as<float>(), nq, nchunks, acc.as<double>(),
-                               alive.as<uint8_t>(), v.cls, n, 1.0 / threshold, dcls.as<int32_t>(), dunrel.as<int32_t>(), dchunks.as<int32_t>());
+                               alive.as<uint8_t>(), v.cls, n, 1.0 / threshold, dcls, dunrel, dchunks);
             TWD_HIP(hipGetLastError());
-            TWD_HIP(hipMemcpyAsync(h_cls, dcls.p, nq * 4, hipMemcpyDeviceToHost, v.stream));
-            TWD_HIP(hipMemcpyAsync(h_unrel, dunrel.p, nq * 4, hipMemcpyDeviceToHost, v.stream));
-            TWD_HIP(hipMemcpyAsync(h_chunks, dchunks.p, nq * 4, hipMemcpyDeviceToHost, v.stream));
+            TWD_HIP(hipMemcpyAsync(h_res, dres.p, sizeof(h_res), hipMemcpyDeviceToHost, v.stream));
             TWD_HIP(hipStreamSynchronize(v.stream));
         }
         for (int i = 0; i < nq; ++i) {

@@ -67,6 +67,8 @@ def main():
         if d >= 256 and n <= 100_000:
             print(f"{tag:>16s} {'twd_conventional(post), 1 query':34s} {timed(one(lambda v: g.twd_conventional(v, 101, 0, 0.24, 64)), reps):9.1f}")
             print(f"{tag:>16s} {'twd_proposed(32), 1 query':34s} {timed(one(lambda v: g.twd_proposed(v, 32, 0.7)), reps):9.1f}")
+            print(f"{tag:>16s} {'twd_conventional(post), 64 queries':34s} {timed(lambda: g.twd_conventional(q, 101, 0, 0.24, 64), max(reps // 8, 5)):9.1f}")
+            print(f"{tag:>16s} {'twd_proposed(32), 64 queries':34s} {timed(lambda: g.twd_proposed(q, 32, 0.7), max(reps // 8, 5)):9.1f}")
         g.close()
     # classification.cpp side at its own scale: 3030 x 256 float64
     n, d = 3030, 256
