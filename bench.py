@@ -32,7 +32,6 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import __graft_entry__ as ge  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 achievable)
 CHUNK_ROWS = 15625      # generation granule: 64 chunks make the 1M-row gallery, any 1/2/4/8 sharding is whole chunks
 
 
@@ -190,6 +189,7 @@ def main():
         launches_per_step = len(kernel_ms) / max(args.steps, 1)
         avg_ms = float(np.mean(kernel_ms)) if len(kernel_ms) else float("nan")
         achieved = bytes_alg / (avg_ms * 1e-3) / 1e9 if len(kernel_ms) else float("nan")
+        peak_gbs = fir.device_peak_hbm_gbs(local_rank)            # 8000: MI355X_MICROARCH.md
         out = {
             "metric": "query-vectors/sec brute-force L2 top-1, 1Mx512 gallery",
             "value": qb * args.steps / elapsed,
@@ -217,9 +217,9 @@ def main():
             "roofline": {
                 "bound": "hbm",
                 "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
+                "peak": peak_gbs,
                 "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
+                "frac": achieved / peak_gbs,
                 "traffic": pmc_traffic(n, d, world),
                 "kernel": "fir::k_scan_l2_lds<1,8,4>" if tuning["queries_per_pass"] == 8 else "fir::k_scan*",
                 "kernel_avg_ms": avg_ms,

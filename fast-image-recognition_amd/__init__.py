@@ -19,6 +19,7 @@ from .capi import (  # noqa: F401
     METRIC_L2,
     device_count,
     device_info,
+    device_peak_hbm_gbs,
     feature_distance,
     key_pack,
     keys_unpack,

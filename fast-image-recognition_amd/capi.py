@@ -32,6 +32,7 @@ SYMBOLS = [
     ("fir_version", C.c_int, []),
     ("fir_device_count", C.c_int, []),
     ("fir_device_info", C.c_int, [C.c_int32, C.c_char_p, C.c_int32, _i32p, _i64p]),
+    ("fir_device_peak_hbm_gbs", C.c_int, [C.c_int32, C.POINTER(C.c_double)]),
     ("fir_gallery_create", C.c_int, [_vp, C.c_int64, C.c_int32, _vp, C.c_int32, C.c_int32, C.POINTER(_vp)]),
     ("fir_gallery_create_dev", C.c_int, [_vp, C.c_int64, C.c_int32, _vp, C.c_int32, C.c_int32, _vp, C.POINTER(_vp)]),
     ("fir_gallery_destroy", C.c_int, [_vp]),
@@ -122,6 +123,12 @@ def device_info(device=0):
     hbm = C.c_int64()
     _check(lib().fir_device_info(device, name, 64, C.byref(cus), C.byref(hbm)))
     return {"arch": name.value.decode(), "cus": cus.value, "hbm_bytes": hbm.value}
+
+
+def device_peak_hbm_gbs(device=0):
+    v = C.c_double()
+    _check(lib().fir_device_peak_hbm_gbs(device, C.byref(v)))
+    return v.value
 
 
 def feature_distance(lhs, rhs, start=0, end=None, metric=METRIC_L2, device=0):

@@ -538,6 +538,18 @@ int fir_device_info(int32_t device, char* name, int32_t cap, int32_t* cus, int64
     return FIR_OK;
 }
 
+int fir_device_peak_hbm_gbs(int32_t device, double* gbs) {
+    int cnt = 0;
+    if (!gbs) return fail(FIR_ERR_ARG, "gbs is NULL");
+    if (hipGetDeviceCount(&cnt) != hipSuccess || device < 0 || device >= cnt)
+        return fail(FIR_ERR_NODEVICE, "device %d not available", device);
+    hipDeviceProp_t prop;
+    FIR_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return fail(FIR_ERR_NODEVICE, "device %d is %s, not gfx950", device, prop.gcnArchName);
+    *gbs = 8000.0;   // MI350X / MI355X: 8 stacks of HBM3E, 8 TB/s (the runtime's clock x bus-width fields do not give this)
+    return FIR_OK;
+}
+
 int fir_gallery_create(const float* rows, int64_t n, int32_t d, const int32_t* class_no, int32_t metric, int32_t device,
                        fir_gallery** out) {
     if (n > 0 && !rows) return fail(FIR_ERR_ARG, "rows is NULL");

@@ -59,6 +59,8 @@ int fir_version(void);
 int fir_device_count(void);
 /* name[cap] <- gcnArchName; *cus, *hbm_bytes as reported by the runtime. */
 int fir_device_info(int32_t device, char* name, int32_t cap, int32_t* cus, int64_t* hbm_bytes);
+/* Spec peak HBM bandwidth in GB/s (the denominator of the roofline report): 8000 on gfx950 (MI350X / MI355X). */
+int fir_device_peak_hbm_gbs(int32_t device, double* gbs);
 
 /* ---- gallery ------------------------------------------------------------------------------
  * Replaces the `std::vector<ImageInfo>` gallery that Classifier::train (ImageTesting.cpp:40)
