@@ -156,14 +156,15 @@ __device__ int block_sum(int v, int* red) {
     return r;
 }
 
-// One workgroup per query. Dynamic LDS: C floats (outputs) + C bytes (classes_to_check).
+// One workgroup per query. Dynamic LDS: C floats (outputs) + nsub x C floats (terms of nsub features) + C bytes (classes_to_check).
 template <bool SEQ>
 __global__ void __launch_bounds__(kBlock) k_fpnn_predict(const double* __restrict__ at, int d, int C, int J, const double* __restrict__ trig,
-                                                         float output_ratio, int32_t* __restrict__ best_class, float* __restrict__ outputs_out,
-                                                         int32_t* __restrict__ chunks_out) {
+                                                         float output_ratio, int nsub, int32_t* __restrict__ best_class,
+                                                         float* __restrict__ outputs_out, int32_t* __restrict__ chunks_out) {
     extern __shared__ unsigned char smem[];
     float* outputs = (float*)smem;
-    unsigned char* alive = smem + (size_t)C * sizeof(float);
+    float* lg = outputs + C;                                  // nsub x C fast-log terms
+    unsigned char* alive = smem + (size_t)(1 + nsub) * C * sizeof(float);
     __shared__ BestF redb[kBlock / 64];
     __shared__ int redi[kBlock / 64];
     const int q = blockIdx.x;
@@ -175,21 +176,32 @@ __global__ void __launch_bounds__(kBlock) k_fpnn_predict(const double* __restric
     for (int cur = 0; cur < d; cur += SEQ ? kChunk : d) {
         const int max_fi = SEQ ? min(cur + kChunk, d) : d;
         ++chunks;
-        for (int c = threadIdx.x; c < C; c += kBlock) {
-            if (!alive[c]) continue;                          // :758 (never false in the exhaustive form)
-            float out = outputs[c];
-            for (int f = cur; f < max_fi; ++f) {
+        // The (feature, class) terms are independent; only their float sum per class is ordered. `nsub` features at a
+        // time: every thread computes terms (consecutive threads = consecutive classes: coalesced model reads, many loads
+        // in flight), then one thread per class adds that class's terms in feature order.
+        for (int f0 = cur; f0 < max_fi; f0 += nsub) {
+            const int nf = min(nsub, max_fi - f0);
+            for (int it = threadIdx.x; it < nf * C; it += kBlock) {
+                const int fl = it / C, c = it - fl * C;
+                if (!alive[c]) continue;                      // :758 (never false in the exhaustive form)
+                const int f = f0 + fl;
                 const double* __restrict__ cv = trig + ((int64_t)q * d + f) * 2 * J;
                 const double* __restrict__ sv = cv + J;
                 const double* __restrict__ m = at + (int64_t)f * K * C + c;
                 double probab = m[0];
                 for (int j = 0; j < J; ++j)
                     probab += (m[(int64_t)(2 * j + 1) * C] * cv[j] + m[(int64_t)(2 * j + 2) * C] * sv[j]);   // :719 / :763
-                out += fasterlog2((float)probab);             // :722 / :765
+                lg[it] = fasterlog2((float)probab);
             }
-            outputs[c] = out;
+            __syncthreads();
+            for (int c = threadIdx.x; c < C; c += kBlock) {
+                if (!alive[c]) continue;
+                float out = outputs[c];
+                for (int fl = 0; fl < nf; ++fl) out += lg[fl * C + c];   // :722 / :765
+                outputs[c] = out;
+            }
+            __syncthreads();
         }
-        __syncthreads();
         // first maximum among the classes still checked, strict '<' from -FLT_MAX (:726-733 / :770-776)
         float bv = -FLT_MAX;
         int bi = -1;
@@ -239,36 +251,42 @@ struct fir_fpnn {
     int d = 0, C = 0, J = 0;
     double scale = 1.0;
     hipStream_t stream = nullptr;
-    Buf at, avg, sd, q, trig, best, outs, chunks;
+    Buf at, avg, sd, trig;
+    void* pin = nullptr;        // pinned staging: queries in, outputs / classes / chunk counts out
 };
 
 namespace {
+// Queries go in and verdicts come out through pinned, device-visible host memory: the kernels read / write it directly,
+// so a call is two launches and ONE synchronisation per batch, with no copy engine in between.
 int predict_common(fir_fpnn* h, const double* queries, int32_t qb, bool seq, float output_ratio, int32_t* best_class, float* outputs,
                    int32_t* chunks_out) {
     if (!h || (qb > 0 && (!queries || !best_class))) return fpnn_fail(FIR_ERR_ARG, "NULL argument");
     if (qb < 0) return fpnn_fail(FIR_ERR_ARG, "qb < 0");
     FPNN_HIP(hipSetDevice(h->device));
-    const size_t lds = (size_t)h->C * 5;
+    const int nsub = (int)std::max<size_t>(1, std::min<size_t>(kChunk, (60 * 1024 - (size_t)h->C * 5) / ((size_t)h->C * 4)));
+    const size_t lds = (size_t)h->C * 5 + (size_t)nsub * h->C * 4;
+    double* pq = (double*)h->pin;
+    float* pouts = (float*)(pq + (size_t)kPredBatch * h->d);
+    int32_t* pbest = (int32_t*)(pouts + (size_t)kPredBatch * h->C);
+    int32_t* pchunks = pbest + kPredBatch;
     for (int q0 = 0; q0 < qb; q0 += kPredBatch) {
         const int nq = std::min(kPredBatch, qb - q0);
-        FPNN_HIP(hipMemcpyAsync(h->q.p, queries + (size_t)q0 * h->d, (size_t)nq * h->d * 8, hipMemcpyHostToDevice, h->stream));
+        std::memcpy(pq, queries + (size_t)q0 * h->d, (size_t)nq * h->d * 8);
         const int64_t nt = (int64_t)nq * h->d;
-        hipLaunchKernelGGL(k_fpnn_trig, dim3((unsigned)((nt + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, h->q.as<double>(), nq, h->d, h->J,
+        hipLaunchKernelGGL(k_fpnn_trig, dim3((unsigned)((nt + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, pq, nq, h->d, h->J,
                            h->avg.as<double>(), h->sd.as<double>(), h->scale, h->trig.as<double>());
         FPNN_HIP(hipGetLastError());
         if (seq)
             hipLaunchKernelGGL(k_fpnn_predict<true>, dim3(nq), dim3(kBlock), lds, h->stream, h->at.as<double>(), h->d, h->C, h->J,
-                               h->trig.as<double>(), output_ratio, h->best.as<int32_t>(), outputs ? h->outs.as<float>() : nullptr,
-                               h->chunks.as<int32_t>());
+                               h->trig.as<double>(), output_ratio, nsub, pbest, outputs ? pouts : nullptr, pchunks);
         else
             hipLaunchKernelGGL(k_fpnn_predict<false>, dim3(nq), dim3(kBlock), lds, h->stream, h->at.as<double>(), h->d, h->C, h->J,
-                               h->trig.as<double>(), output_ratio, h->best.as<int32_t>(), outputs ? h->outs.as<float>() : nullptr,
-                               h->chunks.as<int32_t>());
+                               h->trig.as<double>(), output_ratio, nsub, pbest, outputs ? pouts : nullptr, pchunks);
         FPNN_HIP(hipGetLastError());
-        FPNN_HIP(hipMemcpyAsync(best_class + q0, h->best.p, (size_t)nq * 4, hipMemcpyDeviceToHost, h->stream));
-        if (outputs) FPNN_HIP(hipMemcpyAsync(outputs + (size_t)q0 * h->C, h->outs.p, (size_t)nq * h->C * 4, hipMemcpyDeviceToHost, h->stream));
-        if (chunks_out) FPNN_HIP(hipMemcpyAsync(chunks_out + q0, h->chunks.p, (size_t)nq * 4, hipMemcpyDeviceToHost, h->stream));
         FPNN_HIP(hipStreamSynchronize(h->stream));
+        std::memcpy(best_class + q0, pbest, (size_t)nq * 4);
+        if (outputs) std::memcpy(outputs + (size_t)q0 * h->C, pouts, (size_t)nq * h->C * 4);
+        if (chunks_out) std::memcpy(chunks_out + q0, pchunks, (size_t)nq * 4);
     }
     return FIR_OK;
 }
@@ -283,7 +301,7 @@ int fir_fpnn_train(const double* train_rows, int64_t nt, int32_t d, const int32_
     if (nt <= 0 || d <= 0 || num_classes <= 0 || !train_rows || !train_class || !avg || !sd)
         return fpnn_fail(FIR_ERR_ARG, "bad arguments (nt=%lld d=%d classes=%d)", (long long)nt, d, num_classes);
     if (nt >= ((int64_t)1 << 31) - 64) return fpnn_fail(FIR_ERR_ARG, "nt too large");
-    if ((size_t)num_classes * 5 > 60 * 1024) return fpnn_fail(FIR_ERR_ARG, "num_classes=%d exceeds the LDS score table (12288)", num_classes);
+    if ((size_t)num_classes * 9 > 60 * 1024) return fpnn_fail(FIR_ERR_ARG, "num_classes=%d exceeds the LDS score table (6826)", num_classes);
     std::vector<int32_t> off((size_t)num_classes + 1, 0);
     for (int64_t t = 0; t < nt; ++t) {
         const int32_t cl = train_class[t];
@@ -313,11 +331,8 @@ int fir_fpnn_train(const double* train_rows, int64_t nt, int32_t d, const int32_
     FPNN_HIP(h->at.alloc((size_t)d * K * num_classes * 8));
     FPNN_HIP(h->avg.alloc((size_t)d * 8));
     FPNN_HIP(h->sd.alloc((size_t)d * 8));
-    FPNN_HIP(h->q.alloc((size_t)kPredBatch * d * 8));
     FPNN_HIP(h->trig.alloc((size_t)kPredBatch * d * 2 * J * 8));
-    FPNN_HIP(h->best.alloc((size_t)kPredBatch * 4));
-    FPNN_HIP(h->chunks.alloc((size_t)kPredBatch * 4));
-    FPNN_HIP(h->outs.alloc((size_t)kPredBatch * num_classes * 4));
+    FPNN_HIP(hipHostMalloc(&h->pin, (size_t)kPredBatch * ((size_t)d * 8 + (size_t)num_classes * 4 + 8), hipHostMallocDefault));
     Buf drows, doff;
     FPNN_HIP(drows.alloc((size_t)nt * d * 8));
     FPNN_HIP(doff.alloc(off.size() * 4));
@@ -339,6 +354,7 @@ int fir_fpnn_destroy(fir_fpnn* h) {
     if (!h) return FIR_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->pin) (void)hipHostFree(h->pin);
     delete h;
     return FIR_OK;
 }
