@@ -43,6 +43,26 @@ def test_matches_oracle_on_fresh_data(fir, oracle, seed, n, ncls):
             assert list(k) == [e[2] for e in exp], (fc, th)
 
 
+@pytest.mark.parametrize("n,ncls,class_major", [(3840, 12, True), (3841, 12, False), (20000, 40, True), (11521, 7, False)])
+def test_span_boundaries_and_class_major_galleries(fir, oracle, n, ncls, class_major):
+    """The first-stage kernel takes the rows 3840 at a time and folds runs of equal labels before touching the class
+    posteriors: galleries of exactly one span, one row more, several spans; labels class-major (the reference's
+    order, ImageTesting.cpp:446) and interleaved."""
+    rows, cls, q, _ = gc.twd_case(seed=21 + n % 7, n=n, d=256, n_classes=ncls)
+    if class_major:
+        cls = np.sort(cls)
+    q = q[:6]
+    with fir.Gallery(rows, cls, gc.L2, 0) as g:
+        for (typ, th) in gc.TWD_CONVENTIONAL:
+            c, u = g.twd_conventional(q, ncls, typ, th, 64)
+            exp = [oracle.twd_conventional(rows, cls, qi, ncls, typ, th, 64) for qi in q]
+            assert list(c) == [e[0] for e in exp] and list(u) == [e[1] for e in exp], (typ, th)
+        for (fc, th) in gc.TWD_PROPOSED:
+            c, u, k = g.twd_proposed(q, fc, th)
+            exp = [oracle.twd_proposed(rows, cls, qi, fc, th) for qi in q]
+            assert list(c) == [e[0] for e in exp] and list(u) == [e[1] for e in exp] and list(k) == [e[2] for e in exp], (fc, th)
+
+
 def test_second_best_is_order_dependent(fir, oracle):
     """secondBestDist follows the scan order (ImageTesting.cpp:123-125), not 'best of the other classes':
     rows are arranged so that the two differ."""
