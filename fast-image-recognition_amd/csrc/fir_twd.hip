@@ -77,82 +77,129 @@ __device__ DI block_argmin(DI v, DI* red /* [kBlock/64] in LDS */) {
 
 // ---- ConventionalTWDClassifier, first stage + reliability test (ImageTesting.cpp:108-164) ----
 // dist1[q][n]: distances over [0, reduced_features_count). Dynamic LDS: num_classes doubles.
+//
+// MODE kS1Single: one workgroup per query does everything (galleries up to a few thousand rows: one launch).
+// Larger galleries split the rows of a query over gridDim.x workgroups, in three launches:
+//   kS1Part     each workgroup: first minimum of its row segment -> part[q][b]; class posteriors into gprob[q][C]
+//               (a maximum: order independent; 64-bit atomic max on the bit pattern of a non-negative double)
+//   kS1Records  each workgroup: the state the earlier segments leave behind = fold of part[q][0..b), then the
+//               reference's record walk over its own rows -> chg[q][b] = last class-changing record and the
+//               secondBestDist it set
+//   kS1Final    one workgroup per query: best row = fold of all segments, secondBestDist = the LAST segment's change,
+//               top-5 posteriors, the reliability test, the outputs
+enum { kS1Single = 0, kS1Part = 1, kS1Records = 2, kS1Final = 3 };
+struct S1Chg {
+    int row;
+    int pad;
+    double second;
+};
+constexpr int kPer = 15, kSpan = kBlock * kPer;     // rows per block-wide scan; kPer odd: conflict-free LDS reads
+
+template <int MODE>
 __global__ void __launch_bounds__(kBlock) k_twd_conv_stage1(const float* __restrict__ dist1, const int32_t* __restrict__ cls, int n,
                                                              int num_classes, int type, double threshold, int32_t* __restrict__ class_out,
-                                                             int32_t* __restrict__ unreliable_out) {
+                                                             int32_t* __restrict__ unreliable_out, DI* __restrict__ part,
+                                                             S1Chg* __restrict__ chg, unsigned long long* __restrict__ gprob, int seg_rows) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long probabs[];   // bit patterns of non-negative doubles
     __shared__ DI wave_tot[kBlock / 64];
     __shared__ DI red[kBlock / 64];
     __shared__ DI carry_s;
-    const int q = blockIdx.x;
-    const float* d1 = dist1 + (size_t)q * n;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int c = threadIdx.x; c < num_classes; c += kBlock) probabs[c] = 0ull;     // vector<double> probabs(num_of_classes) = 0
-    if (threadIdx.x == 0) { carry_s.d = 100000.0; carry_s.i = -1; }                // bestDist = 100000, bestInd = -1 (:110-111)
-    __syncthreads();
-    // The rows are taken kSpan = 256 x kPer at a time: loaded coalesced into LDS, then thread t owns the CONTIGUOUS rows
-    // [t*kPer, (t+1)*kPer) of the span, so the reference's scan order holds inside a thread, across the threads and
-    // across spans, with one block-wide scan per span (not per 256 rows). kPer is odd: conflict-free LDS reads.
-    constexpr int kPer = 15, kSpan = kBlock * kPer;
     __shared__ float sd[kSpan];
     __shared__ int32_t sc[kSpan];
+    const int q = MODE == kS1Single || MODE == kS1Final ? blockIdx.x : blockIdx.y;
+    const int nseg = MODE == kS1Single ? 1 : (n + seg_rows - 1) / seg_rows;
+    const int b = MODE == kS1Part || MODE == kS1Records ? blockIdx.x : 0;
+    const float* d1 = dist1 + (size_t)q * n;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool with_prob = type == 0 && (MODE == kS1Single || MODE == kS1Part || MODE == kS1Final);
+    if (with_prob)
+        for (int c = threadIdx.x; c < num_classes; c += kBlock)
+            probabs[c] = MODE == kS1Final ? gprob[(size_t)q * num_classes + c] : 0ull;     // vector<double> probabs(num_of_classes) = 0
+    // rows of this workgroup and the state the rows before them leave behind
+    const int row_begin = MODE == kS1Single ? 0 : b * seg_rows;
+    const int row_end = MODE == kS1Single ? n : min(n, row_begin + seg_rows);
+    if (threadIdx.x == 0) {
+        DI in;
+        in.d = 100000.0;                                                            // bestDist = 100000, bestInd = -1 (:110-111)
+        in.i = -1;
+        if (MODE == kS1Records)
+            for (int k = 0; k < b; ++k) in = later_wins_if_smaller(in, part[(size_t)q * nseg + k]);
+        if (MODE == kS1Final)
+            for (int k = 0; k < nseg; ++k) in = later_wins_if_smaller(in, part[(size_t)q * nseg + k]);
+        carry_s = in;
+    }
+    __syncthreads();
     int last_change_row = -1;          // last record row whose class differs from the previous record's class
     double second_at_change = 0.0;     // what secondBestDist was set to at that row (:124-125)
-    for (int base = 0; base < n; base += kSpan) {
-        const int live = min(kSpan, n - base);
-        for (int i = threadIdx.x; i < live; i += kBlock) { sd[i] = d1[base + i]; sc[i] = cls[base + i]; }
-        __syncthreads();
-        const int r0 = min(threadIdx.x * kPer, live), r1 = min(r0 + kPer, live);
-        // pass 1: the segment's first minimum; class posteriors (order independent: a maximum), one LDS atomic per run of
-        // equal labels (galleries are class-major, ImageTesting.cpp:446)
-        DI own;
-        own.d = __builtin_huge_val();
-        own.i = -1;
-        int run_class = -1;
-        double run_max = 0.0;
-        for (int r = r0; r < r1; ++r) {
-            const double d = (double)sd[r];                                         // distances[j] (double) (:117)
-            if (d < own.d) { own.d = d; own.i = base + r; }
-            if (type == 0) {
-                const double probab = exp(-d * 100);                                // DIST_WEIGHT = 100 (:113,119)
-                const int cl = sc[r];
-                if (cl != run_class) {
-                    if (run_class >= 0 && run_class < num_classes) atomicMax(&probabs[run_class], (unsigned long long)__double_as_longlong(run_max));
-                    run_class = cl;
-                    run_max = probab;
-                } else if (run_max < probab) run_max = probab;                      // :120-121
-            }
-        }
-        if (type == 0 && run_class >= 0 && run_class < num_classes) atomicMax(&probabs[run_class], (unsigned long long)__double_as_longlong(run_max));
-        // exclusive scan of the segment minima, seeded with what the earlier spans left behind
-        DI inc = own;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const DI o = shfl_up_di(inc, off);
-            if (lane >= off) inc = later_wins_if_smaller(o, inc);
-        }
-        if (lane == 63) wave_tot[wave] = inc;
-        __syncthreads();
-        DI pre = carry_s;
-        for (int w = 0; w < wave; ++w) pre = later_wins_if_smaller(pre, wave_tot[w]);
-        DI excl = shfl_up_di(inc, 1);
-        excl = lane == 0 ? pre : later_wins_if_smaller(pre, excl);
-        // pass 2: the reference's loop over this thread's rows, entered with the state the earlier rows left behind
-        if (own.i >= 0 && own.d < excl.d) {      // otherwise no row of this segment sets a record
-            DI cur = excl;
-            int cur_class = cur.i >= 0 ? cls[cur.i] : -1;
+    if (MODE != kS1Final) {
+        // The rows are taken kSpan at a time: loaded coalesced into LDS, then thread t owns the CONTIGUOUS rows
+        // [t*kPer, (t+1)*kPer) of the span, so the reference's scan order holds inside a thread, across the threads and
+        // across spans, with one block-wide scan per span (not per 256 rows).
+        for (int base = row_begin; base < row_end; base += kSpan) {
+            const int live = min(kSpan, row_end - base);
+            for (int i = threadIdx.x; i < live; i += kBlock) { sd[i] = d1[base + i]; sc[i] = cls[base + i]; }
+            __syncthreads();
+            const int r0 = min(threadIdx.x * kPer, live), r1 = min(r0 + kPer, live);
+            // pass 1: the segment's first minimum; class posteriors, one LDS atomic per run of equal labels (galleries
+            // are class-major, ImageTesting.cpp:446)
+            DI own;
+            own.d = __builtin_huge_val();
+            own.i = -1;
+            int run_class = -1;
+            double run_max = 0.0;
             for (int r = r0; r < r1; ++r) {
-                const double d = (double)sd[r];
-                if (d < cur.d) {                                                     // a new best (:123)
+                const double d = (double)sd[r];                                     // distances[j] (double) (:117)
+                if (d < own.d) { own.d = d; own.i = base + r; }
+                if (with_prob) {
+                    const double probab = exp(-d * 100);                            // DIST_WEIGHT = 100 (:113,119)
                     const int cl = sc[r];
-                    if (cur.i != -1 && cur_class != cl) { last_change_row = base + r; second_at_change = cur.d; }   // :124-125
-                    cur.d = d; cur.i = base + r; cur_class = cl;
+                    if (cl != run_class) {
+                        if (run_class >= 0 && run_class < num_classes) atomicMax(&probabs[run_class], (unsigned long long)__double_as_longlong(run_max));
+                        run_class = cl;
+                        run_max = probab;
+                    } else if (run_max < probab) run_max = probab;                  // :120-121
                 }
             }
+            if (with_prob && run_class >= 0 && run_class < num_classes) atomicMax(&probabs[run_class], (unsigned long long)__double_as_longlong(run_max));
+            // exclusive scan of the thread minima, seeded with what the earlier rows left behind
+            DI inc = own;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const DI o = shfl_up_di(inc, off);
+                if (lane >= off) inc = later_wins_if_smaller(o, inc);
+            }
+            if (lane == 63) wave_tot[wave] = inc;
+            __syncthreads();
+            DI pre = carry_s;
+            for (int w = 0; w < wave; ++w) pre = later_wins_if_smaller(pre, wave_tot[w]);
+            DI excl = shfl_up_di(inc, 1);
+            excl = lane == 0 ? pre : later_wins_if_smaller(pre, excl);
+            // pass 2: the reference's loop over this thread's rows, entered with the state the earlier rows left behind
+            if (MODE != kS1Part && own.i >= 0 && own.d < excl.d) {      // otherwise no row of this thread sets a record
+                DI cur = excl;
+                int cur_class = cur.i >= 0 ? cls[cur.i] : -1;
+                for (int r = r0; r < r1; ++r) {
+                    const double d = (double)sd[r];
+                    if (d < cur.d) {                                                 // a new best (:123)
+                        const int cl = sc[r];
+                        if (cur.i != -1 && cur_class != cl) { last_change_row = base + r; second_at_change = cur.d; }   // :124-125
+                        cur.d = d; cur.i = base + r; cur_class = cl;
+                    }
+                }
+            }
+            __syncthreads();
+            if (threadIdx.x == kBlock - 1) carry_s = later_wins_if_smaller(pre, inc);
+            __syncthreads();
         }
-        __syncthreads();
-        if (threadIdx.x == kBlock - 1) carry_s = later_wins_if_smaller(pre, inc);
-        __syncthreads();
+    }
+    if (MODE == kS1Part) {
+        // this segment's own first minimum (the seed (100000, -1) wins over rows that are not below it, like the reference's
+        // initial state does) and its share of the class posteriors
+        if (threadIdx.x == 0) part[(size_t)q * nseg + b] = carry_s;
+        if (with_prob)
+            for (int c = threadIdx.x; c < num_classes; c += kBlock)
+                if (probabs[c]) atomicMax(&gprob[(size_t)q * num_classes + c], probabs[c]);
+        return;
     }
     const DI best = carry_s;
     DI lc;
@@ -161,9 +208,18 @@ __global__ void __launch_bounds__(kBlock) k_twd_conv_stage1(const float* __restr
     const DI lcw = block_argmin(lc, red);
     // the thread that owns the winning row publishes its value
     __shared__ double second_s;
-    if (threadIdx.x == 0) second_s = 100000.0;                                      // secondBestDist = 100000 (:111)
+    __shared__ int second_row_s;
+    if (threadIdx.x == 0) { second_s = 100000.0; second_row_s = -1; }               // secondBestDist = 100000 (:111)
     __syncthreads();
-    if (lcw.i >= 0 && last_change_row == lcw.i) second_s = second_at_change;
+    if (lcw.i >= 0 && last_change_row == lcw.i) { second_s = second_at_change; second_row_s = lcw.i; }
+    __syncthreads();
+    if (MODE == kS1Records) {
+        if (threadIdx.x == 0) { chg[(size_t)q * nseg + b].row = second_row_s; chg[(size_t)q * nseg + b].second = second_s; }
+        return;
+    }
+    if (MODE == kS1Final && threadIdx.x == 0)
+        for (int k = nseg - 1; k >= 0; --k)
+            if (chg[(size_t)q * nseg + k].row >= 0) { second_s = chg[(size_t)q * nseg + k].second; break; }
     __syncthreads();
     const double secondBest = second_s;
 
@@ -201,26 +257,47 @@ __global__ void __launch_bounds__(kBlock) k_twd_conv_stage1(const float* __restr
 }
 
 // ---- second stage (ImageTesting.cpp:165-180) for the unreliable queries ----
-// One workgroup per query of the batch; the reliable ones (unreliable[slot] == 0) return at once, so the host does not
-// have to look at the first stage's verdicts before queueing this. dist1 / dist2: [slot][n] over [0, reduced) / [reduced, 256).
+// The reliable queries (unreliable[slot] == 0) return at once, so the host does not have to look at the first stage's
+// verdicts before queueing this. dist1 / dist2: [slot][n] over [0, reduced) / [reduced, 256).
+// PARTS = false: one workgroup per query. PARTS = true: gridDim.x workgroups per query (blockIdx.y) leave their segment's
+// best (value, row) in part[q][b]; k_twd_conv_stage2_final folds them.
+template <bool PARTS>
 __global__ void __launch_bounds__(kBlock) k_twd_conv_stage2(const float* __restrict__ dist1, const float* __restrict__ dist2,
                                                              const int32_t* __restrict__ unreliable, const int32_t* __restrict__ cls, int n,
-                                                             int reduced, int32_t* __restrict__ class_out) {
+                                                             int reduced, int32_t* __restrict__ class_out, DI* __restrict__ part, int seg_rows) {
     __shared__ DI red[kBlock / 64];
-    const int slot = blockIdx.x;
+    const int slot = PARTS ? blockIdx.y : blockIdx.x;
     if (!unreliable[slot]) return;
     const float* d1 = dist1 + (size_t)slot * n;
     const float* d2 = dist2 + (size_t)slot * n;
+    const int row_begin = PARTS ? blockIdx.x * seg_rows : 0;
+    const int row_end = PARTS ? min(n, row_begin + seg_rows) : n;
     DI m;
     m.d = 100000.0;      // bestDist = 100000 (:168); only strictly smaller rows qualify
     m.i = -1;
-    for (int row = threadIdx.x; row < n; row += kBlock) {
+    for (int row = row_begin + threadIdx.x; row < row_end; row += kBlock) {
         const float tail = d2[row] * (float)(kLastFeature - reduced);               // float * int -> float (:174)
         const double v = ((double)d1[row] * reduced + tail) / kLastFeature;         // :173-174
         if (v < m.d || (v == m.d && m.i >= 0 && row < m.i)) { m.d = v; m.i = row; }
     }
     const DI w = block_argmin(m, red);
-    if (threadIdx.x == 0) class_out[slot] = w.i >= 0 ? cls[w.i] : -1;
+    if (threadIdx.x == 0) {
+        if (PARTS) part[(size_t)slot * gridDim.x + blockIdx.x] = w;
+        else class_out[slot] = w.i >= 0 ? cls[w.i] : -1;
+    }
+}
+__global__ void k_twd_conv_stage2_final(const DI* __restrict__ part, int nseg, const int32_t* __restrict__ unreliable,
+                                        const int32_t* __restrict__ cls, int32_t* __restrict__ class_out) {
+    const int slot = blockIdx.x;
+    if (threadIdx.x != 0 || !unreliable[slot]) return;
+    DI best;
+    best.d = 100000.0;
+    best.i = -1;
+    for (int b = 0; b < nseg; ++b) {                 // segments in row order: an equal value later on does not replace the earlier row
+        const DI p = part[(size_t)slot * nseg + b];
+        if (p.i >= 0 && p.d < best.d) best = p;
+    }
+    class_out[slot] = best.i >= 0 ? cls[best.i] : -1;
 }
 
 // ---- ProposedTWDClassifier (ImageTesting.cpp:207-288, CHECK_ALL_INSTANCES) ----
@@ -326,6 +403,15 @@ int fir_twd_conventional(fir_gallery* g, const float* queries, int32_t qb, int32
     TWD_SLOT(dres, 3, (size_t)2 * kBatch * 4);                 // class[kBatch], unreliable[kBatch]
     int32_t* dcls = dres.as<int32_t>();
     int32_t* dunrel = dcls + kBatch;
+    // galleries beyond a few spans: the rows of every query are split over `nseg` workgroups (see k_twd_conv_stage1)
+    const int nseg = n > 4 * kSpan ? std::min(256, (n + 2 * kSpan - 1) / (2 * kSpan)) : 1;
+    const int seg_rows = nseg > 1 ? ((n + nseg - 1) / nseg + kSpan - 1) / kSpan * kSpan : n;
+    const int nseg_eff = nseg > 1 ? (n + seg_rows - 1) / seg_rows : 1;
+    TWD_SLOT(dpart, 7, (size_t)batch * nseg_eff * (sizeof(DI) * 2 + sizeof(S1Chg)) + (size_t)batch * num_classes * 8);
+    DI* part1 = dpart.as<DI>();
+    DI* part2 = part1 + (size_t)batch * nseg_eff;
+    S1Chg* chg = (S1Chg*)(part2 + (size_t)batch * nseg_eff);
+    unsigned long long* gprob = (unsigned long long*)(chg + (size_t)batch * nseg_eff);
     for (int q0 = 0; q0 < qb; q0 += batch) {
         const int nq = std::min(batch, qb - q0);
         int32_t h_res[2 * kBatch];
@@ -336,12 +422,29 @@ int fir_twd_conventional(fir_gallery* g, const float* queries, int32_t qb, int32
             // the verdicts come back with ONE copy and ONE synchronisation per batch
             TWD_HIP(hipMemcpyAsync(dq.p, queries + (size_t)q0 * v.d, (size_t)nq * v.d * 4, hipMemcpyHostToDevice, v.stream));
             if ((rc = fir_range_distances_dev(g, dq.as<float>(), nq, 0, reduced_features_count, d1.as<float>(), v.stream))) return rc;
-            hipLaunchKernelGGL(k_twd_conv_stage1, dim3(nq), dim3(kBlock), (size_t)num_classes * 8, v.stream, d1.as<float>(), v.cls, n,
-                               num_classes, type, threshold, dcls, dunrel);
+            const size_t plds = (size_t)num_classes * 8;
+            if (nseg_eff == 1) {
+                hipLaunchKernelGGL(k_twd_conv_stage1<kS1Single>, dim3(nq), dim3(kBlock), plds, v.stream, d1.as<float>(), v.cls, n, num_classes, type,
+                                   threshold, dcls, dunrel, (DI*)nullptr, (S1Chg*)nullptr, (unsigned long long*)nullptr, n);
+            } else {
+                if (type == 0) TWD_HIP(hipMemsetAsync(gprob, 0, (size_t)nq * num_classes * 8, v.stream));
+                hipLaunchKernelGGL(k_twd_conv_stage1<kS1Part>, dim3(nseg_eff, nq), dim3(kBlock), plds, v.stream, d1.as<float>(), v.cls, n, num_classes,
+                                   type, threshold, dcls, dunrel, part1, chg, gprob, seg_rows);
+                hipLaunchKernelGGL(k_twd_conv_stage1<kS1Records>, dim3(nseg_eff, nq), dim3(kBlock), plds, v.stream, d1.as<float>(), v.cls, n,
+                                   num_classes, type, threshold, dcls, dunrel, part1, chg, gprob, seg_rows);
+                hipLaunchKernelGGL(k_twd_conv_stage1<kS1Final>, dim3(nq), dim3(kBlock), plds, v.stream, d1.as<float>(), v.cls, n, num_classes, type,
+                                   threshold, dcls, dunrel, part1, chg, gprob, seg_rows);
+            }
             TWD_HIP(hipGetLastError());
             if ((rc = fir_range_distances_dev(g, dq.as<float>(), nq, reduced_features_count, kLastFeature, d2.as<float>(), v.stream))) return rc;
-            hipLaunchKernelGGL(k_twd_conv_stage2, dim3(nq), dim3(kBlock), 0, v.stream, d1.as<float>(), d2.as<float>(), dunrel, v.cls, n,
-                               reduced_features_count, dcls);
+            if (nseg_eff == 1) {
+                hipLaunchKernelGGL(k_twd_conv_stage2<false>, dim3(nq), dim3(kBlock), 0, v.stream, d1.as<float>(), d2.as<float>(), dunrel, v.cls, n,
+                                   reduced_features_count, dcls, (DI*)nullptr, n);
+            } else {
+                hipLaunchKernelGGL(k_twd_conv_stage2<true>, dim3(nseg_eff, nq), dim3(kBlock), 0, v.stream, d1.as<float>(), d2.as<float>(), dunrel,
+                                   v.cls, n, reduced_features_count, dcls, part2, seg_rows);
+                hipLaunchKernelGGL(k_twd_conv_stage2_final, dim3(nq), dim3(64), 0, v.stream, part2, nseg_eff, dunrel, v.cls, dcls);
+            }
             TWD_HIP(hipGetLastError());
             TWD_HIP(hipMemcpyAsync(h_res, dres.p, sizeof(h_res), hipMemcpyDeviceToHost, v.stream));
             TWD_HIP(hipStreamSynchronize(v.stream));

@@ -43,7 +43,7 @@ def test_matches_oracle_on_fresh_data(fir, oracle, seed, n, ncls):
             assert list(k) == [e[2] for e in exp], (fc, th)
 
 
-@pytest.mark.parametrize("n,ncls,class_major", [(3840, 12, True), (3841, 12, False), (20000, 40, True), (11521, 7, False)])
+@pytest.mark.parametrize("n,ncls,class_major", [(3840, 12, True), (3841, 12, False), (20000, 40, True), (11521, 7, False), (15361, 9, False), (60000, 101, True)])
 def test_span_boundaries_and_class_major_galleries(fir, oracle, n, ncls, class_major):
     """The first-stage kernel takes the rows 3840 at a time and folds runs of equal labels before touching the class
     posteriors: galleries of exactly one span, one row more, several spans; labels class-major (the reference's
