@@ -353,6 +353,102 @@ __global__ void __launch_bounds__(kBlock) k_twd_proposed(const float* __restrict
     }
 }
 
+// ---- the same classifier with the rows of a query split over gridDim.x workgroups (large galleries) ----
+// Three small launches per chunk c, all queued up front (a finished query's workgroups return at once):
+//   k_twd_prop_min    distances[j] += chunk distance over the alive rows; each segment's first minimum -> part[c][q][b]
+//   k_twd_prop_prune  (every workgroup folds the segments' minima itself) rows above bestDist / threshold die, the
+//                     survivors of another class than the best row's are counted into cnt[c][q]
+//   k_twd_prop_step   one thread per query: the reference's loop bookkeeping (bestInd, break conditions, num_of_unreliable)
+struct PropState {
+    int bestInd, unreliable, used, done;
+};
+__global__ void k_twd_prop_init(PropState* state, int nq) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < nq) state[q] = PropState{-1, 0, 0, 0};
+}
+__device__ __forceinline__ DI prop_fold(const DI* __restrict__ parts, int nseg) {
+    DI w;
+    w.d = 100000.0;                                                                 // bestDist = 100000 per chunk (:230)
+    w.i = -1;
+    for (int b = 0; b < nseg; ++b) {
+        const DI p = parts[b];
+        if (p.i >= 0 && p.d < w.d) w = p;                                           // segments in row order, strict '<'
+    }
+    return w;
+}
+__global__ void __launch_bounds__(kBlock) k_twd_prop_min(const float* __restrict__ cd, int nq, int c, double* __restrict__ acc,
+                                                          const uint8_t* __restrict__ alive, int n, int seg_rows,
+                                                          const PropState* __restrict__ state, DI* __restrict__ part) {
+    __shared__ DI red[kBlock / 64];
+    const int q = blockIdx.y, b = blockIdx.x;
+    if (state[q].done) return;
+    double* a = acc + (size_t)q * n;
+    const uint8_t* live = alive + (size_t)q * n;
+    const float* dc = cd + ((size_t)c * nq + q) * n;
+    const int row_end = min(n, (b + 1) * seg_rows);
+    DI m;
+    m.d = 100000.0;
+    m.i = -1;
+    for (int row = b * seg_rows + threadIdx.x; row < row_end; row += kBlock) {
+        if (c > 0 && !live[row]) continue;                                          // :236-241 (every row is alive in the first chunk)
+        const double v = (c > 0 ? a[row] : 0.0) + (double)dc[row];                  // distances[j] += ... (:250)
+        a[row] = v;
+        if (v < m.d) { m.d = v; m.i = row; }
+    }
+    const DI w = block_argmin(m, red);
+    if (threadIdx.x == 0) part[((size_t)c * nq + q) * gridDim.x + b] = w;
+}
+__global__ void __launch_bounds__(kBlock) k_twd_prop_prune(int nq, int c, const double* __restrict__ acc, uint8_t* __restrict__ alive,
+                                                            const int32_t* __restrict__ cls, int n, int seg_rows, double threshold,
+                                                            const PropState* __restrict__ state, const DI* __restrict__ part,
+                                                            int* __restrict__ cnt) {
+    __shared__ DI best_s;
+    __shared__ int others_s;
+    const int q = blockIdx.y, b = blockIdx.x;
+    if (state[q].done) return;
+    if (threadIdx.x == 0) { best_s = prop_fold(part + ((size_t)c * nq + q) * gridDim.x, gridDim.x); others_s = 0; }
+    __syncthreads();
+    const DI w = best_s;
+    const int bestInd = w.i >= 0 ? w.i : state[q].bestInd;                          // :255-258
+    if (bestInd < 0) return;                                                        // the reference breaks before pruning
+    const double dist_threshold = w.d * threshold;                                  // :263
+    const int bestClass = cls[bestInd];
+    const double* a = acc + (size_t)q * n;
+    uint8_t* live = alive + (size_t)q * n;
+    const int row_end = min(n, (b + 1) * seg_rows);
+    int others = 0;
+    for (int row = b * seg_rows + threadIdx.x; row < row_end; row += kBlock) {
+        if (c > 0 && !live[row]) continue;
+        if (a[row] > dist_threshold) live[row] = 0;                                 // :268-269
+        else {
+            if (c == 0) live[row] = 1;
+            if (cls[row] != bestClass) ++others;                                    // :270-271
+        }
+    }
+    atomicAdd(&others_s, others);
+    __syncthreads();
+    if (threadIdx.x == 0 && others_s) atomicAdd(&cnt[(size_t)c * nq + q], others_s);
+}
+__global__ void k_twd_prop_step(int nq, int c, int nseg, const DI* __restrict__ part, const int* __restrict__ cnt, const int32_t* __restrict__ cls,
+                                PropState* __restrict__ state, int32_t* __restrict__ class_out, int32_t* __restrict__ unreliable_out,
+                                int32_t* __restrict__ chunks_out) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    PropState st = state[q];
+    if (!st.done) {
+        ++st.used;
+        const DI w = prop_fold(part + ((size_t)c * nq + q) * nseg, nseg);
+        if (w.i >= 0) st.bestInd = w.i;                                             // :255-258
+        if (st.bestInd < 0) st.done = 1;
+        else if (1 + cnt[(size_t)c * nq + q] == 1) st.done = 1;                     // num_of_variants == 1 (:265,285)
+        else if (c == 0) ++st.unreliable;                                           // :287-288
+        state[q] = st;
+    }
+    class_out[q] = st.bestInd >= 0 ? cls[st.bestInd] : -1;
+    unreliable_out[q] = st.unreliable;
+    chunks_out[q] = st.used;
+}
+
 // Queries per internal batch: as many as keep the per-batch distance tables under `budget` bytes (a multiple of 8, <= kBatch).
 int batch_for(int64_t n, size_t bytes_per_query_row, size_t budget = (size_t)512 << 20) {
     const size_t per_query = (size_t)std::max<int64_t>(n, 1) * bytes_per_query_row;
@@ -481,6 +577,14 @@ int fir_twd_proposed(fir_gallery* g, const float* queries, int32_t qb, int32_t r
     int32_t* dcls = dres.as<int32_t>();
     int32_t* dunrel = dcls + kBatch;
     int32_t* dchunks = dcls + 2 * kBatch;
+    // large galleries: the rows of every query are split over `nseg` workgroups, three small launches per chunk
+    const int nseg_want = n > 16384 ? std::min(256, (n + 8191) / 8192) : 1;
+    const int seg_rows = nseg_want > 1 ? ((n + nseg_want - 1) / nseg_want + 255) / 256 * 256 : n;
+    const int nseg = nseg_want > 1 ? (n + seg_rows - 1) / seg_rows : 1;
+    TWD_SLOT(pws, 7, (size_t)batch * sizeof(PropState) + (size_t)nchunks * batch * sizeof(int) + (size_t)nchunks * batch * nseg * sizeof(DI) + 64);
+    DI* ppart = pws.as<DI>();
+    PropState* pstate = (PropState*)(ppart + (size_t)nchunks * batch * nseg);
+    int* pcnt = (int*)(pstate + batch);
     for (int q0 = 0; q0 < qb; q0 += batch) {
         const int nq = std::min(batch, qb - q0);
         int32_t h_res[3 * kBatch];
@@ -493,8 +597,21 @@ int fir_twd_proposed(fir_gallery* g, const float* queries, int32_t qb, int32_t r
             TWD_HIP(hipMemcpyAsync(dq.p, queries + (size_t)q0 * v.d, (size_t)nq * v.d * 4, hipMemcpyHostToDevice, v.stream));
             // all chunk distances cd[c][slot][n] from ONE pass over features [0, 256)
             if ((rc = fir_subrange_distances_dev_(g, dq.as<float>(), nq, 0, kLastFeature, reduced_features_count, cd.as<float>(), v.stream))) return rc;
-            hipLaunchKernelGGL(k_twd_proposed, dim3(nq), dim3(kBlock), 0, v.stream, cd.as<float>(), nq, nchunks, acc.as<double>(),
-                               alive.as<uint8_t>(), v.cls, n, 1.0 / threshold, dcls, dunrel, dchunks);
+            if (nseg == 1) {
+                hipLaunchKernelGGL(k_twd_proposed, dim3(nq), dim3(kBlock), 0, v.stream, cd.as<float>(), nq, nchunks, acc.as<double>(),
+                                   alive.as<uint8_t>(), v.cls, n, 1.0 / threshold, dcls, dunrel, dchunks);
+            } else {
+                hipLaunchKernelGGL(k_twd_prop_init, dim3((nq + 63) / 64), dim3(64), 0, v.stream, pstate, nq);
+                TWD_HIP(hipMemsetAsync(pcnt, 0, (size_t)nchunks * nq * sizeof(int), v.stream));
+                for (int c = 0; c < nchunks; ++c) {
+                    hipLaunchKernelGGL(k_twd_prop_min, dim3(nseg, nq), dim3(kBlock), 0, v.stream, cd.as<float>(), nq, c, acc.as<double>(),
+                                       alive.as<uint8_t>(), n, seg_rows, pstate, ppart);
+                    hipLaunchKernelGGL(k_twd_prop_prune, dim3(nseg, nq), dim3(kBlock), 0, v.stream, nq, c, acc.as<double>(), alive.as<uint8_t>(),
+                                       v.cls, n, seg_rows, 1.0 / threshold, pstate, ppart, pcnt);
+                    hipLaunchKernelGGL(k_twd_prop_step, dim3((nq + 63) / 64), dim3(64), 0, v.stream, nq, c, nseg, ppart, pcnt, v.cls, pstate, dcls,
+                                       dunrel, dchunks);
+                }
+            }
             TWD_HIP(hipGetLastError());
             TWD_HIP(hipMemcpyAsync(h_res, dres.p, sizeof(h_res), hipMemcpyDeviceToHost, v.stream));
             TWD_HIP(hipStreamSynchronize(v.stream));
