@@ -77,6 +77,7 @@ struct fir_gallery {
     int last_waves = 0;       // waves of the most recent scan launch
     int large_batch_min = 0;  // > 0: fir_search_top1 sends L2 whole-range batches of at least this many queries through fir_gemm_*
     fir_gemm* gemm = nullptr; // created on first use
+    int64_t tiles_limit = 0, tile_begin = 0;  // tiles_limit > 0: scans cover tiles [tile_begin, tile_begin + tiles_limit) only (row samples of the top-K threshold)
     int max_tiles_per_launch = 64;   // query tiles (gallery passes) folded into one launch of the hand-scheduled kernels
 
     struct Occ { const void* fn; size_t lds; int waves; };
@@ -212,7 +213,8 @@ int top1_qpp(const fir_gallery* g, int qb, int cap) {
     if (g->qpp > 0) return cap;
     const int64_t simds = (int64_t)g->cus * 4;
     int q = cap;
-    while (q > 1 && g->tiles * ((qb + q - 1) / q) < simds) q /= 2;
+    const int64_t tiles = g->tiles_limit > 0 ? std::min<int64_t>(g->tiles_limit, g->tiles) : g->tiles;
+    while (q > 1 && tiles * ((qb + q - 1) / q) < simds) q /= 2;
     return q;
 }
 
@@ -269,16 +271,18 @@ int run_pass(fir_gallery* g, hipStream_t st, int epi, const float* d_queries, in
     const int waves = g->waves_req > 0 ? std::min(g->waves_req, max_waves) : pick_waves(g->tiles, max_waves, g->cus * 4);
     g->last_waves = waves;
     if (waves_used) *waves_used = waves;
-    ScanArgs a;
-    a.gal4 = g->gal4;
+    ScanArgs a{};
     a.qt = qt;
-    a.n = g->n;
-    a.tiles = (int32_t)g->tiles;
+    const int64_t tile0 = g->tiles_limit > 0 ? std::min<int64_t>(g->tile_begin, g->tiles) : 0;
+    const int64_t tiles = g->tiles_limit > 0 ? std::min<int64_t>(g->tiles_limit, g->tiles - tile0) : g->tiles;
+    a.gal4 = g->gal4 + (size_t)tile0 * g->dp4 * 64;
+    a.row_offset = g->row_offset + tile0 * kTileRows;
+    a.n = std::min<int64_t>(g->n - tile0 * kTileRows, tiles * kTileRows);
+    a.tiles = (int32_t)tiles;
     a.dp4 = g->dp4;
     a.start = start;
     a.end = end;
     a.waves = waves;
-    a.row_offset = g->row_offset;
     a.keys = keys;
     a.out = out;
     a.out_stride = out_stride;
@@ -331,8 +335,17 @@ int top1_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start, 
     return FIR_OK;
 }
 
+int topk_lists_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start, int32_t end, int32_t k, uint64_t* d_keys,
+                   hipStream_t st);
+
 int topk_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start, int32_t end, int32_t k, uint64_t* d_keys,
-             hipStream_t st) {
+             hipStream_t st, bool allow_lists = true) {
+    // batches over a large gallery: threshold from a row sample, append scan at the speed of the top-1 scan, K smallest
+    // of each candidate list (exact distances throughout); anything it cannot certify falls back to the scan below
+    if (allow_lists && g->tiles_limit == 0 && qb >= 8 && g->n >= 65536 && g->metric == kL2 && !(start & 3) && !(end & 3)) {
+        const int rc2 = topk_lists_dev(g, d_queries, qb, start, end, k, d_keys, st);
+        if (rc2 != FIR_ERR_STATE) return rc2;      // FIR_ERR_STATE: not certified -> the register-list scan answers
+    }
     int rc = grow(g->qt, g->qt_cap, (size_t)qb * g->dp4 * 4);
     if (rc) return rc;
     const int qcap = std::min(effective_qpp(g), 4);   // 2*kKMax registers per query per lane
@@ -349,6 +362,78 @@ int topk_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start, 
     }
     FIR_HIP(hipGetLastError());
     return FIR_OK;
+}
+
+// The K nearest rows of a batch through candidate lists (see k_scan_l2_lds<..., APPEND>). Returns FIR_ERR_STATE (without
+// setting the error text) when a query could not be certified: fewer than K sample rows below 100000, or a list overflow.
+constexpr int kListCap = 4096;
+int topk_lists_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start, int32_t end, int32_t k, uint64_t* d_keys,
+                   hipStream_t st) {
+    size_t lds_bytes = 0;
+    scan_fn probe = pick_fast(kEpiTop1, 8, g->metric, start, end, g->dp4, &lds_bytes);
+    if (!probe || lds_bytes == 0 || lds_bytes > 64 * 1024) return FIR_ERR_STATE;      // needs the LDS-tile kernel
+    const int qpad = (qb + 7) / 8 * 8;
+    void *p_skeys = nullptr, *p_small = nullptr, *p_lists = nullptr;
+    int rc;
+    if ((rc = fir_gallery_scratch_(g, 12, (size_t)qb * k * 8, &p_skeys))) return rc;
+    if ((rc = fir_gallery_scratch_(g, 13, (size_t)qpad * 8 + 16, &p_small))) return rc;
+    if ((rc = fir_gallery_scratch_(g, 14, (size_t)qpad * kListCap * 8, &p_lists))) return rc;
+    uint64_t* skeys = (uint64_t*)p_skeys;
+    float* tau = (float*)p_small;
+    int32_t* counts = (int32_t*)(tau + qpad);
+    int32_t* flag = counts + qpad;
+    uint64_t* lists = (uint64_t*)p_lists;
+    if ((rc = grow(g->qt, g->qt_cap, (size_t)qpad * g->dp4 * 4 + 64))) return rc;      // before anything is queued on it
+    // 1. nearest row inside each of k disjoint groups of sample tiles (k top-1 scans, each over all the queries): the
+    //    largest of the k distances is a threshold at least k rows pass; about 2.3 * n * k / rows_sampled rows will
+    const int64_t want_rows = std::max<int64_t>(16384, (int64_t)g->n * k / 256);
+    const int64_t group_tiles = std::max<int64_t>(1, std::min<int64_t>(g->tiles / k, (want_rows / k + kTileRows - 1) / kTileRows));
+    for (int i = 0; i < k && !rc; ++i) {
+        g->tile_begin = i * group_tiles;
+        g->tiles_limit = group_tiles;
+        rc = top1_dev(g, d_queries, qb, start, end, skeys + (size_t)i * qb, st);
+    }
+    g->tiles_limit = 0;
+    g->tile_begin = 0;
+    if (rc) return rc;
+    FIR_HIP(hipMemsetAsync(flag, 0, 4, st));
+    hipLaunchKernelGGL(k_topk_tau, dim3((qpad + 63) / 64), dim3(64), 0, st, skeys, qb, qpad, k, tau, counts, flag);
+    // 2. the append scan over the whole gallery: 8 queries per tile, every tile of the call in one launch (blockIdx.y)
+    const int kk = g->dp4 * 4;
+    scan_fn fn = (scan_fn)k_scan_l2_lds<1, FIR_FAST_U, FIR_FAST_WPS, true>;
+    const int max_waves = max_waves_for(g, fn, lds_bytes);
+    const int waves = g->waves_req > 0 ? std::min(g->waves_req, max_waves) : pick_waves(g->tiles, max_waves, g->cus * 4);
+    for (int q0 = 0; q0 < qpad; q0 += 8 * g->max_tiles_per_launch) {
+        const int ny = std::min(g->max_tiles_per_launch, (qpad - q0) / 8);
+        const int live = std::max(0, std::min(qb - q0, ny * 8));
+        float* qt = g->qt + (size_t)q0 * kk;
+        hipLaunchKernelGGL(k_transpose_queries, dim3((unsigned)(((int64_t)kk * 8 * ny + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
+                           d_queries + (size_t)q0 * g->d, live, g->d, g->dp4, 8, qt, (uint64_t*)nullptr, 0);
+        ScanArgs a{};
+        a.gal4 = g->gal4;
+        a.qt = qt;
+        a.n = g->n;
+        a.tiles = (int32_t)g->tiles;
+        a.dp4 = g->dp4;
+        a.start = start;
+        a.end = end;
+        a.waves = waves;
+        a.row_offset = g->row_offset;
+        a.keys = lists + (size_t)q0 * kListCap;
+        a.k = kListCap;
+        a.tau = tau + q0;
+        a.counts = counts + q0;
+        a.qt_stride = (int64_t)kk * 8;
+        a.nt = gallery_bytes(g) > kL2ResidentBytes ? 1 : 0;
+        hipLaunchKernelGGL(fn, dim3(waves / 4, ny), dim3(kBlock), lds_bytes, st, a);
+    }
+    // 3. the K smallest keys of every list
+    hipLaunchKernelGGL(k_topk_select, dim3(qb), dim3(kBlock), 0, st, lists, counts, kListCap, k, d_keys, flag);
+    FIR_HIP(hipGetLastError());
+    int32_t h_flag = 0;
+    FIR_HIP(hipMemcpyAsync(&h_flag, flag, 4, hipMemcpyDeviceToHost, st));
+    FIR_HIP(hipStreamSynchronize(st));
+    return h_flag ? FIR_ERR_STATE : FIR_OK;
 }
 
 int range_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start, int32_t end, float* d_out, hipStream_t st) {

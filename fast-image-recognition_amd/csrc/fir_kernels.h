@@ -80,6 +80,8 @@ struct ScanArgs {
     int64_t qt_stride;    // floats between the query tiles of consecutive blockIdx.y (top-1 kernels)
     int32_t nt;           // non-temporal gallery loads (galleries that do not fit the L2s)
     int32_t step;         // k_scan_subranges: features per sub-range
+    const float* tau;     // append form of the L2 scan: rows with distance <= tau[query] are appended ...
+    int32_t* counts;      // ... counts[query] entries so far, lists = keys[query * k + slot] (k = capacity per query)
 };
 
 template <int QB, int METRIC, int U>
@@ -396,6 +398,8 @@ __device__ __forceinline__ void l2_chunk(f2 (&acc)[NB][4], const float4 g, f2 (&
 // query tile must be followed by >= 64 readable floats (prefetch of the unit past the end).
 template <int NB, int U, int WPS>
 __global__ void __launch_bounds__(kBlock, WPS) k_scan_l2_fast(const ScanArgs a) {
+    constexpr bool APPEND = false;     // the candidate-list form exists for the LDS-tile kernel only
+    int32_t* counts = nullptr;
     constexpr int QB = 8 * NB;
     const int lane = threadIdx.x & 63;
     const int gw = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
@@ -439,11 +443,23 @@ __global__ void __launch_bounds__(kBlock, WPS) k_scan_l2_fast(const ScanArgs a) 
                 for (int i = 0; i < 4; ++i) {
                     const float d0 = acc[b][i].x / fcount, d1 = acc[b][i].y / fcount;   // db_features.cpp:40
                     const int q0 = b * 8 + 2 * i;
-                    if (d0 < best_d[q0]) { best_d[q0] = d0; best_i[q0] = (int32_t)row; }           // db_features.cpp:329-332
-                    if (d1 < best_d[q0 + 1]) { best_d[q0 + 1] = d1; best_i[q0 + 1] = (int32_t)row; }
+                    if constexpr (APPEND) {
+                        if (d0 <= best_d[q0]) {
+                            const int slot = atomicAdd(&counts[q0], 1);
+                            if (slot < a.k) keys[(size_t)q0 * a.k + slot] = key_pack(d0, (uint32_t)(row + a.row_offset));
+                        }
+                        if (d1 <= best_d[q0 + 1]) {
+                            const int slot = atomicAdd(&counts[q0 + 1], 1);
+                            if (slot < a.k) keys[(size_t)(q0 + 1) * a.k + slot] = key_pack(d1, (uint32_t)(row + a.row_offset));
+                        }
+                    } else {
+                        if (d0 < best_d[q0]) { best_d[q0] = d0; best_i[q0] = (int32_t)row; }           // db_features.cpp:329-332
+                        if (d1 < best_d[q0 + 1]) { best_d[q0 + 1] = d1; best_i[q0 + 1] = (int32_t)row; }
+                    }
                 }
         }
     }
+    if constexpr (APPEND) return;
 #pragma unroll
     for (int q = 0; q < QB; ++q) {
         uint64_t key = best_i[q] >= 0 ? key_pack(best_d[q], (uint32_t)((int64_t)best_i[q] + a.row_offset)) : kKeyNone;
@@ -522,7 +538,10 @@ __device__ __forceinline__ void l2_chunk_lds(f2 (&acc)[NB][4], const float4 g, f
 }
 
 // Dynamic LDS: (dp4 + 1) * 4 * QB floats (the query tile + one zero chunk of slack).
-template <int NB, int U, int WPS>
+// APPEND = true: instead of a running first minimum, every row whose distance is <= tau[query] is appended (packed key) to
+// that query's candidate list: the distances are the exact ones, so the K nearest rows are the K smallest keys of a list
+// whose threshold came from a row sample (fir_capi.hip, topk_dev) -- the top-K scan at the speed of the top-1 scan.
+template <int NB, int U, int WPS, bool APPEND = false>
 __global__ void __launch_bounds__(kBlock, WPS) k_scan_l2_lds(const ScanArgs a) {
     constexpr int QB = 8 * NB;
     extern __shared__ __attribute__((aligned(16))) float4 lq[];
@@ -543,12 +562,16 @@ __global__ void __launch_bounds__(kBlock, WPS) k_scan_l2_lds(const ScanArgs a) {
     int zero_v;
     asm volatile("v_mov_b32 %0, 0" : "=v"(zero_v));
     const float4* lqv = lq + zero_v;
-    uint64_t* keys = a.keys + (size_t)blockIdx.y * QB;
+    uint64_t* keys = a.keys + (size_t)blockIdx.y * QB * (APPEND ? a.k : 1);
 
-    float best_d[QB];
+    float best_d[QB];      // APPEND: the thresholds tau
     int32_t best_i[QB];
 #pragma unroll
-    for (int q = 0; q < QB; ++q) { best_d[q] = kNotFound; best_i[q] = -1; }
+    for (int q = 0; q < QB; ++q) {
+        best_d[q] = APPEND ? a.tau[(size_t)blockIdx.y * QB + q] : kNotFound;
+        best_i[q] = -1;
+    }
+    int32_t* counts = APPEND ? a.counts + (size_t)blockIdx.y * QB : nullptr;
 
     for (int t = gw; t < a.tiles; t += a.waves) {
 #ifdef FIR_DEBUG_TILEMOD   // timing experiments only: every tile reads one of the first few (cache-resident stream)
@@ -602,11 +625,23 @@ __global__ void __launch_bounds__(kBlock, WPS) k_scan_l2_lds(const ScanArgs a) {
                 for (int i = 0; i < 4; ++i) {
                     const float d0 = acc[b][i].x / fcount, d1 = acc[b][i].y / fcount;   // db_features.cpp:40
                     const int q0 = b * 8 + 2 * i;
-                    if (d0 < best_d[q0]) { best_d[q0] = d0; best_i[q0] = (int32_t)row; }           // db_features.cpp:329-332
-                    if (d1 < best_d[q0 + 1]) { best_d[q0 + 1] = d1; best_i[q0 + 1] = (int32_t)row; }
+                    if constexpr (APPEND) {
+                        if (d0 <= best_d[q0]) {
+                            const int slot = atomicAdd(&counts[q0], 1);
+                            if (slot < a.k) keys[(size_t)q0 * a.k + slot] = key_pack(d0, (uint32_t)(row + a.row_offset));
+                        }
+                        if (d1 <= best_d[q0 + 1]) {
+                            const int slot = atomicAdd(&counts[q0 + 1], 1);
+                            if (slot < a.k) keys[(size_t)(q0 + 1) * a.k + slot] = key_pack(d1, (uint32_t)(row + a.row_offset));
+                        }
+                    } else {
+                        if (d0 < best_d[q0]) { best_d[q0] = d0; best_i[q0] = (int32_t)row; }           // db_features.cpp:329-332
+                        if (d1 < best_d[q0 + 1]) { best_d[q0 + 1] = d1; best_i[q0 + 1] = (int32_t)row; }
+                    }
                 }
         }
     }
+    if constexpr (APPEND) return;
 #pragma unroll
     for (int q = 0; q < QB; ++q) {
         uint64_t key = best_i[q] >= 0 ? key_pack(best_d[q], (uint32_t)((int64_t)best_i[q] + a.row_offset)) : kKeyNone;
@@ -642,6 +677,53 @@ __global__ void __launch_bounds__(kBlock) k_topk_merge(const uint64_t* part, int
         for (int i = 1; i < kBlock / 64; ++i) m = red[i] < m ? red[i] : m;
         __syncthreads();
         if (threadIdx.x == 0) out[(size_t)(q0 + q) * K + r] = m;
+        prev = m;
+        first = false;
+    }
+}
+
+// Thresholds of the append form. gkeys[i][q] = nearest row of query q inside the i-th of K DISJOINT row groups of a
+// sample (top-1 scans): tau[q] = the largest of those K distances, so at least K rows (one per group) are <= tau[q].
+// A group without any row below 100000 raises the flag (the caller then uses the register-list scan). Padding queries
+// [nq, nq_pad) get a threshold nothing reaches.
+__global__ void k_topk_tau(const uint64_t* __restrict__ gkeys, int nq, int nq_pad, int K, float* __restrict__ tau, int32_t* __restrict__ counts,
+                           int32_t* __restrict__ flag) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq_pad) return;
+    counts[q] = 0;
+    if (q >= nq) { tau[q] = -1.0f; return; }
+    uint64_t worst = 0;
+    for (int i = 0; i < K; ++i) {
+        const uint64_t key = gkeys[(size_t)i * nq + q];
+        worst = key > worst ? key : worst;
+    }
+    if (worst == kKeyNone) { tau[q] = -1.0f; atomicOr(flag, 1); return; }
+    tau[q] = f32_from_orderable((uint32_t)(worst >> 32));
+}
+// The K smallest keys of each query's candidate list (count <= cap entries; more raises the flag). One block per query.
+__global__ void __launch_bounds__(kBlock) k_topk_select(const uint64_t* __restrict__ lists, const int32_t* __restrict__ counts, int cap, int K,
+                                                         uint64_t* __restrict__ out, int32_t* __restrict__ flag) {
+    __shared__ uint64_t red[kBlock / 64];
+    const int q = blockIdx.x;
+    const int cnt = counts[q];
+    if (cnt > cap || cnt < K) { if (threadIdx.x == 0) atomicOr(flag, 1); return; }
+    const uint64_t* l = lists + (size_t)q * cap;
+    uint64_t prev = 0;
+    bool first = true;
+    for (int r = 0; r < K; ++r) {
+        uint64_t cand = kKeyNone;
+        for (int i = threadIdx.x; i < cnt; i += kBlock) {
+            const uint64_t v = l[i];
+            if ((first || v > prev) && v < cand) cand = v;
+        }
+        cand = wave_min_u64(cand);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cand;
+        __syncthreads();
+        uint64_t m = red[0];
+#pragma unroll
+        for (int i = 1; i < kBlock / 64; ++i) m = red[i] < m ? red[i] : m;
+        __syncthreads();
+        if (threadIdx.x == 0) out[(size_t)q * K + r] = m;
         prev = m;
         first = false;
     }

@@ -111,6 +111,10 @@ int fir_gallery_classes_of(fir_gallery* g, const int32_t* idx, int32_t n, int32_
  * distances by ascending row index; unused slots idx -1 / dist 100000. idx[qb*k], dist[qb*k]. */
 int fir_search_topk(fir_gallery* g, const float* queries, int32_t qb, int32_t start_pos, int32_t end_pos, int32_t k,
                     int32_t* idx, float* dist);
+/* Batches of >= 8 queries over >= 65536 rows (L2, whole-chunk ranges) take a candidate-list form: a threshold from a
+ * row sample, an append scan at the speed of the top-1 scan, the K smallest of each list -- the same keys; that form
+ * synchronises `stream` once before returning (it has to know that no list overflowed; if one did, the register-list
+ * scan answers instead). */
 int fir_search_topk_keys_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start_pos, int32_t end_pos,
                              int32_t k, uint64_t* d_keys /* [qb*k] ascending */, void* stream);
 

@@ -300,6 +300,39 @@ def test_sharded_topk_merge_and_pnn_partial_sums(fir, oracle):
     assert np.array_equal(sharding.first_max_class(torch.from_numpy(total)).numpy(), wbest)
 
 
+def test_topk_candidate_lists_on_large_galleries(fir, oracle):
+    """Batches of >= 8 queries over >= 65536 rows take the candidate-list form of the top-K scan (threshold from a row
+    sample, append scan, K smallest of each list). Same answers as the oracle -- also with ties at the threshold, with
+    more ties than a list holds (falls back to the register-list scan) and with rows that never qualify."""
+    n, d, k = 70000, 64, 5
+    rows = synth.make_gallery(71, n, d, L2)
+    q, _ = synth.make_queries(71, rows, 11, L2)
+    rows[100:106] = rows[69990]                  # seven equal rows: ties inside and at the K-th place, ordered by row
+    q[0] = rows[69990]
+    with fir.Gallery(rows, None, L2, 0) as g:
+        idx, dist = g.search_topk(q, k)
+        idx8, dist8 = g.search_topk(q, 8, 4, 60)       # another K and a sub-range
+    for j in range(len(q)):
+        ei, ed = oracle.topk(rows, q[j], 0, d, k, L2)
+        assert np.array_equal(idx[j], ei), j
+        assert_bits_equal(dist[j], ed)
+        ei, ed = oracle.topk(rows, q[j], 4, 60, 8, L2)
+        assert np.array_equal(idx8[j], ei), j
+        assert_bits_equal(dist8[j], ed)
+    assert list(idx[0]) == [100, 101, 102, 103, 104]
+    rows[1000:9000] = rows[69990]                # 8000 more copies: the list overflows, the fallback answers
+    with fir.Gallery(rows, None, L2, 0) as g:
+        idx, dist = g.search_topk(q, k)
+    for j in range(len(q)):
+        ei, ed = oracle.topk(rows, q[j], 0, d, k, L2)
+        assert np.array_equal(idx[j], ei), j
+        assert_bits_equal(dist[j], ed)
+    far = np.full_like(q, 3000.0)                # nothing within 100000: every slot stays -1 / 100000
+    with fir.Gallery(rows, None, L2, 0) as g:
+        idx, dist = g.search_topk(far, k)
+    assert (idx == -1).all() and (dist == np.float32(100000.0)).all()
+
+
 def test_errors_are_reported_not_crashed(fir):
     rows = synth.make_gallery(61, 100, 32, L2)
     with fir.Gallery(rows, None, L2, 0) as g:
