@@ -178,6 +178,30 @@ def main():
                 "identical_keys_to_scan": bool(torch.equal(keys, k2)), "fallback_queries": gm.stats()["fallback_queries"]}
         gm.close()
 
+    # also outside the timed region (N = 1): the other scans of the same gallery, for the record
+    also = None
+    if world == 1 and not args.no_mfma:
+        def rate(fn, nq, reps):
+            fn()
+            torch.cuda.synchronize()
+            t_0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            return nq * reps / (time.perf_counter() - t_0)
+
+        with torch.cuda.stream(work_stream):
+            k5 = torch.empty((qb, 5), device=dev, dtype=torch.int64)
+            also = {"l2_top5_queries_per_s": rate(lambda: g.search_topk_keys_dev(q.data_ptr(), qb, 5, k5.data_ptr(), stream=stream), qb, 2)}
+            top5_first_is_top1 = bool(torch.equal(k5[:, 0], keys))
+            q32 = q[:32].contiguous()
+            k32 = torch.empty(32, device=dev, dtype=torch.int64)
+            for name, metric in (("chi2", fir.METRIC_CHI2), ("kl", fir.METRIC_KL)):
+                g.set_metric(metric)
+                also[f"{name}_top1_queries_per_s"] = rate(lambda: g.search_top1_keys_dev(q32.data_ptr(), 32, k32.data_ptr(), stream=stream), 32, 2)
+            g.set_metric(fir.METRIC_L2)
+            also["l2_top5_first_column_is_top1"] = top5_first_is_top1
+
     idx, dd = fir.keys_unpack(keys.cpu().numpy().view(np.uint64))
     # size-independent property at full size: every planted query finds its source row, closer than any fresh one does
     planted = planted_rows.cpu().numpy()
@@ -213,6 +237,7 @@ def main():
                 "row_sharding": f"{world} shard(s) of {row_hi - row_lo} rows",
                 "planted_queries_found": planted_ok,
                 "same_step_through_mfma_path": mfma,
+                "other_scans_same_gallery": also,
             },
             "roofline": {
                 "bound": "hbm",
