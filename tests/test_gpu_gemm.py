@@ -37,6 +37,22 @@ def test_gemm_equals_scan(fir, oracle, seed, n, d, qb, precision):
     assert st["fallback_queries"] <= qb // 4 + 2, st      # the certificate normally holds on random data
 
 
+@pytest.mark.parametrize("n,d,qb", [(3000, 48, 128), (3000, 100, 129), (9000, 512, 257), (2500, 700, 192), (1200, 1280, 130),
+                                    (5000, 264, 513), (70, 512, 640), (4000, 40, 65)])
+def test_paired_passes_all_shapes(fir, n, d, qb):
+    """The 128-queries-per-gallery-read kernel (pairs of 64-query passes): feature counts whose last LDS slab holds 4, 8
+    or 12 k-blocks, an odd number of passes (the last one goes through the 64-query kernel), a ragged last pass, more
+    than one super-batch, fewer rows than one workgroup covers."""
+    rows = synth.make_gallery(100 + d, n, d, 0)
+    q, _ = synth.make_queries(100 + d, rows, qb, 0)
+    if n > 1000:
+        rows[n - 1] = rows[17]                   # an exact tie across row blocks: the lower row wins
+        q[3] = rows[17]
+    (idx, dist), (eidx, edist), st = run_both(fir, rows, q, 1)
+    assert np.array_equal(idx, eidx)
+    assert np.array_equal(dist.view(np.uint32), edist.view(np.uint32))
+
+
 @pytest.mark.parametrize("precision", [0, 1])
 def test_gemm_adversarial_near_ties_and_duplicates(fir, oracle, precision):
     """20 rows within a few ulps of the best (more than the 8 re-ranked candidates), exact duplicates of the best,
