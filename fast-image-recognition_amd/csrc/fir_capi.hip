@@ -342,7 +342,7 @@ int topk_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start, 
              hipStream_t st, bool allow_lists = true) {
     // batches over a large gallery: threshold from a row sample, append scan at the speed of the top-1 scan, K smallest
     // of each candidate list (exact distances throughout); anything it cannot certify falls back to the scan below
-    if (allow_lists && g->tiles_limit == 0 && qb >= 8 && g->n >= 65536 && g->metric == kL2 && !(start & 3) && !(end & 3)) {
+    if (allow_lists && g->tiles_limit == 0 && qb >= 8 && g->n >= 65536) {
         const int rc2 = topk_lists_dev(g, d_queries, qb, start, end, k, d_keys, st);
         if (rc2 != FIR_ERR_STATE) return rc2;      // FIR_ERR_STATE: not certified -> the register-list scan answers
     }
@@ -369,9 +369,11 @@ int topk_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start, 
 constexpr int kListCap = 4096;
 int topk_lists_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start, int32_t end, int32_t k, uint64_t* d_keys,
                    hipStream_t st) {
+    // the hand-scheduled LDS-tile kernel where it applies (L2, whole-chunk ranges, tile within 64 KiB), else the generic one
     size_t lds_bytes = 0;
     scan_fn probe = pick_fast(kEpiTop1, 8, g->metric, start, end, g->dp4, &lds_bytes);
-    if (!probe || lds_bytes == 0 || lds_bytes > 64 * 1024) return FIR_ERR_STATE;      // needs the LDS-tile kernel
+    const bool fast = probe && lds_bytes > 0 && lds_bytes <= 64 * 1024;
+    if (!fast) lds_bytes = 0;
     const int qpad = (qb + 7) / 8 * 8;
     void *p_skeys = nullptr, *p_small = nullptr, *p_lists = nullptr;
     int rc;
@@ -400,7 +402,10 @@ int topk_lists_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t s
     hipLaunchKernelGGL(k_topk_tau, dim3((qpad + 63) / 64), dim3(64), 0, st, skeys, qb, qpad, k, tau, counts, flag);
     // 2. the append scan over the whole gallery: 8 queries per tile, every tile of the call in one launch (blockIdx.y)
     const int kk = g->dp4 * 4;
-    scan_fn fn = (scan_fn)k_scan_l2_lds<1, FIR_FAST_U, FIR_FAST_WPS, true>;
+    scan_fn fn = fast ? (scan_fn)k_scan_l2_lds<1, FIR_FAST_U, FIR_FAST_WPS, true>
+                      : g->metric == kL2 ? (scan_fn)k_scan<8, kL2, kU, kEpiAppend, kKMax, kWps>
+                      : g->metric == kChi2 ? (scan_fn)k_scan<8, kChi2, kU, kEpiAppend, kKMax, kWps>
+                                           : (scan_fn)k_scan<8, kKL, kU, kEpiAppend, kKMax, kWps>;
     const int max_waves = max_waves_for(g, fn, lds_bytes);
     const int waves = g->waves_req > 0 ? std::min(g->waves_req, max_waves) : pick_waves(g->tiles, max_waves, g->cus * 4);
     for (int q0 = 0; q0 < qpad; q0 += 8 * g->max_tiles_per_launch) {

@@ -12,7 +12,7 @@ constexpr float kNotFound = 100000.0f;  // db_features.cpp:323, ann.cpp:116
 constexpr uint64_t kKeyNone = 0xFFFFFFFFFFFFFFFFull;
 
 enum { kL2 = 0, kChi2 = 1, kKL = 2 };
-enum { kEpiTop1 = 0, kEpiTopK = 1, kEpiStore = 2 };
+enum { kEpiTop1 = 0, kEpiTopK = 1, kEpiStore = 2, kEpiAppend = 3 };
 
 typedef const float __attribute__((address_space(4)))* sfloat_p;  // constant AS => s_load when uniform
 

@@ -139,8 +139,8 @@ template <int QB, int METRIC, int U, int EPI, int KMAX, int WPS, int LDSQ = 0>
 __global__ void __launch_bounds__(kBlock, WPS) k_scan(const ScanArgs a) {
     const int lane = threadIdx.x & 63;
     const int gw = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-    // blockIdx.y = query tile (top-1 only): several tiles of QB queries share one launch
-    const float* qsrc = a.qt + (EPI == kEpiTop1 ? (size_t)blockIdx.y * a.qt_stride : 0);
+    // blockIdx.y = query tile (top-1 and append forms): several tiles of QB queries share one launch
+    const float* qsrc = a.qt + (EPI == kEpiTop1 || EPI == kEpiAppend ? (size_t)blockIdx.y * a.qt_stride : 0);
     extern __shared__ __attribute__((aligned(16))) float lds_q[];
     if constexpr (LDSQ) {
         const int nf = a.dp4 * 4 * QB;
@@ -156,13 +156,17 @@ __global__ void __launch_bounds__(kBlock, WPS) k_scan(const ScanArgs a) {
     const int c_hi = a.end >> 2;                  // one past the last whole chunk
     const float fcount = (float)(a.end - a.start);  // db_features.cpp:40 divides by (end_pos-start_pos)
 
-    float best_d[EPI == kEpiTop1 ? QB : 1];
+    float best_d[EPI == kEpiTop1 || EPI == kEpiAppend ? QB : 1];      // kEpiAppend: the thresholds tau
     int32_t best_i[EPI == kEpiTop1 ? QB : 1];
     float kd[EPI == kEpiTopK ? QB : 1][EPI == kEpiTopK ? KMAX : 1];
     int32_t ki[EPI == kEpiTopK ? QB : 1][EPI == kEpiTopK ? KMAX : 1];
     if constexpr (EPI == kEpiTop1) {
 #pragma unroll
         for (int q = 0; q < QB; ++q) { best_d[q] = kNotFound; best_i[q] = -1; }
+    }
+    if constexpr (EPI == kEpiAppend) {
+#pragma unroll
+        for (int q = 0; q < QB; ++q) best_d[q] = a.tau[(size_t)blockIdx.y * QB + q];
     }
     if constexpr (EPI == kEpiTopK) {
 #pragma unroll
@@ -233,6 +237,13 @@ __global__ void __launch_bounds__(kBlock, WPS) k_scan(const ScanArgs a) {
                             kd[q][i] = sw ? cd : td; ki[q][i] = sw ? ci : ti;
                             cd = sw ? td : cd; ci = sw ? ti : ci;
                         }
+                    }
+                } else if constexpr (EPI == kEpiAppend) {
+                    // candidate-list form of the top-K scan (see k_scan_l2_lds<..., APPEND>): rows at or below the threshold
+                    if (dist <= best_d[q]) {
+                        const size_t qy = (size_t)blockIdx.y * QB + q;
+                        const int slot = atomicAdd(&a.counts[qy], 1);
+                        if (slot < a.k) a.keys[qy * a.k + slot] = key_pack(dist, (uint32_t)(row + a.row_offset));
                     }
                 } else {
                     if (q < a.nq) a.out[(size_t)q * a.out_stride + row] = dist;
