@@ -47,6 +47,10 @@ def cases():
             end = int(rng.integers(start + 1, d + 1))
         qpp = int(rng.choice([-1, -1, 1, 2, 4, 8, 16]))
         out.append((i, n, d, metric, qb, start, end, qpp))
+    # very long feature vectors: the 8- and 16-query tiles no longer fit LDS (scalar-operand form of the hand-scheduled kernel)
+    out.append((60, 300, 5000, L2, 8, 0, 5000, -1))
+    out.append((61, 700, 4800, L2, 16, 0, 4800, 16))
+    out.append((62, 200, 2300, L2, 9, 4, 2296, 8))        # 8-query tile between 64 and 144 KiB: the opt-in LDS size
     return out
 
 
