@@ -333,6 +333,52 @@ def test_topk_candidate_lists_on_large_galleries(fir, oracle):
     assert (idx == -1).all() and (dist == np.float32(100000.0)).all()
 
 
+def test_handles_release_their_device_memory(fir):
+    """Create / use / destroy every kind of handle repeatedly: free device memory ends where it started."""
+    import torch
+
+    import golden_cases as gc
+
+    rows = synth.make_gallery(81, 20000, 256, L2)
+    cls = synth.make_labels(20000, 40)
+    q, _ = synth.make_queries(81, rows, 16, L2)
+    x, lab, ncls = gc.cls_case(seed=82, n=600, d=64, n_classes=6)
+    order = np.argsort(lab, kind="stable")
+
+    def cycle():
+        with fir.Gallery(rows, cls, L2, 0) as g:
+            g.search_top1(q)
+            g.search_topk(q, 5)
+            g.twd_conventional(q, 40, 0, 0.24, 64)
+            g.twd_proposed(q, 32, 0.7)
+            g.rows_distances(q[:2], np.arange(10, dtype=np.int32).reshape(2, 5))
+            dem = fir.Dem(g, 3, 6)
+            dem.likelihoods(q[:3])
+            dem.close()
+            with fir.GemmSearch(g) as m:
+                keys = torch.empty(16, dtype=torch.int64, device="cuda")
+                tq = torch.from_numpy(q).cuda()
+                m.search_top1_keys_dev(tq.data_ptr(), 16, keys.data_ptr())
+                torch.cuda.synchronize()
+        c = fir.ClsModel(x[order], lab[order], ncls, x.mean(0), 0)
+        c.pnn_predict(x[:4])
+        c.close()
+        f = fir.Fpnn(x[order], lab[order], ncls, x.mean(0), x.std(0), 1.0, 0)
+        f.predict(x[:4])
+        f.close()
+
+    cycle()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(5):
+        cycle()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 64 << 20, (free0, free1)       # allocator granularity, not a per-cycle leak (one cycle allocates > 200 MB)
+
+
 def test_errors_are_reported_not_crashed(fir):
     rows = synth.make_gallery(61, 100, 32, L2)
     with fir.Gallery(rows, None, L2, 0) as g:
