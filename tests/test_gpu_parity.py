@@ -333,6 +333,36 @@ def test_topk_candidate_lists_on_large_galleries(fir, oracle):
     assert (idx == -1).all() and (dist == np.float32(100000.0)).all()
 
 
+@pytest.mark.parametrize("scale", [1e-18, 1e-20, 3e-23])
+def test_denormal_products_and_sums_match_the_cpu(fir, oracle, scale):
+    """Un-normalised inputs of tiny magnitude: (q - g)^2 and the running sums fall into the float denormal range (and
+    partly to zero). The GPU keeps denormals like the reference's SSE arithmetic: same bits, same first minimum."""
+    rows = (synth.make_gallery(91, 3000, 96, L2) * np.float32(scale)).astype(np.float32)
+    q = (synth.make_queries(91, rows, 9, L2)[0] * np.float32(scale)).astype(np.float32)
+    for metric in (L2, CHI2):
+        with fir.Gallery(rows, None, metric, 0) as g:
+            idx, dist = g.search_top1(q)
+            allq = g.range_distances(q[:2])
+            k_idx, k_dist = g.search_topk(q, 3)
+        for j in range(len(q)):
+            ei, ed = oracle.recognize_bf(rows, q[j], 0, 96, metric)
+            assert idx[j] == ei and bits(dist[j]) == bits(ed), (metric, j, dist[j], ed)
+            ki, kd = oracle.topk(rows, q[j], 0, 96, 3, metric)
+            assert np.array_equal(k_idx[j], ki) and np.array_equal(bits(k_dist[j]), bits(kd))
+        for j in range(2):
+            assert np.array_equal(bits(allq[j]), bits(oracle.all_distances(rows, q[j], 0, 96, metric)))
+    # the hand-scheduled packed-f32 kernels (8 and 16 queries per pass) on a gallery large enough to select them
+    big = (synth.make_gallery(92, 70000, 64, L2) * np.float32(scale)).astype(np.float32)
+    qb16 = (synth.make_queries(92, big, 16, L2)[0] * np.float32(scale)).astype(np.float32)
+    with fir.Gallery(big, None, L2, 0) as g:
+        for qpp in (8, 16):
+            g.set_tuning(qpp, 0)
+            idx, dist = g.search_top1(qb16)
+            for j in range(16):
+                ei, ed = oracle.recognize_bf(big, qb16[j], 0, 64, L2)
+                assert idx[j] == ei and bits(dist[j]) == bits(ed), (qpp, j, dist[j], ed)
+
+
 def test_handles_release_their_device_memory(fir):
     """Create / use / destroy every kind of handle repeatedly: free device memory ends where it started."""
     import torch
