@@ -53,6 +53,18 @@ def test_paired_passes_all_shapes(fir, n, d, qb):
     assert np.array_equal(dist.view(np.uint32), edist.view(np.uint32))
 
 
+@pytest.mark.parametrize("scale", [1e-20, 1e-6, 30.0, 1e15, 1e19])
+@pytest.mark.parametrize("precision", [0, 1])
+def test_extreme_magnitudes_fall_back_to_the_same_answers(fir, scale, precision):
+    """Inputs far from unit norm: products in the denormal range, distances beyond the 100000 cut-off, squares that
+    overflow. Whatever the proxies become, the certificate or the fallback returns the exact scan's keys."""
+    rows = (synth.make_gallery(55, 6000, 128, 0) * np.float32(scale)).astype(np.float32)
+    q = (synth.make_queries(55, rows / np.float32(scale), 70, 0)[0] * np.float32(scale)).astype(np.float32)
+    (idx, dist), (eidx, edist), st = run_both(fir, rows, q, precision)
+    assert np.array_equal(idx, eidx)
+    assert np.array_equal(dist.view(np.uint32), edist.view(np.uint32))
+
+
 @pytest.mark.parametrize("precision", [0, 1])
 def test_gemm_adversarial_near_ties_and_duplicates(fir, oracle, precision):
     """20 rows within a few ulps of the best (more than the 8 re-ranked candidates), exact duplicates of the best,
