@@ -363,6 +363,32 @@ def test_denormal_products_and_sums_match_the_cpu(fir, oracle, scale):
                 assert idx[j] == ei and bits(dist[j]) == bits(ed), (qpp, j, dist[j], ed)
 
 
+def test_mixed_sign_inputs_follow_the_reference_guards(fir, oracle):
+    """Negative and zero features: chi-square / KL only add a feature when lhs + rhs > 0, KL only the terms whose own
+    value is > 0 (db_features.cpp:29-36). Same rows, same bits (chi-square), as the CPU."""
+    rng = np.random.default_rng(7)
+    rows = (rng.random((5000, 40), dtype=np.float32) - np.float32(0.35)).astype(np.float32)
+    rows[rng.random(rows.shape) < 0.1] = 0
+    q = (rng.random((9, 40), dtype=np.float32) - np.float32(0.35)).astype(np.float32)
+    q[0] = -rows[17]                              # lhs + rhs == 0 everywhere: nothing is added, distance 0
+    for metric in (CHI2, KL):
+        with fir.Gallery(rows, None, metric, 0) as g:
+            idx, dist = g.search_top1(q)
+            allq = g.range_distances(q[:3], 3, 37)
+        for j in range(len(q)):
+            ei, ed = oracle.recognize_bf(rows, q[j], 0, 40, metric)
+            if metric == CHI2:
+                assert idx[j] == ei and bits(dist[j]) == bits(ed), (j, dist[j], ed)
+            else:
+                assert abs(float(dist[j]) - float(ed)) <= 1e-5 * abs(float(ed)) + 1e-7, (j, dist[j], ed)
+        for j in range(3):
+            exp = oracle.all_distances(rows, q[j], 3, 37, metric)
+            if metric == CHI2:
+                assert np.array_equal(bits(allq[j]), bits(exp))
+            else:
+                assert np.allclose(allq[j], exp, rtol=1e-5, atol=1e-7)
+
+
 def test_handles_release_their_device_memory(fir):
     """Create / use / destroy every kind of handle repeatedly: free device memory ends where it started."""
     import torch
