@@ -285,6 +285,7 @@ struct fir_cls {
     double* sums = nullptr; size_t sums_cap = 0;
     double* scores = nullptr; size_t scores_cap = 0;
     int32_t* best = nullptr; size_t best_cap = 0;
+    void* pin = nullptr;              // pinned, device-visible staging of small calls: queries in, classes (+ chunk counts) out
     double total_training_size = 0;   // 0: nt. PNNwithClustering keeps the full size as denominator (classification.cpp:390,393)
 };
 
@@ -321,17 +322,43 @@ int cls_grow(T*& p, size_t& cap, size_t need) {
 }
 
 // distance sums of all qb queries into c->sums (device), in passes of kQB queries
+// Small calls (what a per-image predict() loop makes): the queries are read from, and the class ids written to, pinned
+// host memory by the kernels themselves -- no copy engine, one synchronisation per call.
+constexpr size_t kPinQueryBytes = 256 * 1024;
+constexpr int kPinResults = 4096;                 // int32 slots: classes [0, 2048), chunk counts [2048, 4096)
+bool cls_small(const fir_cls* c, int32_t qb) { return (size_t)qb * c->d * sizeof(double) <= kPinQueryBytes && qb <= kPinResults / 2; }
+int cls_ensure_pin(fir_cls* c) {
+    if (c->pin) return FIR_OK;
+    CLS_HIP(hipHostMalloc(&c->pin, kPinQueryBytes + kPinResults * sizeof(int32_t), hipHostMallocDefault));
+    return FIR_OK;
+}
+int32_t* cls_pin_results(fir_cls* c) { return (int32_t*)((char*)c->pin + kPinQueryBytes); }
+// -> device-visible pointer to the staged queries
+int cls_stage_queries(fir_cls* c, const double* queries, int32_t qb, const double** d_q) {
+    int rc;
+    if (cls_small(c, qb)) {
+        if ((rc = cls_ensure_pin(c))) return rc;
+        std::memcpy(c->pin, queries, (size_t)qb * c->d * sizeof(double));
+        *d_q = (const double*)c->pin;
+        return FIR_OK;
+    }
+    if ((rc = cls_grow(c->dq, c->dq_cap, (size_t)qb * c->d))) return rc;
+    CLS_HIP(hipMemcpyAsync(c->dq, queries, (size_t)qb * c->d * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    *d_q = c->dq;
+    return FIR_OK;
+}
+
 int cls_scan(fir_cls* c, const double* queries, int32_t qb) {
     int rc;
-    if ((rc = cls_grow(c->dq, c->dq_cap, (size_t)qb * c->d))) return rc;
+    const double* dq = nullptr;
+    if ((rc = cls_stage_queries(c, queries, qb, &dq))) return rc;
     if ((rc = cls_grow(c->sums, c->sums_cap, (size_t)qb * std::max<int64_t>(c->nt, 1)))) return rc;
-    CLS_HIP(hipMemcpyAsync(c->dq, queries, (size_t)qb * c->d * sizeof(double), hipMemcpyHostToDevice, c->stream));
     const int kk = c->dp2 * 2;
     const int waves = (int)std::min<int64_t>(std::max<int64_t>((c->tiles + 3) / 4 * 4, 4), (int64_t)c->cus * 16);
     for (int q0 = 0; q0 < qb; q0 += kQB) {
         const int nq = std::min(kQB, qb - q0);
         hipLaunchKernelGGL(k_cls_prep_queries, dim3((kk * kQB + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream,
-                           c->dq + (size_t)q0 * c->d, nq, c->d, c->dp2, c->avg, c->qn);
+                           dq + (size_t)q0 * c->d, nq, c->d, c->dp2, c->avg, c->qn);
         hipLaunchKernelGGL(k_cls_scan, dim3(waves / 4), dim3(kBlock), 0, c->stream, c->gal2, c->qn, c->nt, (int)c->tiles, c->dp2,
                            c->d, waves, nq, 0, c->dp2, c->sums + (size_t)q0 * c->nt);
     }
@@ -415,6 +442,7 @@ int fir_cls_destroy(fir_cls* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->gal2); (void)hipFree(c->avg); (void)hipFree(c->class_off); (void)hipFree(c->dq); (void)hipFree(c->qn);
     (void)hipFree(c->sums); (void)hipFree(c->scores); (void)hipFree(c->best);
+    if (c->pin) (void)hipHostFree(c->pin);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return FIR_OK;
@@ -445,11 +473,14 @@ int fir_cls_pnn_predict(fir_cls* c, const double* queries, int32_t qb, double va
     const double denom = (double)(2 * (size_t)c->d) * var;                       // 2*num_of_cont_features*var, :213
     hipLaunchKernelGGL(k_cls_pnn, dim3(c->num_classes, qb), dim3(64), 0, c->stream, c->sums, c->class_off, c->nt, c->num_classes, denom,
                        c->total_training_size > 0 ? c->total_training_size : (double)c->nt, c->scores);
-    hipLaunchKernelGGL(k_cls_argbest, dim3(qb), dim3(64), 0, c->stream, c->scores, c->class_off, c->num_classes, 0, c->best);
+    const bool small = cls_small(c, qb);
+    int32_t* dbest = small ? cls_pin_results(c) : c->best;
+    hipLaunchKernelGGL(k_cls_argbest, dim3(qb), dim3(64), 0, c->stream, c->scores, c->class_off, c->num_classes, 0, dbest);
     CLS_HIP(hipGetLastError());
     if (scores) CLS_HIP(hipMemcpyAsync(scores, c->scores, (size_t)qb * c->num_classes * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    if (best_class) CLS_HIP(hipMemcpyAsync(best_class, c->best, (size_t)qb * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    if (best_class && !small) CLS_HIP(hipMemcpyAsync(best_class, c->best, (size_t)qb * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     CLS_HIP(hipStreamSynchronize(c->stream));
+    if (best_class && small) std::memcpy(best_class, dbest, (size_t)qb * sizeof(int32_t));
     return FIR_OK;
 }
 
@@ -463,27 +494,36 @@ int fir_cls_pnn_predict_seq(fir_cls* c, const double* queries, int32_t qb, doubl
     const int nchunks = (c->d + 31) / 32;
     const int64_t ntp = std::max<int64_t>(c->nt, 1);
     int rc;
-    if ((rc = cls_grow(c->dq, c->dq_cap, (size_t)qb * c->d))) return rc;
+    const double* dq = nullptr;
+    if ((rc = cls_stage_queries(c, queries, qb, &dq))) return rc;
     if ((rc = cls_grow(c->sums, c->sums_cap, (size_t)(nchunks + 1) * kQB * ntp))) return rc;   // chunk sums + running sums
     if ((rc = cls_grow(c->best, c->best_cap, (size_t)2 * std::max(qb, kQB)))) return rc;
-    CLS_HIP(hipMemcpyAsync(c->dq, queries, (size_t)qb * c->d * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    const bool small = cls_small(c, qb);
+    int32_t* dbest = small ? cls_pin_results(c) : c->best;
+    int32_t* dchunks = small ? cls_pin_results(c) + kPinResults / 2 : c->best + std::max(qb, kQB);
     const int kk = c->dp2 * 2;
     const int waves = (int)std::min<int64_t>(std::max<int64_t>((c->tiles + 3) / 4 * 4, 4), (int64_t)c->cus * 16);
     double* run = c->sums + (size_t)nchunks * kQB * ntp;
     for (int q0 = 0; q0 < qb; q0 += kQB) {
         const int nq = std::min(kQB, qb - q0);
         hipLaunchKernelGGL(k_cls_prep_queries, dim3((kk * kQB + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream,
-                           c->dq + (size_t)q0 * c->d, nq, c->d, c->dp2, c->avg, c->qn);
+                           dq + (size_t)q0 * c->d, nq, c->d, c->dp2, c->avg, c->qn);
         for (int ch = 0; ch < nchunks; ++ch)
             hipLaunchKernelGGL(k_cls_scan, dim3(waves / 4), dim3(kBlock), 0, c->stream, c->gal2, c->qn, c->nt, (int)c->tiles, c->dp2,
                                c->d, waves, nq, ch * 16, std::min(c->dp2, (ch + 1) * 16), c->sums + (size_t)ch * nq * c->nt);
         hipLaunchKernelGGL(k_cls_pnn_seq, dim3(nq), dim3(kBlock), (size_t)c->num_classes * 12, c->stream, c->sums, nq, nchunks, run,
-                           c->class_off, c->nt, c->num_classes, c->d, var, c->best + q0, c->best + std::max(qb, kQB) + q0);
+                           c->class_off, c->nt, c->num_classes, c->d, var, dbest + q0, dchunks + q0);
     }
     CLS_HIP(hipGetLastError());
-    CLS_HIP(hipMemcpyAsync(best_class, c->best, (size_t)qb * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    if (chunks_out) CLS_HIP(hipMemcpyAsync(chunks_out, c->best + std::max(qb, kQB), (size_t)qb * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    if (!small) {
+        CLS_HIP(hipMemcpyAsync(best_class, dbest, (size_t)qb * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        if (chunks_out) CLS_HIP(hipMemcpyAsync(chunks_out, dchunks, (size_t)qb * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    }
     CLS_HIP(hipStreamSynchronize(c->stream));
+    if (small) {
+        std::memcpy(best_class, dbest, (size_t)qb * sizeof(int32_t));
+        if (chunks_out) std::memcpy(chunks_out, dchunks, (size_t)qb * sizeof(int32_t));
+    }
     return FIR_OK;
 }
 
@@ -498,10 +538,13 @@ int fir_cls_knn_predict(fir_cls* c, const double* queries, int32_t qb, int32_t k
     if ((rc = cls_grow(c->scores, c->scores_cap, (size_t)qb * c->num_classes))) return rc;
     if ((rc = cls_grow(c->best, c->best_cap, (size_t)qb))) return rc;
     hipLaunchKernelGGL(k_cls_knn_kth, dim3(c->num_classes, qb), dim3(64), 0, c->stream, c->sums, c->class_off, c->nt, c->num_classes, c->d, k, c->scores);
-    hipLaunchKernelGGL(k_cls_argbest, dim3(qb), dim3(64), 0, c->stream, c->scores, c->class_off, c->num_classes, 1, c->best);
+    const bool small = cls_small(c, qb);
+    int32_t* dbest = small ? cls_pin_results(c) : c->best;
+    hipLaunchKernelGGL(k_cls_argbest, dim3(qb), dim3(64), 0, c->stream, c->scores, c->class_off, c->num_classes, 1, dbest);
     CLS_HIP(hipGetLastError());
-    CLS_HIP(hipMemcpyAsync(best_class, c->best, (size_t)qb * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    if (!small) CLS_HIP(hipMemcpyAsync(best_class, c->best, (size_t)qb * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     CLS_HIP(hipStreamSynchronize(c->stream));
+    if (small) std::memcpy(best_class, dbest, (size_t)qb * sizeof(int32_t));
     return FIR_OK;
 }
 
