@@ -288,7 +288,7 @@ def pmc_traffic(args, n, d, world):
             cmd += ["--qpp", str(args.qpp)]
         try:
             subprocess.run(cmd, cwd=out_dir, env=dict(os.environ, TMPDIR=out_dir), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
-                           timeout=240, check=True)
+                           timeout=150, check=True)
             vals = []
             for f in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(f)):
