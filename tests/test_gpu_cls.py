@@ -35,7 +35,9 @@ def test_reference_predictions_reproduced(fir, oracle):
         np.testing.assert_allclose(scores[i], es, rtol=1e-12, atol=0)
 
 
-@pytest.mark.parametrize("seed,n,d,ncls,frac", [(3, 500, 64, 10, 0.5), (4, 1200, 257, 25, 0.4), (5, 200, 3, 4, 0.7), (6, 130, 2100, 5, 0.5)])
+@pytest.mark.parametrize("seed,n,d,ncls,frac", [(3, 500, 64, 10, 0.5), (4, 1200, 257, 25, 0.4), (5, 200, 3, 4, 0.7), (6, 130, 2100, 5, 0.5),
+                                                  (7, 135, 1, 3, 0.5), (8, 129, 33, 2, 0.5), (9, 6000, 31, 40, 0.9), (10, 20000, 96, 101, 0.95),
+                                                  (11, 300, 640, 7, 0.43)])
 def test_matches_oracle_on_fresh_data(fir, oracle, seed, n, d, ncls, frac):
     x, lab, _ = gc.cls_case(seed=seed, n=n, d=d, n_classes=ncls)
     rng = np.random.default_rng(seed)
