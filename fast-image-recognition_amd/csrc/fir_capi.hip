@@ -343,6 +343,14 @@ int topk_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start, 
     // batches over a large gallery: threshold from a row sample, append scan at the speed of the top-1 scan, K smallest
     // of each candidate list (exact distances throughout); anything it cannot certify falls back to the scan below
     if (allow_lists && g->tiles_limit == 0 && qb >= 8 && g->n >= 65536) {
+        constexpr int kListBatch = 1024;           // candidate lists are 32 KiB per query: bounded scratch for any qb
+        if (qb > kListBatch) {
+            for (int q0 = 0; q0 < qb; q0 += kListBatch) {
+                const int rc3 = topk_dev(g, d_queries + (size_t)q0 * g->d, std::min(kListBatch, qb - q0), start, end, k, d_keys + (size_t)q0 * k, st);
+                if (rc3) return rc3;
+            }
+            return FIR_OK;
+        }
         const int rc2 = topk_lists_dev(g, d_queries, qb, start, end, k, d_keys, st);
         if (rc2 != FIR_ERR_STATE) return rc2;      // FIR_ERR_STATE: not certified -> the register-list scan answers
     }

@@ -327,6 +327,10 @@ def test_topk_candidate_lists_on_large_galleries(fir, oracle):
         ei, ed = oracle.topk(rows, q[j], 0, d, k, L2)
         assert np.array_equal(idx[j], ei), j
         assert_bits_equal(dist[j], ed)
+    big_q = np.tile(q, (120, 1))[:1100]          # more queries than one candidate-list batch (1024)
+    with fir.Gallery(rows, None, L2, 0) as g:
+        bidx, bdist = g.search_topk(big_q, k)
+    assert np.array_equal(bidx[:11], idx) and np.array_equal(bidx[1089:1100], idx[:11]) and np.array_equal(bits(bdist[:11]), bits(dist))
     far = np.full_like(q, 3000.0)                # nothing within 100000: every slot stays -1 / 100000
     with fir.Gallery(rows, None, L2, 0) as g:
         idx, dist = g.search_topk(far, k)
