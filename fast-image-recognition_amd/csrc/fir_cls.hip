@@ -348,6 +348,12 @@ int cls_stage_queries(fir_cls* c, const double* queries, int32_t qb, const doubl
     return FIR_OK;
 }
 
+// Queries per internal batch: the distance table (qb x nt doubles) stays under 1 GiB whatever the caller's batch is.
+int32_t cls_batch(const fir_cls* c) {
+    const int64_t per_query = std::max<int64_t>(c->nt, 1) * (int64_t)sizeof(double);
+    return (int32_t)std::max<int64_t>(kQB, std::min<int64_t>(1 << 20, ((int64_t)1 << 30) / per_query / kQB * kQB));
+}
+
 int cls_scan(fir_cls* c, const double* queries, int32_t qb) {
     int rc;
     const double* dq = nullptr;
@@ -464,6 +470,15 @@ int fir_cls_pnn_predict(fir_cls* c, const double* queries, int32_t qb, double va
     if (!c || (qb > 0 && !queries)) return cls_fail(FIR_ERR_ARG, "NULL argument");
     if (qb < 0) return cls_fail(FIR_ERR_ARG, "qb < 0");
     if (qb == 0) return FIR_OK;
+    if (qb > cls_batch(c)) {
+        const int32_t b = cls_batch(c);
+        for (int32_t q0 = 0; q0 < qb; q0 += b) {
+            const int rc0 = fir_cls_pnn_predict(c, queries + (size_t)q0 * c->d, std::min(b, qb - q0), var,
+                                                scores ? scores + (size_t)q0 * c->num_classes : nullptr, best_class ? best_class + q0 : nullptr);
+            if (rc0) return rc0;
+        }
+        return FIR_OK;
+    }
     CLS_HIP(hipSetDevice(c->device));
     if (var <= 0) { var = 0.00002; if (c->d > 2000) var /= 10; }                // classification.cpp:190-193
     int rc = cls_scan(c, queries, qb);
@@ -532,6 +547,14 @@ int fir_cls_knn_predict(fir_cls* c, const double* queries, int32_t qb, int32_t k
     if (qb < 0) return cls_fail(FIR_ERR_ARG, "qb < 0");
     if (k < 1 || k > kKMax) return cls_fail(FIR_ERR_ARG, "k=%d outside [1,%d]", k, kKMax);
     if (qb == 0) return FIR_OK;
+    if (qb > cls_batch(c)) {
+        const int32_t b = cls_batch(c);
+        for (int32_t q0 = 0; q0 < qb; q0 += b) {
+            const int rc0 = fir_cls_knn_predict(c, queries + (size_t)q0 * c->d, std::min(b, qb - q0), k, best_class + q0);
+            if (rc0) return rc0;
+        }
+        return FIR_OK;
+    }
     CLS_HIP(hipSetDevice(c->device));
     int rc = cls_scan(c, queries, qb);
     if (rc) return rc;

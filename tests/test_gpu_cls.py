@@ -65,6 +65,27 @@ def test_matches_oracle_on_fresh_data(fir, oracle, seed, n, d, ncls, frac):
             assert pnn[i] == ep
 
 
+def test_batches_larger_than_the_internal_distance_table(fir, oracle):
+    """200 000 training rows: the qb x nt distance table is capped at 1 GiB, so 700 queries are answered in two internal
+    batches -- same answers as asking for them in pieces, and as the oracle on a sample."""
+    rng = np.random.default_rng(12)
+    nt, d, ncls = 200_000, 4, 5
+    x = rng.random((nt, d))
+    lab = np.sort(rng.integers(0, ncls, nt)).astype(np.int32)
+    x += lab[:, None] * 0.15
+    q = rng.random((700, d)) + rng.integers(0, ncls, 700)[:, None] * 0.15
+    avg = x.mean(0)
+    with fir.ClsModel(x, lab, ncls, avg, 0) as m:
+        knn = m.knn_predict(q, 3)
+        pnn, _ = m.pnn_predict(q)
+        knn_parts = np.concatenate([m.knn_predict(q[:100], 3), m.knn_predict(q[100:], 3)])
+        pnn_parts = np.concatenate([m.pnn_predict(q[:300])[0], m.pnn_predict(q[300:])[0]])
+    assert np.array_equal(knn, knn_parts) and np.array_equal(pnn, pnn_parts)
+    for i in (0, 1, 350, 667, 668, 669, 699):
+        assert knn[i] == oracle.knn_predict(x, lab, avg, ncls, q[i], 3)[0], i
+    assert np.mean(knn == pnn) > 0.5
+
+
 def test_classes_smaller_than_k_and_bad_arguments(fir, oracle):
     x, lab, ncls = gc.cls_case(seed=9, n=40, d=16, n_classes=8)        # 5 rows per class, k = 8 never reached
     order = np.argsort(lab, kind="stable")
