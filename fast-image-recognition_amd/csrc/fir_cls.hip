@@ -68,15 +68,20 @@ __global__ void __launch_bounds__(kBlock) k_cls_prep_queries(const double* __res
 }
 
 // sums[q][row] = sum_k ((g-avg) - (q-avg))^2, sequential in k.
-// c0, c1: double2-chunk range [c0, c1) of the features to sum (whole scan: 0, dp2).
+// lo, hi: double2-chunk range [lo, hi) of the features (whole scan: 0, dp2). cstep < hi - lo: the range is cut into
+// consecutive sub-ranges of cstep chunks, each a fresh sum written `sub_stride` doubles after the previous one (the
+// 32-feature chunks of the sequential PNN, classification.cpp:245-262, from ONE pass over the training rows).
 __global__ void __launch_bounds__(kBlock) k_cls_scan(const double2* __restrict__ gal2, const double* __restrict__ qn, int64_t nt,
-                                                      int tiles, int dp2, int d, int waves, int nq, int c0, int c1,
-                                                      double* __restrict__ sums) {
+                                                      int tiles, int dp2, int d, int waves, int nq, int lo, int hi,
+                                                      double* __restrict__ sums_base, int cstep, int64_t sub_stride) {
     const int lane = threadIdx.x & 63;
     const int gw = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     sdouble_p qc = (sdouble_p)(uintptr_t)qn;
     for (int t = gw; t < tiles; t += waves) {
-        const double2* p = gal2 + (size_t)t * dp2 * 64 + lane;
+      const double2* p = gal2 + (size_t)t * dp2 * 64 + lane;
+      double* sums = sums_base;
+      for (int c0 = lo; c0 < hi; c0 += cstep, sums += sub_stride) {
+        const int c1 = min(hi, c0 + cstep);
         double acc[kQB];
 #pragma unroll
         for (int q = 0; q < kQB; ++q) acc[q] = 0.0;
@@ -122,6 +127,7 @@ __global__ void __launch_bounds__(kBlock) k_cls_scan(const double2* __restrict__
             for (int q = 0; q < kQB; ++q)
                 if (q < nq) sums[(size_t)q * nt + row] = acc[q];
         }
+      }
     }
 }
 
@@ -366,7 +372,7 @@ int cls_scan(fir_cls* c, const double* queries, int32_t qb) {
         hipLaunchKernelGGL(k_cls_prep_queries, dim3((kk * kQB + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream,
                            dq + (size_t)q0 * c->d, nq, c->d, c->dp2, c->avg, c->qn);
         hipLaunchKernelGGL(k_cls_scan, dim3(waves / 4), dim3(kBlock), 0, c->stream, c->gal2, c->qn, c->nt, (int)c->tiles, c->dp2,
-                           c->d, waves, nq, 0, c->dp2, c->sums + (size_t)q0 * c->nt);
+                           c->d, waves, nq, 0, c->dp2, c->sums + (size_t)q0 * c->nt, c->dp2, (int64_t)0);
     }
     CLS_HIP(hipGetLastError());
     return FIR_OK;
@@ -523,9 +529,9 @@ int fir_cls_pnn_predict_seq(fir_cls* c, const double* queries, int32_t qb, doubl
         const int nq = std::min(kQB, qb - q0);
         hipLaunchKernelGGL(k_cls_prep_queries, dim3((kk * kQB + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream,
                            dq + (size_t)q0 * c->d, nq, c->d, c->dp2, c->avg, c->qn);
-        for (int ch = 0; ch < nchunks; ++ch)
-            hipLaunchKernelGGL(k_cls_scan, dim3(waves / 4), dim3(kBlock), 0, c->stream, c->gal2, c->qn, c->nt, (int)c->tiles, c->dp2,
-                               c->d, waves, nq, ch * 16, std::min(c->dp2, (ch + 1) * 16), c->sums + (size_t)ch * nq * c->nt);
+        // all 32-feature chunk sums (16 double2 chunks each) from one pass: chunk ch lands at sums + ch * nq * nt
+        hipLaunchKernelGGL(k_cls_scan, dim3(waves / 4), dim3(kBlock), 0, c->stream, c->gal2, c->qn, c->nt, (int)c->tiles, c->dp2, c->d, waves, nq,
+                           0, c->dp2, c->sums, 16, (int64_t)nq * c->nt);
         hipLaunchKernelGGL(k_cls_pnn_seq, dim3(nq), dim3(kBlock), (size_t)c->num_classes * 12, c->stream, c->sums, nq, nchunks, run,
                            c->class_off, c->nt, c->num_classes, c->d, var, dbest + q0, dchunks + q0);
     }
