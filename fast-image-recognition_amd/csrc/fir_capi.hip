@@ -516,12 +516,23 @@ int subranges_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t st
     return FIR_OK;
 }
 
+// hipGetDeviceCount, the first time on the private random state of fir_runtime_init_ (it starts the runtime).
+hipError_t device_count(int* cnt) {
+    static bool started = false;
+    if (started) return hipGetDeviceCount(cnt);
+    char state[256];
+    char* caller = initstate(1u, state, sizeof state);
+    const hipError_t e = hipGetDeviceCount(cnt);
+    setstate(caller);
+    started = true;
+    return e;
+}
+
 int set_device(int device) {
     int cnt = 0;
-    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) return fail(FIR_ERR_NODEVICE, "no HIP device visible");
+    if (device_count(&cnt) != hipSuccess || cnt <= 0) return fail(FIR_ERR_NODEVICE, "no HIP device visible");
     if (device < 0 || device >= cnt) return fail(FIR_ERR_NODEVICE, "device %d out of range (%d visible)", device, cnt);
-    FIR_HIP(hipSetDevice(device));
-    return FIR_OK;
+    return fir_runtime_init_(device);
 }
 
 int gallery_alloc(int64_t n, int32_t d, int32_t metric, int32_t device, fir_gallery** out) {
@@ -582,6 +593,38 @@ int fir_gallery_view_(fir_gallery* g, fir_gallery_view* out) {
     out->cls = g->cls; out->stream = g->stream;
     return FIR_OK;
 }
+__global__ void k_runtime_warmup(int* p) {
+    if (p && threadIdx.x == 0 && blockIdx.x == 0) *p = 1;
+}
+int fir_runtime_init_(int device) {
+    static bool touched[64] = {};
+    if (device >= 0 && device < 64 && !touched[device]) {
+        char state[256];
+        char* caller = initstate(1u, state, sizeof state);      // the runtime's start-up draws from here ...
+        hipError_t e = hipSetDevice(device);
+        void* p = nullptr;
+        hipStream_t st = nullptr;
+        hipDeviceProp_t prop;
+        if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
+        if (e == hipSuccess) e = hipMalloc(&p, 256);             // forces the context ...
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+        if (e == hipSuccess) {                                   // ... the code object load, a queue, a copy in each direction
+            int h = 0;
+            hipLaunchKernelGGL(k_runtime_warmup, dim3(1), dim3(64), 0, st, (int*)p);
+            e = hipMemcpyAsync(&h, p, sizeof h, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(p, &h, sizeof h, hipMemcpyHostToDevice, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+        }
+        if (st) (void)hipStreamDestroy(st);
+        if (p) (void)hipFree(p);
+        setstate(caller);                                        // ... and the caller's rand() stream continues where it was
+        if (e != hipSuccess) return fail(FIR_ERR_HIP, "device %d start-up failed: %s", device, hipGetErrorString(e));
+        touched[device] = true;
+        return FIR_OK;
+    }
+    FIR_HIP(hipSetDevice(device));
+    return FIR_OK;
+}
 int fir_gallery_scratch_(fir_gallery* g, int slot, size_t bytes, void** out) {
     if (!g || !out || slot < 0 || slot >= 16) return fail(FIR_ERR_ARG, "bad scratch request");
     if (bytes > g->scratch_cap[slot]) {
@@ -620,13 +663,13 @@ int fir_version(void) { return 100; }
 
 int fir_device_count(void) {
     int cnt = 0;
-    if (hipGetDeviceCount(&cnt) != hipSuccess) return 0;
+    if (device_count(&cnt) != hipSuccess) return 0;
     return cnt;
 }
 
 int fir_device_info(int32_t device, char* name, int32_t cap, int32_t* cus, int64_t* hbm_bytes) {
     int cnt = 0;
-    if (hipGetDeviceCount(&cnt) != hipSuccess || device < 0 || device >= cnt)
+    if (device_count(&cnt) != hipSuccess || device < 0 || device >= cnt)
         return fail(FIR_ERR_NODEVICE, "device %d not available", device);
     hipDeviceProp_t prop;
     FIR_HIP(hipGetDeviceProperties(&prop, device));
@@ -639,7 +682,7 @@ int fir_device_info(int32_t device, char* name, int32_t cap, int32_t* cus, int64
 int fir_device_peak_hbm_gbs(int32_t device, double* gbs) {
     int cnt = 0;
     if (!gbs) return fail(FIR_ERR_ARG, "gbs is NULL");
-    if (hipGetDeviceCount(&cnt) != hipSuccess || device < 0 || device >= cnt)
+    if (device_count(&cnt) != hipSuccess || device < 0 || device >= cnt)
         return fail(FIR_ERR_NODEVICE, "device %d not available", device);
     hipDeviceProp_t prop;
     FIR_HIP(hipGetDeviceProperties(&prop, device));

@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "../../include/fir_amd.h"
+#include "fir_internal.h"
 
 namespace {
 
@@ -398,9 +399,10 @@ int fir_cls_create(const double* train_rows, int64_t nt, int32_t d, const int32_
     }
     for (int i = 0; i < num_classes; ++i) off[(size_t)i + 1] += off[(size_t)i];
     int cnt = 0;
-    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) return cls_fail(FIR_ERR_NODEVICE, "no HIP device visible");
+    cnt = fir_device_count();        // the guarded first touch of the runtime (fir_runtime_init_)
+    if (cnt <= 0) return cls_fail(FIR_ERR_NODEVICE, "no HIP device visible");
     if (device < 0 || device >= cnt) return cls_fail(FIR_ERR_NODEVICE, "device %d out of range (%d visible)", device, cnt);
-    CLS_HIP(hipSetDevice(device));
+    { const int rc0 = fir_runtime_init_(device); if (rc0) return rc0; }
     hipDeviceProp_t prop;
     CLS_HIP(hipGetDeviceProperties(&prop, device));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)

@@ -315,9 +315,10 @@ int fir_fpnn_train(const double* train_rows, int64_t nt, int32_t d, const int32_
     if (J <= 3) J = 3;
     if (J > kMaxJ) return fpnn_fail(FIR_ERR_ARG, "J=%d harmonics exceed the supported %d", J, kMaxJ);
     int cnt = 0;
-    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) return fpnn_fail(FIR_ERR_NODEVICE, "no HIP device visible");
+    cnt = fir_device_count();        // the guarded first touch of the runtime (fir_runtime_init_)
+    if (cnt <= 0) return fpnn_fail(FIR_ERR_NODEVICE, "no HIP device visible");
     if (device < 0 || device >= cnt) return fpnn_fail(FIR_ERR_NODEVICE, "device %d out of range (%d visible)", device, cnt);
-    FPNN_HIP(hipSetDevice(device));
+    { const int rc0 = fir_runtime_init_(device); if (rc0) return rc0; }
     hipDeviceProp_t prop;
     FPNN_HIP(hipGetDeviceProperties(&prop, device));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <iostream>
 
 #include "fir_classification.h"
 
@@ -15,6 +16,7 @@ static void print_vec(const char* key, const std::vector<int>& v, bool comma) {
 }
 
 int main(int argc, char** argv) {
+    std::cout.rdbuf(nullptr);   // stdout carries this driver's JSON (printf); the loader's reference-style cout lines are dropped
     if (argc >= 5 && !std::strcmp(argv[1], "--dump")) {       // --dump <features.txt> <features_count> <out.bin>: loader only, no GPU
         load_image_dataset(argv[2], std::atoi(argv[3]));
         fir::ClassificationState& st = fir::classification_state();

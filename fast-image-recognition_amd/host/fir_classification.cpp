@@ -8,6 +8,7 @@
 #include <cstring>
 #include <cstdlib>
 #include <fstream>
+#include <iostream>
 #include <map>
 #include <sstream>
 
@@ -28,6 +29,7 @@ void load_image_dataset(const std::string& features_file, int features_count) {
     st.dataset.clear(); st.tmp_dataset.clear(); st.indices.clear(); st.training_set.clear(); st.test_set.clear();
     st.num_of_cont_features = (size_t)features_count;
     st.num_of_classes = 0;
+    std::cout << features_file << std::endl;                               // classification.cpp:798-799
     std::ifstream in(features_file);
     if (!in) return;
     std::map<std::string, int> class_id;                                   // classification.cpp:803
@@ -81,6 +83,7 @@ void load_image_dataset(const std::string& features_file, int features_count) {
     st.indices.assign(st.num_of_classes, std::vector<size_t>());
     for (size_t i = 0; i < st.dataset.size(); ++i) st.indices[(size_t)st.dataset[i].output].push_back(i);
     st.num_of_cont_features_orig = st.num_of_cont_features;               // classification.cpp:995
+    std::cout << st.num_of_classes << ' ' << st.num_of_cont_features << ' ' << st.dataset.size() << std::endl;   // :859-860
 }
 
 void split_train_test(double fraction, bool shuffle) {

@@ -49,6 +49,10 @@ void set_classification_device(int device);
 
 // classification.cpp:795-862 (reads `features_file`; the reference hard-wires FEATURES_FILE_NAME).
 void load_image_dataset(const std::string& features_file, int features_count = FEATURES_COUNT);
+#ifdef DB_H
+// the reference's call form (classification.cpp:795,992): reads FEATURES_FILE_NAME of its db.h, when that header came first
+inline void load_image_dataset() { load_image_dataset(FEATURES_FILE_NAME, FEATURES_COUNT); }
+#endif
 // classification.cpp:942-990. `shuffle` = false keeps file order inside each class (the reference always shuffles).
 void split_train_test(double fraction, bool shuffle = true);
 

@@ -151,6 +151,10 @@ int loadImages(ImagesDatabase& imagesDb, std::string features_file, std::unorder
         const float* src = &packed.rows[(size_t)r * FEATURES_COUNT];
         imagesDb[first_new + (size_t)packed.class_no[(size_t)r]].emplace_back(src, src + FEATURES_COUNT);
     }
+    double avg_count = 0;                                            // db_features.cpp:107-112
+    for (size_t i = 0; i < imagesDb.size(); ++i) avg_count += (double)imagesDb[i].size();
+    avg_count /= (double)imagesDb.size();
+    std::cout << "total size=" << imagesDb.size() << " totalImages=" << total << " avg_count=" << avg_count << std::endl;
     return (int)total;
 }
 

@@ -27,7 +27,9 @@
 #ifndef FIR_FRACTION
 #define FIR_FRACTION 0.03
 #endif
+#ifndef DB_H   // the reference's own db.h (pure configuration, qt_cpp/db.h:1-2), when included first, already defines FRACTION
 const double FRACTION = FIR_FRACTION;
+#endif
 
 // qt_cpp/db_features.h:12 -- compile-time metric switch, kept as a macro and mapped to the
 // runtime enum: define FIR_USE_CHI2 or FIR_USE_KL to get the other arms of db_features.cpp:25-39.

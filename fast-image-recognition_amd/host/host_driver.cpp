@@ -19,7 +19,9 @@ int main(int argc, char** argv) {
     if (argc < 2) { std::fprintf(stderr, "usage: host_driver <features.txt> [max_features ...]\n"); return 2; }
     ImagesDatabase total;
     std::unordered_map<std::string, int> person2index;
+    std::streambuf* cout_buf = std::cout.rdbuf(nullptr);   // the shim prints what the reference prints (std::cout); stdout carries JSON here
     const int n = loadImages(total, argv[1], person2index);
+    std::cout.rdbuf(cout_buf);
     std::vector<ImageInfo> dbImages, testImages;
     getTrainingAndTestImages(total, dbImages, testImages, /*randomize=*/false);
     std::printf("{\n\"images\": %d, \"classes\": %zu, \"gallery\": %zu, \"queries\": %zu,\n", n, total.size(), dbImages.size(), testImages.size());

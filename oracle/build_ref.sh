@@ -69,6 +69,78 @@ cls_tu() {
     echo '#include "ref_wrap_cls.inc"'
 }
 
+# The reference's own experiment harness (testRecognitionMethod + testRecognition, ImageTesting.cpp:439-501,503-548, minus the
+# three OpenCV classifiers of :536-538), twice:
+#   harness_reference  with the reference's own classes (ImageTesting.cpp:35-288) and db_features.cpp -- pure CPU
+#   harness_dropin     the same harness lines against THIS repo's host shim: db.h stays the reference's (configuration only),
+#                      "db_features.h" resolves to host/compat, line 33 (the file-static counter) becomes the shim's counter,
+#                      lines 35-288 become one #include -- exactly the edit INTEGRATION.md describes
+harness_tu() {   # $1 = reference | dropin
+    echo "#include \"$REF/db.h\""
+    sed -n '1,18p;21,32p' "$REF/ImageTesting.cpp"            # the includes, `using namespace std`, print_endl (not :19-20, the two project headers)
+    if [ "$1" = reference ]; then
+        echo "#include \"$REF/db_features.h\""
+        sed -n '1,162p;319,335p' "$REF/db_features.cpp" | grep -v '^#include "db'
+        sed -n '33,288p' "$REF/ImageTesting.cpp"
+    else
+        echo '#include "compat/db_features.h"'
+        echo '#include "fir_classifiers.h"                          /* was: the classes of ImageTesting.cpp:35-288 */'
+        echo '#define num_of_unreliable fir::num_of_unreliable()   /* was: static int num_of_unreliable (ImageTesting.cpp:33) */'
+    fi
+    sed -n '439,501p;503,535p;539,548p' "$REF/ImageTesting.cpp"
+    echo 'int main() { testRecognition(); return 0; }'
+}
+# testANN (ann.cpp:24-81, minus the FLANN method of :56): BruteForce and DirectedEnumeration over imageCountToCheck ratios.
+ann_harness_tu() {   # $1 = reference | dropin
+    echo "#include \"$REF/db.h\""
+    if [ "$1" = reference ]; then
+        echo "#include \"$REF/db_features.h\""
+        sed -n '1,162p;319,335p' "$REF/db_features.cpp" | grep -v '^#include "db'
+        sed -n '1,47p;61,100p' "$REF/ann.h"
+        echo '#endif'
+        sed -n '3,22p' "$REF/ann.cpp"
+        sed -n '24,55p;57,81p;84,126p;268,507p' "$REF/ann.cpp"
+    else
+        echo '#include "compat/db_features.h"'
+        echo '#include "compat/ann.h"                               /* was: ann.h and the classes of ann.cpp:84-126,268-507 */'
+        sed -n '3,22p' "$REF/ann.cpp"
+        sed -n '24,55p;57,81p' "$REF/ann.cpp"
+    fi
+    echo 'int main() { testANN(); return 0; }'
+}
+# testClassification1 (classification.cpp:991-1089, minus the three OpenCV classifiers of :1009-1011 and the OpenCV PCA
+# projection of :1032-1034): kNN-1/3, PNN, PNN with clustering, FPNN x2, sequential PNN, sequential FPNN x2 over six
+# training fractions, two random splits each.
+cls_harness_tu() {   # $1 = reference | dropin
+    if [ "$1" = reference ]; then
+        sed -n '1,10p;19,428p;617,862p;942,990p' "$REF/classification.cpp"
+    else
+        echo "#include \"$REF/db.h\""
+        sed -n '1,9p;20,28p' "$REF/classification.cpp"      # the std includes, `using namespace std`, print_endl
+        echo '#include "fir_classification.h"                  /* was: the classes and loaders of classification.cpp:31-990 */'
+        echo '#include "compat/classification_globals.h"       /* was: the file-scope state of classification.cpp:53-62 */'
+        sed -n '33p' "$REF/classification.cpp"                # NO_PCA_FEATURES
+    fi
+    sed -n '991,1008p;1012,1031p;1035,1089p' "$REF/classification.cpp"
+    echo 'int main() { testClassification1(); return 0; }'
+}
+HOSTDIR=$HERE/../fast-image-recognition_amd/host
+cls_harness_tu reference | $CXX -std=c++11 -O2 -w -I"$REF" -include cmath -include cfloat -include cstdint -x c++ - -o "$OUT/harness_cls_reference"
+if [ -f "$HOSTDIR/../libfir_host.so" ]; then
+    cls_harness_tu dropin | $CXX -std=c++11 -O2 -w -I"$HOSTDIR" -include cmath -include cfloat -include cstdint -x c++ - -o "$OUT/harness_cls_dropin" \
+        -L"$HOSTDIR/.." -lfir_host -lfir_amd -Wl,-rpath,'$ORIGIN/../../fast-image-recognition_amd'
+fi
+ann_harness_tu reference | $CXX -std=c++11 -O2 -w -I"$REF" -include cmath -include cfloat -include unordered_map -include iostream -include algorithm -x c++ - -o "$OUT/harness_ann_reference"
+if [ -f "$HOSTDIR/../libfir_host.so" ]; then
+    ann_harness_tu dropin | $CXX -std=c++11 -O2 -w -I"$HOSTDIR" -include cmath -include cfloat -include unordered_map -x c++ - -o "$OUT/harness_ann_dropin" \
+        -L"$HOSTDIR/.." -lfir_host -lfir_amd -Wl,-rpath,'$ORIGIN/../../fast-image-recognition_amd'
+fi
+harness_tu reference | $CXX -std=c++11 -O2 -w -I"$REF" -include cmath -x c++ - -o "$OUT/harness_reference"
+if [ -f "$HOSTDIR/../libfir_host.so" ]; then
+    harness_tu dropin | $CXX -std=c++11 -O2 -w -I"$HOSTDIR" -include cmath -x c++ - -o "$OUT/harness_dropin" \
+        -L"$HOSTDIR/.." -lfir_host -lfir_amd -Wl,-rpath,'$ORIGIN/../../fast-image-recognition_amd'
+fi
+
 match_tu 0 | $CXX $CXXFLAGS -x c++ - -o "$OUT/libref_l2.so"
 match_tu 1 | $CXX $CXXFLAGS -x c++ - -o "$OUT/libref_chi2.so"
 match_tu 2 | $CXX $CXXFLAGS -x c++ - -o "$OUT/libref_kl.so"

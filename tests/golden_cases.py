@@ -124,6 +124,70 @@ def video_text():
     return "\n".join(out) + "\n"
 
 
+HARNESS_FEATURES_FILE = "101_ObjectCategories_inception_resnet_v2.txt"     # FEATURES_FILE_NAME of the reference's db.h as shipped
+
+
+def write_harness_features(path, signal=0.35):
+    """A Caltech-like feature file for the reference's own harness (testRecognition, ImageTesting.cpp:503-548): 9 classes
+    of 36-44 images (30 per class become the gallery, db_features.cpp:133), 1536 features, records interleaved."""
+    d = 1536
+    counts = [38, 36, 44, 40, 37, 41, 39, 36, 42]
+    centers = synth.uniform01(len(counts) * d, 71).reshape(len(counts), d)
+    order = [c for i in range(max(counts)) for c in range(len(counts)) if i < counts[c]]
+    names, classes, feats = [], [], []
+    for k, c in enumerate(order):
+        names.append(f"/data/101_ObjectCategories/cat{c}/image_{k:04d}.jpg")
+        classes.append(f"cat{c}")
+        feats.append(signal * centers[c] + synth.uniform01(d, 5000 + k))
+    synth.write_feature_file(path, names, classes, np.array(feats, np.float32))
+    return counts
+
+
+def harness_result_lines(stdout):
+    """The lines of the harness output that carry results (names, per-test and average error / recall / unreliable
+    ratio), with the wall-clock field removed."""
+    import re
+
+    keep = []
+    for line in stdout.splitlines():
+        line = line.strip()
+        if line.startswith(("BF", "TWD", "Proposed TWD", "test=", "Avg error=")):
+            keep.append(re.sub(r" time\(ms\)=.*$", "", line))
+    return keep
+
+
+CLS_HARNESS_SIGNAL = 0.2      # a harder file for testClassification1: the nearest-neighbour classifiers make errors too
+
+
+def cls_harness_result_lines(stdout):
+    """testClassification1's result lines (classification.cpp:1071-1082): classifier name, then fraction / db_size / error /
+    sigma / recall, with the per-query time removed."""
+    import re
+
+    keep = []
+    for line in stdout.splitlines():
+        line = line.strip()
+        if line:
+            keep.append(re.sub(r" avg time\(us\)=\S+", "", line))
+    return keep
+
+
+def ann_harness_result_lines(stdout):
+    """testANN's result lines (ann.cpp:24-81 through testSetRecognition :94-109 and the DirectedEnumeration constructor):
+    sizes, the threshold line, one error / checkedPercent line per method and ratio, wall-clock fields removed."""
+    import re
+
+    keep = []
+    for line in stdout.splitlines():
+        line = line.strip()
+        if line.startswith("init took"):
+            continue
+        if " error=" in line and "total_time" in line:
+            line = re.sub(r" total_time \(ms\)\S+", "", line)
+        keep.append(line)
+    return keep
+
+
 FPNN_SCALES = (1.0, 0.33)                 # classification.cpp:1002-1007
 FPNN_RATIOS = (0.9, 0.99)                 # output_ratio: the default (:620) and a tighter pruning threshold
 
