@@ -196,7 +196,10 @@ def main():
             k5 = torch.empty((qb, 5), device=dev, dtype=torch.int64)
             also = {"l2_top5_queries_per_s": rate(lambda: g.search_topk_keys_dev(q.data_ptr(), qb, 5, k5.data_ptr(), stream=stream), qb, 2)}
             top5_first_is_top1 = bool(torch.equal(k5[:, 0], keys))
-            q32 = q[:32].contiguous()
+            # chi-square / KL compare non-negative feature vectors that went through the loader's |x| < 1e-4 -> 0 rule
+            # (db_features.cpp:85-86) like the gallery rows did; the L2 step's planted queries carry signed noise
+            q32 = q[:32].clamp_min(0.0)
+            q32 = torch.where(q32 < 1e-4 / 13.0, torch.zeros_like(q32), q32).contiguous()
             k32 = torch.empty(32, device=dev, dtype=torch.int64)
             for name, metric in (("chi2", fir.METRIC_CHI2), ("kl", fir.METRIC_KL)):
                 g.set_metric(metric)

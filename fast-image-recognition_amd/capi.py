@@ -81,6 +81,7 @@ SYMBOLS = [
     ("fir_profile_read", C.c_int, [_vp, _vp, C.c_int32, _i32p, C.POINTER(C.c_double)]),
     ("fir_gallery_sync", C.c_int, [_vp]),
     ("fir_gallery_set_tuning", C.c_int, [_vp, C.c_int32, C.c_int32]),
+    ("fir_gallery_value_range", C.c_int, [_vp, _i32p, _i32p]),
     ("fir_gallery_get_tuning", C.c_int, [_vp, _i32p, _i32p, _i32p]),
 ]
 
@@ -202,6 +203,13 @@ class Gallery:
 
     def set_large_batch_mfma(self, min_queries):
         _check(lib().fir_gallery_set_large_batch_mfma(self._h, min_queries))
+
+    def value_range(self):
+        """(every gallery value in the plain range, every query value of the last search too) -- chi-square / KL scans
+        use the short division sequence when both hold (include/fir_amd.h)."""
+        a, b = C.c_int32(), C.c_int32()
+        _check(lib().fir_gallery_value_range(self._h, C.byref(a), C.byref(b)))
+        return bool(a.value), bool(b.value)
 
     def set_tuning(self, queries_per_pass=0, waves=0):
         _check(lib().fir_gallery_set_tuning(self._h, queries_per_pass, waves))

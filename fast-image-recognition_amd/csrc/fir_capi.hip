@@ -43,6 +43,10 @@ int fail(int code, const char* fmt, ...) {
 #endif
 constexpr int kU = FIR_U;    // float4 chunks per lane per load group (FIR_U KiB per wave in flight per group)
 constexpr int kWps = FIR_WPS;     // waves per SIMD the scan kernels are register-budgeted for (<= 128 VGPRs)
+// The plain-range chi-square / KL kernels pair their operands for v_pk_fma_f32 and want more registers (with 128 the
+// chi-square loop spills, and every reload waits for the gallery loads in flight); pick_waves never asks for more than 3.
+constexpr int kWpsPlain = 3;
+constexpr int wps_of(int metric) { return metric >= kChi2InRange ? kWpsPlain : kWps; }
 constexpr int kKMax = 8;     // per-lane candidate list length of the top-K scan
 
 }  // namespace
@@ -58,6 +62,10 @@ struct fir_gallery {
     float4* gal4 = nullptr;
     int32_t* cls = nullptr;
     hipStream_t stream = nullptr;
+    // chi-square / KL: range[0] = a gallery value outside in_plain_range() was uploaded, range[1] = serial of the last query
+    // transposition that met one (fir_common.h); the scans read both and pick their division sequence on the device
+    int32_t* range = nullptr;
+    int q_serial = 0;
 
     // workspaces (grown on demand, never inside a *_dev call once large enough)
     float* qt = nullptr;      size_t qt_cap = 0;      // transposed query tiles
@@ -106,7 +114,7 @@ typedef void (*scan_fn)(const ScanArgs);
 
 template <int EPI>
 scan_fn pick_kernel(int qb, int metric) {
-#define FIR_CASE(QB, M) if (qb == QB && metric == M) return (scan_fn)k_scan<QB, M, kU, EPI, kKMax, kWps>;
+#define FIR_CASE(QB, M) if (qb == QB && metric == M) return (scan_fn)k_scan<QB, M, kU, EPI, kKMax, wps_of(M)>;
 #ifdef FIR_MINIMAL   // experiment builds: only the L2 top-1 kernels
     if constexpr (EPI == kEpiTop1) { FIR_CASE(8, 0) FIR_CASE(4, 0) FIR_CASE(2, 0) FIR_CASE(1, 0) }
     return nullptr;
@@ -114,8 +122,10 @@ scan_fn pick_kernel(int qb, int metric) {
     FIR_CASE(1, 0) FIR_CASE(2, 0) FIR_CASE(4, 0)
     FIR_CASE(1, 1) FIR_CASE(2, 1) FIR_CASE(4, 1)
     FIR_CASE(1, 2) FIR_CASE(2, 2) FIR_CASE(4, 2)
+    FIR_CASE(1, 3) FIR_CASE(2, 3) FIR_CASE(4, 3)      // 3, 4: the plain-range forms of 1, 2 (fir_common.h)
+    FIR_CASE(1, 4) FIR_CASE(2, 4) FIR_CASE(4, 4)
     if constexpr (EPI != kEpiTopK) {   // the top-K scan keeps 2*kKMax registers per query: 4 queries at most
-        FIR_CASE(8, 0) FIR_CASE(8, 1) FIR_CASE(8, 2)
+        FIR_CASE(8, 0) FIR_CASE(8, 1) FIR_CASE(8, 2) FIR_CASE(8, 3) FIR_CASE(8, 4)
     }
 #undef FIR_CASE
     return nullptr;
@@ -163,9 +173,10 @@ scan_fn pick_deep(int epi, int qb, int metric, int dp4, size_t* lds_bytes) {
     const size_t need = (size_t)dp4 * 4 * qb * sizeof(float);
     if (need > 64 * 1024) return nullptr;
 #ifndef FIR_MINIMAL
-#define FIR_DEEP(QB, M, E) if (epi == E && qb == QB && metric == M) { *lds_bytes = need; return (scan_fn)k_scan<QB, M, kUDeep, E, kKMax, kWps, 1>; }
+#define FIR_DEEP(QB, M, E) if (epi == E && qb == QB && metric == M) { *lds_bytes = need; return (scan_fn)k_scan<QB, M, kUDeep, E, kKMax, wps_of(M), 1>; }
     FIR_DEEP(1, 0, kEpiTop1) FIR_DEEP(1, 1, kEpiTop1) FIR_DEEP(1, 2, kEpiTop1)
     FIR_DEEP(1, 0, kEpiStore) FIR_DEEP(1, 1, kEpiStore) FIR_DEEP(1, 2, kEpiStore)
+    FIR_DEEP(1, 3, kEpiTop1) FIR_DEEP(1, 4, kEpiTop1) FIR_DEEP(1, 3, kEpiStore) FIR_DEEP(1, 4, kEpiStore)
 #undef FIR_DEEP
 #endif
     return nullptr;
@@ -255,7 +266,7 @@ int run_pass(fir_gallery* g, hipStream_t st, int epi, const float* d_queries, in
         const int64_t total = std::max<int64_t>((int64_t)kk * qb_tile * ny, init_keys);
         const int blocks = (int)((total + kBlock - 1) / kBlock);
         hipLaunchKernelGGL(k_transpose_queries, dim3(blocks), dim3(kBlock), 0, st, d_queries + (size_t)q0 * g->d, qb_tile * ny,
-                           g->d, g->dp4, qb_tile, qt, init_keys > 0 ? keys : nullptr, init_keys);
+                           g->d, g->dp4, qb_tile, qt, init_keys > 0 ? keys : nullptr, init_keys, g->range, ++g->q_serial);
     }
     size_t lds_bytes = 0;
     scan_fn fn = pick_fast(epi, qb_tile, g->metric, start, end, g->dp4, &lds_bytes);
@@ -267,7 +278,16 @@ int run_pass(fir_gallery* g, hipStream_t st, int epi, const float* d_queries, in
         for (const auto& e : g->occ) known = known || (e.fn == (const void*)fn && e.lds == lds_bytes);
         if (!known) FIR_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxQueryTileLds));
     }
-    const int max_waves = max_waves_for(g, fn, lds_bytes);
+    // chi-square / KL: the plain-range twin of the kernel, launched next to it with the same grid -- which of the two
+    // does the pass is decided on the device from the range flags (k_scan), the other returns at once
+    scan_fn fn_plain = nullptr;
+    if (g->metric != kL2) {
+        size_t lds2 = 0;
+        if (g->tiles <= (int64_t)g->cus * 4 && lds_bytes > 0) fn_plain = pick_deep(epi, qb_tile, g->metric + 2, g->dp4, &lds2);
+        if (!fn_plain && lds_bytes == 0) fn_plain = pick(epi, qb_tile, g->metric + 2);
+    }
+    int max_waves = max_waves_for(g, fn, lds_bytes);
+    if (fn_plain) max_waves = std::min(max_waves, max_waves_for(g, fn_plain, lds_bytes));
     const int waves = g->waves_req > 0 ? std::min(g->waves_req, max_waves) : pick_waves(g->tiles, max_waves, g->cus * 4);
     g->last_waves = waves;
     if (waves_used) *waves_used = waves;
@@ -290,6 +310,8 @@ int run_pass(fir_gallery* g, hipStream_t st, int epi, const float* d_queries, in
     a.k = k;
     a.qt_stride = (int64_t)kk * qb_tile;
     a.nt = gallery_bytes(g) > kL2ResidentBytes ? 1 : 0;
+    a.range = g->range;
+    a.serial = g->q_serial;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (g->profiling) {
         if (g->ev_used + 2 > g->ev.size()) {
@@ -304,6 +326,7 @@ int run_pass(fir_gallery* g, hipStream_t st, int epi, const float* d_queries, in
         FIR_HIP(hipEventRecord(e0, st));
     }
     hipLaunchKernelGGL(fn, dim3(waves / 4, ny), dim3(kBlock), lds_bytes, st, a);
+    if (fn_plain) hipLaunchKernelGGL(fn_plain, dim3(waves / 4, ny), dim3(kBlock), lds_bytes, st, a);
     if (g->profiling) {
         FIR_HIP(hipEventRecord(e1, st));
         // algorithmic bytes of one pass: the gallery range once, the query tile, the keys
@@ -414,15 +437,20 @@ int topk_lists_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t s
                       : g->metric == kL2 ? (scan_fn)k_scan<8, kL2, kU, kEpiAppend, kKMax, kWps>
                       : g->metric == kChi2 ? (scan_fn)k_scan<8, kChi2, kU, kEpiAppend, kKMax, kWps>
                                            : (scan_fn)k_scan<8, kKL, kU, kEpiAppend, kKMax, kWps>;
-    const int max_waves = max_waves_for(g, fn, lds_bytes);
+    const scan_fn fn_plain = g->metric == kChi2 ? (scan_fn)k_scan<8, kChi2InRange, kU, kEpiAppend, kKMax, kWpsPlain>
+                           : g->metric == kKL ? (scan_fn)k_scan<8, kKLInRange, kU, kEpiAppend, kKMax, kWpsPlain> : nullptr;   // see run_pass
+    int max_waves = max_waves_for(g, fn, lds_bytes);
+    if (fn_plain) max_waves = std::min(max_waves, max_waves_for(g, fn_plain, lds_bytes));
     const int waves = g->waves_req > 0 ? std::min(g->waves_req, max_waves) : pick_waves(g->tiles, max_waves, g->cus * 4);
     for (int q0 = 0; q0 < qpad; q0 += 8 * g->max_tiles_per_launch) {
         const int ny = std::min(g->max_tiles_per_launch, (qpad - q0) / 8);
         const int live = std::max(0, std::min(qb - q0, ny * 8));
         float* qt = g->qt + (size_t)q0 * kk;
         hipLaunchKernelGGL(k_transpose_queries, dim3((unsigned)(((int64_t)kk * 8 * ny + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
-                           d_queries + (size_t)q0 * g->d, live, g->d, g->dp4, 8, qt, (uint64_t*)nullptr, 0);
+                           d_queries + (size_t)q0 * g->d, live, g->d, g->dp4, 8, qt, (uint64_t*)nullptr, 0, g->range, ++g->q_serial);
         ScanArgs a{};
+        a.range = g->range;
+        a.serial = g->q_serial;
         a.gal4 = g->gal4;
         a.qt = qt;
         a.n = g->n;
@@ -439,6 +467,7 @@ int topk_lists_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t s
         a.qt_stride = (int64_t)kk * 8;
         a.nt = gallery_bytes(g) > kL2ResidentBytes ? 1 : 0;
         hipLaunchKernelGGL(fn, dim3(waves / 4, ny), dim3(kBlock), lds_bytes, st, a);
+        if (fn_plain) hipLaunchKernelGGL(fn_plain, dim3(waves / 4, ny), dim3(kBlock), lds_bytes, st, a);
     }
     // 3. the K smallest keys of every list
     hipLaunchKernelGGL(k_topk_select, dim3(qb), dim3(kBlock), 0, st, lists, counts, kListCap, k, d_keys, flag);
@@ -567,6 +596,14 @@ int gallery_alloc(int64_t n, int32_t d, int32_t metric, int32_t device, fir_gall
         delete g;
         return fail(FIR_ERR_NOMEM, "hipMalloc of %zu gallery bytes: %s", f4 * sizeof(float4), hipGetErrorString(e));
     }
+    e = hipMalloc((void**)&g->range, 2 * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMemset(g->range, 0, 2 * sizeof(int32_t));
+    if (e != hipSuccess) {
+        (void)hipFree(g->gal4); (void)hipFree(g->range);
+        (void)hipStreamDestroy(g->stream);
+        delete g;
+        return fail(FIR_ERR_NOMEM, "hipMalloc of the range flags: %s", hipGetErrorString(e));
+    }
     *out = g;
     return FIR_OK;
 }
@@ -577,7 +614,8 @@ int retile_slab(fir_gallery* g, const float* d_rows, int64_t slab_rows, int64_t 
     if (total == 0) return FIR_OK;
     const int64_t blocks = (total + kBlock - 1) / kBlock;
     if (blocks > 0x7FFFFFFF) return fail(FIR_ERR_ARG, "slab too large");
-    hipLaunchKernelGGL(k_retile, dim3((unsigned)blocks), dim3(kBlock), 0, st, d_rows, slab_rows, row0, g->n, g->d, g->dp4, g->gal4);
+    hipLaunchKernelGGL(k_retile, dim3((unsigned)blocks), dim3(kBlock), 0, st, d_rows, slab_rows, row0, g->n, g->d, g->dp4, g->gal4,
+                       g->range);
     FIR_HIP(hipGetLastError());
     return FIR_OK;
 }
@@ -758,7 +796,7 @@ int fir_gallery_destroy(fir_gallery* g) {
     if (g->gemm) { fir_gemm_destroy(g->gemm); g->gemm = nullptr; }
     for (hipEvent_t e : g->ev) (void)hipEventDestroy(e);
     (void)hipFree(g->gal4); (void)hipFree(g->cls); (void)hipFree(g->qt); (void)hipFree(g->dq); (void)hipFree(g->dkeys);
-    (void)hipFree(g->part); (void)hipFree(g->dout); (void)hipFree(g->didx);
+    (void)hipFree(g->part); (void)hipFree(g->dout); (void)hipFree(g->didx); (void)hipFree(g->range);
     if (g->pin) (void)hipHostFree(g->pin);
     for (void* p : g->scratch) if (p) (void)hipFree(p);
     if (g->stream) (void)hipStreamDestroy(g->stream);
@@ -1006,6 +1044,17 @@ int fir_gallery_sync(fir_gallery* g) {
     if (!g) return fail(FIR_ERR_ARG, "gallery is NULL");
     FIR_HIP(hipSetDevice(g->device));
     FIR_HIP(hipStreamSynchronize(g->stream));
+    return FIR_OK;
+}
+
+int fir_gallery_value_range(fir_gallery* g, int32_t* gallery_plain, int32_t* last_queries_plain) {
+    if (!g || !gallery_plain || !last_queries_plain) return fail(FIR_ERR_ARG, "fir_gallery_value_range: null argument");
+    FIR_HIP(hipSetDevice(g->device));
+    int32_t h[2] = {0, 0};
+    FIR_HIP(hipStreamSynchronize(g->stream));
+    FIR_HIP(hipMemcpy(h, g->range, sizeof h, hipMemcpyDeviceToHost));
+    *gallery_plain = h[0] == 0;
+    *last_queries_plain = g->q_serial > 0 && h[1] != g->q_serial;
     return FIR_OK;
 }
 

@@ -11,7 +11,8 @@ constexpr int kBlock = 256;     // 4 waves per workgroup, one per SIMD
 constexpr float kNotFound = 100000.0f;  // db_features.cpp:323, ann.cpp:116
 constexpr uint64_t kKeyNone = 0xFFFFFFFFFFFFFFFFull;
 
-enum { kL2 = 0, kChi2 = 1, kKL = 2 };
+enum { kL2 = 0, kChi2 = 1, kKL = 2,
+       kChi2InRange = 3, kKLInRange = 4 };   // kernel-internal: the same arithmetic for operands known to be 0 or in [2^-26, 2^16]
 enum { kEpiTop1 = 0, kEpiTopK = 1, kEpiStore = 2, kEpiAppend = 3 };
 
 typedef const float __attribute__((address_space(4)))* sfloat_p;  // constant AS => s_load when uniform
@@ -32,6 +33,46 @@ __host__ __device__ __forceinline__ uint64_t key_pack(float dist, uint32_t idx) 
     return ((uint64_t)f32_orderable(dist + 0.0f) << 32) | (uint64_t)idx;  // +0.0f: -0 -> +0
 }
 
+// ---- chi-square / KL for operands in the "plain" range ---------------------------------------------------------------
+// The correctly rounded f32 division the compiler emits is v_div_scale x2, v_rcp, seven fma/mul steps, v_div_fmas and
+// v_div_fixup. For a denominator and a numerator that are far from the ends of the exponent range the two v_div_scale
+// return their operand unchanged with VCC = 0, v_div_fmas is then a plain fma and v_div_fixup passes the quotient
+// through: what remains is the reciprocal with one Newton step and the seven arithmetic steps below -- the same
+// instructions on the same operands, so the same bits. in_plain_range() is the condition the gallery upload and the
+// query transposition check for every value (0, or 2^-26 <= x <= 2^16: then x + y is 0 or in [2^-26, 2^17], (x - y)^2 is 0
+// or in [2^-98, 2^32] -- above the 2^-103 where v_div_scale starts scaling numerators --, every quotient below lies in
+// [2^-115, 2^58], and none of the v_div_scale / v_div_fixup cases applies; L1-normalised 1536-feature rows, whose
+// smallest non-zero entries are near 1e-7, are inside);
+// one value outside it and the kernels take accum<kChi2> / accum<kKL> for the whole call. Halves the VALU work per
+// element of the chi-square scan (packs pairwise into v_pk_fma_f32) and more for KL, where the two quotients also share
+// the reciprocal and the divergent `if (l > 0)` branches become a v_max.
+__host__ __device__ __forceinline__ bool in_plain_range(float x) {
+    uint32_t b;
+    __builtin_memcpy(&b, &x, 4);
+    return b == 0u || (b >= 0x32800000u && b <= 0x47800000u);    // +0, or 2^-26 .. 2^16 (negatives, NaN, inf: no)
+}
+#ifdef __HIP_DEVICE_COMPILE__
+__device__ __forceinline__ float rcp_newton(float s) {             // first three steps of the f32 division sequence
+    const float y0 = __builtin_amdgcn_rcpf(s);
+    const float e = __builtin_fmaf(-s, y0, 1.0f);
+    return __builtin_fmaf(e, y0, y0);
+}
+__device__ __forceinline__ float div_plain(float n, float s, float y) {   // the remaining five; y = rcp_newton(s)
+    float q = n * y;
+    float r = __builtin_fmaf(-s, q, n);
+    q = __builtin_fmaf(r, y, q);
+    r = __builtin_fmaf(-s, q, n);
+    return __builtin_fmaf(r, y, q);
+}
+__device__ __forceinline__ float log_plain(float x) {              // logf(x) as the compiler expands it, for normal finite x > 0
+    const float y = __builtin_amdgcn_logf(x);                      // v_log_f32 (log2)
+    const float p = y * 0x1.62e42ep-1f;
+    float pl = __builtin_fmaf(y, 0x1.62e42ep-1f, -p);
+    pl = __builtin_fmaf(y, 0x1.efa39ep-25f, pl);
+    return p + pl;
+}
+#endif
+
 // One feature of the reference's distance loop, lhs = query (test image), rhs = gallery row
 // (ImageInfo::distance, db_features.h:24-26). The translation unit is compiled with
 // -ffp-contract=off: sub, mul, add (and the chi-square divide) each round once, like the
@@ -46,7 +87,7 @@ __device__ __forceinline__ float accum(float acc, float l, float r) {
         const float df = l - r;
         const float term = df * df / s;                         // db_features.cpp:31
         return (s > 0.0f) ? acc + term : acc;                   // db_features.cpp:29
-    } else {
+    } else if constexpr (METRIC == kKL) {
         const float s = l + r;                                  // db_features.cpp:29,33-36
         float a = acc;
         if (s > 0.0f) {
@@ -55,6 +96,24 @@ __device__ __forceinline__ float accum(float acc, float l, float r) {
         }
         return a;
     }
+#ifdef __HIP_DEVICE_COMPILE__
+    else if constexpr (METRIC == kChi2InRange) {
+        const float df = l - r;
+        const float n = df * df;
+        const float s = __builtin_fmaxf(l + r, 0x1p-30f);       // l + r == 0 only for l == r == 0: then n == 0 and the term is +0
+        return acc + div_plain(n, s, rcp_newton(s));
+    } else {
+        const float s = __builtin_fmaxf(l + r, 0x1p-30f);
+        const float y = rcp_newton(s);
+        // l == 0: the quotient is 0, clamped; l * log(clamp) = -0 and acc + -0 = acc, as if the term had been skipped
+        const float ql = __builtin_fmaxf(div_plain(2.0f * l, s, y), 0x1p-60f);
+        const float qr = __builtin_fmaxf(div_plain(2.0f * r, s, y), 0x1p-60f);
+        float a = acc + l * log_plain(ql);
+        return a + r * log_plain(qr);
+    }
+#else
+    else return acc;
+#endif
 }
 
 // 64-bit wave-wide minimum (all lanes end with the result).

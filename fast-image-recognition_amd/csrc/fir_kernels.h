@@ -82,6 +82,8 @@ struct ScanArgs {
     int32_t step;         // k_scan_subranges: features per sub-range
     const float* tau;     // append form of the L2 scan: rows with distance <= tau[query] are appended ...
     int32_t* counts;      // ... counts[query] entries so far, lists = keys[query * k + slot] (k = capacity per query)
+    const int32_t* range; // chi-square / KL: range[0] != 0 = some gallery value is outside in_plain_range(), range[1] = serial
+    int32_t serial;       // of the last query transposition that met one; NULL or a match = IEEE division sequence
 };
 
 template <int QB, int METRIC, int U>
@@ -99,6 +101,9 @@ struct TileAcc {
         for (int j = 0; j < 4; ++j) {
 #pragma unroll
             for (int q = 0; q < QB; ++q) acc[q] = accum<METRIC>(acc[q], sq[j * QB + q], gv[j]);
+            // plain-range forms: QB independent division chains (QB/2 packed) are enough to hide the pipeline latency;
+            // left alone the scheduler interleaves all 4*QB chains of the chunk and spills
+            if constexpr (METRIC >= kChi2InRange && QB >= 4) __builtin_amdgcn_sched_barrier(0);
         }
     }
     // acc[q] += contribution of one group of U chunks starting at chunk c. QP = constant-address-space pointer: the
@@ -137,6 +142,12 @@ struct TileAcc {
 // scalar-load latency of the default form is what it waits for.
 template <int QB, int METRIC, int U, int EPI, int KMAX, int WPS, int LDSQ = 0>
 __global__ void __launch_bounds__(kBlock, WPS) k_scan(const ScanArgs a) {
+    if constexpr (METRIC != kL2) {
+        // chi-square / KL come as a pair of launches: the kernel whose arithmetic matches the operands of this call runs
+        // (every value in the plain range -> the kChi2InRange / kKLInRange form, fir_common.h), the other one returns here
+        const bool plain = a.range != nullptr && a.range[0] == 0 && a.range[1] != a.serial;
+        if (plain != (METRIC == kChi2InRange || METRIC == kKLInRange)) return;
+    }
     const int lane = threadIdx.x & 63;
     const int gw = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     // blockIdx.y = query tile (top-1 and append forms): several tiles of QB queries share one launch
@@ -742,8 +753,10 @@ __global__ void __launch_bounds__(kBlock) k_topk_select(const uint64_t* __restri
 
 // rows[n][d] row-major  ->  tiled layout (see top of file). One thread per output float4.
 // row0 = first row of this slab (multiple of 64); rows beyond n and features beyond d are zero.
+// range[0] is set when a value outside in_plain_range() goes by (the chi-square / KL scans then keep the full division).
 __global__ void __launch_bounds__(kBlock) k_retile(const float* __restrict__ rows, int64_t slab_rows, int64_t row0,
-                                                    int64_t n, int d, int dp4, float4* __restrict__ gal4) {
+                                                    int64_t n, int d, int dp4, float4* __restrict__ gal4,
+                                                    int32_t* __restrict__ range) {
     const int64_t o = (int64_t)blockIdx.x * kBlock + threadIdx.x;   // float4 index inside the slab's tiles
     const int64_t slab_tiles = (slab_rows + kTileRows - 1) / kTileRows;
     if (o >= slab_tiles * dp4 * 64) return;
@@ -760,14 +773,17 @@ __global__ void __launch_bounds__(kBlock) k_retile(const float* __restrict__ row
         for (int j = 0; j < 4; ++j)
             if (c * 4 + j < d) v[j] = src[j];
     }
+    if (range && !(in_plain_range(v[0]) && in_plain_range(v[1]) && in_plain_range(v[2]) && in_plain_range(v[3]))) range[0] = 1;
     gal4[((row0 / kTileRows + tl) * dp4 + c) * 64 + r] = make_float4(v[0], v[1], v[2], v[3]);
 }
 
 // queries[nq][d] row-major -> tiles of QB queries, transposed: qt[tile][k][QB], k < dp4*4.
 // Queries past nq and features past d are zero. keys[0..nkeys) (may be NULL) are preset to "no row yet" on the way:
 // the top-1 scans that follow only ever lower them.
+// range[1] = serial when a query value outside in_plain_range() goes by (serial numbers the transpositions of a handle).
 __global__ void __launch_bounds__(kBlock) k_transpose_queries(const float* __restrict__ q, int nq, int d, int dp4, int QB,
-                                                               float* __restrict__ qt, uint64_t* __restrict__ keys, int nkeys) {
+                                                               float* __restrict__ qt, uint64_t* __restrict__ keys, int nkeys,
+                                                               int32_t* __restrict__ range = nullptr, int serial = 0) {
     const int kk = dp4 * 4;
     const int64_t total = (int64_t)((nq + QB - 1) / QB) * kk * QB;
     const int64_t o = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -780,7 +796,9 @@ __global__ void __launch_bounds__(kBlock) k_transpose_queries(const float* __res
     const int qi = (int)(r % QB);
     const int tile = (int)(r / QB);
     const int qq = tile * QB + qi;
-    qt[((int64_t)tile * kk + k) * QB + qi] = (qq < nq && k < d) ? q[(int64_t)qq * d + k] : 0.0f;
+    const float v = (qq < nq && k < d) ? q[(int64_t)qq * d + k] : 0.0f;
+    if (range && !in_plain_range(v)) range[1] = serial;
+    qt[((int64_t)tile * kk + k) * QB + qi] = v;
 }
 
 // feature_distance for one pair (db_features.cpp:22-42): one lane, sequential, exact order.

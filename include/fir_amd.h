@@ -248,6 +248,16 @@ int fir_gemm_stats(const fir_gemm* m, int64_t* passes, int64_t* fallback_queries
 int fir_profile_enable(fir_gallery* g, int32_t on);
 int fir_profile_read(fir_gallery* g, float* ms, int32_t cap, int32_t* count, double* bytes_per_launch);
 
+/* Chi-square / KL galleries: which division sequence the scans use. The IEEE f32 division the compiler emits carries
+ * scaling and fix-up steps for operands near the ends of the exponent range; when every gallery value and every query
+ * value of a call is +0 or within [2^-26, 2^16] (any L1- or L2-normalised non-negative feature vector is) those steps
+ * are the identity, and the scans run the same arithmetic without them -- the same bits, about half the VALU work for
+ * chi-square and a third for KL. The check is made on the device while rows are uploaded and queries transposed; one
+ * value outside the range (a negative, a NaN, a denormal) and the whole call takes the full sequence.
+ * *gallery_plain: every uploaded value was in range; *last_queries_plain: so was every query value of the most recent
+ * search on this handle. Synchronises the handle's stream. */
+int fir_gallery_value_range(fir_gallery* g, int32_t* gallery_plain, int32_t* last_queries_plain);
+
 /* Block until all work queued by this handle is done. */
 int fir_gallery_sync(fir_gallery* g);
 

@@ -1,0 +1,71 @@
+"""Chi-square / KL scans pick their f32 division sequence from the operands' range (include/fir_amd.h,
+fir_gallery_value_range; csrc/fir_common.h). Both sequences are the same arithmetic, so results must not depend on
+which one ran: the same queries give the same bits whether or not an out-of-range query rides in the batch."""
+import numpy as np
+import pytest
+
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _l1_rows(seed, n, d, lo_exp=None):
+    rows = synth.make_gallery(seed, n, d, 1)          # non-negative, |x| < 1e-4 -> 0, L1-normalised (db_features.cpp:85-101)
+    if lo_exp is not None:
+        rows = rows.copy()
+        rows[::7, 3] = np.float32(2.0 ** lo_exp)      # plant values at the low edge of the plain range
+    return rows
+
+
+@pytest.mark.parametrize("metric", [1, 2])
+@pytest.mark.parametrize("n,d,qb", [(4099, 512, 13), (1000, 1536, 8), (257, 130, 3), (20000, 64, 33)])
+def test_results_do_not_depend_on_the_division_sequence(fir, oracle, metric, n, d, qb):
+    rows = _l1_rows(31 + n, n, d, lo_exp=-26)
+    queries, _ = synth.make_queries(31 + n, rows, qb, 1)
+    poisoned = np.vstack([queries, -np.abs(queries[:1])])          # a negative query value: outside the plain range
+    with fir.Gallery(rows, None, metric, 0) as g:
+        idx, dist = g.search_top1(queries)
+        assert g.value_range() == (True, True)
+        idx2, dist2 = g.search_top1(poisoned)
+        assert g.value_range() == (True, False)
+        kidx, kdist = g.search_topk(queries, 5)
+        assert g.value_range() == (True, True)
+        kidx2, kdist2 = g.search_topk(poisoned, 5)
+        m = min(qb, 7)
+        all1 = g.range_distances(queries[:m], 0, d)
+        all2 = g.range_distances(np.vstack([queries[:m], poisoned[-1:]]), 0, d)
+    assert np.array_equal(idx, idx2[:qb])
+    assert np.array_equal(dist.view(np.uint32), dist2[:qb].view(np.uint32))
+    assert np.array_equal(kidx, kidx2[:qb])
+    assert np.array_equal(kdist.view(np.uint32), kdist2[:qb].view(np.uint32))
+    assert np.array_equal(all1.view(np.uint32), all2[:m].view(np.uint32))
+    if metric == 1:                                                 # chi-square is bit-exact against the reference arithmetic
+        eidx, edist = oracle.top1_batch(rows, queries, 0, d, 1)
+        assert np.array_equal(idx, eidx)
+        assert np.array_equal(dist.view(np.uint32), edist.view(np.uint32))
+
+
+@pytest.mark.parametrize("metric", [1, 2])
+def test_gallery_values_outside_the_range_keep_the_full_sequence(fir, oracle, metric):
+    n, d, qb = 3000, 256, 9
+    rows = _l1_rows(77, n, d)
+    queries, _ = synth.make_queries(77, rows, qb, 1)
+    odd = rows.copy()
+    odd[1234, 17] = np.float32(1e-41)                              # a denormal: v_div_scale would scale this one
+    with fir.Gallery(odd, None, metric, 0) as g:
+        idx, dist = g.search_top1(queries)
+        assert g.value_range() == (False, True)
+    eidx, edist = oracle.top1_batch(odd, queries, 0, d, metric)
+    assert np.array_equal(idx, eidx)
+    if metric == 1:
+        assert np.array_equal(dist.view(np.uint32), edist.view(np.uint32))
+    else:
+        assert np.allclose(dist, edist, rtol=1e-5, atol=0)          # KL: the tolerance north_star states
+
+
+def test_l2_galleries_report_the_range_too(fir):
+    rows = synth.make_gallery(5, 500, 128, 0)
+    q, _ = synth.make_queries(5, rows, 4, 0)
+    with fir.Gallery(rows, None, 0, 0) as g:
+        g.search_top1(q)
+        assert g.value_range() == (True, True)

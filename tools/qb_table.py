@@ -34,6 +34,7 @@ def main():
     dev = torch.device("cuda", 0)
     n, d = a.rows, a.dim
     x = torch.rand((n, d), device=dev)
+    x = torch.where(x < 1e-4, torch.zeros_like(x), x)          # the loader's rule (db_features.cpp:85-86)
     xl2 = x / x.norm(dim=1, keepdim=True)
     g = fir.Gallery(dev_ptr=xl2.data_ptr(), n=n, d=d, metric=0, device=0)
     x1 = x / x.sum(dim=1, keepdim=True)
@@ -59,6 +60,7 @@ def main():
     for name, gal, metric in (("chi2", g1, 1), ("KL", g1, 2)):
         gal.set_metric(metric)
         q = torch.rand((qb, d), device=dev)
+        q = torch.where(q < 1e-4, torch.zeros_like(q), q)
         q = (q / q.sum(dim=1, keepdim=True)).contiguous()
         keys = torch.empty(qb * 5, device=dev, dtype=torch.int64)
         with torch.cuda.stream(st):
