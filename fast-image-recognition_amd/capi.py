@@ -59,6 +59,7 @@ SYMBOLS = [
     ("fir_cls_pnn_predict", C.c_int, [_vp, _vp, C.c_int32, C.c_double, _vp, _vp]),
     ("fir_cls_pnn_predict_seq", C.c_int, [_vp, _vp, C.c_int32, C.c_double, _vp, _vp]),
     ("fir_cls_knn_predict", C.c_int, [_vp, _vp, C.c_int32, C.c_int32, _vp]),
+    ("fir_cls_knn_class_nearest", C.c_int, [_vp, _vp, C.c_int32, C.c_int32, _vp]),
     ("fir_gemm_create", C.c_int, [_vp, C.POINTER(_vp)]),
     ("fir_gemm_create_ex", C.c_int, [_vp, C.c_int32, C.POINTER(_vp)]),
     ("fir_gemm_destroy", C.c_int, [_vp]),
@@ -490,6 +491,13 @@ class ClsModel:
         chunks = np.empty(q.shape[0], np.int32)
         _check(lib().fir_cls_pnn_predict_seq(self._h, pq, q.shape[0], var, best.ctypes.data_as(_vp), chunks.ctypes.data_as(_vp)))
         return best, chunks
+
+    def knn_class_nearest(self, queries, k):
+        """[qb, num_classes, k] smallest mean distances per class among the rows held (sharded kNN vote)."""
+        q, pq = self._q(queries)
+        out = np.empty((q.shape[0], self.num_classes, k), np.float64)
+        _check(lib().fir_cls_knn_class_nearest(self._h, pq, q.shape[0], k, out.ctypes.data_as(_vp)))
+        return out
 
     def knn_predict(self, queries, k):
         q, pq = self._q(queries)

@@ -155,7 +155,8 @@ __global__ void __launch_bounds__(64) k_cls_pnn(const double* __restrict__ sums,
 // is the class whose k-th nearest member is nearest. kth[q][c] = k-th smallest mean distance of
 // class c (+inf when the class has fewer than k rows). One wave per (class, query).
 __global__ void __launch_bounds__(64) k_cls_knn_kth(const double* __restrict__ sums, const int32_t* __restrict__ class_off, int64_t nt,
-                                                     int num_classes, int d, int k, double* __restrict__ kth) {
+                                                     int num_classes, int d, int k, double* __restrict__ kth,
+                                                     double* __restrict__ nearest /* NULL, or [q][class][k]: the k smallest, ascending */) {
     const int c = blockIdx.x, q = blockIdx.y;
     const double* s = sums + (size_t)q * nt;
     double best[kKMax];
@@ -181,6 +182,7 @@ __global__ void __launch_bounds__(64) k_cls_knn_kth(const double* __restrict__ s
             m = o < m ? o : m;
         }
         res = m;
+        if (nearest && threadIdx.x == 0) nearest[((size_t)q * num_classes + c) * k + r] = m;   // DBL_MAX once the class is exhausted
         const unsigned long long who = __ballot(best[0] == m);
         const int winner = __ffsll((long long)who) - 1;
         if ((int)threadIdx.x == winner) {
@@ -568,7 +570,8 @@ int fir_cls_knn_predict(fir_cls* c, const double* queries, int32_t qb, int32_t k
     if (rc) return rc;
     if ((rc = cls_grow(c->scores, c->scores_cap, (size_t)qb * c->num_classes))) return rc;
     if ((rc = cls_grow(c->best, c->best_cap, (size_t)qb))) return rc;
-    hipLaunchKernelGGL(k_cls_knn_kth, dim3(c->num_classes, qb), dim3(64), 0, c->stream, c->sums, c->class_off, c->nt, c->num_classes, c->d, k, c->scores);
+    hipLaunchKernelGGL(k_cls_knn_kth, dim3(c->num_classes, qb), dim3(64), 0, c->stream, c->sums, c->class_off, c->nt, c->num_classes, c->d, k, c->scores,
+                       (double*)nullptr);
     const bool small = cls_small(c, qb);
     int32_t* dbest = small ? cls_pin_results(c) : c->best;
     hipLaunchKernelGGL(k_cls_argbest, dim3(qb), dim3(64), 0, c->stream, c->scores, c->class_off, c->num_classes, 1, dbest);
@@ -576,6 +579,34 @@ int fir_cls_knn_predict(fir_cls* c, const double* queries, int32_t qb, int32_t k
     if (!small) CLS_HIP(hipMemcpyAsync(best_class, c->best, (size_t)qb * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     CLS_HIP(hipStreamSynchronize(c->stream));
     if (small) std::memcpy(best_class, dbest, (size_t)qb * sizeof(int32_t));
+    return FIR_OK;
+}
+
+int fir_cls_knn_class_nearest(fir_cls* c, const double* queries, int32_t qb, int32_t k, double* nearest) {
+    if (!c || !nearest || (qb > 0 && !queries)) return cls_fail(FIR_ERR_ARG, "NULL argument");
+    if (qb < 0) return cls_fail(FIR_ERR_ARG, "qb < 0");
+    if (k < 1 || k > kKMax) return cls_fail(FIR_ERR_ARG, "k=%d outside [1,%d]", k, kKMax);
+    if (qb == 0) return FIR_OK;
+    const size_t per_query = (size_t)c->num_classes * k;
+    if (qb > cls_batch(c)) {
+        const int32_t b = cls_batch(c);
+        for (int32_t q0 = 0; q0 < qb; q0 += b) {
+            const int rc0 = fir_cls_knn_class_nearest(c, queries + (size_t)q0 * c->d, std::min(b, qb - q0), k, nearest + (size_t)q0 * per_query);
+            if (rc0) return rc0;
+        }
+        return FIR_OK;
+    }
+    CLS_HIP(hipSetDevice(c->device));
+    int rc = cls_scan(c, queries, qb);
+    if (rc) return rc;
+    // scores: [qb][num_classes] k-th values, then [qb][num_classes][k] lists
+    if ((rc = cls_grow(c->scores, c->scores_cap, (size_t)qb * c->num_classes * (1 + (size_t)k)))) return rc;
+    double* lists = c->scores + (size_t)qb * c->num_classes;
+    hipLaunchKernelGGL(k_cls_knn_kth, dim3(c->num_classes, qb), dim3(64), 0, c->stream, c->sums, c->class_off, c->nt, c->num_classes, c->d, k, c->scores,
+                       lists);
+    CLS_HIP(hipGetLastError());
+    CLS_HIP(hipMemcpyAsync(nearest, lists, (size_t)qb * per_query * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    CLS_HIP(hipStreamSynchronize(c->stream));
     return FIR_OK;
 }
 

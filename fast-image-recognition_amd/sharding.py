@@ -7,7 +7,8 @@ because the low word is the GLOBAL row index. One all-reduce(MIN) of qb x 8 byte
 exchange step of the path; RCCL carries it over xGMI (torch.distributed backend "nccl"), gloo in
 the CPU tests. The K nearest rows are an all-gather of every rank's K packed keys plus an integer
 K-way merge; the PNN class scores (qt_cpp/classification.cpp:188-226, partial sums over the rank's
-training rows divided by the GLOBAL training-set size) are one all-reduce(SUM) of qb x C doubles.
+training rows divided by the GLOBAL training-set size) are one all-reduce(SUM) of qb x C doubles; the kNN vote
+(classification.cpp:116-170) is an all-gather of every rank's K nearest mean distances per class.
 Plumbing only: no distance is computed here.
 """
 import torch
@@ -74,3 +75,40 @@ def first_max_class(scores_f64):
     """The reference's arg-max (strict '<' from -DBL_MAX in class order, classification.cpp:217-224): first maximum."""
     mx = scores_f64.max(dim=1, keepdim=True).values
     return (scores_f64 == mx).to(torch.int8).argmax(dim=1).to(torch.int32)
+
+
+_DBL_MAX = torch.finfo(torch.float64).max
+
+
+def merge_knn_class_nearest(parts_f64, k):
+    """parts_f64[P, qb, C, k] (fir_cls_knn_class_nearest of every training-row shard: the k smallest mean distances per
+    class, ascending, DBL_MAX-padded) -> kth[qb, C]: the k-th smallest of each class over all shards. The reference's
+    vote (classification.cpp:151-160: rows in distance order vote until one class has k) is won by the class whose
+    k-th nearest member is nearest, which is the first minimum of this table."""
+    p, qb, c, kk = parts_f64.shape
+    cat = parts_f64.permute(1, 2, 0, 3).reshape(qb, c, p * kk)
+    return torch.sort(cat, dim=2).values[:, :, k - 1].contiguous()
+
+
+def allgather_knn_class_nearest(nearest_f64, k, group=None):
+    """Every rank contributes its [qb, C, k] table; every rank gets the merged kth[qb, C]."""
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    buf = [torch.empty_like(nearest_f64) for _ in range(world)]
+    dist.all_gather(buf, nearest_f64.contiguous(), group=group)
+    return merge_knn_class_nearest(torch.stack(buf), k)
+
+
+def knn_class_of(kth_f64, class_sizes):
+    """First minimum of kth[qb, C] in class order; when no class has k rows anywhere (all DBL_MAX) the reference's loop
+    ends without a winner and its arg-max of the vote counts picks the first largest class (classification.cpp:161-168).
+    class_sizes[C] = GLOBAL training rows per class."""
+    mn = kth_f64.min(dim=1, keepdim=True).values
+    best = (kth_f64 == mn).to(torch.int8).argmax(dim=1).to(torch.int32)
+    none = mn.squeeze(1) >= _DBL_MAX
+    if bool(none.any()):
+        sizes = torch.as_tensor(class_sizes, dtype=torch.int64)
+        largest = int((sizes == sizes.max()).to(torch.int8).argmax())
+        best = torch.where(none, torch.full_like(best, largest), best)
+    return best

@@ -168,6 +168,11 @@ int fir_cls_pnn_predict_seq(fir_cls* c, const double* queries, int32_t qb, doubl
 /* KNNClassifier::predict, classification.cpp:116-170: rows sorted by mean distance vote for their
  * class until one class has k votes. 1 <= k <= 8. best_class[qb]. */
 int fir_cls_knn_predict(fir_cls* c, const double* queries, int32_t qb, int32_t k, int32_t* best_class);
+/* The part of that vote a row shard can do alone: nearest[qb][num_classes][k] <- the k smallest mean distances of every
+ * class among the rows held, ascending, DBL_MAX where the class has fewer. The class that first collects k votes in the
+ * globally sorted order is the one whose k-th nearest member is nearest, so ranks exchange these lists, keep the k
+ * smallest per class and take the first minimum of the k-th values (sharding.py: merge_knn_class_nearest). */
+int fir_cls_knn_class_nearest(fir_cls* c, const double* queries, int32_t qb, int32_t k, double* nearest);
 
 /* ---- FPNNClassifier: orthogonal-series (trigonometric) PNN, classification.cpp:618-791 ----------
  * train() (:661-696): train_rows[nt][d] float64, class-major like fir_cls_create (train_class non-decreasing), avg[d] /

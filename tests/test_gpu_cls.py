@@ -100,3 +100,41 @@ def test_classes_smaller_than_k_and_bad_arguments(fir, oracle):
             m.knn_predict(q, 9)
     with pytest.raises(fir.FirError):
         fir.ClsModel(tr, tcls[::-1].copy(), ncls, avg, 0)               # classes must be non-decreasing
+
+
+@pytest.mark.parametrize("shards", [2, 3])
+def test_knn_vote_over_training_row_shards(fir, oracle, shards):
+    """SURVEY 8e for the kNN classifier: every shard of the training rows exports its k nearest mean distances per class
+    (fir_cls_knn_class_nearest); the k-th of the merged lists decides (sharding.merge_knn_class_nearest / knn_class_of).
+    Same classes as the unsharded call and as the oracle, including k larger than every class (no winner: largest class)."""
+    import torch
+    from fast_image_recognition_amd import sharding
+
+    x, lab, ncls = gc.cls_case(seed=21, n=600, d=48, n_classes=9)
+    order = np.argsort(lab, kind="stable")
+    tr, tcls = x[order][:520], lab[order][:520]
+    q = x[order][520:560]
+    _, _, avg, _ = oracle.train_stats(tr)
+    sizes = np.bincount(tcls, minlength=ncls)
+    for k in (1, 3, 8):
+        if k == 8:                                                     # shrink every class below k
+            keep = np.concatenate([np.flatnonzero(tcls == c)[:5 + (c == 4)] for c in range(ncls)])
+            tr_k, tcls_k = tr[keep], tcls[keep]
+        else:
+            tr_k, tcls_k = tr, tcls
+        sizes = np.bincount(tcls_k, minlength=ncls)
+        parts = []
+        for r in range(shards):
+            lo, hi = sharding.shard_bounds(tr_k.shape[0], shards, r)
+            with fir.ClsModel(tr_k[lo:hi], tcls_k[lo:hi], ncls, avg, 0) as m:
+                near = m.knn_class_nearest(q, k)
+            assert near.shape == (q.shape[0], ncls, k)
+            assert np.all(np.diff(near, axis=2) >= 0)
+            parts.append(torch.from_numpy(near))
+        kth = sharding.merge_knn_class_nearest(torch.stack(parts), k)
+        got = sharding.knn_class_of(kth, sizes).numpy()
+        with fir.ClsModel(tr_k, tcls_k, ncls, avg, 0) as m:
+            whole = m.knn_predict(q, k)
+        assert np.array_equal(got, whole), k
+        for i in range(q.shape[0]):
+            assert got[i] == oracle.knn_predict(tr_k, tcls_k, avg, ncls, q[i], k)[0], (k, i)

@@ -102,7 +102,21 @@ def _worker_topk_pnn(rank, world, port, n, d, qb, k, out_dir):
     st = torch.from_numpy(part)
     sharding.allreduce_sum_scores(st)
     best = sharding.first_max_class(st).numpy()
-    np.savez(os.path.join(out_dir, f"k{rank}.npz"), idx=idx.reshape(qb, k), dist=dd.reshape(qb, k), scores=st.numpy(), best=best)
+    # ---- kNN vote: every shard's K nearest mean distances per class, all-gather, K-th of the merged lists ----
+    knn = {}
+    sizes = np.bincount(tcls, minlength=ncls)
+    for kk in (1, 3):
+        near = np.full((qs.shape[0], ncls, kk), np.finfo(np.float64).max)
+        for i, qi in enumerate(qs):
+            if thi > tlo:
+                _, dall = orc.knn_predict(tr[tlo:thi], tcls[tlo:thi], avg, ncls, qi, kk)    # mean distances of the shard's rows
+                for c in range(ncls):
+                    dc = np.sort(dall[tcls[tlo:thi] == c])[:kk]
+                    near[i, c, :dc.size] = dc
+        kth = sharding.allgather_knn_class_nearest(torch.from_numpy(near), kk)
+        knn[kk] = sharding.knn_class_of(kth, sizes).numpy()
+    np.savez(os.path.join(out_dir, f"k{rank}.npz"), idx=idx.reshape(qb, k), dist=dd.reshape(qb, k), scores=st.numpy(), best=best,
+             knn1=knn[1], knn3=knn[3])
     dist.destroy_process_group()
 
 
@@ -133,6 +147,8 @@ def test_sharded_topk_and_pnn_equal_unsharded(tmp_path, oracle, world, n):
             assert np.array_equal(z["dist"][i].view(np.uint32), exp[i][1].view(np.uint32))
         assert np.allclose(z["scores"], np.array([e[1] for e in pe]), rtol=1e-12, atol=1e-300)    # summation order differs
         assert list(z["best"]) == [e[0] for e in pe]
+        for kk in (1, 3):                                                                          # the kNN vote
+            assert list(z[f"knn{kk}"]) == [oracle.knn_predict(tr, tcls, avg, ncls, qi, kk)[0] for qi in x[order][200:]], (r, kk)
 
 
 @pytest.mark.parametrize("world,n", [(2, 1000), (2, 70), (3, 129)])
