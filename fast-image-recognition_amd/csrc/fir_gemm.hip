@@ -9,12 +9,13 @@
 // The GEMM only NOMINATES rows; the answer is still the reference's:
 //   1. proxies of a row sample give, per query, an upper bound tau of its C-th smallest proxy;
 //   2. the full pass appends every row with p < tau to the query's candidate list;
-//   3. the C best candidates are re-ranked with the reference's own arithmetic (sequential,
-//      un-fused f32: fir::accum<kL2>), first-minimum tie-break on (distance, row);
-//   4. a rigorous bound certifies the winner: every non-candidate row has p >= p_C, hence a
-//      reference distance >= (|q|^2 + p_C)/d - E, with E covering every rounding on both sides;
-//      if that does not exceed the winner's exact distance (near ties beyond C candidates,
-//      candidate overflow), the query is re-run through the exact streaming scan.
+//   3. every appended row whose proxy lies within the rounding window of the smallest one is re-ranked
+//      with the reference's own arithmetic (sequential, un-fused f32: fir::accum<kL2>), first-minimum
+//      tie-break on (distance, row);
+//   4. a rigorous bound certifies the winner: every other row has p >= p_excl, hence a reference
+//      distance >= (|q|^2 + p_excl)/d - E, with E covering every rounding on both sides; if that does
+//      not exceed the winner's exact distance (the window reaches tau, the list overflowed, NaN), the
+//      query is re-run through the exact streaming scan.
 // So results are bit-identical to the scan path's -- index and distance -- by construction.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -42,7 +43,8 @@ constexpr int kQT = 64;                // queries per pass (2 accumulator tiles 
 constexpr int kSlab8 = 64;             // query features staged in LDS at a time, in groups of 8 (512 features)
 constexpr int kSlab16 = 32;            // bf16 variant: k-blocks of 16 features staged at a time (512 features)
 constexpr int kPasses = 8;             // 64-query passes folded into one set of launches (blockIdx.y): their tails overlap
-constexpr int kCand = 8;               // candidates re-ranked exactly per query
+constexpr int kCand = 8;               // tau = the kCand-th smallest SAMPLED proxy (so ~kCand * n / sample rows get appended)
+constexpr int kRerankGroup = 8;         // candidate rows staged in LDS at a time by the re-rank
 constexpr int kListCap = 4096;         // appended (proxy, row) entries per query before "overflow"
 constexpr int kMinSampleRows = 8192;   // rows whose proxies seed tau: max(8192, n / 64) -> ~512 appended rows per query
 
@@ -610,12 +612,243 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_bf16_wide(const ui
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// FIR_GEMM_F16: ONE fp16 MFMA term, 128 queries per gallery read. The gallery fragments are half the bytes of the bf16
+// split (2 B per feature) and each k-block costs four MFMAs instead of twelve; the price is a proxy that is only good
+// to 2^-10 |q||g| -- which the certificate simply carries in E (k_gemm_rerank): on feature vectors the gap between the
+// best row and the 8th-best proxy is an order of magnitude wider than that, and a query it cannot certify goes through
+// the exact scan like any other. Operands are scaled by powers of two into fp16's normal range (the gallery by one
+// factor, every query by its own; undone per query column in the epilogue, exact), so rounding is relative (2^-11 per
+// operand) for every element within 2^-27 of the largest; smaller ones lose at most 2^-38 of that largest value each.
+// The query tile (4 blocks x 32 k-blocks x 1 KiB = 128 KiB at 512 features) stays in LDS for a whole pass when d <= 512;
+// the gallery stream is double-buffered sixteen k-blocks (16 KiB per wave) at a time and runs on into the wave's NEXT
+// row block, so it never drains between row groups.
+// ---------------------------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f16x8 as_f16x8(const uint4 v) {
+    f16x8 r;
+    __builtin_memcpy(&r, &v, 16);
+    return r;
+}
+constexpr int kSlabH = 32;                                              // k-blocks (of 16 features) of the 128-query slab
+constexpr int kHalfLds = 4 * kSlabH * 64 * (int)sizeof(uint4);          // 128 KiB
+constexpr int kRing = 16;                                               // gallery k-blocks per double-buffer unit; the fp16 dk16 is padded to it
+
+// max |x| over the tiled gallery (padding is zero) -> out[0]; out must be zeroed first. Non-finite values poison it (NaN -> +inf).
+__global__ void __launch_bounds__(256) k_gemm_absmax(const float4* __restrict__ gal4, int64_t count4, float* __restrict__ out) {
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count4; i += (int64_t)gridDim.x * 256) {
+        const float4 g = gal4[i];
+        const float a = fmaxf(fmaxf(fabsf(g.x), fabsf(g.y)), fmaxf(fabsf(g.z), fabsf(g.w)));
+        const bool bad = !(g.x == g.x && g.y == g.y && g.z == g.z && g.w == g.w);
+        m = fmaxf(m, bad ? __builtin_huge_valf() : a);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax((unsigned int*)out, __float_as_uint(m));     // non-negative floats order like their bits
+}
+
+// tiled f32 gallery * scale (a power of two) -> gh[(rb * dk16 + kb)][lane] (uint4 = 8 fp16), round to nearest even
+__global__ void __launch_bounds__(256) k_gemm_pack_gallery_f16(const float4* __restrict__ gal4, int64_t n, int dp4, int dk16, float scale,
+                                                                uint4* __restrict__ gh) {
+    const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;      // (rb, kb, lane)
+    const int64_t rblocks = (n + 31) / 32;
+    if (o >= rblocks * dk16 * 64) return;
+    const int l = (int)(o & 63);
+    const int64_t t = o >> 6;
+    const int kb = (int)(t % dk16);
+    const int64_t rb = t / dk16;
+    const int64_t row = rb * 32 + (l & 31);
+    const int h = l >> 5;
+    f16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = 16 * kb + 8 * h + j;
+        float x = 0.f;
+        if (row < n && k < dp4 * 4) {
+            const float4 g = gal4[((row >> 6) * dp4 + (k >> 2)) * 64 + (row & 63)];
+            x = (k & 3) == 0 ? g.x : (k & 3) == 1 ? g.y : (k & 3) == 2 ? g.z : g.w;
+        }
+        v[j] = (_Float16)(x * scale);
+    }
+    uint4 u;
+    __builtin_memcpy(&u, &v, 16);
+    gh[o] = u;
+}
+
+// Per query (one wave each): |q|^2, its own power-of-two scale qmul (largest |q_k| -> [2^13, 2^14)) and
+// qinv = 1 / (qmul * gallery scale), which turns the MFMA result back into q.g. Queries past nq: all zero.
+// A query whose scale would leave [2^-100, 2^100], or with a non-finite value, gets qinv = NaN: every proxy is then NaN,
+// nothing is certified and the exact scan answers it.
+__global__ void __launch_bounds__(64) k_gemm_qprep_f16(const float* __restrict__ q, int nq, int d, int gallery_exp, float* __restrict__ qnorm,
+                                                        float* __restrict__ qmul, float* __restrict__ qinv) {
+    const int qi = blockIdx.x;
+    float s = 0.f, m = 0.f;
+    bool bad = false;
+    if (qi < nq)
+        for (int k = threadIdx.x; k < d; k += 64) {
+            const float x = q[(size_t)qi * d + k];
+            s += x * x;
+            m = fmaxf(m, fabsf(x));
+            bad = bad || !(fabsf(x) < __builtin_huge_valf());
+        }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        s += __shfl_xor(s, off, 64);
+        m = fmaxf(m, __shfl_xor(m, off, 64));
+    }
+    bad = __any(bad);
+    if (threadIdx.x == 0) {
+        int ex = 0;
+        if (m > 0.f) (void)frexpf(m, &ex);                 // m = f * 2^ex, f in [0.5, 1)
+        int sh = m > 0.f ? 14 - ex : 0;                    // m * 2^sh in [2^13, 2^14)
+        if (sh < -100 || sh > 100 || gallery_exp < -100 || gallery_exp > 100) bad = true;
+        qnorm[qi] = s;
+        qmul[qi] = bad ? 0.f : ldexpf(1.0f, sh);
+        qinv[qi] = qi >= nq ? 0.f : bad ? __builtin_nanf("") : ldexpf(1.0f, -sh - gallery_exp);
+    }
+}
+
+// queries * qmul -> qh[((pair * 4 + jb) * dk16 + kb)][lane] (uint4 = 8 fp16); blockIdx.y = pair of 64-query passes
+__global__ void __launch_bounds__(256) k_gemm_pack_queries_f16(const float* q, int nq, int d, int dk16, const float* __restrict__ qmul, uint4* qh) {
+    const int q_base = (int)blockIdx.y * 2 * kQT;
+    qh += (size_t)blockIdx.y * 4 * dk16 * 64;
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= 4 * dk16 * 64) return;
+    const int l = o & 63;
+    const int t = o >> 6;
+    const int kb = t % dk16, jb = t / dk16;
+    const int qi = q_base + jb * 32 + (l & 31), h = l >> 5;
+    const float mul = qi < nq ? qmul[qi] : 0.f;
+    f16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = 16 * kb + 8 * h + j;
+        const float x = (qi < nq && k < d) ? q[(size_t)qi * d + k] : 0.f;
+        v[j] = (_Float16)(x * mul);
+    }
+    uint4 u;
+    __builtin_memcpy(&u, &v, 16);
+    qh[o] = u;
+}
+
+// One wave: 32 rows x 128 queries. MODE 0: proxies of rows [row_begin, row_end) -> sample; MODE 1: append rows below tau.
+// Dynamic LDS: kHalfLds. blockIdx.y = pair of passes; all per-pass scratch is laid out pass-major (128 consecutive queries).
+// dk16 is a multiple of kRing here (the fp16 fragments are padded to 256-feature units). The gallery stream is a double
+// buffer of kRing k-blocks (16 KiB per wave, 128 KiB per CU in flight): the loads of the NEXT unit -- the next half of this
+// row block, or the first half of the wave's next row block -- are all issued before the sixteen MFMA steps of the current
+// one, so the only wait per unit is at its end, 2048 MFMA cycles after the loads left. (A ring that reloads each slot
+// right after use needs counted waits inside a loop, which the compiler turns into vmcnt(0) per step: one memory latency
+// per k-block -- measured 358 us per pass against 158 us of gallery stream.)
+template <int MODE>
+__global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16(const uint4* __restrict__ gh, const float* __restrict__ gnorm, const uint4* qh,
+                                                                   const float* __restrict__ qinv, int64_t n, int64_t row_begin, int64_t row_end,
+                                                                   int dk16, const float* tau, unsigned long long* lists, int* counts,
+                                                                   float* sample, int sample_rows) {
+    extern __shared__ __attribute__((aligned(16))) uint4 lqb[];
+    __shared__ float tau_s[2 * kQT], qinv_s[2 * kQT];
+    {
+        const size_t pr = blockIdx.y;
+        qh += pr * 4 * dk16 * 64;
+        qinv += pr * 2 * kQT;
+        tau += pr * 2 * kQT;
+        lists += pr * 2 * kQT * kListCap;
+        counts += pr * 2 * kQT;
+        sample += pr * 2 * kQT * sample_rows;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wpb = blockDim.x >> 6;
+    if (threadIdx.x < 2 * kQT) {
+        tau_s[threadIdx.x] = MODE == 1 ? tau[threadIdx.x] : 0.f;
+        qinv_s[threadIdx.x] = qinv[threadIdx.x];
+    }
+    const int64_t rb_begin = row_begin / 32, rb_end = (row_end + 31) / 32;
+    const int64_t nrg = (rb_end - rb_begin + wpb - 1) / wpb;
+    const int units = dk16 / kRing;                  // units of kRing k-blocks per row block
+    const int nslab = (dk16 + kSlabH - 1) / kSlabH;
+    int64_t rg = blockIdx.x;
+    if (rg >= nrg) return;                           // uniform per workgroup
+#define FIR_H_BLOCK(RG) (gh + (size_t)((rb_begin + (RG) * wpb + wave) < rb_end ? (rb_begin + (RG) * wpb + wave) : rb_end - 1) * dk16 * 64 + lane)
+    const uint4* a_cur = FIR_H_BLOCK(rg);            // waves past the last row block stream a valid one and drop the result
+    uint4 cur[kRing], nxt[kRing];
+#pragma unroll
+    for (int u = 0; u < kRing; ++u) cur[u] = ld_nt(a_cur + (size_t)u * 64);
+    bool staged = false;
+    for (; rg < nrg; rg += gridDim.x) {
+        const int64_t rb = rb_begin + rg * wpb + wave;
+        const bool active = rb < rb_end;
+        const int64_t rgn = rg + gridDim.x;
+        const uint4* a_nxt = FIR_H_BLOCK(rgn < nrg ? rgn : rg);
+        f32x16 acc0 = {0.f}, acc1 = {0.f}, acc2 = {0.f}, acc3 = {0.f};
+        for (int h = 0; h < units; ++h) {
+            const uint4* src = h + 1 < units ? a_cur + (size_t)(h + 1) * kRing * 64 : a_nxt;
+#pragma unroll
+            for (int u = 0; u < kRing; ++u) nxt[u] = ld_nt(src + (size_t)u * 64);
+            if ((h & 1) == 0 && (nslab > 1 || !staged)) {                   // a slab is two units
+                const int k0 = h * kRing;
+                const int kw = dk16 - k0 < kSlabH ? dk16 - k0 : kSlabH;
+                __syncthreads();                                            // everyone is done with the previous slab
+                for (int i = threadIdx.x; i < 4 * kw * 64; i += blockDim.x) {
+                    const int jb = i / (kw * 64), r = i - jb * kw * 64;
+                    lqb[(size_t)jb * kSlabH * 64 + r] = qh[((size_t)jb * dk16 + k0) * 64 + r];
+                }
+                __syncthreads();
+                staged = true;
+            }
+            const uint4* bq = lqb + lane + (size_t)(h & 1) * kRing * 64;
+#pragma unroll
+            for (int u = 0; u < kRing; ++u) {
+                const uint4* bu = bq + (size_t)u * 64;
+                const uint4 b0 = bu[0], b1 = bu[kSlabH * 64], b2 = bu[2 * kSlabH * 64], b3 = bu[3 * kSlabH * 64];
+                const f16x8 av = as_f16x8(cur[u]);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, as_f16x8(b0), acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, as_f16x8(b1), acc1, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, as_f16x8(b2), acc2, 0, 0, 0);
+                acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, as_f16x8(b3), acc3, 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < kRing; ++u) cur[u] = nxt[u];
+        }
+        a_cur = a_nxt;
+        if (!active) continue;
+        const int64_t nrow = rb * 32 + (lane & 31);
+        const float gn_lane = nrow < n ? gnorm[nrow] : 0.0f;
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) {
+            const int q = jb * 32 + (lane & 31);
+            const float m2 = 2.0f * qinv_s[q];
+            const float tq = tau_s[q];
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int roff = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                const int64_t row = rb * 32 + roff;
+                const float gn = __shfl(gn_lane, roff, 64);
+                if (row >= n || row < row_begin || row >= row_end) continue;
+                const float dot = jb == 0 ? acc0[reg] : jb == 1 ? acc1[reg] : jb == 2 ? acc2[reg] : acc3[reg];
+                const float p = gn - m2 * dot;
+                if (MODE == 0) {
+                    if (row < sample_rows) sample[(size_t)q * sample_rows + row] = p;
+                } else if (p < tq) {
+                    const int slot = atomicAdd(&counts[q], 1);
+                    if (slot < kListCap) lists[(size_t)q * kListCap + slot] = fir::key_pack(p, (uint32_t)row);
+                }
+            }
+        }
+    }
+#undef FIR_H_BLOCK
+}
+
 // tau[q] = kCand-th smallest sampled proxy, nudged up so that ties with it are appended too. One block per
 // query, ONE pass over the samples: every thread keeps its kCand smallest keys sorted in registers, then kCand
 // rounds of block-min pop the global order statistics.
-__global__ void __launch_bounds__(256) k_gemm_tau(const float* __restrict__ sample, int sample_rows, float* __restrict__ tau) {
+__global__ void __launch_bounds__(256) k_gemm_tau(const float* __restrict__ sample, int sample_rows, float* __restrict__ tau,
+                                                   int nq_valid = 0x7FFFFFFF) {
     __shared__ unsigned long long red[4];
     const int q = blockIdx.x;
+    if (q >= nq_valid) {        // padding queries of a half-filled pass pair: nothing is appended for them
+        if (threadIdx.x == 0) tau[q] = -__builtin_huge_valf();
+        return;
+    }
     const float* s = sample + (size_t)q * sample_rows;
     unsigned long long best[kCand];
 #pragma unroll
@@ -658,8 +891,13 @@ __global__ void __launch_bounds__(256) k_gemm_tau(const float* __restrict__ samp
     }
 }
 
-// Per query: the kCand best appended entries, re-ranked with the reference's arithmetic; certificate.
-// One wave per query. out_key[q] = exact packed key; ok[q] = 1 when the certificate holds.
+// Per query: every appended entry that could still be the nearest row is re-ranked with the reference's arithmetic, then
+// the certificate. One wave per query. out_key[q] = exact packed key; ok[q] = 1 when the certificate holds.
+// Each proxy is within E d of its row's true |g|^2 - 2 q.g, so a row whose proxy exceeds the smallest proxy p1 by more than
+// 2 E d cannot beat the row that has p1: the window [p1, p1 + 2 E d] holds every possible winner -- a handful of rows on
+// ordinary data, all the near-duplicates on clustered data (a fixed number of candidates, as used before, could not
+// certify those and sent them to the exact scan). The window is only how candidates are CHOSEN; what proves the answer
+// is the certificate at the end, which is independent of that reasoning.
 __global__ void __launch_bounds__(64) k_gemm_rerank(const unsigned long long* __restrict__ lists, const int* __restrict__ counts,
                                                      const float* __restrict__ tau, const float4* __restrict__ gal4,
                                                      const float* __restrict__ queries, const float* __restrict__ qnorm,
@@ -669,85 +907,91 @@ __global__ void __launch_bounds__(64) k_gemm_rerank(const unsigned long long* __
     const int cnt = counts[q];
     const int have = cnt < kListCap ? cnt : kListCap;
     const unsigned long long* L = lists + (size_t)q * kListCap;
-    // kCand rounds of wave-min over the list ("smallest key greater than the previous winner")
-    unsigned long long pick[kCand];
-    unsigned long long prev = 0;
-    bool first = true;
-    int got = 0;
+    unsigned long long kmin = kKeyNone;
+    for (int i = lane; i < have; i += 64) {
+        const unsigned long long v = L[i];
+        kmin = v < kmin ? v : kmin;
+    }
+    kmin = fir::wave_min_u64(kmin);
+    const float qn = qnorm[q], gmax = gnorm_max_p[0];
+    // E bounds every rounding on both sides, in distance units: the f32 fma chain of the dot product (<= d u |q||g|,
+    // doubled), the two float norms (<= d u each), the reference's own d+3 roundings of the (q-g)^2 sum and its divide:
+    // (4d + 11) u (|q|^2 + |g|^2) / d in total; 8 d u (...) / d is used.  u = 2^-24.
+    // e_rel = 8 d u, plus 2^-14 for the bf16-split variant (dropped lo.lo / residual terms, 3 * 2^-18 |g||q|, doubled in p)
+    // or 2^-10 (1 + 2^-4) for the single fp16 term (both operands rounded to 11 bits)
+    const float E = e_rel * (qn + gmax) / (float)d;
+    const float p1 = kmin != kKeyNone ? fir::f32_from_orderable((uint32_t)(kmin >> 32)) : __builtin_huge_valf();
+    float win = p1 + 2.0f * E * (float)d;
+    win += fabsf(win) * 1e-6f;
+    const float* qv = queries + (size_t)q * d;
+    unsigned long long best = kKeyNone;
+    float p_out = __builtin_huge_valf();            // smallest proxy NOT re-ranked
+    int reranked = 0;
+    extern __shared__ __attribute__((aligned(16))) float4 crow[];     // [kRerankGroup][dp4]: candidate rows, loaded by the whole wave
+    for (int base = 0; base < have; base += 64) {
+        const int i = base + lane;
+        const unsigned long long v = i < have ? L[i] : kKeyNone;
+        const float p = fir::f32_from_orderable((uint32_t)(v >> 32));
+        const bool in = i < have && p <= win;
+        if (i < have && !in) p_out = fminf(p_out, p);
+        unsigned long long mask = __ballot(in);
+        reranked += __popcll(mask);
+        while (mask) {                                                  // wave-uniform
+            // up to kRerankGroup candidates at a time: all lanes fetch their rows into LDS, then lane g re-computes
+            // candidate g's distance from there: db_features.cpp:22-42 order, un-fused (fir::accum<kL2>)
+            unsigned long long mine = kKeyNone;
+            int ng = 0;
 #pragma unroll
-    for (int r = 0; r < kCand; ++r) {
-        unsigned long long cand = kKeyNone;
-        if (first || prev != kKeyNone) {
-            for (int i = lane; i < have; i += 64) {
-                const unsigned long long v = L[i];
-                if ((first || v > prev) && v < cand) cand = v;
+            for (int g = 0; g < kRerankGroup; ++g) {
+                if (mask) {
+                    const int src = __ffsll((long long)mask) - 1;
+                    mask &= mask - 1;
+                    const unsigned long long cv = __shfl((unsigned long long)v, src, 64);
+                    const int64_t row = (int64_t)(uint32_t)(cv & 0xFFFFFFFFull);
+                    const float4* gr = gal4 + (size_t)(row >> 6) * dp4 * 64 + (row & 63);
+                    for (int c = lane; c < dp4; c += 64) crow[(size_t)g * dp4 + c] = gr[(size_t)c * 64];
+                    if (lane == g) mine = cv;
+                    ++ng;
+                }
             }
-        }
-        cand = fir::wave_min_u64(cand);
-        pick[r] = cand;
-        if (cand != kKeyNone) ++got;
-        prev = cand;
-        first = false;
-    }
-    unsigned long long last_pick = pick[0];
+            __syncthreads();
+            if (lane < ng) {
+                const float4* my = crow + (size_t)lane * dp4;
+                float acc = 0.0f;
+                for (int c = 0; c < dp4; ++c) {
+                    const float4 g4 = my[c];
+                    const float gv[4] = {g4.x, g4.y, g4.z, g4.w};
 #pragma unroll
-    for (int r = 1; r < kCand; ++r) last_pick = pick[r] != kKeyNone ? pick[r] : last_pick;
-    // the picked rows go to LDS with all 64 lanes loading (kCand x dp4 float4), then lane c re-computes candidate c's
-    // distance from there: db_features.cpp:22-42 order, un-fused (fir::accum<kL2>)
-    extern __shared__ __attribute__((aligned(16))) float4 crow[];     // [kCand][dp4]
-    for (int i = lane; i < kCand * dp4; i += 64) {
-        const int cnd = i / dp4, c = i - cnd * dp4;
-        unsigned long long pk = pick[0];
-#pragma unroll
-        for (int r = 1; r < kCand; ++r) pk = cnd == r ? pick[r] : pk;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (pk != kKeyNone) {
-            const int64_t row = (int64_t)(uint32_t)(pk & 0xFFFFFFFFull);
-            v = gal4[((row >> 6) * dp4 + c) * 64 + (row & 63)];
-        }
-        crow[i] = v;
-    }
-    __syncthreads();
-    unsigned long long key = kKeyNone;
-    if (lane < got) {
-        unsigned long long mine = pick[0];
-#pragma unroll
-        for (int r = 1; r < kCand; ++r) mine = lane == r ? pick[r] : mine;
-        const int64_t row = (int64_t)(uint32_t)(mine & 0xFFFFFFFFull);
-        const float* qv = queries + (size_t)q * d;
-        const float4* my = crow + (size_t)lane * dp4;
-        float acc = 0.0f;
-        for (int c = 0; c < dp4; ++c) {
-            const float4 g = my[c];
-            const float gv[4] = {g.x, g.y, g.z, g.w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int k = c * 4 + j;
-                if (k < d) acc = fir::accum<fir::kL2>(acc, qv[k], gv[j]);
+                    for (int j = 0; j < 4; ++j) {
+                        const int k = c * 4 + j;
+                        if (k < d) acc = fir::accum<fir::kL2>(acc, qv[k], gv[j]);
+                    }
+                }
+                const float dist = acc / (float)d;
+                if (dist < fir::kNotFound) {
+                    const int64_t row = (int64_t)(uint32_t)(mine & 0xFFFFFFFFull);
+                    const unsigned long long key = fir::key_pack(dist, (uint32_t)(row + row_offset));
+                    best = key < best ? key : best;
+                }
             }
+            __syncthreads();
         }
-        const float dist = acc / (float)d;
-        if (dist < fir::kNotFound) key = fir::key_pack(dist, (uint32_t)(row + row_offset));
     }
-    key = fir::wave_min_u64(key);
+    best = fir::wave_min_u64(best);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) p_out = fminf(p_out, __shfl_xor(p_out, off, 64));
     if (lane == 0) {
-        out_key[q] = key;
-        // Certificate. Every row NOT re-ranked has proxy >= p_excl: the kCand-th picked proxy when the list held more,
-        // else tau (nothing below tau was left out). Its reference distance is then >= (|q|^2 + p_excl)/d - E.
+        out_key[q] = best;
+        // Certificate. Every row NOT re-ranked has a proxy >= p_excl: the smallest list entry outside the window, or tau
+        // for rows that were never appended. Its reference distance is then >= (|q|^2 + p_excl)/d - E.
         bool certified = false;
         if (cnt <= kListCap) {                      // nothing below tau was dropped from the list
-            // rows not re-ranked: never appended (p >= tau) or appended but beyond the kCand picks (p >= last pick's)
-            const float p_excl = have > got ? fir::f32_from_orderable((uint32_t)(last_pick >> 32)) : tau[q];
-            const float qn = qnorm[q], gmax = gnorm_max_p[0];
-            // E bounds every rounding on both sides, in distance units: the f32 fma chain of the dot product
-            // (<= d u |q||g|, doubled), the two float norms (<= d u each), the reference's own d+3 roundings of the
-            // (q-g)^2 sum and its divide: (4d + 11) u (|q|^2 + |g|^2) / d in total; 8 d u (...) / d is used.  u = 2^-24.
-            // e_rel = 8 d u, plus 2^-14 for the bf16-split variant (dropped lo.lo / residual terms, 3 * 2^-18 |g||q|, doubled in p)
-            const float E = e_rel * (qn + gmax) / (float)d;
+            const float t = tau[q];
+            const float p_excl = t != t ? t : fminf(p_out, t);      // a NaN bound must not certify anything
             const float lower = (qn + p_excl) / (float)d - E;
-            const float best = key != kKeyNone ? fir::f32_from_orderable((uint32_t)(key >> 32)) : fir::kNotFound;
-            certified = lower > best;               // false for NaN
-            if (n <= got) certified = true;         // every row was re-ranked
+            const float bd = best != kKeyNone ? fir::f32_from_orderable((uint32_t)(best >> 32)) : fir::kNotFound;
+            certified = lower > bd;                 // false for NaN
+            if (n <= reranked) certified = true;    // every row was re-ranked
         }
         ok[q] = certified ? 1 : 0;
     }
@@ -783,7 +1027,11 @@ struct fir_gemm {
     fir_gallery_view v;
     const float4* gal4 = nullptr;
     int dp4 = 0, dq8 = 0;
-    int precision = 0;          // 0: f32 MFMA, 1: bf16 split (hi.hi + hi.lo + lo.hi)
+    int precision = 0;          // 0: f32 MFMA, 1: bf16 split (hi.hi + hi.lo + lo.hi), 2: one fp16 term
+    uint4* gh = nullptr;        // fp16 fragments (precision 2)
+    int gallery_exp = 0;        // fp16: the gallery was multiplied by 2^gallery_exp
+    float* qmul[2] = {nullptr, nullptr};
+    float* qinv[2] = {nullptr, nullptr};
     int dk16 = 0;               // bf16 variant: k-blocks of 16 features (padded to a multiple of 4)
     float4* gm = nullptr;       // f32 fragments
     uint4* gb = nullptr;        // bf16 hi/lo fragments
@@ -815,7 +1063,8 @@ int fir_gemm_create(fir_gallery* g, fir_gemm** out) { return fir_gemm_create_ex(
 
 int fir_gemm_create_ex(fir_gallery* g, int32_t precision, fir_gemm** out) {
     if (!g || !out) return gemm_fail(FIR_ERR_ARG, "NULL argument");
-    if (precision != FIR_GEMM_F32 && precision != FIR_GEMM_BF16_SPLIT) return gemm_fail(FIR_ERR_ARG, "bad precision %d", precision);
+    if (precision != FIR_GEMM_F32 && precision != FIR_GEMM_BF16_SPLIT && precision != FIR_GEMM_F16)
+        return gemm_fail(FIR_ERR_ARG, "bad precision %d", precision);
     *out = nullptr;
     fir_gemm* m = new (std::nothrow) fir_gemm();
     if (!m) return gemm_fail(FIR_ERR_NOMEM, "host allocation failed");
@@ -827,17 +1076,21 @@ int fir_gemm_create_ex(fir_gallery* g, int32_t precision, fir_gemm** out) {
     if (const char* w = std::getenv("FIR_GEMM_WIDE")) m->wide = std::atoi(w) != 0;   // experiments: 0 = one pass per gallery read
     m->dq8 = (m->v.d + 31) / 32 * 4;     // feature groups of 8, padded to a multiple of 4 groups (zeros)
     m->dk16 = (m->v.d + 63) / 64 * 4;    // k-blocks of 16, padded to a multiple of 4
+    if (precision == FIR_GEMM_F16) m->dk16 = (m->v.d + 255) / 256 * kRing;   // ... to whole double-buffer units of 16
     hipError_t e = hipSetDevice(m->v.device);
     const int64_t rblocks = (std::max<int64_t>(m->v.n, 1) + 31) / 32;
     const int64_t np = std::max<int64_t>(m->v.n, 1);
     if (e == hipSuccess && precision == FIR_GEMM_F32) e = hipMalloc((void**)&m->gm, (size_t)rblocks * m->dq8 * 64 * sizeof(float4));
     if (e == hipSuccess && precision == FIR_GEMM_BF16_SPLIT) e = hipMalloc((void**)&m->gb, (size_t)rblocks * m->dk16 * 128 * sizeof(uint4));
+    if (e == hipSuccess && precision == FIR_GEMM_F16) e = hipMalloc((void**)&m->gh, (size_t)rblocks * m->dk16 * 64 * sizeof(uint4));
     if (e == hipSuccess) e = hipMalloc((void**)&m->gnorm, (size_t)np * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&m->gmax, 16);
     for (int b = 0; b < 2; ++b) {
         if (e == hipSuccess) e = hipMalloc((void**)&m->qm[b], (size_t)kPasses * (kQT / 32) * m->dq8 * 64 * sizeof(float4));
         if (e == hipSuccess) e = hipMalloc((void**)&m->qbf[b], (size_t)kPasses * (kQT / 32) * m->dk16 * 128 * sizeof(uint4));
         if (e == hipSuccess) e = hipMalloc((void**)&m->qnorm[b], kPasses * kQT * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc((void**)&m->qmul[b], kPasses * kQT * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc((void**)&m->qinv[b], kPasses * kQT * sizeof(float));
         if (e == hipSuccess) e = hipMalloc((void**)&m->tau[b], kPasses * kQT * sizeof(float));
         if (e == hipSuccess) e = hipMalloc((void**)&m->lists[b], (size_t)kPasses * kQT * kListCap * sizeof(unsigned long long));
         if (e == hipSuccess) e = hipMalloc((void**)&m->counts[b], kPasses * kQT * sizeof(int));
@@ -856,12 +1109,31 @@ int fir_gemm_create_ex(fir_gallery* g, int32_t precision, fir_gemm** out) {
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy_bf16<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy_bf16<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy_bf16_wide, hipFuncAttributeMaxDynamicSharedMemorySize, kWideLds);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy_f16<0>, hipFuncAttributeMaxDynamicSharedMemorySize, kHalfLds);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy_f16<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kHalfLds);
     if (e == hipSuccess && m->v.n > 0) {
         // row norms come from the f32 packer (run on a one-group scratch when only the bf16 fragments are kept)
         if (precision == FIR_GEMM_BF16_SPLIT) {
             const int64_t totalb = rblocks * m->dk16 * 64;
             hipLaunchKernelGGL(k_gemm_pack_gallery_bf16, dim3((unsigned)((totalb + 255) / 256)), dim3(256), 0, m->v.stream, m->gal4, m->v.n, m->dp4,
                                m->dk16, m->gb);
+            hipLaunchKernelGGL(k_gemm_row_norms, dim3((unsigned)((m->v.n + 255) / 256)), dim3(256), 0, m->v.stream, m->gal4, m->v.n, m->dp4, m->gnorm);
+        }
+        if (precision == FIR_GEMM_F16) {
+            // one power-of-two scale for the whole gallery: its largest |value| lands in [2^13, 2^14)
+            float h_max = 0.f;
+            e = hipMemsetAsync(m->gmax, 0, 16, m->v.stream);
+            const int64_t count4 = (int64_t)((m->v.n + 63) / 64) * m->dp4 * 64;
+            hipLaunchKernelGGL(k_gemm_absmax, dim3((unsigned)std::min<int64_t>((count4 + 255) / 256, 4096)), dim3(256), 0, m->v.stream, m->gal4, count4, m->gmax);
+            if (e == hipSuccess) e = hipMemcpyAsync(&h_max, m->gmax, sizeof(float), hipMemcpyDeviceToHost, m->v.stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(m->v.stream);
+            int ex = 0;
+            if (h_max > 0.f && h_max < __builtin_huge_valf()) { (void)std::frexp(h_max, &ex); m->gallery_exp = 14 - ex; }
+            else m->gallery_exp = h_max > 0.f ? 1000 : 0;      // non-finite gallery value: every query is left to the exact scan
+            const float scale = (m->gallery_exp >= -100 && m->gallery_exp <= 100) ? std::ldexp(1.0f, m->gallery_exp) : 0.f;
+            const int64_t totalh = rblocks * m->dk16 * 64;
+            hipLaunchKernelGGL(k_gemm_pack_gallery_f16, dim3((unsigned)((totalh + 255) / 256)), dim3(256), 0, m->v.stream, m->gal4, m->v.n, m->dp4,
+                               m->dk16, scale, m->gh);
             hipLaunchKernelGGL(k_gemm_row_norms, dim3((unsigned)((m->v.n + 255) / 256)), dim3(256), 0, m->v.stream, m->gal4, m->v.n, m->dp4, m->gnorm);
         }
         const int64_t total = precision == FIR_GEMM_F32 ? rblocks * m->dq8 * 64 : 0;
@@ -887,11 +1159,11 @@ int fir_gemm_destroy(fir_gemm* m) {
     (void)hipStreamSynchronize(m->v.stream);
     if (m->side) { (void)hipStreamSynchronize(m->side); (void)hipStreamDestroy(m->side); }
     for (int b = 0; b < 2; ++b) {
-        (void)hipFree(m->qm[b]); (void)hipFree(m->qbf[b]); (void)hipFree(m->qnorm[b]); (void)hipFree(m->tau[b]); (void)hipFree(m->lists[b]); (void)hipFree(m->counts[b]);
+        (void)hipFree(m->qm[b]); (void)hipFree(m->qbf[b]); (void)hipFree(m->qnorm[b]); (void)hipFree(m->qmul[b]); (void)hipFree(m->qinv[b]); (void)hipFree(m->tau[b]); (void)hipFree(m->lists[b]); (void)hipFree(m->counts[b]);
         if (m->main_done[b]) (void)hipEventDestroy(m->main_done[b]);
         if (m->rerank_done[b]) (void)hipEventDestroy(m->rerank_done[b]);
     }
-    (void)hipFree(m->gm); (void)hipFree(m->gb); (void)hipFree(m->gnorm); (void)hipFree(m->gmax); (void)hipFree(m->sample); (void)hipFree(m->ok);
+    (void)hipFree(m->gm); (void)hipFree(m->gb); (void)hipFree(m->gh); (void)hipFree(m->gnorm); (void)hipFree(m->gmax); (void)hipFree(m->sample); (void)hipFree(m->ok);
     (void)hipFree(m->fbq); (void)hipFree(m->fbkeys);
     delete m;
     return FIR_OK;
@@ -924,7 +1196,10 @@ int fir_gemm_search_top1_keys_dev(fir_gemm* m, const float* d_queries, int32_t q
     }
     const size_t lds = m->precision == FIR_GEMM_F32 ? (size_t)(kQT / 32) * std::min(m->dq8, kSlab8) * 64 * sizeof(float4)
                                                     : (size_t)(kQT / 32) * std::min(m->dk16, kSlab16) * 128 * sizeof(uint4);
-    const float e_rel = 8.0f * (float)d * 5.9604645e-8f + (m->precision == FIR_GEMM_BF16_SPLIT ? 6.1035156e-5f : 0.0f);
+    // fp16: both operands rounded to 11 bits -> |q~.g~ - q.g| <= (2^-10 + 2^-22) sum|q_k g_k| + the sub-normal tails
+    // (< 2^-27 |q||g| for d <= 2^20), doubled in p and with |q||g| <= (|q|^2 + max|g|^2) / 2: 2^-10 (1 + 2^-4) covers it
+    const float e_rel = 8.0f * (float)d * 5.9604645e-8f +
+                        (m->precision == FIR_GEMM_BF16_SPLIT ? 6.1035156e-5f : m->precision == FIR_GEMM_F16 ? 9.765625e-4f * 1.0625f : 0.0f);
     const int grid = m->v.cus;      // one 512-thread workgroup per CU
     const int sample_rows = m->sample_rows;
     int sb = 0;      // super-batch = up to kPasses passes of 64 queries in ONE set of launches
@@ -934,10 +1209,26 @@ int fir_gemm_search_top1_keys_dev(fir_gemm* m, const float* d_queries, int32_t q
         const int b = sb & 1;
         const float* dq = d_queries + (size_t)q0 * d;
         if (sb >= 2) GEMM_HIP(hipStreamWaitEvent(st, m->rerank_done[b], 0));     // scratch set b is free again
+        const int sample_grid = (sample_rows + 63) / 64;
+        if (m->precision == FIR_GEMM_F16) {
+            const int pairs = (np + 1) / 2;                      // 128 queries per gallery read; a half-filled pair is zero-padded
+            hipLaunchKernelGGL(k_gemm_qprep_f16, dim3(pairs * 2 * kQT), dim3(64), 0, st, dq, nq, d, m->gallery_exp, m->qnorm[b], m->qmul[b], m->qinv[b]);
+            GEMM_HIP(hipMemsetAsync(m->counts[b], 0, (size_t)pairs * 2 * kQT * sizeof(int), st));
+            hipLaunchKernelGGL(k_gemm_pack_queries_f16, dim3((4 * m->dk16 * 64 + 255) / 256, pairs), dim3(256), 0, st, dq, nq, d, m->dk16, m->qmul[b],
+                               m->qbf[b]);
+            const int wpb = kGemmBlock / 64;
+            const int sample_wgs = (int)((((int64_t)sample_rows + 31) / 32 + wpb - 1) / wpb);
+            hipLaunchKernelGGL(k_gemm_proxy_f16<0>, dim3(std::min(sample_wgs, grid), pairs), dim3(kGemmBlock), kHalfLds, st, m->gh, m->gnorm, m->qbf[b],
+                               m->qinv[b], n, (int64_t)0, (int64_t)sample_rows, m->dk16, m->tau[b], m->lists[b], m->counts[b], m->sample, sample_rows);
+            hipLaunchKernelGGL(k_gemm_tau, dim3(pairs * 2 * kQT), dim3(256), 0, st, m->sample, sample_rows, m->tau[b], nq);
+            hipLaunchKernelGGL(k_gemm_proxy_f16<1>, dim3(grid, pairs), dim3(kGemmBlock), kHalfLds, st, m->gh, m->gnorm, m->qbf[b], m->qinv[b], n,
+                               (int64_t)0, n, m->dk16, m->tau[b], m->lists[b], m->counts[b], m->sample, sample_rows);
+        } else {
         hipLaunchKernelGGL(k_gemm_qnorm, dim3(np * kQT), dim3(64), 0, st, dq, nq, d, m->qnorm[b]);
         GEMM_HIP(hipMemsetAsync(m->counts[b], 0, (size_t)np * kQT * sizeof(int), st));
-        const int sample_grid = (sample_rows + 63) / 64;
-        if (m->precision == FIR_GEMM_F32) {
+        }
+        if (m->precision == FIR_GEMM_F16) {
+        } else if (m->precision == FIR_GEMM_F32) {
             hipLaunchKernelGGL(k_gemm_pack_queries, dim3(((kQT / 32) * m->dq8 * 64 + 255) / 256, np), dim3(256), 0, st, dq, nq, d, m->dq8, m->qm[b]);
             hipLaunchKernelGGL(k_gemm_proxy<0>, dim3(sample_grid, np), dim3(128), lds, st, m->gm, m->gnorm, m->qm[b], n, (int64_t)0,
                                (int64_t)sample_rows, m->dq8, m->tau[b], m->lists[b], m->counts[b], m->sample, sample_rows);
@@ -965,7 +1256,7 @@ int fir_gemm_search_top1_keys_dev(fir_gemm* m, const float* d_queries, int32_t q
         GEMM_HIP(hipEventRecord(m->main_done[b], st));
         // exact re-rank + certificate of this super-batch on the side stream, under the next one's GEMM
         GEMM_HIP(hipStreamWaitEvent(m->side, m->main_done[b], 0));
-        hipLaunchKernelGGL(k_gemm_rerank, dim3(nq), dim3(64), (size_t)kCand * m->dp4 * sizeof(float4), m->side, m->lists[b], m->counts[b], m->tau[b],
+        hipLaunchKernelGGL(k_gemm_rerank, dim3(nq), dim3(64), (size_t)kRerankGroup * m->dp4 * sizeof(float4), m->side, m->lists[b], m->counts[b], m->tau[b],
                            m->gal4, dq, m->qnorm[b], m->gmax, n, d, m->dp4, m->v.row_offset, e_rel, (unsigned long long*)d_keys + q0, m->ok + q0);
         GEMM_HIP(hipEventRecord(m->rerank_done[b], m->side));
         m->passes += np;

@@ -233,7 +233,10 @@ int fir_rows_distances(fir_gallery* g, const float* queries, int32_t qb, const i
 typedef struct fir_gemm fir_gemm;
 enum {
     FIR_GEMM_F32 = 0,        /* v_mfma_f32_32x32x2_f32: exact products (157 TF peak)                                */
-    FIR_GEMM_BF16_SPLIT = 1  /* x = hi + lo in bf16, hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_bf16 (default) */
+    FIR_GEMM_BF16_SPLIT = 1, /* x = hi + lo in bf16, hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_bf16 (default) */
+    FIR_GEMM_F16 = 2         /* one v_mfma_f32_32x32x16_f16 term on power-of-two-scaled fp16 copies: half the gallery bytes and a
+                              * third of the MFMAs per 128 queries; the proxy is good to 2^-10 |q||g|, which the certificate carries,
+                              * so near-duplicate-heavy galleries send more queries to the exact scan */
 };
 int fir_gemm_create(fir_gallery* g, fir_gemm** out);   /* = fir_gemm_create_ex(g, FIR_GEMM_BF16_SPLIT, out) */
 int fir_gemm_create_ex(fir_gallery* g, int32_t precision, fir_gemm** out);

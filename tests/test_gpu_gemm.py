@@ -25,7 +25,7 @@ def run_both(fir, rows, q, precision=1):
 
 
 @pytest.mark.parametrize("seed,n,d,qb", [(1, 5000, 512, 70), (2, 40000, 512, 64), (3, 1000, 256, 5), (4, 333, 100, 130), (5, 7, 64, 3), (6, 70000, 128, 200), (7, 3000, 1280, 70), (8, 900, 1536, 9), (9, 2000, 520, 33)])
-@pytest.mark.parametrize("precision", [0, 1])
+@pytest.mark.parametrize("precision", [0, 1, 2])
 def test_gemm_equals_scan(fir, oracle, seed, n, d, qb, precision):
     rows = synth.make_gallery(seed, n, d, 0)
     q, _ = synth.make_queries(seed, rows, qb, 0)
@@ -34,7 +34,8 @@ def test_gemm_equals_scan(fir, oracle, seed, n, d, qb, precision):
     assert np.array_equal(dist.view(np.uint32), edist.view(np.uint32))
     for i in (0, qb - 1):
         assert (idx[i], dist[i]) == oracle.recognize_bf(rows, q[i], 0, d, 0)
-    assert st["fallback_queries"] <= qb // 4 + 2, st      # the certificate normally holds on random data
+    if precision != 2 or n >= 1000:
+        assert st["fallback_queries"] <= qb // 4 + 2, st  # the certificate normally holds on random data (fp16: given enough rows to sample)
 
 
 @pytest.mark.parametrize("n,d,qb", [(3000, 48, 128), (3000, 100, 129), (9000, 512, 257), (2500, 700, 192), (1200, 1280, 130),
@@ -48,13 +49,14 @@ def test_paired_passes_all_shapes(fir, n, d, qb):
     if n > 1000:
         rows[n - 1] = rows[17]                   # an exact tie across row blocks: the lower row wins
         q[3] = rows[17]
-    (idx, dist), (eidx, edist), st = run_both(fir, rows, q, 1)
-    assert np.array_equal(idx, eidx)
-    assert np.array_equal(dist.view(np.uint32), edist.view(np.uint32))
+    for precision in (1, 2):
+        (idx, dist), (eidx, edist), st = run_both(fir, rows, q, precision)
+        assert np.array_equal(idx, eidx), precision
+        assert np.array_equal(dist.view(np.uint32), edist.view(np.uint32)), precision
 
 
 @pytest.mark.parametrize("scale", [1e-20, 1e-6, 30.0, 1e15, 1e19])
-@pytest.mark.parametrize("precision", [0, 1])
+@pytest.mark.parametrize("precision", [0, 1, 2])
 def test_extreme_magnitudes_fall_back_to_the_same_answers(fir, scale, precision):
     """Inputs far from unit norm: products in the denormal range, distances beyond the 100000 cut-off, squares that
     overflow. Whatever the proxies become, the certificate or the fallback returns the exact scan's keys."""
@@ -65,10 +67,10 @@ def test_extreme_magnitudes_fall_back_to_the_same_answers(fir, scale, precision)
     assert np.array_equal(dist.view(np.uint32), edist.view(np.uint32))
 
 
-@pytest.mark.parametrize("precision", [0, 1])
+@pytest.mark.parametrize("precision", [0, 1, 2])
 def test_gemm_adversarial_near_ties_and_duplicates(fir, oracle, precision):
-    """20 rows within a few ulps of the best (more than the 8 re-ranked candidates), exact duplicates of the best,
-    a NaN row and unnormalised rows: the certificate must refuse and the exact scan must answer."""
+    """20 rows within a few ulps of the best, exact duplicates of the best, a NaN row and unnormalised rows: every row
+    inside the rounding window of the best proxy is re-ranked exactly, so the lowest row of a tie wins as in the scan."""
     n, d = 30000, 512
     rows = synth.make_gallery(9, n, d, 0)
     q, pick = synth.make_queries(9, rows, 12, 0)
@@ -89,7 +91,6 @@ def test_gemm_adversarial_near_ties_and_duplicates(fir, oracle, precision):
     assert np.array_equal(idx, eidx)
     assert np.array_equal(dist.view(np.uint32), edist.view(np.uint32))
     assert idx[2] == 5 and dist[2] == 0
-    assert st["fallback_queries"] >= 1        # the near-tie queries cannot be certified with 8 candidates
     for i in range(4):
         assert (idx[i], dist[i]) == oracle.recognize_bf(rows, q[i], 0, d, 0)
 
@@ -118,3 +119,40 @@ def test_host_call_auto_dispatch(fir):
     assert np.array_equal(a[0][:50], c[0])
     assert d[0].shape == (300,)
     assert np.array_equal(e[0], a[0] + 1000) and np.array_equal(e[1].view(np.uint32), a[1].view(np.uint32))
+
+
+def test_fp16_term_wide_dynamic_range_and_mixed_scales(fir):
+    """FIR_GEMM_F16 scales the gallery by one power of two and every query by its own: rows and queries whose values span
+    many binades (elements far below the largest lose their low bits in fp16, some flush to zero), queries at very
+    different magnitudes in one batch, an all-zero query and an infinite one. Same keys as the scan, whatever is certified."""
+    rng = np.random.default_rng(5)
+    n, d, qb = 20000, 320, 140                      # 320 features: 20 k-blocks, the ring does not run on into the next row block
+    rows = synth.make_gallery(61, n, d, 0)
+    rows *= np.exp2(rng.integers(-12, 1, size=(n, 1))).astype(np.float32)        # row norms over 12 binades
+    rows[:, ::5] *= np.float32(2.0 ** -20)                                        # a fifth of the features 20 binades down
+    q, _ = synth.make_queries(61, rows, qb, 0)
+    q *= np.exp2(rng.integers(-30, 30, size=(qb, 1))).astype(np.float32)
+    q[7] = 0
+    q[8, 3] = np.inf
+    q[9] = rows[123]
+    (idx, dist), (eidx, edist), st = run_both(fir, rows, q, 2)
+    assert np.array_equal(idx, eidx)
+    assert np.array_equal(dist.view(np.uint32), edist.view(np.uint32), )
+    assert idx[9] == 123
+
+
+@pytest.mark.parametrize("precision", [0, 1, 2])
+def test_more_ties_than_the_candidate_list_holds(fir, precision):
+    """5000 copies of one row: more entries below tau than a query's candidate list (4096) can take. The overflow is
+    detected, the certificate refuses and the exact scan answers -- the lowest copy."""
+    n, d = 9000, 128
+    rows = synth.make_gallery(77, n, d, 0)
+    rows[2000:7000] = rows[10]
+    q, _ = synth.make_queries(77, rows, 66, 0)
+    q[0] = rows[10]
+    q[1] = rows[10] * np.float32(1.001)
+    (idx, dist), (eidx, edist), st = run_both(fir, rows, q, precision)
+    assert np.array_equal(idx, eidx)
+    assert np.array_equal(dist.view(np.uint32), edist.view(np.uint32))
+    assert idx[0] == 10 and dist[0] == 0
+    assert st["fallback_queries"] >= 1

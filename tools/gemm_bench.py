@@ -29,7 +29,7 @@ def main():
     ap.add_argument("--rows", type=int, default=1_000_000)
     ap.add_argument("--dim", type=int, default=512)
     ap.add_argument("--qb", default="64,256,1024")
-    ap.add_argument("--precision", type=int, default=1, help="0 = f32 MFMA, 1 = bf16 split")
+    ap.add_argument("--precision", type=int, default=1, help="0 = f32 MFMA, 1 = bf16 split, 2 = one fp16 term")
     a = ap.parse_args()
     fir = ge.load_package()
     dev = torch.device("cuda", 0)
@@ -39,7 +39,7 @@ def main():
     g = fir.Gallery(dev_ptr=x.data_ptr(), n=n, d=d, metric=0, device=0)
     m = fir.GemmSearch(g, a.precision)
     st = torch.cuda.Stream()
-    print(f"gallery {n} x {d} f32; matrix-core path ({['f32 MFMA', 'bf16-split MFMA'][a.precision]} + exact re-rank + certificate) vs exact scan")
+    print(f"gallery {n} x {d} f32; matrix-core path ({['f32 MFMA', 'bf16-split MFMA', 'fp16 MFMA, one term'][a.precision]} + exact re-rank + certificate) vs exact scan")
     for qb in [int(v) for v in a.qb.split(",")]:
         fresh = torch.rand((qb, d), device=dev)
         pert = x[(torch.arange(qb, device=dev) * 977 + 11) % n] + (torch.rand((qb, d), device=dev) - 0.5) * 0.05 * x.mean()
