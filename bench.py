@@ -174,9 +174,9 @@ def main():
                 gm.search_top1_keys_dev(q.data_ptr(), qb, k2.data_ptr(), stream=stream)
             torch.cuda.synchronize()
             tg = (time.perf_counter() - tg0) / 5
-        mfma = {"kernel": "bf16-split MFMA (hi.hi + hi.lo + lo.hi, 128 queries per gallery read) nominates 8 candidates, reference arithmetic re-ranks, certificate + exact-scan fallback",
+        mfma = {"kernel": "fp16 MFMA (one term, power-of-two-scaled operands, 128 queries per gallery read) nominates rows, reference arithmetic re-ranks every row inside the rounding window, certificate + exact-scan fallback",
                 "queries_per_s": qb / tg, "ms_per_step": tg * 1e3, "tflops_dot_products": 2.0 * n * d * qb / tg / 1e12,
-                "gallery_GBps": (row_hi - row_lo) * d * 4.0 * (-(-qb // 128)) / tg / 1e9,     # hi+lo fragments: 4 B per feature, once per 128 queries
+                "gallery_GBps": (row_hi - row_lo) * d * 2.0 * (-(-qb // 128)) / tg / 1e9,     # fp16 fragments: 2 B per feature, once per 128 queries
                 "identical_keys_to_scan": bool(torch.equal(keys, k2)), "fallback_queries": gm.stats()["fallback_queries"]}
         gm.close()
 

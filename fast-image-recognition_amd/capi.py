@@ -313,9 +313,9 @@ class Gallery:
 class GemmSearch:
     """Large-batch L2 top-1 through the matrix cores (fir_gemm_*): same answers as Gallery.search_top1."""
 
-    F32, BF16_SPLIT = 0, 1
+    F32, BF16_SPLIT, F16 = 0, 1, 2
 
-    def __init__(self, gallery, precision=1):
+    def __init__(self, gallery, precision=2):
         self._g = gallery           # keeps the gallery alive
         self._h = _vp()
         _check(lib().fir_gemm_create_ex(gallery._h, precision, C.byref(self._h)))

@@ -1059,7 +1059,7 @@ struct fir_gemm {
 
 extern "C" {
 
-int fir_gemm_create(fir_gallery* g, fir_gemm** out) { return fir_gemm_create_ex(g, FIR_GEMM_BF16_SPLIT, out); }
+int fir_gemm_create(fir_gallery* g, fir_gemm** out) { return fir_gemm_create_ex(g, FIR_GEMM_F16, out); }
 
 int fir_gemm_create_ex(fir_gallery* g, int32_t precision, fir_gemm** out) {
     if (!g || !out) return gemm_fail(FIR_ERR_ARG, "NULL argument");

@@ -226,19 +226,19 @@ int fir_rows_distances(fir_gallery* g, const float* queries, int32_t qb, const i
                        int32_t end_pos, float* out);
 
 /* ---- large query batches through the matrix cores (L2, whole feature range) ------------------------
- * Same answers as fir_search_top1 -- bit-identical index and distance: an f32-MFMA GEMM only nominates
+ * Same answers as fir_search_top1 -- bit-identical index and distance: an MFMA GEMM only nominates
  * candidate rows, the reference's arithmetic re-ranks them, a rounding-error certificate proves no other
  * row can win, and uncertified queries are re-run through the exact streaming scan (fir_gemm.hip).
  * Costs one extra copy of the gallery in MFMA fragment order. The gallery handle must outlive it. */
 typedef struct fir_gemm fir_gemm;
 enum {
     FIR_GEMM_F32 = 0,        /* v_mfma_f32_32x32x2_f32: exact products (157 TF peak)                                */
-    FIR_GEMM_BF16_SPLIT = 1, /* x = hi + lo in bf16, hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_bf16 (default) */
-    FIR_GEMM_F16 = 2         /* one v_mfma_f32_32x32x16_f16 term on power-of-two-scaled fp16 copies: half the gallery bytes and a
-                              * third of the MFMAs per 128 queries; the proxy is good to 2^-10 |q||g|, which the certificate carries,
-                              * so near-duplicate-heavy galleries send more queries to the exact scan */
+    FIR_GEMM_BF16_SPLIT = 1, /* x = hi + lo in bf16, hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_bf16           */
+    FIR_GEMM_F16 = 2         /* (default) one v_mfma_f32_32x32x16_f16 term on power-of-two-scaled fp16 copies: half the gallery
+                              * bytes and a third of the MFMAs per 128 queries; the proxy is good to 2^-10 |q||g|, which the
+                              * certificate carries: more rows fall inside the rounding window and are re-ranked exactly */
 };
-int fir_gemm_create(fir_gallery* g, fir_gemm** out);   /* = fir_gemm_create_ex(g, FIR_GEMM_BF16_SPLIT, out) */
+int fir_gemm_create(fir_gallery* g, fir_gemm** out);   /* = fir_gemm_create_ex(g, FIR_GEMM_F16, out) */
 int fir_gemm_create_ex(fir_gallery* g, int32_t precision, fir_gemm** out);
 int fir_gemm_destroy(fir_gemm* m);
 int fir_gemm_search_top1_keys_dev(fir_gemm* m, const float* d_queries, int32_t qb, uint64_t* d_keys, void* stream);

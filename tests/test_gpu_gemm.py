@@ -10,7 +10,7 @@ import synth
 pytestmark = pytest.mark.gpu
 
 
-def run_both(fir, rows, q, precision=1):
+def run_both(fir, rows, q, precision=2):
     dev = torch.device("cuda", 0)
     with fir.Gallery(rows, None, 0, 0) as g:
         eidx, edist = g.search_top1(q)
