@@ -703,7 +703,8 @@ __global__ void __launch_bounds__(64) k_gemm_qprep_f16(const float* __restrict__
         if (m > 0.f) (void)frexpf(m, &ex);                 // m = f * 2^ex, f in [0.5, 1)
         int sh = m > 0.f ? 14 - ex : 0;                    // m * 2^sh in [2^13, 2^14)
         if (sh < -100 || sh > 100 || gallery_exp < -100 || gallery_exp > 100) bad = true;
-        qnorm[qi] = s;
+        // bad: the proxies of this query are NaN and say nothing about any row -- a NaN norm keeps the certificate from holding
+        qnorm[qi] = (bad && qi < nq) ? __builtin_nanf("") : s;
         qmul[qi] = bad ? 0.f : ldexpf(1.0f, sh);
         qinv[qi] = qi >= nq ? 0.f : bad ? __builtin_nanf("") : ldexpf(1.0f, -sh - gallery_exp);
     }
@@ -827,7 +828,8 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16(const uint4* _
                 const float dot = jb == 0 ? acc0[reg] : jb == 1 ? acc1[reg] : jb == 2 ? acc2[reg] : acc3[reg];
                 const float p = gn - m2 * dot;
                 if (MODE == 0) {
-                    if (row < sample_rows) sample[(size_t)q * sample_rows + row] = p;
+                    // [row][128 queries]: the 32 lanes of a half-wave (consecutive queries) write 128 contiguous bytes
+                    if (row < sample_rows) sample[(size_t)row * (2 * kQT) + q] = p;
                 } else if (p < tq) {
                     const int slot = atomicAdd(&counts[q], 1);
                     if (slot < kListCap) lists[(size_t)q * kListCap + slot] = fir::key_pack(p, (uint32_t)row);
@@ -889,6 +891,38 @@ __global__ void __launch_bounds__(256) k_gemm_tau(const float* __restrict__ samp
         }
         tau[q] = t;
     }
+}
+
+// tau for the fp16 flow, stage 1. The sample is laid out [row][128 queries] (coalesced writes from the MFMA tiles); here
+// lane = query, blockIdx = (64-query half, pair of passes, 1/kTauSplit of the rows), the four waves split the block's rows
+// and every lane keeps the minimum of eight interleaved row subsets: kTauSplit * 32 = 1024 group minima per query, written
+// to part[query][1024]. Stage 2 is k_gemm_tau over those: the kCand-th smallest group minimum has at least kCand sampled
+// rows at or below it (all the append pass needs), and with ~15 rows per group it is the exact order statistic in all
+// but a few per cent of the cases -- for 1/60 of the reads per thread that k_gemm_tau would make on the raw sample.
+constexpr int kTauSplit = 32;
+constexpr int kTauGroups = kTauSplit * 32;
+__global__ void __launch_bounds__(256) k_gemm_tau_groups(const float* __restrict__ sample, int sample_rows, float* __restrict__ part) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int qi = blockIdx.x * 64 + lane;                          // query inside the pair
+    const size_t qg = (size_t)blockIdx.y * 2 * kQT + qi;            // query inside the super-batch
+    const float* s = sample + (size_t)blockIdx.y * 2 * kQT * sample_rows + qi;
+    const int per = (sample_rows + kTauSplit - 1) / kTauSplit;
+    const int r_begin = (int)blockIdx.z * per;
+    const int r_end = r_begin + per < sample_rows ? r_begin + per : sample_rows;
+    float m[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) m[i] = __builtin_huge_valf();
+    for (int r0 = r_begin + wave * 8; r0 < r_end; r0 += 32) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (r0 + i < r_end) {
+                const float v = s[(size_t)(r0 + i) * (2 * kQT)];
+                m[i] = v < m[i] ? v : m[i];                          // NaN never enters, like k_gemm_tau's ordering
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) part[qg * kTauGroups + (size_t)blockIdx.z * 32 + wave * 8 + i] = m[i];
 }
 
 // Per query: every appended entry that could still be the nearest row is re-ranked with the reference's arithmetic, then
@@ -1030,6 +1064,7 @@ struct fir_gemm {
     int precision = 0;          // 0: f32 MFMA, 1: bf16 split (hi.hi + hi.lo + lo.hi), 2: one fp16 term
     uint4* gh = nullptr;        // fp16 fragments (precision 2)
     int gallery_exp = 0;        // fp16: the gallery was multiplied by 2^gallery_exp
+    float* tau_part = nullptr;  // fp16: group minima of the sampled proxies, [query][kTauGroups]
     float* qmul[2] = {nullptr, nullptr};
     float* qinv[2] = {nullptr, nullptr};
     int dk16 = 0;               // bf16 variant: k-blocks of 16 features (padded to a multiple of 4)
@@ -1100,6 +1135,7 @@ int fir_gemm_create_ex(fir_gallery* g, int32_t precision, fir_gemm** out) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking);
     m->sample_rows = (int)std::min<int64_t>(np, std::max<int64_t>(kMinSampleRows, np / 64));
     if (e == hipSuccess) e = hipMalloc((void**)&m->sample, (size_t)kPasses * kQT * m->sample_rows * sizeof(float));
+    if (e == hipSuccess && precision == FIR_GEMM_F16) e = hipMalloc((void**)&m->tau_part, (size_t)kPasses * kQT * kTauGroups * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&m->fbq, (size_t)kQT * m->v.d * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&m->fbkeys, kQT * sizeof(unsigned long long));
     const int lds_bytes = precision == FIR_GEMM_F32 ? (kQT / 32) * std::min(m->dq8, kSlab8) * 64 * (int)sizeof(float4)
@@ -1164,7 +1200,7 @@ int fir_gemm_destroy(fir_gemm* m) {
         if (m->rerank_done[b]) (void)hipEventDestroy(m->rerank_done[b]);
     }
     (void)hipFree(m->gm); (void)hipFree(m->gb); (void)hipFree(m->gh); (void)hipFree(m->gnorm); (void)hipFree(m->gmax); (void)hipFree(m->sample); (void)hipFree(m->ok);
-    (void)hipFree(m->fbq); (void)hipFree(m->fbkeys);
+    (void)hipFree(m->fbq); (void)hipFree(m->fbkeys); (void)hipFree(m->tau_part);
     delete m;
     return FIR_OK;
 }
@@ -1220,7 +1256,8 @@ int fir_gemm_search_top1_keys_dev(fir_gemm* m, const float* d_queries, int32_t q
             const int sample_wgs = (int)((((int64_t)sample_rows + 31) / 32 + wpb - 1) / wpb);
             hipLaunchKernelGGL(k_gemm_proxy_f16<0>, dim3(std::min(sample_wgs, grid), pairs), dim3(kGemmBlock), kHalfLds, st, m->gh, m->gnorm, m->qbf[b],
                                m->qinv[b], n, (int64_t)0, (int64_t)sample_rows, m->dk16, m->tau[b], m->lists[b], m->counts[b], m->sample, sample_rows);
-            hipLaunchKernelGGL(k_gemm_tau, dim3(pairs * 2 * kQT), dim3(256), 0, st, m->sample, sample_rows, m->tau[b], nq);
+            hipLaunchKernelGGL(k_gemm_tau_groups, dim3(2, pairs, kTauSplit), dim3(256), 0, st, m->sample, sample_rows, m->tau_part);
+            hipLaunchKernelGGL(k_gemm_tau, dim3(pairs * 2 * kQT), dim3(256), 0, st, m->tau_part, kTauGroups, m->tau[b], nq);
             hipLaunchKernelGGL(k_gemm_proxy_f16<1>, dim3(grid, pairs), dim3(kGemmBlock), kHalfLds, st, m->gh, m->gnorm, m->qbf[b], m->qinv[b], n,
                                (int64_t)0, n, m->dk16, m->tau[b], m->lists[b], m->counts[b], m->sample, sample_rows);
         } else {
