@@ -196,6 +196,14 @@ def main():
             k5 = torch.empty((qb, 5), device=dev, dtype=torch.int64)
             also = {"l2_top5_queries_per_s": rate(lambda: g.search_topk_keys_dev(q.data_ptr(), qb, 5, k5.data_ptr(), stream=stream), qb, 2)}
             top5_first_is_top1 = bool(torch.equal(k5[:, 0], keys))
+            # the same step with 16 queries per gallery pass: more queries/s, but the kernel is then bound by the f32 vector
+            # pipes (3 un-fused ops per feature and query), not by HBM -- the timed step keeps the library's choice (8)
+            k16 = torch.empty_like(keys)
+            g.set_tuning(16, 0)
+            r16 = rate(lambda: g.search_top1_keys_dev(q.data_ptr(), qb, k16.data_ptr(), stream=stream), qb, 3)
+            g.set_tuning(-1, 0)
+            also["l2_top1_16_queries_per_pass"] = {"queries_per_s": r16, "gallery_GBps": (row_hi - row_lo) * d * 4.0 * (qb / 16) * (r16 / qb) / 1e9,
+                                                   "identical_keys": bool(torch.equal(k16, keys))}
             # chi-square / KL compare non-negative feature vectors that went through the loader's |x| < 1e-4 -> 0 rule
             # (db_features.cpp:85-86) like the gallery rows did; the L2 step's planted queries carry signed noise
             q32 = q[:32].clamp_min(0.0)
