@@ -156,3 +156,23 @@ def test_more_ties_than_the_candidate_list_holds(fir, precision):
     assert np.array_equal(dist.view(np.uint32), edist.view(np.uint32))
     assert idx[0] == 10 and dist[0] == 0
     assert st["fallback_queries"] >= 1
+
+
+@pytest.mark.parametrize("precision", [1, 2])
+@pytest.mark.parametrize("spread", [0.3, 0.05, 0.005])
+def test_clustered_gallery_like_identities(fir, precision, spread):
+    """A gallery of 600 identities x 40 images (each image = the identity's centre + noise of the given relative size), queries
+    drawn the same way: dozens of rows sit within the proxy's rounding window of the best one. They are all re-ranked
+    exactly, so the keys equal the scan's, and with a window re-rank only a handful of queries may need the exact scan."""
+    rng = np.random.default_rng(17)
+    ids, per, d, qb = 600, 40, 256, 200
+    centres = rng.random((ids, d), dtype=np.float32)
+    rows = np.repeat(centres, per, axis=0) * (1 + spread * (rng.random((ids * per, d), dtype=np.float32) - 0.5))
+    rows = synth.normalise(rows, 0)
+    who = rng.integers(0, ids, qb)
+    q = synth.normalise(centres[who] * (1 + spread * (rng.random((qb, d), dtype=np.float32) - 0.5)), 0)
+    (idx, dist), (eidx, edist), st = run_both(fir, rows, q, precision)
+    assert np.array_equal(idx, eidx)
+    assert np.array_equal(dist.view(np.uint32), edist.view(np.uint32))
+    assert np.all(idx // per == who)                      # the nearest image belongs to the query's identity
+    assert st["fallback_queries"] <= qb // 10, st

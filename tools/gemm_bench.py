@@ -30,11 +30,17 @@ def main():
     ap.add_argument("--dim", type=int, default=512)
     ap.add_argument("--qb", default="64,256,1024")
     ap.add_argument("--precision", type=int, default=1, help="0 = f32 MFMA, 1 = bf16 split, 2 = one fp16 term")
+    ap.add_argument("--identities", type=int, default=0, help="> 0: a clustered gallery, rows = identity centre * (1 + spread * noise)")
+    ap.add_argument("--spread", type=float, default=0.05)
     a = ap.parse_args()
     fir = ge.load_package()
     dev = torch.device("cuda", 0)
     n, d = a.rows, a.dim
-    x = torch.rand((n, d), device=dev)
+    if a.identities > 0:
+        centres = torch.rand((a.identities, d), device=dev)
+        x = centres[torch.arange(n, device=dev) % a.identities] * (1 + a.spread * (torch.rand((n, d), device=dev) - 0.5))
+    else:
+        x = torch.rand((n, d), device=dev)
     x = x / x.norm(dim=1, keepdim=True)
     g = fir.Gallery(dev_ptr=x.data_ptr(), n=n, d=d, metric=0, device=0)
     m = fir.GemmSearch(g, a.precision)
