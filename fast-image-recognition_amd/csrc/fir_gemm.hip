@@ -485,11 +485,14 @@ __global__ void __launch_bounds__(kGemmBlock, kGemmMinBlocks) k_gemm_proxy_bf16(
 // MFMAs per k-block). The gallery stream -- what bounds k_gemm_proxy_bf16 (5.7 TB/s, MFMA pipe ~25 % busy) -- is read
 // once per 128 queries instead of once per 64. The query fragments of 128 queries only fit LDS 256 features at a time
 // (4 query blocks x 16 k-blocks x {hi, lo} x 1 KiB = 128 KiB), so every row group of a workgroup re-stages the slabs;
-// the gallery fragments keep streaming through the staging barriers (their register ring is indexed by the global
-// k-block, not by the slab). blockIdx.y = pair of passes; the per-pass scratch (tau, lists, counts, query fragments) is
+// the gallery fragments keep streaming through the staging barriers (a double buffer of eight k-blocks that runs on
+// into the wave's next row block). What bounds this kernel is the re-staging itself -- two workgroup barriers around
+// a 128 KiB copy per slab; changing the gallery ring into the double buffer left its 552 us per pass unchanged, whereas the
+// fp16 kernel below, whose 128-query tile stays resident, went from 358 to 200 us. blockIdx.y = pair of passes; the per-pass scratch (tau, lists, counts, query fragments) is
 // laid out pass-major, so the pair's 128 queries are simply consecutive.
 // ---------------------------------------------------------------------------------------------
 constexpr int kSlabW = 16;             // k-blocks (of 16 features) of the 128-query slab
+constexpr int kUnitW = kSlabW / 2;     // k-blocks per unit of the gallery double buffer (hi + lo: 16 KiB per wave); dk16 is a multiple of it
 constexpr int kWideLds = 4 * kSlabW * 128 * (int)sizeof(uint4);   // 128 KiB
 __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_bf16_wide(const uint4* __restrict__ gb, const float* __restrict__ gnorm,
                                                                          const uint4* qbf, int64_t n, int dk16, const float* tau,
@@ -508,87 +511,60 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_bf16_wide(const ui
     if (threadIdx.x < 2 * kQT) tau_s[threadIdx.x] = tau[threadIdx.x];
     const int64_t rb_end = (n + 31) / 32;
     const int64_t nrg = (rb_end + wpb - 1) / wpb;
-    const int nslab = (dk16 + kSlabW - 1) / kSlabW;
-    const int klast = dk16 - 1;
-    for (int64_t rg = blockIdx.x; rg < nrg; rg += gridDim.x) {
+    const int units = dk16 / kUnitW;
+    int64_t rg = blockIdx.x;
+    if (rg >= nrg) return;                           // uniform per workgroup
+    // The gallery stream is a double buffer of kUnitW k-blocks (see k_gemm_proxy_f16): all loads of the next unit -- of this
+    // row block or of the wave's next one -- leave before the 96 MFMAs of the current unit.
+#define FIR_W_BLOCK(RG) (gb + (size_t)(((RG) * wpb + wave) < rb_end ? ((RG) * wpb + wave) : rb_end - 1) * dk16 * 128 + lane)
+    const uint4* a_cur = FIR_W_BLOCK(rg);            // inactive waves stream a valid block and drop it
+    uint4 ch[kUnitW], cl[kUnitW], nh[kUnitW], nl[kUnitW];
+#pragma unroll
+    for (int u = 0; u < kUnitW; ++u) {
+        ch[u] = ld_nt(a_cur + (size_t)u * 128);
+        cl[u] = ld_nt(a_cur + (size_t)u * 128 + 64);
+    }
+    for (; rg < nrg; rg += gridDim.x) {
         const int64_t rb = rg * wpb + wave;
         const bool active = rb < rb_end;
-        const uint4* a = gb + (size_t)(active ? rb : rb_end - 1) * dk16 * 128 + lane;    // inactive waves stream a valid block and drop it
+        const int64_t rgn = rg + gridDim.x;
+        const uint4* a_nxt = FIR_W_BLOCK(rgn < nrg ? rgn : rg);
         f32x16 acc0 = {0.f}, acc1 = {0.f}, acc2 = {0.f}, acc3 = {0.f};
-#define FIR_W_LD(KG) ld_nt(a + (size_t)((KG) < klast ? (KG) : klast) * 128)
-#define FIR_W_LDL(KG) ld_nt(a + (size_t)((KG) < klast ? (KG) : klast) * 128 + 64)
-        uint4 h0 = FIR_W_LD(0), l0 = FIR_W_LDL(0), h1 = FIR_W_LD(1), l1 = FIR_W_LDL(1), h2 = FIR_W_LD(2), l2 = FIR_W_LDL(2),
-              h3 = FIR_W_LD(3), l3 = FIR_W_LDL(3), h4 = FIR_W_LD(4), l4 = FIR_W_LDL(4), h5 = FIR_W_LD(5), l5 = FIR_W_LDL(5),
-              h6 = FIR_W_LD(6), l6 = FIR_W_LDL(6), h7 = FIR_W_LD(7), l7 = FIR_W_LDL(7);
-        for (int sl = 0; sl < nslab; ++sl) {
-            const int k0 = sl * kSlabW;
-            const int kw = dk16 - k0 < kSlabW ? dk16 - k0 : kSlabW;        // k-blocks in this slab (a multiple of 4)
-            __syncthreads();                                                // everyone is done with the previous slab
-            for (int i = threadIdx.x; i < 4 * kw * 128; i += blockDim.x) {
-                const int jb = i / (kw * 128), r = i - jb * kw * 128;
-                lqb[(size_t)jb * kSlabW * 128 + r] = qbf[((size_t)jb * dk16 + k0) * 128 + r];
+        for (int h = 0; h < units; ++h) {
+            const uint4* src = h + 1 < units ? a_cur + (size_t)(h + 1) * kUnitW * 128 : a_nxt;
+#pragma unroll
+            for (int u = 0; u < kUnitW; ++u) {
+                nh[u] = ld_nt(src + (size_t)u * 128);
+                nl[u] = ld_nt(src + (size_t)u * 128 + 64);
             }
-            __syncthreads();
-            const uint4* bq = lqb + lane;
-            // query fragments one k-block ahead: blocks 0..3, hi and lo
-            uint4 b0h = bq[0], b0l = bq[64], b1h = bq[kSlabW * 128], b1l = bq[kSlabW * 128 + 64], b2h = bq[2 * kSlabW * 128],
-                  b2l = bq[2 * kSlabW * 128 + 64], b3h = bq[3 * kSlabW * 128], b3l = bq[3 * kSlabW * 128 + 64];
-#define FIR_W_STEP(AH, AL, KB)                                                                                   \
-            {                                                                                                    \
-                const int kn = (KB) + 1 < kw ? (KB) + 1 : (KB);                                                  \
-                const uint4* nq = bq + (size_t)kn * 128;                                                         \
-                const uint4 n0h = nq[0], n0l = nq[64], n1h = nq[kSlabW * 128], n1l = nq[kSlabW * 128 + 64];      \
-                const uint4 n2h = nq[2 * kSlabW * 128], n2l = nq[2 * kSlabW * 128 + 64];                         \
-                const uint4 n3h = nq[3 * kSlabW * 128], n3l = nq[3 * kSlabW * 128 + 64];                         \
-                __builtin_amdgcn_sched_barrier(0);                                                               \
-                const bf16x8 ah = as_bf16x8(AH), al = as_bf16x8(AL);                                             \
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, as_bf16x8(b0h), acc0, 0, 0, 0);               \
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, as_bf16x8(b1h), acc1, 0, 0, 0);               \
-                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, as_bf16x8(b2h), acc2, 0, 0, 0);               \
-                acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, as_bf16x8(b3h), acc3, 0, 0, 0);               \
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, as_bf16x8(b0l), acc0, 0, 0, 0);               \
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, as_bf16x8(b1l), acc1, 0, 0, 0);               \
-                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, as_bf16x8(b2l), acc2, 0, 0, 0);               \
-                acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, as_bf16x8(b3l), acc3, 0, 0, 0);               \
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, as_bf16x8(b0h), acc0, 0, 0, 0);               \
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, as_bf16x8(b1h), acc1, 0, 0, 0);               \
-                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, as_bf16x8(b2h), acc2, 0, 0, 0);               \
-                acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, as_bf16x8(b3h), acc3, 0, 0, 0);               \
-                b0h = n0h; b0l = n0l; b1h = n1h; b1l = n1l; b2h = n2h; b2l = n2l; b3h = n3h; b3l = n3l;          \
+            if ((h & 1) == 0) {                                             // a slab is two units; 128 queries never fit whole
+                const int k0 = h * kUnitW;
+                const int kw = dk16 - k0 < kSlabW ? dk16 - k0 : kSlabW;
+                __syncthreads();                                            // everyone is done with the previous slab
+                for (int i = threadIdx.x; i < 4 * kw * 128; i += blockDim.x) {
+                    const int jb = i / (kw * 128), r = i - jb * kw * 128;
+                    lqb[(size_t)jb * kSlabW * 128 + r] = qbf[((size_t)jb * dk16 + k0) * 128 + r];
+                }
+                __syncthreads();
             }
-#define FIR_W_NEXT(AH, AL, OFF)                     \
-            {                                       \
-                AH = FIR_W_LD(k0 + kb + (OFF) + 8); \
-                AL = FIR_W_LDL(k0 + kb + (OFF) + 8);\
-            }
-            for (int kb = 0; kb < kw; kb += 8) {
-                FIR_W_STEP(h0, l0, kb)
-                FIR_W_NEXT(h0, l0, 0)
-                FIR_W_STEP(h1, l1, kb + 1)
-                FIR_W_NEXT(h1, l1, 1)
-                FIR_W_STEP(h2, l2, kb + 2)
-                FIR_W_NEXT(h2, l2, 2)
-                FIR_W_STEP(h3, l3, kb + 3)
-                FIR_W_NEXT(h3, l3, 3)
-                if (kb + 4 < kw) {      // kw is a multiple of 4, not necessarily of 8
-                    FIR_W_STEP(h4, l4, kb + 4)
-                    FIR_W_NEXT(h4, l4, 4)
-                    FIR_W_STEP(h5, l5, kb + 5)
-                    FIR_W_NEXT(h5, l5, 5)
-                    FIR_W_STEP(h6, l6, kb + 6)
-                    FIR_W_NEXT(h6, l6, 6)
-                    FIR_W_STEP(h7, l7, kb + 7)
-                    FIR_W_NEXT(h7, l7, 7)
-                } else {
-                    // a 4-block tail: registers 4..7 hold the NEXT slab's first blocks only if the ring stays aligned, and
-                    // dk16 % 8 == 4 happens in the last slab only, where nothing follows
+            const uint4* bq = lqb + lane + (size_t)(h & 1) * kUnitW * 128;
+#pragma unroll
+            for (int u = 0; u < kUnitW; ++u) {
+                const uint4* bu = bq + (size_t)u * 128;
+                const bf16x8 ah = as_bf16x8(ch[u]), al = as_bf16x8(cl[u]);
+#pragma unroll
+                for (int jb = 0; jb < 4; ++jb) {
+                    const bf16x8 bh = as_bf16x8(bu[(size_t)jb * kSlabW * 128]), bl = as_bf16x8(bu[(size_t)jb * kSlabW * 128 + 64]);
+                    f32x16& acc = jb == 0 ? acc0 : jb == 1 ? acc1 : jb == 2 ? acc2 : acc3;
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
                 }
             }
-#undef FIR_W_NEXT
-#undef FIR_W_STEP
+#pragma unroll
+            for (int u = 0; u < kUnitW; ++u) { ch[u] = nh[u]; cl[u] = nl[u]; }
         }
-#undef FIR_W_LD
-#undef FIR_W_LDL
+        a_cur = a_nxt;
         if (!active) continue;
         const int64_t nrow = rb * 32 + (lane & 31);
         const float gn_lane = nrow < n ? gnorm[nrow] : 0.0f;
@@ -610,6 +586,7 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_bf16_wide(const ui
             }
         }
     }
+#undef FIR_W_BLOCK
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1117,7 +1094,7 @@ int fir_gemm_create_ex(fir_gallery* g, int32_t precision, fir_gemm** out) {
     m->precision = precision;
     if (const char* w = std::getenv("FIR_GEMM_WIDE")) m->wide = std::atoi(w) != 0;   // experiments: 0 = one pass per gallery read
     m->dq8 = (m->v.d + 31) / 32 * 4;     // feature groups of 8, padded to a multiple of 4 groups (zeros)
-    m->dk16 = (m->v.d + 63) / 64 * 4;    // k-blocks of 16, padded to a multiple of 4
+    m->dk16 = (m->v.d + 127) / 128 * 8;  // k-blocks of 16, padded to a multiple of 8 (the paired-pass kernel's double-buffer unit)
     if (precision == FIR_GEMM_F16) m->dk16 = (m->v.d + 255) / 256 * kRing;   // ... to whole double-buffer units of 16
     hipError_t e = hipSetDevice(m->v.device);
     const int64_t rblocks = (std::max<int64_t>(m->v.n, 1) + 31) / 32;
