@@ -718,7 +718,12 @@ __global__ void __launch_bounds__(256) k_gemm_pack_queries_f16(const float* q, i
 // one, so the only wait per unit is at its end, 2048 MFMA cycles after the loads left. (A ring that reloads each slot
 // right after use needs counted waits inside a loop, which the compiler turns into vmcnt(0) per step: one memory latency
 // per k-block -- measured 358 us per pass against 158 us of gallery stream.)
-template <int MODE>
+// STREAMED = 1 (rows longer than 512 features: the 128-query tile does not fit LDS): the query fragments go through two
+// 64-KiB LDS buffers of one unit (16 k-blocks) each, filled by global_load_lds (no registers, asynchronous): the slab of
+// the NEXT unit is requested before the current unit's MFMAs, lands under them, and one workgroup barrier per unit
+// publishes it. (Staging slabs with ordinary loads between two barriers, as the resident form does once per pass, cost
+// 40 % at d = 1280: 740 us per pass against 394 us of gallery stream.)
+template <int MODE, int STREAMED>
 __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16(const uint4* __restrict__ gh, const float* __restrict__ gnorm, const uint4* qh,
                                                                    const float* __restrict__ qinv, int64_t n, int64_t row_begin, int64_t row_end,
                                                                    int dk16, const float* tau, unsigned long long* lists, int* counts,
@@ -752,6 +757,23 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16(const uint4* _
 #pragma unroll
     for (int u = 0; u < kRing; ++u) cur[u] = ld_nt(a_cur + (size_t)u * 64);
     bool staged = false;
+    // STREAMED: unit hq of the query tile -> LDS buffer bsel; every wave moves its share of the 64 one-KiB pieces
+    // (piece = (query block jb, k-block kb): 64 lanes x 16 B, contiguous in qh and in LDS)
+    auto request_slab = [&](int hq, int bsel) {
+        uint4* dst = lqb + (size_t)bsel * 4 * kRing * 64;
+        const int per_wave = 4 * kRing / wpb;
+        for (int c = 0; c < per_wave; ++c) {
+            const int piece = wave * per_wave + c, jb = piece / kRing, kb = piece - jb * kRing;
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(qh + ((size_t)jb * dk16 + (size_t)hq * kRing + kb) * 64 + lane),
+                                             (void __attribute__((address_space(3)))*)(dst + (size_t)piece * 64), 16, 0, 0);
+        }
+    };
+    int tsel = 0;                                    // STREAMED: LDS buffer of the current unit
+    if (STREAMED) {
+        request_slab(0, 0);
+        __builtin_amdgcn_s_waitcnt(0);               // (also the prologue's gallery loads: once per kernel)
+        __syncthreads();
+    }
     for (; rg < nrg; rg += gridDim.x) {
         const int64_t rb = rb_begin + rg * wpb + wave;
         const bool active = rb < rb_end;
@@ -760,9 +782,10 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16(const uint4* _
         f32x16 acc0 = {0.f}, acc1 = {0.f}, acc2 = {0.f}, acc3 = {0.f};
         for (int h = 0; h < units; ++h) {
             const uint4* src = h + 1 < units ? a_cur + (size_t)(h + 1) * kRing * 64 : a_nxt;
+            if (STREAMED) request_slab(h + 1 < units ? h + 1 : 0, tsel ^ 1);   // its last readers passed the barrier that ended the previous unit
 #pragma unroll
             for (int u = 0; u < kRing; ++u) nxt[u] = ld_nt(src + (size_t)u * 64);
-            if ((h & 1) == 0 && (nslab > 1 || !staged)) {                   // a slab is two units
+            if (!STREAMED && (h & 1) == 0 && (nslab > 1 || !staged)) {      // a slab is two units
                 const int k0 = h * kRing;
                 const int kw = dk16 - k0 < kSlabH ? dk16 - k0 : kSlabH;
                 __syncthreads();                                            // everyone is done with the previous slab
@@ -773,11 +796,12 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16(const uint4* _
                 __syncthreads();
                 staged = true;
             }
-            const uint4* bq = lqb + lane + (size_t)(h & 1) * kRing * 64;
+            const uint4* bq = STREAMED ? lqb + lane + (size_t)tsel * 4 * kRing * 64 : lqb + lane + (size_t)(h & 1) * kRing * 64;
+            constexpr int jstride = (STREAMED ? kRing : kSlabH) * 64;        // uint4s between the query blocks of a k-block
 #pragma unroll
             for (int u = 0; u < kRing; ++u) {
                 const uint4* bu = bq + (size_t)u * 64;
-                const uint4 b0 = bu[0], b1 = bu[kSlabH * 64], b2 = bu[2 * kSlabH * 64], b3 = bu[3 * kSlabH * 64];
+                const uint4 b0 = bu[0], b1 = bu[jstride], b2 = bu[2 * jstride], b3 = bu[3 * jstride];
                 const f16x8 av = as_f16x8(cur[u]);
                 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, as_f16x8(b0), acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, as_f16x8(b1), acc1, 0, 0, 0);
@@ -786,6 +810,11 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16(const uint4* _
             }
 #pragma unroll
             for (int u = 0; u < kRing; ++u) cur[u] = nxt[u];
+            if (STREAMED) {
+                __builtin_amdgcn_s_waitcnt(0);       // this wave's pieces of the next slab have landed (they left before nxt's loads)
+                __syncthreads();                     // ... and everyone's; and nobody still reads the buffer the next request overwrites
+                tsel ^= 1;
+            }
         }
         a_cur = a_nxt;
         if (!active) continue;
@@ -946,6 +975,9 @@ __global__ void __launch_bounds__(64) k_gemm_rerank(const unsigned long long* __
     float p_out = __builtin_huge_valf();            // smallest proxy NOT re-ranked
     int reranked = 0;
     extern __shared__ __attribute__((aligned(16))) float4 crow[];     // [kRerankGroup][dp4]: candidate rows, loaded by the whole wave
+    float4* qrow = crow + (size_t)kRerankGroup * dp4;                 // [dp4]: the query, zero-padded like the gallery rows (a (0-0)^2 term adds +0)
+    for (int k = lane; k < dp4 * 4; k += 64) ((float*)qrow)[k] = k < d ? qv[k] : 0.0f;
+    __syncthreads();
     for (int base = 0; base < have; base += 64) {
         const int i = base + lane;
         const unsigned long long v = i < have ? L[i] : kKeyNone;
@@ -977,13 +1009,11 @@ __global__ void __launch_bounds__(64) k_gemm_rerank(const unsigned long long* __
                 const float4* my = crow + (size_t)lane * dp4;
                 float acc = 0.0f;
                 for (int c = 0; c < dp4; ++c) {
-                    const float4 g4 = my[c];
-                    const float gv[4] = {g4.x, g4.y, g4.z, g4.w};
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int k = c * 4 + j;
-                        if (k < d) acc = fir::accum<fir::kL2>(acc, qv[k], gv[j]);
-                    }
+                    const float4 g4 = my[c], q4 = qrow[c];
+                    acc = fir::accum<fir::kL2>(acc, q4.x, g4.x);
+                    acc = fir::accum<fir::kL2>(acc, q4.y, g4.y);
+                    acc = fir::accum<fir::kL2>(acc, q4.z, g4.z);
+                    acc = fir::accum<fir::kL2>(acc, q4.w, g4.w);
                 }
                 const float dist = acc / (float)d;
                 if (dist < fir::kNotFound) {
@@ -1071,6 +1101,7 @@ struct fir_gemm {
     float* fbq = nullptr;                 // fallback queries (device)
     unsigned long long* fbkeys = nullptr;
     int64_t passes = 0, fallbacks = 0;
+    int streamed = -1;                    // fp16: query slabs through the LDS double buffer (-1: when the tile does not fit, d > 512)
     bool wide = true;                     // bf16: pairs of passes through k_gemm_proxy_bf16_wide (FIR_GEMM_WIDE=0 turns it off)
 };
 
@@ -1129,8 +1160,11 @@ int fir_gemm_create_ex(fir_gallery* g, int32_t precision, fir_gemm** out) {
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy_bf16<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy_bf16<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy_bf16_wide, hipFuncAttributeMaxDynamicSharedMemorySize, kWideLds);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy_f16<0>, hipFuncAttributeMaxDynamicSharedMemorySize, kHalfLds);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy_f16<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kHalfLds);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy_f16<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kHalfLds);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy_f16<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kHalfLds);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy_f16<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kHalfLds);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy_f16<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kHalfLds);
+    if (const char* w = std::getenv("FIR_GEMM_STREAMED")) m->streamed = std::atoi(w);   // experiments: 0 / 1 force the form, -1 = by row length
     if (e == hipSuccess && m->v.n > 0) {
         // row norms come from the f32 packer (run on a one-group scratch when only the bf16 fragments are kept)
         if (precision == FIR_GEMM_BF16_SPLIT) {
@@ -1238,12 +1272,22 @@ int fir_gemm_search_top1_keys_dev(fir_gemm* m, const float* d_queries, int32_t q
                                m->qbf[b]);
             const int wpb = kGemmBlock / 64;
             const int sample_wgs = (int)((((int64_t)sample_rows + 31) / 32 + wpb - 1) / wpb);
-            hipLaunchKernelGGL(k_gemm_proxy_f16<0>, dim3(std::min(sample_wgs, grid), pairs), dim3(kGemmBlock), kHalfLds, st, m->gh, m->gnorm, m->qbf[b],
-                               m->qinv[b], n, (int64_t)0, (int64_t)sample_rows, m->dk16, m->tau[b], m->lists[b], m->counts[b], m->sample, sample_rows);
+            const bool streamed = m->streamed >= 0 ? m->streamed != 0 : m->dk16 > kSlabH;
+            const dim3 sgrid(std::min(sample_wgs, grid), pairs), mgrid(grid, pairs);
+            if (streamed)
+                hipLaunchKernelGGL((k_gemm_proxy_f16<0, 1>), sgrid, dim3(kGemmBlock), kHalfLds, st, m->gh, m->gnorm, m->qbf[b], m->qinv[b], n, (int64_t)0,
+                                   (int64_t)sample_rows, m->dk16, m->tau[b], m->lists[b], m->counts[b], m->sample, sample_rows);
+            else
+                hipLaunchKernelGGL((k_gemm_proxy_f16<0, 0>), sgrid, dim3(kGemmBlock), kHalfLds, st, m->gh, m->gnorm, m->qbf[b], m->qinv[b], n, (int64_t)0,
+                                   (int64_t)sample_rows, m->dk16, m->tau[b], m->lists[b], m->counts[b], m->sample, sample_rows);
             hipLaunchKernelGGL(k_gemm_tau_groups, dim3(2, pairs, kTauSplit), dim3(256), 0, st, m->sample, sample_rows, m->tau_part);
             hipLaunchKernelGGL(k_gemm_tau, dim3(pairs * 2 * kQT), dim3(256), 0, st, m->tau_part, kTauGroups, m->tau[b], nq, m->qnorm[b], m->gmax, e_rel);
-            hipLaunchKernelGGL(k_gemm_proxy_f16<1>, dim3(grid, pairs), dim3(kGemmBlock), kHalfLds, st, m->gh, m->gnorm, m->qbf[b], m->qinv[b], n,
-                               (int64_t)0, n, m->dk16, m->tau[b], m->lists[b], m->counts[b], m->sample, sample_rows);
+            if (streamed)
+                hipLaunchKernelGGL((k_gemm_proxy_f16<1, 1>), mgrid, dim3(kGemmBlock), kHalfLds, st, m->gh, m->gnorm, m->qbf[b], m->qinv[b], n, (int64_t)0, n,
+                                   m->dk16, m->tau[b], m->lists[b], m->counts[b], m->sample, sample_rows);
+            else
+                hipLaunchKernelGGL((k_gemm_proxy_f16<1, 0>), mgrid, dim3(kGemmBlock), kHalfLds, st, m->gh, m->gnorm, m->qbf[b], m->qinv[b], n, (int64_t)0, n,
+                                   m->dk16, m->tau[b], m->lists[b], m->counts[b], m->sample, sample_rows);
         } else {
         hipLaunchKernelGGL(k_gemm_qnorm, dim3(np * kQT), dim3(64), 0, st, dq, nq, d, m->qnorm[b]);
         GEMM_HIP(hipMemsetAsync(m->counts[b], 0, (size_t)np * kQT * sizeof(int), st));
@@ -1277,7 +1321,7 @@ int fir_gemm_search_top1_keys_dev(fir_gemm* m, const float* d_queries, int32_t q
         GEMM_HIP(hipEventRecord(m->main_done[b], st));
         // exact re-rank + certificate of this super-batch on the side stream, under the next one's GEMM
         GEMM_HIP(hipStreamWaitEvent(m->side, m->main_done[b], 0));
-        hipLaunchKernelGGL(k_gemm_rerank, dim3(nq), dim3(64), (size_t)kRerankGroup * m->dp4 * sizeof(float4), m->side, m->lists[b], m->counts[b], m->tau[b],
+        hipLaunchKernelGGL(k_gemm_rerank, dim3(nq), dim3(64), (size_t)(kRerankGroup + 1) * m->dp4 * sizeof(float4), m->side, m->lists[b], m->counts[b], m->tau[b],
                            m->gal4, dq, m->qnorm[b], m->gmax, n, d, m->dp4, m->v.row_offset, e_rel, (unsigned long long*)d_keys + q0, m->ok + q0);
         GEMM_HIP(hipEventRecord(m->rerank_done[b], m->side));
         m->passes += np;
