@@ -94,7 +94,7 @@ public:
 inline void invalidate(const std::vector<ImageInfo>& dbImages) { GalleryCache::invalidate(dbImages); }
 
 // Galleries uploaded from now on send whole-range L2 batches of >= min_queries test images through the matrix-core
-// path (fir_gallery_set_large_batch_mfma): same answers, ~6x the throughput, one extra copy of the gallery. 0 = off.
+// path (fir_gallery_set_large_batch_mfma): same answers, ~15-20x the throughput, one extra copy of the gallery. 0 = off.
 void set_large_batch_mfma(int min_queries);
 void set_device(int device);   // default 0
 int device();
