@@ -737,7 +737,7 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16(const uint4* _
         tau += pr * 2 * kQT;
         lists += pr * 2 * kQT * kListCap;
         counts += pr * 2 * kQT;
-        sample += pr * 2 * kQT * sample_rows;
+        sample += pr * 2 * kQT * ((sample_rows + 31) / 32);      // MODE 0 writes one minimum per (row block, query)
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wpb = blockDim.x >> 6;
@@ -825,6 +825,7 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16(const uint4* _
             const int q = jb * 32 + (lane & 31);
             const float m2 = 2.0f * qinv_s[q];
             const float tq = tau_s[q];
+            float mn = __builtin_huge_valf();
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int roff = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
@@ -834,12 +835,18 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16(const uint4* _
                 const float dot = jb == 0 ? acc0[reg] : jb == 1 ? acc1[reg] : jb == 2 ? acc2[reg] : acc3[reg];
                 const float p = gn - m2 * dot;
                 if (MODE == 0) {
-                    // [row][128 queries]: the 32 lanes of a half-wave (consecutive queries) write 128 contiguous bytes
-                    if (row < sample_rows) sample[(size_t)row * (2 * kQT) + q] = p;
+                    if (row < sample_rows) mn = p < mn ? p : mn;         // NaN never enters, like k_gemm_tau's ordering
                 } else if (p < tq) {
                     const int slot = atomicAdd(&counts[q], 1);
                     if (slot < kListCap) lists[(size_t)q * kListCap + slot] = fir::key_pack(p, (uint32_t)row);
                 }
+            }
+            if (MODE == 0) {
+                // what tau needs from the sample is one minimum per (row block, query): sample[(row block) * 128 + query],
+                // the two half-waves hold the block's rows 4..7 mod 8 and 0..3 mod 8
+                const float o = __shfl_xor(mn, 32, 64);
+                mn = o < mn ? o : mn;
+                if (lane < 32) sample[(size_t)(rb - rb_begin) * (2 * kQT) + q] = mn;
             }
         }
     }
@@ -853,19 +860,23 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16(const uint4* _
 // gallery dozens of rows lie within the window of the best one, the kCand-th smallest would cut through them and the
 // certificate could never hold (measured: 75 of 200 queries of a 600-identity gallery went to the exact scan).
 __global__ void __launch_bounds__(256) k_gemm_tau(const float* __restrict__ sample, int sample_rows, float* __restrict__ tau,
-                                                   int nq_valid, const float* __restrict__ qnorm, const float* __restrict__ gnorm_max_p, float e_rel) {
+                                                   int nq_valid, const float* __restrict__ qnorm, const float* __restrict__ gnorm_max_p, float e_rel,
+                                                   int qgroup = 1) {
+    // qgroup > 1 (fp16 flow): the sample of a group of qgroup queries is laid out [value][query of the group] and holds one
+    // MINIMUM per 32-row block instead of every proxy: the kCand-th smallest block minimum still has kCand sampled rows at or
+    // below it, which is all the append pass needs, and is within a rank or two of the exact order statistic
     __shared__ unsigned long long red[4];
     const int q = blockIdx.x;
     if (q >= nq_valid) {        // padding queries of a half-filled pass pair: nothing is appended for them
         if (threadIdx.x == 0) tau[q] = -__builtin_huge_valf();
         return;
     }
-    const float* s = sample + (size_t)q * sample_rows;
+    const float* s = sample + (size_t)(q / qgroup) * qgroup * sample_rows + (q % qgroup);
     unsigned long long best[kCand];
 #pragma unroll
     for (int i = 0; i < kCand; ++i) best[i] = kKeyNone;
     for (int i = threadIdx.x; i < sample_rows; i += 256) {
-        unsigned long long v = fir::key_pack(s[i], (uint32_t)i);
+        unsigned long long v = fir::key_pack(s[(size_t)i * qgroup], (uint32_t)i);
         if (v < best[kCand - 1]) {
 #pragma unroll
             for (int j = 0; j < kCand; ++j) {
@@ -904,38 +915,6 @@ __global__ void __launch_bounds__(256) k_gemm_tau(const float* __restrict__ samp
         }
         tau[q] = t;
     }
-}
-
-// tau for the fp16 flow, stage 1. The sample is laid out [row][128 queries] (coalesced writes from the MFMA tiles); here
-// lane = query, blockIdx = (64-query half, pair of passes, 1/kTauSplit of the rows), the four waves split the block's rows
-// and every lane keeps the minimum of eight interleaved row subsets: kTauSplit * 32 = 1024 group minima per query, written
-// to part[query][1024]. Stage 2 is k_gemm_tau over those: the kCand-th smallest group minimum has at least kCand sampled
-// rows at or below it (all the append pass needs), and with ~15 rows per group it is the exact order statistic in all
-// but a few per cent of the cases -- for 1/60 of the reads per thread that k_gemm_tau would make on the raw sample.
-constexpr int kTauSplit = 32;
-constexpr int kTauGroups = kTauSplit * 32;
-__global__ void __launch_bounds__(256) k_gemm_tau_groups(const float* __restrict__ sample, int sample_rows, float* __restrict__ part) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int qi = blockIdx.x * 64 + lane;                          // query inside the pair
-    const size_t qg = (size_t)blockIdx.y * 2 * kQT + qi;            // query inside the super-batch
-    const float* s = sample + (size_t)blockIdx.y * 2 * kQT * sample_rows + qi;
-    const int per = (sample_rows + kTauSplit - 1) / kTauSplit;
-    const int r_begin = (int)blockIdx.z * per;
-    const int r_end = r_begin + per < sample_rows ? r_begin + per : sample_rows;
-    float m[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) m[i] = __builtin_huge_valf();
-    for (int r0 = r_begin + wave * 8; r0 < r_end; r0 += 32) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            if (r0 + i < r_end) {
-                const float v = s[(size_t)(r0 + i) * (2 * kQT)];
-                m[i] = v < m[i] ? v : m[i];                          // NaN never enters, like k_gemm_tau's ordering
-            }
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) part[qg * kTauGroups + (size_t)blockIdx.z * 32 + wave * 8 + i] = m[i];
 }
 
 // Per query: every appended entry that could still be the nearest row is re-ranked with the reference's arithmetic, then
@@ -1078,7 +1057,6 @@ struct fir_gemm {
     int precision = 0;          // 0: f32 MFMA, 1: bf16 split (hi.hi + hi.lo + lo.hi), 2: one fp16 term
     uint4* gh = nullptr;        // fp16 fragments (precision 2)
     int gallery_exp = 0;        // fp16: the gallery was multiplied by 2^gallery_exp
-    float* tau_part = nullptr;  // fp16: group minima of the sampled proxies, [query][kTauGroups]
     float* qmul[2] = {nullptr, nullptr};
     float* qinv[2] = {nullptr, nullptr};
     int dk16 = 0;               // bf16 variant: k-blocks of 16 features (padded to a multiple of 4)
@@ -1150,7 +1128,6 @@ int fir_gemm_create_ex(fir_gallery* g, int32_t precision, fir_gemm** out) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking);
     m->sample_rows = (int)std::min<int64_t>(np, std::max<int64_t>(kMinSampleRows, np / 64));
     if (e == hipSuccess) e = hipMalloc((void**)&m->sample, (size_t)kPasses * kQT * m->sample_rows * sizeof(float));
-    if (e == hipSuccess && precision == FIR_GEMM_F16) e = hipMalloc((void**)&m->tau_part, (size_t)kPasses * kQT * kTauGroups * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&m->fbq, (size_t)kQT * m->v.d * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&m->fbkeys, kQT * sizeof(unsigned long long));
     const int lds_bytes = precision == FIR_GEMM_F32 ? (kQT / 32) * std::min(m->dq8, kSlab8) * 64 * (int)sizeof(float4)
@@ -1218,7 +1195,7 @@ int fir_gemm_destroy(fir_gemm* m) {
         if (m->rerank_done[b]) (void)hipEventDestroy(m->rerank_done[b]);
     }
     (void)hipFree(m->gm); (void)hipFree(m->gb); (void)hipFree(m->gh); (void)hipFree(m->gnorm); (void)hipFree(m->gmax); (void)hipFree(m->sample); (void)hipFree(m->ok);
-    (void)hipFree(m->fbq); (void)hipFree(m->fbkeys); (void)hipFree(m->tau_part);
+    (void)hipFree(m->fbq); (void)hipFree(m->fbkeys);
     delete m;
     return FIR_OK;
 }
@@ -1280,8 +1257,8 @@ int fir_gemm_search_top1_keys_dev(fir_gemm* m, const float* d_queries, int32_t q
             else
                 hipLaunchKernelGGL((k_gemm_proxy_f16<0, 0>), sgrid, dim3(kGemmBlock), kHalfLds, st, m->gh, m->gnorm, m->qbf[b], m->qinv[b], n, (int64_t)0,
                                    (int64_t)sample_rows, m->dk16, m->tau[b], m->lists[b], m->counts[b], m->sample, sample_rows);
-            hipLaunchKernelGGL(k_gemm_tau_groups, dim3(2, pairs, kTauSplit), dim3(256), 0, st, m->sample, sample_rows, m->tau_part);
-            hipLaunchKernelGGL(k_gemm_tau, dim3(pairs * 2 * kQT), dim3(256), 0, st, m->tau_part, kTauGroups, m->tau[b], nq, m->qnorm[b], m->gmax, e_rel);
+            hipLaunchKernelGGL(k_gemm_tau, dim3(pairs * 2 * kQT), dim3(256), 0, st, m->sample, (sample_rows + 31) / 32, m->tau[b], nq, m->qnorm[b], m->gmax,
+                               e_rel, 2 * kQT);
             if (streamed)
                 hipLaunchKernelGGL((k_gemm_proxy_f16<1, 1>), mgrid, dim3(kGemmBlock), kHalfLds, st, m->gh, m->gnorm, m->qbf[b], m->qinv[b], n, (int64_t)0, n,
                                    m->dk16, m->tau[b], m->lists[b], m->counts[b], m->sample, sample_rows);
