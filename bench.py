@@ -45,7 +45,30 @@ def gen_chunk(chunk, rows, d, device):
     return x / x.norm(dim=1, keepdim=True)
 
 
+# The contract is ONE JSON line on stdout. Libraries underneath print there too (RCCL writes a five-line version banner to
+# stdout when its first communicator comes up), so file descriptor 1 is pointed at stderr for the whole run and the line goes
+# to a private duplicate of the original stdout.
+_REAL_STDOUT = None
+
+
+def capture_stdout():
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit_line(text):
+    sys.stdout.flush()
+    data = (text + "\n").encode()
+    fd = _REAL_STDOUT if _REAL_STDOUT is not None else 1
+    while data:
+        data = data[os.write(fd, data):]
+
+
 def main():
+    capture_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -273,7 +296,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit_line(json.dumps(out))
 
 
 def pmc_traffic(args, n, d, world):
