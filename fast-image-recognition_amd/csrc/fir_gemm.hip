@@ -44,7 +44,8 @@ constexpr int kSlab8 = 64;             // query features staged in LDS at a time
 constexpr int kSlab16 = 32;            // bf16 variant: k-blocks of 16 features staged at a time (512 features)
 constexpr int kPasses = 8;             // 64-query passes folded into one set of launches (blockIdx.y): their tails overlap
 constexpr int kCand = 8;               // tau = the kCand-th smallest SAMPLED proxy (so ~kCand * n / sample rows get appended)
-constexpr int kRerankGroup = 8;         // candidate rows staged in LDS at a time by the re-rank
+constexpr int kRerankGroup = 8;         // candidate rows staged in LDS at a time by the re-rank (fewer when rows are longer than ~4000 features)
+constexpr size_t kRerankLdsMax = 144 * 1024;
 constexpr int kListCap = 4096;         // appended (proxy, row) entries per query before "overflow"
 constexpr int kMinSampleRows = 8192;   // rows whose proxies seed tau: max(8192, n / 64) -> ~512 appended rows per query
 
@@ -928,7 +929,7 @@ __global__ void __launch_bounds__(64) k_gemm_rerank(const unsigned long long* __
                                                      const float* __restrict__ tau, const float4* __restrict__ gal4,
                                                      const float* __restrict__ queries, const float* __restrict__ qnorm,
                                                      const float* __restrict__ gnorm_max_p, int64_t n, int d, int dp4, int64_t row_offset, float e_rel,
-                                                     unsigned long long* __restrict__ out_key, int* __restrict__ ok) {
+                                                     int ngroup, unsigned long long* __restrict__ out_key, int* __restrict__ ok) {
     const int q = blockIdx.x, lane = threadIdx.x;
     const int cnt = counts[q];
     const int have = cnt < kListCap ? cnt : kListCap;
@@ -953,8 +954,8 @@ __global__ void __launch_bounds__(64) k_gemm_rerank(const unsigned long long* __
     unsigned long long best = kKeyNone;
     float p_out = __builtin_huge_valf();            // smallest proxy NOT re-ranked
     int reranked = 0;
-    extern __shared__ __attribute__((aligned(16))) float4 crow[];     // [kRerankGroup][dp4]: candidate rows, loaded by the whole wave
-    float4* qrow = crow + (size_t)kRerankGroup * dp4;                 // [dp4]: the query, zero-padded like the gallery rows (a (0-0)^2 term adds +0)
+    extern __shared__ __attribute__((aligned(16))) float4 crow[];     // [ngroup][dp4]: candidate rows, loaded by the whole wave
+    float4* qrow = crow + (size_t)ngroup * dp4;                 // [dp4]: the query, zero-padded like the gallery rows (a (0-0)^2 term adds +0)
     for (int k = lane; k < dp4 * 4; k += 64) ((float*)qrow)[k] = k < d ? qv[k] : 0.0f;
     __syncthreads();
     for (int base = 0; base < have; base += 64) {
@@ -966,12 +967,11 @@ __global__ void __launch_bounds__(64) k_gemm_rerank(const unsigned long long* __
         unsigned long long mask = __ballot(in);
         reranked += __popcll(mask);
         while (mask) {                                                  // wave-uniform
-            // up to kRerankGroup candidates at a time: all lanes fetch their rows into LDS, then lane g re-computes
+            // up to ngroup (<= kRerankGroup) candidates at a time: all lanes fetch their rows into LDS, then lane g re-computes
             // candidate g's distance from there: db_features.cpp:22-42 order, un-fused (fir::accum<kL2>)
             unsigned long long mine = kKeyNone;
             int ng = 0;
-#pragma unroll
-            for (int g = 0; g < kRerankGroup; ++g) {
+            for (int g = 0; g < ngroup; ++g) {
                 if (mask) {
                     const int src = __ffsll((long long)mask) - 1;
                     mask &= mask - 1;
@@ -1079,6 +1079,7 @@ struct fir_gemm {
     float* fbq = nullptr;                 // fallback queries (device)
     unsigned long long* fbkeys = nullptr;
     int64_t passes = 0, fallbacks = 0;
+    int rerank_group = kRerankGroup;      // candidate rows the re-rank stages in LDS at a time
     int streamed = -1;                    // fp16: query slabs through the LDS double buffer (-1: when the tile does not fit, d > 512)
     bool wide = true;                     // bf16: pairs of passes through k_gemm_proxy_bf16_wide (FIR_GEMM_WIDE=0 turns it off)
 };
@@ -1137,6 +1138,13 @@ int fir_gemm_create_ex(fir_gallery* g, int32_t precision, fir_gemm** out) {
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy_bf16<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy_bf16<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy_bf16_wide, hipFuncAttributeMaxDynamicSharedMemorySize, kWideLds);
+    {   // the re-rank keeps the query and up to kRerankGroup candidate rows in LDS
+        const size_t row_bytes = (size_t)m->dp4 * sizeof(float4);
+        m->rerank_group = (int)std::min<size_t>(kRerankGroup, kRerankLdsMax / row_bytes > 1 ? kRerankLdsMax / row_bytes - 1 : 0);
+        if (m->rerank_group < 1) { delete m; return gemm_fail(FIR_ERR_ARG, "rows of %d features are too long for the matrix-core path's re-rank", m->v.d); }
+        if (e == hipSuccess && (size_t)(m->rerank_group + 1) * row_bytes > 64 * 1024)
+            e = hipFuncSetAttribute((const void*)k_gemm_rerank, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRerankLdsMax);
+    }
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy_f16<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kHalfLds);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy_f16<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kHalfLds);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy_f16<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kHalfLds);
@@ -1298,8 +1306,9 @@ int fir_gemm_search_top1_keys_dev(fir_gemm* m, const float* d_queries, int32_t q
         GEMM_HIP(hipEventRecord(m->main_done[b], st));
         // exact re-rank + certificate of this super-batch on the side stream, under the next one's GEMM
         GEMM_HIP(hipStreamWaitEvent(m->side, m->main_done[b], 0));
-        hipLaunchKernelGGL(k_gemm_rerank, dim3(nq), dim3(64), (size_t)(kRerankGroup + 1) * m->dp4 * sizeof(float4), m->side, m->lists[b], m->counts[b], m->tau[b],
-                           m->gal4, dq, m->qnorm[b], m->gmax, n, d, m->dp4, m->v.row_offset, e_rel, (unsigned long long*)d_keys + q0, m->ok + q0);
+        hipLaunchKernelGGL(k_gemm_rerank, dim3(nq), dim3(64), (size_t)(m->rerank_group + 1) * m->dp4 * sizeof(float4), m->side, m->lists[b], m->counts[b], m->tau[b],
+                           m->gal4, dq, m->qnorm[b], m->gmax, n, d, m->dp4, m->v.row_offset, e_rel, m->rerank_group, (unsigned long long*)d_keys + q0,
+                           m->ok + q0);
         GEMM_HIP(hipEventRecord(m->rerank_done[b], m->side));
         m->passes += np;
     }

@@ -176,3 +176,18 @@ def test_clustered_gallery_like_identities(fir, precision, spread):
     assert np.array_equal(dist.view(np.uint32), edist.view(np.uint32))
     assert np.all(idx // per == who)                      # the nearest image belongs to the query's identity
     assert st["fallback_queries"] <= qb // 10, st
+
+
+@pytest.mark.parametrize("precision", [1, 2])
+def test_long_rows(fir, precision):
+    """2048- and 4100-feature rows: the re-rank's LDS tile (query + candidate rows) needs more than the default 64 KiB, and
+    beyond ~4000 features fewer than eight candidate rows fit at a time."""
+    for d, n, qb in ((2048, 1500, 66), (4100, 700, 40)):
+        rows = synth.make_gallery(200 + d, n, d, 0)
+        q, _ = synth.make_queries(200 + d, rows, qb, 0)
+        rows[n - 1] = rows[3]
+        q[0] = rows[3]
+        (idx, dist), (eidx, edist), st = run_both(fir, rows, q, precision)
+        assert np.array_equal(idx, eidx), d
+        assert np.array_equal(dist.view(np.uint32), edist.view(np.uint32)), d
+        assert idx[0] == 3
