@@ -236,6 +236,13 @@ int check_range(const fir_gallery* g, int32_t& start, int32_t& end) {
     return FIR_OK;
 }
 
+// Serial number of a query transposition (fir_gallery::range): wraps without overflow; a collision after 2^32 calls only
+// sends one chi-square / KL call through the full division sequence.
+int next_serial(fir_gallery* g) {
+    g->q_serial = (int)((unsigned)g->q_serial + 1u);
+    return g->q_serial;
+}
+
 int largest_pow2_le(int x, int cap) {
     int p = 1;
     while (p * 2 <= x && p * 2 <= cap) p *= 2;
@@ -266,7 +273,7 @@ int run_pass(fir_gallery* g, hipStream_t st, int epi, const float* d_queries, in
         const int64_t total = std::max<int64_t>((int64_t)kk * qb_tile * ny, init_keys);
         const int blocks = (int)((total + kBlock - 1) / kBlock);
         hipLaunchKernelGGL(k_transpose_queries, dim3(blocks), dim3(kBlock), 0, st, d_queries + (size_t)q0 * g->d, qb_tile * ny,
-                           g->d, g->dp4, qb_tile, qt, init_keys > 0 ? keys : nullptr, init_keys, g->range, ++g->q_serial);
+                           g->d, g->dp4, qb_tile, qt, init_keys > 0 ? keys : nullptr, init_keys, g->range, next_serial(g));
     }
     size_t lds_bytes = 0;
     scan_fn fn = pick_fast(epi, qb_tile, g->metric, start, end, g->dp4, &lds_bytes);
@@ -447,7 +454,7 @@ int topk_lists_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t s
         const int live = std::max(0, std::min(qb - q0, ny * 8));
         float* qt = g->qt + (size_t)q0 * kk;
         hipLaunchKernelGGL(k_transpose_queries, dim3((unsigned)(((int64_t)kk * 8 * ny + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
-                           d_queries + (size_t)q0 * g->d, live, g->d, g->dp4, 8, qt, (uint64_t*)nullptr, 0, g->range, ++g->q_serial);
+                           d_queries + (size_t)q0 * g->d, live, g->d, g->dp4, 8, qt, (uint64_t*)nullptr, 0, g->range, next_serial(g));
         ScanArgs a{};
         a.range = g->range;
         a.serial = g->q_serial;
@@ -1054,7 +1061,7 @@ int fir_gallery_value_range(fir_gallery* g, int32_t* gallery_plain, int32_t* las
     FIR_HIP(hipStreamSynchronize(g->stream));
     FIR_HIP(hipMemcpy(h, g->range, sizeof h, hipMemcpyDeviceToHost));
     *gallery_plain = h[0] == 0;
-    *last_queries_plain = g->q_serial > 0 && h[1] != g->q_serial;
+    *last_queries_plain = g->q_serial != 0 && h[1] != g->q_serial;
     return FIR_OK;
 }
 
