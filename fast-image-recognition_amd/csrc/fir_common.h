@@ -103,13 +103,27 @@ __device__ __forceinline__ float accum(float acc, float l, float r) {
         const float s = __builtin_fmaxf(l + r, 0x1p-30f);       // l + r == 0 only for l == r == 0: then n == 0 and the term is +0
         return acc + div_plain(n, s, rcp_newton(s));
     } else {
+        // the two quotients 2l/s and 2r/s share the reciprocal and go through the division steps and the log's
+        // multiply as ONE packed pair (v_pk_mul_f32 / v_pk_fma_f32): the same operations per component as div_plain / log_plain
+        typedef float f2v __attribute__((ext_vector_type(2)));
         const float s = __builtin_fmaxf(l + r, 0x1p-30f);
         const float y = rcp_newton(s);
+        const f2v lr = {l, r}, ys = {y, y}, ns = {-s, -s};
+        const f2v n2 = lr * 2.0f;
+        f2v q2 = n2 * ys;
+        f2v r2 = __builtin_elementwise_fma(ns, q2, n2);
+        q2 = __builtin_elementwise_fma(r2, ys, q2);
+        r2 = __builtin_elementwise_fma(ns, q2, n2);
+        q2 = __builtin_elementwise_fma(r2, ys, q2);
         // l == 0: the quotient is 0, clamped; l * log(clamp) = -0 and acc + -0 = acc, as if the term had been skipped
-        const float ql = __builtin_fmaxf(div_plain(2.0f * l, s, y), 0x1p-60f);
-        const float qr = __builtin_fmaxf(div_plain(2.0f * r, s, y), 0x1p-60f);
-        float a = acc + l * log_plain(ql);
-        return a + r * log_plain(qr);
+        const f2v lg = {__builtin_amdgcn_logf(__builtin_fmaxf(q2.x, 0x1p-60f)), __builtin_amdgcn_logf(__builtin_fmaxf(q2.y, 0x1p-60f))};
+        const f2v c = {0x1.62e42ep-1f, 0x1.62e42ep-1f}, cc = {0x1.efa39ep-25f, 0x1.efa39ep-25f};
+        const f2v p = lg * c;
+        f2v pl = __builtin_elementwise_fma(lg, c, -p);
+        pl = __builtin_elementwise_fma(lg, cc, pl);
+        const f2v t = lr * (p + pl);
+        const float a = acc + t.x;
+        return a + t.y;
     }
 #else
     else return acc;
