@@ -5,6 +5,7 @@
 #include "fir_kernels.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -66,6 +67,9 @@ struct fir_gallery {
     // transposition that met one (fir_common.h); the scans read both and pick their division sequence on the device
     int32_t* range = nullptr;
     int q_serial = 0;
+    uint64_t* one_keys = nullptr;   // one-query calls on small galleries (top1_one_query): device key + completion counter, armed once
+    int32_t* one_done = nullptr;    // and re-armed by the kernel itself
+    uint64_t one_ticket = 0;        // number of such calls so far: the word the host waits for
 
     // workspaces (grown on demand, never inside a *_dev call once large enough)
     float* qt = nullptr;      size_t qt_cap = 0;      // transposed query tiles
@@ -803,7 +807,7 @@ int fir_gallery_destroy(fir_gallery* g) {
     if (g->gemm) { fir_gemm_destroy(g->gemm); g->gemm = nullptr; }
     for (hipEvent_t e : g->ev) (void)hipEventDestroy(e);
     (void)hipFree(g->gal4); (void)hipFree(g->cls); (void)hipFree(g->qt); (void)hipFree(g->dq); (void)hipFree(g->dkeys);
-    (void)hipFree(g->part); (void)hipFree(g->dout); (void)hipFree(g->didx); (void)hipFree(g->range);
+    (void)hipFree(g->part); (void)hipFree(g->dout); (void)hipFree(g->didx); (void)hipFree(g->range); (void)hipFree(g->one_keys);
     if (g->pin) (void)hipHostFree(g->pin);
     for (void* p : g->scratch) if (p) (void)hipFree(p);
     if (g->stream) (void)hipStreamDestroy(g->stream);
@@ -885,6 +889,58 @@ __global__ void __launch_bounds__(kBlock) k_publish_keys(const uint64_t* __restr
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i < n) host_keys[i] = keys[i];
 }
+// One L2 query against a gallery of few tiles -- the reference's own call pattern, recognize() per test image against
+// ~3 000 rows. Such a call is mostly fixed cost (three launches and a stream synchronisation next to ~20 us of kernels),
+// so here it is ONE launch and no synchronisation: the scan stages the query in LDS straight from the pinned buffer (a
+// one-query tile needs no transposition), its last workgroup writes the key and then a ticket to pinned host memory and
+// re-arms the device key, and the host spins on the ticket (falling back to hipStreamSynchronize after 2 ms).
+// 3 030 x 1536: 34 instead of 40 us per call (profiles/r01_sweep_notes.md). Returns 1 when the shape does not qualify.
+int top1_one_query(fir_gallery* g, const float* pinned_query, int32_t start, int32_t end, uint64_t* pinned_key) {
+    static const bool off = std::getenv("FIR_NO_ONE_QUERY") != nullptr;      // experiments
+    if (off || g->metric != kL2 || g->n <= 0 || g->tiles > (int64_t)g->cus * 4 || g->tiles_limit > 0 || g->profiling) return 1;
+    size_t lds_bytes = 0;
+    scan_fn fn = pick_deep(kEpiTop1, 1, g->metric, g->dp4, &lds_bytes);
+    if (!fn) return 1;
+    if (!g->one_keys) {
+        FIR_HIP(hipMalloc((void**)&g->one_keys, 64));
+        g->one_done = (int32_t*)(g->one_keys + 4);
+        const uint64_t init[8] = {kKeyNone, kKeyNone, kKeyNone, kKeyNone, 0, 0, 0, 0};
+        FIR_HIP(hipMemcpy(g->one_keys, init, sizeof init, hipMemcpyHostToDevice));
+    }
+    const int max_waves = max_waves_for(g, fn, lds_bytes);
+    const int waves = g->waves_req > 0 ? std::min(g->waves_req, max_waves) : pick_waves(g->tiles, max_waves, g->cus * 4);
+    g->last_waves = waves;
+    ScanArgs a{};
+    a.qt = pinned_query;
+    a.gal4 = g->gal4;
+    a.row_offset = g->row_offset;
+    a.n = g->n;
+    a.tiles = (int32_t)g->tiles;
+    a.dp4 = g->dp4;
+    a.start = start;
+    a.end = end;
+    a.waves = waves;
+    a.keys = g->one_keys;
+    a.nq = 1;
+    a.qt_stride = (int64_t)g->dp4 * 4;
+    a.nt = gallery_bytes(g) > kL2ResidentBytes ? 1 : 0;
+    a.publish = pinned_key;
+    a.done = g->one_done;
+    a.ticket = ++g->one_ticket;
+    volatile uint64_t* flag = pinned_key + 1;
+    hipLaunchKernelGGL(fn, dim3(waves / 4, 1), dim3(kBlock), lds_bytes, g->stream, a);
+    FIR_HIP(hipGetLastError());
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int spins = 0; __atomic_load_n(flag, __ATOMIC_ACQUIRE) != a.ticket; ++spins) {
+        if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {
+            FIR_HIP(hipStreamSynchronize(g->stream));       // a slow or failed launch: let the runtime report it
+            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != a.ticket) return fail(FIR_ERR_HIP, "one-query scan did not publish its result");
+            break;
+        }
+    }
+    return FIR_OK;
+}
+
 int ensure_pin(fir_gallery* g) {
     if (g->pin) return FIR_OK;
     FIR_HIP(hipHostMalloc(&g->pin, kPinQueryBytes + kPinKeys * sizeof(uint64_t), hipHostMallocDefault));
@@ -908,6 +964,12 @@ int fir_search_top1(fir_gallery* g, const float* queries, int32_t qb, int32_t st
         float* hq = (float*)g->pin;
         uint64_t* hk = (uint64_t*)((char*)g->pin + kPinQueryBytes);
         std::memcpy(hq, queries, (size_t)qb * g->d * sizeof(float));
+        if (qb == 1) {
+            for (int k = g->d; k < g->dp4 * 4; ++k) hq[k] = 0.0f;        // the one-query tile, zero padded
+            rc = top1_one_query(g, hq, start_pos, end_pos, hk);
+            if (rc < 0) return rc;
+            if (rc == FIR_OK) return fir_keys_unpack(hk, 1, idx, dist);
+        }
         if ((rc = top1_dev(g, hq, qb, start_pos, end_pos, g->dkeys, g->stream))) return rc;
         hipLaunchKernelGGL(k_publish_keys, dim3((qb + kBlock - 1) / kBlock), dim3(kBlock), 0, g->stream, g->dkeys, qb, hk);
         FIR_HIP(hipGetLastError());

@@ -82,6 +82,9 @@ struct ScanArgs {
     int32_t step;         // k_scan_subranges: features per sub-range
     const float* tau;     // append form of the L2 scan: rows with distance <= tau[query] are appended ...
     int32_t* counts;      // ... counts[query] entries so far, lists = keys[query * k + slot] (k = capacity per query)
+    uint64_t* publish;    // top-1, whole call = ONE launch: the last workgroup to finish writes keys[0..QB) to publish[0..QB) (pinned
+    int32_t* done;        // host memory), then `ticket` to publish[QB] -- the host spins on that word instead of synchronising
+    uint64_t ticket;      // the stream -- and re-arms keys and the done counter for the next call
     const int32_t* range; // chi-square / KL: range[0] != 0 = some gallery value is outside in_plain_range(), range[1] = serial
     int32_t serial;       // of the last query transposition that met one; NULL or a match = IEEE division sequence
 };
@@ -273,6 +276,21 @@ __global__ void __launch_bounds__(kBlock, WPS) k_scan(const ScanArgs a) {
                 // most waves lose against what is already there: read first, contend only to win
                 const uint64_t cur = __hip_atomic_load(keys + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (key < cur) atomicMin((unsigned long long*)(keys + q), (unsigned long long)key);
+            }
+        }
+        if (a.publish) {
+            __shared__ int last_block;
+            __threadfence();                                   // this workgroup's minima are out before it is counted
+            __syncthreads();
+            if (threadIdx.x == 0) last_block = atomicAdd(a.done, 1) == (int)(gridDim.x * gridDim.y) - 1;
+            __syncthreads();
+            if (last_block && threadIdx.x == 0) {
+#pragma unroll
+                for (int q = 0; q < QB; ++q)
+                    __hip_atomic_store(a.publish + q, atomicExch((unsigned long long*)(keys + q), (unsigned long long)kKeyNone), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_SYSTEM);
+                *a.done = 0;
+                __hip_atomic_store(a.publish + QB, a.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // after the keys
             }
         }
     }
