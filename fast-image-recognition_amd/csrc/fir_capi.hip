@@ -885,9 +885,30 @@ int fir_search_top1_keys_dev(fir_gallery* g, const float* d_queries, int32_t qb,
 namespace {
 constexpr size_t kPinQueryBytes = 256 * 1024;    // host-pointer calls up to this many query bytes take the pinned path
 constexpr size_t kPinKeys = 4096;                // and up to this many result keys
-__global__ void __launch_bounds__(kBlock) k_publish_keys(const uint64_t* __restrict__ keys, int n, uint64_t* __restrict__ host_keys) {
+// ticket != 0 (single-block launches only): after the keys, host_keys[n] <- ticket -- the host spins on that word instead of
+// synchronising the stream (wait_ticket)
+__global__ void __launch_bounds__(kBlock) k_publish_keys(const uint64_t* __restrict__ keys, int n, uint64_t* __restrict__ host_keys,
+                                                         uint64_t ticket) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i < n) host_keys[i] = keys[i];
+    if (ticket) {
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(host_keys + n, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+// Spin (2 ms at most, then the stream synchronisation) until the kernels queued on the handle's stream have written
+// `ticket` to the pinned word: cheaper than hipStreamSynchronize for calls that take tens of microseconds.
+int wait_ticket(fir_gallery* g, volatile uint64_t* flag, uint64_t ticket) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int spins = 0; __atomic_load_n(flag, __ATOMIC_ACQUIRE) != ticket; ++spins) {
+        if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {
+            FIR_HIP(hipStreamSynchronize(g->stream));       // a long or failed launch: let the runtime report it
+            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != ticket) return fail(FIR_ERR_HIP, "the result ticket was not published");
+            break;
+        }
+    }
+    return FIR_OK;
 }
 // One L2 query against a gallery of few tiles -- the reference's own call pattern, recognize() per test image against
 // ~3 000 rows. Such a call is mostly fixed cost (three launches and a stream synchronisation next to ~20 us of kernels),
@@ -927,18 +948,9 @@ int top1_one_query(fir_gallery* g, const float* pinned_query, int32_t start, int
     a.publish = pinned_key;
     a.done = g->one_done;
     a.ticket = ++g->one_ticket;
-    volatile uint64_t* flag = pinned_key + 1;
     hipLaunchKernelGGL(fn, dim3(waves / 4, 1), dim3(kBlock), lds_bytes, g->stream, a);
     FIR_HIP(hipGetLastError());
-    const auto t0 = std::chrono::steady_clock::now();
-    for (int spins = 0; __atomic_load_n(flag, __ATOMIC_ACQUIRE) != a.ticket; ++spins) {
-        if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {
-            FIR_HIP(hipStreamSynchronize(g->stream));       // a slow or failed launch: let the runtime report it
-            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != a.ticket) return fail(FIR_ERR_HIP, "one-query scan did not publish its result");
-            break;
-        }
-    }
-    return FIR_OK;
+    return wait_ticket(g, pinned_key + 1, a.ticket);
 }
 
 int ensure_pin(fir_gallery* g) {
@@ -971,9 +983,11 @@ int fir_search_top1(fir_gallery* g, const float* queries, int32_t qb, int32_t st
             if (rc == FIR_OK) return fir_keys_unpack(hk, 1, idx, dist);
         }
         if ((rc = top1_dev(g, hq, qb, start_pos, end_pos, g->dkeys, g->stream))) return rc;
-        hipLaunchKernelGGL(k_publish_keys, dim3((qb + kBlock - 1) / kBlock), dim3(kBlock), 0, g->stream, g->dkeys, qb, hk);
+        const uint64_t ticket = qb <= kBlock && !g->profiling ? ++g->one_ticket : 0;     // one block publishes: the host can wait on its ticket
+        hipLaunchKernelGGL(k_publish_keys, dim3((qb + kBlock - 1) / kBlock), dim3(kBlock), 0, g->stream, g->dkeys, qb, hk, ticket);
         FIR_HIP(hipGetLastError());
-        FIR_HIP(hipStreamSynchronize(g->stream));
+        if (ticket) { if ((rc = wait_ticket(g, hk + qb, ticket))) return rc; }
+        else FIR_HIP(hipStreamSynchronize(g->stream));
         return fir_keys_unpack(hk, qb, idx, dist);
     }
     if ((rc = grow(g->dq, g->dq_cap, (size_t)qb * g->d))) return rc;
