@@ -883,7 +883,7 @@ int fir_search_top1_keys_dev(fir_gallery* g, const float* d_queries, int32_t qb,
 }
 
 namespace {
-constexpr size_t kPinQueryBytes = 256 * 1024;    // host-pointer calls up to this many query bytes take the pinned path
+constexpr size_t kPinQueryBytes = 512 * 1024;    // host-pointer calls up to this many query bytes take the pinned path (a 64 x 1536 TWD batch fits)
 constexpr size_t kPinKeys = 4096;                // and up to this many result keys
 // ticket != 0 (single-block launches only): after the keys, host_keys[n] <- ticket -- the host spins on that word instead of
 // synchronising the stream (wait_ticket)
@@ -959,6 +959,18 @@ int ensure_pin(fir_gallery* g) {
     return FIR_OK;
 }
 }  // namespace
+
+int fir_gallery_pin_(fir_gallery* g, void** base, size_t* query_bytes, uint64_t** results) {
+    if (!g) return FIR_ERR_ARG;
+    const int rc = ensure_pin(g);
+    if (rc) return rc;
+    *base = g->pin;
+    *query_bytes = kPinQueryBytes;
+    *results = (uint64_t*)((char*)g->pin + kPinQueryBytes);
+    return FIR_OK;
+}
+uint64_t fir_gallery_next_ticket_(fir_gallery* g) { return ++g->one_ticket; }
+int fir_gallery_wait_ticket_(fir_gallery* g, volatile uint64_t* flag, uint64_t ticket) { return wait_ticket(g, flag, ticket); }
 
 int fir_search_top1(fir_gallery* g, const float* queries, int32_t qb, int32_t start_pos, int32_t end_pos, int32_t* idx,
                     float* dist) {
@@ -1063,8 +1075,21 @@ int fir_search_topk(fir_gallery* g, const float* queries, int32_t qb, int32_t st
     int rc = check_range(g, start_pos, end_pos);
     if (rc) return rc;
     FIR_HIP(hipSetDevice(g->device));
-    if ((rc = grow(g->dq, g->dq_cap, (size_t)qb * g->d))) return rc;
     if ((rc = grow(g->dkeys, g->dkeys_cap, (size_t)qb * k))) return rc;
+    if ((size_t)qb * g->d * sizeof(float) <= kPinQueryBytes && qb * k <= kBlock && qb < 8 && !g->profiling) {
+        // small call (below the candidate-list form, which synchronises by itself): pinned queries in, keys + ticket out, as in fir_search_top1
+        if ((rc = ensure_pin(g))) return rc;
+        float* hq = (float*)g->pin;
+        uint64_t* hk = (uint64_t*)((char*)g->pin + kPinQueryBytes);
+        std::memcpy(hq, queries, (size_t)qb * g->d * sizeof(float));
+        if ((rc = topk_dev(g, hq, qb, start_pos, end_pos, k, g->dkeys, g->stream))) return rc;
+        const uint64_t ticket = ++g->one_ticket;
+        hipLaunchKernelGGL(k_publish_keys, dim3(1), dim3(kBlock), 0, g->stream, g->dkeys, qb * k, hk, ticket);
+        FIR_HIP(hipGetLastError());
+        if ((rc = wait_ticket(g, hk + qb * k, ticket))) return rc;
+        return fir_keys_unpack(hk, qb * k, idx, dist);
+    }
+    if ((rc = grow(g->dq, g->dq_cap, (size_t)qb * g->d))) return rc;
     FIR_HIP(hipMemcpyAsync(g->dq, queries, (size_t)qb * g->d * sizeof(float), hipMemcpyHostToDevice, g->stream));
     if ((rc = topk_dev(g, g->dq, qb, start_pos, end_pos, k, g->dkeys, g->stream))) return rc;
     std::vector<uint64_t> keys((size_t)qb * k);

@@ -34,3 +34,11 @@ extern "C" int fir_subrange_distances_dev_(fir_gallery* g, const float* d_querie
 // lean on that stream (std::random_shuffle in getTrainingAndTestImages and DirectedEnumeration::init, srand(13) in
 // testRecognitionMethod), so the start-up runs on a private random state and the caller's is handed back untouched.
 extern "C" int fir_runtime_init_(int device);
+
+// Small host-pointer calls of the other translation units, without copy engine and without stream synchronisation: the
+// handle's pinned, device-visible buffer (queries go in at `base`, up to *query_bytes; results come back at *results, 4096
+// eight-byte words), a fresh ticket number, and the wait for the word a call's last kernel writes it to (spins for 2 ms,
+// then synchronises the stream). See fir_search_top1 in fir_capi.hip.
+extern "C" int fir_gallery_pin_(fir_gallery* g, void** base, size_t* query_bytes, uint64_t** results);
+extern "C" uint64_t fir_gallery_next_ticket_(fir_gallery* g);
+extern "C" int fir_gallery_wait_ticket_(fir_gallery* g, volatile uint64_t* flag, uint64_t ticket);

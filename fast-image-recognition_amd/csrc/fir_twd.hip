@@ -15,6 +15,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <cstring>
 #include <cstdarg>
 #include <cstdio>
 #include <vector>
@@ -478,6 +479,15 @@ int check_common(fir_gallery* g, const float* queries, int32_t qb, int32_t reduc
 
 }  // namespace
 
+// The verdicts of a batch go to pinned host memory, then the ticket the host is spinning on (fir_gallery_wait_ticket_).
+__global__ void __launch_bounds__(256) k_twd_publish(const int32_t* __restrict__ res, int count, int32_t* __restrict__ host_res,
+                                                     uint64_t* __restrict__ host_ticket, uint64_t ticket) {
+    for (int i = threadIdx.x; i < count; i += 256) host_res[i] = res[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(host_ticket, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 extern "C" {
 
 int fir_twd_conventional(fir_gallery* g, const float* queries, int32_t qb, int32_t num_classes, int32_t type, double threshold,
@@ -516,8 +526,14 @@ int fir_twd_conventional(fir_gallery* g, const float* queries, int32_t qb, int32
         } else {
             // both stages are queued back to back -- the second one decides on the device which queries it concerns -- and
             // the verdicts come back with ONE copy and ONE synchronisation per batch
-            TWD_HIP(hipMemcpyAsync(dq.p, queries + (size_t)q0 * v.d, (size_t)nq * v.d * 4, hipMemcpyHostToDevice, v.stream));
-            if ((rc = fir_range_distances_dev(g, dq.as<float>(), nq, 0, reduced_features_count, d1.as<float>(), v.stream))) return rc;
+            // small batches: the kernels read the queries from pinned host memory and the verdicts come back through it, with
+            // a ticket instead of a stream synchronisation (no copy engine on either side)
+            void* pin_base = nullptr; size_t pin_cap = 0; uint64_t* pin_res = nullptr;
+            const bool pinned = fir_gallery_pin_(g, &pin_base, &pin_cap, &pin_res) == FIR_OK && (size_t)nq * v.d * 4 <= pin_cap;
+            const float* qsrc = dq.as<float>();
+            if (pinned) { std::memcpy(pin_base, queries + (size_t)q0 * v.d, (size_t)nq * v.d * 4); qsrc = (const float*)pin_base; }
+            else TWD_HIP(hipMemcpyAsync(dq.p, queries + (size_t)q0 * v.d, (size_t)nq * v.d * 4, hipMemcpyHostToDevice, v.stream));
+            if ((rc = fir_range_distances_dev(g, qsrc, nq, 0, reduced_features_count, d1.as<float>(), v.stream))) return rc;
             const size_t plds = (size_t)num_classes * 8;
             if (nseg_eff == 1) {
                 hipLaunchKernelGGL(k_twd_conv_stage1<kS1Single>, dim3(nq), dim3(kBlock), plds, v.stream, d1.as<float>(), v.cls, n, num_classes, type,
@@ -532,7 +548,7 @@ int fir_twd_conventional(fir_gallery* g, const float* queries, int32_t qb, int32
                                    threshold, dcls, dunrel, part1, chg, gprob, seg_rows);
             }
             TWD_HIP(hipGetLastError());
-            if ((rc = fir_range_distances_dev(g, dq.as<float>(), nq, reduced_features_count, kLastFeature, d2.as<float>(), v.stream))) return rc;
+            if ((rc = fir_range_distances_dev(g, qsrc, nq, reduced_features_count, kLastFeature, d2.as<float>(), v.stream))) return rc;
             if (nseg_eff == 1) {
                 hipLaunchKernelGGL(k_twd_conv_stage2<false>, dim3(nq), dim3(kBlock), 0, v.stream, d1.as<float>(), d2.as<float>(), dunrel, v.cls, n,
                                    reduced_features_count, dcls, (DI*)nullptr, n);
@@ -542,8 +558,16 @@ int fir_twd_conventional(fir_gallery* g, const float* queries, int32_t qb, int32
                 hipLaunchKernelGGL(k_twd_conv_stage2_final, dim3(nq), dim3(64), 0, v.stream, part2, nseg_eff, dunrel, v.cls, dcls);
             }
             TWD_HIP(hipGetLastError());
-            TWD_HIP(hipMemcpyAsync(h_res, dres.p, sizeof(h_res), hipMemcpyDeviceToHost, v.stream));
-            TWD_HIP(hipStreamSynchronize(v.stream));
+            if (pinned) {
+                const uint64_t ticket = fir_gallery_next_ticket_(g);
+                hipLaunchKernelGGL(k_twd_publish, dim3(1), dim3(256), 0, v.stream, dcls, 2 * kBatch, (int32_t*)pin_res, pin_res + kBatch, ticket);
+                TWD_HIP(hipGetLastError());
+                if ((rc = fir_gallery_wait_ticket_(g, pin_res + kBatch, ticket))) return rc;
+                std::memcpy(h_res, pin_res, sizeof(h_res));
+            } else {
+                TWD_HIP(hipMemcpyAsync(h_res, dres.p, sizeof(h_res), hipMemcpyDeviceToHost, v.stream));
+                TWD_HIP(hipStreamSynchronize(v.stream));
+            }
         }
         for (int i = 0; i < nq; ++i) {
             class_out[q0 + i] = h_res[i];
@@ -594,9 +618,13 @@ int fir_twd_proposed(fir_gallery* g, const float* queries, int32_t qb, int32_t r
         if (n == 0) {
             for (int i = 0; i < nq; ++i) { h_cls[i] = -1; h_unrel[i] = 0; h_chunks[i] = 0; }
         } else {
-            TWD_HIP(hipMemcpyAsync(dq.p, queries + (size_t)q0 * v.d, (size_t)nq * v.d * 4, hipMemcpyHostToDevice, v.stream));
+            void* pin_base = nullptr; size_t pin_cap = 0; uint64_t* pin_res = nullptr;      // as in fir_twd_conventional
+            const bool pinned = fir_gallery_pin_(g, &pin_base, &pin_cap, &pin_res) == FIR_OK && (size_t)nq * v.d * 4 <= pin_cap;
+            const float* qsrc = dq.as<float>();
+            if (pinned) { std::memcpy(pin_base, queries + (size_t)q0 * v.d, (size_t)nq * v.d * 4); qsrc = (const float*)pin_base; }
+            else TWD_HIP(hipMemcpyAsync(dq.p, queries + (size_t)q0 * v.d, (size_t)nq * v.d * 4, hipMemcpyHostToDevice, v.stream));
             // all chunk distances cd[c][slot][n] from ONE pass over features [0, 256)
-            if ((rc = fir_subrange_distances_dev_(g, dq.as<float>(), nq, 0, kLastFeature, reduced_features_count, cd.as<float>(), v.stream))) return rc;
+            if ((rc = fir_subrange_distances_dev_(g, qsrc, nq, 0, kLastFeature, reduced_features_count, cd.as<float>(), v.stream))) return rc;
             if (nseg == 1) {
                 hipLaunchKernelGGL(k_twd_proposed, dim3(nq), dim3(kBlock), 0, v.stream, cd.as<float>(), nq, nchunks, acc.as<double>(),
                                    alive.as<uint8_t>(), v.cls, n, 1.0 / threshold, dcls, dunrel, dchunks);
@@ -613,8 +641,16 @@ int fir_twd_proposed(fir_gallery* g, const float* queries, int32_t qb, int32_t r
                 }
             }
             TWD_HIP(hipGetLastError());
-            TWD_HIP(hipMemcpyAsync(h_res, dres.p, sizeof(h_res), hipMemcpyDeviceToHost, v.stream));
-            TWD_HIP(hipStreamSynchronize(v.stream));
+            if (pinned) {
+                const uint64_t ticket = fir_gallery_next_ticket_(g);
+                hipLaunchKernelGGL(k_twd_publish, dim3(1), dim3(256), 0, v.stream, dcls, 3 * kBatch, (int32_t*)pin_res, pin_res + 2 * kBatch, ticket);
+                TWD_HIP(hipGetLastError());
+                if ((rc = fir_gallery_wait_ticket_(g, pin_res + 2 * kBatch, ticket))) return rc;
+                std::memcpy(h_res, pin_res, sizeof(h_res));
+            } else {
+                TWD_HIP(hipMemcpyAsync(h_res, dres.p, sizeof(h_res), hipMemcpyDeviceToHost, v.stream));
+                TWD_HIP(hipStreamSynchronize(v.stream));
+            }
         }
         for (int i = 0; i < nq; ++i) {
             class_out[q0 + i] = h_cls[i];
