@@ -197,17 +197,29 @@ __global__ void __launch_bounds__(64) k_cls_knn_kth(const double* __restrict__ s
 // PNNClassifier::predict_sequentional, classification.cpp:228-295. cs[chunk][q][nt]: per-row sums of
 // 32-feature chunk `chunk`; dist[q][nt] workspace. One workgroup per query; wave w owns classes
 // w, w+4, ... (rows of a class are contiguous), so every class output is summed in a fixed order.
-// Dynamic LDS: num_classes doubles (outputs) + num_classes ints (classes_to_check).
-__global__ void __launch_bounds__(kBlock) k_cls_pnn_seq(const double* __restrict__ cs, int nq, int nchunks, double* __restrict__ dist,
-                                                         const int32_t* __restrict__ class_off, int64_t nt, int num_classes, int d,
-                                                         double var, int32_t* __restrict__ best_class, int32_t* __restrict__ chunks_out) {
+// Dynamic LDS: num_classes doubles (outputs) + num_classes ints (classes_to_check) + num_classes + 1 ints (class offsets).
+// 1024 threads per query. Every chunk is three short phases instead of one wave walking its classes one after the other
+// (25 classes x 8 chunks of dependent loads, exp and reduction: 400 us for ONE query at 3 030 x 256): (A) all threads, one
+// row each: running sum and its exp() -> ev[t]; (B) one wave per class adds the class's ev in the order the single-phase
+// kernel used (lane l takes rows l, l + 64, ...; then the wave tree), so the outputs are bit-for-bit what they were;
+// (C) one wave does the first-maximum / threshold / count bookkeeping in parallel (first maximum = larger value, then
+// lower class).
+constexpr int kSeqBlock = 1024;
+__global__ void __launch_bounds__(kSeqBlock) k_cls_pnn_seq(const double* __restrict__ cs, int nq, int nchunks, double* __restrict__ dist,
+                                                            double* __restrict__ ev, const int32_t* __restrict__ class_off, int64_t nt,
+                                                            int num_classes, int d, double var, int32_t* __restrict__ best_class,
+                                                            int32_t* __restrict__ chunks_out) {
     extern __shared__ __attribute__((aligned(16))) double outputs[];
     int* checked = (int*)(outputs + num_classes);
+    int* off = checked + num_classes;                                               // class_off, [num_classes + 1]
     __shared__ int best_s, stop_s;
     const int q = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nwaves = kSeqBlock / 64;
     double* dq = dist + (size_t)q * nt;
-    for (int64_t t = threadIdx.x; t < nt; t += kBlock) dq[t] = 0.0;                 // distances[i][t] = 0 (:238-241)
-    for (int c = threadIdx.x; c < num_classes; c += kBlock) { checked[c] = 1; outputs[c] = 0.0; }
+    double* eq = ev + (size_t)q * nt;
+    for (int64_t t = threadIdx.x; t < nt; t += kSeqBlock) dq[t] = 0.0;             // distances[i][t] = 0 (:238-241)
+    for (int c = threadIdx.x; c < num_classes; c += kSeqBlock) { checked[c] = 1; outputs[c] = 0.0; }
+    for (int c = threadIdx.x; c <= num_classes; c += kSeqBlock) off[c] = class_off[c];
     if (threadIdx.x == 0) { best_s = -1; stop_s = 0; }
     __syncthreads();
     const double den = (double)nt;                                                  // total_training_size (:244)
@@ -217,32 +229,52 @@ __global__ void __launch_bounds__(kBlock) k_cls_pnn_seq(const double* __restrict
         int max_fi = (ch + 1) * 32;                                                 // delta_features_count = 32 (:182,247-249)
         if (max_fi > d) max_fi = d;
         const double* csq = cs + ((size_t)ch * nq + q) * nt;
-        for (int c = wave; c < num_classes; c += kBlock / 64) {
-            if (!checked[c]) continue;                                              // :251
-            double acc = 0.0;
-            for (int t = class_off[c] + lane; t < class_off[c + 1]; t += 64) {
+        // (A) rows in parallel
+        for (int64_t t = threadIdx.x; t < nt; t += kSeqBlock) {
+            int lo = 0, hi = num_classes;                                           // class of row t: off[lo] <= t < off[lo + 1]
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (off[mid] <= t) lo = mid; else hi = mid;
+            }
+            if (checked[lo]) {                                                      // :251 (a dropped class never comes back)
                 const double v = dq[t] + csq[t];                                    // distances[i][t] += diff*diff ... (:264)
                 dq[t] = v;
-                acc += exp(-v / (2 * var * max_fi));                                // :266
+                eq[t] = exp(-v / (2 * var * max_fi));                               // :266
             }
+        }
+        __syncthreads();
+        // (B) one wave per class
+        for (int c = wave; c < num_classes; c += nwaves) {
+            if (!checked[c]) continue;
+            double acc = 0.0;
+            for (int t = off[c] + lane; t < off[c + 1]; t += 64) acc += eq[t];
             acc = wave_sum(acc);
             if (lane == 0) outputs[c] = acc / den;                                  // :268
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            double max_output = -DBL_MAX;
-            int best = best_s;
-            for (int i = 0; i < num_classes; ++i)
-                if (checked[i] && max_output < outputs[i]) { max_output = outputs[i]; best = i; }   // :272-279
-            best_s = best;
-            const float output_threshold = (float)(max_output / 1000000000);        // output_dividor = 1E9 (:186,282)
+        // (C) bookkeeping, one wave
+        if (wave == 0) {
+            double mx = -DBL_MAX;
+            int bi = 0x7FFFFFFF;
+            for (int i = lane; i < num_classes; i += 64)
+                if (checked[i] && mx < outputs[i]) { mx = outputs[i]; bi = i; }     // :272-279, this lane's first maximum
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                const double om = __shfl_xor(mx, o, 64);
+                const int oi = __shfl_xor(bi, o, 64);
+                if (om > mx || (om == mx && oi < bi)) { mx = om; bi = oi; }
+            }
+            const int best = bi != 0x7FFFFFFF ? bi : best_s;                        // nothing exceeded -DBL_MAX: the previous best stays
+            const float output_threshold = (float)(mx / 1000000000);                // output_dividor = 1E9 (:186,282)
             int variants = 0;
-            for (int i = 0; i < num_classes; ++i)
+            for (int i = lane; i < num_classes; i += 64)
                 if (checked[i]) {
                     if (outputs[i] < output_threshold) checked[i] = 0;              // :285-286
                     else ++variants;
                 }
-            stop_s = variants == 1;                                                 // :291
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) variants += __shfl_xor(variants, o, 64);
+            if (lane == 0) { best_s = best; stop_s = variants == 1; }               // :291
         }
         __syncthreads();
         if (stop_s) break;
@@ -512,7 +544,7 @@ int fir_cls_pnn_predict(fir_cls* c, const double* queries, int32_t qb, double va
 int fir_cls_pnn_predict_seq(fir_cls* c, const double* queries, int32_t qb, double var, int32_t* best_class, int32_t* chunks_out) {
     if (!c || !best_class || (qb > 0 && !queries)) return cls_fail(FIR_ERR_ARG, "NULL argument");
     if (qb < 0) return cls_fail(FIR_ERR_ARG, "qb < 0");
-    if ((size_t)c->num_classes * 12 > 60 * 1024) return cls_fail(FIR_ERR_ARG, "num_classes=%d too large for the LDS tables", c->num_classes);
+    if ((size_t)c->num_classes * 16 + 4 > 60 * 1024) return cls_fail(FIR_ERR_ARG, "num_classes=%d too large for the LDS tables", c->num_classes);
     if (qb == 0) return FIR_OK;
     CLS_HIP(hipSetDevice(c->device));
     if (var <= 0) { var = 0.00002; if (c->d > 2000) var /= 10; }                // classification.cpp:229-233
@@ -521,7 +553,7 @@ int fir_cls_pnn_predict_seq(fir_cls* c, const double* queries, int32_t qb, doubl
     int rc;
     const double* dq = nullptr;
     if ((rc = cls_stage_queries(c, queries, qb, &dq))) return rc;
-    if ((rc = cls_grow(c->sums, c->sums_cap, (size_t)(nchunks + 1) * kQB * ntp))) return rc;   // chunk sums + running sums
+    if ((rc = cls_grow(c->sums, c->sums_cap, (size_t)(nchunks + 2) * kQB * ntp))) return rc;   // chunk sums + running sums + their exp()
     if ((rc = cls_grow(c->best, c->best_cap, (size_t)2 * std::max(qb, kQB)))) return rc;
     const bool small = cls_small(c, qb);
     int32_t* dbest = small ? cls_pin_results(c) : c->best;
@@ -536,8 +568,8 @@ int fir_cls_pnn_predict_seq(fir_cls* c, const double* queries, int32_t qb, doubl
         // all 32-feature chunk sums (16 double2 chunks each) from one pass: chunk ch lands at sums + ch * nq * nt
         hipLaunchKernelGGL(k_cls_scan, dim3(waves / 4), dim3(kBlock), 0, c->stream, c->gal2, c->qn, c->nt, (int)c->tiles, c->dp2, c->d, waves, nq,
                            0, c->dp2, c->sums, 16, (int64_t)nq * c->nt);
-        hipLaunchKernelGGL(k_cls_pnn_seq, dim3(nq), dim3(kBlock), (size_t)c->num_classes * 12, c->stream, c->sums, nq, nchunks, run,
-                           c->class_off, c->nt, c->num_classes, c->d, var, dbest + q0, dchunks + q0);
+        hipLaunchKernelGGL(k_cls_pnn_seq, dim3(nq), dim3(kSeqBlock), (size_t)c->num_classes * 16 + 4, c->stream, c->sums, nq, nchunks, run,
+                           run + (size_t)kQB * ntp, c->class_off, c->nt, c->num_classes, c->d, var, dbest + q0, dchunks + q0);
     }
     CLS_HIP(hipGetLastError());
     if (!small) {
