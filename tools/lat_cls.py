@@ -29,3 +29,22 @@ for name, fn in calls.items():
         fn()
         ts.append(time.perf_counter() - t0)
     print("%-18s median %.1f us" % (name, np.median(ts) * 1e6))
+
+# FPNN (orthogonal-series PNN) and the DEM likelihood update at the same scale
+sd = x.std(0) + 1e-9
+f = fir.Fpnn(x, lab, ncls, x.mean(0), sd, 1.0, 0)
+rows32 = rng.random((3030, 256), dtype=np.float32)
+g = fir.Gallery(rows32, (np.arange(3030) % 101).astype(np.int32), 0, 0)
+dem = fir.Dem(g, 0, 45)
+q32 = rng.random((1, 256), dtype=np.float32)
+more = {"fpnn predict": lambda: f.predict(q), "fpnn predict_seq": lambda: f.predict_seq(q, 0.9), "dem likelihoods": lambda: dem.likelihoods(q32),
+        "rows_distances(64)": lambda: g.rows_distances(q32, np.arange(64, dtype=np.int32))}
+for name, fn in more.items():
+    for _ in range(100):
+        fn()
+    ts = []
+    for _ in range(1000):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    print("%-18s median %.1f us" % (name, np.median(ts) * 1e6))
