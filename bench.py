@@ -1,24 +1,35 @@
 #!/usr/bin/env python3
 """bench.py -- query-vectors/sec of brute-force L2 top-1 over a 1M x 512 float32 gallery.
 
-Contract: `python bench.py --gpus N --steps K --warmup W` (N > 1 is launched by
-torch.distributed.run, one rank per GPU). A "step" is one batch of `--batch` query vectors
-matched against the whole gallery: ceil(batch / queries_per_pass) gallery passes of the scan
-kernel plus, for N > 1, one RCCL all-reduce(MIN) over the packed (distance, index) keys.
-Queries and gallery are resident in HBM before the timed region starts.
+Contract: `python bench.py --gpus N --steps K --warmup W`. Invoked plainly with N > 1 it starts the N ranks itself
+(`python -m torch.distributed.run`, one child process per GPU, before this process has made any GPU call) and relays
+rank 0's line; invoked by torch.distributed.run it is one of those ranks.
 
-Multi-GPU: the SAME 1M x 512 gallery is sharded by rows over the N ranks ("scaling":
-"strong"); every rank scans its shard for all queries and the global nearest neighbour is the
-integer minimum of the ranks' packed keys (exact first-minimum tie-break).
+A "step" is one batch of `--batch` query vectors matched against the whole gallery through the library's default
+dispatch (fir_search_top1_keys_dev): for batches >= 128 that is the fp16 matrix-core nomination pass + exact re-rank +
+certificate (identical keys to the exact scan, checked in this run), plus, for N > 1, the RCCL all-reduce(MIN) of the
+packed (distance, index) keys that the LIBRARY issues (fir_sharded_*, ncclAllReduce(ncclMin, ncclUint64)). Queries and
+gallery are resident in HBM before the timed region starts. `value` is that loop.
 
-Rank 0 prints ONE JSON line. `roofline` is measured live with HIP events around every scan
-launch on the stream the kernel runs on; `cpu_baseline` (N = 1 only) times the reference's own
-recognize_image_bf (oracle/_ref, built from /root/reference in the build container) on the
-host cores over a bounded sample of the same queries, and cross-checks the GPU answers.
+The same run also times, with the same steps / warmup:
+  * the exact streaming scan at 8 queries per gallery pass (matrix-core path switched off, 256-query steps): the
+    metric's "achieved HBM GB/s" clause -> `roofline`;
+  * N = 1: chi-square / KL / top-5 scans of the same gallery (BASELINE config 3), the 100k x 512 gallery (config 2),
+    the float64 PNN / kNN classifiers (K3);
+  * a 10M x 512 gallery split over the N ranks (BASELINE config 4) -> `config4`;
+  * N = 1: the reference's own recognize_image_bf and the OpenMP restatement on ALL host cores -> `cpu_baseline`, `cpu_all`.
+
+Multi-GPU: the SAME 1M x 512 gallery is sharded by rows over the N ranks ("scaling": "strong"); `config4` is the
+larger gallery of BASELINE.json configs[3].
+
+Rank 0 prints ONE JSON line. Kernel times are HIP events on the stream the kernels run on (fir_profile_read); kernel
+names, grids, LDS bytes and registers come from the library (fir_gallery_last_dispatch), not from this script.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import threading
 import time
@@ -33,6 +44,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import __graft_entry__ as ge  # noqa: E402
 
 CHUNK_ROWS = 15625      # generation granule: 64 chunks make the 1M-row gallery, any 1/2/4/8 sharding is whole chunks
+PEAK_MFMA_F16_TFLOPS = 2500.0      # dense fp16 / bf16 MFMA peak, MI355X_MICROARCH.md
+PEAK_VALU_WAVE_INSTR_PER_S = 256 * 4 * 2.4e9 / 4.0   # one wave64 VALU instruction per 4 cycles per SIMD (profiles/r01_ubench_valu_issue_rate.txt)
 
 
 def gen_chunk(chunk, rows, d, device):
@@ -67,39 +80,178 @@ def emit_line(text):
         data = data[os.write(fd, data):]
 
 
-def main():
-    capture_stdout()
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rows", type=int, default=1_000_000)
     ap.add_argument("--dim", type=int, default=512)
-    ap.add_argument("--batch", type=int, default=256, help="query vectors per step")
-    ap.add_argument("--qpp", type=int, default=0, help="queries per gallery pass (0 = library default)")
+    ap.add_argument("--batch", type=int, default=4096, help="query vectors per step of the headline loop")
+    ap.add_argument("--scan-batch", type=int, default=256, help="query vectors per step of the exact-scan loop (the HBM roofline)")
+    ap.add_argument("--qpp", type=int, default=0, help="queries per gallery pass of the exact scan (0 = library default)")
     ap.add_argument("--waves", type=int, default=0)
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
-    ap.add_argument("--no-mfma", action="store_true", help="skip the (untimed) matrix-core cross-check of the same step")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of each CPU baseline leg (0 = skip)")
+    ap.add_argument("--no-extras", "--no-mfma", dest="no_extras", action="store_true",
+                    help="only the two timed loops: skip the config-2/3 scans, the K3 classifiers and config 4")
+    ap.add_argument("--config4-rows", type=int, default=10_000_000, help="rows of the config-4 gallery (0 = skip)")
     ap.add_argument("--pmc-child", action="store_true", help="internal: this process IS the counter pass (no nested pass, short run)")
     ap.add_argument("--no-pmc", action="store_true", help="do not start the rocprofv3 counter pass; report the recorded one")
-    ap.add_argument("--force-dist", action="store_true", help="initialise the process group even for one rank (exercises the RCCL key exchange on a 1-GPU box)")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' rehearses the N>1 path with all ranks on ONE GPU")
-    args = ap.parse_args()
+    ap.add_argument("--force-dist", action="store_true", help="one rank, but through the sharded handle and its RCCL communicator")
+    ap.add_argument("--shards-per-device", type=int, default=1, help="logical shards per rank (exercises the split on few GPUs)")
+    ap.add_argument("--backend", default="nccl", help="'gloo' rehearses the N>1 path with all ranks on ONE GPU (keys exchanged through host memory)")
+    ap.add_argument("--dry-run", action="store_true", help="rendezvous, shard arithmetic and key exchange only, no GPU work (CPU test of the launch path)")
+    return ap.parse_args(argv)
 
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` invoked plainly: start N rank processes (fresh children; this parent has made no GPU
+    call and makes none), wait, relay rank 0's JSON line."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
+    line = None
+    for ln in p.stdout.decode(errors="replace").splitlines():
+        ln = ln.strip()
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        elif ln:
+            print(ln, file=sys.stderr)
+    if p.returncode != 0 or line is None:
+        print(f"bench.py: the {args.gpus}-rank run failed (exit {p.returncode}, result line {'found' if line else 'missing'})", file=sys.stderr)
+        sys.exit(p.returncode or 1)
+    emit_line(line)
+
+
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def dry_run(args, world, rank):
+    """No GPU: the ranks rendezvous (gloo), split the rows and reduce made-up packed keys exactly as the real run does."""
+    import torch.distributed as dist
+    fir = ge.load_package()
+    from fast_image_recognition_amd import sharding
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = sharding.shard_bounds(args.rows, world, rank, granule=CHUNK_ROWS)
+    qb = args.batch
+    # query i's best row lives in shard i % world: that rank holds (distance 0.25, row), the others a worse one of their own
+    keys = np.array([fir.key_pack(0.25 if i % world == rank else 0.5, min(lo + i, max(hi - 1, lo))) for i in range(qb)], np.uint64)
+    t = sharding.keys_as_int64(torch.from_numpy(keys.view(np.int64)).clone())
+    if world > 1:
+        sharding.allreduce_min_keys(t)
+    merged = sharding.keys_from_int64(t).numpy().view(np.uint64)
+    idx, dd = fir.keys_unpack(merged)
+    ok = bool(np.all(dd == np.float32(0.25)))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        emit_line(json.dumps({"metric": "query-vectors/sec brute-force L2 top-1, 1Mx512 gallery", "value": None, "unit": "queries/s", "n_gpus": world,
+                              "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "strong",
+                              "vs_baseline": None, "dtype": "f32", "data": "synthetic", "dry_run": True,
+                              "config": {"workload": "dry run: rendezvous + row split + key exchange only", "row_sharding": f"{world} shard(s)",
+                                         "exchange_ok": ok}}))
+
+
+class Matcher:
+    """One rank's view of the (sharded) gallery: `step(q, qb, keys)` = scan of the local rows + the exchange."""
+
+    def __init__(self, fir, args, shard, n_local, d, row_lo, world, rank, local_rank, dist, dev, work_stream):
+        from fast_image_recognition_amd import sharding
+        self.fir, self.args, self.dist, self.dev, self.world = fir, args, dist, dev, world
+        self.sharding = sharding
+        self.ws = work_stream
+        self.stream = work_stream.cuda_stream
+        self.sh = None
+        self.in_library_rccl = (dist is not None and args.backend == "nccl") or args.shards_per_device > 1 or args.force_dist
+        if self.in_library_rccl:
+            # the key exchange is the library's: every rank passes the id rank 0 made
+            idt = torch.zeros(fir.capi.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(fir.comm_unique_id()), dtype=torch.uint8))
+            if dist is not None and world > 1:
+                dist.broadcast(idt, 0)
+            self.sh = fir.ShardedGallery(dev_ptr=shard.data_ptr(), n=n_local, d=d, metric=fir.METRIC_L2, devices=[local_rank],
+                                         shards_per_device=args.shards_per_device, first_global_row=row_lo,
+                                         comm_id=bytes(idt.cpu().numpy().tobytes()), proc_rank=rank, nprocs=world)
+            self.parts = [self.sh.shard(i)[0] for i in range(self.sh.info()["nshards"])]
+            self.parts = [p for p in self.parts if p is not None]
+            self.g = self.parts[0]
+        else:
+            self.g = fir.Gallery(dev_ptr=shard.data_ptr(), n=n_local, d=d, metric=fir.METRIC_L2, device=local_rank, stream=self.stream)
+            self.g.set_row_offset(row_lo)
+            self.parts = [self.g]
+
+    def set_mfma(self, v):
+        for p in self.parts:
+            p.set_large_batch_mfma(v)
+
+    def set_tuning(self, qpp, waves):
+        for p in self.parts:
+            p.set_tuning(qpp, waves)
+
+    def step(self, q, qb, keys):
+        with torch.cuda.stream(self.ws):
+            if self.sh is not None:
+                self.sh.search_top1_keys_dev(q.data_ptr(), qb, keys.data_ptr(), stream=self.stream)      # scan + ncclAllReduce(min, u64)
+                return
+            self.g.search_top1_keys_dev(q.data_ptr(), qb, keys.data_ptr(), stream=self.stream)
+            if self.dist is not None:            # gloo rehearsal: ranks share a GPU, the keys go through host memory
+                k = self.sharding.keys_as_int64(keys)
+                kh = k.cpu()
+                self.sharding.allreduce_min_keys(kh)
+                keys.copy_(self.sharding.keys_from_int64(kh.to(self.dev)))
+
+    def close(self):
+        if self.sh is not None:
+            self.sh.close()
+        else:
+            self.g.close()
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        capture_stdout()
+        return spawn_ranks(args)
+    capture_stdout()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.dry_run:
+        return dry_run(args, world, rank)
     dist = None
-    if world > 1 or args.force_dist:
+    if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        else:   # rehearsal: ranks may share a GPU, the key exchange goes through host memory
+        else:   # rehearsal: ranks may share a GPU
             dist.init_process_group(args.backend, rank=rank, world_size=world)
             local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
@@ -107,58 +259,8 @@ def main():
     fir = ge.load_package()
     from fast_image_recognition_amd import sharding
 
-    n, d, qb = args.rows, args.dim, args.batch
-    row_lo, row_hi = sharding.shard_bounds(n, world, rank, granule=CHUNK_ROWS)
-    c_lo, c_hi = row_lo // CHUNK_ROWS, (row_hi + CHUNK_ROWS - 1) // CHUNK_ROWS
-
-    # ---- gallery shard, generated on the device, re-tiled by the library, source freed ----
-    shard = torch.empty((row_hi - row_lo, d), device=dev, dtype=torch.float32)
-    for c in range(c_lo, c_hi):
-        r0 = c * CHUNK_ROWS
-        rows = min(CHUNK_ROWS, n - r0)
-        shard[r0 - row_lo: r0 - row_lo + rows] = gen_chunk(c, rows, d, dev)
-    torch.cuda.synchronize()
-    # all timed work runs on one explicit (non-default) stream: the library launches on it and torch
-    # orders the RCCL all-reduce after it
-    work_stream = torch.cuda.Stream(device=dev)
-    stream = work_stream.cuda_stream
-    g = fir.Gallery(dev_ptr=shard.data_ptr(), n=shard.shape[0], d=d, metric=fir.METRIC_L2, device=local_rank, stream=stream)
-    g.set_row_offset(row_lo)
-    if args.qpp or args.waves:
-        g.set_tuning(args.qpp, args.waves)
-
-    # ---- queries: even = fresh draws, odd = perturbed copies of known gallery rows of chunk 0 ----
-    c0 = gen_chunk(0, min(CHUNK_ROWS, n), d, dev)
-    gq = torch.Generator(device=dev)
-    gq.manual_seed(424243)
-    fresh = torch.rand((qb, d), generator=gq, device=dev)
-    planted_rows = (torch.arange(qb, device=dev) * 977 + 11) % c0.shape[0]
-    noise = (torch.rand((qb, d), generator=gq, device=dev) - 0.5) * 0.05 * c0.mean()
-    pert = (c0[planted_rows] + noise).clamp_min(0)
-    q = torch.where((torch.arange(qb, device=dev) % 2 == 0)[:, None], fresh, pert)
-    q = (q / q.norm(dim=1, keepdim=True)).contiguous()
-    del c0, fresh, pert, noise
-    keys = torch.empty(qb, device=dev, dtype=torch.int64)   # packed u64 keys (viewed int64 for torch)
-    host_shard = None
-    if world == 1 and args.cpu_seconds > 0:
-        host_shard = shard.cpu().numpy()
-    del shard
-    torch.cuda.empty_cache()
-
-    torch.cuda.synchronize()
-
-    def step():
-        with torch.cuda.stream(work_stream):
-            g.search_top1_keys_dev(q.data_ptr(), qb, keys.data_ptr(), stream=stream)
-            if dist is not None:
-                k = sharding.keys_as_int64(keys)           # order-preserving u64 -> i64 (x ^ 2^63)
-                if args.backend == "nccl":
-                    sharding.allreduce_min_keys(k)         # RCCL all-reduce(MIN) over xGMI
-                else:
-                    kh = k.cpu()
-                    sharding.allreduce_min_keys(kh)
-                    k = kh.to(dev)
-                keys.copy_(sharding.keys_from_int64(k))
+    d = args.dim
+    work_stream = torch.cuda.Stream(device=dev)   # all timed work runs on one explicit (non-default) stream
 
     def fence():
         torch.cuda.synchronize()
@@ -166,132 +268,193 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    g.profile_enable(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    t1 = time.perf_counter()
-    kernel_ms, bytes_alg = g.profile_read()
-    g.profile_enable(False)
-    tuning = g.get_tuning()
-    elapsed = t1 - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        return float(t.item())
 
-    # outside the timed region: the same step through the matrix-core path (fir_gemm_*), which must return the same keys
-    mfma = None
-    if world == 1 and not args.no_mfma:
-        gm = fir.GemmSearch(g)
-        k2 = torch.empty_like(keys)
-        with torch.cuda.stream(work_stream):
-            gm.search_top1_keys_dev(q.data_ptr(), qb, k2.data_ptr(), stream=stream)
-            torch.cuda.synchronize()
-            tg0 = time.perf_counter()
-            for _ in range(5):
-                gm.search_top1_keys_dev(q.data_ptr(), qb, k2.data_ptr(), stream=stream)
-            torch.cuda.synchronize()
-            tg = (time.perf_counter() - tg0) / 5
-        mfma = {"kernel": "fp16 MFMA (one term, power-of-two-scaled operands, 128 queries per gallery read) nominates rows, reference arithmetic re-ranks every row inside the rounding window, certificate + exact-scan fallback",
-                "queries_per_s": qb / tg, "ms_per_step": tg * 1e3, "tflops_dot_products": 2.0 * n * d * qb / tg / 1e12,
-                "gallery_GBps": (row_hi - row_lo) * d * 2.0 * (-(-qb // 128)) / tg / 1e9,     # fp16 fragments: 2 B per feature, once per 128 queries
-                "identical_keys_to_scan": bool(torch.equal(keys, k2)), "fallback_queries": gm.stats()["fallback_queries"]}
-        gm.close()
+    def build(n):
+        """This rank's row block of the n-row synthetic gallery, generated on the device -> (Matcher, row_lo, row_hi, host copy or None)."""
+        row_lo, row_hi = sharding.shard_bounds(n, world, rank, granule=CHUNK_ROWS)
+        shard = torch.empty((row_hi - row_lo, d), device=dev, dtype=torch.float32)
+        for c in range(row_lo // CHUNK_ROWS, (row_hi + CHUNK_ROWS - 1) // CHUNK_ROWS):
+            r0 = c * CHUNK_ROWS
+            rows = min(CHUNK_ROWS, n - r0)
+            shard[r0 - row_lo: r0 - row_lo + rows] = gen_chunk(c, rows, d, dev)
+        torch.cuda.synchronize()
+        m = Matcher(fir, args, shard, row_hi - row_lo, d, row_lo, world, rank, local_rank, dist if world > 1 else None, dev, work_stream)
+        return m, row_lo, row_hi, shard
 
-    # also outside the timed region (N = 1): the other scans of the same gallery, for the record
-    also = None
-    if world == 1 and not args.no_mfma:
-        def rate(fn, nq, reps):
-            fn()
-            torch.cuda.synchronize()
-            t_0 = time.perf_counter()
-            for _ in range(reps):
-                fn()
-            torch.cuda.synchronize()
-            return nq * reps / (time.perf_counter() - t_0)
+    def make_queries(qb, n):
+        """even = fresh draws, odd = perturbed copies of known gallery rows of chunk 0"""
+        c0 = gen_chunk(0, min(CHUNK_ROWS, n), d, dev)
+        gq = torch.Generator(device=dev)
+        gq.manual_seed(424243)
+        fresh = torch.rand((qb, d), generator=gq, device=dev)
+        planted_rows = (torch.arange(qb, device=dev) * 977 + 11) % c0.shape[0]
+        noise = (torch.rand((qb, d), generator=gq, device=dev) - 0.5) * 0.05 * c0.mean()
+        pert = (c0[planted_rows] + noise).clamp_min(0)
+        q = torch.where((torch.arange(qb, device=dev) % 2 == 0)[:, None], fresh, pert)
+        return (q / q.norm(dim=1, keepdim=True)).contiguous(), planted_rows.cpu().numpy()
 
-        with torch.cuda.stream(work_stream):
-            k5 = torch.empty((qb, 5), device=dev, dtype=torch.int64)
-            also = {"l2_top5_queries_per_s": rate(lambda: g.search_topk_keys_dev(q.data_ptr(), qb, 5, k5.data_ptr(), stream=stream), qb, 2)}
-            top5_first_is_top1 = bool(torch.equal(k5[:, 0], keys))
-            # the same step with 16 queries per gallery pass: more queries/s, but the kernel is then bound by the f32 vector
-            # pipes (3 un-fused ops per feature and query), not by HBM -- the timed step keeps the library's choice (8)
-            k16 = torch.empty_like(keys)
-            g.set_tuning(16, 0)
-            r16 = rate(lambda: g.search_top1_keys_dev(q.data_ptr(), qb, k16.data_ptr(), stream=stream), qb, 3)
-            g.set_tuning(-1, 0)
-            also["l2_top1_16_queries_per_pass"] = {"queries_per_s": r16, "gallery_GBps": (row_hi - row_lo) * d * 4.0 * (qb / 16) * (r16 / qb) / 1e9,
-                                                   "identical_keys": bool(torch.equal(k16, keys))}
-            # chi-square / KL compare non-negative feature vectors that went through the loader's |x| < 1e-4 -> 0 rule
-            # (db_features.cpp:85-86) like the gallery rows did; the L2 step's planted queries carry signed noise
-            q32 = q[:32].clamp_min(0.0)
-            q32 = torch.where(q32 < 1e-4 / 13.0, torch.zeros_like(q32), q32).contiguous()
-            k32 = torch.empty(32, device=dev, dtype=torch.int64)
-            for name, metric in (("chi2", fir.METRIC_CHI2), ("kl", fir.METRIC_KL)):
-                g.set_metric(metric)
-                also[f"{name}_top1_queries_per_s"] = rate(lambda: g.search_top1_keys_dev(q32.data_ptr(), 32, k32.data_ptr(), stream=stream), 32, 2)
-            g.set_metric(fir.METRIC_L2)
-            also["l2_top5_first_column_is_top1"] = top5_first_is_top1
+    def timed_loop(m, q, qb, keys, steps, warmup):
+        """W untimed + K timed steps, barrier + synchronize on both sides, MAX over ranks; the launches of the dominant
+        kernel are bracketed by HIP events inside the library."""
+        for _ in range(warmup):
+            m.step(q, qb, keys)
+        fence()
+        for p in m.parts:
+            p.profile_enable(True)
+        if m.sh is not None:
+            m.sh.profile_enable(True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            m.step(q, qb, keys)
+        fence()
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+        kernel_ms = np.concatenate([p.profile_read()[0] for p in m.parts]) if m.parts else np.zeros(0)
+        exch_ms = m.sh.profile_read() if m.sh is not None else np.zeros(0)
+        for p in m.parts:
+            p.profile_enable(False)
+        if m.sh is not None:
+            m.sh.profile_enable(False)
+        disp = m.g.last_dispatch()
+        return elapsed, kernel_ms, exch_ms, disp
 
-    idx, dd = fir.keys_unpack(keys.cpu().numpy().view(np.uint64))
-    # size-independent property at full size: every planted query finds its source row, closer than any fresh one does
-    planted = planted_rows.cpu().numpy()
+    n, qb = args.rows, args.batch
+    m, row_lo, row_hi, shard = build(n)
+    host_shard = shard.cpu().numpy() if (world == 1 and args.cpu_seconds > 0 and not args.pmc_child) else None
+    small_src = shard[:100_000].clone() if (world == 1 and not args.no_extras and n >= 100_000) else None
+    del shard
+    torch.cuda.empty_cache()
+    q, planted = make_queries(qb, n)
+    keys = torch.empty(qb, device=dev, dtype=torch.int64)      # packed u64 keys (viewed int64 for torch)
+
+    # ---- headline: the library's default dispatch ----
+    elapsed, k_ms, x_ms, disp = timed_loop(m, q, qb, keys, args.steps, args.warmup)
+    keys_default = keys.clone()
+    head = {"elapsed": elapsed, "kernel_ms": k_ms, "exch_ms": x_ms, "disp": disp}
+
+    # ---- the exact streaming scan, matrix-core path off: the metric's HBM clause ----
+    sqb = min(args.scan_batch, qb)
+    m.set_mfma(0)
+    if args.qpp or args.waves:
+        m.set_tuning(args.qpp, args.waves)
+    skeys = torch.empty(sqb, device=dev, dtype=torch.int64)
+    s_elapsed, s_ms, s_x_ms, s_disp = timed_loop(m, q, sqb, skeys, args.steps, args.warmup)
+    tuning = m.g.get_tuning()
+    identical = bool(torch.equal(skeys, keys_default[:sqb]))
+    # every query of the headline batch through the exact scan once (outside the timed regions): the keys must be identical
+    if not args.pmc_child and qb > sqb:
+        ek = torch.empty(qb, device=dev, dtype=torch.int64)
+        m.step(q, qb, ek)
+        torch.cuda.synchronize()
+        identical = identical and bool(torch.equal(ek, keys_default))
+        del ek
+    m.set_mfma(-1)
+    if args.qpp or args.waves:
+        m.set_tuning(-1, 0)
+
+    idx, dd = fir.keys_unpack(keys_default.cpu().numpy().view(np.uint64))
     odd = np.arange(qb) % 2 == 1
-    planted_ok = bool(np.all(idx[odd] == planted[odd])) if n >= CHUNK_ROWS else None
+    planted_ok = bool(np.all(idx[odd] == planted[odd])) if n >= CHUNK_ROWS else None   # every planted query finds its source row
+
+    also = None
+    cfg2 = None
+    k3 = None
+    if world == 1 and not args.no_extras and not args.pmc_child:
+        also = other_scans(fir, m.g, q, keys_default, dev, work_stream, n, d)
+        k3 = k3_classifiers(fir, dev, args)
+        if small_src is not None:
+            cfg2 = config2(fir, small_src, q, dev, work_stream, d)
+    del small_src
+    m_n = row_hi - row_lo
+
+    cpu = None
+    if host_shard is not None:
+        cpu = cpu_baselines(host_shard, q.cpu().numpy(), idx, dd, args.cpu_seconds)
+        del host_shard
+    m.close()
+    torch.cuda.empty_cache()
+
+    # ---- BASELINE config 4: 10M x 512 split over the ranks ----
+    cfg4 = None
+    if args.config4_rows > 0 and not args.no_extras and not args.pmc_child:
+        cfg4 = config4(args, build, make_queries, timed_loop, fir, dev, world)
 
     out = None
     if rank == 0:
-        launches_per_step = len(kernel_ms) / max(args.steps, 1)
-        avg_ms = float(np.mean(kernel_ms)) if len(kernel_ms) else float("nan")
-        achieved = bytes_alg / (avg_ms * 1e-3) / 1e9 if len(kernel_ms) else float("nan")
         peak_gbs = fir.device_peak_hbm_gbs(local_rank)            # 8000: MI355X_MICROARCH.md
-        traffic, traffic_how = pmc_traffic(args, n, d, world)
+        traffic = pmc_traffic(args, n, d, world)
+
+        def kernel_block(ms, dsp):
+            avg = float(np.mean(ms)) if len(ms) else float("nan")
+            return avg, {"kernel": dsp["kernel"], "kernel_avg_ms": avg, "launches_timed": int(len(ms)), "grid": dsp["grid"], "block": dsp["block"],
+                         "lds_bytes_per_workgroup": dsp["lds_bytes"], "vgprs": dsp["vgprs"], "queries_per_gallery_read": dsp["queries_per_pass"],
+                         "bytes_per_launch": dsp["bytes_per_launch"]}
+
+        s_avg, s_blk = kernel_block(s_ms, s_disp)
+        s_ach = s_disp["bytes_per_launch"] / (s_avg * 1e-3) / 1e9 if len(s_ms) else float("nan")
+        roofline = {"bound": "hbm", "achieved": s_ach, "peak": peak_gbs, "unit": "GB/s", "frac": s_ach / peak_gbs,
+                    "traffic": traffic.get("scan"), "traffic_source": traffic.get("how"),
+                    "measured_in": f"exact-scan loop of this run: {args.steps} steps of {sqb} queries, matrix-core path off, {s_elapsed / args.steps * 1e3:.3f} ms per step, "
+                                   f"{sqb * args.steps / s_elapsed:.0f} queries/s",
+                    "queries_per_s": sqb * args.steps / s_elapsed, **s_blk}
+        h_avg, h_blk = kernel_block(head["kernel_ms"], head["disp"])
+        hd = head["disp"]
+        roofline_mfma = None
+        if hd["path"] == "mfma" and len(head["kernel_ms"]):
+            tf = hd["flops_per_launch"] / (h_avg * 1e-3) / 1e12
+            gbs = hd["bytes_per_launch"] / (h_avg * 1e-3) / 1e9
+            roofline_mfma = {"bound": "hbm (fp16 gallery stream, read once per 128 queries); the MFMA pipe is the second roof",
+                             "flops_per_launch": hd["flops_per_launch"], "achieved_tflops": tf, "peak_tflops": PEAK_MFMA_F16_TFLOPS, "frac_of_mfma_peak": tf / PEAK_MFMA_F16_TFLOPS,
+                             "stream_GBps": gbs, "peak_GBps": peak_gbs, "frac_of_hbm_peak": gbs / peak_gbs, "traffic": traffic.get("mfma"),
+                             "kernel_time_share_of_step": float(np.sum(head["kernel_ms"])) / (head["elapsed"] * 1e3) if world == 1 else None, **h_blk}
         out = {
             "metric": "query-vectors/sec brute-force L2 top-1, 1Mx512 gallery",
-            "value": qb * args.steps / elapsed,
+            "value": qb * args.steps / head["elapsed"],
             "unit": "queries/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": head["elapsed"] / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{n}x{d} f32 gallery, batched L2 top-1 (configs[1] kernel at the metric's 1Mx512 size)",
+                "workload": f"{n}x{d} f32 gallery, batched L2 top-1 through the library's default dispatch (the metric's 1Mx512 size; configs[1]'s kernel is the exact-scan loop under `roofline`)",
                 "query_batch": qb,
-                "queries_per_pass": tuning["queries_per_pass"],
-                "gallery_passes_per_step": -(-qb // max(tuning["queries_per_pass"], 1)),
-                "scan_launches_per_step": launches_per_step,
-                "waves": tuning["waves"],
-                "row_sharding": f"{world} shard(s) of {row_hi - row_lo} rows",
+                "path": hd["path"],
+                "path_note": "fp16 MFMA (one term, power-of-two-scaled operands, 128 queries per gallery read) nominates rows, the reference's f32 arithmetic re-ranks every row "
+                             "inside the rounding window, a rounding-error certificate proves the rest cannot win, uncertified queries go through the exact scan" if hd["path"] == "mfma" else "exact streaming scan",
+                "identical_keys_to_exact_scan": identical,
                 "planted_queries_found": planted_ok,
-                "same_step_through_mfma_path": mfma,
+                "row_sharding": f"{world} rank(s) x {args.shards_per_device} shard(s), {m_n} rows on this rank",
+                "key_exchange": ("RCCL ncclAllReduce(ncclMin, ncclUint64) issued by libfir_amd.so (fir_sharded_search_top1_keys_dev)" if m.in_library_rccl
+                                 else "torch.distributed gloo through host memory (rehearsal)") if (world > 1 or m.in_library_rccl) else None,
+                "exchange_us_per_step": float(np.mean(head["exch_ms"]) * 1e3) if len(head["exch_ms"]) else None,
+                "exact_scan": {"queries_per_pass": tuning["queries_per_pass"], "waves": tuning["waves"], "query_batch": sqb,
+                               "gallery_passes_per_step": -(-sqb // max(tuning["queries_per_pass"], 1)), "launches_per_step": len(s_ms) / max(args.steps, 1) / max(len(m.parts), 1),
+                               "exchange_us_per_step": float(np.mean(s_x_ms) * 1e3) if len(s_x_ms) else None},
+                "kl_note": "KL top-1 identity is tolerance-graded (device v_log_f32 vs glibc logf: distances within 1e-5 relative, same winner unless the runner-up is closer than that); L2 and chi-square are bit-exact",
                 "other_scans_same_gallery": also,
+                "config2_100kx512": cfg2,
+                "k3_float64_classifiers": k3,
             },
-            "roofline": {
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": peak_gbs,
-                "unit": "GB/s",
-                "frac": achieved / peak_gbs,
-                "traffic": traffic,
-                "traffic_source": traffic_how,
-                "kernel": "fir::k_scan_l2_lds<1,8,4>" if tuning["queries_per_pass"] == 8 else "fir::k_scan*",
-                "kernel_avg_ms": avg_ms,
-                "bytes_per_launch": bytes_alg,
-            },
+            "roofline": roofline,
+            "roofline_mfma": roofline_mfma,
+            "config4": cfg4,
         }
-        if host_shard is not None:
-            out["cpu_baseline"] = cpu_baseline(host_shard, q.cpu().numpy(), idx, dd, args.cpu_seconds)
-    g.close()
+        if also:
+            out["roofline_chi2"] = also.pop("roofline_chi2", None)
+            out["roofline_kl"] = also.pop("roofline_kl", None)
+        if cpu is not None:
+            out["cpu_baseline"] = cpu["reference"]
+            out["cpu_all"] = cpu["all"]
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -299,17 +462,146 @@ def main():
         emit_line(json.dumps(out))
 
 
+def rate(fn, nq, reps):
+    fn()
+    torch.cuda.synchronize()
+    t_0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return nq * reps / (time.perf_counter() - t_0)
+
+
+# VALU issue slots (wave64 instructions) per (row, feature, query) element of the plain-range chi-square / KL scans, counted
+# in the compiled loops (chi-square 12.6 of which the quarter-rate v_rcp_f32 is 4; KL 34 of which v_rcp + 2 v_log are 12)
+CHI2_SLOTS, KL_SLOTS = 12.6, 34.0
+
+
+def other_scans(fir, g, q, keys, dev, ws, n, d):
+    """Outside the timed regions (N = 1): the other scans of the same gallery -- BASELINE config 3's chi-square / KL / top-5."""
+    stream = ws.cuda_stream
+    qb = min(q.shape[0], 256)
+    with torch.cuda.stream(ws):
+        k5 = torch.empty((qb, 5), device=dev, dtype=torch.int64)
+        also = {"l2_top5_queries_per_s": rate(lambda: g.search_topk_keys_dev(q.data_ptr(), qb, 5, k5.data_ptr(), stream=stream), qb, 2)}
+        also["l2_top5_first_column_is_top1"] = bool(torch.equal(k5[:, 0], keys[:qb]))
+        # the exact scan with 16 queries per gallery pass: more queries/s, but bound by the f32 vector pipes (3 un-fused ops per
+        # feature and query), not by HBM
+        k16 = torch.empty(qb, device=dev, dtype=torch.int64)
+        g.set_large_batch_mfma(0)
+        g.set_tuning(16, 0)
+        r16 = rate(lambda: g.search_top1_keys_dev(q.data_ptr(), qb, k16.data_ptr(), stream=stream), qb, 3)
+        g.set_tuning(-1, 0)
+        g.set_large_batch_mfma(-1)
+        also["l2_top1_exact_scan_16_queries_per_pass"] = {"queries_per_s": r16, "gallery_GBps": n * d * 4.0 * (r16 / 16) / 1e9,
+                                                          "identical_keys": bool(torch.equal(k16, keys[:qb]))}
+        # chi-square / KL compare non-negative feature vectors that went through the loader's |x| < 1e-4 -> 0 rule
+        # (db_features.cpp:85-86) like the gallery rows did; the L2 step's planted queries carry signed noise
+        q32 = q[:32].clamp_min(0.0)
+        q32 = torch.where(q32 < 1e-4 / 13.0, torch.zeros_like(q32), q32).contiguous()
+        k32 = torch.empty(32, device=dev, dtype=torch.int64)
+        k32_5 = torch.empty((32, 5), device=dev, dtype=torch.int64)
+        for name, metric, slots in (("chi2", fir.METRIC_CHI2, CHI2_SLOTS), ("kl", fir.METRIC_KL, KL_SLOTS)):
+            g.set_metric(metric)
+            g.profile_enable(True)
+            r1 = rate(lambda: g.search_top1_keys_dev(q32.data_ptr(), 32, k32.data_ptr(), stream=stream), 32, 2)
+            ms, _ = g.profile_read()
+            g.profile_enable(False)
+            dsp = g.last_dispatch()
+            plain = g.value_range()
+            r5 = rate(lambda: g.search_topk_keys_dev(q32.data_ptr(), 32, 5, k32_5.data_ptr(), stream=stream), 32, 2)
+            also[f"{name}_top1_queries_per_s"] = r1
+            also[f"{name}_top5_queries_per_s"] = r5
+            also[f"{name}_top5_first_column_is_top1"] = bool(torch.equal(k32_5[:, 0], k32))
+            # each pass is launched as a (full, plain-range) pair of which one returns at once: per-pass time = sum over the pair
+            per_pass_ms = float(np.mean(ms)) if len(ms) else float("nan")
+            qpp = dsp["queries_per_pass"]
+            elems_per_pass = float(n) * d * qpp
+            wave_instr_per_s = elems_per_pass / 64.0 * slots / (per_pass_ms * 1e-3) if per_pass_ms == per_pass_ms else float("nan")
+            also[f"roofline_{name}"] = {"bound": "valu", "model": f"{slots} VALU issue slots per (row, feature, query) element in the plain-range form (DESIGN.md section 4), "
+                                                                    "peak = 256 CUs x 4 SIMDs x one wave64 instruction per 4 cycles at 2.4 GHz",
+                                       "achieved": wave_instr_per_s / 1e9, "peak": PEAK_VALU_WAVE_INSTR_PER_S / 1e9, "unit": "G wave-instructions/s",
+                                       "frac": wave_instr_per_s / PEAK_VALU_WAVE_INSTR_PER_S, "kernel": dsp["kernel"] + " (launched next to its plain-range twin; the one that applies runs)",
+                                       "plain_range_form_ran": bool(plain[0] and plain[1]), "kernel_ms_per_pass": per_pass_ms, "queries_per_pass": qpp,
+                                       "gallery_GBps": n * d * 4.0 / (per_pass_ms * 1e-3) / 1e9, "frac_of_hbm_peak": n * d * 4.0 / (per_pass_ms * 1e-3) / 1e9 / 8000.0,
+                                       "vgprs": dsp["vgprs"], "lds_bytes_per_workgroup": dsp["lds_bytes"], "queries_per_s": r1}
+        g.set_metric(fir.METRIC_L2)
+    return also
+
+
+def config2(fir, src, q, dev, ws, d):
+    """BASELINE config 2: 100k x 512, batched L2 top-1 with the library's automatic tuning (cache-resident gallery)."""
+    stream = ws.cuda_stream
+    out = {}
+    with torch.cuda.stream(ws):
+        g = fir.Gallery(dev_ptr=src.data_ptr(), n=src.shape[0], d=d, metric=fir.METRIC_L2, device=dev.index, stream=stream)
+        for qb in (256, min(q.shape[0], 4096)):
+            k = torch.empty(qb, device=dev, dtype=torch.int64)
+            g.set_large_batch_mfma(0)
+            r_scan = rate(lambda: g.search_top1_keys_dev(q.data_ptr(), qb, k.data_ptr(), stream=stream), qb, 5)
+            dsp = g.last_dispatch()
+            ks = k.clone()
+            g.set_large_batch_mfma(-1)
+            r_def = rate(lambda: g.search_top1_keys_dev(q.data_ptr(), qb, k.data_ptr(), stream=stream), qb, 5)
+            dd = g.last_dispatch()
+            out[f"batch_{qb}"] = {"exact_scan_queries_per_s": r_scan, "exact_scan_kernel": dsp["kernel"], "exact_scan_queries_per_pass": dsp["queries_per_pass"],
+                                  "default_dispatch_queries_per_s": r_def, "default_dispatch_path": dd["path"], "default_dispatch_kernel": dd["kernel"],
+                                  "identical_keys": bool(torch.equal(ks, k))}
+        g.close()
+    return out
+
+
+def k3_classifiers(fir, dev, args):
+    """K3 (BASELINE.md section 3 row "GPU-1 chi2/KL/PNN, 1M x 512"): the float64 PNN / kNN classifiers
+    (classification.cpp:116-226) over a 1M x 512 training set resident in HBM (4 GB of doubles)."""
+    if not hasattr(fir, "k3_bench"):
+        return None
+    return fir.k3_bench(dev, args)
+
+
+def config4(args, build, make_queries, timed_loop, fir, dev, world):
+    n4 = args.config4_rows
+    steps = max(3, args.steps // 4)
+    m, lo, hi, shard = build(n4)
+    del shard
+    torch.cuda.empty_cache()
+    qb = args.batch
+    q, planted = make_queries(qb, n4)
+    keys = torch.empty(qb, device=dev, dtype=torch.int64)
+    el, k_ms, x_ms, disp = timed_loop(m, q, qb, keys, steps, 1)
+    kd = keys.clone()
+    sqb = min(args.scan_batch, qb)
+    m.set_mfma(0)
+    sk = torch.empty(sqb, device=dev, dtype=torch.int64)
+    sel, s_ms, sx_ms, sdisp = timed_loop(m, q, sqb, sk, steps, 1)
+    m.set_mfma(-1)
+    idx, _ = fir.keys_unpack(kd.cpu().numpy().view(np.uint64))
+    odd = np.arange(qb) % 2 == 1
+    out = {"workload": f"{n4}x{args.dim} f32 gallery row-sharded over {world} rank(s): {hi - lo} rows on rank 0 (BASELINE configs[3])", "steps": steps,
+           "query_batch": qb, "queries_per_s": qb * steps / el, "ms_per_step": el / steps * 1e3, "path": disp["path"], "kernel": disp["kernel"],
+           "kernel_avg_ms": float(np.mean(k_ms)) if len(k_ms) else None,
+           "stream_GBps_per_gpu": disp["bytes_per_launch"] / (float(np.mean(k_ms)) * 1e-3) / 1e9 if len(k_ms) else None,
+           "exchange_us_per_step": float(np.mean(x_ms) * 1e3) if len(x_ms) else None,
+           "exact_scan": {"query_batch": sqb, "queries_per_s": sqb * steps / sel, "ms_per_step": sel / steps * 1e3, "kernel": sdisp["kernel"],
+                          "kernel_avg_ms": float(np.mean(s_ms)) if len(s_ms) else None,
+                          "achieved_GBps_per_gpu": sdisp["bytes_per_launch"] / (float(np.mean(s_ms)) * 1e-3) / 1e9 if len(s_ms) else None,
+                          "exchange_us_per_step": float(np.mean(sx_ms) * 1e3) if len(sx_ms) else None},
+           "identical_keys_to_exact_scan": bool(torch.equal(sk, kd[:sqb])), "planted_queries_found": bool(np.all(idx[odd] == planted[odd]))}
+    m.close()
+    torch.cuda.empty_cache()
+    return out
+
+
 def pmc_traffic(args, n, d, world):
-    """HBM bytes per scan launch from the PMC counters: FETCH_SIZE (rocprofv3 unit: KiB) x 1024 x 2, as
-    MI355X_MICROARCH.md prescribes for 16 B/lane streams on gfx950, averaged over the scan launches. Counters cannot be
+    """HBM bytes per launch of the two dominant kernels from the PMC counters: FETCH_SIZE (rocprofv3 unit: KiB) x 1024 x 2, as
+    MI355X_MICROARCH.md prescribes for 16 B/lane streams on gfx950, averaged over the launches. Counters cannot be
     collected from inside the timed run, so after it this process starts `rocprofv3 --pmc FETCH_SIZE -- python3 bench.py
-    --pmc-child ...` (its own pass with only that counter, a few steps of the same workload) as a child process and
-    reads its CSV. Without rocprofv3 (or if the pass fails) the pass recorded under profiles/ is reported for the shape
-    it was taken on. Returns (bytes, how)."""
+    --pmc-child ...` (its own pass with only that counter, a few steps of the same two loops) as a child process and
+    reads its CSV. Without rocprofv3 (or if the pass fails) the scan pass recorded under profiles/ is reported for the shape
+    it was taken on. Returns {"scan": bytes, "mfma": bytes, "how": str}."""
     import csv
     import glob
     import shutil
-    import subprocess
     import tempfile
 
     under_profiler = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", "")
@@ -317,45 +609,53 @@ def pmc_traffic(args, n, d, world):
         out_dir = tempfile.mkdtemp(prefix="fir_pmc_")
         cmd = ["rocprofv3", "--pmc", "FETCH_SIZE", "--output-format", "csv", "-d", out_dir, "-o", "pmc", "--",
                sys.executable, os.path.abspath(__file__), "--pmc-child", "--steps", "3", "--warmup", "1", "--rows", str(n), "--dim", str(d),
-               "--batch", str(args.batch), "--cpu-seconds", "0", "--no-mfma"]
+               "--batch", str(args.batch), "--scan-batch", str(args.scan_batch), "--cpu-seconds", "0", "--no-extras"]
         if args.qpp:
             cmd += ["--qpp", str(args.qpp)]
         try:
             subprocess.run(cmd, cwd=out_dir, env=dict(os.environ, TMPDIR=out_dir), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
-                           timeout=150, check=True)
-            vals = []
+                           timeout=200, check=True)
+            vals = {"scan": [], "mfma": []}
             for f in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(f)):
-                    if r["Counter_Name"] == "FETCH_SIZE" and "k_scan_l2" in r["Kernel_Name"]:
-                        vals.append(float(r["Counter_Value"]))
-            if vals:
-                return sum(vals) / len(vals) * 1024 * 2, f"rocprofv3 --pmc FETCH_SIZE child pass of this run, {len(vals)} scan launches"
+                    if r["Counter_Name"] != "FETCH_SIZE":
+                        continue
+                    if "k_scan_l2" in r["Kernel_Name"]:
+                        vals["scan"].append(float(r["Counter_Value"]))
+                    elif "k_gemm_proxy_f16<1" in r["Kernel_Name"]:
+                        vals["mfma"].append(float(r["Counter_Value"]))
+            if vals["scan"] or vals["mfma"]:
+                res = {k: (sum(v) / len(v) * 1024 * 2 if v else None) for k, v in vals.items()}
+                res["how"] = f"rocprofv3 --pmc FETCH_SIZE child pass of this run ({len(vals['scan'])} scan, {len(vals['mfma'])} matrix-core launches), KiB x 1024 x 2"
+                return res
         except Exception:
             pass
         finally:
             shutil.rmtree(out_dir, ignore_errors=True)
     path = os.path.join(ROOT, "profiles", "r01_rocprofv3_pmc_fetch_size.json")
-    if os.path.exists(path) and (n, d, world) == (1_000_000, 512, 1):
+    if os.path.exists(path) and (n, d, world, args.scan_batch) == (1_000_000, 512, 1, 256):
         for e in json.load(open(path)):
             if "k_scan_l2" in e["kernel"] and e["counter"] == "FETCH_SIZE":
-                return e["bytes_per_launch_corrected"], "recorded pass profiles/r01_rocprofv3_pmc_fetch_size.json"
-    return None, None
+                return {"scan": e["bytes_per_launch_corrected"], "mfma": None, "how": "recorded pass profiles/r01_rocprofv3_pmc_fetch_size.json"}
+    return {}
 
 
-def cpu_baseline(rows, queries, gpu_idx, gpu_dist, budget_s):
-    """The reference's recognize_image_bf (qt_cpp/db_features.cpp:319-335) on the host cores:
-    one query per thread at a time (the reference itself is single threaded; queries are
-    independent). Falls back to the C restatement when oracle/_ref is not present."""
+def cpu_baselines(rows, queries, gpu_idx, gpu_dist, budget_s):
+    """Both CPU rows of BASELINE.md section 3 on ALL host cores of this box (count and model stated):
+    `reference`: the reference's own recognize_image_bf (qt_cpp/db_features.cpp:319-335, oracle/_ref), one query per thread at a
+    time -- the reference itself is single threaded, queries are independent (falls back to the C restatement when
+    oracle/_ref is not present);  `all`: the C restatement with OpenMP over queries (bit-identical arithmetic)."""
     import oracle_lib
 
-    cores = max(1, min(len(os.sched_getaffinity(0)), 16))
+    cores = max(1, len(os.sched_getaffinity(0)))
+    model = cpu_model()
     d = rows.shape[1]
     kind = "reference" if oracle_lib.have_ref() else "port"
+    orc = oracle_lib.load_oracle()
     if kind == "reference":
         db = oracle_lib.load_ref("l2").db(rows, None, 0)
         fn = lambda qv: db.recognize_image_bf(qv, d)  # noqa: E731
     else:
-        orc = oracle_lib.load_oracle()
         fn = lambda qv: orc.recognize_bf(rows, qv, 0, d, 0)[0]  # noqa: E731
     # calibrate with one query, then run whole rounds of `cores` queries inside the budget
     t0 = time.perf_counter()
@@ -378,14 +678,19 @@ def cpu_baseline(rows, queries, gpu_idx, gpu_dist, budget_s):
         x.join()
     dt = time.perf_counter() - t0
     agree = int(sum(int(res[i]) == int(gpu_idx[i]) for i in range(nq)))
-    return {
-        "value": nq / dt,
-        "unit": "queries/s",
-        "cores": cores,
-        "kind": kind,
-        "sample": f"{nq} of the step's {queries.shape[0]} queries against the full {rows.shape[0]}x{d} gallery, "
-                  f"{cores} threads x recognize_image_bf ({t_one:.2f} s/query/thread); GPU index identical on {agree}/{nq}",
-    }
+    ref = {"value": nq / dt, "unit": "queries/s", "cores": cores, "cpu_model": model, "kind": kind,
+           "sample": f"{nq} of the step's {queries.shape[0]} queries against the full {rows.shape[0]}x{d} gallery, "
+                     f"{cores} threads x recognize_image_bf ({t_one:.2f} s/query/thread); GPU index identical on {agree}/{nq}"}
+    # CPU-all: OpenMP over queries, same sample size
+    t0 = time.perf_counter()
+    oi, od, threads = orc.top1_batch_omp(rows, queries[:nq], 0, d, 0)
+    dt2 = time.perf_counter() - t0
+    same = int(np.sum((oi == gpu_idx[:nq]) & (od.view(np.uint32) == np.ascontiguousarray(gpu_dist[:nq], np.float32).view(np.uint32))))
+    allc = {"value": nq / dt2, "unit": "queries/s", "cores": threads, "cpu_model": model, "kind": "port",
+            "effective_GBps": nq / dt2 * rows.shape[0] * d * 4.0 / 1e9,
+            "sample": f"the same {nq} queries, oracle/oracle.c restatement with OpenMP over queries ({threads} threads); "
+                      f"GPU index AND distance bits identical on {same}/{nq}"}
+    return {"reference": ref, "all": allc}
 
 
 if __name__ == "__main__":

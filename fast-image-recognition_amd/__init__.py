@@ -17,6 +17,8 @@ from .capi import (  # noqa: F401
     METRIC_CHI2,
     METRIC_KL,
     METRIC_L2,
+    ShardedGallery,
+    comm_unique_id,
     device_count,
     device_info,
     device_peak_hbm_gbs,

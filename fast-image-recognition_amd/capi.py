@@ -78,8 +78,23 @@ SYMBOLS = [
     ("fir_fpnn_get_model", C.c_int, [_vp, _vp]),
     ("fir_fpnn_predict", C.c_int, [_vp, _vp, C.c_int32, _vp, _vp]),
     ("fir_fpnn_predict_seq", C.c_int, [_vp, _vp, C.c_int32, C.c_float, _vp, _vp]),
+    ("fir_comm_unique_id", C.c_int, [_vp]),
+    ("fir_gallery_create_sharded", C.c_int, [_vp, C.c_int64, C.c_int32, _vp, C.c_int32, _vp, C.c_int32, C.POINTER(_vp)]),
+    ("fir_gallery_create_sharded_ex", C.c_int, [_vp, C.c_int64, C.c_int32, _vp, C.c_int32, _vp, C.c_int32, _vp, C.POINTER(_vp)]),
+    ("fir_sharded_destroy", C.c_int, [_vp]),
+    ("fir_sharded_info", C.c_int, [_vp, _i64p, _i32p, _i32p, _i32p, _i32p, _i32p]),
+    ("fir_sharded_shard", C.c_int, [_vp, C.c_int32, C.POINTER(_vp), _i64p, _i64p]),
+    ("fir_sharded_set_metric", C.c_int, [_vp, C.c_int32]),
+    ("fir_sharded_search_top1", C.c_int, [_vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp]),
+    ("fir_sharded_search_topk", C.c_int, [_vp, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp, _vp]),
+    ("fir_sharded_classify_top1", C.c_int, [_vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp]),
+    ("fir_sharded_search_top1_keys_dev", C.c_int, [_vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp]),
+    ("fir_sharded_sync", C.c_int, [_vp]),
+    ("fir_sharded_profile_enable", C.c_int, [_vp, C.c_int32]),
+    ("fir_sharded_profile_read", C.c_int, [_vp, _vp, C.c_int32, _i32p]),
     ("fir_profile_enable", C.c_int, [_vp, C.c_int32]),
     ("fir_profile_read", C.c_int, [_vp, _vp, C.c_int32, _i32p, C.POINTER(C.c_double)]),
+    ("fir_gallery_last_dispatch", C.c_int, [_vp, _vp]),
     ("fir_gallery_sync", C.c_int, [_vp]),
     ("fir_gallery_set_tuning", C.c_int, [_vp, C.c_int32, C.c_int32]),
     ("fir_gallery_value_range", C.c_int, [_vp, _i32p, _i32p]),
@@ -153,6 +168,12 @@ def keys_unpack(keys):
     dist = np.empty(keys.shape, np.float32)
     _check(lib().fir_keys_unpack(keys.ctypes.data_as(_vp), keys.size, idx.ctypes.data_as(_vp), dist.ctypes.data_as(_vp)))
     return idx, dist
+
+
+class DispatchInfo(C.Structure):
+    _fields_ = [("struct_bytes", C.c_int32), ("path", C.c_int32), ("kernel", C.c_char * 160), ("launches", C.c_int32), ("grid_x", C.c_int32),
+                ("grid_y", C.c_int32), ("block", C.c_int32), ("lds_bytes", C.c_int32), ("vgprs", C.c_int32), ("queries_per_pass", C.c_int32),
+                ("bytes_per_launch", C.c_double), ("flops_per_launch", C.c_double)]
 
 
 class Gallery:
@@ -308,6 +329,147 @@ class Gallery:
 
     def sync(self):
         _check(lib().fir_gallery_sync(self._h))
+
+    def last_dispatch(self):
+        """The dominant kernel of the most recent top-1 search as the library launched it (fir_gallery_last_dispatch)."""
+        o = DispatchInfo()
+        o.struct_bytes = C.sizeof(DispatchInfo)
+        _check(lib().fir_gallery_last_dispatch(self._h, C.byref(o)))
+        return {"path": "mfma" if o.path == 1 else "scan", "kernel": o.kernel.decode(), "launches": o.launches, "grid": [o.grid_x, o.grid_y],
+                "block": o.block, "lds_bytes": o.lds_bytes, "vgprs": o.vgprs, "queries_per_pass": o.queries_per_pass,
+                "bytes_per_launch": o.bytes_per_launch, "flops_per_launch": o.flops_per_launch}
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """RCCL unique id (bytes) made by process 0 of a multi-process sharded gallery; hand it to the other processes."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    _check(lib().fir_comm_unique_id(buf))
+    return buf.raw
+
+
+class ShardOpts(C.Structure):
+    _fields_ = [("struct_bytes", C.c_int32), ("shards_per_device", C.c_int32), ("first_global_row", C.c_int64), ("comm_id", _vp),
+                ("proc_rank", C.c_int32), ("nprocs", C.c_int32), ("rows_on_device", C.c_int32), ("reserved", C.c_int32)]
+
+
+class _BorrowedGallery(Gallery):
+    """A shard's fir_gallery handle, owned by the ShardedGallery it came from."""
+
+    def __init__(self, handle, n, d, device):  # noqa: super().__init__ not called on purpose
+        self._h = handle
+        self.n, self.d, self.device = n, d, device
+
+    def close(self):
+        self._h = _vp()
+
+
+class ShardedGallery:
+    """Owns one fir_sharded handle: a gallery split by rows over `devices` (x shards_per_device logical shards each);
+    the ranks' keys are reduced by RCCL inside the library (include/fir_amd.h)."""
+
+    def __init__(self, rows=None, class_no=None, metric=METRIC_L2, devices=(0,), shards_per_device=1, *, first_global_row=0,
+                 comm_id=None, proc_rank=0, nprocs=1, dev_ptr=None, n=None, d=None, dev_class_ptr=None):
+        self._h = _vp()
+        devs = np.ascontiguousarray(list(devices), dtype=np.int32)
+        o = ShardOpts()
+        o.struct_bytes = C.sizeof(ShardOpts)
+        o.shards_per_device = shards_per_device
+        o.first_global_row = first_global_row
+        self._id = C.create_string_buffer(comm_id, COMM_ID_BYTES) if comm_id is not None else None
+        o.comm_id = C.cast(self._id, _vp) if self._id is not None else None
+        o.proc_rank, o.nprocs = proc_rank, nprocs
+        if dev_ptr is not None:
+            o.rows_on_device = 1
+            rp, cp = _vp(dev_ptr), (_vp(dev_class_ptr) if dev_class_ptr else None)
+            self.n, self.d = int(n), int(d)
+        else:
+            rows = np.ascontiguousarray(rows, dtype=np.float32)
+            if rows.ndim != 2:
+                raise ValueError("rows must be [n, d]")
+            self.n, self.d = rows.shape
+            rp = rows.ctypes.data_as(_vp)
+            cp = None
+            if class_no is not None:
+                class_no = np.ascontiguousarray(class_no, dtype=np.int32)
+                cp = class_no.ctypes.data_as(_vp)
+        _check(lib().fir_gallery_create_sharded_ex(rp, self.n, self.d, cp, metric, devs.ctypes.data_as(_vp), devs.size, C.byref(o),
+                                                   C.byref(self._h)))
+        self.devices = [int(v) for v in devs]
+
+    def close(self):
+        if self._h:
+            lib().fir_sharded_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def info(self):
+        n, d, nd, ns, nr, fr = C.c_int64(), C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        _check(lib().fir_sharded_info(self._h, C.byref(n), C.byref(d), C.byref(nd), C.byref(ns), C.byref(nr), C.byref(fr)))
+        return {"n_local": n.value, "d": d.value, "ndev": nd.value, "nshards": ns.value, "nranks": nr.value, "first_rank": fr.value}
+
+    def shard(self, i):
+        """(borrowed Gallery or None, first global row, rows) of local shard i."""
+        g, lo, rows = _vp(), C.c_int64(), C.c_int64()
+        _check(lib().fir_sharded_shard(self._h, i, C.byref(g), C.byref(lo), C.byref(rows)))
+        return (_BorrowedGallery(g, rows.value, self.d, None) if g else None), lo.value, rows.value
+
+    def set_metric(self, metric):
+        _check(lib().fir_sharded_set_metric(self._h, metric))
+
+    def search_top1(self, queries, start=0, end=0):
+        q, pq = _f32(queries)
+        q = q.reshape(-1, self.d)
+        idx = np.empty(q.shape[0], np.int32)
+        dist = np.empty(q.shape[0], np.float32)
+        _check(lib().fir_sharded_search_top1(self._h, pq, q.shape[0], start, end, idx.ctypes.data_as(_vp), dist.ctypes.data_as(_vp)))
+        return idx, dist
+
+    def search_topk(self, queries, k, start=0, end=0):
+        q, pq = _f32(queries)
+        q = q.reshape(-1, self.d)
+        idx = np.empty((q.shape[0], k), np.int32)
+        dist = np.empty((q.shape[0], k), np.float32)
+        _check(lib().fir_sharded_search_topk(self._h, pq, q.shape[0], start, end, k, idx.ctypes.data_as(_vp), dist.ctypes.data_as(_vp)))
+        return idx, dist
+
+    def classify_top1(self, queries, start=0, end=0):
+        q, pq = _f32(queries)
+        q = q.reshape(-1, self.d)
+        cls = np.empty(q.shape[0], np.int32)
+        idx = np.empty(q.shape[0], np.int32)
+        dist = np.empty(q.shape[0], np.float32)
+        _check(lib().fir_sharded_classify_top1(self._h, pq, q.shape[0], start, end, cls.ctypes.data_as(_vp), idx.ctypes.data_as(_vp),
+                                               dist.ctypes.data_as(_vp)))
+        return cls, idx, dist
+
+    def search_top1_keys_dev(self, q_ptr, qb, keys_ptr, start=0, end=0, stream=None):
+        _check(lib().fir_sharded_search_top1_keys_dev(self._h, _vp(q_ptr), qb, start, end, _vp(keys_ptr), _vp(stream) if stream else None))
+
+    def sync(self):
+        _check(lib().fir_sharded_sync(self._h))
+
+    def profile_enable(self, on=True):
+        _check(lib().fir_sharded_profile_enable(self._h, 1 if on else 0))
+
+    def profile_read(self, cap=65536):
+        ms = np.empty(cap, np.float32)
+        cnt = C.c_int32()
+        _check(lib().fir_sharded_profile_read(self._h, ms.ctypes.data_as(_vp), cap, C.byref(cnt)))
+        return ms[: min(cnt.value, cap)].copy()
 
 
 class GemmSearch:

@@ -87,8 +87,14 @@ struct fir_gallery {
     int waves_req = 0;        // 0 = automatic
     int max_waves = 0;        // upper bound over all scan kernels (8 blocks per CU)
     int last_waves = 0;       // waves of the most recent scan launch
-    int large_batch_min = 0;  // > 0: fir_search_top1 sends L2 whole-range batches of at least this many queries through fir_gemm_*
+    // L2 whole-range batches of at least this many queries go through fir_gemm_* (same keys): -1 = automatic
+    // (kAutoMfmaQueries queries against at least kAutoMfmaRows rows), 0 = never, > 0 = the caller's threshold
+    int large_batch_min = -1;
+    bool gemm_failed = false; // automatic mode: the matrix-core path could not be set up for this shape (rows too long): scan
     fir_gemm* gemm = nullptr; // created on first use
+    fir_dispatch_info last{}; // dominant kernel of the most recent search
+    int call_launches = 0;    // scan launches of the current call (note_dispatch)
+    bool quiet = false;       // scans on behalf of another path (the matrix-core path's uncertified queries): not recorded, not timed
     int64_t tiles_limit = 0, tile_begin = 0;  // tiles_limit > 0: scans cover tiles [tile_begin, tile_begin + tiles_limit) only (row samples of the top-K threshold)
     int max_tiles_per_launch = 64;   // query tiles (gallery passes) folded into one launch of the hand-scheduled kernels
 
@@ -233,6 +239,42 @@ int top1_qpp(const fir_gallery* g, int qb, int cap) {
     return q;
 }
 
+// Automatic matrix-core dispatch (fir_gallery_set_large_batch_mfma): measured on MI355X, 1M x 512: 256 queries 444k/s
+// against 26k/s through the exact scan, identical keys (profiles/); below ~64k rows the gallery is cache-resident and the
+// scan's 16-queries-per-pass form is within reach of it, and the fixed cost of the path (sample pass, re-rank,
+// certificate read-back) is not amortised.
+constexpr int kAutoMfmaQueries = 128;
+constexpr int64_t kAutoMfmaRows = 65536;
+bool wants_mfma(const fir_gallery* g, int32_t qb, int32_t start, int32_t end) {
+    if (g->metric != FIR_METRIC_L2 || start != 0 || end != g->d || g->n <= 0 || g->tiles_limit > 0) return false;
+    if (g->large_batch_min == 0 || g->gemm_failed) return false;
+    if (g->large_batch_min > 0) return qb >= g->large_batch_min;
+    return qb >= kAutoMfmaQueries && g->n >= kAutoMfmaRows && g->qpp == 0;     // a pinned queries-per-pass asks for the scan
+}
+
+void note_dispatch(fir_gallery* g, const void* fn, const char* name, int launches_add, int gx, int gy, int block, size_t dyn_lds, int qpp,
+                   double bytes, double flops, int path) {
+    fir_dispatch_info& L = g->last;
+    if (launches_add == 0 || std::strncmp(L.kernel, name, sizeof(L.kernel)) != 0) {
+        std::memset(&L, 0, sizeof L);
+        std::snprintf(L.kernel, sizeof(L.kernel), "%s", name);
+        hipFuncAttributes at;
+        if (fn && hipFuncGetAttributes(&at, fn) == hipSuccess) {
+            L.vgprs = at.numRegs;
+            L.lds_bytes = (int32_t)(at.sharedSizeBytes + dyn_lds);
+        } else {
+            L.lds_bytes = (int32_t)dyn_lds;
+        }
+    }
+    L.struct_bytes = (int32_t)sizeof L;
+    L.path = path;
+    L.launches += 1;
+    L.grid_x = gx; L.grid_y = gy; L.block = block;
+    L.queries_per_pass = qpp;
+    L.bytes_per_launch = bytes;
+    L.flops_per_launch = flops;
+}
+
 int check_range(const fir_gallery* g, int32_t& start, int32_t& end) {
     if (end == 0) end = g->d;   // db_features.cpp:320-321
     if (start < 0 || end > g->d || start >= end)
@@ -280,9 +322,17 @@ int run_pass(fir_gallery* g, hipStream_t st, int epi, const float* d_queries, in
                            g->d, g->dp4, qb_tile, qt, init_keys > 0 ? keys : nullptr, init_keys, g->range, next_serial(g));
     }
     size_t lds_bytes = 0;
+    char kname[160];
     scan_fn fn = pick_fast(epi, qb_tile, g->metric, start, end, g->dp4, &lds_bytes);
-    if (!fn && g->tiles <= (int64_t)g->cus * 4) fn = pick_deep(epi, qb_tile, g->metric, g->dp4, &lds_bytes);
-    if (!fn) fn = pick(epi, qb_tile, g->metric);
+    if (fn) std::snprintf(kname, sizeof kname, "fir::%s<%d, %d, %d, false>", lds_bytes ? "k_scan_l2_lds" : "k_scan_l2_fast", qb_tile / 8, FIR_FAST_U, FIR_FAST_WPS);
+    if (!fn && g->tiles <= (int64_t)g->cus * 4) {
+        fn = pick_deep(epi, qb_tile, g->metric, g->dp4, &lds_bytes);
+        if (fn) std::snprintf(kname, sizeof kname, "fir::k_scan<%d, %d, %d, %d, %d, %d, 1>", qb_tile, g->metric, kUDeep, epi, kKMax, wps_of(g->metric));
+    }
+    if (!fn) {
+        fn = pick(epi, qb_tile, g->metric);
+        std::snprintf(kname, sizeof kname, "fir::k_scan<%d, %d, %d, %d, %d, %d, 0>", qb_tile, g->metric, kU, epi, kKMax, wps_of(g->metric));
+    }
     if (!fn) return fail(FIR_ERR_ARG, "no kernel for qb=%d metric=%d", qb_tile, g->metric);
     if (lds_bytes > 64 * 1024) {   // more than the default dynamic LDS limit: opt in once per kernel
         bool known = false;
@@ -338,11 +388,13 @@ int run_pass(fir_gallery* g, hipStream_t st, int epi, const float* d_queries, in
     }
     hipLaunchKernelGGL(fn, dim3(waves / 4, ny), dim3(kBlock), lds_bytes, st, a);
     if (fn_plain) hipLaunchKernelGGL(fn_plain, dim3(waves / 4, ny), dim3(kBlock), lds_bytes, st, a);
+    // algorithmic bytes of one launch: per pass the gallery range once, the query tile, the keys
+    const double bytes_alg = ny * ((double)a.n * (end - start) * 4.0 + (double)qb_tile * (end - start) * 4.0 + qb_tile * 8.0);
     if (g->profiling) {
         FIR_HIP(hipEventRecord(e1, st));
-        // algorithmic bytes of one pass: the gallery range once, the query tile, the keys
-        g->last_bytes = ny * ((double)g->n * (end - start) * 4.0 + (double)qb_tile * (end - start) * 4.0 + qb_tile * 8.0);
+        g->last_bytes = bytes_alg;
     }
+    if (!g->quiet) note_dispatch(g, (const void*)fn, kname, g->call_launches++, waves / 4, ny, kBlock, lds_bytes, qb_tile, bytes_alg, 0.0, 0);
     FIR_HIP(hipGetLastError());
     return FIR_OK;
 }
@@ -833,8 +885,8 @@ int fir_gallery_set_metric(fir_gallery* g, int32_t metric) {
 
 int fir_gallery_set_large_batch_mfma(fir_gallery* g, int32_t min_queries) {
     if (!g) return fail(FIR_ERR_ARG, "gallery is NULL");
-    if (min_queries < 0) return fail(FIR_ERR_ARG, "min_queries < 0");
-    g->large_batch_min = min_queries;
+    g->large_batch_min = min_queries < 0 ? -1 : min_queries;
+    g->gemm_failed = false;
     if (min_queries == 0 && g->gemm) { fir_gemm_destroy(g->gemm); g->gemm = nullptr; }
     return FIR_OK;
 }
@@ -871,6 +923,23 @@ int fir_feature_distance(const float* lhs, const float* rhs, int32_t len, int32_
     return FIR_OK;
 }
 
+namespace {
+// The matrix-core path for this call, if it applies: 0 = done, 1 = take the scan, < 0 = error.
+int try_mfma(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start, int32_t end, uint64_t* d_keys, hipStream_t st) {
+    if (!wants_mfma(g, qb, start, end)) return 1;
+    if (!g->gemm) {
+        const int rc = fir_gemm_create(g, &g->gemm);
+        if (rc) {
+            g->gemm = nullptr;
+            if (g->large_batch_min > 0 || rc != FIR_ERR_ARG) return rc;    // asked for explicitly, or a real failure
+            g->gemm_failed = true;                                           // automatic: this shape stays with the scan
+            return 1;
+        }
+    }
+    return fir_gemm_search_top1_keys_dev(g->gemm, d_queries, qb, d_keys, st);
+}
+}  // namespace
+
 int fir_search_top1_keys_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start_pos, int32_t end_pos,
                              uint64_t* d_keys, void* stream) {
     if (!g || !d_keys || (qb > 0 && !d_queries)) return fail(FIR_ERR_ARG, "NULL argument");
@@ -879,7 +948,62 @@ int fir_search_top1_keys_dev(fir_gallery* g, const float* d_queries, int32_t qb,
     int rc = check_range(g, start_pos, end_pos);
     if (rc) return rc;
     FIR_HIP(hipSetDevice(g->device));
-    return top1_dev(g, d_queries, qb, start_pos, end_pos, d_keys, stream ? (hipStream_t)stream : g->stream);
+    hipStream_t st = stream ? (hipStream_t)stream : g->stream;
+    g->call_launches = 0;
+    rc = try_mfma(g, d_queries, qb, start_pos, end_pos, d_keys, st);
+    if (rc <= 0) return rc;
+    return top1_dev(g, d_queries, qb, start_pos, end_pos, d_keys, st);
+}
+
+// The exact streaming scan, whatever the batch size (fir_gemm.hip sends its uncertified queries here).
+int fir_search_top1_exact_keys_dev_(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start_pos, int32_t end_pos, uint64_t* d_keys,
+                                    void* stream) {
+    if (!g || !d_keys || (qb > 0 && !d_queries)) return fail(FIR_ERR_ARG, "NULL argument");
+    if (qb <= 0) return qb < 0 ? fail(FIR_ERR_ARG, "qb < 0") : FIR_OK;
+    int rc = check_range(g, start_pos, end_pos);
+    if (rc) return rc;
+    FIR_HIP(hipSetDevice(g->device));
+    const bool was_profiling = g->profiling;
+    g->profiling = false;
+    g->quiet = true;
+    rc = top1_dev(g, d_queries, qb, start_pos, end_pos, d_keys, stream ? (hipStream_t)stream : g->stream);
+    g->quiet = false;
+    g->profiling = was_profiling;
+    return rc;
+}
+
+// Profiling hooks for the library's other translation units: an event pair around one launch on `st`.
+int fir_gallery_profile_begin_(fir_gallery* g, void* st) {
+    if (!g->profiling) return FIR_OK;
+    if (g->ev_used + 2 > g->ev.size())
+        for (int i = 0; i < 64; ++i) {
+            hipEvent_t e;
+            FIR_HIP(hipEventCreate(&e));
+            g->ev.push_back(e);
+        }
+    FIR_HIP(hipEventRecord(g->ev[g->ev_used], (hipStream_t)st));
+    return FIR_OK;
+}
+int fir_gallery_profile_end_(fir_gallery* g, void* st, double bytes_alg) {
+    if (!g->profiling) return FIR_OK;
+    FIR_HIP(hipEventRecord(g->ev[g->ev_used + 1], (hipStream_t)st));
+    g->ev_used += 2;
+    g->last_bytes = bytes_alg;
+    return FIR_OK;
+}
+void fir_gallery_note_dispatch_(fir_gallery* g, const void* fn, const char* name, int first, int gx, int gy, int block, size_t dyn_lds, int qpp,
+                                double bytes, double flops) {
+    note_dispatch(g, fn, name, first ? 0 : 1, gx, gy, block, dyn_lds, qpp, bytes, flops, 1);
+}
+
+int fir_gallery_last_dispatch(fir_gallery* g, fir_dispatch_info* out) {
+    if (!g || !out) return fail(FIR_ERR_ARG, "NULL argument");
+    if (out->struct_bytes < 8 || out->struct_bytes > (int32_t)sizeof(fir_dispatch_info)) return fail(FIR_ERR_ARG, "fir_dispatch_info.struct_bytes = %d", out->struct_bytes);
+    const int32_t nb = out->struct_bytes;
+    fir_dispatch_info tmp = g->last;
+    tmp.struct_bytes = nb;
+    std::memcpy(out, &tmp, (size_t)nb);
+    return FIR_OK;
 }
 
 namespace {
@@ -980,7 +1104,8 @@ int fir_search_top1(fir_gallery* g, const float* queries, int32_t qb, int32_t st
     int rc = check_range(g, start_pos, end_pos);
     if (rc) return rc;
     FIR_HIP(hipSetDevice(g->device));
-    const bool mfma = g->large_batch_min > 0 && qb >= g->large_batch_min && g->metric == FIR_METRIC_L2 && start_pos == 0 && end_pos == g->d && g->n > 0;
+    const bool mfma = wants_mfma(g, qb, start_pos, end_pos);
+    g->call_launches = 0;
     if (!mfma && (size_t)qb * g->d * sizeof(float) <= kPinQueryBytes && (size_t)qb <= kPinKeys) {
         // small call: queries are read from, and keys written to, pinned host memory by the kernels themselves
         if ((rc = ensure_pin(g))) return rc;
@@ -1005,13 +1130,9 @@ int fir_search_top1(fir_gallery* g, const float* queries, int32_t qb, int32_t st
     if ((rc = grow(g->dq, g->dq_cap, (size_t)qb * g->d))) return rc;
     if ((rc = grow(g->dkeys, g->dkeys_cap, (size_t)qb))) return rc;
     FIR_HIP(hipMemcpyAsync(g->dq, queries, (size_t)qb * g->d * sizeof(float), hipMemcpyHostToDevice, g->stream));
-    // opt-in: large L2 whole-range batches go through the matrix cores (same keys, fir_gemm.hip)
-    if (g->large_batch_min > 0 && qb >= g->large_batch_min && g->metric == FIR_METRIC_L2 && start_pos == 0 && end_pos == g->d && g->n > 0) {
-        if (!g->gemm && (rc = fir_gemm_create(g, &g->gemm))) return rc;
-        rc = fir_gemm_search_top1_keys_dev(g->gemm, g->dq, qb, g->dkeys, g->stream);
-    } else {
-        rc = top1_dev(g, g->dq, qb, start_pos, end_pos, g->dkeys, g->stream);
-    }
+    // large L2 whole-range batches go through the matrix cores (same keys, fir_gemm.hip) unless switched off
+    rc = try_mfma(g, g->dq, qb, start_pos, end_pos, g->dkeys, g->stream);
+    if (rc > 0) rc = top1_dev(g, g->dq, qb, start_pos, end_pos, g->dkeys, g->stream);
     if (rc) return rc;
     std::vector<uint64_t> keys((size_t)qb);
     FIR_HIP(hipMemcpyAsync(keys.data(), g->dkeys, (size_t)qb * sizeof(uint64_t), hipMemcpyDeviceToHost, g->stream));

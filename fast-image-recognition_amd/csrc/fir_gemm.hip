@@ -1073,7 +1073,8 @@ struct fir_gemm {
     unsigned long long* lists[2] = {nullptr, nullptr};
     int* counts[2] = {nullptr, nullptr};
     hipStream_t side = nullptr;
-    hipEvent_t main_done[2] = {nullptr, nullptr}, rerank_done[2] = {nullptr, nullptr};
+    hipEvent_t main_done[2] = {nullptr, nullptr}, rerank_done[2] = {nullptr, nullptr}, prep_done[2] = {nullptr, nullptr};
+    hipEvent_t queries_ready = nullptr;
     int* ok = nullptr; size_t ok_cap = 0;  // certificate flags of one call
     int sample_rows = 0;
     float* fbq = nullptr;                 // fallback queries (device)
@@ -1125,7 +1126,9 @@ int fir_gemm_create_ex(fir_gallery* g, int32_t precision, fir_gemm** out) {
         if (e == hipSuccess) e = hipMalloc((void**)&m->counts[b], kPasses * kQT * sizeof(int));
         if (e == hipSuccess) e = hipEventCreateWithFlags(&m->main_done[b], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&m->rerank_done[b], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&m->prep_done[b], hipEventDisableTiming);
     }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&m->queries_ready, hipEventDisableTiming);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking);
     m->sample_rows = (int)std::min<int64_t>(np, std::max<int64_t>(kMinSampleRows, np / 64));
     if (e == hipSuccess) e = hipMalloc((void**)&m->sample, (size_t)kPasses * kQT * m->sample_rows * sizeof(float));
@@ -1201,7 +1204,9 @@ int fir_gemm_destroy(fir_gemm* m) {
         (void)hipFree(m->qm[b]); (void)hipFree(m->qbf[b]); (void)hipFree(m->qnorm[b]); (void)hipFree(m->qmul[b]); (void)hipFree(m->qinv[b]); (void)hipFree(m->tau[b]); (void)hipFree(m->lists[b]); (void)hipFree(m->counts[b]);
         if (m->main_done[b]) (void)hipEventDestroy(m->main_done[b]);
         if (m->rerank_done[b]) (void)hipEventDestroy(m->rerank_done[b]);
+        if (m->prep_done[b]) (void)hipEventDestroy(m->prep_done[b]);
     }
+    if (m->queries_ready) (void)hipEventDestroy(m->queries_ready);
     (void)hipFree(m->gm); (void)hipFree(m->gb); (void)hipFree(m->gh); (void)hipFree(m->gnorm); (void)hipFree(m->gmax); (void)hipFree(m->sample); (void)hipFree(m->ok);
     (void)hipFree(m->fbq); (void)hipFree(m->fbkeys);
     delete m;
@@ -1225,7 +1230,7 @@ int fir_gemm_search_top1_keys_dev(fir_gemm* m, const float* d_queries, int32_t q
     hipStream_t st = stream ? (hipStream_t)stream : m->v.stream;
     const int d = m->v.d;
     const int64_t n = m->v.n;
-    if (n == 0) return fir_search_top1_keys_dev(m->g, d_queries, qb, 0, 0, d_keys, st);
+    if (n == 0) return fir_search_top1_exact_keys_dev_(m->g, d_queries, qb, 0, 0, d_keys, st);
     if ((size_t)qb > m->ok_cap) {
         if (m->ok) GEMM_HIP(hipFree(m->ok));
         m->ok = nullptr;
@@ -1241,56 +1246,94 @@ int fir_gemm_search_top1_keys_dev(fir_gemm* m, const float* d_queries, int32_t q
                         (m->precision == FIR_GEMM_BF16_SPLIT ? 6.1035156e-5f : m->precision == FIR_GEMM_F16 ? 9.765625e-4f * 1.0625f : 0.0f);
     const int grid = m->v.cus;      // one 512-thread workgroup per CU
     const int sample_rows = m->sample_rows;
-    int sb = 0;      // super-batch = up to kPasses passes of 64 queries in ONE set of launches
-    for (int q0 = 0; q0 < qb; q0 += kPasses * kQT, ++sb) {
+    const int sample_grid = (sample_rows + 63) / 64;
+    const int nsb = (qb + kPasses * kQT - 1) / (kPasses * kQT);      // super-batch = up to kPasses passes of 64 queries in ONE set of launches
+    // Two streams. `st` carries only the full passes over the gallery, back to back; `side` carries everything small:
+    // the preparation of super-batch i+1 (query norms / scales / fragments, the sample pass, tau) and the exact re-rank +
+    // certificate of super-batch i, both under super-batch i's (or i+1's) full pass. Order on `side`:
+    // prep(0) prep(1) rerank(0) prep(2) rerank(1) ... -- prep(i+2) reuses the scratch set rerank(i) has just finished with.
+    GEMM_HIP(hipEventRecord(m->queries_ready, st));
+    GEMM_HIP(hipStreamWaitEvent(m->side, m->queries_ready, 0));
+    auto prep = [&](int sb) -> int {
+        hipStream_t ps = m->side;
+        const int q0 = sb * kPasses * kQT;
         const int nq = std::min(kPasses * kQT, qb - q0);
         const int np = (nq + kQT - 1) / kQT;
         const int b = sb & 1;
         const float* dq = d_queries + (size_t)q0 * d;
-        if (sb >= 2) GEMM_HIP(hipStreamWaitEvent(st, m->rerank_done[b], 0));     // scratch set b is free again
-        const int sample_grid = (sample_rows + 63) / 64;
         if (m->precision == FIR_GEMM_F16) {
             const int pairs = (np + 1) / 2;                      // 128 queries per gallery read; a half-filled pair is zero-padded
-            hipLaunchKernelGGL(k_gemm_qprep_f16, dim3(pairs * 2 * kQT), dim3(64), 0, st, dq, nq, d, m->gallery_exp, m->qnorm[b], m->qmul[b], m->qinv[b]);
-            GEMM_HIP(hipMemsetAsync(m->counts[b], 0, (size_t)pairs * 2 * kQT * sizeof(int), st));
-            hipLaunchKernelGGL(k_gemm_pack_queries_f16, dim3((4 * m->dk16 * 64 + 255) / 256, pairs), dim3(256), 0, st, dq, nq, d, m->dk16, m->qmul[b],
+            hipLaunchKernelGGL(k_gemm_qprep_f16, dim3(pairs * 2 * kQT), dim3(64), 0, ps, dq, nq, d, m->gallery_exp, m->qnorm[b], m->qmul[b], m->qinv[b]);
+            GEMM_HIP(hipMemsetAsync(m->counts[b], 0, (size_t)pairs * 2 * kQT * sizeof(int), ps));
+            hipLaunchKernelGGL(k_gemm_pack_queries_f16, dim3((4 * m->dk16 * 64 + 255) / 256, pairs), dim3(256), 0, ps, dq, nq, d, m->dk16, m->qmul[b],
                                m->qbf[b]);
             const int wpb = kGemmBlock / 64;
             const int sample_wgs = (int)((((int64_t)sample_rows + 31) / 32 + wpb - 1) / wpb);
             const bool streamed = m->streamed >= 0 ? m->streamed != 0 : m->dk16 > kSlabH;
-            const dim3 sgrid(std::min(sample_wgs, grid), pairs), mgrid(grid, pairs);
+            const dim3 sgrid(std::min(sample_wgs, grid), pairs);
             if (streamed)
-                hipLaunchKernelGGL((k_gemm_proxy_f16<0, 1>), sgrid, dim3(kGemmBlock), kHalfLds, st, m->gh, m->gnorm, m->qbf[b], m->qinv[b], n, (int64_t)0,
+                hipLaunchKernelGGL((k_gemm_proxy_f16<0, 1>), sgrid, dim3(kGemmBlock), kHalfLds, ps, m->gh, m->gnorm, m->qbf[b], m->qinv[b], n, (int64_t)0,
                                    (int64_t)sample_rows, m->dk16, m->tau[b], m->lists[b], m->counts[b], m->sample, sample_rows);
             else
-                hipLaunchKernelGGL((k_gemm_proxy_f16<0, 0>), sgrid, dim3(kGemmBlock), kHalfLds, st, m->gh, m->gnorm, m->qbf[b], m->qinv[b], n, (int64_t)0,
+                hipLaunchKernelGGL((k_gemm_proxy_f16<0, 0>), sgrid, dim3(kGemmBlock), kHalfLds, ps, m->gh, m->gnorm, m->qbf[b], m->qinv[b], n, (int64_t)0,
                                    (int64_t)sample_rows, m->dk16, m->tau[b], m->lists[b], m->counts[b], m->sample, sample_rows);
-            hipLaunchKernelGGL(k_gemm_tau, dim3(pairs * 2 * kQT), dim3(256), 0, st, m->sample, (sample_rows + 31) / 32, m->tau[b], nq, m->qnorm[b], m->gmax,
+            hipLaunchKernelGGL(k_gemm_tau, dim3(pairs * 2 * kQT), dim3(256), 0, ps, m->sample, (sample_rows + 31) / 32, m->tau[b], nq, m->qnorm[b], m->gmax,
                                e_rel, 2 * kQT);
+        } else {
+            hipLaunchKernelGGL(k_gemm_qnorm, dim3(np * kQT), dim3(64), 0, ps, dq, nq, d, m->qnorm[b]);
+            GEMM_HIP(hipMemsetAsync(m->counts[b], 0, (size_t)np * kQT * sizeof(int), ps));
+            if (m->precision == FIR_GEMM_F32) {
+                hipLaunchKernelGGL(k_gemm_pack_queries, dim3(((kQT / 32) * m->dq8 * 64 + 255) / 256, np), dim3(256), 0, ps, dq, nq, d, m->dq8, m->qm[b]);
+                hipLaunchKernelGGL(k_gemm_proxy<0>, dim3(sample_grid, np), dim3(128), lds, ps, m->gm, m->gnorm, m->qm[b], n, (int64_t)0,
+                                   (int64_t)sample_rows, m->dq8, m->tau[b], m->lists[b], m->counts[b], m->sample, sample_rows);
+            } else {
+                hipLaunchKernelGGL(k_gemm_pack_queries_bf16, dim3(((kQT / 32) * m->dk16 * 64 + 255) / 256, np), dim3(256), 0, ps, dq, nq, d, m->dk16,
+                                   m->qbf[b]);
+                hipLaunchKernelGGL(k_gemm_proxy_bf16<0>, dim3(sample_grid, np), dim3(128), 0, ps, m->gb, m->gnorm, m->qbf[b], n, (int64_t)0,
+                                   (int64_t)sample_rows, m->dk16, m->tau[b], m->lists[b], m->counts[b], m->sample, sample_rows);
+            }
+            hipLaunchKernelGGL(k_gemm_tau, dim3(np * kQT), dim3(256), 0, ps, m->sample, sample_rows, m->tau[b], 0x7FFFFFFF, m->qnorm[b], m->gmax, e_rel);
+        }
+        GEMM_HIP(hipGetLastError());
+        GEMM_HIP(hipEventRecord(m->prep_done[b], ps));
+        return FIR_OK;
+    };
+    int rcp = prep(0);
+    if (rcp) return rcp;
+    for (int sb = 0; sb < nsb; ++sb) {
+        const int q0 = sb * kPasses * kQT;
+        const int nq = std::min(kPasses * kQT, qb - q0);
+        const int np = (nq + kQT - 1) / kQT;
+        const int b = sb & 1;
+        const float* dq = d_queries + (size_t)q0 * d;
+        if (sb + 1 < nsb && (rcp = prep(sb + 1))) return rcp;
+        GEMM_HIP(hipStreamWaitEvent(st, m->prep_done[b], 0));
+        // ---- the full pass(es) over the gallery: the launch fir_profile_read times and fir_gallery_last_dispatch names ----
+        if (m->precision == FIR_GEMM_F16) {
+            const int pairs = (np + 1) / 2;
+            const bool streamed = m->streamed >= 0 ? m->streamed != 0 : m->dk16 > kSlabH;
+            const dim3 mgrid(grid, pairs);
+            const int64_t rblocks = (n + 31) / 32;
+            const double bytes = pairs * ((double)rblocks * m->dk16 * 1024.0 + 4.0 * m->dk16 * 1024.0 + 128.0 * 8.0);   // fp16 fragments once per 128 queries + the query tile + keys
+            const double flops = 2.0 * (double)n * d * 128.0 * pairs;
+            int rc2 = fir_gallery_profile_begin_(m->g, st);
+            if (rc2) return rc2;
             if (streamed)
                 hipLaunchKernelGGL((k_gemm_proxy_f16<1, 1>), mgrid, dim3(kGemmBlock), kHalfLds, st, m->gh, m->gnorm, m->qbf[b], m->qinv[b], n, (int64_t)0, n,
                                    m->dk16, m->tau[b], m->lists[b], m->counts[b], m->sample, sample_rows);
             else
                 hipLaunchKernelGGL((k_gemm_proxy_f16<1, 0>), mgrid, dim3(kGemmBlock), kHalfLds, st, m->gh, m->gnorm, m->qbf[b], m->qinv[b], n, (int64_t)0, n,
                                    m->dk16, m->tau[b], m->lists[b], m->counts[b], m->sample, sample_rows);
-        } else {
-        hipLaunchKernelGGL(k_gemm_qnorm, dim3(np * kQT), dim3(64), 0, st, dq, nq, d, m->qnorm[b]);
-        GEMM_HIP(hipMemsetAsync(m->counts[b], 0, (size_t)np * kQT * sizeof(int), st));
-        }
-        if (m->precision == FIR_GEMM_F16) {
+            if ((rc2 = fir_gallery_profile_end_(m->g, st, bytes))) return rc2;
+            fir_gallery_note_dispatch_(m->g, streamed ? (const void*)k_gemm_proxy_f16<1, 1> : (const void*)k_gemm_proxy_f16<1, 0>,
+                                       streamed ? "fir::k_gemm_proxy_f16<1, 1>" : "fir::k_gemm_proxy_f16<1, 0>", sb == 0, grid, pairs, kGemmBlock, kHalfLds, 128,
+                                       bytes, flops);
         } else if (m->precision == FIR_GEMM_F32) {
-            hipLaunchKernelGGL(k_gemm_pack_queries, dim3(((kQT / 32) * m->dq8 * 64 + 255) / 256, np), dim3(256), 0, st, dq, nq, d, m->dq8, m->qm[b]);
-            hipLaunchKernelGGL(k_gemm_proxy<0>, dim3(sample_grid, np), dim3(128), lds, st, m->gm, m->gnorm, m->qm[b], n, (int64_t)0,
-                               (int64_t)sample_rows, m->dq8, m->tau[b], m->lists[b], m->counts[b], m->sample, sample_rows);
-            hipLaunchKernelGGL(k_gemm_tau, dim3(np * kQT), dim3(256), 0, st, m->sample, sample_rows, m->tau[b], 0x7FFFFFFF, m->qnorm[b], m->gmax, e_rel);
             hipLaunchKernelGGL(k_gemm_proxy<1>, dim3(grid, np), dim3(kGemmBlock), lds, st, m->gm, m->gnorm, m->qm[b], n, (int64_t)0, n, m->dq8,
                                m->tau[b], m->lists[b], m->counts[b], m->sample, sample_rows);
+            fir_gallery_note_dispatch_(m->g, (const void*)k_gemm_proxy<1>, "fir::k_gemm_proxy<1>", sb == 0, grid, np, kGemmBlock, lds, 64,
+                                       np * ((double)((n + 31) / 32) * m->dq8 * 1024.0), 2.0 * (double)n * d * 64.0 * np);
         } else {
-            hipLaunchKernelGGL(k_gemm_pack_queries_bf16, dim3(((kQT / 32) * m->dk16 * 64 + 255) / 256, np), dim3(256), 0, st, dq, nq, d, m->dk16,
-                               m->qbf[b]);
-            hipLaunchKernelGGL(k_gemm_proxy_bf16<0>, dim3(sample_grid, np), dim3(128), 0, st, m->gb, m->gnorm, m->qbf[b], n, (int64_t)0,
-                               (int64_t)sample_rows, m->dk16, m->tau[b], m->lists[b], m->counts[b], m->sample, sample_rows);
-            hipLaunchKernelGGL(k_gemm_tau, dim3(np * kQT), dim3(256), 0, st, m->sample, sample_rows, m->tau[b], 0x7FFFFFFF, m->qnorm[b], m->gmax, e_rel);
             // pairs of passes share one read of the gallery (128 queries per wave); an odd last pass goes alone
             const int pairs = m->wide ? np / 2 : 0;
             if (pairs > 0)
@@ -1302,9 +1345,12 @@ int fir_gemm_search_top1_keys_dev(fir_gemm* m, const float* d_queries, int32_t q
                                    m->qbf[b] + p0 * (kQT / 32) * m->dk16 * 128, n, (int64_t)0, n, m->dk16, m->tau[b] + p0 * kQT,
                                    m->lists[b] + p0 * kQT * kListCap, m->counts[b] + p0 * kQT, m->sample + p0 * kQT * sample_rows, sample_rows);
             }
+            fir_gallery_note_dispatch_(m->g, (const void*)k_gemm_proxy_bf16_wide, pairs > 0 ? "fir::k_gemm_proxy_bf16_wide" : "fir::k_gemm_proxy_bf16<1>", sb == 0,
+                                       grid, pairs > 0 ? pairs : np, kGemmBlock, pairs > 0 ? (size_t)kWideLds : lds, pairs > 0 ? 128 : 64,
+                                       (pairs + (np - 2 * pairs)) * ((double)((n + 31) / 32) * m->dk16 * 2048.0), 2.0 * (double)n * d * 64.0 * np);
         }
         GEMM_HIP(hipEventRecord(m->main_done[b], st));
-        // exact re-rank + certificate of this super-batch on the side stream, under the next one's GEMM
+        // exact re-rank + certificate of this super-batch on the side stream, under the next one's full pass
         GEMM_HIP(hipStreamWaitEvent(m->side, m->main_done[b], 0));
         hipLaunchKernelGGL(k_gemm_rerank, dim3(nq), dim3(64), (size_t)(m->rerank_group + 1) * m->dp4 * sizeof(float4), m->side, m->lists[b], m->counts[b], m->tau[b],
                            m->gal4, dq, m->qnorm[b], m->gmax, n, d, m->dp4, m->v.row_offset, e_rel, m->rerank_group, (unsigned long long*)d_keys + q0,
@@ -1312,7 +1358,7 @@ int fir_gemm_search_top1_keys_dev(fir_gemm* m, const float* d_queries, int32_t q
         GEMM_HIP(hipEventRecord(m->rerank_done[b], m->side));
         m->passes += np;
     }
-    for (int b = 0; b < 2 && b < sb; ++b) GEMM_HIP(hipStreamWaitEvent(st, m->rerank_done[b], 0));   // join the side stream
+    GEMM_HIP(hipStreamWaitEvent(st, m->rerank_done[(nsb - 1) & 1], 0));   // join the side stream (it is in order: the last re-rank is the last thing on it)
     GEMM_HIP(hipGetLastError());
     std::vector<int> h_ok((size_t)qb);
     GEMM_HIP(hipMemcpyAsync(h_ok.data(), m->ok, (size_t)qb * sizeof(int), hipMemcpyDeviceToHost, st));
@@ -1326,7 +1372,7 @@ int fir_gemm_search_top1_keys_dev(fir_gemm* m, const float* d_queries, int32_t q
         const int nf = (int)std::min<size_t>(kQT, which.size() - f0);
         for (int i = 0; i < nf; ++i)
             GEMM_HIP(hipMemcpyAsync(m->fbq + (size_t)i * d, d_queries + (size_t)which[f0 + i] * d, (size_t)d * sizeof(float), hipMemcpyDeviceToDevice, st));
-        int rc = fir_search_top1_keys_dev(m->g, m->fbq, nf, 0, 0, (uint64_t*)m->fbkeys, st);
+        int rc = fir_search_top1_exact_keys_dev_(m->g, m->fbq, nf, 0, 0, (uint64_t*)m->fbkeys, st);
         if (rc) return rc;
         for (int i = 0; i < nf; ++i)
             GEMM_HIP(hipMemcpyAsync(d_keys + which[f0 + i], m->fbkeys + i, sizeof(uint64_t), hipMemcpyDeviceToDevice, st));

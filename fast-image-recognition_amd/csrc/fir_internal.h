@@ -42,3 +42,15 @@ extern "C" int fir_runtime_init_(int device);
 extern "C" int fir_gallery_pin_(fir_gallery* g, void** base, size_t* query_bytes, uint64_t** results);
 extern "C" uint64_t fir_gallery_next_ticket_(fir_gallery* g);
 extern "C" int fir_gallery_wait_ticket_(fir_gallery* g, volatile uint64_t* flag, uint64_t ticket);
+
+// The exact streaming scan whatever the batch size (fir_search_top1_keys_dev may route large L2 batches through fir_gemm_*,
+// whose uncertified queries must not come back to it).
+extern "C" int fir_search_top1_exact_keys_dev_(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start_pos, int32_t end_pos,
+                                               uint64_t* d_keys, void* stream);
+
+// fir_profile_enable / fir_profile_read / fir_gallery_last_dispatch for kernels launched by the other translation units:
+// an event pair around ONE launch on `st` (no-ops unless profiling is on), and the record of the call's dominant kernel.
+extern "C" int fir_gallery_profile_begin_(fir_gallery* g, void* st);
+extern "C" int fir_gallery_profile_end_(fir_gallery* g, void* st, double bytes_alg);
+extern "C" void fir_gallery_note_dispatch_(fir_gallery* g, const void* fn, const char* name, int first, int gx, int gy, int block, size_t dyn_lds,
+                                           int qpp, double bytes, double flops);

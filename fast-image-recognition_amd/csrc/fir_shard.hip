@@ -1,0 +1,565 @@
+// fir_shard.hip -- one gallery sharded by rows over several GPUs, behind the C ABI.
+//
+// Every shard is an ordinary fir_gallery on its device with row_offset = the global index of its first row; a query
+// batch is scanned by all shards at once and the only exchange is
+//   top-1:  ncclAllReduce(ncclMin, ncclUint64) of qb packed keys (the low word is the GLOBAL row index, so the integer
+//           minimum is the reference's first-minimum rule over the whole gallery, db_features.cpp:329-332);
+//   top-K:  ncclAllGather of every rank's K keys per query + an integer K-way merge;
+//   class:  ncclAllReduce(ncclMin, ncclInt32) of "classNo of the winning row if I hold it, else INT32_MAX".
+// All payloads are KB-sized: the collectives are latency-bound and run on the stream that produced the keys.
+//
+// Two ways to span GPUs, freely combined (ranks = processes x devices per process):
+//   * one process, a device list: one worker thread per device issues that device's launches and its RCCL call;
+//   * one process per GPU (torch.distributed.run style): process 0 makes an id with fir_comm_unique_id, hands it
+//     to the others out of band, and every process passes it in fir_shard_opts.
+// Several logical shards per device (shards_per_device) exist so that the whole path -- split, per-shard scan,
+// on-device minimum, RCCL call -- can be exercised on a one-GPU box.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <condition_variable>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <mutex>
+#include <new>
+#include <thread>
+#include <vector>
+
+#include "../../include/fir_amd.h"
+#include "fir_common.h"
+#include "fir_internal.h"
+
+namespace {
+
+using fir::kKeyNone;
+
+thread_local char g_sh_err[512];
+int sh_fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_sh_err, sizeof(g_sh_err), fmt, ap);
+    va_end(ap);
+    fir_set_last_error_(g_sh_err);
+    return code;
+}
+#define SH_HIP(expr)                                                                                                   \
+    do {                                                                                                               \
+        hipError_t e_ = (expr);                                                                                        \
+        if (e_ != hipSuccess) return sh_fail(e_ == hipErrorOutOfMemory ? FIR_ERR_NOMEM : FIR_ERR_HIP, "%s failed: %s (%s:%d)", #expr, \
+                                             hipGetErrorString(e_), __FILE__, __LINE__);                               \
+    } while (0)
+#define SH_NCCL(expr)                                                                                                  \
+    do {                                                                                                               \
+        ncclResult_t r_ = (expr);                                                                                      \
+        if (r_ != ncclSuccess) return sh_fail(FIR_ERR_COMM, "%s failed: %s (%s:%d)", #expr, ncclGetErrorString(r_), __FILE__, __LINE__); \
+    } while (0)
+
+// keys[q] = min over parts p of parts[p][q]   (the shards of one device, before the RCCL call)
+__global__ void __launch_bounds__(256) k_shard_min_keys(const uint64_t* __restrict__ parts, int nparts, int n, uint64_t* __restrict__ keys) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    uint64_t m = kKeyNone;
+    for (int p = 0; p < nparts; ++p) {
+        const uint64_t v = parts[(size_t)p * n + i];
+        m = v < m ? v : m;
+    }
+    keys[i] = m;
+}
+
+// out[q][0..k) = the k smallest of parts[p][q][0..k), p < nparts, ascending. Every part is ascending and keys are unique
+// (global row index in the low word), FIR_KEY_NONE sorts last: exactly fir_search_topk over the union of the parts.
+__global__ void __launch_bounds__(64) k_shard_merge_topk(const uint64_t* __restrict__ parts, int nparts, int qb, int k, uint64_t* __restrict__ out) {
+    const int q = blockIdx.x * 64 + threadIdx.x;
+    if (q >= qb) return;
+    uint64_t prev = 0;
+    bool first = true;
+    for (int j = 0; j < k; ++j) {           // j-th smallest = the smallest key greater than the previous pick
+        uint64_t m = kKeyNone;
+        for (int p = 0; p < nparts; ++p) {
+            const uint64_t* L = parts + ((size_t)p * qb + q) * k;
+            for (int i = 0; i < k; ++i) {
+                const uint64_t v = L[i];
+                if ((first || v > prev) && v < m) m = v;
+            }
+        }
+        out[(size_t)q * k + j] = m;
+        if (m == kKeyNone) { for (int r = j + 1; r < k; ++r) out[(size_t)q * k + r] = kKeyNone; break; }
+        prev = m;
+        first = false;
+    }
+}
+
+// cls_out[q] = classNo of the row keys[q] names when rows [lo, hi) are held here (cls = their labels), left alone otherwise
+__global__ void __launch_bounds__(256) k_shard_class_owned(const uint64_t* __restrict__ keys, int n, const int32_t* __restrict__ cls, int64_t lo,
+                                                            int64_t hi, int32_t* __restrict__ cls_out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t v = keys[i];
+    if (v == kKeyNone) return;
+    const int64_t row = (int64_t)(uint32_t)(v & 0xFFFFFFFFull);
+    if (row >= lo && row < hi) cls_out[i] = cls[row - lo];
+}
+__global__ void __launch_bounds__(256) k_shard_fill_i32(int32_t* p, int n, int32_t v) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+__global__ void __launch_bounds__(256) k_shard_fill_u64(uint64_t* p, int n, uint64_t v) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+struct Worker {       // one thread per device of a multi-device handle: its launches and its RCCL calls
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::function<int()> job;
+    bool has_job = false, done = false, quit = false;
+    int rc = 0;
+    char err[512] = "";
+    void loop() {
+        for (;;) {
+            std::function<int()> j;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return has_job || quit; });
+                if (quit) return;
+                j = job;
+                has_job = false;
+            }
+            const int r = j();
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                rc = r;
+                if (r) { strncpy(err, fir_last_error(), sizeof(err) - 1); err[sizeof(err) - 1] = 0; }
+                done = true;
+            }
+            cv.notify_all();
+        }
+    }
+};
+
+struct Shard {
+    int slot = 0;              // index into devs
+    fir_gallery* g = nullptr;  // nullptr: no rows (more shards than 64-row tiles)
+    int64_t lo = 0, hi = 0;    // global rows
+    const int32_t* cls = nullptr;
+};
+
+struct DevCtx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    ncclComm_t comm = nullptr;
+    float* dq = nullptr;        size_t dq_cap = 0;
+    uint64_t* parts = nullptr;  size_t parts_cap = 0;     // [shards here][qb * k]
+    uint64_t* keys = nullptr;   size_t keys_cap = 0;      // [qb * k] reduced
+    uint64_t* gath = nullptr;   size_t gath_cap = 0;      // [nranks][qb * k]
+    int32_t* cls = nullptr;     size_t cls_cap = 0;
+    std::vector<int> shards;
+    Worker* worker = nullptr;
+    std::vector<hipEvent_t> evs;                          // pairs around the RCCL calls (profiling, device slot 0)
+    size_t ev_used = 0;
+};
+
+template <typename T>
+int grow_dev(T*& p, size_t& cap, size_t need) {
+    if (need <= cap) return FIR_OK;
+    if (p) SH_HIP(hipFree(p));
+    p = nullptr;
+    cap = 0;
+    const size_t want = std::max<size_t>(need, 1024);
+    SH_HIP(hipMalloc((void**)&p, want * sizeof(T)));
+    cap = want;
+    return FIR_OK;
+}
+
+}  // namespace
+
+struct fir_sharded {
+    int d = 0, metric = 0;
+    int64_t n_local = 0, first_row = 0;
+    int ndev = 0, spd = 1, nranks = 1, rank0 = 0;
+    bool has_labels = false;
+    std::vector<DevCtx> devs;
+    std::vector<Shard> shards;
+    void* pin = nullptr;  size_t pin_cap = 0;      // pinned host staging: queries in, keys / classes out
+    bool profiling = false;
+};
+
+namespace {
+
+// Run fn(slot) for every device: inline for one device, on the per-device worker threads otherwise.
+int run_all(fir_sharded* h, const std::function<int(int)>& fn) {
+    if (h->ndev == 1) return fn(0);
+    for (int s = 0; s < h->ndev; ++s) {
+        Worker* w = h->devs[s].worker;
+        {
+            std::lock_guard<std::mutex> lk(w->mu);
+            w->job = [fn, s] { return fn(s); };
+            w->has_job = true;
+            w->done = false;
+        }
+        w->cv.notify_all();
+    }
+    int rc = FIR_OK;
+    for (int s = 0; s < h->ndev; ++s) {
+        Worker* w = h->devs[s].worker;
+        std::unique_lock<std::mutex> lk(w->mu);
+        w->cv.wait(lk, [&] { return w->done; });
+        if (w->rc && rc == FIR_OK) { rc = w->rc; fir_set_last_error_(w->err); }
+    }
+    return rc;
+}
+
+int ensure_pin(fir_sharded* h, size_t bytes) {
+    if (bytes <= h->pin_cap) return FIR_OK;
+    if (h->pin) SH_HIP(hipHostFree(h->pin));
+    h->pin = nullptr;
+    h->pin_cap = 0;
+    const size_t want = std::max<size_t>(bytes, 1 << 20);
+    SH_HIP(hipHostMalloc(&h->pin, want, hipHostMallocPortable));
+    h->pin_cap = want;
+    return FIR_OK;
+}
+
+int check_range(const fir_sharded* h, int32_t& start, int32_t& end) {
+    if (end == 0) end = h->d;
+    if (start < 0 || end > h->d || start >= end) return sh_fail(FIR_ERR_ARG, "feature range [%d,%d) not inside [0,%d)", start, end, h->d);
+    return FIR_OK;
+}
+
+// The keys of one device: every shard it holds scans the batch (K keys per query, K = 1: top-1), then the minimum /
+// K-way merge over those shards lands in dc.keys.
+int device_keys(fir_sharded* h, int slot, const float* d_queries, int32_t qb, int32_t start, int32_t end, int32_t k, hipStream_t st) {
+    DevCtx& dc = h->devs[slot];
+    const size_t per = (size_t)qb * k;
+    int rc;
+    if ((rc = grow_dev(dc.parts, dc.parts_cap, per * std::max<size_t>(dc.shards.size(), 1)))) return rc;
+    if ((rc = grow_dev(dc.keys, dc.keys_cap, per))) return rc;
+    int live = 0;
+    for (size_t i = 0; i < dc.shards.size(); ++i) {
+        Shard& s = h->shards[dc.shards[i]];
+        if (!s.g) continue;
+        uint64_t* out = dc.parts + (size_t)live * per;
+        rc = k == 1 ? fir_search_top1_keys_dev(s.g, d_queries, qb, start, end, out, st)
+                    : fir_search_topk_keys_dev(s.g, d_queries, qb, start, end, k, out, st);
+        if (rc) return rc;
+        ++live;
+    }
+    if (live == 0) hipLaunchKernelGGL(k_shard_fill_u64, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, st, dc.keys, (int)per, kKeyNone);
+    else if (k == 1) hipLaunchKernelGGL(k_shard_min_keys, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, st, dc.parts, live, (int)per, dc.keys);
+    else hipLaunchKernelGGL(k_shard_merge_topk, dim3((qb + 63) / 64), dim3(64), 0, st, dc.parts, live, qb, k, dc.keys);
+    SH_HIP(hipGetLastError());
+    return FIR_OK;
+}
+
+// The exchange step over all ranks, on `st`, result in `keys` (in place).
+int exchange_keys(fir_sharded* h, int slot, uint64_t* keys, int32_t qb, int32_t k, hipStream_t st) {
+    DevCtx& dc = h->devs[slot];
+    const size_t per = (size_t)qb * k;
+    const bool prof = h->profiling && slot == 0;
+    if (prof) {
+        if (dc.ev_used + 2 > dc.evs.size())
+            for (int i = 0; i < 64; ++i) {
+                hipEvent_t e;
+                SH_HIP(hipEventCreate(&e));
+                dc.evs.push_back(e);
+            }
+        SH_HIP(hipEventRecord(dc.evs[dc.ev_used], st));
+    }
+    if (k == 1) {
+        SH_NCCL(ncclAllReduce(keys, keys, per, ncclUint64, ncclMin, dc.comm, st));
+    } else {
+        int rc;
+        if ((rc = grow_dev(dc.gath, dc.gath_cap, per * (size_t)h->nranks))) return rc;
+        SH_NCCL(ncclAllGather(keys, dc.gath, per, ncclUint64, dc.comm, st));
+        hipLaunchKernelGGL(k_shard_merge_topk, dim3((qb + 63) / 64), dim3(64), 0, st, dc.gath, h->nranks, qb, k, keys);
+        SH_HIP(hipGetLastError());
+    }
+    if (prof) {
+        SH_HIP(hipEventRecord(dc.evs[dc.ev_used + 1], st));
+        dc.ev_used += 2;
+    }
+    return FIR_OK;
+}
+
+// class of every winning row: the rank that holds the row knows it, everyone else contributes INT32_MAX
+int device_classes(fir_sharded* h, int slot, const uint64_t* keys, int32_t qb, hipStream_t st) {
+    DevCtx& dc = h->devs[slot];
+    int rc;
+    if ((rc = grow_dev(dc.cls, dc.cls_cap, (size_t)qb))) return rc;
+    hipLaunchKernelGGL(k_shard_fill_i32, dim3((qb + 255) / 256), dim3(256), 0, st, dc.cls, qb, 0x7FFFFFFF);
+    for (int si : dc.shards) {
+        const Shard& s = h->shards[si];
+        if (!s.g || !s.cls) continue;
+        hipLaunchKernelGGL(k_shard_class_owned, dim3((qb + 255) / 256), dim3(256), 0, st, keys, qb, s.cls, s.lo, s.hi, dc.cls);
+    }
+    SH_HIP(hipGetLastError());
+    SH_NCCL(ncclAllReduce(dc.cls, dc.cls, (size_t)qb, ncclInt32, ncclMin, dc.comm, st));
+    return FIR_OK;
+}
+
+// Host-pointer search: queries go to every device from pinned memory, keys (and classes) come back from device slot 0.
+int search_host(fir_sharded* h, const float* queries, int32_t qb, int32_t start, int32_t end, int32_t k, int32_t* idx, float* dist,
+                int32_t* class_out) {
+    if (!h || (qb > 0 && !queries)) return sh_fail(FIR_ERR_ARG, "NULL argument");
+    if (qb < 0) return sh_fail(FIR_ERR_ARG, "qb < 0");
+    if (k < 1 || k > 8) return sh_fail(FIR_ERR_ARG, "k=%d outside [1,8]", k);
+    if (class_out && !h->has_labels) return sh_fail(FIR_ERR_STATE, "the sharded gallery was created without class labels");
+    if (qb == 0) return FIR_OK;
+    int rc = check_range(h, start, end);
+    if (rc) return rc;
+    const size_t qbytes = (size_t)qb * h->d * sizeof(float), kbytes = (size_t)qb * k * sizeof(uint64_t);
+    if ((rc = ensure_pin(h, qbytes + kbytes + (size_t)qb * sizeof(int32_t)))) return rc;
+    float* hq = (float*)h->pin;
+    uint64_t* hk = (uint64_t*)((char*)h->pin + qbytes);
+    int32_t* hc = (int32_t*)((char*)h->pin + qbytes + kbytes);
+    std::memcpy(hq, queries, qbytes);
+    rc = run_all(h, [&](int slot) -> int {
+        DevCtx& dc = h->devs[slot];
+        SH_HIP(hipSetDevice(dc.device));
+        int r;
+        if ((r = grow_dev(dc.dq, dc.dq_cap, (size_t)qb * h->d))) return r;
+        SH_HIP(hipMemcpyAsync(dc.dq, hq, qbytes, hipMemcpyHostToDevice, dc.stream));
+        if ((r = device_keys(h, slot, dc.dq, qb, start, end, k, dc.stream))) return r;
+        if ((r = exchange_keys(h, slot, dc.keys, qb, k, dc.stream))) return r;
+        if (class_out && (r = device_classes(h, slot, dc.keys, qb, dc.stream))) return r;
+        if (slot == 0) {
+            SH_HIP(hipMemcpyAsync(hk, dc.keys, kbytes, hipMemcpyDeviceToHost, dc.stream));
+            if (class_out) SH_HIP(hipMemcpyAsync(hc, dc.cls, (size_t)qb * sizeof(int32_t), hipMemcpyDeviceToHost, dc.stream));
+        }
+        SH_HIP(hipStreamSynchronize(dc.stream));
+        return FIR_OK;
+    });
+    if (rc) return rc;
+    if (class_out)
+        for (int i = 0; i < qb; ++i) class_out[i] = hc[i] == 0x7FFFFFFF ? -1 : hc[i];     // ImageTesting.cpp:63: no row found -> -1
+    if (idx || dist) return fir_keys_unpack(hk, qb * k, idx, dist);
+    return FIR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fir_comm_unique_id(void* id_out) {
+    if (!id_out) return sh_fail(FIR_ERR_ARG, "id_out is NULL");
+    static_assert(sizeof(ncclUniqueId) <= FIR_COMM_ID_BYTES, "FIR_COMM_ID_BYTES too small");
+    ncclUniqueId id;
+    SH_NCCL(ncclGetUniqueId(&id));
+    std::memset(id_out, 0, FIR_COMM_ID_BYTES);
+    std::memcpy(id_out, &id, sizeof id);
+    return FIR_OK;
+}
+
+int fir_sharded_destroy(fir_sharded* h) {
+    if (!h) return FIR_OK;
+    for (Shard& s : h->shards)
+        if (s.g) fir_gallery_destroy(s.g);
+    for (DevCtx& dc : h->devs) {
+        if (dc.worker) {
+            { std::lock_guard<std::mutex> lk(dc.worker->mu); dc.worker->quit = true; }
+            dc.worker->cv.notify_all();
+            if (dc.worker->th.joinable()) dc.worker->th.join();
+            delete dc.worker;
+        }
+        (void)hipSetDevice(dc.device);
+        if (dc.stream) (void)hipStreamSynchronize(dc.stream);
+        if (dc.comm) (void)ncclCommDestroy(dc.comm);
+        (void)hipFree(dc.dq); (void)hipFree(dc.parts); (void)hipFree(dc.keys); (void)hipFree(dc.gath); (void)hipFree(dc.cls);
+        for (hipEvent_t e : dc.evs) (void)hipEventDestroy(e);
+        if (dc.stream) (void)hipStreamDestroy(dc.stream);
+    }
+    if (h->pin) (void)hipHostFree(h->pin);
+    delete h;
+    return FIR_OK;
+}
+
+int fir_gallery_create_sharded_ex(const float* rows, int64_t n, int32_t d, const int32_t* class_no, int32_t metric, const int32_t* devices,
+                                  int32_t ndev, const fir_shard_opts* opts, fir_sharded** out) {
+    if (!out) return sh_fail(FIR_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (!devices || ndev < 1 || ndev > 64) return sh_fail(FIR_ERR_ARG, "device list of %d entries", ndev);
+    if (n < 0 || d <= 0 || (n > 0 && !rows)) return sh_fail(FIR_ERR_ARG, "bad gallery shape n=%lld d=%d", (long long)n, d);
+    fir_shard_opts o;
+    std::memset(&o, 0, sizeof o);
+    if (opts) {
+        if (opts->struct_bytes < 8 || opts->struct_bytes > (int32_t)sizeof o) return sh_fail(FIR_ERR_ARG, "fir_shard_opts.struct_bytes = %d", opts->struct_bytes);
+        std::memcpy(&o, opts, (size_t)opts->struct_bytes);
+    }
+    const int spd = o.shards_per_device > 0 ? o.shards_per_device : 1;
+    const int nprocs = o.comm_id ? o.nprocs : 1, proc = o.comm_id ? o.proc_rank : 0;
+    if (spd > 64) return sh_fail(FIR_ERR_ARG, "shards_per_device = %d", spd);
+    if (nprocs < 1 || proc < 0 || proc >= nprocs) return sh_fail(FIR_ERR_ARG, "process %d of %d", proc, nprocs);
+    if (o.rows_on_device && ndev != 1) return sh_fail(FIR_ERR_ARG, "device-resident rows need a one-entry device list (they live on one device)");
+    if (o.first_global_row < 0 || o.first_global_row + n >= ((int64_t)1 << 31)) return sh_fail(FIR_ERR_ARG, "rows [%lld, +%lld) do not fit 32-bit indices", (long long)o.first_global_row, (long long)n);
+    for (int i = 0; i < ndev; ++i)
+        for (int j = 0; j < i; ++j)
+            if (devices[i] == devices[j]) return sh_fail(FIR_ERR_ARG, "device %d listed twice (use shards_per_device for logical shards)", devices[i]);
+    const int cnt = fir_device_count();
+    for (int i = 0; i < ndev; ++i)
+        if (devices[i] < 0 || devices[i] >= cnt) return sh_fail(FIR_ERR_NODEVICE, "device %d out of range (%d visible)", devices[i], cnt);
+
+    fir_sharded* h = new (std::nothrow) fir_sharded();
+    if (!h) return sh_fail(FIR_ERR_NOMEM, "host allocation failed");
+    h->d = d; h->metric = metric; h->n_local = n; h->first_row = o.first_global_row;
+    h->ndev = ndev; h->spd = spd; h->nranks = nprocs * ndev; h->rank0 = proc * ndev;
+    h->has_labels = class_no != nullptr;
+    h->devs.resize((size_t)ndev);
+    int rc = FIR_OK;
+    auto bail = [&](int code) { fir_sharded_destroy(h); return code; };
+
+    // shards: whole 64-row tiles, contiguous, device-major (device i holds shards i*spd .. i*spd+spd-1)
+    const int nsh = ndev * spd;
+    const int64_t tiles = (n + fir::kTileRows - 1) / fir::kTileRows;
+    const int64_t per = ((tiles + nsh - 1) / nsh) * fir::kTileRows;
+    h->shards.resize((size_t)nsh);
+    for (int s = 0; s < nsh && rc == FIR_OK; ++s) {
+        Shard& sh = h->shards[(size_t)s];
+        sh.slot = s / spd;
+        const int64_t lo = std::min<int64_t>((int64_t)s * per, n), hi = std::min<int64_t>((int64_t)(s + 1) * per, n);
+        sh.lo = o.first_global_row + lo;
+        sh.hi = o.first_global_row + hi;
+        h->devs[(size_t)sh.slot].shards.push_back(s);
+        if (hi <= lo) continue;
+        const int dev = devices[sh.slot];
+        if (o.rows_on_device) rc = fir_gallery_create_dev(rows + lo * d, hi - lo, d, class_no ? class_no + lo : nullptr, metric, dev, nullptr, &sh.g);
+        else rc = fir_gallery_create(rows + lo * d, hi - lo, d, class_no ? class_no + lo : nullptr, metric, dev, &sh.g);
+        if (rc == FIR_OK) rc = fir_gallery_set_row_offset(sh.g, sh.lo);
+        if (rc == FIR_OK) {
+            fir_gallery_view v;
+            fir_gallery_view_(sh.g, &v);
+            sh.cls = v.cls;
+        }
+    }
+    if (rc) return bail(rc);
+
+    // per-device stream, events, communicator (rank = proc * ndev + slot)
+    ncclUniqueId id;
+    if (o.comm_id) std::memcpy(&id, o.comm_id, sizeof id);
+    else if (ncclGetUniqueId(&id) != ncclSuccess) return bail(sh_fail(FIR_ERR_COMM, "ncclGetUniqueId failed"));
+    for (int s = 0; s < ndev; ++s) {
+        DevCtx& dc = h->devs[(size_t)s];
+        dc.device = devices[s];
+        hipError_t e = hipSetDevice(dc.device);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&dc.stream, hipStreamNonBlocking);
+        if (e != hipSuccess) return bail(sh_fail(FIR_ERR_HIP, "device %d set-up: %s", dc.device, hipGetErrorString(e)));
+    }
+    ncclResult_t nr = ncclGroupStart();
+    for (int s = 0; s < ndev && nr == ncclSuccess; ++s) {
+        (void)hipSetDevice(h->devs[(size_t)s].device);
+        nr = ncclCommInitRank(&h->devs[(size_t)s].comm, h->nranks, id, h->rank0 + s);
+    }
+    if (nr == ncclSuccess) nr = ncclGroupEnd(); else (void)ncclGroupEnd();
+    if (nr != ncclSuccess) return bail(sh_fail(FIR_ERR_COMM, "RCCL communicator of %d ranks: %s", h->nranks, ncclGetErrorString(nr)));
+    if (ndev > 1)
+        for (int s = 0; s < ndev; ++s) {
+            Worker* w = new (std::nothrow) Worker();
+            if (!w) return bail(sh_fail(FIR_ERR_NOMEM, "host allocation failed"));
+            h->devs[(size_t)s].worker = w;
+            w->th = std::thread([w] { w->loop(); });
+        }
+    *out = h;
+    return FIR_OK;
+}
+
+int fir_gallery_create_sharded(const float* rows, int64_t n, int32_t d, const int32_t* class_no, int32_t metric, const int32_t* devices,
+                               int32_t ndev, fir_sharded** out) {
+    return fir_gallery_create_sharded_ex(rows, n, d, class_no, metric, devices, ndev, nullptr, out);
+}
+
+int fir_sharded_info(const fir_sharded* h, int64_t* n_local, int32_t* d, int32_t* ndev, int32_t* nshards, int32_t* nranks, int32_t* first_rank) {
+    if (!h) return sh_fail(FIR_ERR_ARG, "handle is NULL");
+    if (n_local) *n_local = h->n_local;
+    if (d) *d = h->d;
+    if (ndev) *ndev = h->ndev;
+    if (nshards) *nshards = (int32_t)h->shards.size();
+    if (nranks) *nranks = h->nranks;
+    if (first_rank) *first_rank = h->rank0;
+    return FIR_OK;
+}
+
+int fir_sharded_shard(fir_sharded* h, int32_t i, fir_gallery** g, int64_t* first_global_row, int64_t* rows) {
+    if (!h || i < 0 || i >= (int32_t)h->shards.size()) return sh_fail(FIR_ERR_ARG, "shard %d of %d", i, h ? (int)h->shards.size() : 0);
+    if (g) *g = h->shards[(size_t)i].g;
+    if (first_global_row) *first_global_row = h->shards[(size_t)i].lo;
+    if (rows) *rows = h->shards[(size_t)i].hi - h->shards[(size_t)i].lo;
+    return FIR_OK;
+}
+
+int fir_sharded_set_metric(fir_sharded* h, int32_t metric) {
+    if (!h) return sh_fail(FIR_ERR_ARG, "handle is NULL");
+    for (Shard& s : h->shards)
+        if (s.g) { const int rc = fir_gallery_set_metric(s.g, metric); if (rc) return rc; }
+    h->metric = metric;
+    return FIR_OK;
+}
+
+int fir_sharded_search_top1(fir_sharded* h, const float* queries, int32_t qb, int32_t start_pos, int32_t end_pos, int32_t* idx, float* dist) {
+    return search_host(h, queries, qb, start_pos, end_pos, 1, idx, dist, nullptr);
+}
+
+int fir_sharded_search_topk(fir_sharded* h, const float* queries, int32_t qb, int32_t start_pos, int32_t end_pos, int32_t k, int32_t* idx,
+                            float* dist) {
+    return search_host(h, queries, qb, start_pos, end_pos, k, idx, dist, nullptr);
+}
+
+int fir_sharded_classify_top1(fir_sharded* h, const float* queries, int32_t qb, int32_t start_pos, int32_t end_pos, int32_t* class_out,
+                              int32_t* idx, float* dist) {
+    if (!class_out) return sh_fail(FIR_ERR_ARG, "class_out is NULL");
+    return search_host(h, queries, qb, start_pos, end_pos, 1, idx, dist, class_out);
+}
+
+int fir_sharded_search_top1_keys_dev(fir_sharded* h, const float* d_queries, int32_t qb, int32_t start_pos, int32_t end_pos, uint64_t* d_keys,
+                                     void* stream) {
+    if (!h || !d_keys || (qb > 0 && !d_queries)) return sh_fail(FIR_ERR_ARG, "NULL argument");
+    if (h->ndev != 1) return sh_fail(FIR_ERR_STATE, "device-pointer calls need a one-device handle (one process per GPU); this one lists %d", h->ndev);
+    if (qb < 0) return sh_fail(FIR_ERR_ARG, "qb < 0");
+    if (qb == 0) return FIR_OK;
+    int rc = check_range(h, start_pos, end_pos);
+    if (rc) return rc;
+    DevCtx& dc = h->devs[0];
+    SH_HIP(hipSetDevice(dc.device));
+    hipStream_t st = stream ? (hipStream_t)stream : dc.stream;
+    if ((rc = device_keys(h, 0, d_queries, qb, start_pos, end_pos, 1, st))) return rc;
+    if ((rc = exchange_keys(h, 0, dc.keys, qb, 1, st))) return rc;
+    SH_HIP(hipMemcpyAsync(d_keys, dc.keys, (size_t)qb * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
+    return FIR_OK;
+}
+
+int fir_sharded_sync(fir_sharded* h) {
+    if (!h) return sh_fail(FIR_ERR_ARG, "handle is NULL");
+    for (DevCtx& dc : h->devs) {
+        SH_HIP(hipSetDevice(dc.device));
+        SH_HIP(hipStreamSynchronize(dc.stream));
+    }
+    return FIR_OK;
+}
+
+int fir_sharded_profile_enable(fir_sharded* h, int32_t on) {
+    if (!h) return sh_fail(FIR_ERR_ARG, "handle is NULL");
+    h->profiling = on != 0;
+    h->devs[0].ev_used = 0;
+    return FIR_OK;
+}
+
+int fir_sharded_profile_read(fir_sharded* h, float* exchange_ms, int32_t cap, int32_t* count) {
+    if (!h) return sh_fail(FIR_ERR_ARG, "handle is NULL");
+    DevCtx& dc = h->devs[0];
+    SH_HIP(hipSetDevice(dc.device));
+    const int32_t have = (int32_t)(dc.ev_used / 2);
+    for (int32_t i = 0; i < have; ++i) {
+        SH_HIP(hipEventSynchronize(dc.evs[2 * (size_t)i + 1]));
+        float ms = 0.f;
+        SH_HIP(hipEventElapsedTime(&ms, dc.evs[2 * (size_t)i], dc.evs[2 * (size_t)i + 1]));
+        if (exchange_ms && i < cap) exchange_ms[i] = ms;
+    }
+    if (count) *count = have;
+    dc.ev_used = 0;
+    return FIR_OK;
+}
+
+}  // extern "C"

@@ -46,7 +46,8 @@ enum {
     FIR_ERR_HIP = -2,      /* a HIP runtime call failed                      */
     FIR_ERR_NOMEM = -3,    /* host or device allocation failed               */
     FIR_ERR_NODEVICE = -4, /* no gfx950 device / device index out of range   */
-    FIR_ERR_STATE = -5     /* call not valid for this handle (e.g. no labels) */
+    FIR_ERR_STATE = -5,    /* call not valid for this handle (e.g. no labels) */
+    FIR_ERR_COMM = -6      /* an RCCL call failed                             */
 };
 
 #define FIR_NOT_FOUND_DIST 100000.0f
@@ -242,11 +243,67 @@ int fir_gemm_create(fir_gallery* g, fir_gemm** out);   /* = fir_gemm_create_ex(g
 int fir_gemm_create_ex(fir_gallery* g, int32_t precision, fir_gemm** out);
 int fir_gemm_destroy(fir_gemm* m);
 int fir_gemm_search_top1_keys_dev(fir_gemm* m, const float* d_queries, int32_t qb, uint64_t* d_keys, void* stream);
-/* Opt-in for the host-pointer call: fir_search_top1 sends L2 whole-range batches of >= min_queries queries through
- * the matrix-core path (created on first use, costs the extra gallery copy); 0 switches it off and frees the copy. */
+/* fir_search_top1 and fir_search_top1_keys_dev send L2 whole-range batches through this path BY DEFAULT when the batch
+ * has >= 128 queries and the gallery >= 65536 rows (created on first use; costs the extra fp16 gallery copy, n*d*2
+ * bytes; identical keys). min_queries > 0: the caller's threshold instead (any gallery size); 0: never, frees the copy
+ * (the exact streaming scan answers everything); < 0: back to the default. */
 int fir_gallery_set_large_batch_mfma(fir_gallery* g, int32_t min_queries);
 /* passes = 64-query GEMM passes run so far, fallback_queries = queries answered by the exact scan instead. */
 int fir_gemm_stats(const fir_gemm* m, int64_t* passes, int64_t* fallback_queries);
+
+/* ---- one gallery sharded by rows over several GPUs (BASELINE.json configs[3]) -----------------
+ * The reference is single threaded and single device; this is how BruteForce::recognize (ann.cpp:113-126) and
+ * BruteForceClassifier::recognize (ImageTesting.cpp:58-71) use a whole node. Rows are split into contiguous blocks
+ * of whole 64-row tiles, one block (or shards_per_device blocks) per listed device; every shard scans the batch and
+ * the ranks exchange
+ *   top-1: ncclAllReduce(ncclMin, ncclUint64) over the packed keys -- the low word is the GLOBAL row index, so the
+ *          integer minimum is the first-minimum rule of db_features.cpp:329-332 over the whole gallery;
+ *   top-K: ncclAllGather of K keys per query per rank + an integer K-way merge;
+ *   class: ncclAllReduce(ncclMin, ncclInt32) of classNo-if-I-hold-the-winning-row.
+ * RCCL over xGMI; the handle owns the per-device streams and communicators. Results are identical to the
+ * one-device calls on the unsplit gallery (index, distance bits, tie-break). */
+typedef struct fir_sharded fir_sharded;
+#define FIR_COMM_ID_BYTES 128
+typedef struct fir_shard_opts {
+    int32_t struct_bytes;       /* sizeof(fir_shard_opts) */
+    int32_t shards_per_device;  /* logical shards per listed device (0 or 1: one); > 1 exercises the split on few GPUs   */
+    int64_t first_global_row;   /* global index of rows[0]: this process's row block in a multi-process gallery          */
+    const void* comm_id;        /* NULL: this process holds the whole gallery. Else FIR_COMM_ID_BYTES bytes that process 0
+                                 * got from fir_comm_unique_id and handed to every process (any out-of-band channel)     */
+    int32_t proc_rank, nprocs;  /* with comm_id: this process among nprocs; each lists the same NUMBER of devices        */
+    int32_t rows_on_device;     /* 1: rows / class_no are device pointers on devices[0] (one-entry device list only)     */
+    int32_t reserved;
+} fir_shard_opts;
+int fir_comm_unique_id(void* id_out /* [FIR_COMM_ID_BYTES] */);
+/* Single process, all rows, one shard per listed device. devices[ndev]: HIP device indices, no repeats. */
+int fir_gallery_create_sharded(const float* rows, int64_t n, int32_t d, const int32_t* class_no, int32_t metric,
+                               const int32_t* devices, int32_t ndev, fir_sharded** out);
+/* General form. Collective over all processes of the communicator (like every search call below). */
+int fir_gallery_create_sharded_ex(const float* rows, int64_t n, int32_t d, const int32_t* class_no, int32_t metric,
+                                  const int32_t* devices, int32_t ndev, const fir_shard_opts* opts, fir_sharded** out);
+int fir_sharded_destroy(fir_sharded* h);
+int fir_sharded_info(const fir_sharded* h, int64_t* n_local, int32_t* d, int32_t* ndev, int32_t* nshards, int32_t* nranks,
+                     int32_t* first_rank);
+/* Shard i of this process (borrowed: tuning, profiling; NULL when the shard holds no rows), its first global row, its rows. */
+int fir_sharded_shard(fir_sharded* h, int32_t i, fir_gallery** g, int64_t* first_global_row, int64_t* rows);
+int fir_sharded_set_metric(fir_sharded* h, int32_t metric);
+/* fir_search_top1 / fir_search_topk over the whole sharded gallery; indices are global rows. */
+int fir_sharded_search_top1(fir_sharded* h, const float* queries, int32_t qb, int32_t start_pos, int32_t end_pos,
+                            int32_t* idx, float* dist);
+int fir_sharded_search_topk(fir_sharded* h, const float* queries, int32_t qb, int32_t start_pos, int32_t end_pos,
+                            int32_t k, int32_t* idx, float* dist);
+/* Batched BruteForceClassifier::recognize (ImageTesting.cpp:58-71): class_out[qb] <- classNo of the nearest row or -1;
+ * idx / dist may be NULL. Needs class labels. */
+int fir_sharded_classify_top1(fir_sharded* h, const float* queries, int32_t qb, int32_t start_pos, int32_t end_pos,
+                              int32_t* class_out, int32_t* idx, float* dist);
+/* One process per GPU (one-entry device list): device pointers on that GPU, asynchronous on `stream`
+ * (NULL = the handle's); d_keys[qb] <- the reduced keys, identical on every rank. */
+int fir_sharded_search_top1_keys_dev(fir_sharded* h, const float* d_queries, int32_t qb, int32_t start_pos,
+                                     int32_t end_pos, uint64_t* d_keys, void* stream);
+int fir_sharded_sync(fir_sharded* h);
+/* HIP events around the exchange step on this process's first device: durations (ms) since the previous read. */
+int fir_sharded_profile_enable(fir_sharded* h, int32_t on);
+int fir_sharded_profile_read(fir_sharded* h, float* exchange_ms, int32_t cap, int32_t* count);
 
 /* ---- profiling ------------------------------------------------------------------------------
  * When enabled, every gallery-scan kernel launch is bracketed by HIP events on the stream it
@@ -255,6 +312,22 @@ int fir_gemm_stats(const fir_gemm* m, int64_t* passes, int64_t* fallback_queries
  * LAST launch (gallery range + query tile + keys). */
 int fir_profile_enable(fir_gallery* g, int32_t on);
 int fir_profile_read(fir_gallery* g, float* ms, int32_t cap, int32_t* count, double* bytes_per_launch);
+/* What the most recent top-1 search on this handle dispatched: its dominant kernel (the gallery-streaming one) as the
+ * library launched it, with the code object's resource numbers -- so that a benchmark reports the kernel that ran,
+ * not the one it expects. With profiling on, fir_profile_read's durations are the launches of exactly this kernel. */
+typedef struct fir_dispatch_info {
+    int32_t struct_bytes;     /* in: sizeof(fir_dispatch_info) */
+    int32_t path;             /* 0 = exact streaming scan; 1 = matrix-core nomination + exact re-rank + certificate */
+    char kernel[160];         /* e.g. "fir::k_scan_l2_lds<1, 8, 4, false>" */
+    int32_t launches;         /* launches of it in that call */
+    int32_t grid_x, grid_y, block;
+    int32_t lds_bytes;        /* static + dynamic LDS of one workgroup */
+    int32_t vgprs;            /* registers per lane (hipFuncGetAttributes) */
+    int32_t queries_per_pass; /* queries that share one read of the gallery */
+    double bytes_per_launch;  /* algorithmic HBM bytes of one launch */
+    double flops_per_launch;  /* matrix-core path: 2 * rows * d * queries of one launch; 0 for the scan */
+} fir_dispatch_info;
+int fir_gallery_last_dispatch(fir_gallery* g, fir_dispatch_info* out);
 
 /* Chi-square / KL galleries: which division sequence the scans use. The IEEE f32 division the compiler emits carries
  * scaling and fix-up steps for operands near the ends of the exponent range; when every gallery value and every query

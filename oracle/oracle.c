@@ -77,6 +77,27 @@ int64_t orc_recognize_bf(const float* rows, int64_t n, int d, const float* query
     return bestInd;
 }
 
+/* The "CPU-all" row of BASELINE.md section 3: recognize_image_bf for a batch of queries, one query per OpenMP thread at a
+ * time (queries are independent; every query's arithmetic is orc_recognize_bf's, so the results are bit-identical to
+ * the single-threaded reference). Returns the number of threads used. */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+int orc_recognize_bf_batch_omp(const float* rows, int64_t n, int d, const float* queries, int nq, int start_pos, int end_pos,
+                               int metric, int64_t* idx_out, float* dist_out) {
+    int threads = 1;
+#ifdef _OPENMP
+    threads = omp_get_max_threads();
+#pragma omp parallel for schedule(dynamic, 1)
+#endif
+    for (int q = 0; q < nq; ++q) {
+        float bd = 100000.0f;
+        idx_out[q] = orc_recognize_bf(rows, n, d, queries + (int64_t)q * d, start_pos, end_pos, metric, &bd);
+        dist_out[q] = bd;
+    }
+    return threads;
+}
+
 /* K smallest rows of the reference's distance vector (db_features.cpp:325-333 generalised from
  * 1 to K winners): ascending distance, equal distances in ascending row order, only rows with
  * distance < 100000, unused slots idx = -1 / dist = 100000. K = 1 equals orc_recognize_bf. */

@@ -29,6 +29,7 @@ def test_library_exports_every_declared_symbol(fir):
 def test_no_torch_or_oracle_in_the_product_library(fir):
     out = os.popen(f"ldd {fir.lib_path()}").read()
     assert "libamdhip64" in out
+    assert "librccl" in out        # the row-sharded gallery reduces its keys with RCCL inside the library
     assert "torch" not in out and "oracle" not in out and "libref" not in out
 
 
@@ -57,3 +58,5 @@ def test_device_calls_fail_loudly_without_a_gpu(fir):
         fir.Gallery(np.zeros((4, 8), np.float32), None, 0, 0)
     with pytest.raises(fir.FirError):
         fir.feature_distance(np.zeros(8, np.float32), np.zeros(8, np.float32))
+    with pytest.raises(fir.FirError):
+        fir.ShardedGallery(np.zeros((4, 8), np.float32), None, 0, devices=[0])

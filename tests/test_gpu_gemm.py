@@ -191,3 +191,45 @@ def test_long_rows(fir, precision):
         assert np.array_equal(idx, eidx), d
         assert np.array_equal(dist.view(np.uint32), edist.view(np.uint32)), d
         assert idx[0] == 3
+
+
+def test_default_dispatch_takes_the_matrix_cores_for_big_batches_over_big_galleries(fir, oracle):
+    """No opt-in: >= 128 queries against >= 65536 rows (L2, whole range) go through fir_gemm_* by default, smaller batches,
+    smaller galleries, sub-ranges and chi-square stay with the exact scan; fir_gallery_last_dispatch says which kernel ran;
+    set_large_batch_mfma(0) is the opt-out. Keys are identical either way, and the oracle's on a sample."""
+    n, d = 70000, 64
+    rows = synth.make_gallery(23, n, d, 0)
+    q, _ = synth.make_queries(23, rows, 300, 0)
+    rows[n - 1] = rows[7]
+    q[3] = rows[7]                                    # exact tie: the first row wins on either path
+    with fir.Gallery(rows, None, 0, 0) as g:
+        a = g.search_top1(q)
+        da = g.last_dispatch()
+        assert da["path"] == "mfma" and "k_gemm_proxy_f16<1" in da["kernel"] and da["queries_per_pass"] == 128
+        assert da["lds_bytes"] >= 128 * 1024 and da["vgprs"] > 0 and da["flops_per_launch"] > 0 and da["bytes_per_launch"] > 0
+        b = g.search_top1(q[:100])                    # below 128 queries
+        assert g.last_dispatch()["path"] == "scan"
+        c = g.search_top1(q, 0, 32)                   # a sub-range
+        assert g.last_dispatch()["path"] == "scan"
+        g.set_large_batch_mfma(0)                     # opt-out
+        e = g.search_top1(q)
+        de = g.last_dispatch()
+        assert de["path"] == "scan" and "k_scan_l2" in de["kernel"] and de["flops_per_launch"] == 0
+        g.set_large_batch_mfma(-1)                    # back to the default
+        f = g.search_top1(q)
+        assert g.last_dispatch()["path"] == "mfma"
+    assert np.array_equal(a[0], e[0]) and np.array_equal(a[1].view(np.uint32), e[1].view(np.uint32))
+    assert np.array_equal(a[0], f[0]) and np.array_equal(a[0][:100], b[0]) and c[0].shape == (300,)
+    assert a[0][3] == 7
+    eidx, edist = oracle.top1_batch(rows, q[:40], 0, d, 0)
+    assert np.array_equal(a[0][:40], eidx) and np.array_equal(a[1][:40].view(np.uint32), edist.view(np.uint32))
+    small = synth.make_gallery(24, 20000, 64, 0)
+    with fir.Gallery(small, None, 0, 0) as g:         # below 65536 rows: the scan, unless asked for
+        g.search_top1(q)
+        assert g.last_dispatch()["path"] == "scan"
+        g.set_large_batch_mfma(128)
+        g.search_top1(q)
+        assert g.last_dispatch()["path"] == "mfma"
+    with fir.Gallery(synth.make_gallery(25, 70000, 64, 1), None, 1, 0) as g:     # chi-square never
+        g.search_top1(synth.make_queries(25, rows, 130, 1)[0])
+        assert g.last_dispatch()["path"] == "scan"
