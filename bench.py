@@ -134,6 +134,25 @@ def spawn_ranks(args):
     emit_line(line)
 
 
+def host_cores():
+    """CPUs this process may actually use: the affinity mask, cut to the cgroup's CPU quota when one is set (a one-GPU box hands
+    out a share of the host: 256 hardware threads in the mask, 16 CPUs of quota)."""
+    n = max(1, len(os.sched_getaffinity(0)))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, int(quota / period + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_model():
     try:
         for ln in open("/proc/cpuinfo"):
@@ -408,7 +427,8 @@ def main():
         if hd["path"] == "mfma" and len(head["kernel_ms"]):
             tf = hd["flops_per_launch"] / (h_avg * 1e-3) / 1e12
             gbs = hd["bytes_per_launch"] / (h_avg * 1e-3) / 1e9
-            roofline_mfma = {"bound": "hbm (fp16 gallery stream, read once per 128 queries); the MFMA pipe is the second roof",
+            roofline_mfma = {"bound": "mfma" if tf / PEAK_MFMA_F16_TFLOPS >= gbs / peak_gbs else "hbm",
+                             "note": f"fp16 gallery fragments leave HBM once per {hd['queries_per_pass']} queries (the pairs of a launch walk the same rows together and share the stream through L2)",
                              "flops_per_launch": hd["flops_per_launch"], "achieved_tflops": tf, "peak_tflops": PEAK_MFMA_F16_TFLOPS, "frac_of_mfma_peak": tf / PEAK_MFMA_F16_TFLOPS,
                              "stream_GBps": gbs, "peak_GBps": peak_gbs, "frac_of_hbm_peak": gbs / peak_gbs, "traffic": traffic.get("mfma"),
                              "kernel_time_share_of_step": float(np.sum(head["kernel_ms"])) / (head["elapsed"] * 1e3) if world == 1 else None, **h_blk}
@@ -516,6 +536,8 @@ def other_scans(fir, g, q, keys, dev, ws, n, d):
             # each pass is launched as a (full, plain-range) pair of which one returns at once: per-pass time = sum over the pair
             per_pass_ms = float(np.mean(ms)) if len(ms) else float("nan")
             qpp = dsp["queries_per_pass"]
+            passes = max(1, dsp["grid"][1])                          # query tiles folded into one launch (blockIdx.y)
+            per_pass_ms /= passes
             elems_per_pass = float(n) * d * qpp
             wave_instr_per_s = elems_per_pass / 64.0 * slots / (per_pass_ms * 1e-3) if per_pass_ms == per_pass_ms else float("nan")
             also[f"roofline_{name}"] = {"bound": "valu", "model": f"{slots} VALU issue slots per (row, feature, query) element in the plain-range form (DESIGN.md section 4), "
@@ -647,8 +669,9 @@ def cpu_baselines(rows, queries, gpu_idx, gpu_dist, budget_s):
     oracle/_ref is not present);  `all`: the C restatement with OpenMP over queries (bit-identical arithmetic)."""
     import oracle_lib
 
-    cores = max(1, len(os.sched_getaffinity(0)))
-    model = cpu_model()
+    cores = host_cores()
+    mask = len(os.sched_getaffinity(0))
+    model = cpu_model() + f" ({mask} hardware threads in the affinity mask, {cores} usable under the cgroup CPU quota)"
     d = rows.shape[1]
     kind = "reference" if oracle_lib.have_ref() else "port"
     orc = oracle_lib.load_oracle()
@@ -683,7 +706,7 @@ def cpu_baselines(rows, queries, gpu_idx, gpu_dist, budget_s):
                      f"{cores} threads x recognize_image_bf ({t_one:.2f} s/query/thread); GPU index identical on {agree}/{nq}"}
     # CPU-all: OpenMP over queries, same sample size
     t0 = time.perf_counter()
-    oi, od, threads = orc.top1_batch_omp(rows, queries[:nq], 0, d, 0)
+    oi, od, threads = orc.top1_batch_omp(rows, queries[:nq], 0, d, 0, threads=cores)
     dt2 = time.perf_counter() - t0
     same = int(np.sum((oi == gpu_idx[:nq]) & (od.view(np.uint32) == np.ascontiguousarray(gpu_dist[:nq], np.float32).view(np.uint32))))
     allc = {"value": nq / dt2, "unit": "queries/s", "cores": threads, "cpu_model": model, "kind": "port",

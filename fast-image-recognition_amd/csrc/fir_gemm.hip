@@ -42,7 +42,7 @@ constexpr int kGemmMinBlocks = kGemmBlock <= 512 ? 2 : 1;
 constexpr int kQT = 64;                // queries per pass (2 accumulator tiles of 32 per wave)
 constexpr int kSlab8 = 64;             // query features staged in LDS at a time, in groups of 8 (512 features)
 constexpr int kSlab16 = 32;            // bf16 variant: k-blocks of 16 features staged at a time (512 features)
-constexpr int kPasses = 8;             // 64-query passes folded into one set of launches (blockIdx.y): their tails overlap
+constexpr int kPasses = 16;            // 64-query passes per super-batch (one set of launches, one set of scratch): 1024 queries
 constexpr int kCand = 8;               // tau = the kCand-th smallest SAMPLED proxy (so ~kCand * n / sample rows get appended)
 constexpr int kRerankGroup = 8;         // candidate rows staged in LDS at a time by the re-rank (fewer when rows are longer than ~4000 features)
 constexpr size_t kRerankLdsMax = 144 * 1024;
@@ -610,7 +610,7 @@ __device__ __forceinline__ f16x8 as_f16x8(const uint4 v) {
 }
 constexpr int kSlabH = 32;                                              // k-blocks (of 16 features) of the 128-query slab
 constexpr int kHalfLds = 4 * kSlabH * 64 * (int)sizeof(uint4);          // 128 KiB
-constexpr int kRing = 16;                                               // gallery k-blocks per double-buffer unit; the fp16 dk16 is padded to it
+constexpr int kRing = 8;                                                // gallery k-blocks per double-buffer unit (8 KiB per wave); the fp16 dk16 is padded to it
 
 // max |x| over the tiled gallery (padding is zero) -> out[0]; out must be zeroed first. Non-finite values poison it (NaN -> +inf).
 __global__ void __launch_bounds__(256) k_gemm_absmax(const float4* __restrict__ gal4, int64_t count4, float* __restrict__ out) {
@@ -728,11 +728,30 @@ template <int MODE, int STREAMED>
 __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16(const uint4* __restrict__ gh, const float* __restrict__ gnorm, const uint4* qh,
                                                                    const float* __restrict__ qinv, int64_t n, int64_t row_begin, int64_t row_end,
                                                                    int dk16, const float* tau, unsigned long long* lists, int* counts,
-                                                                   float* sample, int sample_rows) {
+                                                                   float* sample, int sample_rows, int share, int nt) {
     extern __shared__ __attribute__((aligned(16))) uint4 lqb[];
     __shared__ float tau_s[2 * kQT], qinv_s[2 * kQT];
+    // Which pair of passes (128 queries) and which row groups this workgroup takes.
+    // share == 0: blockIdx.y = pair, row groups blockIdx.x, + gridDim.x, ... (the sample pass).
+    // share == P (a power of two, the full pass): ONE workgroup per CU, all resident at once; the P pairs of the launch read the
+    // gallery TOGETHER: the row groups are cut into gridDim.x / P contiguous ranges and P workgroups -- one per pair, placed on the
+    // same XCD (blocks b and b + 8 share one) -- walk the same range at the same time, so the fp16 gallery stream leaves HBM once
+    // per P * 128 queries and the other P - 1 readers hit in the XCD's L2 (or, when they drift apart, in the Infinity Cache).
+    int pair_of_wg = (int)blockIdx.y;
+    int64_t rg_first = blockIdx.x, rg_step = gridDim.x, rg_last = -1;      // rg_last < 0: up to nrg
+    if (share > 0) {
+        const int w = (int)blockIdx.x, xcd = w & 7, slot = w >> 3;
+        const int ranges = ((int)gridDim.x >> 3) / share * 8;             // whole groups of `share` slots per XCD
+        const int range = xcd + 8 * (slot / share);
+        if (range >= ranges) return;                                       // uniform per workgroup
+        pair_of_wg = slot % share;
+        const int64_t nrg_all = (((row_end + 31) / 32 - row_begin / 32) + (blockDim.x >> 6) - 1) / (blockDim.x >> 6);
+        rg_first = nrg_all * range / ranges;
+        rg_last = nrg_all * (range + 1) / ranges;
+        rg_step = 1;
+    }
     {
-        const size_t pr = blockIdx.y;
+        const size_t pr = (size_t)pair_of_wg;
         qh += pr * 4 * dk16 * 64;
         qinv += pr * 2 * kQT;
         tau += pr * 2 * kQT;
@@ -750,15 +769,20 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16(const uint4* _
     const int64_t nrg = (rb_end - rb_begin + wpb - 1) / wpb;
     const int units = dk16 / kRing;                  // units of kRing k-blocks per row block
     const int nslab = (dk16 + kSlabH - 1) / kSlabH;
-    int64_t rg = blockIdx.x;
-    if (rg >= nrg) return;                           // uniform per workgroup
+    const int64_t rg_end = rg_last >= 0 ? rg_last : nrg;
+    int64_t rg = rg_first;
+    if (rg >= rg_end) return;                        // uniform per workgroup
+    // streamed once per launch from HBM: non-temporal; shared between the pairs of a launch: ordinary loads, so that the line
+    // stays in L2 for the other readers
+#define FIR_H_LD(P) (nt ? ld_nt(P) : *(P))
 #define FIR_H_BLOCK(RG) (gh + (size_t)((rb_begin + (RG) * wpb + wave) < rb_end ? (rb_begin + (RG) * wpb + wave) : rb_end - 1) * dk16 * 64 + lane)
     const uint4* a_cur = FIR_H_BLOCK(rg);            // waves past the last row block stream a valid one and drop the result
     uint4 cur[kRing], nxt[kRing];
 #pragma unroll
-    for (int u = 0; u < kRing; ++u) cur[u] = ld_nt(a_cur + (size_t)u * 64);
-    bool staged = false;
-    // STREAMED: unit hq of the query tile -> LDS buffer bsel; every wave moves its share of the 64 one-KiB pieces
+    for (int u = 0; u < kRing; ++u) cur[u] = FIR_H_LD(a_cur + (size_t)u * 64);
+    constexpr int kUnitsPerSlab = kSlabH / kRing;
+    const bool resident = !STREAMED && nslab == 1;   // the whole 128-query tile stays in LDS for the launch (d <= 512)
+    // STREAMED: unit hq of the query tile -> LDS buffer bsel; every wave moves its share of the 4 * kRing one-KiB pieces
     // (piece = (query block jb, k-block kb): 64 lanes x 16 B, contiguous in qh and in LDS)
     auto request_slab = [&](int hq, int bsel) {
         uint4* dst = lqb + (size_t)bsel * 4 * kRing * 64;
@@ -774,19 +798,41 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16(const uint4* _
         request_slab(0, 0);
         __builtin_amdgcn_s_waitcnt(0);               // (also the prologue's gallery loads: once per kernel)
         __syncthreads();
+    } else if (resident) {
+        for (int i = threadIdx.x; i < 4 * dk16 * 64; i += blockDim.x) {
+            const int jb = i / (dk16 * 64), r = i - jb * dk16 * 64;
+            lqb[(size_t)jb * kSlabH * 64 + r] = qh[(size_t)jb * dk16 * 64 + r];
+        }
+        __syncthreads();
     }
-    for (; rg < nrg; rg += gridDim.x) {
+    constexpr int jstride = (STREAMED ? kRing : kSlabH) * 64;        // uint4s between the query blocks of a k-block
+    // the four query fragments of the k-block the next MFMA group consumes: always read one group ahead
+    uint4 b0, b1, b2, b3;
+    if (resident) { const uint4* bu = lqb + lane; b0 = bu[0]; b1 = bu[jstride]; b2 = bu[2 * jstride]; b3 = bu[3 * jstride]; }
+    for (; rg < rg_end; rg += rg_step) {
         const int64_t rb = rb_begin + rg * wpb + wave;
         const bool active = rb < rb_end;
-        const int64_t rgn = rg + gridDim.x;
-        const uint4* a_nxt = FIR_H_BLOCK(rgn < nrg ? rgn : rg);
+        const int64_t rgn = rg + rg_step;
+        const uint4* a_nxt = FIR_H_BLOCK(rgn < rg_end ? rgn : rg);
         f32x16 acc0 = {0.f}, acc1 = {0.f}, acc2 = {0.f}, acc3 = {0.f};
+        float4 gn4[4];                               // this lane's 16 squared row norms (rows 8g + 4h + 0..3 of the block), for the epilogue
+        const bool full_block = active && rb * 32 >= row_begin && rb * 32 + 32 <= row_end && rb * 32 + 32 <= n && (MODE == 1 || rb * 32 + 32 <= sample_rows);
         for (int h = 0; h < units; ++h) {
             const uint4* src = h + 1 < units ? a_cur + (size_t)(h + 1) * kRing * 64 : a_nxt;
             if (STREAMED) request_slab(h + 1 < units ? h + 1 : 0, tsel ^ 1);   // its last readers passed the barrier that ended the previous unit
+            if (nt) {
 #pragma unroll
-            for (int u = 0; u < kRing; ++u) nxt[u] = ld_nt(src + (size_t)u * 64);
-            if (!STREAMED && (h & 1) == 0 && (nslab > 1 || !staged)) {      // a slab is two units
+                for (int u = 0; u < kRing; ++u) nxt[u] = ld_nt(src + (size_t)u * 64);
+            } else {
+#pragma unroll
+                for (int u = 0; u < kRing; ++u) nxt[u] = src[(size_t)u * 64];
+            }
+            if (h == units - 1 && full_block) {
+                const float4* gp = (const float4*)(gnorm + rb * 32 + 4 * (lane >> 5));
+#pragma unroll
+                for (int g = 0; g < 4; ++g) gn4[g] = gp[2 * g];
+            }
+            if (!STREAMED && !resident && (h % kUnitsPerSlab) == 0) {      // forced non-streamed form with rows longer than a slab: re-stage
                 const int k0 = h * kRing;
                 const int kw = dk16 - k0 < kSlabH ? dk16 - k0 : kSlabH;
                 __syncthreads();                                            // everyone is done with the previous slab
@@ -795,19 +841,28 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16(const uint4* _
                     lqb[(size_t)jb * kSlabH * 64 + r] = qh[((size_t)jb * dk16 + k0) * 64 + r];
                 }
                 __syncthreads();
-                staged = true;
             }
-            const uint4* bq = STREAMED ? lqb + lane + (size_t)tsel * 4 * kRing * 64 : lqb + lane + (size_t)(h & 1) * kRing * 64;
-            constexpr int jstride = (STREAMED ? kRing : kSlabH) * 64;        // uint4s between the query blocks of a k-block
+            const uint4* bq = STREAMED ? lqb + lane + (size_t)tsel * 4 * kRing * 64 : lqb + lane + (size_t)(h % kUnitsPerSlab) * kRing * 64;
+            if (!resident) { b0 = bq[0]; b1 = bq[jstride]; b2 = bq[2 * jstride]; b3 = bq[3 * jstride]; }
+            // where the fragments of the k-block AFTER this unit live, when that is known now (resident tile): the pipeline runs on
+            // through the unit boundary and through the epilogue into the wave's next row block
+            const uint4* bq_after = lqb + lane + (size_t)((h + 1 < units ? h + 1 : 0) % kUnitsPerSlab) * kRing * 64;
 #pragma unroll
             for (int u = 0; u < kRing; ++u) {
-                const uint4* bu = bq + (size_t)u * 64;
-                const uint4 b0 = bu[0], b1 = bu[jstride], b2 = bu[2 * jstride], b3 = bu[3 * jstride];
+                uint4 n0 = b0, n1 = b1, n2 = b2, n3 = b3;
+                if (u + 1 < kRing) {
+                    const uint4* bu = bq + (size_t)(u + 1) * 64;
+                    n0 = bu[0]; n1 = bu[jstride]; n2 = bu[2 * jstride]; n3 = bu[3 * jstride];
+                } else if (resident) {
+                    n0 = bq_after[0]; n1 = bq_after[jstride]; n2 = bq_after[2 * jstride]; n3 = bq_after[3 * jstride];
+                }
+                __builtin_amdgcn_sched_barrier(0);                           // the four reads of the next group stay ahead of this group's MFMAs
                 const f16x8 av = as_f16x8(cur[u]);
                 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, as_f16x8(b0), acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, as_f16x8(b1), acc1, 0, 0, 0);
                 acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, as_f16x8(b2), acc2, 0, 0, 0);
                 acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, as_f16x8(b3), acc3, 0, 0, 0);
+                b0 = n0; b1 = n1; b2 = n2; b3 = n3;
             }
 #pragma unroll
             for (int u = 0; u < kRing; ++u) cur[u] = nxt[u];
@@ -819,6 +874,44 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16(const uint4* _
         }
         a_cur = a_nxt;
         if (!active) continue;
+        if (full_block) {
+            // every row of the block is a live row of the pass: p = |g|^2 - 2 q.g per accumulator, one running minimum per lane and
+            // tile; only a lane whose minimum is below its query's tau looks at its 16 values again
+            const float gnv[16] = {gn4[0].x, gn4[0].y, gn4[0].z, gn4[0].w, gn4[1].x, gn4[1].y, gn4[1].z, gn4[1].w,
+                                   gn4[2].x, gn4[2].y, gn4[2].z, gn4[2].w, gn4[3].x, gn4[3].y, gn4[3].z, gn4[3].w};
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb) {
+                const int q = jb * 32 + (lane & 31);
+                const float m2 = 2.0f * qinv_s[q];
+                const float tq = tau_s[q];
+                float pv[16];
+                float mn = __builtin_huge_valf();
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const float dot = jb == 0 ? acc0[reg] : jb == 1 ? acc1[reg] : jb == 2 ? acc2[reg] : acc3[reg];
+                    pv[reg] = gnv[reg] - m2 * dot;
+                    mn = pv[reg] < mn ? pv[reg] : mn;                        // NaN never enters, like k_gemm_tau's ordering
+                }
+                if (MODE == 1) {
+                    if (mn < tq) {
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg) {
+                            if (pv[reg] < tq) {
+                                const int64_t row = rb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                                const int slot = atomicAdd(&counts[q], 1);
+                                if (slot < kListCap) lists[(size_t)q * kListCap + slot] = fir::key_pack(pv[reg], (uint32_t)row);
+                            }
+                        }
+                    }
+                } else {
+                    const float o = __shfl_xor(mn, 32, 64);
+                    mn = o < mn ? o : mn;
+                    if (lane < 32) sample[(size_t)(rb - rb_begin) * (2 * kQT) + q] = mn;
+                }
+            }
+            continue;
+        }
+        // a block that straddles the end of the rows (or of the sample): row by row
         const int64_t nrow = rb * 32 + (lane & 31);
         const float gn_lane = nrow < n ? gnorm[nrow] : 0.0f;
 #pragma unroll
@@ -852,6 +945,7 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16(const uint4* _
         }
     }
 #undef FIR_H_BLOCK
+#undef FIR_H_LD
 }
 
 // tau[q] = kCand-th smallest sampled proxy, nudged up so that ties with it are appended too. One block per
@@ -1083,6 +1177,7 @@ struct fir_gemm {
     int rerank_group = kRerankGroup;      // candidate rows the re-rank stages in LDS at a time
     int streamed = -1;                    // fp16: query slabs through the LDS double buffer (-1: when the tile does not fit, d > 512)
     bool wide = true;                     // bf16: pairs of passes through k_gemm_proxy_bf16_wide (FIR_GEMM_WIDE=0 turns it off)
+    int share_max = 8;                    // fp16: up to this many pairs of passes (x 128 queries) read the gallery together in one launch (FIR_GEMM_SHARE; 0 = the old one-pair-at-a-time grid)
 };
 
 
@@ -1106,7 +1201,7 @@ int fir_gemm_create_ex(fir_gallery* g, int32_t precision, fir_gemm** out) {
     if (const char* w = std::getenv("FIR_GEMM_WIDE")) m->wide = std::atoi(w) != 0;   // experiments: 0 = one pass per gallery read
     m->dq8 = (m->v.d + 31) / 32 * 4;     // feature groups of 8, padded to a multiple of 4 groups (zeros)
     m->dk16 = (m->v.d + 127) / 128 * 8;  // k-blocks of 16, padded to a multiple of 8 (the paired-pass kernel's double-buffer unit)
-    if (precision == FIR_GEMM_F16) m->dk16 = (m->v.d + 255) / 256 * kRing;   // ... to whole double-buffer units of 16
+    if (precision == FIR_GEMM_F16) m->dk16 = (m->v.d + 16 * kRing - 1) / (16 * kRing) * kRing;   // ... to whole double-buffer units
     hipError_t e = hipSetDevice(m->v.device);
     const int64_t rblocks = (std::max<int64_t>(m->v.n, 1) + 31) / 32;
     const int64_t np = std::max<int64_t>(m->v.n, 1);
@@ -1152,6 +1247,7 @@ int fir_gemm_create_ex(fir_gallery* g, int32_t precision, fir_gemm** out) {
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy_f16<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kHalfLds);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy_f16<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kHalfLds);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy_f16<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kHalfLds);
+    if (const char* w = std::getenv("FIR_GEMM_SHARE")) m->share_max = std::max(0, std::min(8, std::atoi(w)));
     if (const char* w = std::getenv("FIR_GEMM_STREAMED")) m->streamed = std::atoi(w);   // experiments: 0 / 1 force the form, -1 = by row length
     if (e == hipSuccess && m->v.n > 0) {
         // row norms come from the f32 packer (run on a one-group scratch when only the bf16 fragments are kept)
@@ -1273,10 +1369,10 @@ int fir_gemm_search_top1_keys_dev(fir_gemm* m, const float* d_queries, int32_t q
             const dim3 sgrid(std::min(sample_wgs, grid), pairs);
             if (streamed)
                 hipLaunchKernelGGL((k_gemm_proxy_f16<0, 1>), sgrid, dim3(kGemmBlock), kHalfLds, ps, m->gh, m->gnorm, m->qbf[b], m->qinv[b], n, (int64_t)0,
-                                   (int64_t)sample_rows, m->dk16, m->tau[b], m->lists[b], m->counts[b], m->sample, sample_rows);
+                                   (int64_t)sample_rows, m->dk16, m->tau[b], m->lists[b], m->counts[b], m->sample, sample_rows, 0, 1);
             else
                 hipLaunchKernelGGL((k_gemm_proxy_f16<0, 0>), sgrid, dim3(kGemmBlock), kHalfLds, ps, m->gh, m->gnorm, m->qbf[b], m->qinv[b], n, (int64_t)0,
-                                   (int64_t)sample_rows, m->dk16, m->tau[b], m->lists[b], m->counts[b], m->sample, sample_rows);
+                                   (int64_t)sample_rows, m->dk16, m->tau[b], m->lists[b], m->counts[b], m->sample, sample_rows, 0, 1);
             hipLaunchKernelGGL(k_gemm_tau, dim3(pairs * 2 * kQT), dim3(256), 0, ps, m->sample, (sample_rows + 31) / 32, m->tau[b], nq, m->qnorm[b], m->gmax,
                                e_rel, 2 * kQT);
         } else {
@@ -1312,22 +1408,44 @@ int fir_gemm_search_top1_keys_dev(fir_gemm* m, const float* d_queries, int32_t q
         if (m->precision == FIR_GEMM_F16) {
             const int pairs = (np + 1) / 2;
             const bool streamed = m->streamed >= 0 ? m->streamed != 0 : m->dk16 > kSlabH;
-            const dim3 mgrid(grid, pairs);
             const int64_t rblocks = (n + 31) / 32;
-            const double bytes = pairs * ((double)rblocks * m->dk16 * 1024.0 + 4.0 * m->dk16 * 1024.0 + 128.0 * 8.0);   // fp16 fragments once per 128 queries + the query tile + keys
+            const int share_cap = m->share_max > 0 ? m->share_max : 8;
+            int nlaunch = 0, p_first = 1;
+            for (int p0 = 0; p0 < pairs;) {
+                int P = 1;
+                while (P * 2 <= pairs - p0 && P * 2 <= share_cap) P *= 2;
+                if (p0 == 0) p_first = P;
+                p0 += P;
+                ++nlaunch;
+            }
+            // algorithmic bytes: the fp16 fragments once per group of pairs that reads them together (once per pair without sharing),
+            // every pair's query tile and keys
+            const double bytes = (m->share_max > 0 ? nlaunch : pairs) * ((double)rblocks * m->dk16 * 1024.0) + pairs * (4.0 * m->dk16 * 1024.0 + 128.0 * 8.0);
             const double flops = 2.0 * (double)n * d * 128.0 * pairs;
             int rc2 = fir_gallery_profile_begin_(m->g, st);
             if (rc2) return rc2;
-            if (streamed)
-                hipLaunchKernelGGL((k_gemm_proxy_f16<1, 1>), mgrid, dim3(kGemmBlock), kHalfLds, st, m->gh, m->gnorm, m->qbf[b], m->qinv[b], n, (int64_t)0, n,
-                                   m->dk16, m->tau[b], m->lists[b], m->counts[b], m->sample, sample_rows);
-            else
-                hipLaunchKernelGGL((k_gemm_proxy_f16<1, 0>), mgrid, dim3(kGemmBlock), kHalfLds, st, m->gh, m->gnorm, m->qbf[b], m->qinv[b], n, (int64_t)0, n,
-                                   m->dk16, m->tau[b], m->lists[b], m->counts[b], m->sample, sample_rows);
+            // the pairs of the super-batch read the gallery together, a power of two (<= share_max) of them per launch
+            for (int p0 = 0; p0 < pairs;) {
+                int P = 1;
+                while (P * 2 <= pairs - p0 && P * 2 <= share_cap) P *= 2;
+                const int share = m->share_max > 0 ? P : 0;
+                const dim3 g1 = share > 0 ? dim3(grid, 1) : dim3(grid, P);
+                const int nt = (share <= 1) ? 1 : 0;
+                const size_t qo = (size_t)p0;
+                if (streamed)
+                    hipLaunchKernelGGL((k_gemm_proxy_f16<1, 1>), g1, dim3(kGemmBlock), kHalfLds, st, m->gh, m->gnorm, m->qbf[b] + qo * 4 * m->dk16 * 64, m->qinv[b] + qo * 2 * kQT,
+                                       n, (int64_t)0, n, m->dk16, m->tau[b] + qo * 2 * kQT, m->lists[b] + qo * 2 * kQT * kListCap, m->counts[b] + qo * 2 * kQT, m->sample,
+                                       sample_rows, share, nt);
+                else
+                    hipLaunchKernelGGL((k_gemm_proxy_f16<1, 0>), g1, dim3(kGemmBlock), kHalfLds, st, m->gh, m->gnorm, m->qbf[b] + qo * 4 * m->dk16 * 64, m->qinv[b] + qo * 2 * kQT,
+                                       n, (int64_t)0, n, m->dk16, m->tau[b] + qo * 2 * kQT, m->lists[b] + qo * 2 * kQT * kListCap, m->counts[b] + qo * 2 * kQT, m->sample,
+                                       sample_rows, share, nt);
+                p0 += P;
+            }
             if ((rc2 = fir_gallery_profile_end_(m->g, st, bytes))) return rc2;
             fir_gallery_note_dispatch_(m->g, streamed ? (const void*)k_gemm_proxy_f16<1, 1> : (const void*)k_gemm_proxy_f16<1, 0>,
-                                       streamed ? "fir::k_gemm_proxy_f16<1, 1>" : "fir::k_gemm_proxy_f16<1, 0>", sb == 0, grid, pairs, kGemmBlock, kHalfLds, 128,
-                                       bytes, flops);
+                                       streamed ? "fir::k_gemm_proxy_f16<1, 1>" : "fir::k_gemm_proxy_f16<1, 0>", sb == 0, grid, m->share_max > 0 ? nlaunch : pairs, kGemmBlock, kHalfLds,
+                                       m->share_max > 0 ? 128 * p_first : 128, bytes, flops);
         } else if (m->precision == FIR_GEMM_F32) {
             hipLaunchKernelGGL(k_gemm_proxy<1>, dim3(grid, np), dim3(kGemmBlock), lds, st, m->gm, m->gnorm, m->qm[b], n, (int64_t)0, n, m->dq8,
                                m->tau[b], m->lists[b], m->counts[b], m->sample, sample_rows);

@@ -84,11 +84,11 @@ int64_t orc_recognize_bf(const float* rows, int64_t n, int d, const float* query
 #include <omp.h>
 #endif
 int orc_recognize_bf_batch_omp(const float* rows, int64_t n, int d, const float* queries, int nq, int start_pos, int end_pos,
-                               int metric, int64_t* idx_out, float* dist_out) {
+                               int metric, int want_threads, int64_t* idx_out, float* dist_out) {
     int threads = 1;
 #ifdef _OPENMP
-    threads = omp_get_max_threads();
-#pragma omp parallel for schedule(dynamic, 1)
+    threads = want_threads > 0 ? want_threads : omp_get_max_threads();
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
 #endif
     for (int q = 0; q < nq; ++q) {
         float bd = 100000.0f;

@@ -107,7 +107,7 @@ class Oracle:
         i = self.L.orc_recognize_bf(_p(rows), n, d, _p(q), start, end, metric, C.byref(bd))
         return int(i), np.float32(bd.value)
 
-    def top1_batch_omp(self, rows, queries, start, end, metric=0):
+    def top1_batch_omp(self, rows, queries, start, end, metric=0, threads=0):
         """recognize_image_bf for every query, queries spread over all host cores (OpenMP); returns (idx, dist, threads)."""
         rows, n, d = self._rows(rows)
         queries = np.ascontiguousarray(queries, np.float32).reshape(-1, d)
@@ -115,8 +115,8 @@ class Oracle:
         dist = np.empty(queries.shape[0], np.float32)
         fn = self.L.orc_recognize_bf_batch_omp
         fn.restype = C.c_int
-        fn.argtypes = [_vp, C.c_int64, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]
-        threads = fn(_p(rows), n, d, _p(queries), queries.shape[0], start, end, metric, _p(idx), _p(dist))
+        fn.argtypes = [_vp, C.c_int64, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]
+        threads = fn(_p(rows), n, d, _p(queries), queries.shape[0], start, end, metric, threads, _p(idx), _p(dist))
         return idx.astype(np.int32), dist, int(threads)
 
     def top1_batch(self, rows, queries, start, end, metric=0):

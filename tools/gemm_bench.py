@@ -54,6 +54,7 @@ def main():
         k1 = torch.empty(qb, device=dev, dtype=torch.int64)
         k2 = torch.empty(qb, device=dev, dtype=torch.int64)
         with torch.cuda.stream(st):
+            g.set_large_batch_mfma(0)
             t_scan = timed(lambda: g.search_top1_keys_dev(q.data_ptr(), qb, k1.data_ptr(), stream=st.cuda_stream), 3)
             s0 = m.stats()
             t_gemm = timed(lambda: m.search_top1_keys_dev(q.data_ptr(), qb, k2.data_ptr(), stream=st.cuda_stream), 3)
@@ -62,6 +63,7 @@ def main():
         calls = 4
         fb = (s1["fallback_queries"] - s0["fallback_queries"]) / calls
         flops = 2.0 * n * d * qb
+        g.set_large_batch_mfma(-1)
         print(f"Qb={qb:5d}  scan {t_scan*1e3:8.2f} ms ({qb/t_scan:9.0f} q/s)   gemm {t_gemm*1e3:8.2f} ms ({qb/t_gemm:9.0f} q/s, "
               f"{flops/t_gemm/1e12:6.1f} TFLOP/s of the dot products)  identical keys: {same}  fallback queries/call: {fb:.1f}", flush=True)
     m.close()
