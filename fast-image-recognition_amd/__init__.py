@@ -17,6 +17,7 @@ from .capi import (  # noqa: F401
     METRIC_CHI2,
     METRIC_KL,
     METRIC_L2,
+    ShardedClsModel,
     ShardedGallery,
     comm_unique_id,
     device_count,

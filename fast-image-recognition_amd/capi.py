@@ -53,7 +53,11 @@ SYMBOLS = [
     ("fir_twd_conventional", C.c_int, [_vp, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_int32, _vp, _vp]),
     ("fir_twd_proposed", C.c_int, [_vp, _vp, C.c_int32, C.c_int32, C.c_double, _vp, _vp, _vp]),
     ("fir_cls_create", C.c_int, [_vp, C.c_int64, C.c_int32, _vp, C.c_int32, _vp, C.c_int32, C.POINTER(_vp)]),
+    ("fir_cls_create_dev", C.c_int, [_vp, C.c_int64, C.c_int32, _vp, C.c_int32, _vp, C.c_int32, C.POINTER(_vp)]),
     ("fir_cls_destroy", C.c_int, [_vp]),
+    ("fir_cls_create_sharded", C.c_int, [_vp, C.c_int64, C.c_int32, _vp, C.c_int32, _vp, _vp, C.c_int32, _vp, C.POINTER(_vp)]),
+    ("fir_cls_sharded_destroy", C.c_int, [_vp]),
+    ("fir_cls_sharded_pnn_predict", C.c_int, [_vp, _vp, C.c_int32, C.c_double, _vp, _vp]),
     ("fir_cls_set_total_training_size", C.c_int, [_vp, C.c_int64]),
     ("fir_cls_distance_sums", C.c_int, [_vp, _vp, C.c_int32, _vp]),
     ("fir_cls_pnn_predict", C.c_int, [_vp, _vp, C.c_int32, C.c_double, _vp, _vp]),
@@ -352,7 +356,7 @@ def comm_unique_id():
 
 class ShardOpts(C.Structure):
     _fields_ = [("struct_bytes", C.c_int32), ("shards_per_device", C.c_int32), ("first_global_row", C.c_int64), ("comm_id", _vp),
-                ("proc_rank", C.c_int32), ("nprocs", C.c_int32), ("rows_on_device", C.c_int32), ("reserved", C.c_int32)]
+                ("proc_rank", C.c_int32), ("nprocs", C.c_int32), ("rows_on_device", C.c_int32), ("reserved", C.c_int32), ("total_rows", C.c_int64)]
 
 
 class _BorrowedGallery(Gallery):
@@ -600,13 +604,18 @@ class ClsModel:
     """Owns one fir_cls handle: the training set of the double-precision kNN / PNN classifiers
     (qt_cpp/classification.cpp:116-226) in the reference's class-major scan order."""
 
-    def __init__(self, train_rows, train_class, num_classes, avg, device=0):
-        tr = np.ascontiguousarray(train_rows, dtype=np.float64)
+    def __init__(self, train_rows, train_class, num_classes, avg, device=0, *, dev_ptr=None, nt=None, d=None):
         tc = np.ascontiguousarray(train_class, dtype=np.int32)
         av = np.ascontiguousarray(avg, dtype=np.float64)
         self._h = _vp()
-        self.nt, self.d = tr.shape
         self.num_classes = int(num_classes)
+        if dev_ptr is not None:          # rows already in the device's memory (float64, row-major)
+            self.nt, self.d = int(nt), int(d)
+            _check(lib().fir_cls_create_dev(_vp(dev_ptr), self.nt, self.d, tc.ctypes.data_as(_vp), num_classes, av.ctypes.data_as(_vp), device,
+                                            C.byref(self._h)))
+            return
+        tr = np.ascontiguousarray(train_rows, dtype=np.float64)
+        self.nt, self.d = tr.shape
         _check(lib().fir_cls_create(tr.ctypes.data_as(_vp), tr.shape[0], tr.shape[1], tc.ctypes.data_as(_vp), num_classes,
                                     av.ctypes.data_as(_vp), device, C.byref(self._h)))
 
@@ -666,3 +675,46 @@ class ClsModel:
         best = np.empty(q.shape[0], np.int32)
         _check(lib().fir_cls_knn_predict(self._h, pq, q.shape[0], k, best.ctypes.data_as(_vp)))
         return best
+
+
+class ShardedClsModel:
+    """Owns one fir_cls_sharded handle: the PNN training set split by rows over `devices` (x shards_per_device), class
+    scores added across shards on the device and across ranks by RCCL (ncclAllReduce(ncclSum, ncclDouble))."""
+
+    def __init__(self, train_rows, train_class, num_classes, avg, devices=(0,), shards_per_device=1):
+        tr = np.ascontiguousarray(train_rows, dtype=np.float64)
+        tc = np.ascontiguousarray(train_class, dtype=np.int32)
+        av = np.ascontiguousarray(avg, dtype=np.float64)
+        devs = np.ascontiguousarray(list(devices), dtype=np.int32)
+        o = ShardOpts()
+        o.struct_bytes = C.sizeof(ShardOpts)
+        o.shards_per_device = shards_per_device
+        self._h = _vp()
+        self.nt, self.d = tr.shape
+        self.num_classes = int(num_classes)
+        _check(lib().fir_cls_create_sharded(tr.ctypes.data_as(_vp), tr.shape[0], tr.shape[1], tc.ctypes.data_as(_vp), num_classes, av.ctypes.data_as(_vp),
+                                            devs.ctypes.data_as(_vp), devs.size, C.byref(o), C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().fir_cls_sharded_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def pnn_predict(self, queries, var=0.0):
+        q = np.ascontiguousarray(queries, dtype=np.float64).reshape(-1, self.d)
+        scores = np.empty((q.shape[0], self.num_classes), np.float64)
+        best = np.empty(q.shape[0], np.int32)
+        _check(lib().fir_cls_sharded_pnn_predict(self._h, q.ctypes.data_as(_vp), q.shape[0], var, scores.ctypes.data_as(_vp), best.ctypes.data_as(_vp)))
+        return best, scores

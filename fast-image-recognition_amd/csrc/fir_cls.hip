@@ -207,7 +207,7 @@ __global__ void __launch_bounds__(64) k_cls_knn_kth(const double* __restrict__ s
 constexpr int kSeqBlock = 1024;
 __global__ void __launch_bounds__(kSeqBlock) k_cls_pnn_seq(const double* __restrict__ cs, int nq, int nchunks, double* __restrict__ dist,
                                                             double* __restrict__ ev, const int32_t* __restrict__ class_off, int64_t nt,
-                                                            int num_classes, int d, double var, int32_t* __restrict__ best_class,
+                                                            int num_classes, int d, double var, double den, int32_t* __restrict__ best_class,
                                                             int32_t* __restrict__ chunks_out) {
     extern __shared__ __attribute__((aligned(16))) double outputs[];
     int* checked = (int*)(outputs + num_classes);
@@ -222,7 +222,7 @@ __global__ void __launch_bounds__(kSeqBlock) k_cls_pnn_seq(const double* __restr
     for (int c = threadIdx.x; c <= num_classes; c += kSeqBlock) off[c] = class_off[c];
     if (threadIdx.x == 0) { best_s = -1; stop_s = 0; }
     __syncthreads();
-    const double den = (double)nt;                                                  // total_training_size (:244)
+    // den = total_training_size (:244): the rows held, unless fir_cls_set_total_training_size said otherwise
     int used = 0;
     for (int ch = 0; ch < nchunks; ++ch) {
         ++used;
@@ -392,7 +392,8 @@ int cls_stage_queries(fir_cls* c, const double* queries, int32_t qb, const doubl
 // Queries per internal batch: the distance table (qb x nt doubles) stays under 1 GiB whatever the caller's batch is.
 int32_t cls_batch(const fir_cls* c) {
     const int64_t per_query = std::max<int64_t>(c->nt, 1) * (int64_t)sizeof(double);
-    return (int32_t)std::max<int64_t>(kQB, std::min<int64_t>(1 << 20, ((int64_t)1 << 30) / per_query / kQB * kQB));
+    // ... and within gridDim.y of the per-(class, query) kernels (65535)
+    return (int32_t)std::max<int64_t>(kQB, std::min<int64_t>(65532, ((int64_t)1 << 30) / per_query / kQB * kQB));
 }
 
 int cls_scan(fir_cls* c, const double* queries, int32_t qb) {
@@ -417,8 +418,21 @@ int cls_scan(fir_cls* c, const double* queries, int32_t qb) {
 
 extern "C" {
 
+static int cls_create(const double* train_rows, bool rows_on_device, int64_t nt, int32_t d, const int32_t* train_class, int32_t num_classes,
+                      const double* avg, int32_t device, fir_cls** out);
+
 int fir_cls_create(const double* train_rows, int64_t nt, int32_t d, const int32_t* train_class, int32_t num_classes,
                    const double* avg, int32_t device, fir_cls** out) {
+    return cls_create(train_rows, false, nt, d, train_class, num_classes, avg, device, out);
+}
+
+int fir_cls_create_dev(const double* d_train_rows, int64_t nt, int32_t d, const int32_t* train_class, int32_t num_classes,
+                       const double* avg, int32_t device, fir_cls** out) {
+    return cls_create(d_train_rows, true, nt, d, train_class, num_classes, avg, device, out);
+}
+
+static int cls_create(const double* train_rows, bool rows_on_device, int64_t nt, int32_t d, const int32_t* train_class, int32_t num_classes,
+                      const double* avg, int32_t device, fir_cls** out) {
     if (!out) return cls_fail(FIR_ERR_ARG, "out is NULL");
     *out = nullptr;
     if (nt < 0 || d <= 0 || num_classes <= 0 || !avg || (nt > 0 && (!train_rows || !train_class)))
@@ -461,14 +475,14 @@ int fir_cls_create(const double* train_rows, int64_t nt, int32_t d, const int32_
     if (e == hipSuccess) e = hipMemcpy(c->avg, avg, (size_t)d * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(c->class_off, off.data(), off.size() * sizeof(int32_t), hipMemcpyHostToDevice);
     const int64_t slab = std::max<int64_t>(kTileRows, ((int64_t)(256u << 20) / ((int64_t)d * 8)) / kTileRows * kTileRows);
-    if (e == hipSuccess && nt > 0) e = hipMalloc((void**)&stage, (size_t)std::min<int64_t>(slab, c->tiles * kTileRows) * d * sizeof(double));
+    if (e == hipSuccess && nt > 0 && !rows_on_device) e = hipMalloc((void**)&stage, (size_t)std::min<int64_t>(slab, c->tiles * kTileRows) * d * sizeof(double));
     for (int64_t r0 = 0; e == hipSuccess && r0 < nt; r0 += slab) {
         const int64_t have = std::min<int64_t>(slab, nt - r0);
-        e = hipMemcpyAsync(stage, train_rows + r0 * d, (size_t)have * d * sizeof(double), hipMemcpyHostToDevice, c->stream);
+        if (!rows_on_device) e = hipMemcpyAsync(stage, train_rows + r0 * d, (size_t)have * d * sizeof(double), hipMemcpyHostToDevice, c->stream);
         if (e != hipSuccess) break;
         const int64_t total = ((have + kTileRows - 1) / kTileRows) * c->dp2 * 64;
-        hipLaunchKernelGGL(k_cls_retile, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, stage, have, r0, nt, d,
-                           c->dp2, c->avg, c->gal2);
+        hipLaunchKernelGGL(k_cls_retile, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream,
+                           rows_on_device ? train_rows + r0 * d : stage, have, r0, nt, d, c->dp2, c->avg, c->gal2);
         e = hipStreamSynchronize(c->stream);
     }
     if (stage) (void)hipFree(stage);
@@ -541,6 +555,27 @@ int fir_cls_pnn_predict(fir_cls* c, const double* queries, int32_t qb, double va
     return FIR_OK;
 }
 
+// PNN class scores of qb <= *max_batch queries, left on the device (valid until the handle's next call), queued on the
+// handle's stream: the row-sharded PNN (fir_shard.hip) adds the shards' partial sums before the arg-max.
+int fir_cls_pnn_scores_dev_(fir_cls* c, const double* queries, int32_t qb, double var, double** d_scores, void** stream, int32_t* max_batch) {
+    if (!c || !d_scores || !stream) return cls_fail(FIR_ERR_ARG, "NULL argument");
+    if (max_batch) *max_batch = cls_batch(c);
+    if (qb == 0) return FIR_OK;
+    if (qb < 0 || qb > cls_batch(c) || !queries) return cls_fail(FIR_ERR_ARG, "bad batch %d (at most %d at a time)", qb, cls_batch(c));
+    CLS_HIP(hipSetDevice(c->device));
+    if (var <= 0) { var = 0.00002; if (c->d > 2000) var /= 10; }                // classification.cpp:190-193
+    int rc = cls_scan(c, queries, qb);
+    if (rc) return rc;
+    if ((rc = cls_grow(c->scores, c->scores_cap, (size_t)qb * c->num_classes))) return rc;
+    const double denom = (double)(2 * (size_t)c->d) * var;
+    hipLaunchKernelGGL(k_cls_pnn, dim3(c->num_classes, qb), dim3(64), 0, c->stream, c->sums, c->class_off, c->nt, c->num_classes, denom,
+                       c->total_training_size > 0 ? c->total_training_size : (double)c->nt, c->scores);
+    CLS_HIP(hipGetLastError());
+    *d_scores = c->scores;
+    *stream = c->stream;
+    return FIR_OK;
+}
+
 int fir_cls_pnn_predict_seq(fir_cls* c, const double* queries, int32_t qb, double var, int32_t* best_class, int32_t* chunks_out) {
     if (!c || !best_class || (qb > 0 && !queries)) return cls_fail(FIR_ERR_ARG, "NULL argument");
     if (qb < 0) return cls_fail(FIR_ERR_ARG, "qb < 0");
@@ -569,7 +604,8 @@ int fir_cls_pnn_predict_seq(fir_cls* c, const double* queries, int32_t qb, doubl
         hipLaunchKernelGGL(k_cls_scan, dim3(waves / 4), dim3(kBlock), 0, c->stream, c->gal2, c->qn, c->nt, (int)c->tiles, c->dp2, c->d, waves, nq,
                            0, c->dp2, c->sums, 16, (int64_t)nq * c->nt);
         hipLaunchKernelGGL(k_cls_pnn_seq, dim3(nq), dim3(kSeqBlock), (size_t)c->num_classes * 16 + 4, c->stream, c->sums, nq, nchunks, run,
-                           run + (size_t)kQB * ntp, c->class_off, c->nt, c->num_classes, c->d, var, dbest + q0, dchunks + q0);
+                           run + (size_t)kQB * ntp, c->class_off, c->nt, c->num_classes, c->d, var,
+                           c->total_training_size > 0 ? c->total_training_size : (double)c->nt, dbest + q0, dchunks + q0);
     }
     CLS_HIP(hipGetLastError());
     if (!small) {

@@ -54,3 +54,6 @@ extern "C" int fir_gallery_profile_begin_(fir_gallery* g, void* st);
 extern "C" int fir_gallery_profile_end_(fir_gallery* g, void* st, double bytes_alg);
 extern "C" void fir_gallery_note_dispatch_(fir_gallery* g, const void* fn, const char* name, int first, int gx, int gy, int block, size_t dyn_lds,
                                            int qpp, double bytes, double flops);
+
+struct fir_cls;
+extern "C" int fir_cls_pnn_scores_dev_(fir_cls* c, const double* queries, int32_t qb, double var, double** d_scores, void** stream, int32_t* max_batch);

@@ -192,7 +192,12 @@ struct fir_sharded {
 namespace {
 
 // Run fn(slot) for every device: inline for one device, on the per-device worker threads otherwise.
-int run_all(fir_sharded* h, const std::function<int(int)>& fn) {
+int run_all(std::vector<DevCtx>& devs, const std::function<int(int)>& fn);
+int run_all(fir_sharded* h, const std::function<int(int)>& fn) { return run_all(h->devs, fn); }
+int run_all(std::vector<DevCtx>& devs, const std::function<int(int)>& fn) {
+    const int ndev = (int)devs.size();
+    struct { std::vector<DevCtx>& devs; int ndev; } hh{devs, ndev};
+    auto* h = &hh;
     if (h->ndev == 1) return fn(0);
     for (int s = 0; s < h->ndev; ++s) {
         Worker* w = h->devs[s].worker;
@@ -343,7 +348,234 @@ int search_host(fir_sharded* h, const float* queries, int32_t qb, int32_t start,
 
 }  // namespace
 
+namespace {
+
+// per-device stream, communicator (rank = first_rank + slot) and, for several devices, worker threads
+int setup_devices(std::vector<DevCtx>& devs, const int32_t* devices, int ndev, int nranks, int first_rank, const void* comm_id) {
+    ncclUniqueId id;
+    if (comm_id) std::memcpy(&id, comm_id, sizeof id);
+    else SH_NCCL(ncclGetUniqueId(&id));
+    for (int s = 0; s < ndev; ++s) {
+        DevCtx& dc = devs[(size_t)s];
+        dc.device = devices[s];
+        SH_HIP(hipSetDevice(dc.device));
+        SH_HIP(hipStreamCreateWithFlags(&dc.stream, hipStreamNonBlocking));
+    }
+    ncclResult_t nr = ncclGroupStart();
+    for (int s = 0; s < ndev && nr == ncclSuccess; ++s) {
+        (void)hipSetDevice(devs[(size_t)s].device);
+        nr = ncclCommInitRank(&devs[(size_t)s].comm, nranks, id, first_rank + s);
+    }
+    if (nr == ncclSuccess) nr = ncclGroupEnd(); else (void)ncclGroupEnd();
+    if (nr != ncclSuccess) return sh_fail(FIR_ERR_COMM, "RCCL communicator of %d ranks: %s", nranks, ncclGetErrorString(nr));
+    if (ndev > 1)
+        for (int s = 0; s < ndev; ++s) {
+            Worker* w = new (std::nothrow) Worker();
+            if (!w) return sh_fail(FIR_ERR_NOMEM, "host allocation failed");
+            devs[(size_t)s].worker = w;
+            w->th = std::thread([w] { w->loop(); });
+        }
+    return FIR_OK;
+}
+
+void teardown_devices(std::vector<DevCtx>& devs) {
+    for (DevCtx& dc : devs) {
+        if (dc.worker) {
+            { std::lock_guard<std::mutex> lk(dc.worker->mu); dc.worker->quit = true; }
+            dc.worker->cv.notify_all();
+            if (dc.worker->th.joinable()) dc.worker->th.join();
+            delete dc.worker;
+            dc.worker = nullptr;
+        }
+        (void)hipSetDevice(dc.device);
+        if (dc.stream) (void)hipStreamSynchronize(dc.stream);
+        if (dc.comm) (void)ncclCommDestroy(dc.comm);
+        (void)hipFree(dc.dq); (void)hipFree(dc.parts); (void)hipFree(dc.keys); (void)hipFree(dc.gath); (void)hipFree(dc.cls);
+        for (hipEvent_t e : dc.evs) (void)hipEventDestroy(e);
+        if (dc.stream) (void)hipStreamDestroy(dc.stream);
+        dc = DevCtx();
+    }
+}
+
+int check_devices(const int32_t* devices, int32_t ndev) {
+    if (!devices || ndev < 1 || ndev > 64) return sh_fail(FIR_ERR_ARG, "device list of %d entries", ndev);
+    for (int i = 0; i < ndev; ++i)
+        for (int j = 0; j < i; ++j)
+            if (devices[i] == devices[j]) return sh_fail(FIR_ERR_ARG, "device %d listed twice (use shards_per_device for logical shards)", devices[i]);
+    const int cnt = fir_device_count();
+    for (int i = 0; i < ndev; ++i)
+        if (devices[i] < 0 || devices[i] >= cnt) return sh_fail(FIR_ERR_NODEVICE, "device %d out of range (%d visible)", devices[i], cnt);
+    return FIR_OK;
+}
+
+int read_opts(const fir_shard_opts* opts, fir_shard_opts* o) {
+    std::memset(o, 0, sizeof *o);
+    if (opts) {
+        if (opts->struct_bytes < 8 || opts->struct_bytes > (int32_t)sizeof *o) return sh_fail(FIR_ERR_ARG, "fir_shard_opts.struct_bytes = %d", opts->struct_bytes);
+        std::memcpy(o, opts, (size_t)opts->struct_bytes);
+    }
+    if (o->shards_per_device <= 0) o->shards_per_device = 1;
+    if (!o->comm_id) { o->nprocs = 1; o->proc_rank = 0; }
+    if (o->shards_per_device > 64) return sh_fail(FIR_ERR_ARG, "shards_per_device = %d", o->shards_per_device);
+    if (o->nprocs < 1 || o->proc_rank < 0 || o->proc_rank >= o->nprocs) return sh_fail(FIR_ERR_ARG, "process %d of %d", o->proc_rank, o->nprocs);
+    return FIR_OK;
+}
+
+// acc[i] += part[i]
+__global__ void __launch_bounds__(256) k_shard_add_f64(double* __restrict__ acc, const double* __restrict__ part, int64_t n, int first) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) acc[i] = first ? part[i] : acc[i] + part[i];
+}
+// best[q] = first maximum of scores[q][0..C) from -DBL_MAX (classification.cpp:217-224); one wave per query
+__global__ void __launch_bounds__(64) k_shard_argmax_first(const double* __restrict__ scores, int num_classes, int32_t* __restrict__ best) {
+    const int q = blockIdx.x, lane = threadIdx.x;
+    const double* s = scores + (size_t)q * num_classes;
+    double mx = -1.7976931348623157e308;
+    int bi = 0x7FFFFFFF;
+    for (int i = lane; i < num_classes; i += 64)
+        if (mx < s[i]) { mx = s[i]; bi = i; }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const double om = __shfl_xor(mx, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (om > mx || (om == mx && oi < bi)) { mx = om; bi = oi; }
+    }
+    if (lane == 0) best[q] = bi == 0x7FFFFFFF ? -1 : bi;
+}
+
+}  // namespace
+
+struct fir_cls_sharded {
+    int d = 0, num_classes = 0, ndev = 0, nranks = 1;
+    int64_t nt_local = 0;
+    std::vector<DevCtx> devs;
+    struct Part { int slot; fir_cls* c; };
+    std::vector<Part> parts;
+    std::vector<double*> acc;      size_t acc_cap = 0;     // per device: summed class scores [qb][C]
+    std::vector<int32_t*> best;                            // per device
+    void* pin = nullptr;  size_t pin_cap = 0;
+};
+
 extern "C" {
+
+int fir_cls_sharded_destroy(fir_cls_sharded* h) {
+    if (!h) return FIR_OK;
+    for (auto& p : h->parts)
+        if (p.c) fir_cls_destroy(p.c);
+    for (size_t s = 0; s < h->devs.size(); ++s) {
+        (void)hipSetDevice(h->devs[s].device);
+        if (s < h->acc.size()) (void)hipFree(h->acc[s]);
+        if (s < h->best.size()) (void)hipFree(h->best[s]);
+    }
+    teardown_devices(h->devs);
+    if (h->pin) (void)hipHostFree(h->pin);
+    delete h;
+    return FIR_OK;
+}
+
+int fir_cls_create_sharded(const double* train_rows, int64_t nt, int32_t d, const int32_t* train_class, int32_t num_classes, const double* avg,
+                           const int32_t* devices, int32_t ndev, const fir_shard_opts* opts, fir_cls_sharded** out) {
+    if (!out) return sh_fail(FIR_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (nt < 0 || d <= 0 || num_classes <= 0 || !avg || (nt > 0 && (!train_rows || !train_class))) return sh_fail(FIR_ERR_ARG, "bad training set (nt=%lld d=%d classes=%d)", (long long)nt, d, num_classes);
+    int rc = check_devices(devices, ndev);
+    if (rc) return rc;
+    fir_shard_opts o;
+    if ((rc = read_opts(opts, &o))) return rc;
+    if (o.rows_on_device) return sh_fail(FIR_ERR_ARG, "fir_cls_create_sharded takes host rows");
+    fir_cls_sharded* h = new (std::nothrow) fir_cls_sharded();
+    if (!h) return sh_fail(FIR_ERR_NOMEM, "host allocation failed");
+    h->d = d; h->num_classes = num_classes; h->ndev = ndev; h->nranks = o.nprocs * ndev; h->nt_local = nt;
+    h->devs.resize((size_t)ndev);
+    h->acc.assign((size_t)ndev, nullptr);
+    h->best.assign((size_t)ndev, nullptr);
+    const int spd = o.shards_per_device, nsh = ndev * spd;
+    const int64_t total = o.total_rows > 0 ? o.total_rows : nt;
+    const int64_t per = (((nt + 63) / 64 + nsh - 1) / nsh) * 64;
+    for (int s = 0; s < nsh && rc == FIR_OK; ++s) {
+        const int64_t lo = std::min<int64_t>((int64_t)s * per, nt), hi = std::min<int64_t>((int64_t)(s + 1) * per, nt);
+        fir_cls_sharded::Part p{s / spd, nullptr};
+        if (hi > lo) {
+            rc = fir_cls_create(train_rows + lo * d, hi - lo, d, train_class + lo, num_classes, avg, devices[p.slot], &p.c);
+            if (rc == FIR_OK) rc = fir_cls_set_total_training_size(p.c, total);     // classification.cpp:215: every partial sum over the global N
+        }
+        h->parts.push_back(p);
+    }
+    if (rc == FIR_OK) rc = setup_devices(h->devs, devices, ndev, h->nranks, o.proc_rank * ndev, o.comm_id);
+    if (rc) { fir_cls_sharded_destroy(h); return rc; }
+    *out = h;
+    return FIR_OK;
+}
+
+int fir_cls_sharded_pnn_predict(fir_cls_sharded* h, const double* queries, int32_t qb, double var, double* scores, int32_t* best_class) {
+    if (!h || (qb > 0 && !queries)) return sh_fail(FIR_ERR_ARG, "NULL argument");
+    if (qb < 0) return sh_fail(FIR_ERR_ARG, "qb < 0");
+    if (qb == 0) return FIR_OK;
+    // internal batches: what every shard's distance table allows (fir_cls_pnn_scores_dev_)
+    int32_t maxb = 1 << 30;
+    for (auto& p : h->parts)
+        if (p.c) { int32_t mb = 0; double* ds; void* st; fir_cls_pnn_scores_dev_(p.c, nullptr, 0, var, &ds, &st, &mb); maxb = std::min(maxb, mb); }
+    maxb = std::min(maxb, 4096);
+    if (qb > maxb) {
+        for (int32_t q0 = 0; q0 < qb; q0 += maxb) {
+            const int rc0 = fir_cls_sharded_pnn_predict(h, queries + (size_t)q0 * h->d, std::min(maxb, qb - q0), var,
+                                                        scores ? scores + (size_t)q0 * h->num_classes : nullptr, best_class ? best_class + q0 : nullptr);
+            if (rc0) return rc0;
+        }
+        return FIR_OK;
+    }
+    const size_t nsc = (size_t)qb * h->num_classes;
+    if (nsc > h->acc_cap) {
+        for (int s = 0; s < h->ndev; ++s) {
+            SH_HIP(hipSetDevice(h->devs[(size_t)s].device));
+            if (h->acc[(size_t)s]) SH_HIP(hipFree(h->acc[(size_t)s]));
+            if (h->best[(size_t)s]) SH_HIP(hipFree(h->best[(size_t)s]));
+            h->acc[(size_t)s] = nullptr; h->best[(size_t)s] = nullptr;
+            SH_HIP(hipMalloc((void**)&h->acc[(size_t)s], nsc * sizeof(double)));
+            SH_HIP(hipMalloc((void**)&h->best[(size_t)s], (size_t)maxb * sizeof(int32_t)));
+        }
+        h->acc_cap = nsc;
+    }
+    const size_t need = nsc * sizeof(double) + (size_t)qb * sizeof(int32_t);
+    if (need > h->pin_cap) {
+        if (h->pin) SH_HIP(hipHostFree(h->pin));
+        h->pin = nullptr; h->pin_cap = 0;
+        SH_HIP(hipHostMalloc(&h->pin, need, hipHostMallocPortable));
+        h->pin_cap = need;
+    }
+    double* hs = (double*)h->pin;
+    int32_t* hb = (int32_t*)((char*)h->pin + nsc * sizeof(double));
+    int rc = run_all(h->devs, [&](int slot) -> int {
+        DevCtx& dc = h->devs[(size_t)slot];
+        SH_HIP(hipSetDevice(dc.device));
+        double* acc = h->acc[(size_t)slot];
+        int first = 1;
+        for (auto& p : h->parts) {
+            if (p.slot != slot || !p.c) continue;
+            double* ds = nullptr;
+            void* st = nullptr;
+            const int r = fir_cls_pnn_scores_dev_(p.c, queries, qb, var, &ds, &st, nullptr);
+            if (r) return r;
+            SH_HIP(hipStreamSynchronize((hipStream_t)st));          // the shard's own stream: its scores are complete
+            hipLaunchKernelGGL(k_shard_add_f64, dim3((unsigned)((nsc + 255) / 256)), dim3(256), 0, dc.stream, acc, ds, (int64_t)nsc, first);
+            first = 0;
+        }
+        if (first) SH_HIP(hipMemsetAsync(acc, 0, nsc * sizeof(double), dc.stream));     // a device without rows adds nothing
+        SH_HIP(hipGetLastError());
+        SH_NCCL(ncclAllReduce(acc, acc, nsc, ncclDouble, ncclSum, dc.comm, dc.stream));
+        hipLaunchKernelGGL(k_shard_argmax_first, dim3(qb), dim3(64), 0, dc.stream, acc, h->num_classes, h->best[(size_t)slot]);
+        if (slot == 0) {
+            if (scores) SH_HIP(hipMemcpyAsync(hs, acc, nsc * sizeof(double), hipMemcpyDeviceToHost, dc.stream));
+            SH_HIP(hipMemcpyAsync(hb, h->best[0], (size_t)qb * sizeof(int32_t), hipMemcpyDeviceToHost, dc.stream));
+        }
+        SH_HIP(hipStreamSynchronize(dc.stream));
+        return FIR_OK;
+    });
+    if (rc) return rc;
+    if (scores) std::memcpy(scores, hs, nsc * sizeof(double));
+    if (best_class) std::memcpy(best_class, hb, (size_t)qb * sizeof(int32_t));
+    return FIR_OK;
+}
 
 int fir_comm_unique_id(void* id_out) {
     if (!id_out) return sh_fail(FIR_ERR_ARG, "id_out is NULL");

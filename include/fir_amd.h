@@ -151,6 +151,9 @@ int fir_twd_proposed(fir_gallery* g, const float* queries, int32_t qb, int32_t r
 typedef struct fir_cls fir_cls;
 int fir_cls_create(const double* train_rows, int64_t nt, int32_t d, const int32_t* train_class, int32_t num_classes,
                    const double* avg, int32_t device, fir_cls** out);
+/* Same, train_rows already in `device`'s memory (row-major float64); train_class and avg are host arrays. */
+int fir_cls_create_dev(const double* d_train_rows, int64_t nt, int32_t d, const int32_t* train_class, int32_t num_classes,
+                       const double* avg, int32_t device, fir_cls** out);
 int fir_cls_destroy(fir_cls* c);
 /* PNNwithClusteringClassifier::predict (classification.cpp:389-428) runs the PNN over the medoid rows
  * only but still divides by the FULL training size: set it here (0 = the number of rows held). */
@@ -273,6 +276,7 @@ typedef struct fir_shard_opts {
     int32_t proc_rank, nprocs;  /* with comm_id: this process among nprocs; each lists the same NUMBER of devices        */
     int32_t rows_on_device;     /* 1: rows / class_no are device pointers on devices[0] (one-entry device list only)     */
     int32_t reserved;
+    int64_t total_rows;         /* fir_cls_create_sharded with comm_id: training rows over ALL processes (PNN divisor); 0 = n */
 } fir_shard_opts;
 int fir_comm_unique_id(void* id_out /* [FIR_COMM_ID_BYTES] */);
 /* Single process, all rows, one shard per listed device. devices[ndev]: HIP device indices, no repeats. */
@@ -301,6 +305,20 @@ int fir_sharded_classify_top1(fir_sharded* h, const float* queries, int32_t qb, 
 int fir_sharded_search_top1_keys_dev(fir_sharded* h, const float* d_queries, int32_t qb, int32_t start_pos,
                                      int32_t end_pos, uint64_t* d_keys, void* stream);
 int fir_sharded_sync(fir_sharded* h);
+
+/* PNNClassifier::predict_bf (classification.cpp:188-226) over training rows split across GPUs: every shard sums
+ * exp(-dist / (2 d var)) over ITS rows per class with the GLOBAL training-set size as divisor, the partial class scores
+ * are added on the device and across ranks with ncclAllReduce(ncclSum, ncclDouble), then the first maximum is the class.
+ * Only the order of the additions differs from the one-device call (scores within 1e-12 relative, same arg-max unless
+ * two classes tie to that precision). train_rows / train_class as in fir_cls_create (class-major); shards are
+ * contiguous row blocks. opts may be NULL (one process, one shard per device). */
+typedef struct fir_cls_sharded fir_cls_sharded;
+int fir_cls_create_sharded(const double* train_rows, int64_t nt, int32_t d, const int32_t* train_class, int32_t num_classes,
+                           const double* avg, const int32_t* devices, int32_t ndev, const fir_shard_opts* opts,
+                           fir_cls_sharded** out);
+int fir_cls_sharded_destroy(fir_cls_sharded* h);
+int fir_cls_sharded_pnn_predict(fir_cls_sharded* h, const double* queries, int32_t qb, double var, double* scores,
+                                int32_t* best_class);
 /* HIP events around the exchange step on this process's first device: durations (ms) since the previous read. */
 int fir_sharded_profile_enable(fir_sharded* h, int32_t on);
 int fir_sharded_profile_read(fir_sharded* h, float* exchange_ms, int32_t cap, int32_t* count);

@@ -138,3 +138,71 @@ def test_knn_vote_over_training_row_shards(fir, oracle, shards):
         assert np.array_equal(got, whole), k
         for i in range(q.shape[0]):
             assert got[i] == oracle.knn_predict(tr_k, tcls_k, avg, ncls, q[i], k)[0], (k, i)
+
+
+def _big_training_set(n, d, ncls, seed):
+    """Class-major float64 training rows: class centres + noise, so that the PNN scores of the right class are not denormal."""
+    rng = np.random.default_rng(seed)
+    centres = rng.random((ncls, d))
+    tcls = np.sort(rng.integers(0, ncls, n)).astype(np.int32)
+    tr = centres[tcls] + 0.004 * rng.standard_normal((n, d))
+    q = centres[rng.integers(0, ncls, 24)] + 0.004 * rng.standard_normal((24, d))
+    return tr, tcls, q
+
+
+def test_k3_pnn_and_knn_at_120k_rows_against_the_oracle(fir, oracle):
+    """K3 at scale: 120 000 x 512 float64 training rows, PNN class scores, PNN / kNN classes and the
+    distance sums of sampled queries against the oracle (one query ~0.15 s on the CPU)."""
+    n, d, ncls = 120_000, 512, 300
+    tr, tcls, q = _big_training_set(n, d, ncls, 77)
+    _, _, avg, _ = oracle.train_stats(tr)
+    with fir.ClsModel(tr, tcls, ncls, avg, 0) as m:
+        pnn, scores = m.pnn_predict(q)
+        knn1, knn3 = m.knn_predict(q, 1), m.knn_predict(q, 3)
+        sums = m.distance_sums(q[:2])
+    for i in (0, 5, 11, 23):
+        ec, es = oracle.pnn_predict(tr, tcls, avg, ncls, q[i])
+        assert pnn[i] == ec
+        np.testing.assert_allclose(scores[i], es, rtol=1e-11, atol=1e-300)     # ~400 rows per class summed in another order
+        e1, dist = oracle.knn_predict(tr, tcls, avg, ncls, q[i], 1)
+        assert knn1[i] == e1 and knn3[i] == oracle.knn_predict(tr, tcls, avg, ncls, q[i], 3)[0]
+        if i < 2:
+            assert np.array_equal((sums[i] / d).view(np.uint64), dist.view(np.uint64))      # per-row sums: bit-identical
+    assert scores.max() > 1e-200                                              # the test is not comparing zeros
+
+
+def test_pnn_over_training_row_shards_inside_the_library(fir, oracle):
+    """fir_cls_create_sharded / fir_cls_sharded_pnn_predict: partial class sums over the GLOBAL training-set size, added on the
+    device and by ncclAllReduce(ncclSum, ncclDouble). Same classes as the one-handle call, scores within 1e-12 (the order
+    of the additions is all that differs); a near-tie of two classes is graded by that tolerance, not by the arg-max."""
+    n, d, ncls = 9000, 96, 31
+    tr, tcls, q = _big_training_set(n, d, ncls, 5)
+    _, _, avg, _ = oracle.train_stats(tr)
+    with fir.ClsModel(tr, tcls, ncls, avg, 0) as m:
+        b0, s0 = m.pnn_predict(q)
+    for spd in (1, 3, 8):
+        with fir.ShardedClsModel(tr, tcls, ncls, avg, devices=[0], shards_per_device=spd) as s:
+            b, sc = s.pnn_predict(q)
+        np.testing.assert_allclose(sc, s0, rtol=1e-12, atol=1e-300)
+        top2 = np.sort(s0, axis=1)[:, -2:]
+        clear = (top2[:, 1] - top2[:, 0]) > 1e-11 * top2[:, 1]
+        assert np.array_equal(b[clear], b0[clear]) and clear.sum() >= 20
+    ec, es = oracle.pnn_predict(tr, tcls, avg, ncls, q[3])
+    assert b0[3] == ec
+    np.testing.assert_allclose(s0[3], es, rtol=1e-12, atol=1e-300)
+
+
+def test_large_query_batch_against_a_tiny_training_set(fir, oracle):
+    """More than 65 535 queries in one call against a training set small enough that the distance table allows it: the
+    per-(class, query) kernels put the query on gridDim.y, so the call must be cut into batches."""
+    n, d, ncls = 130, 4, 3
+    tr, tcls, _ = _big_training_set(n, d, ncls, 9)
+    _, _, avg, _ = oracle.train_stats(tr)
+    rng = np.random.default_rng(1)
+    q = tr[rng.integers(0, n, 70_000)] + 1e-3 * rng.standard_normal((70_000, d))
+    with fir.ClsModel(tr, tcls, ncls, avg, 0) as m:
+        pnn, _ = m.pnn_predict(q)
+        knn = m.knn_predict(q, 1)
+    for i in (0, 65_535, 65_536, 69_999):
+        assert pnn[i] == oracle.pnn_predict(tr, tcls, avg, ncls, q[i])[0]
+        assert knn[i] == oracle.knn_predict(tr, tcls, avg, ncls, q[i], 1)[0]

@@ -149,3 +149,132 @@ def test_chi2_kl_top5_at_1m(fir, oracle, metric):
         assert np.array_equal(merged, k5)
     del x
     torch.cuda.empty_cache()
+
+
+def test_config2_100k_x_512_automatic_tuning_against_the_oracle(fir, oracle):
+    """BASELINE config 2: 100k x 512, batched L2 top-1 with the library's own choices -- the cache-resident gallery takes 16
+    queries per pass in the exact scan, and a 256-query batch takes the matrix cores by default. Both must return the
+    oracle's index and distance bits (24 queries checked outright on the CPU, ~0.08 s each) and each other's keys."""
+    import synth
+
+    n, d, qb = 100_000, 512, 256
+    rows = synth.make_gallery(53, n, d, 0)
+    q, _ = synth.make_queries(53, rows, qb, 0)
+    rows[n - 7] = rows[12]
+    q[5] = rows[12]                                   # exact tie, first row wins
+    with fir.Gallery(rows, None, 0, 0) as g:
+        a_idx, a_dist = g.search_top1(q)              # default dispatch
+        da = g.last_dispatch()
+        g.set_large_batch_mfma(0)
+        b_idx, b_dist = g.search_top1(q)              # exact scan, automatic queries-per-pass
+        db = g.last_dispatch()
+        tun = g.get_tuning()
+        c_idx, c_dist = g.search_top1(q[:24])         # a small batch: the scan at whatever tile the library picks
+    assert da["path"] == "mfma" and db["path"] == "scan"
+    assert tun["queries_per_pass"] == 16 and db["queries_per_pass"] == 16 and "k_scan_l2_lds<2" in db["kernel"]     # cache-resident: 16 per pass
+    assert np.array_equal(a_idx, b_idx) and np.array_equal(a_dist.view(np.uint32), b_dist.view(np.uint32))
+    eidx, edist = oracle.top1_batch(rows, q[:24], 0, d, 0)
+    assert np.array_equal(a_idx[:24], eidx) and np.array_equal(a_dist[:24].view(np.uint32), edist.view(np.uint32))
+    assert np.array_equal(c_idx, eidx) and np.array_equal(c_dist.view(np.uint32), edist.view(np.uint32))
+    assert a_idx[5] == 12 and a_dist[5] == 0.0
+
+
+@pytest.mark.parametrize("precision", [2, 1])         # FIR_GEMM_F16, FIR_GEMM_BF16_SPLIT
+def test_config5_1m_x_1280_matrix_core_path_equals_the_scan(fir, oracle, precision):
+    """BASELINE config 5: 1M x 1280 (EfficientNet-B7 width). The MFMA nomination + exact re-rank + certificate path must
+    return the exact scan's keys bit for bit on a 512-query batch; planted exact copies are found at distance +0.0;
+    the winners' distances are the oracle's bits on the rows fetched back."""
+    n, d, qb = 1_000_000, 1280, 512
+    x = make_gallery(n, d, 4242)
+    planted = np.array([0, 31, 32, n // 2 + 17, n - 33, n - 1], dtype=np.int64)
+    gq = torch.Generator(device="cuda")
+    gq.manual_seed(7)
+    fresh = torch.rand((qb, d), generator=gq, device="cuda")
+    q = fresh / fresh.norm(dim=1, keepdim=True)
+    q[: len(planted)] = x[torch.from_numpy(planted).cuda()]
+    noise = (torch.rand((64, d), generator=gq, device="cuda") - 0.5) * 0.02 * x[:1000].mean()
+    near = (x[torch.arange(64, device="cuda") * 15013 + 5] + noise).clamp_min(0)
+    q[64:128] = near / near.norm(dim=1, keepdim=True)
+    q = q.contiguous()
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        g = fir.Gallery(dev_ptr=x.data_ptr(), n=n, d=d, metric=0, device=0, stream=st.cuda_stream)
+        g.set_large_batch_mfma(0)
+        scan = keys_of(fir, g, q, st)
+        assert g.last_dispatch()["path"] == "scan"
+        gm = fir.GemmSearch(g, precision)
+        k2 = torch.empty(qb, device="cuda", dtype=torch.int64)
+        gm.search_top1_keys_dev(q.data_ptr(), qb, k2.data_ptr(), stream=st.cuda_stream)
+        st.synchronize()
+        got = k2.cpu().numpy().view(np.uint64)
+        fb = gm.stats()["fallback_queries"]
+        gm.close()
+        if precision == 2:                              # and the default dispatch is this path
+            g.set_large_batch_mfma(-1)
+            auto = keys_of(fir, g, q, st)
+            assert g.last_dispatch()["path"] == "mfma" and np.array_equal(auto, scan)
+        g.close()
+    assert np.array_equal(got, scan)
+    assert fb <= qb // 8, fb                           # the certificate holds for (nearly) every query: the path is not the scan in disguise
+    idx, dist = fir.keys_unpack(scan)
+    assert np.array_equal(idx[: len(planted)], planted) and np.all(dist[: len(planted)].view(np.uint32) == 0)
+    assert np.array_equal(idx[64:128], np.arange(64) * 15013 + 5)
+    pick = np.arange(0, qb, 13)
+    host_rows = x[torch.from_numpy(idx[pick].astype(np.int64)).cuda()].cpu().numpy()
+    host_q = q[torch.from_numpy(pick).cuda()].cpu().numpy()
+    for j, i in enumerate(pick):
+        exp = oracle.feature_distance(host_q[j], host_rows[j], 0, d, 0)
+        assert np.float32(dist[i]).view(np.uint32) == np.float32(exp).view(np.uint32), i
+    del x
+    torch.cuda.empty_cache()
+
+
+def test_config4_10m_x_512_as_eight_shards_through_the_library_exchange(fir, oracle):
+    """BASELINE config 4: 10M x 512 row-sharded 8 ways. On one GPU the eight shards are logical (20.5 GB of rows fit), but
+    the split, the per-shard scans, the on-device minimum and the RCCL call are the library's (fir_sharded_*). The reduced
+    keys must equal the scan of the whole gallery as ONE handle -- for the default dispatch (matrix cores in every shard)
+    and for the exact scan -- and planted rows sit at +0.0, the last one in the last shard."""
+    n, d, qb = 10_000_000, 512, 256
+    x = make_gallery(n, d, 99)
+    planted = np.array([0, 1_249_999, 1_250_048, 5_000_000, 8_750_016, n - 1], dtype=np.int64)
+    gq = torch.Generator(device="cuda")
+    gq.manual_seed(11)
+    fresh = torch.rand((qb, d), generator=gq, device="cuda")
+    q = fresh / fresh.norm(dim=1, keepdim=True)
+    q[: len(planted)] = x[torch.from_numpy(planted).cuda()]
+    x[n - 5] = x[3]
+    q[10] = x[3]                                        # a tie between the first and the last shard: the first row wins
+    q = q.contiguous()
+    st = torch.cuda.Stream()
+    keys = torch.empty(qb, device="cuda", dtype=torch.int64)
+    with torch.cuda.stream(st):
+        s = fir.ShardedGallery(dev_ptr=x.data_ptr(), n=n, d=d, metric=0, devices=[0], shards_per_device=8)
+        bounds = [s.shard(i)[1:] for i in range(8)]
+        assert [b[1] for b in bounds] == [1_250_048] * 7 + [n - 7 * 1_250_048]      # whole 64-row tiles per shard
+        s.search_top1_keys_dev(q.data_ptr(), qb, keys.data_ptr(), stream=st.cuda_stream)
+        st.synchronize()
+        sharded_default = keys.cpu().numpy().view(np.uint64).copy()
+        assert s.shard(0)[0].last_dispatch()["path"] == "mfma"
+        for i in range(8):
+            s.shard(i)[0].set_large_batch_mfma(0)
+        s.search_top1_keys_dev(q.data_ptr(), qb, keys.data_ptr(), stream=st.cuda_stream)
+        st.synchronize()
+        sharded_scan = keys.cpu().numpy().view(np.uint64).copy()
+        assert s.shard(7)[0].last_dispatch()["path"] == "scan"
+        s.close()
+        g = fir.Gallery(dev_ptr=x.data_ptr(), n=n, d=d, metric=0, device=0, stream=st.cuda_stream)
+        g.set_large_batch_mfma(0)
+        whole = keys_of(fir, g, q, st)
+        g.close()
+    assert np.array_equal(sharded_scan, whole) and np.array_equal(sharded_default, whole)
+    idx, dist = fir.keys_unpack(whole)
+    assert np.array_equal(idx[: len(planted)], planted) and np.all(dist[: len(planted)].view(np.uint32) == 0)
+    assert idx[10] == 3 and dist[10] == 0.0
+    pick = np.arange(16, qb, 31)
+    host_rows = x[torch.from_numpy(idx[pick].astype(np.int64)).cuda()].cpu().numpy()
+    host_q = q[torch.from_numpy(pick).cuda()].cpu().numpy()
+    for j, i in enumerate(pick):
+        exp = oracle.feature_distance(host_q[j], host_rows[j], 0, d, 0)
+        assert np.float32(dist[i]).view(np.uint32) == np.float32(exp).view(np.uint32), i
+    del x
+    torch.cuda.empty_cache()
