@@ -1073,8 +1073,15 @@ int top1_one_query(fir_gallery* g, const float* pinned_query, int32_t start, int
     a.done = g->one_done;
     a.ticket = ++g->one_ticket;
     hipLaunchKernelGGL(fn, dim3(waves / 4, 1), dim3(kBlock), lds_bytes, g->stream, a);
-    FIR_HIP(hipGetLastError());
-    return wait_ticket(g, pinned_key + 1, a.ticket);
+    const hipError_t le = hipGetLastError();
+    if (le == hipSuccess && wait_ticket(g, pinned_key + 1, a.ticket) == FIR_OK) return FIR_OK;
+    // The launch failed or its last workgroup never published: only that workgroup re-arms the device key and the arrival
+    // counter, so they are re-armed here (else every later one-query call would wait 2 ms and fail), and this call goes
+    // through the general path. If the device itself is gone that path reports it.
+    (void)hipStreamSynchronize(g->stream);
+    const uint64_t init[8] = {kKeyNone, kKeyNone, kKeyNone, kKeyNone, 0, 0, 0, 0};
+    (void)hipMemcpy(g->one_keys, init, sizeof init, hipMemcpyHostToDevice);
+    return 1;
 }
 
 int ensure_pin(fir_gallery* g) {

@@ -6,6 +6,7 @@
 #include "fir_loader.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -20,48 +21,88 @@ namespace fir {
 namespace {
 int g_device = 0;
 int g_metric = FIR_DEFAULT_METRIC;
-int g_large_batch = 0;
+int g_large_batch = -1;
+std::vector<int> g_devices;          // more than one entry (or g_shards_per_device > 1): galleries are row-sharded (fir_sharded_*)
+int g_shards_per_device = 1;
+int g_validation = FIR_CACHE_VALIDATE_THROTTLED;
 
-struct CacheKey {
-    const void* vec;
-    size_t n;
-    const float* first;
-    const float* last;
-    int dim;
-    int metric;
-    bool operator<(const CacheKey& o) const {
-        return std::tie(vec, n, first, last, dim, metric) < std::tie(o.vec, o.n, o.first, o.last, o.dim, o.metric);
-    }
+// One uploaded gallery. What identifies the caller's `std::vector<ImageInfo>` is checked on EVERY lookup: the vector
+// object, its size, and a signature over every row's (feature pointer, length, classNo) -- any reallocation, reorder or
+// relabel is seen at once. What the rows CONTAIN is a 64-bit hash of all feature bytes taken at upload time; it is
+// re-verified on a lookup when the policy says so (fir::set_cache_validation): always, never, or -- the default -- when
+// at least 20 ms have passed since this entry was last verified, so that a loop of per-image recognize() calls (the
+// reference's own pattern, ~35 us each) pays a few per cent for it while an edit made between two runs is caught.
+struct Entry {
+    const void* vec = nullptr;
+    size_t n = 0;
+    int dim = 0, metric = 0;
+    uint64_t signature = 0, content = 0;
+    std::chrono::steady_clock::time_point verified;
+    fir_gallery* g = nullptr;
+    fir_sharded* s = nullptr;
 };
-std::map<CacheKey, fir_gallery*> g_cache;
+std::vector<Entry> g_cache;
 
-CacheKey key_of(const std::vector<ImageInfo>& db, int dim) {
-    CacheKey k;
-    k.vec = &db;
-    k.n = db.size();
-    k.first = db.empty() ? nullptr : db.front().features.data();
-    k.last = db.empty() ? nullptr : db.back().features.data();
-    k.dim = dim;
-    k.metric = g_metric;
-    return k;
+inline uint64_t mix(uint64_t h, uint64_t v) {
+    h ^= v * 0x9E3779B97F4A7C15ull;
+    h = (h << 27) | (h >> 37);
+    return h * 0x94D049BB133111EBull + 0x632BE59BD9B4E019ull;
 }
-}  // namespace
 
-void set_large_batch_mfma(int min_queries) { g_large_batch = min_queries; }
-void set_device(int device) { g_device = device; }
-int device() { return g_device; }
-int metric() { return g_metric; }
-void set_metric(int m) { g_metric = m; }
-void log_error(const char* where) { std::fprintf(stderr, "fir: %s: %s\n", where, fir_last_error()); }
-
-fir_gallery* GalleryCache::get(const std::vector<ImageInfo>& db, int dim) {
-    const CacheKey k = key_of(db, dim);
-    auto it = g_cache.find(k);
-    if (it != g_cache.end()) return it->second;
-    // a different split presented through the same vector object replaces the old upload
-    for (auto i = g_cache.begin(); i != g_cache.end();) {
-        if (i->first.vec == k.vec) { fir_gallery_destroy(i->second); i = g_cache.erase(i); } else ++i;
+uint64_t signature_of(const std::vector<ImageInfo>& db) {
+    uint64_t h = 0x243F6A8885A308D3ull ^ db.size();
+    for (const ImageInfo& im : db) {
+        h = mix(h, (uint64_t)(uintptr_t)im.features.data());
+        h = mix(h, ((uint64_t)im.features.size() << 32) ^ (uint32_t)im.classNo);
     }
+    return h;
+}
+
+uint64_t content_of(const std::vector<ImageInfo>& db, int dim) {
+    uint64_t h[4] = {1, 2, 3, 4};                              // four independent lanes: the multiplies overlap
+    for (const ImageInfo& im : db) {
+        const size_t have = std::min<size_t>(im.features.size(), (size_t)dim);
+        const float* f = im.features.data();
+        size_t k = 0;
+        for (; k + 8 <= have; k += 8) {
+            uint64_t w[4];
+            std::memcpy(w, f + k, 32);
+            h[0] = mix(h[0], w[0]); h[1] = mix(h[1], w[1]); h[2] = mix(h[2], w[2]); h[3] = mix(h[3], w[3]);
+        }
+        for (; k < have; ++k) { uint32_t w; std::memcpy(&w, f + k, 4); h[k & 3] = mix(h[k & 3], w); }
+    }
+    return mix(mix(h[0], h[1]), mix(h[2], h[3]));
+}
+
+void drop(Entry& e) {
+    if (e.g) fir_gallery_destroy(e.g);
+    if (e.s) fir_sharded_destroy(e.s);
+    e.g = nullptr;
+    e.s = nullptr;
+}
+
+bool sharded_mode() { return g_devices.size() > 1 || g_shards_per_device > 1; }
+
+// The entry for (db, dim) under the current metric / device set, uploaded if it is not there or no longer valid.
+Entry* lookup(const std::vector<ImageInfo>& db, int dim) {
+    const uint64_t sig = signature_of(db);
+    const auto now = std::chrono::steady_clock::now();
+    for (size_t i = 0; i < g_cache.size(); ++i) {
+        Entry& e = g_cache[i];
+        if (e.vec != (const void*)&db || e.dim != dim || e.metric != g_metric || (e.s != nullptr) != sharded_mode()) continue;
+        bool valid = e.n == db.size() && e.signature == sig;
+        if (valid && (g_validation == FIR_CACHE_VALIDATE_ALWAYS ||
+                      (g_validation == FIR_CACHE_VALIDATE_THROTTLED && now - e.verified >= std::chrono::milliseconds(20)))) {
+            valid = content_of(db, dim) == e.content;
+            e.verified = std::chrono::steady_clock::now();
+        }
+        if (valid) return &e;
+        drop(e);                                                 // a different split (or edited rows) behind the same vector object
+        g_cache.erase(g_cache.begin() + (long)i);
+        break;
+    }
+    // every other upload of this vector with these features is stale too if the rows changed; uploads of other widths are
+    // checked when they are looked up
     std::vector<float> rows((size_t)db.size() * dim);
     std::vector<int32_t> cls(db.size());
     for (size_t j = 0; j < db.size(); ++j) {
@@ -70,24 +111,75 @@ fir_gallery* GalleryCache::get(const std::vector<ImageInfo>& db, int dim) {
         std::memcpy(&rows[j * dim], f.data(), have * sizeof(float));   // rows shorter than dim are zero padded
         cls[j] = db[j].classNo;
     }
-    fir_gallery* g = nullptr;
-    if (fir_gallery_create(rows.data(), (int64_t)db.size(), dim, cls.data(), g_metric, g_device, &g) != FIR_OK) {
-        log_error("gallery upload");
-        return nullptr;
+    Entry e;
+    e.vec = &db; e.n = db.size(); e.dim = dim; e.metric = g_metric; e.signature = sig;
+    e.content = content_of(db, dim);
+    e.verified = std::chrono::steady_clock::now();
+    if (sharded_mode()) {
+        std::vector<int32_t> devs(g_devices.begin(), g_devices.end());
+        if (devs.empty()) devs.push_back(g_device);
+        fir_shard_opts o;
+        std::memset(&o, 0, sizeof o);
+        o.struct_bytes = (int32_t)sizeof o;
+        o.shards_per_device = g_shards_per_device;
+        if (fir_gallery_create_sharded_ex(rows.data(), (int64_t)db.size(), dim, cls.data(), g_metric, devs.data(), (int32_t)devs.size(), &o, &e.s) != FIR_OK) {
+            log_error("sharded gallery upload");
+            return nullptr;
+        }
+        if (g_large_batch >= 0) {
+            int32_t nsh = 0;
+            fir_sharded_info(e.s, nullptr, nullptr, nullptr, &nsh, nullptr, nullptr);
+            for (int32_t i = 0; i < nsh; ++i) {
+                fir_gallery* part = nullptr;
+                if (fir_sharded_shard(e.s, i, &part, nullptr, nullptr) == FIR_OK && part) fir_gallery_set_large_batch_mfma(part, g_large_batch);
+            }
+        }
+    } else {
+        if (fir_gallery_create(rows.data(), (int64_t)db.size(), dim, cls.data(), g_metric, g_device, &e.g) != FIR_OK) {
+            log_error("gallery upload");
+            return nullptr;
+        }
+        if (g_large_batch >= 0) fir_gallery_set_large_batch_mfma(e.g, g_large_batch);
     }
-    if (g_large_batch > 0) fir_gallery_set_large_batch_mfma(g, g_large_batch);
-    g_cache[k] = g;
-    return g;
+    g_cache.push_back(e);
+    return &g_cache.back();
+}
+}  // namespace
+
+void set_large_batch_mfma(int min_queries) { g_large_batch = min_queries; }
+void set_device(int device) { g_device = device; }
+void set_devices(const std::vector<int>& devices, int shards_per_device) {
+    GalleryCache::clear();
+    g_devices = devices;
+    g_shards_per_device = shards_per_device > 0 ? shards_per_device : 1;
+    if (!devices.empty()) g_device = devices[0];
+}
+void set_cache_validation(int mode) { g_validation = mode; }
+int device() { return g_device; }
+int metric() { return g_metric; }
+void set_metric(int m) { g_metric = m; }
+void log_error(const char* where) { std::fprintf(stderr, "fir: %s: %s\n", where, fir_last_error()); }
+
+fir_gallery* GalleryCache::get(const std::vector<ImageInfo>& db, int dim) {
+    // the single-device handle (TWD classifiers, DirectedEnumeration): always on fir::device(), whatever set_devices said
+    const std::vector<int> devs = g_devices;
+    const int spd = g_shards_per_device;
+    g_devices.clear();
+    g_shards_per_device = 1;
+    Entry* e = lookup(db, dim);
+    g_devices = devs;
+    g_shards_per_device = spd;
+    return e ? e->g : nullptr;
 }
 
 void GalleryCache::invalidate(const std::vector<ImageInfo>& db) {
-    for (auto i = g_cache.begin(); i != g_cache.end();) {
-        if (i->first.vec == (const void*)&db) { fir_gallery_destroy(i->second); i = g_cache.erase(i); } else ++i;
+    for (size_t i = 0; i < g_cache.size();) {
+        if (g_cache[i].vec == (const void*)&db) { drop(g_cache[i]); g_cache.erase(g_cache.begin() + (long)i); } else ++i;
     }
 }
 
 void GalleryCache::clear() {
-    for (auto& kv : g_cache) fir_gallery_destroy(kv.second);
+    for (Entry& e : g_cache) drop(e);
     g_cache.clear();
 }
 
@@ -99,8 +191,8 @@ std::vector<int> recognize_images_bf(const std::vector<ImageInfo>& dbImages, con
     if (tests.empty() || dbImages.empty()) return out;
     // the gallery is uploaded with as many features as the scan reads
     const int dim = max_features;
-    fir_gallery* g = GalleryCache::get(dbImages, dim);
-    if (!g) return out;
+    Entry* e = lookup(dbImages, dim);
+    if (!e) return out;
     std::vector<float> q((size_t)tests.size() * dim, 0.0f);
     for (size_t i = 0; i < tests.size(); ++i) {
         const FeaturesVector& f = tests[i].features;
@@ -108,7 +200,10 @@ std::vector<int> recognize_images_bf(const std::vector<ImageInfo>& dbImages, con
     }
     std::vector<int32_t> idx(tests.size());
     std::vector<float> dist(tests.size());
-    if (fir_search_top1(g, q.data(), (int32_t)tests.size(), 0, max_features, idx.data(), dist.data()) != FIR_OK) {
+    // several devices: every shard scans the batch, RCCL reduces the packed keys inside the library (fir_sharded_search_top1)
+    const int rc = e->s ? fir_sharded_search_top1(e->s, q.data(), (int32_t)tests.size(), 0, max_features, idx.data(), dist.data())
+                        : fir_search_top1(e->g, q.data(), (int32_t)tests.size(), 0, max_features, idx.data(), dist.data());
+    if (rc != FIR_OK) {
         log_error("search_top1");
         return out;
     }

@@ -81,10 +81,13 @@ std::vector<int> recognize_images_bf(const std::vector<ImageInfo>& dbImages, con
                                      int max_features = 0, std::vector<float>* best_dist = nullptr);
 
 // The device copy of one `std::vector<ImageInfo>` gallery. The reference's classifiers only keep
-// a pointer to the caller's vector (ImageTesting.cpp:40, ann.h:28); here the rows are packed and
-// uploaded on first use and the handle is reused while the SAME vector object (address, size,
-// first/last feature pointers) is presented again. Call fir::invalidate(dbImages) after
-// mutating a gallery in place.
+// a pointer to the caller's vector (ImageTesting.cpp:40, ann.h:28) and read it afresh on every call; here the rows are
+// packed and uploaded on first use and the handle is reused while the SAME gallery is presented again, which is checked
+// on every lookup: the vector object, its size and a signature over EVERY row's feature pointer, length and classNo
+// (any reallocation, reorder or relabel re-uploads at once), plus a 64-bit hash of all feature bytes taken at upload
+// time and re-verified per fir::set_cache_validation -- by default whenever 20 ms have passed since the entry was last
+// verified, so an in-place edit of any row is caught by the next run over the gallery, and a tight loop of per-image
+// calls pays a few per cent. fir::invalidate(dbImages) forces the re-upload immediately (train() calls it).
 class GalleryCache {
 public:
     static fir_gallery* get(const std::vector<ImageInfo>& dbImages, int dim);
@@ -93,10 +96,19 @@ public:
 };
 inline void invalidate(const std::vector<ImageInfo>& dbImages) { GalleryCache::invalidate(dbImages); }
 
-// Galleries uploaded from now on send whole-range L2 batches of >= min_queries test images through the matrix-core
-// path (fir_gallery_set_large_batch_mfma): same answers, ~15-20x the throughput, one extra copy of the gallery. 0 = off.
+// Galleries uploaded from now on: fir_gallery_set_large_batch_mfma(min_queries). The library's default (-1) already sends
+// whole-range L2 batches of >= 128 test images against >= 65536 rows through the matrix-core path (same answers);
+// > 0 sets another threshold, 0 switches the path off.
 void set_large_batch_mfma(int min_queries);
 void set_device(int device);   // default 0
+// Several GPUs: galleries uploaded from now on are split by rows over `devices` (one shard each, or shards_per_device
+// logical shards each) and recognize_image(s)_bf / BruteForce / BruteForceClassifier scan all shards at once; the nearest
+// row over the whole gallery is the integer minimum of the shards' packed keys, reduced by RCCL inside libfir_amd.so
+// (fir_sharded_search_top1). An empty list (or one device, one shard) is the single-device path on fir::device().
+void set_devices(const std::vector<int>& devices, int shards_per_device = 1);
+// How often a cached upload's CONTENT is re-verified against the caller's rows (see GalleryCache).
+enum { FIR_CACHE_VALIDATE_NEVER = 0, FIR_CACHE_VALIDATE_THROTTLED = 1, FIR_CACHE_VALIDATE_ALWAYS = 2 };
+void set_cache_validation(int mode);   // default FIR_CACHE_VALIDATE_THROTTLED
 int device();
 int metric();                  // FIR_DEFAULT_METRIC unless set_metric was called
 void set_metric(int metric);

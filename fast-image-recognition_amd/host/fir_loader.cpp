@@ -229,6 +229,17 @@ int load_feature_cache(const std::string& cache_file, PackedFeatures& out) {
     int64_t hdr[4];
     bool ok = std::fread(magic, 1, 8, fp) == 8 && std::memcmp(magic, kMagic, 8) == 0 && std::fread(hdr, sizeof(int64_t), 4, fp) == 4;
     ok = ok && hdr[0] >= 0 && hdr[1] > 0 && hdr[3] >= 0;
+    // a truncated or damaged cache must not size an allocation: the fixed part of the file has to be there in full
+    // (rows, class ids, file indices; the class names follow, at least their length words)
+    if (ok) {
+        struct stat st;
+        ok = ::fstat(::fileno(fp), &st) == 0 && hdr[0] < ((int64_t)1 << 31) && hdr[1] < (1 << 24) && hdr[3] <= hdr[0] + 1 && hdr[2] >= 0 && hdr[2] <= 2;
+        if (ok) {
+            const unsigned __int128 fixed = (unsigned __int128)8 + 32 + (unsigned __int128)hdr[0] * (unsigned __int128)hdr[1] * 4 + (unsigned __int128)hdr[0] * 8 +
+                                            (unsigned __int128)hdr[3] * 4;
+            ok = fixed <= (unsigned __int128)st.st_size;
+        }
+    }
     if (ok) {
         out.n = hdr[0]; out.d = (int)hdr[1]; out.metric = (int)hdr[2];
         out.rows.resize((size_t)out.n * out.d);
@@ -244,6 +255,9 @@ int load_feature_cache(const std::string& cache_file, PackedFeatures& out) {
             ok = ok && std::fread(&s[0], 1, s.size(), fp) == s.size();
             out.class_names.push_back(s);
         }
+        // class ids index class_names (fir_gallery_create and the classifiers trust them)
+        for (int64_t i = 0; ok && i < out.n; ++i) ok = out.class_no[(size_t)i] >= 0 && out.class_no[(size_t)i] < hdr[3];
+        ok = ok && std::fgetc(fp) == EOF;                                   // nothing may follow the last class name
     }
     std::fclose(fp);
     if (!ok) out = PackedFeatures();

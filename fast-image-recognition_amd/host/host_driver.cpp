@@ -4,6 +4,7 @@
 //   host_driver <features.txt> [max_features ...]
 #include <cstdio>
 #include <cstdlib>
+#include <ctime>
 #include <iostream>
 
 #include "compat/ann.h"
@@ -102,6 +103,40 @@ int main(int argc, char** argv) {
     std::vector<int> raw;
     for (const ImageInfo& t : testImages) raw.push_back(recognize_image_bf(dbImages, t));
     print_vec("recognize_image_bf", raw, true);
+    {   // several GPUs (here: logical shards on device 0): the same answers through fir_sharded_* and its RCCL exchange
+        fir::set_devices(std::vector<int>(1, 0), 3);
+        BruteForce ann_sh(dbImages);
+        print_vec("sharded_ann_rows", ann_sh.recognize_batch(testImages), true);
+        BruteForceClassifier bf_sh(256);
+        bf_sh.train(&dbImages);
+        print_vec("sharded_bf_256_batch", bf_sh.recognize_batch(testImages), true);
+        std::vector<int> one;
+        for (size_t k = 0; k < testImages.size() && k < 4; ++k) one.push_back(recognize_image_bf(dbImages, testImages[k]));
+        print_vec("sharded_first4", one, true);
+        fir::set_devices(std::vector<int>());
+    }
+    if (!testImages.empty() && dbImages.size() > 2) {
+        // a gallery row edited IN PLACE (same vector object, same row buffers) between two calls of the free function: the
+        // reference reads the rows afresh every time; the upload cache must notice (fir_db.h, GalleryCache)
+        const size_t mid = dbImages.size() / 2;
+        FeaturesVector& row = const_cast<FeaturesVector&>(dbImages[mid].features);
+        const FeaturesVector saved = row;
+        const int before = recognize_image_bf(dbImages, testImages[0]);
+        fir::set_cache_validation(fir::FIR_CACHE_VALIDATE_ALWAYS);
+        row = testImages[0].features;                      // same length: copied into the same buffer
+        const int after_always = recognize_image_bf(dbImages, testImages[0]);
+        row = saved;
+        const int restored = recognize_image_bf(dbImages, testImages[0]);
+        fir::set_cache_validation(fir::FIR_CACHE_VALIDATE_THROTTLED);
+        row = testImages[0].features;
+        struct timespec ts = {0, 40 * 1000 * 1000};
+        nanosleep(&ts, nullptr);                           // past the 20 ms window of the default policy
+        const int after_default = recognize_image_bf(dbImages, testImages[0]);
+        row = saved;
+        fir::invalidate(dbImages);
+        std::printf("\"edit_row\": %zu, \"edit_before\": %d, \"edit_after_always\": %d, \"edit_restored\": %d, \"edit_after_default\": %d,\n", mid, before,
+                    after_always, restored, after_default);
+    }
     const float d01 = testImages.empty() ? 0.f : testImages[0].distance(dbImages[0]);
     const float d64 = testImages.empty() ? 0.f : testImages[0].distance(dbImages[0], 0, 64);
     std::printf("\"dist_q0_g0\": %.9g, \"dist_q0_g0_64\": %.9g\n}\n", d01, d64);

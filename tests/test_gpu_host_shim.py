@@ -49,6 +49,13 @@ def test_host_shim_matches_oracle_end_to_end(tmp_path, oracle):
     exp_rows = [oracle.recognize_bf(gal, qi, 0, d, 0)[0] for qi in q]
     assert got["ann_rows"] == exp_rows
     assert got["recognize_image_bf"] == exp_rows
+    # the same gallery split into three logical shards (fir::set_devices): split + scans + RCCL exchange inside the library
+    assert got["sharded_ann_rows"] == exp_rows and got["sharded_first4"] == exp_rows[:4]
+    assert got["sharded_bf_256_batch"] == [oracle.bf_classifier(gal, dbc, qi, 256, 0) for qi in q]
+    # a gallery row overwritten in place with query 0's features is found at once (validate-always) and by the default
+    # policy once its 20 ms window has passed; restoring the row restores the answer
+    assert got["edit_before"] == exp_rows[0] == got["edit_restored"]
+    assert got["edit_after_always"] == got["edit_row"] == got["edit_after_default"]
     assert np.float32(got["dist_q0_g0"]) == oracle.feature_distance(q[0], gal[0], 0, d, 0)
     assert np.float32(got["dist_q0_g0_64"]) == oracle.feature_distance(q[0], gal[0], 0, 64, 0)
     acc = np.mean(np.array(got["bf_1536_batch"]) == np.array(got["query_class"]))
