@@ -671,7 +671,7 @@ def pmc_traffic(args, n, d, world):
                         continue
                     if "k_scan_l2" in r["Kernel_Name"]:
                         vals["scan"].append(float(r["Counter_Value"]))
-                    elif "k_gemm_proxy_f16<1" in r["Kernel_Name"]:
+                    elif "k_gemm_proxy_f16" in r["Kernel_Name"] and ("<1," in r["Kernel_Name"] or "false>" in r["Kernel_Name"]):
                         vals["mfma"].append(float(r["Counter_Value"]))
             if vals["scan"] or vals["mfma"]:
                 res = {k: (sum(v) / len(v) * 1024 * 2 if v else None) for k, v in vals.items()}

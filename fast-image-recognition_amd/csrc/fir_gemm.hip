@@ -948,6 +948,8 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16(const uint4* _
 #undef FIR_H_LD
 }
 
+#include "fir_gemm_regtile.h"
+
 // tau[q] = kCand-th smallest sampled proxy, nudged up so that ties with it are appended too. One block per
 // query, ONE pass over the samples: every thread keeps its kCand smallest keys sorted in registers, then kCand
 // rounds of block-min pop the global order statistics.
@@ -1177,6 +1179,9 @@ struct fir_gemm {
     int rerank_group = kRerankGroup;      // candidate rows the re-rank stages in LDS at a time
     int streamed = -1;                    // fp16: query slabs through the LDS double buffer (-1: when the tile does not fit, d > 512)
     bool wide = true;                     // bf16: pairs of passes through k_gemm_proxy_bf16_wide (FIR_GEMM_WIDE=0 turns it off)
+    unsigned int* smin[2] = {nullptr, nullptr};   // register-tile flow: smallest sampled proxy per query (orderable bits)
+    int rt_sample_rows = 0;                // ... over this many rows (n / 16)
+    int regtile = -1;                     // fp16 full pass through the register-tile kernel: -1 = where it measured faster (rows up to 256 features), 0 / 1 = never / wherever it exists (FIR_GEMM_REGTILE)                  // fp16 full pass: query fragments in registers, gallery through the LDS-DMA ring (FIR_GEMM_REGTILE=0: the LDS-tile kernel)
     int share_max = 8;                    // fp16: up to this many pairs of passes (x 128 queries) read the gallery together in one launch (FIR_GEMM_SHARE; 0 = the old one-pair-at-a-time grid)
 };
 
@@ -1216,6 +1221,7 @@ int fir_gemm_create_ex(fir_gallery* g, int32_t precision, fir_gemm** out) {
         if (e == hipSuccess) e = hipMalloc((void**)&m->qnorm[b], kPasses * kQT * sizeof(float));
         if (e == hipSuccess) e = hipMalloc((void**)&m->qmul[b], kPasses * kQT * sizeof(float));
         if (e == hipSuccess) e = hipMalloc((void**)&m->qinv[b], kPasses * kQT * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc((void**)&m->smin[b], kPasses * kQT * sizeof(unsigned int));
         if (e == hipSuccess) e = hipMalloc((void**)&m->tau[b], kPasses * kQT * sizeof(float));
         if (e == hipSuccess) e = hipMalloc((void**)&m->lists[b], (size_t)kPasses * kQT * kListCap * sizeof(unsigned long long));
         if (e == hipSuccess) e = hipMalloc((void**)&m->counts[b], kPasses * kQT * sizeof(int));
@@ -1226,6 +1232,7 @@ int fir_gemm_create_ex(fir_gallery* g, int32_t precision, fir_gemm** out) {
     if (e == hipSuccess) e = hipEventCreateWithFlags(&m->queries_ready, hipEventDisableTiming);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking);
     m->sample_rows = (int)std::min<int64_t>(np, std::max<int64_t>(kMinSampleRows, np / 64));
+    m->rt_sample_rows = (int)std::min<int64_t>(np, std::max<int64_t>(kMinSampleRows, np / 16));
     if (e == hipSuccess) e = hipMalloc((void**)&m->sample, (size_t)kPasses * kQT * m->sample_rows * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&m->fbq, (size_t)kQT * m->v.d * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&m->fbkeys, kQT * sizeof(unsigned long long));
@@ -1247,7 +1254,12 @@ int fir_gemm_create_ex(fir_gallery* g, int32_t precision, fir_gemm** out) {
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy_f16<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kHalfLds);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy_f16<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kHalfLds);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy_f16<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kHalfLds);
+#define FIR_RT_ATTR(D) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy_f16_regtile<D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RegTile<D>::lds_bytes); \
+                       if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy_f16_regtile<D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RegTile<D>::lds_bytes);
+    FIR_RT_ATTR(8) FIR_RT_ATTR(16) FIR_RT_ATTR(32)
+#undef FIR_RT_ATTR
     if (const char* w = std::getenv("FIR_GEMM_SHARE")) m->share_max = std::max(0, std::min(8, std::atoi(w)));
+    if (const char* w = std::getenv("FIR_GEMM_REGTILE")) m->regtile = std::atoi(w);
     if (const char* w = std::getenv("FIR_GEMM_STREAMED")) m->streamed = std::atoi(w);   // experiments: 0 / 1 force the form, -1 = by row length
     if (e == hipSuccess && m->v.n > 0) {
         // row norms come from the f32 packer (run on a one-group scratch when only the bf16 fragments are kept)
@@ -1297,7 +1309,7 @@ int fir_gemm_destroy(fir_gemm* m) {
     (void)hipStreamSynchronize(m->v.stream);
     if (m->side) { (void)hipStreamSynchronize(m->side); (void)hipStreamDestroy(m->side); }
     for (int b = 0; b < 2; ++b) {
-        (void)hipFree(m->qm[b]); (void)hipFree(m->qbf[b]); (void)hipFree(m->qnorm[b]); (void)hipFree(m->qmul[b]); (void)hipFree(m->qinv[b]); (void)hipFree(m->tau[b]); (void)hipFree(m->lists[b]); (void)hipFree(m->counts[b]);
+        (void)hipFree(m->qm[b]); (void)hipFree(m->qbf[b]); (void)hipFree(m->qnorm[b]); (void)hipFree(m->qmul[b]); (void)hipFree(m->qinv[b]); (void)hipFree(m->smin[b]); (void)hipFree(m->tau[b]); (void)hipFree(m->lists[b]); (void)hipFree(m->counts[b]);
         if (m->main_done[b]) (void)hipEventDestroy(m->main_done[b]);
         if (m->rerank_done[b]) (void)hipEventDestroy(m->rerank_done[b]);
         if (m->prep_done[b]) (void)hipEventDestroy(m->prep_done[b]);
@@ -1350,6 +1362,19 @@ int fir_gemm_search_top1_keys_dev(fir_gemm* m, const float* d_queries, int32_t q
     // prep(0) prep(1) rerank(0) prep(2) rerank(1) ... -- prep(i+2) reuses the scratch set rerank(i) has just finished with.
     GEMM_HIP(hipEventRecord(m->queries_ready, st));
     GEMM_HIP(hipStreamWaitEvent(m->side, m->queries_ready, 0));
+    // the register-tile flow (fir_gemm_regtile.h) for fp16 galleries whose rows fit the compute waves' registers
+    typedef void (*rt_fn)(const uint4*, const float*, const uint4*, const float*, int64_t, int64_t, const float*, unsigned long long*, int*, unsigned int*, int, int);
+    rt_fn rt_main = nullptr, rt_sample = nullptr;
+    size_t rt_lds = 0;
+    if (m->precision == FIR_GEMM_F16 && m->share_max > 0 && (grid & 7) == 0 && grid >= 8) {
+#define FIR_RT_PICK(D) if (m->dk16 == D) { rt_main = k_gemm_proxy_f16_regtile<D, false>; rt_sample = k_gemm_proxy_f16_regtile<D, true>; rt_lds = RegTile<D>::lds_bytes; }
+        FIR_RT_PICK(8) FIR_RT_PICK(16) FIR_RT_PICK(32)
+#undef FIR_RT_PICK
+    }
+    const bool rt_flow = rt_main != nullptr;        // sample pass + tau through the register-tile kernel (smallest sampled proxy + one window)
+    // the full pass: both kernels run at ~1 KiB of LDS traffic per MFMA and within 7 % of each other (profiles/r02_gemm_kernel_choice.txt):
+    // register tile ahead up to 256 features, LDS tile ahead at 512
+    const bool rt_full = rt_flow && (m->regtile > 0 || (m->regtile < 0 && m->dk16 <= 16));
     auto prep = [&](int sb) -> int {
         hipStream_t ps = m->side;
         const int q0 = sb * kPasses * kQT;
@@ -1363,6 +1388,20 @@ int fir_gemm_search_top1_keys_dev(fir_gemm* m, const float* d_queries, int32_t q
             GEMM_HIP(hipMemsetAsync(m->counts[b], 0, (size_t)pairs * 2 * kQT * sizeof(int), ps));
             hipLaunchKernelGGL(k_gemm_pack_queries_f16, dim3((4 * m->dk16 * 64 + 255) / 256, pairs), dim3(256), 0, ps, dq, nq, d, m->dk16, m->qmul[b],
                                m->qbf[b]);
+            if (rt_flow) {
+                // the smallest proxy of a row sample per query (register-tile kernel over rows [0, rt_sample_rows)), tau = that + one window
+                GEMM_HIP(hipMemsetD32Async((hipDeviceptr_t)m->smin[b], (int)0xFF800000u, (size_t)pairs * 2 * kQT, ps));
+                for (int p0 = 0; p0 < pairs;) {
+                    int P = 1;
+                    while (P * 2 <= pairs - p0 && P * 2 <= m->share_max) P *= 2;
+                    const size_t qo = (size_t)p0;
+                    hipLaunchKernelGGL(rt_sample, dim3(grid), dim3(512), rt_lds, ps, m->gh, m->gnorm, m->qbf[b] + qo * 4 * m->dk16 * 64, m->qinv[b] + qo * 2 * kQT, n,
+                                       (int64_t)m->rt_sample_rows, m->tau[b] + qo * 2 * kQT, m->lists[b] + qo * 2 * kQT * kListCap, m->counts[b] + qo * 2 * kQT,
+                                       m->smin[b] + qo * 2 * kQT, P, P <= 1 ? 1 : 0);
+                    p0 += P;
+                }
+                hipLaunchKernelGGL(k_gemm_tau_min, dim3((pairs * 2 * kQT + 255) / 256), dim3(256), 0, ps, m->smin[b], m->tau[b], pairs * 2 * kQT, nq, m->qnorm[b], m->gmax, e_rel);
+            } else {
             const int wpb = kGemmBlock / 64;
             const int sample_wgs = (int)((((int64_t)sample_rows + 31) / 32 + wpb - 1) / wpb);
             const bool streamed = m->streamed >= 0 ? m->streamed != 0 : m->dk16 > kSlabH;
@@ -1375,6 +1414,7 @@ int fir_gemm_search_top1_keys_dev(fir_gemm* m, const float* d_queries, int32_t q
                                    (int64_t)sample_rows, m->dk16, m->tau[b], m->lists[b], m->counts[b], m->sample, sample_rows, 0, 1);
             hipLaunchKernelGGL(k_gemm_tau, dim3(pairs * 2 * kQT), dim3(256), 0, ps, m->sample, (sample_rows + 31) / 32, m->tau[b], nq, m->qnorm[b], m->gmax,
                                e_rel, 2 * kQT);
+            }
         } else {
             hipLaunchKernelGGL(k_gemm_qnorm, dim3(np * kQT), dim3(64), 0, ps, dq, nq, d, m->qnorm[b]);
             GEMM_HIP(hipMemsetAsync(m->counts[b], 0, (size_t)np * kQT * sizeof(int), ps));
@@ -1424,6 +1464,8 @@ int fir_gemm_search_top1_keys_dev(fir_gemm* m, const float* d_queries, int32_t q
             const double flops = 2.0 * (double)n * d * 128.0 * pairs;
             int rc2 = fir_gallery_profile_begin_(m->g, st);
             if (rc2) return rc2;
+            bool used_rt = false;
+            size_t used_rt_lds = 0;
             // the pairs of the super-batch read the gallery together, a power of two (<= share_max) of them per launch
             for (int p0 = 0; p0 < pairs;) {
                 int P = 1;
@@ -1432,7 +1474,12 @@ int fir_gemm_search_top1_keys_dev(fir_gemm* m, const float* d_queries, int32_t q
                 const dim3 g1 = share > 0 ? dim3(grid, 1) : dim3(grid, P);
                 const int nt = (share <= 1) ? 1 : 0;
                 const size_t qo = (size_t)p0;
-                if (streamed)
+                if (rt_full && share > 0 && grid / 8 >= share) {
+                    hipLaunchKernelGGL(rt_main, dim3(grid), dim3(512), rt_lds, st, m->gh, m->gnorm, m->qbf[b] + qo * 4 * m->dk16 * 64, m->qinv[b] + qo * 2 * kQT, n, n,
+                                       m->tau[b] + qo * 2 * kQT, m->lists[b] + qo * 2 * kQT * kListCap, m->counts[b] + qo * 2 * kQT, m->smin[b] + qo * 2 * kQT, share, nt);
+                    used_rt = true;
+                    used_rt_lds = rt_lds;
+                } else if (streamed)
                     hipLaunchKernelGGL((k_gemm_proxy_f16<1, 1>), g1, dim3(kGemmBlock), kHalfLds, st, m->gh, m->gnorm, m->qbf[b] + qo * 4 * m->dk16 * 64, m->qinv[b] + qo * 2 * kQT,
                                        n, (int64_t)0, n, m->dk16, m->tau[b] + qo * 2 * kQT, m->lists[b] + qo * 2 * kQT * kListCap, m->counts[b] + qo * 2 * kQT, m->sample,
                                        sample_rows, share, nt);
@@ -1443,6 +1490,12 @@ int fir_gemm_search_top1_keys_dev(fir_gemm* m, const float* d_queries, int32_t q
                 p0 += P;
             }
             if ((rc2 = fir_gallery_profile_end_(m->g, st, bytes))) return rc2;
+            if (used_rt) {
+                char nm[64];
+                std::snprintf(nm, sizeof nm, "fir::k_gemm_proxy_f16_regtile<%d, false>", m->dk16);
+                const void* fp = (const void*)rt_main;
+                fir_gallery_note_dispatch_(m->g, fp, nm, sb == 0, grid, nlaunch, 512, used_rt_lds, 128 * p_first, bytes, flops);
+            } else
             fir_gallery_note_dispatch_(m->g, streamed ? (const void*)k_gemm_proxy_f16<1, 1> : (const void*)k_gemm_proxy_f16<1, 0>,
                                        streamed ? "fir::k_gemm_proxy_f16<1, 1>" : "fir::k_gemm_proxy_f16<1, 0>", sb == 0, grid, m->share_max > 0 ? nlaunch : pairs, kGemmBlock, kHalfLds,
                                        m->share_max > 0 ? 128 * p_first : 128, bytes, flops);

@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <stdint.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <condition_variable>
@@ -191,6 +192,9 @@ struct fir_sharded {
 
 namespace {
 
+int setup_devices(std::vector<DevCtx>& devs, const int32_t* devices, int ndev, int nranks, int first_rank, const void* comm_id);
+void teardown_devices(std::vector<DevCtx>& devs);
+
 // Run fn(slot) for every device: inline for one device, on the per-device worker threads otherwise.
 int run_all(std::vector<DevCtx>& devs, const std::function<int(int)>& fn);
 int run_all(fir_sharded* h, const std::function<int(int)>& fn) { return run_all(h->devs, fn); }
@@ -361,12 +365,20 @@ int setup_devices(std::vector<DevCtx>& devs, const int32_t* devices, int ndev, i
         SH_HIP(hipSetDevice(dc.device));
         SH_HIP(hipStreamCreateWithFlags(&dc.stream, hipStreamNonBlocking));
     }
+    // RCCL writes its version banner to STDOUT when a process's first communicator comes up. The callers of this library print
+    // results there (the reference's harnesses, whose output must stay diffable): file descriptor 1 points at stderr while the
+    // communicator is created.
+    std::fflush(stdout);
+    const int saved_stdout = dup(1);
+    if (saved_stdout >= 0) (void)dup2(2, 1);
     ncclResult_t nr = ncclGroupStart();
     for (int s = 0; s < ndev && nr == ncclSuccess; ++s) {
         (void)hipSetDevice(devs[(size_t)s].device);
         nr = ncclCommInitRank(&devs[(size_t)s].comm, nranks, id, first_rank + s);
     }
     if (nr == ncclSuccess) nr = ncclGroupEnd(); else (void)ncclGroupEnd();
+    std::fflush(stdout);
+    if (saved_stdout >= 0) { (void)dup2(saved_stdout, 1); (void)close(saved_stdout); }
     if (nr != ncclSuccess) return sh_fail(FIR_ERR_COMM, "RCCL communicator of %d ranks: %s", nranks, ncclGetErrorString(nr));
     if (ndev > 1)
         for (int s = 0; s < ndev; ++s) {
@@ -591,20 +603,7 @@ int fir_sharded_destroy(fir_sharded* h) {
     if (!h) return FIR_OK;
     for (Shard& s : h->shards)
         if (s.g) fir_gallery_destroy(s.g);
-    for (DevCtx& dc : h->devs) {
-        if (dc.worker) {
-            { std::lock_guard<std::mutex> lk(dc.worker->mu); dc.worker->quit = true; }
-            dc.worker->cv.notify_all();
-            if (dc.worker->th.joinable()) dc.worker->th.join();
-            delete dc.worker;
-        }
-        (void)hipSetDevice(dc.device);
-        if (dc.stream) (void)hipStreamSynchronize(dc.stream);
-        if (dc.comm) (void)ncclCommDestroy(dc.comm);
-        (void)hipFree(dc.dq); (void)hipFree(dc.parts); (void)hipFree(dc.keys); (void)hipFree(dc.gath); (void)hipFree(dc.cls);
-        for (hipEvent_t e : dc.evs) (void)hipEventDestroy(e);
-        if (dc.stream) (void)hipStreamDestroy(dc.stream);
-    }
+    teardown_devices(h->devs);
     if (h->pin) (void)hipHostFree(h->pin);
     delete h;
     return FIR_OK;
@@ -669,31 +668,8 @@ int fir_gallery_create_sharded_ex(const float* rows, int64_t n, int32_t d, const
     }
     if (rc) return bail(rc);
 
-    // per-device stream, events, communicator (rank = proc * ndev + slot)
-    ncclUniqueId id;
-    if (o.comm_id) std::memcpy(&id, o.comm_id, sizeof id);
-    else if (ncclGetUniqueId(&id) != ncclSuccess) return bail(sh_fail(FIR_ERR_COMM, "ncclGetUniqueId failed"));
-    for (int s = 0; s < ndev; ++s) {
-        DevCtx& dc = h->devs[(size_t)s];
-        dc.device = devices[s];
-        hipError_t e = hipSetDevice(dc.device);
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&dc.stream, hipStreamNonBlocking);
-        if (e != hipSuccess) return bail(sh_fail(FIR_ERR_HIP, "device %d set-up: %s", dc.device, hipGetErrorString(e)));
-    }
-    ncclResult_t nr = ncclGroupStart();
-    for (int s = 0; s < ndev && nr == ncclSuccess; ++s) {
-        (void)hipSetDevice(h->devs[(size_t)s].device);
-        nr = ncclCommInitRank(&h->devs[(size_t)s].comm, h->nranks, id, h->rank0 + s);
-    }
-    if (nr == ncclSuccess) nr = ncclGroupEnd(); else (void)ncclGroupEnd();
-    if (nr != ncclSuccess) return bail(sh_fail(FIR_ERR_COMM, "RCCL communicator of %d ranks: %s", h->nranks, ncclGetErrorString(nr)));
-    if (ndev > 1)
-        for (int s = 0; s < ndev; ++s) {
-            Worker* w = new (std::nothrow) Worker();
-            if (!w) return bail(sh_fail(FIR_ERR_NOMEM, "host allocation failed"));
-            h->devs[(size_t)s].worker = w;
-            w->th = std::thread([w] { w->loop(); });
-        }
+    // per-device stream, communicator (rank = proc * ndev + slot), worker threads
+    if ((rc = setup_devices(h->devs, devices, ndev, h->nranks, h->rank0, o.comm_id))) return bail(rc);
     *out = h;
     return FIR_OK;
 }
