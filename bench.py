@@ -204,6 +204,7 @@ class Matcher:
         self.ws = work_stream
         self.stream = work_stream.cuda_stream
         self.sh = None
+        self.torch_nccl = False
         self.in_library_rccl = (dist is not None and args.backend == "nccl") or args.shards_per_device > 1 or args.force_dist
         if self.in_library_rccl:
             # the key exchange is the library's: every rank passes the id rank 0 made
@@ -212,9 +213,26 @@ class Matcher:
                 idt.copy_(torch.frombuffer(bytearray(fir.comm_unique_id()), dtype=torch.uint8))
             if dist is not None and world > 1:
                 dist.broadcast(idt, 0)
-            self.sh = fir.ShardedGallery(dev_ptr=shard.data_ptr(), n=n_local, d=d, metric=fir.METRIC_L2, devices=[local_rank],
-                                         shards_per_device=args.shards_per_device, first_global_row=row_lo,
-                                         comm_id=bytes(idt.cpu().numpy().tobytes()), proc_rank=rank, nprocs=world)
+            err = None
+            try:
+                self.sh = fir.ShardedGallery(dev_ptr=shard.data_ptr(), n=n_local, d=d, metric=fir.METRIC_L2, devices=[local_rank],
+                                             shards_per_device=args.shards_per_device, first_global_row=row_lo,
+                                             comm_id=bytes(idt.cpu().numpy().tobytes()), proc_rank=rank, nprocs=world)
+            except fir.FirError as e:      # the ranks must agree on what happens next
+                err = e
+            ok = torch.tensor([0 if err else 1], device=dev, dtype=torch.int32)
+            if dist is not None and world > 1:
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                if world == 1 or dist is None:
+                    raise err
+                print(f"bench.py: rank {rank}: the library's RCCL communicator could not be created ({err}); every rank falls back to torch.distributed's", file=sys.stderr)
+                if self.sh is not None:
+                    self.sh.close()
+                    self.sh = None
+                self.in_library_rccl = False
+                self.torch_nccl = True
+        if self.sh is not None:
             self.parts = [self.sh.shard(i)[0] for i in range(self.sh.info()["nshards"])]
             self.parts = [p for p in self.parts if p is not None]
             self.g = self.parts[0]
@@ -237,7 +255,11 @@ class Matcher:
                 self.sh.search_top1_keys_dev(q.data_ptr(), qb, keys.data_ptr(), stream=self.stream)      # scan + ncclAllReduce(min, u64)
                 return
             self.g.search_top1_keys_dev(q.data_ptr(), qb, keys.data_ptr(), stream=self.stream)
-            if self.dist is not None:            # gloo rehearsal: ranks share a GPU, the keys go through host memory
+            if self.dist is not None and self.torch_nccl:      # fallback: torch.distributed's RCCL all-reduce(MIN) on the order-preserving int64 view
+                k = self.sharding.keys_as_int64(keys)
+                self.sharding.allreduce_min_keys(k)
+                keys.copy_(self.sharding.keys_from_int64(k))
+            elif self.dist is not None:          # gloo rehearsal: ranks share a GPU, the keys go through host memory
                 k = self.sharding.keys_as_int64(keys)
                 kh = k.cpu()
                 self.sharding.allreduce_min_keys(kh)
@@ -455,6 +477,7 @@ def main():
                 "planted_queries_found": planted_ok,
                 "row_sharding": f"{world} rank(s) x {args.shards_per_device} shard(s), {m_n} rows on this rank",
                 "key_exchange": ("RCCL ncclAllReduce(ncclMin, ncclUint64) issued by libfir_amd.so (fir_sharded_search_top1_keys_dev)" if m.in_library_rccl
+                                 else "torch.distributed RCCL all-reduce(MIN) (the library's communicator could not be created)" if m.torch_nccl
                                  else "torch.distributed gloo through host memory (rehearsal)") if (world > 1 or m.in_library_rccl) else None,
                 "exchange_us_per_step": float(np.mean(head["exch_ms"]) * 1e3) if len(head["exch_ms"]) else None,
                 "exact_scan": {"queries_per_pass": tuning["queries_per_pass"], "waves": tuning["waves"], "query_batch": sqb,
@@ -492,9 +515,12 @@ def rate(fn, nq, reps):
     return nq * reps / (time.perf_counter() - t_0)
 
 
-# VALU issue slots (wave64 instructions) per (row, feature, query) element of the plain-range chi-square / KL scans, counted
-# in the compiled loops (chi-square 12.6 of which the quarter-rate v_rcp_f32 is 4; KL 34 of which v_rcp + 2 v_log are 12)
-CHI2_SLOTS, KL_SLOTS = 12.6, 34.0
+# VALU issue slots (4 cycles of a SIMD's vector issue) per (row, feature, query) element of the plain-range chi-square / KL
+# scans, counted in the compiled loops of k_scan<8, 3 / 4, ...> (llvm-objdump of libfir_amd.so, 384 elements per loop body):
+# chi-square 10.0 vector instructions (2.94 v_pk_fma, 0.98 v_pk_add, 0.98 v_pk_mul, 1 v_add, 1 v_max, 1 v_rcp, ...) + 1 for the
+# 8-cycle v_rcp_f32 = 11.0; KL 24.9 + 2.96 for v_rcp + 2 v_log = 27.9. The s_nop hazard padding the compiler adds (1.7 / 5.7
+# per element) is not counted: it is part of what keeps the achieved rate below the peak.
+CHI2_SLOTS, KL_SLOTS = 11.0, 27.9
 
 
 def other_scans(fir, g, q, keys, dev, ws, n, d):
@@ -540,7 +566,7 @@ def other_scans(fir, g, q, keys, dev, ws, n, d):
             per_pass_ms /= passes
             elems_per_pass = float(n) * d * qpp
             wave_instr_per_s = elems_per_pass / 64.0 * slots / (per_pass_ms * 1e-3) if per_pass_ms == per_pass_ms else float("nan")
-            also[f"roofline_{name}"] = {"bound": "valu", "model": f"{slots} VALU issue slots per (row, feature, query) element in the plain-range form (DESIGN.md section 4), "
+            also[f"roofline_{name}"] = {"bound": "valu", "model": f"{slots} VALU issue slots per (row, feature, query) element in the plain-range form (counted in the compiled loop, bench.py), "
                                                                     "peak = 256 CUs x 4 SIMDs x one wave64 instruction per 4 cycles at 2.4 GHz",
                                        "achieved": wave_instr_per_s / 1e9, "peak": PEAK_VALU_WAVE_INSTR_PER_S / 1e9, "unit": "G wave-instructions/s",
                                        "frac": wave_instr_per_s / PEAK_VALU_WAVE_INSTR_PER_S, "kernel": dsp["kernel"] + " (launched next to its plain-range twin; the one that applies runs)",
