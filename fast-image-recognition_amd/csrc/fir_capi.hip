@@ -67,6 +67,7 @@ struct fir_gallery {
     // transposition that met one (fir_common.h); the scans read both and pick their division sequence on the device
     int32_t* range = nullptr;
     int q_serial = 0;
+    bool gallery_plain = false;   // host copy of range[0] == 0, read once after the upload (chi-square nomination, topk_lists_dev)
     uint64_t* one_keys = nullptr;   // one-query calls on small galleries (top1_one_query): device key + completion counter, armed once
     int32_t* one_done = nullptr;    // and re-armed by the kernel itself
     uint64_t one_ticket = 0;        // number of such calls so far: the word the host waits for
@@ -399,8 +400,20 @@ int run_pass(fir_gallery* g, hipStream_t st, int epi, const float* d_queries, in
     return FIR_OK;
 }
 
+int topk_lists_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start, int32_t end, int32_t k, uint64_t* d_keys,
+                   hipStream_t st);
+
 int top1_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start, int32_t end, uint64_t* d_keys,
              hipStream_t st) {
+    // chi-square batches over a large plain-range gallery: nomination scan + exact re-rank (topk_lists_dev with K = 1), the same
+    // keys at about twice the rate; it synchronises `st` once (it has to know that no list overflowed) and leaves the call to the
+    // exact scan below when it cannot answer (operands outside the plain range, list overflow)
+    if (g->metric == kChi2 && g->gallery_plain && g->tiles_limit == 0 && !g->quiet && !g->profiling && qb >= 8 && g->n >= 65536 && g->qpp == 0) {
+        int rc0 = FIR_OK;
+        for (int q0 = 0; q0 < qb && rc0 == FIR_OK; q0 += 1024)       // candidate lists are 32 KiB per query: bounded scratch for any qb
+            rc0 = topk_lists_dev(g, d_queries + (size_t)q0 * g->d, std::min(1024, qb - q0), start, end, 1, d_keys + q0, st);
+        if (rc0 != FIR_ERR_STATE) return rc0;
+    }
     int rc = grow(g->qt, g->qt_cap, (size_t)qb * g->dp4 * 4 + 64);   // +64: the fast kernel prefetches one unit past the tile
     if (rc) return rc;
     // 16 queries per pass exist only in the hand-scheduled kernel (whole-chunk L2 ranges)
@@ -468,6 +481,14 @@ int topk_lists_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t s
     scan_fn probe = pick_fast(kEpiTop1, 8, g->metric, start, end, g->dp4, &lds_bytes);
     const bool fast = probe && lds_bytes > 0 && lds_bytes <= 64 * 1024;
     if (!fast) lds_bytes = 0;
+    // chi-square over a plain-range gallery: the append scan runs a NOMINATION metric (1-ulp reciprocal, 5.5 instead of 11 issue
+    // slots per element) against a threshold widened by its error bound, and the few hundred appended rows per query are
+    // re-ranked with the reference's arithmetic before the K smallest are taken: the same keys as the exact scan, about twice
+    // as fast. Every row whose reference distance is <= the unwidened threshold is appended (approx <= exact (1 + eps)), and
+    // the K-th smallest reference distance is <= that threshold (K sample rows are), so the K best are all in the list.
+    static const bool no_nominate = std::getenv("FIR_NO_CHI2_NOMINATION") != nullptr;      // experiments
+    const bool nominate = g->metric == kChi2 && g->gallery_plain && !no_nominate && (size_t)g->d * sizeof(float) <= 48 * 1024;
+    const float tau_scale = nominate ? 1.0f + 1.5f * (2.0f * (float)(end - start) + 16.0f) * 5.9604645e-8f : 1.0f;
     const int qpad = (qb + 7) / 8 * 8;
     void *p_skeys = nullptr, *p_small = nullptr, *p_lists = nullptr;
     int rc;
@@ -493,14 +514,16 @@ int topk_lists_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t s
     g->tile_begin = 0;
     if (rc) return rc;
     FIR_HIP(hipMemsetAsync(flag, 0, 4, st));
-    hipLaunchKernelGGL(k_topk_tau, dim3((qpad + 63) / 64), dim3(64), 0, st, skeys, qb, qpad, k, tau, counts, flag);
+    hipLaunchKernelGGL(k_topk_tau, dim3((qpad + 63) / 64), dim3(64), 0, st, skeys, qb, qpad, k, tau, counts, flag, tau_scale);
     // 2. the append scan over the whole gallery: 8 queries per tile, every tile of the call in one launch (blockIdx.y)
     const int kk = g->dp4 * 4;
     scan_fn fn = fast ? (scan_fn)k_scan_l2_lds<1, FIR_FAST_U, FIR_FAST_WPS, true>
+                      : nominate ? (scan_fn)k_scan<8, kChi2Approx, kU, kEpiAppend, kKMax, kWpsPlain>
                       : g->metric == kL2 ? (scan_fn)k_scan<8, kL2, kU, kEpiAppend, kKMax, kWps>
                       : g->metric == kChi2 ? (scan_fn)k_scan<8, kChi2, kU, kEpiAppend, kKMax, kWps>
                                            : (scan_fn)k_scan<8, kKL, kU, kEpiAppend, kKMax, kWps>;
-    const scan_fn fn_plain = g->metric == kChi2 ? (scan_fn)k_scan<8, kChi2InRange, kU, kEpiAppend, kKMax, kWpsPlain>
+    const scan_fn fn_plain = nominate ? nullptr
+                           : g->metric == kChi2 ? (scan_fn)k_scan<8, kChi2InRange, kU, kEpiAppend, kKMax, kWpsPlain>
                            : g->metric == kKL ? (scan_fn)k_scan<8, kKLInRange, kU, kEpiAppend, kKMax, kWpsPlain> : nullptr;   // see run_pass
     int max_waves = max_waves_for(g, fn, lds_bytes);
     if (fn_plain) max_waves = std::min(max_waves, max_waves_for(g, fn_plain, lds_bytes));
@@ -529,10 +552,15 @@ int topk_lists_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t s
         a.counts = counts + q0;
         a.qt_stride = (int64_t)kk * 8;
         a.nt = gallery_bytes(g) > kL2ResidentBytes ? 1 : 0;
+        a.flag = flag;
         hipLaunchKernelGGL(fn, dim3(waves / 4, ny), dim3(kBlock), lds_bytes, st, a);
         if (fn_plain) hipLaunchKernelGGL(fn_plain, dim3(waves / 4, ny), dim3(kBlock), lds_bytes, st, a);
     }
-    // 3. the K smallest keys of every list
+    // 3. (nomination) the reference's distance of every appended row, keys rewritten in place
+    if (nominate)
+        hipLaunchKernelGGL(k_list_rerank<kChi2>, dim3(qb), dim3(kBlock), (size_t)g->d * sizeof(float), st, lists, counts, kListCap, g->gal4, g->dp4, g->n,
+                           g->row_offset, d_queries, g->d, start, end);
+    // 4. the K smallest keys of every list
     hipLaunchKernelGGL(k_topk_select, dim3(qb), dim3(kBlock), 0, st, lists, counts, kListCap, k, d_keys, flag);
     FIR_HIP(hipGetLastError());
     int32_t h_flag = 0;
@@ -821,6 +849,7 @@ int fir_gallery_create(const float* rows, int64_t n, int32_t d, const int32_t* c
         if (e != hipSuccess) rc = fail(FIR_ERR_HIP, "class upload: %s", hipGetErrorString(e));
     }
     if (rc) { fir_gallery_destroy(g); return rc; }
+    { int32_t r0 = 1; if (hipMemcpy(&r0, g->range, sizeof r0, hipMemcpyDeviceToHost) == hipSuccess) g->gallery_plain = r0 == 0; }
     *out = g;
     return FIR_OK;
 }
@@ -848,6 +877,7 @@ int fir_gallery_create_dev(const float* d_rows, int64_t n, int32_t d, const int3
         if (e != hipSuccess) rc = fail(FIR_ERR_HIP, "gallery retile: %s", hipGetErrorString(e));
     }
     if (rc) { fir_gallery_destroy(g); return rc; }
+    { int32_t r0 = 1; if (hipMemcpy(&r0, g->range, sizeof r0, hipMemcpyDeviceToHost) == hipSuccess) g->gallery_plain = r0 == 0; }
     *out = g;
     return FIR_OK;
 }

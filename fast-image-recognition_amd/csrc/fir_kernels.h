@@ -87,6 +87,7 @@ struct ScanArgs {
     uint64_t ticket;      // the stream -- and re-arms keys and the done counter for the next call
     const int32_t* range; // chi-square / KL: range[0] != 0 = some gallery value is outside in_plain_range(), range[1] = serial
     int32_t serial;       // of the last query transposition that met one; NULL or a match = IEEE division sequence
+    int32_t* flag;        // kChi2Approx (nomination scan): raised when the operands are not all in the plain range -- the caller falls back
 };
 
 template <int QB, int METRIC, int U>
@@ -100,6 +101,29 @@ struct TileAcc {
     }
     static __device__ __forceinline__ void chunk(float (&acc)[QB], const float4 g, const float (&sq)[kSq]) {
         const float gv[4] = {g.x, g.y, g.z, g.w};
+        if constexpr (METRIC == kChi2Approx && (QB % 2) == 0) {
+            // the nomination metric two queries at a time: v_pk_add (l - r, by neg), v_pk_add (l + r), 2 v_max, 2 v_rcp, v_pk_mul x 2,
+            // v_pk_add = 5.5 issue slots per element (the scalar form the compiler finds: 7.2; the exact division sequence: 11)
+            typedef float f2v __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f2v g2 = {gv[j], gv[j]};
+#pragma unroll
+                for (int p = 0; p < QB / 2; ++p) {
+                    const f2v l2 = {sq[j * QB + 2 * p], sq[j * QB + 2 * p + 1]};
+                    const f2v df = l2 - g2;
+                    const f2v s2 = l2 + g2;
+                    const f2v r2 = {__builtin_amdgcn_rcpf(__builtin_fmaxf(s2.x, 0x1p-60f)), __builtin_amdgcn_rcpf(__builtin_fmaxf(s2.y, 0x1p-60f))};
+                    const f2v t2 = (df * df) * r2;
+                    f2v a2 = {acc[2 * p], acc[2 * p + 1]};
+                    a2 = a2 + t2;
+                    acc[2 * p] = a2.x;
+                    acc[2 * p + 1] = a2.y;
+                }
+                if constexpr (QB >= 4) __builtin_amdgcn_sched_barrier(0);
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
 #pragma unroll
@@ -149,7 +173,13 @@ __global__ void __launch_bounds__(kBlock, WPS) k_scan(const ScanArgs a) {
         // chi-square / KL come as a pair of launches: the kernel whose arithmetic matches the operands of this call runs
         // (every value in the plain range -> the kChi2InRange / kKLInRange form, fir_common.h), the other one returns here
         const bool plain = a.range != nullptr && a.range[0] == 0 && a.range[1] != a.serial;
-        if (plain != (METRIC == kChi2InRange || METRIC == kKLInRange)) return;
+        if constexpr (METRIC == kChi2Approx) {
+            // launched alone; its error bound needs non-negative, normal operands: otherwise the caller's exact path answers
+            if (!plain) {
+                if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && a.flag) atomicOr(a.flag, 1);
+                return;
+            }
+        } else if (plain != (METRIC == kChi2InRange || METRIC == kKLInRange)) return;
     }
     const int lane = threadIdx.x & 63;
     const int gw = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
@@ -727,7 +757,7 @@ __global__ void __launch_bounds__(kBlock) k_topk_merge(const uint64_t* part, int
 // A group without any row below 100000 raises the flag (the caller then uses the register-list scan). Padding queries
 // [nq, nq_pad) get a threshold nothing reaches.
 __global__ void k_topk_tau(const uint64_t* __restrict__ gkeys, int nq, int nq_pad, int K, float* __restrict__ tau, int32_t* __restrict__ counts,
-                           int32_t* __restrict__ flag) {
+                           int32_t* __restrict__ flag, float scale = 1.0f) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nq_pad) return;
     counts[q] = 0;
@@ -738,7 +768,8 @@ __global__ void k_topk_tau(const uint64_t* __restrict__ gkeys, int nq, int nq_pa
         worst = key > worst ? key : worst;
     }
     if (worst == kKeyNone) { tau[q] = -1.0f; atomicOr(flag, 1); return; }
-    tau[q] = f32_from_orderable((uint32_t)(worst >> 32));
+    // scale > 1: the append scan that follows uses a cheaper metric whose value is within (scale - 1) of the reference's
+    tau[q] = f32_from_orderable((uint32_t)(worst >> 32)) * scale;
 }
 // The K smallest keys of each query's candidate list (count <= cap entries; more raises the flag). One block per query.
 __global__ void __launch_bounds__(kBlock) k_topk_select(const uint64_t* __restrict__ lists, const int32_t* __restrict__ counts, int cap, int K,
@@ -766,6 +797,42 @@ __global__ void __launch_bounds__(kBlock) k_topk_select(const uint64_t* __restri
         if (threadIdx.x == 0) out[(size_t)q * K + r] = m;
         prev = m;
         first = false;
+    }
+}
+
+// Exact re-rank of a candidate list whose keys were written by a NOMINATION scan (kChi2Approx): every entry's distance is
+// recomputed with the reference's arithmetic (accum<METRIC>, ascending feature order, one IEEE division by the count) and the
+// key rewritten in place; k_topk_select then picks the K smallest. One block per query, one thread per entry; the query sits in LDS.
+template <int METRIC>
+__global__ void __launch_bounds__(kBlock) k_list_rerank(uint64_t* __restrict__ lists, const int32_t* __restrict__ counts, int cap,
+                                                         const float4* __restrict__ gal4, int dp4, int64_t n, int64_t row_offset,
+                                                         const float* __restrict__ queries, int d, int start, int end) {
+    extern __shared__ float lq_rr[];
+    const int q = blockIdx.x;
+    for (int k = threadIdx.x; k < d; k += kBlock) lq_rr[k] = queries[(size_t)q * d + k];
+    __syncthreads();
+    const int cnt = counts[q] < cap ? counts[q] : cap;
+    const float fcount = (float)(end - start);
+    uint64_t* l = lists + (size_t)q * cap;
+    for (int i = threadIdx.x; i < cnt; i += kBlock) {
+        const int64_t row = (int64_t)(uint32_t)(l[i] & 0xFFFFFFFFull) - row_offset;
+        uint64_t key = kKeyNone;
+        if (row >= 0 && row < n) {
+            const float4* gr = gal4 + (size_t)(row >> 6) * dp4 * 64 + (row & 63);
+            float acc = 0.0f;
+            for (int c = start >> 2; c <= (end - 1) >> 2; ++c) {
+                const float4 g4 = gr[(size_t)c * 64];
+                const float gv[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = c * 4 + j;
+                    if (k >= start && k < end) acc = accum<METRIC>(acc, lq_rr[k], gv[j]);
+                }
+            }
+            const float dist = acc / fcount;
+            if (dist < kNotFound) key = key_pack(dist, (uint32_t)(row + row_offset));
+        }
+        l[i] = key;
     }
 }
 

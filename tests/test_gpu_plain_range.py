@@ -69,3 +69,39 @@ def test_l2_galleries_report_the_range_too(fir):
     with fir.Gallery(rows, None, 0, 0) as g:
         g.search_top1(q)
         assert g.value_range() == (True, True)
+
+
+def test_chi2_nomination_scan_returns_the_exact_scans_keys(fir, oracle):
+    """Chi-square batches over a large plain-range gallery take a nomination scan (1-ulp reciprocal) + exact re-rank by default
+    (fir_capi.hip: topk_lists_dev). Keys must be the exact scan's bit for bit -- top-1 and top-5, whole range and a sub-range,
+    with exact duplicates (ties by row) and near-ties one ulp apart -- and the oracle's on a sample. A negative value in a
+    query leaves the plain range: the exact path answers that call."""
+    import synth
+
+    n, d, qb = 70000, 128, 40
+    rows = synth.make_gallery(61, n, d, 1)
+    q, _ = synth.make_queries(61, rows, qb, 1)
+    rows[n - 3] = rows[17]
+    q[2] = rows[17]                                   # exact tie (distance 0): first row wins
+    rows[5000] = rows[4000]
+    rows[5000, 7] = np.nextafter(rows[5000, 7], np.float32(1))     # near-tie one ulp apart
+    q[3] = 0.5 * (rows[4000] + rows[123])
+    with fir.Gallery(rows, None, fir.METRIC_CHI2, 0) as g:
+        a1 = g.search_top1(q)                         # default dispatch: nomination
+        a5 = g.search_topk(q, 5)
+        s1 = g.search_top1(q, 32, 96)
+        g.set_tuning(queries_per_pass=8)              # a pinned tile size keeps top-1 on the exact scan
+        e1 = g.search_top1(q)
+        es1 = g.search_top1(q, 32, 96)
+        g.set_tuning(queries_per_pass=-1)
+        qn = q.copy()
+        qn[0, 0] = -1e-3                               # outside the plain range
+        n1 = g.search_top1(qn)
+    assert np.array_equal(a1[0], e1[0]) and np.array_equal(a1[1].view(np.uint32), e1[1].view(np.uint32))
+    assert np.array_equal(s1[0], es1[0]) and np.array_equal(s1[1].view(np.uint32), es1[1].view(np.uint32))
+    assert np.array_equal(a5[0][:, 0], a1[0]) and a1[0][2] == 17
+    for i in (0, 2, 3, 11, 39):
+        ei, ed = oracle.topk(rows, q[i], 0, d, 5, 1)
+        assert np.array_equal(a5[0][i], ei) and np.array_equal(a5[1][i].view(np.uint32), ed.view(np.uint32))
+    oi, od = oracle.recognize_bf(rows, qn[0], 0, d, 1)
+    assert n1[0][0] == oi and np.float32(n1[1][0]).view(np.uint32) == np.float32(od).view(np.uint32)
