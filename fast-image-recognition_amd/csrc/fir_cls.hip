@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -28,7 +29,8 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr int kTileRows = 64;
-constexpr int kQB = 4;       // queries per pass of the f64 scan
+constexpr int kQB = 4;       // queries per pass of the f64 scan (training sets that stay in the caches, the sequential PNN)
+constexpr int kQBBig = 8;    // ... of a training set streamed from HBM: the pass is HBM-bound up to 8 queries (3 f64 vector ops per element and query)
 constexpr int kKMax = 8;
 
 int cls_fail(int code, const char* fmt, ...);   // defined with the C ABI below
@@ -58,13 +60,14 @@ __global__ void __launch_bounds__(kBlock) k_cls_retile(const double* __restrict_
 }
 
 // queries[nq][d] -> qn[k][QB] = q[k] - avg[k] (the query side of normalize(), :135), zero padded.
+template <int QB>
 __global__ void __launch_bounds__(kBlock) k_cls_prep_queries(const double* __restrict__ q, int nq, int d, int dp2,
                                                               const double* __restrict__ avg, double* __restrict__ qn) {
     const int kk = dp2 * 2;
     const int64_t o = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (o >= (int64_t)kk * kQB) return;
-    const int qi = (int)(o % kQB);
-    const int k = (int)(o / kQB);
+    if (o >= (int64_t)kk * QB) return;
+    const int qi = (int)(o % QB);
+    const int k = (int)(o / QB);
     qn[o] = (qi < nq && k < d) ? q[(int64_t)qi * d + k] - avg[k] : 0.0;
 }
 
@@ -72,6 +75,7 @@ __global__ void __launch_bounds__(kBlock) k_cls_prep_queries(const double* __res
 // lo, hi: double2-chunk range [lo, hi) of the features (whole scan: 0, dp2). cstep < hi - lo: the range is cut into
 // consecutive sub-ranges of cstep chunks, each a fresh sum written `sub_stride` doubles after the previous one (the
 // 32-feature chunks of the sequential PNN, classification.cpp:245-262, from ONE pass over the training rows).
+template <int QB>
 __global__ void __launch_bounds__(kBlock) k_cls_scan(const double2* __restrict__ gal2, const double* __restrict__ qn, int64_t nt,
                                                       int tiles, int dp2, int d, int waves, int nq, int lo, int hi,
                                                       double* __restrict__ sums_base, int cstep, int64_t sub_stride) {
@@ -83,9 +87,9 @@ __global__ void __launch_bounds__(kBlock) k_cls_scan(const double2* __restrict__
       double* sums = sums_base;
       for (int c0 = lo; c0 < hi; c0 += cstep, sums += sub_stride) {
         const int c1 = min(hi, c0 + cstep);
-        double acc[kQB];
+        double acc[QB];
 #pragma unroll
-        for (int q = 0; q < kQB; ++q) acc[q] = 0.0;
+        for (int q = 0; q < QB; ++q) acc[q] = 0.0;
         int c = c0;
         for (; c + 4 <= c1; c += 4) {
             double2 g[4];
@@ -99,8 +103,8 @@ __global__ void __launch_bounds__(kBlock) k_cls_scan(const double2* __restrict__
                     const int k = (c + u) * 2 + j;
                     if (k < d) {
 #pragma unroll
-                        for (int q = 0; q < kQB; ++q) {
-                            const double diff = gv[j] - qc[k * kQB + q];       // :132-137
+                        for (int q = 0; q < QB; ++q) {
+                            const double diff = gv[j] - qc[k * QB + q];       // :132-137
                             acc[q] = acc[q] + diff * diff;                      // :141
                         }
                     }
@@ -115,8 +119,8 @@ __global__ void __launch_bounds__(kBlock) k_cls_scan(const double2* __restrict__
                 const int k = c * 2 + j;
                 if (k < d) {
 #pragma unroll
-                    for (int q = 0; q < kQB; ++q) {
-                        const double diff = gv[j] - qc[k * kQB + q];
+                    for (int q = 0; q < QB; ++q) {
+                        const double diff = gv[j] - qc[k * QB + q];
                         acc[q] = acc[q] + diff * diff;
                     }
                 }
@@ -125,7 +129,7 @@ __global__ void __launch_bounds__(kBlock) k_cls_scan(const double2* __restrict__
         const int64_t row = (int64_t)t * kTileRows + lane;
         if (row < nt) {
 #pragma unroll
-            for (int q = 0; q < kQB; ++q)
+            for (int q = 0; q < QB; ++q)
                 if (q < nq) sums[(size_t)q * nt + row] = acc[q];
         }
       }
@@ -208,7 +212,8 @@ constexpr int kSeqBlock = 1024;
 __global__ void __launch_bounds__(kSeqBlock) k_cls_pnn_seq(const double* __restrict__ cs, int nq, int nchunks, double* __restrict__ dist,
                                                             double* __restrict__ ev, const int32_t* __restrict__ class_off, int64_t nt,
                                                             int num_classes, int d, double var, double den, int32_t* __restrict__ best_class,
-                                                            int32_t* __restrict__ chunks_out) {
+                                                            int32_t* __restrict__ chunks_out, unsigned long long* ticket_word = nullptr,
+                                                            unsigned long long ticket = 0) {
     extern __shared__ __attribute__((aligned(16))) double outputs[];
     int* checked = (int*)(outputs + num_classes);
     int* off = checked + num_classes;                                               // class_off, [num_classes + 1]
@@ -279,14 +284,24 @@ __global__ void __launch_bounds__(kSeqBlock) k_cls_pnn_seq(const double* __restr
         __syncthreads();
         if (stop_s) break;
     }
-    if (threadIdx.x == 0) { best_class[q] = best_s; chunks_out[q] = used; }
+    if (threadIdx.x == 0) {
+        best_class[q] = best_s;
+        chunks_out[q] = used;
+        if (ticket_word) {                                                          // one-query call: see k_cls_argbest
+            __threadfence_system();
+            __hip_atomic_store(ticket_word, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 // mode 0: PNN arg-max, first maximum from -DBL_MAX (classification.cpp:217-224).
 // mode 1: kNN arg-min of kth; when no class has k rows the reference's loop ends without a
 //         break and the arg-max of the vote counts = the largest class (first) wins (:161-168).
 __global__ void __launch_bounds__(64) k_cls_argbest(const double* __restrict__ v, const int32_t* __restrict__ class_off, int num_classes,
-                                                     int mode, int32_t* __restrict__ best_class) {
+                                                     int mode, int32_t* __restrict__ best_class, unsigned long long* ticket_word = nullptr,
+                                                     unsigned long long ticket = 0) {
+    // ticket_word (one-query calls, results in pinned host memory): after the class, the call's ticket -- the host spins on
+    // that word instead of synchronising the stream (cls_wait_ticket)
     const int q = blockIdx.x;
     if (threadIdx.x != 0) return;
     const double* s = v + (size_t)q * num_classes;
@@ -308,6 +323,10 @@ __global__ void __launch_bounds__(64) k_cls_argbest(const double* __restrict__ v
         }
     }
     best_class[q] = best;
+    if (ticket_word) {
+        __threadfence_system();
+        __hip_atomic_store(ticket_word, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 }  // namespace
@@ -327,6 +346,7 @@ struct fir_cls {
     double* scores = nullptr; size_t scores_cap = 0;
     int32_t* best = nullptr; size_t best_cap = 0;
     void* pin = nullptr;              // pinned, device-visible staging of small calls: queries in, classes (+ chunk counts) out
+    unsigned long long ticket = 0;    // one-query calls so far: the word the host waits for
     double total_training_size = 0;   // 0: nt. PNNwithClustering keeps the full size as denominator (classification.cpp:390,393)
 };
 
@@ -370,10 +390,26 @@ constexpr int kPinResults = 4096;                 // int32 slots: classes [0, 20
 bool cls_small(const fir_cls* c, int32_t qb) { return (size_t)qb * c->d * sizeof(double) <= kPinQueryBytes && qb <= kPinResults / 2; }
 int cls_ensure_pin(fir_cls* c) {
     if (c->pin) return FIR_OK;
-    CLS_HIP(hipHostMalloc(&c->pin, kPinQueryBytes + kPinResults * sizeof(int32_t), hipHostMallocDefault));
+    CLS_HIP(hipHostMalloc(&c->pin, kPinQueryBytes + kPinResults * sizeof(int32_t) + 64, hipHostMallocDefault));
+    std::memset((char*)c->pin + kPinQueryBytes + kPinResults * sizeof(int32_t), 0, 64);
     return FIR_OK;
 }
 int32_t* cls_pin_results(fir_cls* c) { return (int32_t*)((char*)c->pin + kPinQueryBytes); }
+unsigned long long* cls_pin_ticket(fir_cls* c) { return (unsigned long long*)((char*)c->pin + kPinQueryBytes + kPinResults * sizeof(int32_t)); }
+// Spin (2 ms at most, then the stream synchronisation) until the call's last kernel has written `ticket` to the pinned word:
+// cheaper than hipStreamSynchronize for calls that take tens of microseconds (as fir_capi.hip's wait_ticket).
+int cls_wait_ticket(fir_cls* c, unsigned long long ticket) {
+    volatile unsigned long long* flag = cls_pin_ticket(c);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int spins = 0; __atomic_load_n(flag, __ATOMIC_ACQUIRE) != ticket; ++spins) {
+        if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {
+            CLS_HIP(hipStreamSynchronize(c->stream));
+            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != ticket) return cls_fail(FIR_ERR_HIP, "the result ticket was not published");
+            break;
+        }
+    }
+    return FIR_OK;
+}
 // -> device-visible pointer to the staged queries
 int cls_stage_queries(fir_cls* c, const double* queries, int32_t qb, const double** d_q) {
     int rc;
@@ -393,7 +429,7 @@ int cls_stage_queries(fir_cls* c, const double* queries, int32_t qb, const doubl
 int32_t cls_batch(const fir_cls* c) {
     const int64_t per_query = std::max<int64_t>(c->nt, 1) * (int64_t)sizeof(double);
     // ... and within gridDim.y of the per-(class, query) kernels (65535)
-    return (int32_t)std::max<int64_t>(kQB, std::min<int64_t>(65532, ((int64_t)1 << 30) / per_query / kQB * kQB));
+    return (int32_t)std::max<int64_t>(kQBBig, std::min<int64_t>(65528, ((int64_t)1 << 30) / per_query / kQBBig * kQBBig));
 }
 
 int cls_scan(fir_cls* c, const double* queries, int32_t qb) {
@@ -403,12 +439,22 @@ int cls_scan(fir_cls* c, const double* queries, int32_t qb) {
     if ((rc = cls_grow(c->sums, c->sums_cap, (size_t)qb * std::max<int64_t>(c->nt, 1)))) return rc;
     const int kk = c->dp2 * 2;
     const int waves = (int)std::min<int64_t>(std::max<int64_t>((c->tiles + 3) / 4 * 4, 4), (int64_t)c->cus * 16);
-    for (int q0 = 0; q0 < qb; q0 += kQB) {
-        const int nq = std::min(kQB, qb - q0);
-        hipLaunchKernelGGL(k_cls_prep_queries, dim3((kk * kQB + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream,
-                           dq + (size_t)q0 * c->d, nq, c->d, c->dp2, c->avg, c->qn);
-        hipLaunchKernelGGL(k_cls_scan, dim3(waves / 4), dim3(kBlock), 0, c->stream, c->gal2, c->qn, c->nt, (int)c->tiles, c->dp2,
-                           c->d, waves, nq, 0, c->dp2, c->sums + (size_t)q0 * c->nt, c->dp2, (int64_t)0);
+    // a training set streamed from HBM takes 8 queries per pass (the pass stays HBM-bound), a cache-resident one 4
+    const bool big = (double)c->tiles * 64.0 * c->dp2 * 16.0 > 256.0 * 1024 * 1024;
+    const int qbt = big ? kQBBig : kQB;
+    for (int q0 = 0; q0 < qb; q0 += qbt) {
+        const int nq = std::min(qbt, qb - q0);
+        if (big) {
+            hipLaunchKernelGGL(k_cls_prep_queries<kQBBig>, dim3((kk * kQBBig + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream,
+                               dq + (size_t)q0 * c->d, nq, c->d, c->dp2, c->avg, c->qn);
+            hipLaunchKernelGGL(k_cls_scan<kQBBig>, dim3(waves / 4), dim3(kBlock), 0, c->stream, c->gal2, c->qn, c->nt, (int)c->tiles, c->dp2,
+                               c->d, waves, nq, 0, c->dp2, c->sums + (size_t)q0 * c->nt, c->dp2, (int64_t)0);
+        } else {
+            hipLaunchKernelGGL(k_cls_prep_queries<kQB>, dim3((kk * kQB + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream,
+                               dq + (size_t)q0 * c->d, nq, c->d, c->dp2, c->avg, c->qn);
+            hipLaunchKernelGGL(k_cls_scan<kQB>, dim3(waves / 4), dim3(kBlock), 0, c->stream, c->gal2, c->qn, c->nt, (int)c->tiles, c->dp2,
+                               c->d, waves, nq, 0, c->dp2, c->sums + (size_t)q0 * c->nt, c->dp2, (int64_t)0);
+        }
     }
     CLS_HIP(hipGetLastError());
     return FIR_OK;
@@ -470,7 +516,7 @@ static int cls_create(const double* train_rows, bool rows_on_device, int64_t nt,
     const size_t g2 = (size_t)std::max<int64_t>(c->tiles, 1) * c->dp2 * 64;
     if (e == hipSuccess) e = hipMalloc((void**)&c->gal2, g2 * sizeof(double2));
     if (e == hipSuccess) e = hipMalloc((void**)&c->avg, (size_t)d * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void**)&c->qn, (size_t)c->dp2 * 2 * kQB * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&c->qn, (size_t)c->dp2 * 2 * kQBBig * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&c->class_off, ((size_t)num_classes + 1) * sizeof(int32_t));
     if (e == hipSuccess) e = hipMemcpy(c->avg, avg, (size_t)d * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(c->class_off, off.data(), off.size() * sizeof(int32_t), hipMemcpyHostToDevice);
@@ -546,11 +592,15 @@ int fir_cls_pnn_predict(fir_cls* c, const double* queries, int32_t qb, double va
                        c->total_training_size > 0 ? c->total_training_size : (double)c->nt, c->scores);
     const bool small = cls_small(c, qb);
     int32_t* dbest = small ? cls_pin_results(c) : c->best;
-    hipLaunchKernelGGL(k_cls_argbest, dim3(qb), dim3(64), 0, c->stream, c->scores, c->class_off, c->num_classes, 0, dbest);
+    const bool one = small && qb == 1 && !scores;       // the reference's predict() per test vector: no stream synchronisation
+    const unsigned long long ticket = one ? ++c->ticket : 0;
+    hipLaunchKernelGGL(k_cls_argbest, dim3(qb), dim3(64), 0, c->stream, c->scores, c->class_off, c->num_classes, 0, dbest,
+                       one ? cls_pin_ticket(c) : (unsigned long long*)nullptr, ticket);
     CLS_HIP(hipGetLastError());
     if (scores) CLS_HIP(hipMemcpyAsync(scores, c->scores, (size_t)qb * c->num_classes * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (best_class && !small) CLS_HIP(hipMemcpyAsync(best_class, c->best, (size_t)qb * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    CLS_HIP(hipStreamSynchronize(c->stream));
+    if (one) { if ((rc = cls_wait_ticket(c, ticket))) return rc; }
+    else CLS_HIP(hipStreamSynchronize(c->stream));
     if (best_class && small) std::memcpy(best_class, dbest, (size_t)qb * sizeof(int32_t));
     return FIR_OK;
 }
@@ -596,18 +646,27 @@ int fir_cls_pnn_predict_seq(fir_cls* c, const double* queries, int32_t qb, doubl
     const int kk = c->dp2 * 2;
     const int waves = (int)std::min<int64_t>(std::max<int64_t>((c->tiles + 3) / 4 * 4, 4), (int64_t)c->cus * 16);
     double* run = c->sums + (size_t)nchunks * kQB * ntp;
+    const bool one = small && qb == 1;
+    const unsigned long long ticket = one ? ++c->ticket : 0;
     for (int q0 = 0; q0 < qb; q0 += kQB) {
         const int nq = std::min(kQB, qb - q0);
-        hipLaunchKernelGGL(k_cls_prep_queries, dim3((kk * kQB + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream,
+        hipLaunchKernelGGL(k_cls_prep_queries<kQB>, dim3((kk * kQB + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream,
                            dq + (size_t)q0 * c->d, nq, c->d, c->dp2, c->avg, c->qn);
         // all 32-feature chunk sums (16 double2 chunks each) from one pass: chunk ch lands at sums + ch * nq * nt
-        hipLaunchKernelGGL(k_cls_scan, dim3(waves / 4), dim3(kBlock), 0, c->stream, c->gal2, c->qn, c->nt, (int)c->tiles, c->dp2, c->d, waves, nq,
+        hipLaunchKernelGGL(k_cls_scan<kQB>, dim3(waves / 4), dim3(kBlock), 0, c->stream, c->gal2, c->qn, c->nt, (int)c->tiles, c->dp2, c->d, waves, nq,
                            0, c->dp2, c->sums, 16, (int64_t)nq * c->nt);
         hipLaunchKernelGGL(k_cls_pnn_seq, dim3(nq), dim3(kSeqBlock), (size_t)c->num_classes * 16 + 4, c->stream, c->sums, nq, nchunks, run,
                            run + (size_t)kQB * ntp, c->class_off, c->nt, c->num_classes, c->d, var,
-                           c->total_training_size > 0 ? c->total_training_size : (double)c->nt, dbest + q0, dchunks + q0);
+                           c->total_training_size > 0 ? c->total_training_size : (double)c->nt, dbest + q0, dchunks + q0,
+                           one ? cls_pin_ticket(c) : (unsigned long long*)nullptr, ticket);
     }
     CLS_HIP(hipGetLastError());
+    if (one) {
+        if ((rc = cls_wait_ticket(c, ticket))) return rc;
+        best_class[0] = dbest[0];
+        if (chunks_out) chunks_out[0] = dchunks[0];
+        return FIR_OK;
+    }
     if (!small) {
         CLS_HIP(hipMemcpyAsync(best_class, dbest, (size_t)qb * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
         if (chunks_out) CLS_HIP(hipMemcpyAsync(chunks_out, dchunks, (size_t)qb * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
@@ -642,10 +701,14 @@ int fir_cls_knn_predict(fir_cls* c, const double* queries, int32_t qb, int32_t k
                        (double*)nullptr);
     const bool small = cls_small(c, qb);
     int32_t* dbest = small ? cls_pin_results(c) : c->best;
-    hipLaunchKernelGGL(k_cls_argbest, dim3(qb), dim3(64), 0, c->stream, c->scores, c->class_off, c->num_classes, 1, dbest);
+    const bool one = small && qb == 1;
+    const unsigned long long ticket = one ? ++c->ticket : 0;
+    hipLaunchKernelGGL(k_cls_argbest, dim3(qb), dim3(64), 0, c->stream, c->scores, c->class_off, c->num_classes, 1, dbest,
+                       one ? cls_pin_ticket(c) : (unsigned long long*)nullptr, ticket);
     CLS_HIP(hipGetLastError());
     if (!small) CLS_HIP(hipMemcpyAsync(best_class, c->best, (size_t)qb * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    CLS_HIP(hipStreamSynchronize(c->stream));
+    if (one) { if ((rc = cls_wait_ticket(c, ticket))) return rc; }
+    else CLS_HIP(hipStreamSynchronize(c->stream));
     if (small) std::memcpy(best_class, dbest, (size_t)qb * sizeof(int32_t));
     return FIR_OK;
 }

@@ -100,6 +100,11 @@ int fir_search_top1(fir_gallery* g, const float* queries, int32_t qb, int32_t st
  * with an integer MIN (RCCL all-reduce on uint64/int64), then unpack. */
 int fir_search_top1_keys_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start_pos, int32_t end_pos,
                              uint64_t* d_keys, void* stream);
+/* Two batch forms synchronise `stream` once before returning (they have to know that their certificate / candidate lists
+ * held, and re-run the exact scan for what did not): L2 whole-range batches that take the matrix-core path (see
+ * fir_gallery_set_large_batch_mfma) and chi-square batches of >= 8 queries over >= 65536 rows, which take a nomination scan
+ * (1-ulp reciprocal, threshold widened by its error bound) + exact re-rank of the appended rows. The keys are the exact
+ * scan's either way; fir_gallery_set_tuning(g, 8, 0) pins the exact scan. */
 /* Host-side unpack of packed keys (pure integer work, no device). */
 int fir_keys_unpack(const uint64_t* keys, int32_t n, int32_t* idx, float* dist);
 uint64_t fir_key_pack(float dist, int32_t idx);
