@@ -817,15 +817,18 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16(const uint4* _
         f32x16 acc0 = {0.f}, acc1 = {0.f}, acc2 = {0.f}, acc3 = {0.f};
         float4 gn4[4];                               // this lane's 16 squared row norms (rows 8g + 4h + 0..3 of the block), for the epilogue
         const bool full_block = active && rb * 32 >= row_begin && rb * 32 + 32 <= row_end && rb * 32 + 32 <= n && (MODE == 1 || rb * 32 + 32 <= sample_rows);
-        for (int h = 0; h < units; ++h) {
+        // one unit of kRing k-blocks: the loads of the NEXT unit go into N while the MFMAs consume C. Units are taken in pairs with
+        // the two buffers swapping roles, so that no register copies sit between the MFMAs (a `cur = nxt` copy per unit was one
+        // vector instruction per MFMA on a SIMD whose vector issue the MFMAs and the epilogue already fill to ~85 %)
+        auto unit = [&](uint4 (&C)[kRing], uint4 (&N)[kRing], int h) {
             const uint4* src = h + 1 < units ? a_cur + (size_t)(h + 1) * kRing * 64 : a_nxt;
             if (STREAMED) request_slab(h + 1 < units ? h + 1 : 0, tsel ^ 1);   // its last readers passed the barrier that ended the previous unit
             if (nt) {
 #pragma unroll
-                for (int u = 0; u < kRing; ++u) nxt[u] = ld_nt(src + (size_t)u * 64);
+                for (int u = 0; u < kRing; ++u) N[u] = ld_nt(src + (size_t)u * 64);
             } else {
 #pragma unroll
-                for (int u = 0; u < kRing; ++u) nxt[u] = src[(size_t)u * 64];
+                for (int u = 0; u < kRing; ++u) N[u] = src[(size_t)u * 64];
             }
             if (h == units - 1 && full_block) {
                 const float4* gp = (const float4*)(gnorm + rb * 32 + 4 * (lane >> 5));
@@ -857,20 +860,28 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16(const uint4* _
                     n0 = bq_after[0]; n1 = bq_after[jstride]; n2 = bq_after[2 * jstride]; n3 = bq_after[3 * jstride];
                 }
                 __builtin_amdgcn_sched_barrier(0);                           // the four reads of the next group stay ahead of this group's MFMAs
-                const f16x8 av = as_f16x8(cur[u]);
+                const f16x8 av = as_f16x8(C[u]);
                 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, as_f16x8(b0), acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, as_f16x8(b1), acc1, 0, 0, 0);
                 acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, as_f16x8(b2), acc2, 0, 0, 0);
                 acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, as_f16x8(b3), acc3, 0, 0, 0);
                 b0 = n0; b1 = n1; b2 = n2; b3 = n3;
             }
-#pragma unroll
-            for (int u = 0; u < kRing; ++u) cur[u] = nxt[u];
             if (STREAMED) {
-                __builtin_amdgcn_s_waitcnt(0);       // this wave's pieces of the next slab have landed (they left before nxt's loads)
+                __builtin_amdgcn_s_waitcnt(0);       // this wave's pieces of the next slab have landed (they left before N's loads)
                 __syncthreads();                     // ... and everyone's; and nobody still reads the buffer the next request overwrites
                 tsel ^= 1;
             }
+        };
+        int h = 0;
+        for (; h + 1 < units; h += 2) {
+            unit(cur, nxt, h);
+            unit(nxt, cur, h + 1);
+        }
+        if (h < units) {                             // an odd number of units per row block: the buffers end up swapped once
+            unit(cur, nxt, h);
+#pragma unroll
+            for (int u = 0; u < kRing; ++u) cur[u] = nxt[u];
         }
         a_cur = a_nxt;
         if (!active) continue;
@@ -889,8 +900,8 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16(const uint4* _
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
                     const float dot = jb == 0 ? acc0[reg] : jb == 1 ? acc1[reg] : jb == 2 ? acc2[reg] : acc3[reg];
-                    pv[reg] = gnv[reg] - m2 * dot;
-                    mn = pv[reg] < mn ? pv[reg] : mn;                        // NaN never enters, like k_gemm_tau's ordering
+                    pv[reg] = __builtin_fmaf(-m2, dot, gnv[reg]);            // one instruction: the proxy only has to be the same number wherever it is compared
+                    mn = fminf(mn, pv[reg]);                                 // NaN never enters, like k_gemm_tau's ordering
                 }
                 if (MODE == 1) {
                     if (mn < tq) {
