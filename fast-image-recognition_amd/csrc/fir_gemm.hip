@@ -790,7 +790,7 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16(const uint4* _
         for (int c = 0; c < per_wave; ++c) {
             const int piece = wave * per_wave + c, jb = piece / kRing, kb = piece - jb * kRing;
             __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(qh + ((size_t)jb * dk16 + (size_t)hq * kRing + kb) * 64 + lane),
-                                             (void __attribute__((address_space(3)))*)(dst + (size_t)piece * 64), 16, 0, 0);
+                                             (void __attribute__((address_space(3)))*)(dst + (size_t)(kb * 4 + jb) * 64), 16, 0, 0);
         }
     };
     int tsel = 0;                                    // STREAMED: LDS buffer of the current unit
@@ -801,13 +801,15 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16(const uint4* _
     } else if (resident) {
         for (int i = threadIdx.x; i < 4 * dk16 * 64; i += blockDim.x) {
             const int jb = i / (dk16 * 64), r = i - jb * dk16 * 64;
-            lqb[(size_t)jb * kSlabH * 64 + r] = qh[(size_t)jb * dk16 * 64 + r];
+            lqb[(size_t)((r >> 6) * 4 + jb) * 64 + (r & 63)] = qh[(size_t)jb * dk16 * 64 + r];
         }
         __syncthreads();
     }
-    constexpr int jstride = (STREAMED ? kRing : kSlabH) * 64;        // uint4s between the query blocks of a k-block
+    // LDS image of the query tile: k-block major, the four query blocks of a k-block side by side -- (kb * 4 + jb) * 1 KiB -- so that
+    // the reads of a unit sit within the 64 KiB an LDS instruction's immediate offset reaches from ONE base register
+    constexpr int jstride = 64;                                      // uint4s between the query blocks of a k-block
     // the four query fragments of the k-block the next MFMA group consumes: always read one group ahead
-    uint4 b0, b1, b2, b3;
+    uint4 b0, b1, b2, b3, c0, c1, c2, c3;
     if (resident) { const uint4* bu = lqb + lane; b0 = bu[0]; b1 = bu[jstride]; b2 = bu[2 * jstride]; b3 = bu[3 * jstride]; }
     for (; rg < rg_end; rg += rg_step) {
         const int64_t rb = rb_begin + rg * wpb + wave;
@@ -841,32 +843,43 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16(const uint4* _
                 __syncthreads();                                            // everyone is done with the previous slab
                 for (int i = threadIdx.x; i < 4 * kw * 64; i += blockDim.x) {
                     const int jb = i / (kw * 64), r = i - jb * kw * 64;
-                    lqb[(size_t)jb * kSlabH * 64 + r] = qh[((size_t)jb * dk16 + k0) * 64 + r];
+                    lqb[(size_t)((r >> 6) * 4 + jb) * 64 + (r & 63)] = qh[((size_t)jb * dk16 + k0) * 64 + r];
                 }
                 __syncthreads();
             }
-            const uint4* bq = STREAMED ? lqb + lane + (size_t)tsel * 4 * kRing * 64 : lqb + lane + (size_t)(h % kUnitsPerSlab) * kRing * 64;
+            const uint4* bq = STREAMED ? lqb + lane + (size_t)tsel * 4 * kRing * 64 : lqb + lane + (size_t)(h % kUnitsPerSlab) * kRing * 4 * 64;
             if (!resident) { b0 = bq[0]; b1 = bq[jstride]; b2 = bq[2 * jstride]; b3 = bq[3 * jstride]; }
             // where the fragments of the k-block AFTER this unit live, when that is known now (resident tile): the pipeline runs on
             // through the unit boundary and through the epilogue into the wave's next row block
-            const uint4* bq_after = lqb + lane + (size_t)((h + 1 < units ? h + 1 : 0) % kUnitsPerSlab) * kRing * 64;
-#pragma unroll
-            for (int u = 0; u < kRing; ++u) {
-                uint4 n0 = b0, n1 = b1, n2 = b2, n3 = b3;
-                if (u + 1 < kRing) {
-                    const uint4* bu = bq + (size_t)(u + 1) * 64;
-                    n0 = bu[0]; n1 = bu[jstride]; n2 = bu[2 * jstride]; n3 = bu[3 * jstride];
-                } else if (resident) {
-                    n0 = bq_after[0]; n1 = bq_after[jstride]; n2 = bq_after[2 * jstride]; n3 = bq_after[3 * jstride];
-                }
-                __builtin_amdgcn_sched_barrier(0);                           // the four reads of the next group stay ahead of this group's MFMAs
-                const f16x8 av = as_f16x8(C[u]);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, as_f16x8(b0), acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, as_f16x8(b1), acc1, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, as_f16x8(b2), acc2, 0, 0, 0);
-                acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, as_f16x8(b3), acc3, 0, 0, 0);
-                b0 = n0; b1 = n1; b2 = n2; b3 = n3;
+            const uint4* bq_after = lqb + lane + (size_t)((h + 1 < units ? h + 1 : 0) % kUnitsPerSlab) * kRing * 4 * 64;
+            // two sets of query fragments, (b0..b3) and (c0..c3), swap roles every k-block: the reads of k-block u + 1 go into the
+            // set the MFMAs of k-block u do not use. (A rotation `b = next` through one set was compiled into eight 64-bit
+            // register copies per k-block -- two vector instructions per MFMA on an already full vector issue port.)
+#define FIR_H_STEP(U, X0, X1, X2, X3, Y0, Y1, Y2, Y3)                                                              \
+            {                                                                                                      \
+                if ((U) + 1 < kRing) {                                                                             \
+                    const uint4* bu = bq + (size_t)((U) + 1) * 4 * 64;                                             \
+                    Y0 = bu[0]; Y1 = bu[jstride]; Y2 = bu[2 * jstride]; Y3 = bu[3 * jstride];                      \
+                } else if (resident) {                                                                             \
+                    Y0 = bq_after[0]; Y1 = bq_after[jstride]; Y2 = bq_after[2 * jstride]; Y3 = bq_after[3 * jstride]; \
+                }                                                                                                  \
+                __builtin_amdgcn_sched_barrier(0); /* the four reads of the next group stay ahead of this group's MFMAs */ \
+                const f16x8 av = as_f16x8(C[U]);                                                                   \
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, as_f16x8(X0), acc0, 0, 0, 0);                    \
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, as_f16x8(X1), acc1, 0, 0, 0);                    \
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, as_f16x8(X2), acc2, 0, 0, 0);                    \
+                acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, as_f16x8(X3), acc3, 0, 0, 0);                    \
             }
+            static_assert(kRing == 8, "the unrolled k-block steps below are written out for kRing = 8");
+            FIR_H_STEP(0, b0, b1, b2, b3, c0, c1, c2, c3)
+            FIR_H_STEP(1, c0, c1, c2, c3, b0, b1, b2, b3)
+            FIR_H_STEP(2, b0, b1, b2, b3, c0, c1, c2, c3)
+            FIR_H_STEP(3, c0, c1, c2, c3, b0, b1, b2, b3)
+            FIR_H_STEP(4, b0, b1, b2, b3, c0, c1, c2, c3)
+            FIR_H_STEP(5, c0, c1, c2, c3, b0, b1, b2, b3)
+            FIR_H_STEP(6, b0, b1, b2, b3, c0, c1, c2, c3)
+            FIR_H_STEP(7, c0, c1, c2, c3, b0, b1, b2, b3)
+#undef FIR_H_STEP
             if (STREAMED) {
                 __builtin_amdgcn_s_waitcnt(0);       // this wave's pieces of the next slab have landed (they left before N's loads)
                 __syncthreads();                     // ... and everyone's; and nobody still reads the buffer the next request overwrites
