@@ -58,6 +58,7 @@ SYMBOLS = [
     ("fir_cls_create_sharded", C.c_int, [_vp, C.c_int64, C.c_int32, _vp, C.c_int32, _vp, _vp, C.c_int32, _vp, C.POINTER(_vp)]),
     ("fir_cls_sharded_destroy", C.c_int, [_vp]),
     ("fir_cls_sharded_pnn_predict", C.c_int, [_vp, _vp, C.c_int32, C.c_double, _vp, _vp]),
+    ("fir_cls_sharded_knn_predict", C.c_int, [_vp, _vp, C.c_int32, C.c_int32, _vp]),
     ("fir_cls_set_total_training_size", C.c_int, [_vp, C.c_int64]),
     ("fir_cls_distance_sums", C.c_int, [_vp, _vp, C.c_int32, _vp]),
     ("fir_cls_pnn_predict", C.c_int, [_vp, _vp, C.c_int32, C.c_double, _vp, _vp]),
@@ -718,3 +719,9 @@ class ShardedClsModel:
         best = np.empty(q.shape[0], np.int32)
         _check(lib().fir_cls_sharded_pnn_predict(self._h, q.ctypes.data_as(_vp), q.shape[0], var, scores.ctypes.data_as(_vp), best.ctypes.data_as(_vp)))
         return best, scores
+
+    def knn_predict(self, queries, k):
+        q = np.ascontiguousarray(queries, dtype=np.float64).reshape(-1, self.d)
+        best = np.empty(q.shape[0], np.int32)
+        _check(lib().fir_cls_sharded_knn_predict(self._h, q.ctypes.data_as(_vp), q.shape[0], k, best.ctypes.data_as(_vp)))
+        return best

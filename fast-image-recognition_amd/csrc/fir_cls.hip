@@ -626,6 +626,26 @@ int fir_cls_pnn_scores_dev_(fir_cls* c, const double* queries, int32_t qb, doubl
     return FIR_OK;
 }
 
+// The k smallest mean distances per class of qb <= *max_batch queries, [qb][num_classes][k] ascending (DBL_MAX where the class has
+// fewer rows here), left on the device and queued on the handle's stream: the row-sharded kNN vote (fir_shard.hip) merges them.
+int fir_cls_knn_nearest_dev_(fir_cls* c, const double* queries, int32_t qb, int32_t k, double** d_lists, void** stream, int32_t* max_batch) {
+    if (!c || !d_lists || !stream) return cls_fail(FIR_ERR_ARG, "NULL argument");
+    if (max_batch) *max_batch = cls_batch(c);
+    if (qb == 0) return FIR_OK;
+    if (qb < 0 || qb > cls_batch(c) || !queries || k < 1 || k > kKMax) return cls_fail(FIR_ERR_ARG, "bad batch %d / k %d", qb, k);
+    CLS_HIP(hipSetDevice(c->device));
+    int rc = cls_scan(c, queries, qb);
+    if (rc) return rc;
+    if ((rc = cls_grow(c->scores, c->scores_cap, (size_t)qb * c->num_classes * (1 + (size_t)k)))) return rc;
+    double* lists = c->scores + (size_t)qb * c->num_classes;
+    hipLaunchKernelGGL(k_cls_knn_kth, dim3(c->num_classes, qb), dim3(64), 0, c->stream, c->sums, c->class_off, c->nt, c->num_classes, c->d, k, c->scores,
+                       lists);
+    CLS_HIP(hipGetLastError());
+    *d_lists = lists;
+    *stream = c->stream;
+    return FIR_OK;
+}
+
 int fir_cls_pnn_predict_seq(fir_cls* c, const double* queries, int32_t qb, double var, int32_t* best_class, int32_t* chunks_out) {
     if (!c || !best_class || (qb > 0 && !queries)) return cls_fail(FIR_ERR_ARG, "NULL argument");
     if (qb < 0) return cls_fail(FIR_ERR_ARG, "qb < 0");

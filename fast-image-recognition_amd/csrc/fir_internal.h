@@ -57,3 +57,4 @@ extern "C" void fir_gallery_note_dispatch_(fir_gallery* g, const void* fn, const
 
 struct fir_cls;
 extern "C" int fir_cls_pnn_scores_dev_(fir_cls* c, const double* queries, int32_t qb, double var, double** d_scores, void** stream, int32_t* max_batch);
+extern "C" int fir_cls_knn_nearest_dev_(fir_cls* c, const double* queries, int32_t qb, int32_t k, double** d_lists, void** stream, int32_t* max_batch);

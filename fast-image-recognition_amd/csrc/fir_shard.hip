@@ -455,6 +455,47 @@ __global__ void __launch_bounds__(64) k_shard_argmax_first(const double* __restr
     if (lane == 0) best[q] = bi == 0x7FFFFFFF ? -1 : bi;
 }
 
+// merged[q][c][0..k) = the k smallest of parts[p][q][c][0..k), p < nparts (every part ascending, DBL_MAX = no such row)
+__global__ void __launch_bounds__(256) k_shard_merge_knn(const double* __restrict__ parts, int nparts, int64_t qc /* qb * C */, int k, double* __restrict__ merged) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= qc) return;
+    double best[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) best[j] = 1.7976931348623157e308;
+    for (int p = 0; p < nparts; ++p)
+        for (int j = 0; j < k; ++j) {
+            double v = parts[((size_t)p * qc + i) * k + j];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const bool sw = v < best[t];
+                const double tmp = best[t];
+                best[t] = sw ? v : tmp;
+                v = sw ? tmp : v;
+            }
+        }
+    for (int j = 0; j < k; ++j) merged[(size_t)i * k + j] = best[j];
+}
+// KNNClassifier::predict's vote (classification.cpp:151-168) from the merged lists: the class that first collects k votes in the
+// globally sorted order is the one whose k-th nearest member is nearest (first minimum); when no class has k rows the
+// reference's loop ends without a break and the largest class (first on ties) wins. One thread per query.
+__global__ void __launch_bounds__(64) k_shard_knn_vote(const double* __restrict__ merged, int qb, int num_classes, int k,
+                                                       const int32_t* __restrict__ class_count, int32_t* __restrict__ best) {
+    const int q = blockIdx.x * 64 + threadIdx.x;
+    if (q >= qb) return;
+    double mn = 1.7976931348623157e308;
+    int b = -1;
+    for (int c = 0; c < num_classes; ++c) {
+        const double v = class_count[c] >= k ? merged[((size_t)q * num_classes + c) * k + (k - 1)] : 1.7976931348623157e308;
+        if (v < mn) { mn = v; b = c; }
+    }
+    if (b < 0) {
+        int mc = -1;
+        for (int c = 0; c < num_classes; ++c)
+            if (class_count[c] > mc) { mc = class_count[c]; b = c; }
+    }
+    best[q] = b;
+}
+
 }  // namespace
 
 struct fir_cls_sharded {
@@ -465,6 +506,8 @@ struct fir_cls_sharded {
     std::vector<Part> parts;
     std::vector<double*> acc;      size_t acc_cap = 0;     // per device: summed class scores [qb][C]
     std::vector<int32_t*> best;                            // per device
+    std::vector<int32_t*> class_count;                     // per device: training rows per class over ALL shards and ranks
+    std::vector<double*> knn;      size_t knn_cap = 0;     // per device: [shards here + nranks][qb][C][k] lists being merged
     void* pin = nullptr;  size_t pin_cap = 0;
 };
 
@@ -478,6 +521,8 @@ int fir_cls_sharded_destroy(fir_cls_sharded* h) {
         (void)hipSetDevice(h->devs[s].device);
         if (s < h->acc.size()) (void)hipFree(h->acc[s]);
         if (s < h->best.size()) (void)hipFree(h->best[s]);
+        if (s < h->class_count.size()) (void)hipFree(h->class_count[s]);
+        if (s < h->knn.size()) (void)hipFree(h->knn[s]);
     }
     teardown_devices(h->devs);
     if (h->pin) (void)hipHostFree(h->pin);
@@ -501,6 +546,8 @@ int fir_cls_create_sharded(const double* train_rows, int64_t nt, int32_t d, cons
     h->devs.resize((size_t)ndev);
     h->acc.assign((size_t)ndev, nullptr);
     h->best.assign((size_t)ndev, nullptr);
+    h->class_count.assign((size_t)ndev, nullptr);
+    h->knn.assign((size_t)ndev, nullptr);
     const int spd = o.shards_per_device, nsh = ndev * spd;
     const int64_t total = o.total_rows > 0 ? o.total_rows : nt;
     const int64_t per = (((nt + 63) / 64 + nsh - 1) / nsh) * 64;
@@ -514,8 +561,101 @@ int fir_cls_create_sharded(const double* train_rows, int64_t nt, int32_t d, cons
         h->parts.push_back(p);
     }
     if (rc == FIR_OK) rc = setup_devices(h->devs, devices, ndev, h->nranks, o.proc_rank * ndev, o.comm_id);
+    // rows per class over all shards and ranks (the kNN vote's "class has k rows" and its largest-class rule)
+    if (rc == FIR_OK) {
+        std::vector<int32_t> cnt((size_t)num_classes, 0);
+        for (int64_t t = 0; t < nt; ++t)
+            if (train_class[t] >= 0 && train_class[t] < num_classes) cnt[(size_t)train_class[t]]++;
+        rc = run_all(h->devs, [&](int slot) -> int {
+            DevCtx& dc = h->devs[(size_t)slot];
+            SH_HIP(hipSetDevice(dc.device));
+            SH_HIP(hipMalloc((void**)&h->class_count[(size_t)slot], (size_t)num_classes * sizeof(int32_t)));
+            int32_t* cc = h->class_count[(size_t)slot];
+            if (slot == 0) SH_HIP(hipMemcpyAsync(cc, cnt.data(), (size_t)num_classes * sizeof(int32_t), hipMemcpyHostToDevice, dc.stream));
+            else SH_HIP(hipMemsetAsync(cc, 0, (size_t)num_classes * sizeof(int32_t), dc.stream));      // this process's rows are counted once
+            SH_NCCL(ncclAllReduce(cc, cc, (size_t)num_classes, ncclInt32, ncclSum, dc.comm, dc.stream));
+            SH_HIP(hipStreamSynchronize(dc.stream));
+            return FIR_OK;
+        });
+    }
     if (rc) { fir_cls_sharded_destroy(h); return rc; }
     *out = h;
+    return FIR_OK;
+}
+
+int fir_cls_sharded_knn_predict(fir_cls_sharded* h, const double* queries, int32_t qb, int32_t k, int32_t* best_class) {
+    if (!h || !best_class || (qb > 0 && !queries)) return sh_fail(FIR_ERR_ARG, "NULL argument");
+    if (qb < 0) return sh_fail(FIR_ERR_ARG, "qb < 0");
+    if (k < 1 || k > 8) return sh_fail(FIR_ERR_ARG, "k=%d outside [1,8]", k);
+    if (qb == 0) return FIR_OK;
+    int32_t maxb = 1 << 30;
+    for (auto& p : h->parts)
+        if (p.c) { int32_t mb = 0; double* ds; void* st; fir_cls_knn_nearest_dev_(p.c, nullptr, 0, k, &ds, &st, &mb); maxb = std::min(maxb, mb); }
+    maxb = std::min(maxb, 1024);
+    if (qb > maxb) {
+        for (int32_t q0 = 0; q0 < qb; q0 += maxb) {
+            const int rc0 = fir_cls_sharded_knn_predict(h, queries + (size_t)q0 * h->d, std::min(maxb, qb - q0), k, best_class + q0);
+            if (rc0) return rc0;
+        }
+        return FIR_OK;
+    }
+    const size_t per = (size_t)qb * h->num_classes * k;                       // doubles in one [qb][C][k] table
+    size_t max_parts = 1;
+    for (int s = 0; s < h->ndev; ++s) {
+        size_t np = 0;
+        for (auto& p : h->parts) np += (p.slot == s && p.c) ? 1 : 0;
+        max_parts = std::max(max_parts, np);
+    }
+    const size_t need = per * (max_parts + 1 + (size_t)h->nranks + 1);
+    if (need > h->knn_cap || !h->best[0]) {
+        for (int s = 0; s < h->ndev; ++s) {
+            SH_HIP(hipSetDevice(h->devs[(size_t)s].device));
+            if (h->knn[(size_t)s]) SH_HIP(hipFree(h->knn[(size_t)s]));
+            h->knn[(size_t)s] = nullptr;
+            SH_HIP(hipMalloc((void**)&h->knn[(size_t)s], need * sizeof(double)));
+            if (!h->best[(size_t)s]) SH_HIP(hipMalloc((void**)&h->best[(size_t)s], (size_t)4096 * sizeof(int32_t)));
+        }
+        h->knn_cap = need;
+    }
+    if ((size_t)qb * sizeof(int32_t) > h->pin_cap) {
+        if (h->pin) SH_HIP(hipHostFree(h->pin));
+        h->pin = nullptr; h->pin_cap = 0;
+        SH_HIP(hipHostMalloc(&h->pin, (size_t)4096 * sizeof(int32_t), hipHostMallocPortable));
+        h->pin_cap = (size_t)4096 * sizeof(int32_t);
+    }
+    int32_t* hb = (int32_t*)h->pin;
+    const int64_t qc = (int64_t)qb * h->num_classes;
+    int rc = run_all(h->devs, [&](int slot) -> int {
+        DevCtx& dc = h->devs[(size_t)slot];
+        SH_HIP(hipSetDevice(dc.device));
+        double* parts = h->knn[(size_t)slot];                                 // [max_parts] tables of the shards held here
+        double* mine = parts + per * max_parts;                               // their merge
+        double* gath = mine + per;                                            // [nranks] tables
+        double* all = gath + per * (size_t)h->nranks;                         // the merge over the ranks
+        int np = 0;
+        for (auto& p : h->parts) {
+            if (p.slot != slot || !p.c) continue;
+            double* dl = nullptr;
+            void* st = nullptr;
+            const int r = fir_cls_knn_nearest_dev_(p.c, queries, qb, k, &dl, &st, nullptr);
+            if (r) return r;
+            SH_HIP(hipStreamSynchronize((hipStream_t)st));
+            SH_HIP(hipMemcpyAsync(parts + per * (size_t)np, dl, per * sizeof(double), hipMemcpyDeviceToDevice, dc.stream));
+            ++np;
+        }
+        hipLaunchKernelGGL(k_shard_merge_knn, dim3((unsigned)((qc + 255) / 256)), dim3(256), 0, dc.stream, parts, np, qc, k, mine);   // np == 0: all DBL_MAX
+        SH_HIP(hipGetLastError());
+        SH_NCCL(ncclAllGather(mine, gath, per, ncclDouble, dc.comm, dc.stream));
+        hipLaunchKernelGGL(k_shard_merge_knn, dim3((unsigned)((qc + 255) / 256)), dim3(256), 0, dc.stream, gath, h->nranks, qc, k, all);
+        hipLaunchKernelGGL(k_shard_knn_vote, dim3((qb + 63) / 64), dim3(64), 0, dc.stream, all, qb, h->num_classes, k, h->class_count[(size_t)slot],
+                           h->best[(size_t)slot]);
+        SH_HIP(hipGetLastError());
+        if (slot == 0) SH_HIP(hipMemcpyAsync(hb, h->best[0], (size_t)qb * sizeof(int32_t), hipMemcpyDeviceToHost, dc.stream));
+        SH_HIP(hipStreamSynchronize(dc.stream));
+        return FIR_OK;
+    });
+    if (rc) return rc;
+    std::memcpy(best_class, hb, (size_t)qb * sizeof(int32_t));
     return FIR_OK;
 }
 

@@ -324,6 +324,10 @@ int fir_cls_create_sharded(const double* train_rows, int64_t nt, int32_t d, cons
 int fir_cls_sharded_destroy(fir_cls_sharded* h);
 int fir_cls_sharded_pnn_predict(fir_cls_sharded* h, const double* queries, int32_t qb, double var, double* scores,
                                 int32_t* best_class);
+/* KNNClassifier::predict (classification.cpp:116-170) over the same shards: every shard's k smallest mean distances per class
+ * (fir_cls_knn_class_nearest) are merged on the device and across ranks (ncclAllGather); the class whose k-th nearest member is
+ * nearest is the one that first collects k votes in the globally sorted order. Exact: the same class as the one-device call. */
+int fir_cls_sharded_knn_predict(fir_cls_sharded* h, const double* queries, int32_t qb, int32_t k, int32_t* best_class);
 /* HIP events around the exchange step on this process's first device: durations (ms) since the previous read. */
 int fir_sharded_profile_enable(fir_sharded* h, int32_t on);
 int fir_sharded_profile_read(fir_sharded* h, float* exchange_ms, int32_t cap, int32_t* count);

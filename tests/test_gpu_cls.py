@@ -206,3 +206,24 @@ def test_large_query_batch_against_a_tiny_training_set(fir, oracle):
     for i in (0, 65_535, 65_536, 69_999):
         assert pnn[i] == oracle.pnn_predict(tr, tcls, avg, ncls, q[i])[0]
         assert knn[i] == oracle.knn_predict(tr, tcls, avg, ncls, q[i], 1)[0]
+
+
+def test_knn_vote_over_training_row_shards_inside_the_library(fir, oracle):
+    """fir_cls_sharded_knn_predict: per-shard k-nearest lists per class, merged on the device and by ncclAllGather; the class is
+    exactly the one-handle call's (and the oracle's), also when a class has fewer than k rows and when it straddles two shards."""
+    n, d, ncls = 6000, 48, 23
+    tr, tcls, q = _big_training_set(n, d, ncls, 12)
+    keep = np.ones(n, bool)
+    keep[np.nonzero(tcls == 5)[0][2:]] = False              # class 5 keeps two rows: it can never collect three votes
+    tr, tcls = tr[keep], tcls[keep]
+    _, _, avg, _ = oracle.train_stats(tr)
+    with fir.ClsModel(tr, tcls, ncls, avg, 0) as m:
+        ref = {k: m.knn_predict(q, k) for k in (1, 3, 5)}
+    for spd in (1, 3, 8):
+        with fir.ShardedClsModel(tr, tcls, ncls, avg, devices=[0], shards_per_device=spd) as s:
+            for k in (1, 3, 5):
+                assert np.array_equal(s.knn_predict(q, k), ref[k]), (spd, k)
+            b, _ = s.pnn_predict(q)                           # the same handle still answers the PNN
+            assert b.shape == (q.shape[0],)
+    for i in (0, 7, 23):
+        assert ref[3][i] == oracle.knn_predict(tr, tcls, avg, ncls, q[i], 3)[0]
