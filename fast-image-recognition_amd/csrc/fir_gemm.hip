@@ -1387,7 +1387,7 @@ int fir_gemm_search_top1_keys_dev(fir_gemm* m, const float* d_queries, int32_t q
     GEMM_HIP(hipEventRecord(m->queries_ready, st));
     GEMM_HIP(hipStreamWaitEvent(m->side, m->queries_ready, 0));
     // the register-tile flow (fir_gemm_regtile.h) for fp16 galleries whose rows fit the compute waves' registers
-    typedef void (*rt_fn)(const uint4*, const float*, const uint4*, const float*, int64_t, int64_t, const float*, unsigned long long*, int*, unsigned int*, int, int);
+    typedef void (*rt_fn)(const uint4*, const float*, const uint4*, const float*, int64_t, int64_t, int, const float*, unsigned long long*, int*, unsigned int*, int, int);
     rt_fn rt_main = nullptr, rt_sample = nullptr;
     size_t rt_lds = 0;
     if (m->precision == FIR_GEMM_F16 && m->share_max > 0 && (grid & 7) == 0 && grid >= 8) {
@@ -1419,8 +1419,11 @@ int fir_gemm_search_top1_keys_dev(fir_gemm* m, const float* d_queries, int32_t q
                     int P = 1;
                     while (P * 2 <= pairs - p0 && P * 2 <= m->share_max) P *= 2;
                     const size_t qo = (size_t)p0;
+                    // every rb_stride-th row block: the sample is spread over the whole gallery
+                    const int64_t sample_blocks = ((int64_t)m->rt_sample_rows + 31) / 32;
+                    const int rb_stride = (int)std::max<int64_t>(1, ((n + 31) / 32) / sample_blocks);
                     hipLaunchKernelGGL(rt_sample, dim3(grid), dim3(512), rt_lds, ps, m->gh, m->gnorm, m->qbf[b] + qo * 4 * m->dk16 * 64, m->qinv[b] + qo * 2 * kQT, n,
-                                       (int64_t)m->rt_sample_rows, m->tau[b] + qo * 2 * kQT, m->lists[b] + qo * 2 * kQT * kListCap, m->counts[b] + qo * 2 * kQT,
+                                       sample_blocks * 32, rb_stride, m->tau[b] + qo * 2 * kQT, m->lists[b] + qo * 2 * kQT * kListCap, m->counts[b] + qo * 2 * kQT,
                                        m->smin[b] + qo * 2 * kQT, P, P <= 1 ? 1 : 0);
                     p0 += P;
                 }
@@ -1499,7 +1502,7 @@ int fir_gemm_search_top1_keys_dev(fir_gemm* m, const float* d_queries, int32_t q
                 const int nt = (share <= 1) ? 1 : 0;
                 const size_t qo = (size_t)p0;
                 if (rt_full && share > 0 && grid / 8 >= share) {
-                    hipLaunchKernelGGL(rt_main, dim3(grid), dim3(512), rt_lds, st, m->gh, m->gnorm, m->qbf[b] + qo * 4 * m->dk16 * 64, m->qinv[b] + qo * 2 * kQT, n, n,
+                    hipLaunchKernelGGL(rt_main, dim3(grid), dim3(512), rt_lds, st, m->gh, m->gnorm, m->qbf[b] + qo * 4 * m->dk16 * 64, m->qinv[b] + qo * 2 * kQT, n, n, 1,
                                        m->tau[b] + qo * 2 * kQT, m->lists[b] + qo * 2 * kQT * kListCap, m->counts[b] + qo * 2 * kQT, m->smin[b] + qo * 2 * kQT, share, nt);
                     used_rt = true;
                     used_rt_lds = rt_lds;

@@ -63,11 +63,12 @@ __device__ __forceinline__ void rt_dma4(const float* g, uint32_t lds_byte) {    
 #endif
 
 // SAMPLE = false: the full pass -- rows [0, rows) of the gallery, every row with p < tau[q] is appended to the query's list.
-// SAMPLE = true: the sample pass -- rows [0, rows) only (rows = the sample), smin[q] <- the smallest proxy seen (as
-// fir::f32_orderable bits, by atomicMin; the caller presets +inf): all the threshold needs (k_gemm_tau_min).
+// SAMPLE = true: the sample pass -- rows / 32 row blocks, every rb_stride-th one of the gallery (spread over all of it: the
+// reference's galleries are ordered by class, a prefix would sample the first classes only), smin[q] <- the smallest proxy seen
+// (as fir::f32_orderable bits, by atomicMin; the caller presets +inf): all the threshold needs (k_gemm_tau_min).
 template <int DKB, bool SAMPLE>
 __global__ void __launch_bounds__(512, 1) k_gemm_proxy_f16_regtile(const uint4* __restrict__ gh, const float* __restrict__ gnorm, const uint4* qh,
-                                                                    const float* __restrict__ qinv, int64_t n, int64_t rows, const float* tau,
+                                                                    const float* __restrict__ qinv, int64_t n, int64_t rows, int rb_stride, const float* tau,
                                                                     unsigned long long* lists, int* counts, unsigned int* smin, int share, int nt) {
     using RT = RegTile<DKB>;
     constexpr int CK = RT::CK, CPR = RT::CPR, P = RT::P;
@@ -106,7 +107,7 @@ __global__ void __launch_bounds__(512, 1) k_gemm_proxy_f16_regtile(const uint4* 
             if (dbg & 4) return;
             const int cc = c < total ? c : total - 1;
             const int i = cc / CPR, cp = cc - i * CPR;
-            const uint4* src = gh + ((size_t)(rb_first + i) * DKB + (size_t)cp * CK) * 64 + lane;
+            const uint4* src = gh + ((size_t)(rb_first + i) * rb_stride * DKB + (size_t)cp * CK) * 64 + lane;
             const uint32_t dst = ring_base + (uint32_t)(c & (kRtRing - 1)) * (CK * 1024);
             if (nt) {                                              // streamed once (one pair per launch): non-temporal
 #pragma unroll
@@ -116,7 +117,7 @@ __global__ void __launch_bounds__(512, 1) k_gemm_proxy_f16_regtile(const uint4* 
                 for (int j = 0; j < P; ++j) rt_dma16<false>(src + (size_t)(lw + 4 * j) * 64, dst + (uint32_t)(lw + 4 * j) * 1024);
             }
             if (cp == 0 && c < total && lw == (i & 3)) {           // the row block's 32 squared norms (one loader asks, twice over the 64 lanes)
-                int64_t row = (rb_first + i) * 32 + (lane & 31);
+                int64_t row = (rb_first + i) * rb_stride * 32 + (lane & 31);
                 row = row < n ? row : n - 1;
                 rt_dma4(gnorm + row, nring_base + (uint32_t)(i & (kRtNormSlots - 1)) * 256);
             }
@@ -203,11 +204,12 @@ __global__ void __launch_bounds__(512, 1) k_gemm_proxy_f16_regtile(const uint4* 
                 }
             }
             if (SAMPLE) {
-                if ((rb_first + i) * 32 > n) {                      // the block that straddles the end of the gallery: its padding rows are no sample
+                const int64_t rbs = (rb_first + i - 1) * rb_stride;
+                if (rbs * 32 + 32 > n) {                            // the block that straddles the end of the gallery: its padding rows are no sample
                     mn = __builtin_huge_valf();
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        if ((rb_first + i - 1) * 32 + 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2) < n) mn = fminf(mn, pv[r]);
+                        if (rbs * 32 + 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2) < n) mn = fminf(mn, pv[r]);
                 }
                 smallest = fminf(smallest, mn);
             } else if (__builtin_amdgcn_ballot_w64(mn < tq) != 0) { // rare (a few per cent of the row blocks): some lane holds a row below its query's tau

@@ -13,7 +13,9 @@ pytestmark = pytest.mark.gpu
 def run_both(fir, rows, q, precision=2):
     dev = torch.device("cuda", 0)
     with fir.Gallery(rows, None, 0, 0) as g:
+        g.set_large_batch_mfma(0)            # the reference answer is the exact scan's, whatever the batch size
         eidx, edist = g.search_top1(q)
+        assert g.last_dispatch()["path"] == "scan"
         tq = torch.from_numpy(np.ascontiguousarray(q, np.float32)).to(dev)
         keys = torch.empty(q.shape[0], dtype=torch.int64, device=dev)
         with fir.GemmSearch(g, precision) as m:
@@ -233,3 +235,20 @@ def test_default_dispatch_takes_the_matrix_cores_for_big_batches_over_big_galler
     with fir.Gallery(synth.make_gallery(25, 70000, 64, 1), None, 1, 0) as g:     # chi-square never
         g.search_top1(synth.make_queries(25, rows, 130, 1)[0])
         assert g.last_dispatch()["path"] == "scan"
+
+
+def test_class_ordered_gallery_is_sampled_across_all_classes(fir):
+    """The reference's galleries are ordered by class. The threshold comes from a row sample; a prefix sample would see the
+    first classes only and a query of a late class would pass thousands of rows (list overflow -> exact scan). The sample
+    is every n-th row block: no fallbacks, and the exact scan's keys."""
+    rng = np.random.default_rng(3)
+    ident, per, d = 700, 100, 64
+    centres = rng.random((ident, d)).astype(np.float32)
+    rows = np.repeat(centres, per, axis=0) * (1 + 0.02 * (rng.random((ident * per, d)).astype(np.float32) - 0.5))
+    rows /= np.linalg.norm(rows, axis=1, keepdims=True)
+    pick = np.arange(300) % 40 + ident * per - 40 * per + (np.arange(300) // 40) * per      # images of the last identities
+    q = rows[pick] * (1 + 0.01 * (rng.random((300, d)).astype(np.float32) - 0.5))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    (idx, dist), (eidx, edist), st = run_both(fir, rows, q)
+    assert np.array_equal(idx, eidx) and np.array_equal(dist.view(np.uint32), edist.view(np.uint32))
+    assert st["fallback_queries"] == 0
