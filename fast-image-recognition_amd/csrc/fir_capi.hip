@@ -762,6 +762,7 @@ int fir_gallery_scratch_(fir_gallery* g, int slot, size_t bytes, void** out) {
         g->scratch_cap[slot] = 0;
         const size_t want = std::max<size_t>(bytes + bytes / 4, 4096);
         FIR_HIP(hipMalloc(&g->scratch[slot], want));
+        FIR_HIP(hipMemset(g->scratch[slot], 0, want));        // a fresh slot reads as zeros (fir_rows_distances' arrival counter)
         g->scratch_cap[slot] = want;
     }
     *out = g->scratch[slot];

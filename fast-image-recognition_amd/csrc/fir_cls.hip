@@ -136,6 +136,62 @@ __global__ void __launch_bounds__(kBlock) k_cls_scan(const double2* __restrict__
     }
 }
 
+// The same sums for ONE query (the reference's predict() per test vector, ~3 000 x 256 training rows): such a call is
+// latency, not bandwidth -- 48 waves, each walking its 128 double2 loads four at a time, took 52 us. Here every wave keeps
+// 16 loads in flight, and the query side of normalize() (q - avg, :135) is computed by the workgroup itself into LDS, which
+// saves the separate k_cls_prep_queries launch. Same operations per element, same order in k.
+// Dynamic LDS: 2 * dp2 doubles.
+__global__ void __launch_bounds__(kBlock) k_cls_scan_one(const double2* __restrict__ gal2, const double* __restrict__ q,
+                                                          const double* __restrict__ avg, int64_t nt, int tiles, int dp2, int d, int waves, int lo,
+                                                          int hi, double* __restrict__ sums_base, int cstep, int64_t sub_stride) {
+    extern __shared__ __attribute__((aligned(16))) double qs1[];
+    for (int k = threadIdx.x; k < dp2 * 2; k += kBlock) qs1[k] = k < d ? q[k] - avg[k] : 0.0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    constexpr int U = 16;
+    for (int t = gw; t < tiles; t += waves) {
+        const double2* p = gal2 + (size_t)t * dp2 * 64 + lane;
+        double* sums = sums_base;
+        for (int c0 = lo; c0 < hi; c0 += cstep, sums += sub_stride) {
+            const int c1 = min(hi, c0 + cstep);
+            double acc = 0.0;
+            int c = c0;
+            for (; c + U <= c1; c += U) {
+                double2 g[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) g[u] = p[(size_t)(c + u) * 64];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const double gv[2] = {g[u].x, g[u].y};
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int k = (c + u) * 2 + j;
+                        if (k < d) {
+                            const double diff = gv[j] - qs1[k];             // :132-137
+                            acc = acc + diff * diff;                        // :141
+                        }
+                    }
+                }
+            }
+            for (; c < c1; ++c) {
+                const double2 g = p[(size_t)c * 64];
+                const double gv[2] = {g.x, g.y};
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int k = c * 2 + j;
+                    if (k < d) {
+                        const double diff = gv[j] - qs1[k];
+                        acc = acc + diff * diff;
+                    }
+                }
+            }
+            const int64_t row = (int64_t)t * kTileRows + lane;
+            if (row < nt) sums[row] = acc;
+        }
+    }
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -294,6 +350,114 @@ __global__ void __launch_bounds__(kSeqBlock) k_cls_pnn_seq(const double* __restr
     }
 }
 
+// The same classifier for training sets of up to kSeqRows * 1024 rows (the reference's scale): a thread keeps the running
+// sums of its (at most kSeqRows) rows in registers and their class from one binary search, the exp() values live in LDS,
+// and the NEXT chunk's sums are in flight while this chunk is worked on -- no global round trip inside a chunk
+// (81 -> see profiles/r02_latency_secondary.txt us per query at 3 030 x 256). Same operations, same summation order.
+// Dynamic LDS: num_classes doubles (outputs) + nt doubles (exp values) + num_classes ints + num_classes + 1 ints.
+constexpr int kSeqRows = 4;
+__global__ void __launch_bounds__(kSeqBlock) k_cls_pnn_seq_small(const double* __restrict__ cs, int nq, int nchunks,
+                                                                  const int32_t* __restrict__ class_off, int nt, int num_classes, int d, double var,
+                                                                  double den, int32_t* __restrict__ best_class, int32_t* __restrict__ chunks_out,
+                                                                  unsigned long long* ticket_word, unsigned long long ticket) {
+    extern __shared__ __attribute__((aligned(16))) double outputs[];
+    double* ev = outputs + num_classes;
+    int* checked = (int*)(ev + nt);
+    int* off = checked + num_classes;
+    __shared__ int best_s, stop_s;
+    const int q = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nwaves = kSeqBlock / 64;
+    for (int c = threadIdx.x; c < num_classes; c += kSeqBlock) { checked[c] = 1; outputs[c] = 0.0; }
+    for (int c = threadIdx.x; c <= num_classes; c += kSeqBlock) off[c] = class_off[c];
+    if (threadIdx.x == 0) { best_s = -1; stop_s = 0; }
+    double run[kSeqRows], nxt[kSeqRows];
+    int cls[kSeqRows];
+#pragma unroll
+    for (int r = 0; r < kSeqRows; ++r) {
+        const int t = threadIdx.x + r * kSeqBlock;
+        run[r] = 0.0;                                                                   // distances[i][t] = 0 (:238-241)
+        nxt[r] = t < nt ? cs[(size_t)q * nt + t] : 0.0;                                 // chunk 0
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kSeqRows; ++r) {
+        const int t = threadIdx.x + r * kSeqBlock;
+        int lo = 0, hi = num_classes;                                                   // class of row t: off[lo] <= t < off[lo + 1]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (off[mid] <= t) lo = mid; else hi = mid;
+        }
+        cls[r] = lo;
+    }
+    int used = 0;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        ++used;
+        int max_fi = (ch + 1) * 32;                                                     // delta_features_count = 32 (:182,247-249)
+        if (max_fi > d) max_fi = d;
+        double cur[kSeqRows];
+#pragma unroll
+        for (int r = 0; r < kSeqRows; ++r) {
+            const int t = threadIdx.x + r * kSeqBlock;
+            cur[r] = nxt[r];
+            if (ch + 1 < nchunks && t < nt) nxt[r] = cs[((size_t)(ch + 1) * nq + q) * nt + t];
+        }
+        // (A) rows in parallel
+#pragma unroll
+        for (int r = 0; r < kSeqRows; ++r) {
+            const int t = threadIdx.x + r * kSeqBlock;
+            if (t < nt && checked[cls[r]]) {                                            // :251 (a dropped class never comes back)
+                const double v = run[r] + cur[r];                                       // distances[i][t] += diff*diff ... (:264)
+                run[r] = v;
+                ev[t] = exp(-v / (2 * var * max_fi));                                   // :266
+            }
+        }
+        __syncthreads();
+        // (B) one wave per class, the summation order of k_cls_pnn_seq
+        for (int c = wave; c < num_classes; c += nwaves) {
+            if (!checked[c]) continue;
+            double acc = 0.0;
+            for (int t = off[c] + lane; t < off[c + 1]; t += 64) acc += ev[t];
+            acc = wave_sum(acc);
+            if (lane == 0) outputs[c] = acc / den;                                      // :268
+        }
+        __syncthreads();
+        // (C) bookkeeping, one wave
+        if (wave == 0) {
+            double mx = -DBL_MAX;
+            int bi = 0x7FFFFFFF;
+            for (int i = lane; i < num_classes; i += 64)
+                if (checked[i] && mx < outputs[i]) { mx = outputs[i]; bi = i; }         // :272-279, this lane's first maximum
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                const double om = __shfl_xor(mx, o, 64);
+                const int oi = __shfl_xor(bi, o, 64);
+                if (om > mx || (om == mx && oi < bi)) { mx = om; bi = oi; }
+            }
+            const int best = bi != 0x7FFFFFFF ? bi : best_s;
+            const float output_threshold = (float)(mx / 1000000000);                    // output_dividor = 1E9 (:186,282)
+            int variants = 0;
+            for (int i = lane; i < num_classes; i += 64)
+                if (checked[i]) {
+                    if (outputs[i] < output_threshold) checked[i] = 0;                  // :285-286
+                    else ++variants;
+                }
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) variants += __shfl_xor(variants, o, 64);
+            if (lane == 0) { best_s = best; stop_s = variants == 1; }                   // :291
+        }
+        __syncthreads();
+        if (stop_s) break;
+    }
+    if (threadIdx.x == 0) {
+        best_class[q] = best_s;
+        chunks_out[q] = used;
+        if (ticket_word) {
+            __threadfence_system();
+            __hip_atomic_store(ticket_word, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 // mode 0: PNN arg-max, first maximum from -DBL_MAX (classification.cpp:217-224).
 // mode 1: kNN arg-min of kth; when no class has k rows the reference's loop ends without a
 //         break and the arg-max of the vote counts = the largest class (first) wins (:161-168).
@@ -302,27 +466,48 @@ __global__ void __launch_bounds__(64) k_cls_argbest(const double* __restrict__ v
                                                      unsigned long long ticket = 0) {
     // ticket_word (one-query calls, results in pinned host memory): after the class, the call's ticket -- the host spins on
     // that word instead of synchronising the stream (cls_wait_ticket)
-    const int q = blockIdx.x;
-    if (threadIdx.x != 0) return;
+    // One wave per query: lane l looks at classes l, l + 64, ... in order (its first extremum), then the lanes are folded
+    // by (better value, then lower class) -- the first extremum of the reference's single loop.
+    const int q = blockIdx.x, lane = threadIdx.x;
     const double* s = v + (size_t)q * num_classes;
-    int best = -1;
+    const int kNone = 0x7FFFFFFF;
+    int best = kNone;
     if (mode == 0) {
         double mx = -DBL_MAX;
-        for (int i = 0; i < num_classes; ++i)
+        for (int i = lane; i < num_classes; i += 64)
             if (mx < s[i]) { mx = s[i]; best = i; }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const double om = __shfl_xor(mx, o, 64);
+            const int oi = __shfl_xor(best, o, 64);
+            if (oi != kNone && (best == kNone || om > mx || (om == mx && oi < best))) { mx = om; best = oi; }
+        }
     } else {
         double mn = DBL_MAX;
-        for (int i = 0; i < num_classes; ++i)
+        for (int i = lane; i < num_classes; i += 64)
             if (s[i] < mn) { mn = s[i]; best = i; }
-        if (best < 0) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const double om = __shfl_xor(mn, o, 64);
+            const int oi = __shfl_xor(best, o, 64);
+            if (oi != kNone && (best == kNone || om < mn || (om == mn && oi < best))) { mn = om; best = oi; }
+        }
+        if (best == kNone) {                                  // wave-uniform: no class has k rows
             int mc = -1;
-            for (int i = 0; i < num_classes; ++i) {
+            for (int i = lane; i < num_classes; i += 64) {
                 const int cnt = class_off[i + 1] - class_off[i];
                 if (cnt > mc) { mc = cnt; best = i; }
             }
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                const int om = __shfl_xor(mc, o, 64);
+                const int oi = __shfl_xor(best, o, 64);
+                if (oi != kNone && (best == kNone || om > mc || (om == mc && oi < best))) { mc = om; best = oi; }
+            }
         }
     }
-    best_class[q] = best;
+    if (lane != 0) return;
+    best_class[q] = best == kNone ? -1 : best;
     if (ticket_word) {
         __threadfence_system();
         __hip_atomic_store(ticket_word, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -442,6 +627,12 @@ int cls_scan(fir_cls* c, const double* queries, int32_t qb) {
     // a training set streamed from HBM takes 8 queries per pass (the pass stays HBM-bound), a cache-resident one 4
     const bool big = (double)c->tiles * 64.0 * c->dp2 * 16.0 > 256.0 * 1024 * 1024;
     const int qbt = big ? kQBBig : kQB;
+    if (qb == 1 && !big) {
+        hipLaunchKernelGGL(k_cls_scan_one, dim3(waves / 4), dim3(kBlock), (size_t)kk * sizeof(double), c->stream, c->gal2, dq, c->avg, c->nt,
+                           (int)c->tiles, c->dp2, c->d, waves, 0, c->dp2, c->sums, c->dp2, (int64_t)0);
+        CLS_HIP(hipGetLastError());
+        return FIR_OK;
+    }
     for (int q0 = 0; q0 < qb; q0 += qbt) {
         const int nq = std::min(qbt, qb - q0);
         if (big) {
@@ -670,15 +861,26 @@ int fir_cls_pnn_predict_seq(fir_cls* c, const double* queries, int32_t qb, doubl
     const unsigned long long ticket = one ? ++c->ticket : 0;
     for (int q0 = 0; q0 < qb; q0 += kQB) {
         const int nq = std::min(kQB, qb - q0);
-        hipLaunchKernelGGL(k_cls_prep_queries<kQB>, dim3((kk * kQB + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream,
-                           dq + (size_t)q0 * c->d, nq, c->d, c->dp2, c->avg, c->qn);
         // all 32-feature chunk sums (16 double2 chunks each) from one pass: chunk ch lands at sums + ch * nq * nt
-        hipLaunchKernelGGL(k_cls_scan<kQB>, dim3(waves / 4), dim3(kBlock), 0, c->stream, c->gal2, c->qn, c->nt, (int)c->tiles, c->dp2, c->d, waves, nq,
-                           0, c->dp2, c->sums, 16, (int64_t)nq * c->nt);
-        hipLaunchKernelGGL(k_cls_pnn_seq, dim3(nq), dim3(kSeqBlock), (size_t)c->num_classes * 16 + 4, c->stream, c->sums, nq, nchunks, run,
-                           run + (size_t)kQB * ntp, c->class_off, c->nt, c->num_classes, c->d, var,
-                           c->total_training_size > 0 ? c->total_training_size : (double)c->nt, dbest + q0, dchunks + q0,
-                           one ? cls_pin_ticket(c) : (unsigned long long*)nullptr, ticket);
+        if (qb == 1) {
+            hipLaunchKernelGGL(k_cls_scan_one, dim3(waves / 4), dim3(kBlock), (size_t)kk * sizeof(double), c->stream, c->gal2, dq, c->avg, c->nt,
+                               (int)c->tiles, c->dp2, c->d, waves, 0, c->dp2, c->sums, 16, (int64_t)c->nt);
+        } else {
+            hipLaunchKernelGGL(k_cls_prep_queries<kQB>, dim3((kk * kQB + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream,
+                               dq + (size_t)q0 * c->d, nq, c->d, c->dp2, c->avg, c->qn);
+            hipLaunchKernelGGL(k_cls_scan<kQB>, dim3(waves / 4), dim3(kBlock), 0, c->stream, c->gal2, c->qn, c->nt, (int)c->tiles, c->dp2, c->d, waves,
+                               nq, 0, c->dp2, c->sums, 16, (int64_t)nq * c->nt);
+        }
+        const size_t small_lds = (size_t)c->num_classes * 16 + 4 + (size_t)c->nt * 8;
+        if (c->nt <= (int64_t)kSeqRows * kSeqBlock && small_lds <= 60 * 1024)
+            hipLaunchKernelGGL(k_cls_pnn_seq_small, dim3(nq), dim3(kSeqBlock), small_lds, c->stream, c->sums, nq, nchunks, c->class_off, (int)c->nt,
+                               c->num_classes, c->d, var, c->total_training_size > 0 ? c->total_training_size : (double)c->nt, dbest + q0,
+                               dchunks + q0, one ? cls_pin_ticket(c) : (unsigned long long*)nullptr, ticket);
+        else
+            hipLaunchKernelGGL(k_cls_pnn_seq, dim3(nq), dim3(kSeqBlock), (size_t)c->num_classes * 16 + 4, c->stream, c->sums, nq, nchunks, run,
+                               run + (size_t)kQB * ntp, c->class_off, c->nt, c->num_classes, c->d, var,
+                               c->total_training_size > 0 ? c->total_training_size : (double)c->nt, dbest + q0, dchunks + q0,
+                               one ? cls_pin_ticket(c) : (unsigned long long*)nullptr, ticket);
     }
     CLS_HIP(hipGetLastError());
     if (one) {

@@ -24,7 +24,9 @@
 #include <algorithm>
 #include <cfloat>
 #include <cstdarg>
+#include <chrono>
 #include <cstdio>
+#include <cstring>
 #include <unordered_map>
 #include <vector>
 
@@ -138,6 +140,7 @@ __global__ void __launch_bounds__(kBlock) k_dem_pick(const Part* __restrict__ pa
 
 constexpr int kMaxUsed = 32;   // ann.cpp:333-334: only the first 32 pivots are walked at query time
 constexpr int kLikBatch = 8;
+constexpr int kPinLikRows = 131072;
 
 // lik[q][nu] = sum over the kept pivots i (in order) of (pd[q][i] - table[i][nu])^2, entries with table < 0 skipped (:441).
 // pd[q][i] = distance(query q, pivot i). One lane per row; the translation unit is built with -ffp-contract=off.
@@ -189,29 +192,65 @@ __global__ void k_dem_lik_fix(const float* __restrict__ table, int n, int used, 
     lik[(size_t)q * n + nu] = acc;
 }
 
-// out[q][k] = distance(query q, gallery row rows[q][k]) over [start,end): lhs = query (ImageInfo::distance). One lane
-// per candidate; a row of the tiled gallery is one float4 per 1 KiB, so this is a gather (16 useful bytes per access).
+// out[q][k] = distance(query q, gallery row rows[q][k]) over [start,end): lhs = query (ImageInfo::distance).
+// A row of the tiled gallery is one float4 per 1 KiB, so a candidate is a gather. One WAVE per `cpw` candidates: its lanes
+// fetch the row's float4s side by side (one memory latency instead of d/4 in a row -- the call is latency, not bandwidth),
+// park them in LDS next to the query (read ONCE per workgroup: on small calls it sits in pinned host memory), and lane j
+// then runs the reference's loop for candidate j in feature order (fir::accum, un-fused).
+// Dynamic LDS: (1 + 4 * cpw) * dp4 float4.
 template <int METRIC>
 __global__ void __launch_bounds__(kBlock) k_rows_dist(const float4* __restrict__ gal4, int dp4, int64_t n, const float* __restrict__ queries, int d,
-                                                      const int32_t* __restrict__ rows, int m, int start, int end, float* __restrict__ out) {
-    const int k = blockIdx.x * kBlock + threadIdx.x;
-    const int q = blockIdx.y;
-    if (k >= m) return;
-    const int64_t row = rows[(size_t)q * m + k];
-    if (row < 0 || row >= n) { out[(size_t)q * m + k] = fir::kNotFound; return; }
-    const float* __restrict__ qv = queries + (size_t)q * d;
-    const float4* __restrict__ base = gal4 + (size_t)(row >> 6) * dp4 * 64 + (row & 63);
-    float acc = 0.0f;
-    for (int c = start >> 2; c <= (end - 1) >> 2; ++c) {
-        const float4 v = base[(size_t)c * 64];
-        const float e[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int f = c * 4 + j;
-            if (f >= start && f < end) acc = fir::accum<METRIC>(acc, qv[f], e[j]);
+                                                      const int32_t* __restrict__ rows, int m, int start, int end, float* __restrict__ out, int cpw,
+                                                      unsigned int* arrivals, unsigned long long* ticket_word, unsigned long long ticket) {
+    // ticket_word (small host-pointer calls: queries, rows and `out` live in pinned host memory): the workgroup that arrives
+    // last publishes the call's ticket after every distance is visible to the host, and re-arms the arrival counter
+    extern __shared__ __attribute__((aligned(16))) float4 rsm[];
+    float* qs = (float*)rsm;
+    const int q = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int k = threadIdx.x; k < dp4 * 4; k += kBlock) qs[k] = k < d ? queries[(size_t)q * d + k] : 0.0f;
+    float4* mine = rsm + dp4 + (size_t)wave * cpw * dp4;
+    const int k0 = (blockIdx.x * (kBlock / 64) + wave) * cpw;
+    const int c0 = start >> 2, c1 = (end - 1) >> 2;
+    for (int j = 0; j < cpw; ++j) {
+        const int k = k0 + j;
+        const int64_t row = k < m ? (int64_t)rows[(size_t)q * m + k] : -1;
+        if (row < 0 || row >= n) continue;                     // wave-uniform
+        const float4* __restrict__ base = gal4 + (size_t)(row >> 6) * dp4 * 64 + (row & 63);
+        for (int c = c0 + lane; c <= c1; c += 64) mine[(size_t)j * dp4 + c] = base[(size_t)c * 64];
+    }
+    __syncthreads();
+    if (lane < cpw && k0 + lane < m) {
+        const int64_t row = rows[(size_t)q * m + k0 + lane];
+        float dist = fir::kNotFound;
+        if (row >= 0 && row < n) {
+            const float* __restrict__ gv = (const float*)(mine + (size_t)lane * dp4);
+            float acc = 0.0f;
+            for (int f = start; f < end; ++f) acc = fir::accum<METRIC>(acc, qs[f], gv[f]);
+            dist = acc / (float)(end - start);
+        }
+        out[(size_t)q * m + k0 + lane] = dist;
+    }
+    if (ticket_word) {
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned int total = gridDim.x * gridDim.y;
+            if (atomicAdd(arrivals, 1u) == total - 1) {
+                atomicExch(arrivals, 0u);
+                __threadfence_system();
+                __hip_atomic_store(ticket_word, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
     }
-    out[(size_t)q * m + k] = acc / (float)(end - start);
+}
+
+// Last kernel of a small fir_dem_likelihoods call: the pivot distances go to pinned host memory, then the ticket.
+__global__ void __launch_bounds__(64) k_dem_publish(const float* __restrict__ pd, int count, float* __restrict__ host_pd,
+                                                     unsigned long long* ticket_word, unsigned long long ticket) {
+    for (int i = threadIdx.x; i < count; i += 64) host_pd[i] = pd[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(ticket_word, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 struct Buf {
@@ -280,6 +319,10 @@ struct fir_dem {
     std::vector<std::pair<int32_t, int32_t> > order_mods;   // (position, value): where likelihood_indices differs from identity after the pivots
     Buf table, pivrows, exc_rows, exc_mult, q, pd, lik;
     int nexc = 0;
+    // galleries up to kPinLikRows rows: queries in and pivot distances / likelihoods out through pinned, device-visible host
+    // memory the kernels address directly, completion by a ticket word (no copy engine, no stream synchronisation)
+    void* pin = nullptr;
+    unsigned long long ticket = 0;
 };
 
 extern "C" {
@@ -369,6 +412,11 @@ int fir_dem_create(fir_gallery* g, int32_t first_pivot, int32_t n_pivots, fir_de
     DEM_HIP(h->q.alloc((size_t)kLikBatch * v.d * 4));
     DEM_HIP(h->pd.alloc((size_t)kLikBatch * kMaxUsed * 4));
     DEM_HIP(h->lik.alloc((size_t)kLikBatch * n * 4));
+    if (n <= kPinLikRows) {
+        const size_t bytes = (size_t)kLikBatch * ((size_t)v.d + kMaxUsed + (size_t)n) * 4 + 64;
+        DEM_HIP(hipHostMalloc(&h->pin, bytes, hipHostMallocDefault));
+        std::memset(h->pin, 0, bytes);
+    }
     guard.h = nullptr;
     *out = h;
     return FIR_OK;
@@ -378,6 +426,7 @@ int fir_dem_destroy(fir_dem* h) {
     if (!h) return FIR_OK;
     (void)hipSetDevice(h->v.device);
     if (h->pivot_rows) fir_gallery_destroy(h->pivot_rows);
+    if (h->pin) (void)hipHostFree(h->pin);
     delete h;
     return FIR_OK;
 }
@@ -413,23 +462,50 @@ int fir_dem_likelihoods(fir_dem* h, const float* queries, int32_t qb, float* piv
     DEM_HIP(hipSetDevice(v.device));
     const int n = (int)v.n, used = h->used;
     const int nblocks = std::min(kMaxBlocks, (n + kBlock - 1) / kBlock);
+    float* hq = (float*)h->pin;
+    float* hpd = hq ? hq + (size_t)kLikBatch * v.d : nullptr;
+    float* hlik = hq ? hpd + (size_t)kLikBatch * kMaxUsed : nullptr;
+    unsigned long long* tword = hq ? (unsigned long long*)(((uintptr_t)(hlik + (size_t)kLikBatch * n) + 7) & ~(uintptr_t)7) : nullptr;
     for (int q0 = 0; q0 < qb; q0 += kLikBatch) {
         const int nq = std::min(kLikBatch, qb - q0);
-        DEM_HIP(hipMemcpyAsync(h->q.p, queries + (size_t)q0 * v.d, (size_t)nq * v.d * 4, hipMemcpyHostToDevice, v.stream));
-        const int rc = fir_range_distances_dev(h->pivot_rows, h->q.as<float>(), nq, 0, v.d, h->pd.as<float>(), v.stream);   // pd[q][used]
+        const float* dq = h->q.as<float>();
+        float* dlik = h->lik.as<float>();
+        if (hq) {
+            std::memcpy(hq, queries + (size_t)q0 * v.d, (size_t)nq * v.d * 4);
+            dq = hq;
+            dlik = hlik;
+        } else {
+            DEM_HIP(hipMemcpyAsync(h->q.p, queries + (size_t)q0 * v.d, (size_t)nq * v.d * 4, hipMemcpyHostToDevice, v.stream));
+        }
+        const int rc = fir_range_distances_dev(h->pivot_rows, dq, nq, 0, v.d, h->pd.as<float>(), v.stream);   // pd[q][used]
         if (rc) return rc;
-        if (pivot_dist_out)
+        if (!hq && pivot_dist_out)
             DEM_HIP(hipMemcpyAsync(pivot_dist_out + (size_t)q0 * used, h->pd.p, (size_t)nq * used * 4, hipMemcpyDeviceToHost, v.stream));
         if (lik_out) {
-            hipLaunchKernelGGL(k_dem_lik<kLikBatch>, dim3(nblocks), dim3(kBlock), 0, v.stream, h->table.as<float>(), n, used, h->pd.as<float>(), nq,
-                               h->lik.as<float>());
+            hipLaunchKernelGGL(k_dem_lik<kLikBatch>, dim3(nblocks), dim3(kBlock), 0, v.stream, h->table.as<float>(), n, used, h->pd.as<float>(), nq, dlik);
             DEM_HIP(hipGetLastError());
             hipLaunchKernelGGL(k_dem_lik_fix, dim3((h->nexc * nq + 63) / 64), dim3(64), 0, v.stream, h->table.as<float>(), n, used, h->pd.as<float>(),
-                               nq, h->exc_rows.as<int32_t>(), h->exc_mult.as<uint8_t>(), h->nexc, h->lik.as<float>());
+                               nq, h->exc_rows.as<int32_t>(), h->exc_mult.as<uint8_t>(), h->nexc, dlik);
             DEM_HIP(hipGetLastError());
-            DEM_HIP(hipMemcpyAsync(lik_out + (size_t)q0 * n, h->lik.p, (size_t)nq * n * 4, hipMemcpyDeviceToHost, v.stream));
+            if (!hq) DEM_HIP(hipMemcpyAsync(lik_out + (size_t)q0 * n, h->lik.p, (size_t)nq * n * 4, hipMemcpyDeviceToHost, v.stream));
         }
-        DEM_HIP(hipStreamSynchronize(v.stream));
+        if (!hq) {
+            DEM_HIP(hipStreamSynchronize(v.stream));
+            continue;
+        }
+        const unsigned long long ticket = ++h->ticket;
+        hipLaunchKernelGGL(k_dem_publish, dim3(1), dim3(64), 0, v.stream, h->pd.as<float>(), nq * used, hpd, tword, ticket);
+        DEM_HIP(hipGetLastError());
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int spins = 0; __atomic_load_n(tword, __ATOMIC_ACQUIRE) != ticket; ++spins) {
+            if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {
+                DEM_HIP(hipStreamSynchronize(v.stream));
+                if (__atomic_load_n(tword, __ATOMIC_ACQUIRE) != ticket) return dem_fail(FIR_ERR_HIP, "the result ticket was not published");
+                break;
+            }
+        }
+        if (pivot_dist_out) std::memcpy(pivot_dist_out + (size_t)q0 * used, hpd, (size_t)nq * used * 4);
+        if (lik_out) std::memcpy(lik_out + (size_t)q0 * n, hlik, (size_t)nq * n * 4);
     }
     return FIR_OK;
 }
@@ -450,22 +526,58 @@ int fir_rows_distances(fir_gallery* g, const float* queries, int32_t qb, const i
     int rc = fir_gallery_info(g, nullptr, nullptr, &metric, nullptr);
     if (rc) return rc;
     DEM_HIP(hipSetDevice(v.device));
-    Buf dq, drows, dout;
-    DEM_HIP(dq.alloc((size_t)qb * v.d * 4));
-    DEM_HIP(drows.alloc((size_t)qb * m * 4));
-    DEM_HIP(dout.alloc((size_t)qb * m * 4));
-    DEM_HIP(hipMemcpyAsync(dq.p, queries, (size_t)qb * v.d * 4, hipMemcpyHostToDevice, v.stream));
-    DEM_HIP(hipMemcpyAsync(drows.p, rows, (size_t)qb * m * 4, hipMemcpyHostToDevice, v.stream));
-    const dim3 grid((m + kBlock - 1) / kBlock, qb);
-#define FIR_ROWS_LAUNCH(M)                                                                                                               \
-    hipLaunchKernelGGL(k_rows_dist<M>, grid, dim3(kBlock), 0, v.stream, (const float4*)gal4, dp4, v.n, dq.as<float>(), v.d, drows.as<int32_t>(), m, \
-                       start_pos, end_pos, dout.as<float>())
-    if (metric == FIR_METRIC_L2) FIR_ROWS_LAUNCH(fir::kL2);
-    else if (metric == FIR_METRIC_CHI2) FIR_ROWS_LAUNCH(fir::kChi2);
-    else FIR_ROWS_LAUNCH(fir::kKL);
+    // candidates per wave: 4 while the workgroup's 1 + 16 rows fit 64 KiB of LDS (d <= 960), else 1 (d <= 3276)
+    const int cpw = (size_t)17 * dp4 * 16 <= 64 * 1024 ? 4 : 1;
+    const size_t lds = (size_t)(1 + (kBlock / 64) * cpw) * dp4 * 16;
+    if (lds > 64 * 1024) return dem_fail(FIR_ERR_ARG, "rows of %d features do not fit the candidate kernel's LDS", v.d);
+    const int per_block = (kBlock / 64) * cpw;
+    const dim3 grid((m + per_block - 1) / per_block, qb);
+#define FIR_ROWS_LAUNCH(M, Q, R, O, A, T, TK)                                                                                             \
+    hipLaunchKernelGGL(k_rows_dist<M>, grid, dim3(kBlock), lds, v.stream, (const float4*)gal4, dp4, v.n, Q, v.d, R, m, start_pos, end_pos, O, cpw, A, \
+                       T, TK)
+#define FIR_ROWS_BY_METRIC(Q, R, O, A, T, TK)                                                                                             \
+    do {                                                                                                                                  \
+        if (metric == FIR_METRIC_L2) FIR_ROWS_LAUNCH(fir::kL2, Q, R, O, A, T, TK);                                                        \
+        else if (metric == FIR_METRIC_CHI2) FIR_ROWS_LAUNCH(fir::kChi2, Q, R, O, A, T, TK);                                               \
+        else FIR_ROWS_LAUNCH(fir::kKL, Q, R, O, A, T, TK);                                                                                \
+    } while (0)
+    const size_t qbytes = ((size_t)qb * v.d * 4 + 15) & ~(size_t)15, rbytes = (size_t)qb * m * 4;
+    // Small calls (the DEM walk: one query, a few hundred candidate rows): everything through the handle's pinned,
+    // device-visible buffer -- no allocation, no copy engine, no stream synchronisation (the last workgroup's ticket).
+    void* pin_base = nullptr;
+    size_t pin_cap = 0;
+    uint64_t* pin_res = nullptr;
+    void* p_arr = nullptr;
+    if ((size_t)qb * m <= 8000 && fir_gallery_pin_(g, &pin_base, &pin_cap, &pin_res) == FIR_OK && qbytes + rbytes <= pin_cap &&
+        fir_gallery_scratch_(g, 11, 16, &p_arr) == FIR_OK) {
+        float* hq = (float*)pin_base;
+        int32_t* hr = (int32_t*)((char*)pin_base + qbytes);
+        float* ho = (float*)pin_res;
+        unsigned long long* tword = (unsigned long long*)(pin_res + 4095);
+        std::memcpy(hq, queries, (size_t)qb * v.d * 4);
+        std::memcpy(hr, rows, rbytes);
+        const unsigned long long ticket = fir_gallery_next_ticket_(g);
+        FIR_ROWS_BY_METRIC(hq, hr, ho, (unsigned int*)p_arr, tword, ticket);
+        const hipError_t le = hipGetLastError();
+        if (le == hipSuccess && fir_gallery_wait_ticket_(g, (volatile uint64_t*)tword, ticket) == FIR_OK) {
+            std::memcpy(out, ho, rbytes);
+            return FIR_OK;
+        }
+        // the launch failed or never published: re-arm the arrival counter and take the general path below
+        (void)hipStreamSynchronize(v.stream);
+        (void)hipMemset(p_arr, 0, 16);
+    }
+    void *dq = nullptr, *drows = nullptr, *dout = nullptr;
+    if ((rc = fir_gallery_scratch_(g, 8, (size_t)qb * v.d * 4, &dq))) return rc;
+    if ((rc = fir_gallery_scratch_(g, 9, rbytes, &drows))) return rc;
+    if ((rc = fir_gallery_scratch_(g, 10, rbytes, &dout))) return rc;
+    DEM_HIP(hipMemcpyAsync(dq, queries, (size_t)qb * v.d * 4, hipMemcpyHostToDevice, v.stream));
+    DEM_HIP(hipMemcpyAsync(drows, rows, rbytes, hipMemcpyHostToDevice, v.stream));
+    FIR_ROWS_BY_METRIC((const float*)dq, (const int32_t*)drows, (float*)dout, (unsigned int*)nullptr, (unsigned long long*)nullptr, 0ull);
+#undef FIR_ROWS_BY_METRIC
 #undef FIR_ROWS_LAUNCH
     DEM_HIP(hipGetLastError());
-    DEM_HIP(hipMemcpyAsync(out, dout.p, (size_t)qb * m * 4, hipMemcpyDeviceToHost, v.stream));
+    DEM_HIP(hipMemcpyAsync(out, dout, rbytes, hipMemcpyDeviceToHost, v.stream));
     DEM_HIP(hipStreamSynchronize(v.stream));
     return FIR_OK;
 }

@@ -6,11 +6,13 @@
 //   k_fpnn_train   one thread per (class, harmonic j, feature): a_cos/a_sin += cos/sin(PI (j+1) val) * cur_mult * (J-j) / (J (J+1))
 //                  over the class's rows in training-set order (:680-690). Lanes run over the features, so the training
 //                  rows (row-major doubles) are read coalesced.
-//   k_fpnn_trig    one thread per (query, feature): val = normalize(x) (:647-655), cos/sin(PI val) and the angle-addition
-//                  recurrence of :706-711 for the J harmonics.
-//   k_fpnn_predict one workgroup per query, threads over the classes: probab = a0 + sum_j (a_cos*cos_j + a_sin*sin_j) in
-//                  double (:717-721), outputs[c] += fasterlog2((float)probab) in float, features in order (:722).
-//                  SEQ form (:736-791): the same in 32-feature chunks with the class pruning rule after each chunk.
+//   k_fpnn_terms   a workgroup per (few features, query): val = normalize(x) (:647-655), cos/sin(PI val) and the
+//                  angle-addition recurrence of :706-711 for the J harmonics, then one thread per (feature, class):
+//                  probab = a0 + sum_j (a_cos*cos_j + a_sin*sin_j) in double (:717-721) -> fasterlog2((float)probab).
+//                  The terms are independent, so a ONE-query call is spread over d / F workgroups (116 -> see
+//                  profiles/r02_latency_secondary.txt us per call at 3030 x 256, 101 classes).
+//   k_fpnn_predict one workgroup per query, threads over the classes: outputs[c] += term in float, features in order
+//                  (:722). SEQ form (:736-791): the same in 32-feature chunks with the class pruning rule after each.
 // The model is kept transposed -- at[(f*(2J+1) + k) * C + c] -- so that the classes of a workgroup read consecutive
 // doubles; fir_fpnn_get_model returns the reference's a[(f*C + c)*(2J+1) + k].
 // The translation unit is built with -ffp-contract=off. cos/sin are the device's double-precision functions (<= 2 ulp);
@@ -22,6 +24,7 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -37,7 +40,7 @@ namespace {
 constexpr int kBlock = 256;
 constexpr int kChunk = 32;        // PNNClassifier::delta_features_count, classification.cpp:182
 constexpr int kMaxJ = 64;
-constexpr int kPredBatch = 64;    // queries per launch (bounds the trig scratch)
+constexpr int kPredBatch = 64;    // queries per launch (bounds the term scratch)
 
 thread_local char g_fpnn_err[512];
 int fpnn_fail(int code, const char* fmt, ...) {
@@ -99,27 +102,47 @@ __global__ void __launch_bounds__(kBlock) k_fpnn_train(const double* __restrict_
     if (j == 0) at[((int64_t)f * K) * C + c] = 0.5;           // :678
 }
 
-// trig[(q*d + f)*2J + j] = cos_vals[j], [.. + J + j] = sin_vals[j]
-__global__ void __launch_bounds__(kBlock) k_fpnn_trig(const double* __restrict__ q, int nq, int d, int J, const double* __restrict__ avg,
-                                                      const double* __restrict__ sd, double scale, double* __restrict__ trig) {
-    const int64_t o = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (o >= (int64_t)nq * d) return;
-    const int f = (int)(o % d);
-    const double PI = 3.141592653589793;
-    const double val = fpnn_normalize(q[o], avg[f], sd[f], scale);
-    double* cv = trig + o * 2 * J;
-    double* sv = cv + J;
-    const double c0 = cos(PI * val), s0 = sin(PI * val);
-    double cp = c0, sp = s0;
-    cv[0] = c0;
-    sv[0] = s0;
-    for (int j = 1; j < J; ++j) {                             // :708-711
-        const double cn = cp * c0 - sp * s0;
-        const double sn = cp * s0 + sp * c0;
-        cv[j] = cn;
-        sv[j] = sn;
-        cp = cn;
-        sp = sn;
+// terms[(q*d + f)*C + c] = fasterlog2((float)probab(q, f, c)), classification.cpp:706-721: every (query, feature, class)
+// term is independent of the others, so they are spread over ceil(d / F) x nq workgroups (a one-query call keeps the
+// whole chip busy instead of one CU); only the per-class float sums over the features are ordered, and k_fpnn_predict
+// does those. The first F threads run the angle-addition recurrences (:708-711) of the workgroup's F features into LDS.
+__global__ void __launch_bounds__(kBlock) k_fpnn_terms(const double* __restrict__ q, int d, int C, int J, int F, const double* __restrict__ avg,
+                                                       const double* __restrict__ sd, double scale, const double* __restrict__ at,
+                                                       float* __restrict__ terms) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_t[];
+    double* trig = (double*)smem_t;                           // [F][2J]: cos_vals, sin_vals
+    const int qi = blockIdx.y, f0 = blockIdx.x * F;
+    const int nf = min(F, d - f0);
+    const int K = 2 * J + 1;
+    if ((int)threadIdx.x < nf) {
+        const int f = f0 + threadIdx.x;
+        const double PI = 3.141592653589793;
+        const double val = fpnn_normalize(q[(int64_t)qi * d + f], avg[f], sd[f], scale);
+        double* cv = trig + (size_t)threadIdx.x * 2 * J;
+        double* sv = cv + J;
+        const double c0 = cos(PI * val), s0 = sin(PI * val);
+        double cp = c0, sp = s0;
+        cv[0] = c0;
+        sv[0] = s0;
+        for (int j = 1; j < J; ++j) {                         // :708-711
+            const double cn = cp * c0 - sp * s0;
+            const double sn = cp * s0 + sp * c0;
+            cv[j] = cn;
+            sv[j] = sn;
+            cp = cn;
+            sp = sn;
+        }
+    }
+    __syncthreads();
+    for (int it = threadIdx.x; it < nf * C; it += kBlock) {
+        const int fl = it / C, c = it - fl * C;
+        const double* cv = trig + (size_t)fl * 2 * J;
+        const double* sv = cv + J;
+        const double* __restrict__ m = at + (int64_t)(f0 + fl) * K * C + c;
+        double probab = m[0];
+        for (int j = 0; j < J; ++j)
+            probab += (m[(int64_t)(2 * j + 1) * C] * cv[j] + m[(int64_t)(2 * j + 2) * C] * sv[j]);   // :719 / :763
+        terms[((int64_t)qi * d + f0) * C + it] = fasterlog2((float)probab);
     }
 }
 
@@ -156,11 +179,14 @@ __device__ int block_sum(int v, int* red) {
     return r;
 }
 
-// One workgroup per query. Dynamic LDS: C floats (outputs) + nsub x C floats (terms of nsub features) + C bytes (classes_to_check).
+// One workgroup per query over the terms k_fpnn_terms left. Dynamic LDS: C floats (outputs) + nsub x C floats (terms of nsub
+// features) + C bytes (classes_to_check).
 template <bool SEQ>
-__global__ void __launch_bounds__(kBlock) k_fpnn_predict(const double* __restrict__ at, int d, int C, int J, const double* __restrict__ trig,
-                                                         float output_ratio, int nsub, int32_t* __restrict__ best_class,
-                                                         float* __restrict__ outputs_out, int32_t* __restrict__ chunks_out) {
+__global__ void __launch_bounds__(kBlock) k_fpnn_predict(int d, int C, const float* __restrict__ terms, float output_ratio, int nsub, int32_t* __restrict__ best_class,
+                                                         float* __restrict__ outputs_out, int32_t* __restrict__ chunks_out,
+                                                         unsigned long long* ticket_word, unsigned long long ticket) {
+    // ticket_word (one-query calls only: a single workgroup): once every thread's results are visible to the host, thread 0
+    // publishes the call's ticket there and the host spins on that word instead of synchronising the stream.
     extern __shared__ unsigned char smem[];
     float* outputs = (float*)smem;
     float* lg = outputs + C;                                  // nsub x C fast-log terms
@@ -168,7 +194,6 @@ __global__ void __launch_bounds__(kBlock) k_fpnn_predict(const double* __restric
     __shared__ BestF redb[kBlock / 64];
     __shared__ int redi[kBlock / 64];
     const int q = blockIdx.x;
-    const int K = 2 * J + 1;
     const float output_delta = fasterlog2(output_ratio);     // the constructor's fastlog(output_ratio), :621
     for (int c = threadIdx.x; c < C; c += kBlock) { outputs[c] = 0.0f; alive[c] = 1; }
     __syncthreads();
@@ -176,23 +201,12 @@ __global__ void __launch_bounds__(kBlock) k_fpnn_predict(const double* __restric
     for (int cur = 0; cur < d; cur += SEQ ? kChunk : d) {
         const int max_fi = SEQ ? min(cur + kChunk, d) : d;
         ++chunks;
-        // The (feature, class) terms are independent; only their float sum per class is ordered. `nsub` features at a
-        // time: every thread computes terms (consecutive threads = consecutive classes: coalesced model reads, many loads
-        // in flight), then one thread per class adds that class's terms in feature order.
+        // `nsub` features at a time: the whole workgroup stages their terms in LDS (independent, coalesced loads), then one
+        // thread per class adds that class's terms in feature order; a class no longer checked keeps its sum (:758).
         for (int f0 = cur; f0 < max_fi; f0 += nsub) {
             const int nf = min(nsub, max_fi - f0);
-            for (int it = threadIdx.x; it < nf * C; it += kBlock) {
-                const int fl = it / C, c = it - fl * C;
-                if (!alive[c]) continue;                      // :758 (never false in the exhaustive form)
-                const int f = f0 + fl;
-                const double* __restrict__ cv = trig + ((int64_t)q * d + f) * 2 * J;
-                const double* __restrict__ sv = cv + J;
-                const double* __restrict__ m = at + (int64_t)f * K * C + c;
-                double probab = m[0];
-                for (int j = 0; j < J; ++j)
-                    probab += (m[(int64_t)(2 * j + 1) * C] * cv[j] + m[(int64_t)(2 * j + 2) * C] * sv[j]);   // :719 / :763
-                lg[it] = fasterlog2((float)probab);
-            }
+            const float* __restrict__ src = terms + ((int64_t)q * d + f0) * C;
+            for (int it = threadIdx.x; it < nf * C; it += kBlock) lg[it] = src[it];
             __syncthreads();
             for (int c = threadIdx.x; c < C; c += kBlock) {
                 if (!alive[c]) continue;
@@ -225,6 +239,11 @@ __global__ void __launch_bounds__(kBlock) k_fpnn_predict(const double* __restric
     }
     if (outputs_out)
         for (int c = threadIdx.x; c < C; c += kBlock) outputs_out[(int64_t)q * C + c] = outputs[c];
+    if (ticket_word) {
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(ticket_word, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // at[(f*K + k)*C + c] -> a[(f*C + c)*K + k]
@@ -251,8 +270,9 @@ struct fir_fpnn {
     int d = 0, C = 0, J = 0;
     double scale = 1.0;
     hipStream_t stream = nullptr;
-    Buf at, avg, sd, trig;
-    void* pin = nullptr;        // pinned staging: queries in, outputs / classes / chunk counts out
+    Buf at, avg, sd, terms;
+    void* pin = nullptr;        // pinned staging: queries in, outputs / classes / chunk counts out, then the ticket word
+    unsigned long long ticket = 0;    // one-query calls so far
 };
 
 namespace {
@@ -269,21 +289,35 @@ int predict_common(fir_fpnn* h, const double* queries, int32_t qb, bool seq, flo
     float* pouts = (float*)(pq + (size_t)kPredBatch * h->d);
     int32_t* pbest = (int32_t*)(pouts + (size_t)kPredBatch * h->C);
     int32_t* pchunks = pbest + kPredBatch;
+    unsigned long long* pticket = (unsigned long long*)(((uintptr_t)(pchunks + kPredBatch) + 63) & ~(uintptr_t)63);
     for (int q0 = 0; q0 < qb; q0 += kPredBatch) {
         const int nq = std::min(kPredBatch, qb - q0);
+        const bool one = qb == 1;
+        const unsigned long long ticket = one ? ++h->ticket : 0;
         std::memcpy(pq, queries + (size_t)q0 * h->d, (size_t)nq * h->d * 8);
-        const int64_t nt = (int64_t)nq * h->d;
-        hipLaunchKernelGGL(k_fpnn_trig, dim3((unsigned)((nt + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, pq, nq, h->d, h->J,
-                           h->avg.as<double>(), h->sd.as<double>(), h->scale, h->trig.as<double>());
+        const int F = std::min(16, std::max(1, kBlock / h->C));   // features per workgroup of the term pass: about one term per thread
+        hipLaunchKernelGGL(k_fpnn_terms, dim3((unsigned)((h->d + F - 1) / F), (unsigned)nq), dim3(kBlock), (size_t)F * 2 * h->J * 8, h->stream, pq,
+                           h->d, h->C, h->J, F, h->avg.as<double>(), h->sd.as<double>(), h->scale, h->at.as<double>(), h->terms.as<float>());
         FPNN_HIP(hipGetLastError());
         if (seq)
-            hipLaunchKernelGGL(k_fpnn_predict<true>, dim3(nq), dim3(kBlock), lds, h->stream, h->at.as<double>(), h->d, h->C, h->J,
-                               h->trig.as<double>(), output_ratio, nsub, pbest, outputs ? pouts : nullptr, pchunks);
+            hipLaunchKernelGGL(k_fpnn_predict<true>, dim3(nq), dim3(kBlock), lds, h->stream, h->d, h->C, h->terms.as<float>(), output_ratio, nsub, pbest, outputs ? pouts : nullptr, pchunks, one ? pticket : nullptr, ticket);
         else
-            hipLaunchKernelGGL(k_fpnn_predict<false>, dim3(nq), dim3(kBlock), lds, h->stream, h->at.as<double>(), h->d, h->C, h->J,
-                               h->trig.as<double>(), output_ratio, nsub, pbest, outputs ? pouts : nullptr, pchunks);
+            hipLaunchKernelGGL(k_fpnn_predict<false>, dim3(nq), dim3(kBlock), lds, h->stream, h->d, h->C, h->terms.as<float>(), output_ratio, nsub, pbest, outputs ? pouts : nullptr, pchunks, one ? pticket : nullptr, ticket);
         FPNN_HIP(hipGetLastError());
-        FPNN_HIP(hipStreamSynchronize(h->stream));
+        if (one) {
+            // tens of microseconds: spin on the pinned ticket (2 ms at most), then fall back to the stream
+            volatile unsigned long long* flag = pticket;
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int spins = 0; __atomic_load_n(flag, __ATOMIC_ACQUIRE) != ticket; ++spins) {
+                if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {
+                    FPNN_HIP(hipStreamSynchronize(h->stream));
+                    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != ticket) return fpnn_fail(FIR_ERR_HIP, "the result ticket was not published");
+                    break;
+                }
+            }
+        } else {
+            FPNN_HIP(hipStreamSynchronize(h->stream));
+        }
         std::memcpy(best_class + q0, pbest, (size_t)nq * 4);
         if (outputs) std::memcpy(outputs + (size_t)q0 * h->C, pouts, (size_t)nq * h->C * 4);
         if (chunks_out) std::memcpy(chunks_out + q0, pchunks, (size_t)nq * 4);
@@ -332,8 +366,9 @@ int fir_fpnn_train(const double* train_rows, int64_t nt, int32_t d, const int32_
     FPNN_HIP(h->at.alloc((size_t)d * K * num_classes * 8));
     FPNN_HIP(h->avg.alloc((size_t)d * 8));
     FPNN_HIP(h->sd.alloc((size_t)d * 8));
-    FPNN_HIP(h->trig.alloc((size_t)kPredBatch * d * 2 * J * 8));
-    FPNN_HIP(hipHostMalloc(&h->pin, (size_t)kPredBatch * ((size_t)d * 8 + (size_t)num_classes * 4 + 8), hipHostMallocDefault));
+    FPNN_HIP(h->terms.alloc((size_t)kPredBatch * d * num_classes * 4));
+    FPNN_HIP(hipHostMalloc(&h->pin, (size_t)kPredBatch * ((size_t)d * 8 + (size_t)num_classes * 4 + 8) + 128, hipHostMallocDefault));
+    std::memset((char*)h->pin + (size_t)kPredBatch * ((size_t)d * 8 + (size_t)num_classes * 4 + 8), 0, 128);
     Buf drows, doff;
     FPNN_HIP(drows.alloc((size_t)nt * d * 8));
     FPNN_HIP(doff.alloc(off.size() * 4));

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Median latency of one-query calls of the float64 classifier entry points (kNN, PNN, sequential PNN) at the reference's
-scale (~3 000 training rows x 256 features after PCA)."""
+"""Median latency of one-query calls of the secondary entry points -- the float64 classifiers (kNN, PNN, sequential PNN),
+FPNN, the DEM likelihood update and the candidate-row distances of the DEM walk -- at the reference's scale (~3 000
+training rows x 256 features after PCA)."""
 import gc
 import os
 import sys
@@ -38,7 +39,8 @@ g = fir.Gallery(rows32, (np.arange(3030) % 101).astype(np.int32), 0, 0)
 dem = fir.Dem(g, 0, 45)
 q32 = rng.random((1, 256), dtype=np.float32)
 more = {"fpnn predict": lambda: f.predict(q), "fpnn predict_seq": lambda: f.predict_seq(q, 0.9), "dem likelihoods": lambda: dem.likelihoods(q32),
-        "rows_distances(64)": lambda: g.rows_distances(q32, np.arange(64, dtype=np.int32))}
+        "rows_distances(64)": lambda: g.rows_distances(q32, np.arange(64, dtype=np.int32)),
+        "rows_distances(900)": lambda: g.rows_distances(q32, np.arange(900, dtype=np.int32) * 3)}
 for name, fn in more.items():
     for _ in range(100):
         fn()
