@@ -265,6 +265,7 @@ __global__ void __launch_bounds__(64) k_cls_knn_kth(const double* __restrict__ s
 // (C) one wave does the first-maximum / threshold / count bookkeeping in parallel (first maximum = larger value, then
 // lower class).
 constexpr int kSeqBlock = 1024;
+constexpr int64_t kSeqParRows = 65536;   // up to here the sequential PNN runs as k_cls_pnn_seq_par (below)
 __global__ void __launch_bounds__(kSeqBlock) k_cls_pnn_seq(const double* __restrict__ cs, int nq, int nchunks, double* __restrict__ dist,
                                                             double* __restrict__ ev, const int32_t* __restrict__ class_off, int64_t nt,
                                                             int num_classes, int d, double var, double den, int32_t* __restrict__ best_class,
@@ -350,105 +351,80 @@ __global__ void __launch_bounds__(kSeqBlock) k_cls_pnn_seq(const double* __restr
     }
 }
 
-// The same classifier for training sets of up to kSeqRows * 1024 rows (the reference's scale): a thread keeps the running
-// sums of its (at most kSeqRows) rows in registers and their class from one binary search, the exp() values live in LDS,
-// and the NEXT chunk's sums are in flight while this chunk is worked on -- no global round trip inside a chunk
-// (81 -> see profiles/r02_latency_secondary.txt us per query at 3 030 x 256). Same operations, same summation order.
-// Dynamic LDS: num_classes doubles (outputs) + nt doubles (exp values) + num_classes ints + num_classes + 1 ints.
-constexpr int kSeqRows = 4;
-__global__ void __launch_bounds__(kSeqBlock) k_cls_pnn_seq_small(const double* __restrict__ cs, int nq, int nchunks,
-                                                                  const int32_t* __restrict__ class_off, int nt, int num_classes, int d, double var,
-                                                                  double den, int32_t* __restrict__ best_class, int32_t* __restrict__ chunks_out,
-                                                                  unsigned long long* ticket_word, unsigned long long ticket) {
-    extern __shared__ __attribute__((aligned(16))) double outputs[];
-    double* ev = outputs + num_classes;
-    int* checked = (int*)(ev + nt);
-    int* off = checked + num_classes;
-    __shared__ int best_s, stop_s;
-    const int q = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nwaves = kSeqBlock / 64;
-    for (int c = threadIdx.x; c < num_classes; c += kSeqBlock) { checked[c] = 1; outputs[c] = 0.0; }
-    for (int c = threadIdx.x; c <= num_classes; c += kSeqBlock) off[c] = class_off[c];
-    if (threadIdx.x == 0) { best_s = -1; stop_s = 0; }
-    double run[kSeqRows], nxt[kSeqRows];
-    int cls[kSeqRows];
+// The sequential PNN with its heavy part made parallel. Which classes are still checked only decides which outputs are LOOKED
+// AT (:251, :272-286); a checked class's output after chunk ch -- the sum over its rows of exp(-(running sum)/(2 var max_fi))
+// -- does not depend on what happened to the other classes. So one wave per (class, chunk, query) computes that output
+// outright (lane l: rows l, l + 64, ... of the class, each row's running sum rebuilt from the chunk sums in chunk order;
+// then the wave tree -- the summation order of k_cls_pnn_seq), 808 independent waves at 101 classes x 8 chunks instead of
+// one workgroup walking the chunks, and one wave then runs the reference's bookkeeping over the chunks (first maximum,
+// threshold, drop, count, stop) on the finished table.
+// k_cls_pnn_seq_par: grid (num_classes, nchunks, nq) x 64 threads. k_cls_pnn_seq_walk: one wave per query, after it on the
+// stream (a device-wide fence + arrival counter inside one kernel cost more than the second launch: 808 L2 write-backs).
+// Dynamic LDS of the walk: num_classes ints (+ nchunks x num_classes doubles: table_in_lds).
+__global__ void __launch_bounds__(64) k_cls_pnn_seq_par(const double* __restrict__ cs, int nq, int nchunks, const int32_t* __restrict__ class_off,
+                                                         int64_t nt, int num_classes, int d, double var, double den, double* __restrict__ table) {
+    const int c = blockIdx.x, ch = blockIdx.y, q = blockIdx.z, lane = threadIdx.x;
+    int max_fi = (ch + 1) * 32;                                                         // delta_features_count = 32 (:182,247-249)
+    if (max_fi > d) max_fi = d;
+    double acc = 0.0;
+    const int t0 = class_off[c], t1 = class_off[c + 1];
+    for (int t = t0 + lane; t < t1; t += 64) {
+        double v = 0.0;                                                                 // distances[i][t] = 0 (:238-241)
+        for (int k0 = 0; k0 <= ch; k0 += 8) {                                           // eight chunk sums in flight, added in chunk order
+            double part[8];
 #pragma unroll
-    for (int r = 0; r < kSeqRows; ++r) {
-        const int t = threadIdx.x + r * kSeqBlock;
-        run[r] = 0.0;                                                                   // distances[i][t] = 0 (:238-241)
-        nxt[r] = t < nt ? cs[(size_t)q * nt + t] : 0.0;                                 // chunk 0
-    }
-    __syncthreads();
+            for (int k = 0; k < 8; ++k) part[k] = k0 + k <= ch ? cs[((size_t)(k0 + k) * nq + q) * nt + t] : 0.0;
 #pragma unroll
-    for (int r = 0; r < kSeqRows; ++r) {
-        const int t = threadIdx.x + r * kSeqBlock;
-        int lo = 0, hi = num_classes;                                                   // class of row t: off[lo] <= t < off[lo + 1]
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (off[mid] <= t) lo = mid; else hi = mid;
+            for (int k = 0; k < 8; ++k)
+                if (k0 + k <= ch) v = v + part[k];                                      // += the chunk's sum (:264)
         }
-        cls[r] = lo;
+        acc += exp(-v / (2 * var * max_fi));                                            // :266
     }
-    int used = 0;
-    for (int ch = 0; ch < nchunks; ++ch) {
+    acc = wave_sum(acc);
+    if (lane == 0) table[((size_t)q * nchunks + ch) * num_classes + c] = acc / den;     // :268
+}
+
+__global__ void __launch_bounds__(64) k_cls_pnn_seq_walk(const double* __restrict__ table, int nchunks, int num_classes,
+                                                          int32_t* __restrict__ best_class, int32_t* __restrict__ chunks_out, int table_in_lds,
+                                                          unsigned long long* ticket_word, unsigned long long ticket) {
+    extern __shared__ __attribute__((aligned(16))) int checked_l[];
+    const int q = blockIdx.x, lane = threadIdx.x;
+    // the last wave of query q: every output is in `table`; it is copied to LDS in one go when it fits (table_in_lds), so
+    // that the walk over the chunks below pays no global round trip per chunk
+    for (int i = lane; i < num_classes; i += 64) checked_l[i] = 1;
+    int best_s = -1, used = 0;
+    const double* tq = table + (size_t)q * nchunks * num_classes;
+    if (table_in_lds) {
+        double* tl = (double*)(checked_l + ((num_classes + 1) & ~1));
+        for (int i = lane; i < nchunks * num_classes; i += 64) tl[i] = tq[i];
+        tq = tl;
+    }
+    for (int chn = 0; chn < nchunks; ++chn) {
         ++used;
-        int max_fi = (ch + 1) * 32;                                                     // delta_features_count = 32 (:182,247-249)
-        if (max_fi > d) max_fi = d;
-        double cur[kSeqRows];
+        const double* o = tq + (size_t)chn * num_classes;
+        double mx = -DBL_MAX;
+        int bi = 0x7FFFFFFF;
+        for (int i = lane; i < num_classes; i += 64)
+            if (checked_l[i] && mx < o[i]) { mx = o[i]; bi = i; }                       // :272-279, this lane's first maximum
 #pragma unroll
-        for (int r = 0; r < kSeqRows; ++r) {
-            const int t = threadIdx.x + r * kSeqBlock;
-            cur[r] = nxt[r];
-            if (ch + 1 < nchunks && t < nt) nxt[r] = cs[((size_t)(ch + 1) * nq + q) * nt + t];
+        for (int s = 32; s >= 1; s >>= 1) {
+            const double om = __shfl_xor(mx, s, 64);
+            const int oi = __shfl_xor(bi, s, 64);
+            if (om > mx || (om == mx && oi < bi)) { mx = om; bi = oi; }
         }
-        // (A) rows in parallel
-#pragma unroll
-        for (int r = 0; r < kSeqRows; ++r) {
-            const int t = threadIdx.x + r * kSeqBlock;
-            if (t < nt && checked[cls[r]]) {                                            // :251 (a dropped class never comes back)
-                const double v = run[r] + cur[r];                                       // distances[i][t] += diff*diff ... (:264)
-                run[r] = v;
-                ev[t] = exp(-v / (2 * var * max_fi));                                   // :266
+        if (bi != 0x7FFFFFFF) best_s = bi;                                              // nothing exceeded -DBL_MAX: the previous best stays
+        const float output_threshold = (float)(mx / 1000000000);                        // output_dividor = 1E9 (:186,282)
+        int variants = 0;
+        for (int i = lane; i < num_classes; i += 64)
+            if (checked_l[i]) {
+                if (o[i] < output_threshold) checked_l[i] = 0;                          // :285-286
+                else ++variants;
             }
-        }
-        __syncthreads();
-        // (B) one wave per class, the summation order of k_cls_pnn_seq
-        for (int c = wave; c < num_classes; c += nwaves) {
-            if (!checked[c]) continue;
-            double acc = 0.0;
-            for (int t = off[c] + lane; t < off[c + 1]; t += 64) acc += ev[t];
-            acc = wave_sum(acc);
-            if (lane == 0) outputs[c] = acc / den;                                      // :268
-        }
-        __syncthreads();
-        // (C) bookkeeping, one wave
-        if (wave == 0) {
-            double mx = -DBL_MAX;
-            int bi = 0x7FFFFFFF;
-            for (int i = lane; i < num_classes; i += 64)
-                if (checked[i] && mx < outputs[i]) { mx = outputs[i]; bi = i; }         // :272-279, this lane's first maximum
 #pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) {
-                const double om = __shfl_xor(mx, o, 64);
-                const int oi = __shfl_xor(bi, o, 64);
-                if (om > mx || (om == mx && oi < bi)) { mx = om; bi = oi; }
-            }
-            const int best = bi != 0x7FFFFFFF ? bi : best_s;
-            const float output_threshold = (float)(mx / 1000000000);                    // output_dividor = 1E9 (:186,282)
-            int variants = 0;
-            for (int i = lane; i < num_classes; i += 64)
-                if (checked[i]) {
-                    if (outputs[i] < output_threshold) checked[i] = 0;                  // :285-286
-                    else ++variants;
-                }
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) variants += __shfl_xor(variants, o, 64);
-            if (lane == 0) { best_s = best; stop_s = variants == 1; }                   // :291
-        }
-        __syncthreads();
-        if (stop_s) break;
+        for (int s = 32; s >= 1; s >>= 1) variants += __shfl_xor(variants, s, 64);
+        if (variants == 1) break;                                                       // :291
     }
-    if (threadIdx.x == 0) {
+    if (lane == 0) {
         best_class[q] = best_s;
         chunks_out[q] = used;
         if (ticket_word) {
@@ -851,6 +827,7 @@ int fir_cls_pnn_predict_seq(fir_cls* c, const double* queries, int32_t qb, doubl
     if ((rc = cls_stage_queries(c, queries, qb, &dq))) return rc;
     if ((rc = cls_grow(c->sums, c->sums_cap, (size_t)(nchunks + 2) * kQB * ntp))) return rc;   // chunk sums + running sums + their exp()
     if ((rc = cls_grow(c->best, c->best_cap, (size_t)2 * std::max(qb, kQB)))) return rc;
+    if ((rc = cls_grow(c->scores, c->scores_cap, (size_t)kQB * nchunks * c->num_classes))) return rc;   // k_cls_pnn_seq_par's table
     const bool small = cls_small(c, qb);
     int32_t* dbest = small ? cls_pin_results(c) : c->best;
     int32_t* dchunks = small ? cls_pin_results(c) + kPinResults / 2 : c->best + std::max(qb, kQB);
@@ -871,11 +848,14 @@ int fir_cls_pnn_predict_seq(fir_cls* c, const double* queries, int32_t qb, doubl
             hipLaunchKernelGGL(k_cls_scan<kQB>, dim3(waves / 4), dim3(kBlock), 0, c->stream, c->gal2, c->qn, c->nt, (int)c->tiles, c->dp2, c->d, waves,
                                nq, 0, c->dp2, c->sums, 16, (int64_t)nq * c->nt);
         }
-        const size_t small_lds = (size_t)c->num_classes * 16 + 4 + (size_t)c->nt * 8;
-        if (c->nt <= (int64_t)kSeqRows * kSeqBlock && small_lds <= 60 * 1024)
-            hipLaunchKernelGGL(k_cls_pnn_seq_small, dim3(nq), dim3(kSeqBlock), small_lds, c->stream, c->sums, nq, nchunks, c->class_off, (int)c->nt,
-                               c->num_classes, c->d, var, c->total_training_size > 0 ? c->total_training_size : (double)c->nt, dbest + q0,
-                               dchunks + q0, one ? cls_pin_ticket(c) : (unsigned long long*)nullptr, ticket);
+        const size_t flags_lds = ((size_t)c->num_classes + 1) / 2 * 8, table_lds = (size_t)nchunks * c->num_classes * 8;
+        const int table_in_lds = flags_lds + table_lds <= 48 * 1024;
+        if (c->nt <= kSeqParRows && flags_lds <= 48 * 1024) {
+            hipLaunchKernelGGL(k_cls_pnn_seq_par, dim3(c->num_classes, nchunks, nq), dim3(64), 0, c->stream, c->sums, nq, nchunks, c->class_off, c->nt,
+                               c->num_classes, c->d, var, c->total_training_size > 0 ? c->total_training_size : (double)c->nt, c->scores);
+            hipLaunchKernelGGL(k_cls_pnn_seq_walk, dim3(nq), dim3(64), flags_lds + (table_in_lds ? table_lds : 0), c->stream, c->scores, nchunks,
+                               c->num_classes, dbest + q0, dchunks + q0, table_in_lds, one ? cls_pin_ticket(c) : (unsigned long long*)nullptr, ticket);
+        }
         else
             hipLaunchKernelGGL(k_cls_pnn_seq, dim3(nq), dim3(kSeqBlock), (size_t)c->num_classes * 16 + 4, c->stream, c->sums, nq, nchunks, run,
                                run + (size_t)kQB * ntp, c->class_off, c->nt, c->num_classes, c->d, var,

@@ -200,10 +200,7 @@ __global__ void k_dem_lik_fix(const float* __restrict__ table, int n, int used, 
 // Dynamic LDS: (1 + 4 * cpw) * dp4 float4.
 template <int METRIC>
 __global__ void __launch_bounds__(kBlock) k_rows_dist(const float4* __restrict__ gal4, int dp4, int64_t n, const float* __restrict__ queries, int d,
-                                                      const int32_t* __restrict__ rows, int m, int start, int end, float* __restrict__ out, int cpw,
-                                                      unsigned int* arrivals, unsigned long long* ticket_word, unsigned long long ticket) {
-    // ticket_word (small host-pointer calls: queries, rows and `out` live in pinned host memory): the workgroup that arrives
-    // last publishes the call's ticket after every distance is visible to the host, and re-arms the arrival counter
+                                                      const int32_t* __restrict__ rows, int m, int start, int end, float* __restrict__ out, int cpw) {
     extern __shared__ __attribute__((aligned(16))) float4 rsm[];
     float* qs = (float*)rsm;
     const int q = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -230,18 +227,13 @@ __global__ void __launch_bounds__(kBlock) k_rows_dist(const float4* __restrict__
         }
         out[(size_t)q * m + k0 + lane] = dist;
     }
-    if (ticket_word) {
-        __threadfence_system();
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const unsigned int total = gridDim.x * gridDim.y;
-            if (atomicAdd(arrivals, 1u) == total - 1) {
-                atomicExch(arrivals, 0u);
-                __threadfence_system();
-                __hip_atomic_store(ticket_word, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-        }
-    }
+}
+
+// One thread, queued behind the kernels of a small host-pointer call whose results went to pinned host memory: the call's
+// ticket. (A device-wide fence + arrival counter inside the producing kernel costs more than this launch: every
+// workgroup's fence is an L2 write-back.)
+__global__ void k_dem_ticket(unsigned long long* ticket_word, unsigned long long ticket) {
+    __hip_atomic_store(ticket_word, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Last kernel of a small fir_dem_likelihoods call: the pivot distances go to pinned host memory, then the ticket.
@@ -532,24 +524,21 @@ int fir_rows_distances(fir_gallery* g, const float* queries, int32_t qb, const i
     if (lds > 64 * 1024) return dem_fail(FIR_ERR_ARG, "rows of %d features do not fit the candidate kernel's LDS", v.d);
     const int per_block = (kBlock / 64) * cpw;
     const dim3 grid((m + per_block - 1) / per_block, qb);
-#define FIR_ROWS_LAUNCH(M, Q, R, O, A, T, TK)                                                                                             \
-    hipLaunchKernelGGL(k_rows_dist<M>, grid, dim3(kBlock), lds, v.stream, (const float4*)gal4, dp4, v.n, Q, v.d, R, m, start_pos, end_pos, O, cpw, A, \
-                       T, TK)
-#define FIR_ROWS_BY_METRIC(Q, R, O, A, T, TK)                                                                                             \
+#define FIR_ROWS_LAUNCH(M, Q, R, O)                                                                                                       \
+    hipLaunchKernelGGL(k_rows_dist<M>, grid, dim3(kBlock), lds, v.stream, (const float4*)gal4, dp4, v.n, Q, v.d, R, m, start_pos, end_pos, O, cpw)
+#define FIR_ROWS_BY_METRIC(Q, R, O)                                                                                                       \
     do {                                                                                                                                  \
-        if (metric == FIR_METRIC_L2) FIR_ROWS_LAUNCH(fir::kL2, Q, R, O, A, T, TK);                                                        \
-        else if (metric == FIR_METRIC_CHI2) FIR_ROWS_LAUNCH(fir::kChi2, Q, R, O, A, T, TK);                                               \
-        else FIR_ROWS_LAUNCH(fir::kKL, Q, R, O, A, T, TK);                                                                                \
+        if (metric == FIR_METRIC_L2) FIR_ROWS_LAUNCH(fir::kL2, Q, R, O);                                                                  \
+        else if (metric == FIR_METRIC_CHI2) FIR_ROWS_LAUNCH(fir::kChi2, Q, R, O);                                                         \
+        else FIR_ROWS_LAUNCH(fir::kKL, Q, R, O);                                                                                          \
     } while (0)
     const size_t qbytes = ((size_t)qb * v.d * 4 + 15) & ~(size_t)15, rbytes = (size_t)qb * m * 4;
     // Small calls (the DEM walk: one query, a few hundred candidate rows): everything through the handle's pinned,
-    // device-visible buffer -- no allocation, no copy engine, no stream synchronisation (the last workgroup's ticket).
+    // device-visible buffer -- no allocation, no copy engine, no stream synchronisation (a ticket written behind the kernel).
     void* pin_base = nullptr;
     size_t pin_cap = 0;
     uint64_t* pin_res = nullptr;
-    void* p_arr = nullptr;
-    if ((size_t)qb * m <= 8000 && fir_gallery_pin_(g, &pin_base, &pin_cap, &pin_res) == FIR_OK && qbytes + rbytes <= pin_cap &&
-        fir_gallery_scratch_(g, 11, 16, &p_arr) == FIR_OK) {
+    if ((size_t)qb * m <= 8000 && fir_gallery_pin_(g, &pin_base, &pin_cap, &pin_res) == FIR_OK && qbytes + rbytes <= pin_cap) {
         float* hq = (float*)pin_base;
         int32_t* hr = (int32_t*)((char*)pin_base + qbytes);
         float* ho = (float*)pin_res;
@@ -557,15 +546,14 @@ int fir_rows_distances(fir_gallery* g, const float* queries, int32_t qb, const i
         std::memcpy(hq, queries, (size_t)qb * v.d * 4);
         std::memcpy(hr, rows, rbytes);
         const unsigned long long ticket = fir_gallery_next_ticket_(g);
-        FIR_ROWS_BY_METRIC(hq, hr, ho, (unsigned int*)p_arr, tword, ticket);
+        FIR_ROWS_BY_METRIC(hq, hr, ho);
+        hipLaunchKernelGGL(k_dem_ticket, dim3(1), dim3(1), 0, v.stream, tword, ticket);
         const hipError_t le = hipGetLastError();
         if (le == hipSuccess && fir_gallery_wait_ticket_(g, (volatile uint64_t*)tword, ticket) == FIR_OK) {
             std::memcpy(out, ho, rbytes);
             return FIR_OK;
         }
-        // the launch failed or never published: re-arm the arrival counter and take the general path below
-        (void)hipStreamSynchronize(v.stream);
-        (void)hipMemset(p_arr, 0, 16);
+        (void)hipStreamSynchronize(v.stream);   // the launch failed or never published: the general path below reports why
     }
     void *dq = nullptr, *drows = nullptr, *dout = nullptr;
     if ((rc = fir_gallery_scratch_(g, 8, (size_t)qb * v.d * 4, &dq))) return rc;
@@ -573,7 +561,7 @@ int fir_rows_distances(fir_gallery* g, const float* queries, int32_t qb, const i
     if ((rc = fir_gallery_scratch_(g, 10, rbytes, &dout))) return rc;
     DEM_HIP(hipMemcpyAsync(dq, queries, (size_t)qb * v.d * 4, hipMemcpyHostToDevice, v.stream));
     DEM_HIP(hipMemcpyAsync(drows, rows, rbytes, hipMemcpyHostToDevice, v.stream));
-    FIR_ROWS_BY_METRIC((const float*)dq, (const int32_t*)drows, (float*)dout, (unsigned int*)nullptr, (unsigned long long*)nullptr, 0ull);
+    FIR_ROWS_BY_METRIC((const float*)dq, (const int32_t*)drows, (float*)dout);
 #undef FIR_ROWS_BY_METRIC
 #undef FIR_ROWS_LAUNCH
     DEM_HIP(hipGetLastError());
