@@ -1073,7 +1073,10 @@ int wait_ticket(fir_gallery* g, volatile uint64_t* flag, uint64_t ticket) {
 // 3 030 x 1536: 34 instead of 40 us per call (profiles/r01_sweep_notes.md). Returns 1 when the shape does not qualify.
 int top1_one_query(fir_gallery* g, const float* pinned_query, int32_t start, int32_t end, uint64_t* pinned_key) {
     static const bool off = std::getenv("FIR_NO_ONE_QUERY") != nullptr;      // experiments
-    if (off || g->metric != kL2 || g->n <= 0 || g->tiles > (int64_t)g->cus * 4 || g->tiles_limit > 0 || g->profiling) return 1;
+    // up to 256 tiles (16 384 rows): every workgroup of this form ends on a device-wide fence before it is counted, and beyond
+    // ~90 workgroups those fences cost more than the two extra launches of the general path (12 000 x 512: 25.5 against
+    // 28.1 us; 24 000: 32.8 / 32.2; 50 000: 44.4 / 35.4)
+    if (off || g->metric != kL2 || g->n <= 0 || g->tiles > 256 || g->tiles_limit > 0 || g->profiling) return 1;
     size_t lds_bytes = 0;
     scan_fn fn = pick_deep(kEpiTop1, 1, g->metric, g->dp4, &lds_bytes);
     if (!fn) return 1;
