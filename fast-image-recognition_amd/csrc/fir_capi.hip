@@ -594,9 +594,11 @@ scan_fn pick_subranges(int qb, int metric) {
     return nullptr;
 }
 
-int subranges_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start, int32_t end, int32_t step, float* d_out, hipStream_t st) {
-    const int nsub = (end - start) / step;
-    if (step % (4 * kUSub) != 0 || start % 4 != 0) {   // one pass per sub-range (any step)
+int subranges_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start, int32_t end, int32_t step, float* d_out, hipStream_t st,
+                  int32_t step2 = 0) {
+    // step2 != 0: two sub-ranges, [start, start + step) and [start + step, end) with end - start - step == step2 (whole load groups both)
+    const int nsub = step2 ? 2 : (end - start) / step;
+    if (!step2 && (step % (4 * kUSub) != 0 || start % 4 != 0)) {   // one pass per sub-range (any step)
         for (int ci = 0; ci < nsub; ++ci) {
             const int rc = range_dev(g, d_queries, qb, start + ci * step, start + (ci + 1) * step, d_out + (size_t)ci * qb * g->n, st);
             if (rc) return rc;
@@ -623,6 +625,7 @@ int subranges_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t st
         a.start = start;
         a.end = end;
         a.step = step;
+        a.step2 = step2;
         a.waves = pick_waves(g->tiles, max_waves, g->cus * 4);
         a.row_offset = g->row_offset;
         a.out = d_out + (size_t)q0 * g->n;
@@ -777,6 +780,18 @@ int fir_subrange_distances_dev_(fir_gallery* g, const float* d_queries, int32_t 
     if (g->n == 0) return FIR_OK;
     FIR_HIP(hipSetDevice(g->device));
     return subranges_dev(g, d_queries, qb, start, end, step, d_out, stream ? (hipStream_t)stream : g->stream);
+}
+int fir_split_distances_dev_(fir_gallery* g, const float* d_queries, int32_t qb, int32_t split, int32_t end, float* d_out, void* stream) {
+    if (!g || !d_queries || !d_out) return fail(FIR_ERR_ARG, "NULL argument");
+    if (qb <= 0) return fail(FIR_ERR_ARG, "qb=%d must be positive", qb);
+    if (split <= 0 || split >= end || end > g->d) return fail(FIR_ERR_ARG, "split %d / end %d outside (0,%d]", split, end, g->d);
+    if (g->n == 0) return FIR_OK;
+    FIR_HIP(hipSetDevice(g->device));
+    hipStream_t st = stream ? (hipStream_t)stream : g->stream;
+    if (split % (4 * kUSub) == 0 && (end - split) % (4 * kUSub) == 0) return subranges_dev(g, d_queries, qb, 0, end, split, d_out, st, end - split);
+    const int rc = range_dev(g, d_queries, qb, 0, split, d_out, st);
+    if (rc) return rc;
+    return range_dev(g, d_queries, qb, split, end, d_out + (size_t)qb * g->n, st);
 }
 int fir_gallery_tiled_(fir_gallery* g, const void** gal4, int* dp4) {
     if (!g || !gal4 || !dp4) return FIR_ERR_ARG;

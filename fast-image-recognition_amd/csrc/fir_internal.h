@@ -30,6 +30,10 @@ extern "C" int fir_gallery_scratch_(fir_gallery* g, int slot, size_t bytes, void
 extern "C" int fir_subrange_distances_dev_(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start, int32_t end, int32_t step,
                                            float* d_out, void* stream);
 
+// d_out[q * n + row] = distance over [0, split), d_out[(qb + q) * n + row] = distance over [split, end): ONE gallery pass when
+// both widths are multiples of 32 features (the two stages of the conventional TWD: 64 and 192), two otherwise.
+extern "C" int fir_split_distances_dev_(fir_gallery* g, const float* d_queries, int32_t qb, int32_t split, int32_t end, float* d_out, void* stream);
+
 // First touch of a device by this library. The HIP runtime's start-up draws from libc's rand(); the reference's harnesses
 // lean on that stream (std::random_shuffle in getTrainingAndTestImages and DirectedEnumeration::init, srand(13) in
 // testRecognitionMethod), so the start-up runs on a private random state and the caller's is handed back untouched.

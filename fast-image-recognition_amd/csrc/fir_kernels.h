@@ -80,6 +80,7 @@ struct ScanArgs {
     int64_t qt_stride;    // floats between the query tiles of consecutive blockIdx.y (top-1 kernels)
     int32_t nt;           // non-temporal gallery loads (galleries that do not fit the L2s)
     int32_t step;         // k_scan_subranges: features per sub-range
+    int32_t step2;        // ... != 0: the first sub-range has `step` features, every later one `step2` (the two stages of the conventional TWD)
     const float* tau;     // append form of the L2 scan: rows with distance <= tau[query] are appended ...
     int32_t* counts;      // ... counts[query] entries so far, lists = keys[query * k + slot] (k = capacity per query)
     uint64_t* publish;    // top-1, whole call = ONE launch: the last workgroup to finish writes keys[0..QB) to publish[0..QB) (pinned
@@ -364,13 +365,14 @@ __global__ void __launch_bounds__(kBlock, WPS) k_scan_subranges(const ScanArgs a
     const int lane = threadIdx.x & 63;
     const int gw = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     sfloat_p qc = (sfloat_p)(uintptr_t)a.qt;
-    const float fcount = (float)a.step;                               // db_features.cpp:40
-    const int cstep = a.step >> 2;
     for (int t = gw; t < a.tiles; t += a.waves) {
         const float4* tile = a.gal4 + (size_t)t * a.dp4 * 64 + lane;
         const int64_t row = (int64_t)t * kTileRows + lane;
-        int ci = 0;
+        int ci = 0, cstep = a.step >> 2;
         for (int c0 = a.start >> 2; c0 < (a.end >> 2); c0 += cstep, ++ci) {
+            const int feats = ci > 0 && a.step2 ? a.step2 : a.step;
+            cstep = feats >> 2;
+            const float fcount = (float)feats;                        // db_features.cpp:40
             float acc[QB];
 #pragma unroll
             for (int q = 0; q < QB; ++q) acc[q] = 0.0f;

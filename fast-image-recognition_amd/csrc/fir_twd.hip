@@ -88,6 +88,10 @@ __device__ DI block_argmin(DI v, DI* red /* [kBlock/64] in LDS */) {
 //               secondBestDist it set
 //   kS1Final    one workgroup per query: best row = fold of all segments, secondBestDist = the LAST segment's change,
 //               top-5 posteriors, the reliability test, the outputs
+// The second stage (:165-180) needs no launches of its own: both partial distances come from ONE gallery pass
+// (fir_split_distances_dev_), kS1Part also leaves each segment's second-stage minimum behind, and the deciding workgroup
+// (kS1Single / kS1Final) takes it when the reliability test fails -- and, on a one-query call, writes the verdict and the
+// ticket to pinned host memory itself. 100 000 x 512, one query: 13 launches / 99 us -> 6 / 81 us; 3 030 x 1536: 51 -> 45 us.
 enum { kS1Single = 0, kS1Part = 1, kS1Records = 2, kS1Final = 3 };
 struct S1Chg {
     int row;
@@ -100,7 +104,14 @@ template <int MODE>
 __global__ void __launch_bounds__(kBlock) k_twd_conv_stage1(const float* __restrict__ dist1, const int32_t* __restrict__ cls, int n,
                                                              int num_classes, int type, double threshold, int32_t* __restrict__ class_out,
                                                              int32_t* __restrict__ unreliable_out, DI* __restrict__ part,
-                                                             S1Chg* __restrict__ chg, unsigned long long* __restrict__ gprob, int seg_rows) {
+                                                             S1Chg* __restrict__ chg, unsigned long long* __restrict__ gprob, int seg_rows,
+                                                             const float* __restrict__ dist2, int reduced, DI* __restrict__ part2,
+                                                             int32_t* __restrict__ host_res, int host_stride, uint64_t* __restrict__ host_ticket,
+                                                             uint64_t ticket) {
+    // dist2[q][n]: distances over [reduced, 256), already there -- the second stage (ImageTesting.cpp:165-180) rides along:
+    // kS1Part leaves each segment's second-stage minimum in part2 (for every query: whether it is needed is only known at
+    // the end), kS1Final / kS1Single take it when the reliability test fails.
+    // host_res (one-query calls): class and verdict also go to pinned host memory, then `ticket` to host_ticket.
     extern __shared__ __attribute__((aligned(16))) unsigned long long probabs[];   // bit patterns of non-negative doubles
     __shared__ DI wave_tot[kBlock / 64];
     __shared__ DI red[kBlock / 64];
@@ -130,6 +141,9 @@ __global__ void __launch_bounds__(kBlock) k_twd_conv_stage1(const float* __restr
         carry_s = in;
     }
     __syncthreads();
+    DI m2;                             // second stage: bestDist = 100000 (:168), only strictly smaller rows qualify
+    m2.d = 100000.0;
+    m2.i = -1;
     int last_change_row = -1;          // last record row whose class differs from the previous record's class
     double second_at_change = 0.0;     // what secondBestDist was set to at that row (:124-125)
     if (MODE != kS1Final) {
@@ -138,7 +152,16 @@ __global__ void __launch_bounds__(kBlock) k_twd_conv_stage1(const float* __restr
         // across spans, with one block-wide scan per span (not per 256 rows).
         for (int base = row_begin; base < row_end; base += kSpan) {
             const int live = min(kSpan, row_end - base);
-            for (int i = threadIdx.x; i < live; i += kBlock) { sd[i] = d1[base + i]; sc[i] = cls[base + i]; }
+            for (int i = threadIdx.x; i < live; i += kBlock) {
+                const float dv = d1[base + i];
+                sd[i] = dv;
+                sc[i] = cls[base + i];
+                if (MODE == kS1Part) {                                              // :173-174 for row base + i (rows ascend per thread)
+                    const float tail = dist2[(size_t)q * n + base + i] * (float)(kLastFeature - reduced);
+                    const double v = ((double)dv * reduced + tail) / kLastFeature;
+                    if (v < m2.d) { m2.d = v; m2.i = base + i; }
+                }
+            }
             __syncthreads();
             const int r0 = min(threadIdx.x * kPer, live), r1 = min(r0 + kPer, live);
             // pass 1: the segment's first minimum; class posteriors, one LDS atomic per run of equal labels (galleries
@@ -197,6 +220,8 @@ __global__ void __launch_bounds__(kBlock) k_twd_conv_stage1(const float* __restr
         // this segment's own first minimum (the seed (100000, -1) wins over rows that are not below it, like the reference's
         // initial state does) and its share of the class posteriors
         if (threadIdx.x == 0) part[(size_t)q * nseg + b] = carry_s;
+        const DI w2 = block_argmin(m2, red);
+        if (threadIdx.x == 0) part2[(size_t)q * nseg + b] = w2;
         if (with_prob)
             for (int c = threadIdx.x; c < num_classes; c += kBlock)
                 if (probabs[c]) atomicMax(&gprob[(size_t)q * num_classes + c], probabs[c]);
@@ -251,54 +276,41 @@ __global__ void __launch_bounds__(kBlock) k_twd_conv_stage1(const float* __restr
             reliable = (best.d / secondBest) < threshold;                           // :161
         }
     }
+    int cls_final = best.i >= 0 ? cls[best.i] : -1;
+    if (!reliable) {                                                                // block-uniform
+        // second stage (:165-180): the row with the smallest distance over [0, 256), rebuilt from the two partial distances
+        DI w;
+        if (MODE == kS1Single) {
+            const float* d2 = dist2 + (size_t)q * n;
+            DI m;
+            m.d = 100000.0;
+            m.i = -1;
+            for (int row = threadIdx.x; row < n; row += kBlock) {
+                const float tail = d2[row] * (float)(kLastFeature - reduced);       // float * int -> float (:174)
+                const double v = ((double)d1[row] * reduced + tail) / kLastFeature; // :173-174
+                if (v < m.d) { m.d = v; m.i = row; }
+            }
+            w = block_argmin(m, red);
+        } else {
+            w.d = 100000.0;
+            w.i = -1;
+            for (int k = 0; k < nseg; ++k) {             // segments in row order: an equal value later on does not replace the earlier row
+                const DI p2 = part2[(size_t)q * nseg + k];
+                if (p2.i >= 0 && p2.d < w.d) w = p2;
+            }
+        }
+        cls_final = w.i >= 0 ? cls[w.i] : -1;
+    }
     if (threadIdx.x == 0) {
         unreliable_out[q] = reliable ? 0 : 1;
-        class_out[q] = best.i >= 0 ? cls[best.i] : -1;                              // overwritten by the second stage when unreliable
+        class_out[q] = cls_final;
+        if (host_res) {
+            host_res[q] = cls_final;
+            host_res[host_stride + q] = reliable ? 0 : 1;
+            __threadfence_system();
+            __hip_atomic_store(host_ticket, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
-}
-
-// ---- second stage (ImageTesting.cpp:165-180) for the unreliable queries ----
-// The reliable queries (unreliable[slot] == 0) return at once, so the host does not have to look at the first stage's
-// verdicts before queueing this. dist1 / dist2: [slot][n] over [0, reduced) / [reduced, 256).
-// PARTS = false: one workgroup per query. PARTS = true: gridDim.x workgroups per query (blockIdx.y) leave their segment's
-// best (value, row) in part[q][b]; k_twd_conv_stage2_final folds them.
-template <bool PARTS>
-__global__ void __launch_bounds__(kBlock) k_twd_conv_stage2(const float* __restrict__ dist1, const float* __restrict__ dist2,
-                                                             const int32_t* __restrict__ unreliable, const int32_t* __restrict__ cls, int n,
-                                                             int reduced, int32_t* __restrict__ class_out, DI* __restrict__ part, int seg_rows) {
-    __shared__ DI red[kBlock / 64];
-    const int slot = PARTS ? blockIdx.y : blockIdx.x;
-    if (!unreliable[slot]) return;
-    const float* d1 = dist1 + (size_t)slot * n;
-    const float* d2 = dist2 + (size_t)slot * n;
-    const int row_begin = PARTS ? blockIdx.x * seg_rows : 0;
-    const int row_end = PARTS ? min(n, row_begin + seg_rows) : n;
-    DI m;
-    m.d = 100000.0;      // bestDist = 100000 (:168); only strictly smaller rows qualify
-    m.i = -1;
-    for (int row = row_begin + threadIdx.x; row < row_end; row += kBlock) {
-        const float tail = d2[row] * (float)(kLastFeature - reduced);               // float * int -> float (:174)
-        const double v = ((double)d1[row] * reduced + tail) / kLastFeature;         // :173-174
-        if (v < m.d || (v == m.d && m.i >= 0 && row < m.i)) { m.d = v; m.i = row; }
-    }
-    const DI w = block_argmin(m, red);
-    if (threadIdx.x == 0) {
-        if (PARTS) part[(size_t)slot * gridDim.x + blockIdx.x] = w;
-        else class_out[slot] = w.i >= 0 ? cls[w.i] : -1;
-    }
-}
-__global__ void k_twd_conv_stage2_final(const DI* __restrict__ part, int nseg, const int32_t* __restrict__ unreliable,
-                                        const int32_t* __restrict__ cls, int32_t* __restrict__ class_out) {
-    const int slot = blockIdx.x;
-    if (threadIdx.x != 0 || !unreliable[slot]) return;
-    DI best;
-    best.d = 100000.0;
-    best.i = -1;
-    for (int b = 0; b < nseg; ++b) {                 // segments in row order: an equal value later on does not replace the earlier row
-        const DI p = part[(size_t)slot * nseg + b];
-        if (p.i >= 0 && p.d < best.d) best = p;
-    }
-    class_out[slot] = best.i >= 0 ? cls[best.i] : -1;
 }
 
 // ---- ProposedTWDClassifier (ImageTesting.cpp:207-288, CHECK_ALL_INSTANCES) ----
@@ -307,7 +319,10 @@ __global__ void k_twd_conv_stage2_final(const DI* __restrict__ part, int nseg, c
 __global__ void __launch_bounds__(kBlock) k_twd_proposed(const float* __restrict__ cd, int nq, int nchunks, double* __restrict__ acc,
                                                           uint8_t* __restrict__ alive, const int32_t* __restrict__ cls, int n,
                                                           double threshold /* 1/th */, int32_t* __restrict__ class_out,
-                                                          int32_t* __restrict__ unreliable_out, int32_t* __restrict__ chunks_out) {
+                                                          int32_t* __restrict__ unreliable_out, int32_t* __restrict__ chunks_out,
+                                                          int32_t* __restrict__ host_res, int host_stride, uint64_t* __restrict__ host_ticket,
+                                                          uint64_t ticket) {
+    // host_res (one-query calls): the three outputs also go to pinned host memory, then `ticket` to host_ticket
     __shared__ DI red[kBlock / 64];
     __shared__ int cnt_s;
     const int q = blockIdx.x;
@@ -348,9 +363,17 @@ __global__ void __launch_bounds__(kBlock) k_twd_proposed(const float* __restrict
         if (c == 0) ++unreliable;                                                   // :287-288
     }
     if (threadIdx.x == 0) {
-        class_out[q] = bestInd >= 0 ? cls[bestInd] : -1;
+        const int cl = bestInd >= 0 ? cls[bestInd] : -1;
+        class_out[q] = cl;
         unreliable_out[q] = unreliable;
         chunks_out[q] = used;
+        if (host_res) {
+            host_res[q] = cl;
+            host_res[host_stride + q] = unreliable;
+            host_res[2 * host_stride + q] = used;
+            __threadfence_system();
+            __hip_atomic_store(host_ticket, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -504,8 +527,7 @@ int fir_twd_conventional(fir_gallery* g, const float* queries, int32_t qb, int32
     const int n = (int)v.n;
     const int batch = std::min(batch_for(n, 8), std::max(8, (qb + 7) / 8 * 8));
     TWD_SLOT(dq, 0, (size_t)batch * v.d * 4);
-    TWD_SLOT(d1, 1, (size_t)batch * std::max(n, 1) * 4);
-    TWD_SLOT(d2, 2, (size_t)batch * std::max(n, 1) * 4);
+    TWD_SLOT(d1, 1, (size_t)2 * batch * std::max(n, 1) * 4);    // [0, reduced) distances of the batch, then [reduced, 256)
     TWD_SLOT(dres, 3, (size_t)2 * kBatch * 4);                 // class[kBatch], unreliable[kBatch]
     int32_t* dcls = dres.as<int32_t>();
     int32_t* dunrel = dcls + kBatch;
@@ -533,35 +555,37 @@ int fir_twd_conventional(fir_gallery* g, const float* queries, int32_t qb, int32
             const float* qsrc = dq.as<float>();
             if (pinned) { std::memcpy(pin_base, queries + (size_t)q0 * v.d, (size_t)nq * v.d * 4); qsrc = (const float*)pin_base; }
             else TWD_HIP(hipMemcpyAsync(dq.p, queries + (size_t)q0 * v.d, (size_t)nq * v.d * 4, hipMemcpyHostToDevice, v.stream));
-            if ((rc = fir_range_distances_dev(g, qsrc, nq, 0, reduced_features_count, d1.as<float>(), v.stream))) return rc;
+            // both partial distances from one pass over features [0, 256); every stage is queued back to back
+            if ((rc = fir_split_distances_dev_(g, qsrc, nq, reduced_features_count, kLastFeature, d1.as<float>(), v.stream))) return rc;
+            const float* d2 = d1.as<float>() + (size_t)nq * n;
             const size_t plds = (size_t)num_classes * 8;
+            // a one-query call: the deciding workgroup writes the verdict to pinned host memory and the ticket itself
+            const bool self_publish = pinned && nq == 1;
+            const uint64_t ticket = pinned ? fir_gallery_next_ticket_(g) : 0;
+            int32_t* hres = self_publish ? (int32_t*)pin_res : (int32_t*)nullptr;
+            uint64_t* hticket = self_publish ? pin_res + kBatch : (uint64_t*)nullptr;
             if (nseg_eff == 1) {
                 hipLaunchKernelGGL(k_twd_conv_stage1<kS1Single>, dim3(nq), dim3(kBlock), plds, v.stream, d1.as<float>(), v.cls, n, num_classes, type,
-                                   threshold, dcls, dunrel, (DI*)nullptr, (S1Chg*)nullptr, (unsigned long long*)nullptr, n);
+                                   threshold, dcls, dunrel, (DI*)nullptr, (S1Chg*)nullptr, (unsigned long long*)nullptr, n, d2,
+                                   reduced_features_count, (DI*)nullptr, hres, kBatch, hticket, ticket);
             } else {
                 if (type == 0) TWD_HIP(hipMemsetAsync(gprob, 0, (size_t)nq * num_classes * 8, v.stream));
                 hipLaunchKernelGGL(k_twd_conv_stage1<kS1Part>, dim3(nseg_eff, nq), dim3(kBlock), plds, v.stream, d1.as<float>(), v.cls, n, num_classes,
-                                   type, threshold, dcls, dunrel, part1, chg, gprob, seg_rows);
+                                   type, threshold, dcls, dunrel, part1, chg, gprob, seg_rows, d2, reduced_features_count, part2, (int32_t*)nullptr, 0,
+                                   (uint64_t*)nullptr, (uint64_t)0);
                 hipLaunchKernelGGL(k_twd_conv_stage1<kS1Records>, dim3(nseg_eff, nq), dim3(kBlock), plds, v.stream, d1.as<float>(), v.cls, n,
-                                   num_classes, type, threshold, dcls, dunrel, part1, chg, gprob, seg_rows);
+                                   num_classes, type, threshold, dcls, dunrel, part1, chg, gprob, seg_rows, d2, reduced_features_count, part2,
+                                   (int32_t*)nullptr, 0, (uint64_t*)nullptr, (uint64_t)0);
                 hipLaunchKernelGGL(k_twd_conv_stage1<kS1Final>, dim3(nq), dim3(kBlock), plds, v.stream, d1.as<float>(), v.cls, n, num_classes, type,
-                                   threshold, dcls, dunrel, part1, chg, gprob, seg_rows);
-            }
-            TWD_HIP(hipGetLastError());
-            if ((rc = fir_range_distances_dev(g, qsrc, nq, reduced_features_count, kLastFeature, d2.as<float>(), v.stream))) return rc;
-            if (nseg_eff == 1) {
-                hipLaunchKernelGGL(k_twd_conv_stage2<false>, dim3(nq), dim3(kBlock), 0, v.stream, d1.as<float>(), d2.as<float>(), dunrel, v.cls, n,
-                                   reduced_features_count, dcls, (DI*)nullptr, n);
-            } else {
-                hipLaunchKernelGGL(k_twd_conv_stage2<true>, dim3(nseg_eff, nq), dim3(kBlock), 0, v.stream, d1.as<float>(), d2.as<float>(), dunrel,
-                                   v.cls, n, reduced_features_count, dcls, part2, seg_rows);
-                hipLaunchKernelGGL(k_twd_conv_stage2_final, dim3(nq), dim3(64), 0, v.stream, part2, nseg_eff, dunrel, v.cls, dcls);
+                                   threshold, dcls, dunrel, part1, chg, gprob, seg_rows, d2, reduced_features_count, part2, hres, kBatch, hticket,
+                                   ticket);
             }
             TWD_HIP(hipGetLastError());
             if (pinned) {
-                const uint64_t ticket = fir_gallery_next_ticket_(g);
-                hipLaunchKernelGGL(k_twd_publish, dim3(1), dim3(256), 0, v.stream, dcls, 2 * kBatch, (int32_t*)pin_res, pin_res + kBatch, ticket);
-                TWD_HIP(hipGetLastError());
+                if (!self_publish) {
+                    hipLaunchKernelGGL(k_twd_publish, dim3(1), dim3(256), 0, v.stream, dcls, 2 * kBatch, (int32_t*)pin_res, pin_res + kBatch, ticket);
+                    TWD_HIP(hipGetLastError());
+                }
                 if ((rc = fir_gallery_wait_ticket_(g, pin_res + kBatch, ticket))) return rc;
                 std::memcpy(h_res, pin_res, sizeof(h_res));
             } else {
@@ -625,9 +649,13 @@ int fir_twd_proposed(fir_gallery* g, const float* queries, int32_t qb, int32_t r
             else TWD_HIP(hipMemcpyAsync(dq.p, queries + (size_t)q0 * v.d, (size_t)nq * v.d * 4, hipMemcpyHostToDevice, v.stream));
             // all chunk distances cd[c][slot][n] from ONE pass over features [0, 256)
             if ((rc = fir_subrange_distances_dev_(g, qsrc, nq, 0, kLastFeature, reduced_features_count, cd.as<float>(), v.stream))) return rc;
+            const bool self_publish = pinned && nq == 1 && nseg == 1;    // the deciding workgroup writes verdict and ticket itself
+            const uint64_t ticket = pinned ? fir_gallery_next_ticket_(g) : 0;
             if (nseg == 1) {
                 hipLaunchKernelGGL(k_twd_proposed, dim3(nq), dim3(kBlock), 0, v.stream, cd.as<float>(), nq, nchunks, acc.as<double>(),
-                                   alive.as<uint8_t>(), v.cls, n, 1.0 / threshold, dcls, dunrel, dchunks);
+                                   alive.as<uint8_t>(), v.cls, n, 1.0 / threshold, dcls, dunrel, dchunks,
+                                   self_publish ? (int32_t*)pin_res : (int32_t*)nullptr, kBatch, self_publish ? pin_res + 2 * kBatch : (uint64_t*)nullptr,
+                                   ticket);
             } else {
                 hipLaunchKernelGGL(k_twd_prop_init, dim3((nq + 63) / 64), dim3(64), 0, v.stream, pstate, nq);
                 TWD_HIP(hipMemsetAsync(pcnt, 0, (size_t)nchunks * nq * sizeof(int), v.stream));
@@ -642,9 +670,10 @@ int fir_twd_proposed(fir_gallery* g, const float* queries, int32_t qb, int32_t r
             }
             TWD_HIP(hipGetLastError());
             if (pinned) {
-                const uint64_t ticket = fir_gallery_next_ticket_(g);
-                hipLaunchKernelGGL(k_twd_publish, dim3(1), dim3(256), 0, v.stream, dcls, 3 * kBatch, (int32_t*)pin_res, pin_res + 2 * kBatch, ticket);
-                TWD_HIP(hipGetLastError());
+                if (!self_publish) {
+                    hipLaunchKernelGGL(k_twd_publish, dim3(1), dim3(256), 0, v.stream, dcls, 3 * kBatch, (int32_t*)pin_res, pin_res + 2 * kBatch, ticket);
+                    TWD_HIP(hipGetLastError());
+                }
                 if ((rc = fir_gallery_wait_ticket_(g, pin_res + 2 * kBatch, ticket))) return rc;
                 std::memcpy(h_res, pin_res, sizeof(h_res));
             } else {
