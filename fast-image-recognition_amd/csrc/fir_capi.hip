@@ -437,15 +437,23 @@ int top1_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start, 
 int topk_lists_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start, int32_t end, int32_t k, uint64_t* d_keys,
                    hipStream_t st);
 
+int try_mfma_topk(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start, int32_t end, int32_t k, uint64_t* d_keys, hipStream_t st);
+
 int topk_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start, int32_t end, int32_t k, uint64_t* d_keys,
-             hipStream_t st, bool allow_lists = true) {
+             hipStream_t st, bool allow_lists = true, bool allow_mfma = true) {
+    // large whole-range L2 batches over a large gallery: the matrix-core nomination pass + exact re-rank (fir_gemm.hip), the
+    // same keys; what it cannot certify comes back through this function with allow_mfma = false
+    if (allow_mfma) {
+        const int rcm = try_mfma_topk(g, d_queries, qb, start, end, k, d_keys, st);
+        if (rcm <= 0) return rcm;
+    }
     // batches over a large gallery: threshold from a row sample, append scan at the speed of the top-1 scan, K smallest
     // of each candidate list (exact distances throughout); anything it cannot certify falls back to the scan below
     if (allow_lists && g->tiles_limit == 0 && qb >= 8 && g->n >= 65536) {
         constexpr int kListBatch = 1024;           // candidate lists are 32 KiB per query: bounded scratch for any qb
         if (qb > kListBatch) {
             for (int q0 = 0; q0 < qb; q0 += kListBatch) {
-                const int rc3 = topk_dev(g, d_queries + (size_t)q0 * g->d, std::min(kListBatch, qb - q0), start, end, k, d_keys + (size_t)q0 * k, st);
+                const int rc3 = topk_dev(g, d_queries + (size_t)q0 * g->d, std::min(kListBatch, qb - q0), start, end, k, d_keys + (size_t)q0 * k, st, true, false);
                 if (rc3) return rc3;
             }
             return FIR_OK;
@@ -971,20 +979,47 @@ int fir_feature_distance(const float* lhs, const float* rhs, int32_t len, int32_
 
 namespace {
 // The matrix-core path for this call, if it applies: 0 = done, 1 = take the scan, < 0 = error.
+int ensure_gemm(fir_gallery* g);
+}  // namespace
+namespace {
+int try_mfma_topk_impl(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start, int32_t end, int32_t k, uint64_t* d_keys, hipStream_t st) {
+    if (k < 2 || !wants_mfma(g, qb, start, end)) return 1;       // K = 1 callers use the top-1 entry points
+    const int rc = ensure_gemm(g);
+    if (rc) return rc;
+    return fir_gemm_search_topk_keys_dev(g->gemm, d_queries, qb, k, d_keys, st);
+}
+// 0 = the handle has its fir_gemm, 1 = this shape stays with the scan, < 0 = error
+int ensure_gemm(fir_gallery* g) {
+    if (g->gemm) return 0;
+    const int rc = fir_gemm_create(g, &g->gemm);
+    if (rc) {
+        g->gemm = nullptr;
+        if (g->large_batch_min > 0 || rc != FIR_ERR_ARG) return rc;    // asked for explicitly, or a real failure
+        g->gemm_failed = true;                                           // automatic: this shape stays with the scan
+        return 1;
+    }
+    return 0;
+}
 int try_mfma(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start, int32_t end, uint64_t* d_keys, hipStream_t st) {
     if (!wants_mfma(g, qb, start, end)) return 1;
-    if (!g->gemm) {
-        const int rc = fir_gemm_create(g, &g->gemm);
-        if (rc) {
-            g->gemm = nullptr;
-            if (g->large_batch_min > 0 || rc != FIR_ERR_ARG) return rc;    // asked for explicitly, or a real failure
-            g->gemm_failed = true;                                           // automatic: this shape stays with the scan
-            return 1;
-        }
-    }
+    const int rc = ensure_gemm(g);
+    if (rc) return rc;
     return fir_gemm_search_top1_keys_dev(g->gemm, d_queries, qb, d_keys, st);
 }
 }  // namespace
+namespace {
+int try_mfma_topk(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start, int32_t end, int32_t k, uint64_t* d_keys, hipStream_t st) {
+    return try_mfma_topk_impl(g, d_queries, qb, start, end, k, d_keys, st);
+}
+}  // namespace
+
+int fir_search_topk_exact_keys_dev_(fir_gallery* g, const float* d_queries, int32_t qb, int32_t k, uint64_t* d_keys, void* stream) {
+    if (!g || !d_keys || (qb > 0 && !d_queries)) return fail(FIR_ERR_ARG, "NULL argument");
+    if (qb <= 0) return qb < 0 ? fail(FIR_ERR_ARG, "qb < 0") : FIR_OK;
+    if (k < 1 || k > kKMax) return fail(FIR_ERR_ARG, "k=%d outside [1,%d]", k, kKMax);
+    FIR_HIP(hipSetDevice(g->device));
+    return topk_dev(g, d_queries, qb, 0, g->d, k, d_keys, stream ? (hipStream_t)stream : g->stream, true, false);
+}
 
 int fir_search_top1_keys_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start_pos, int32_t end_pos,
                              uint64_t* d_keys, void* stream) {

@@ -982,7 +982,10 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16(const uint4* _
 // certificate could never hold (measured: 75 of 200 queries of a 600-identity gallery went to the exact scan).
 __global__ void __launch_bounds__(256) k_gemm_tau(const float* __restrict__ sample, int sample_rows, float* __restrict__ tau,
                                                    int nq_valid, const float* __restrict__ qnorm, const float* __restrict__ gnorm_max_p, float e_rel,
-                                                   int qgroup = 1) {
+                                                   int qgroup = 1, int kth_window = 0) {
+    // kth_window (top-K, K <= kCand): the bound is the kCand-th smallest sampled proxy PLUS one window -- at least K rows
+    // lie at or below the kCand-th smallest, and every row within a window of the K-th best one must be appended for the
+    // certificate of rank K to be able to hold
     // qgroup > 1 (fp16 flow): the sample of a group of qgroup queries is laid out [value][query of the group] and holds one
     // MINIMUM per 32-row block instead of every proxy: the kCand-th smallest block minimum still has kCand sampled rows at or
     // below it, which is all the append pass needs, and is within a rank or two of the exact order statistic
@@ -1031,7 +1034,7 @@ __global__ void __launch_bounds__(256) k_gemm_tau(const float* __restrict__ samp
             float v = fir::f32_from_orderable((uint32_t)(m >> 32));
             const float v1 = fir::f32_from_orderable((uint32_t)(smallest >> 32));
             const float window = 2.5f * e_rel * (qnorm[q] + gnorm_max_p[0]);       // 2 E d of the re-rank, with room
-            v = fmaxf(v, v1 + window);                                               // a NaN window leaves v as it is
+            v = kth_window ? v + window : fmaxf(v, v1 + window);                     // (top-1) a NaN window leaves v as it is
             t = v + fabsf(v) * 1e-6f + 1e-30f;
         }
         tau[q] = t;
@@ -1137,6 +1140,129 @@ __global__ void __launch_bounds__(64) k_gemm_rerank(const unsigned long long* __
             const float p_excl = t != t ? t : fminf(p_out, t);      // a NaN bound must not certify anything
             const float lower = (qn + p_excl) / (float)d - E;
             const float bd = best != kKeyNone ? fir::f32_from_orderable((uint32_t)(best >> 32)) : fir::kNotFound;
+            certified = lower > bd;                 // false for NaN
+            if (n <= reranked) certified = true;    // every row was re-ranked
+        }
+        ok[q] = certified ? 1 : 0;
+    }
+}
+
+// The K nearest rows (K <= kTopKMax) from the same lists: as k_gemm_rerank with the window hung on the K-th smallest proxy
+// of the list, every lane keeping the K smallest exact keys it computed, K rounds of wave-minimum at the end, and the
+// certificate taken against the K-th exact distance: no row outside the re-ranked set can be among the K nearest, nor tie
+// with the K-th (strict '>'). out_key[q * k + r], ascending; kKeyNone where fewer than K rows are below 100000.
+constexpr int kTopKMax = 8;
+__global__ void __launch_bounds__(64) k_gemm_rerank_topk(const unsigned long long* __restrict__ lists, const int* __restrict__ counts,
+                                                          const float* __restrict__ tau, const float4* __restrict__ gal4,
+                                                          const float* __restrict__ queries, const float* __restrict__ qnorm,
+                                                          const float* __restrict__ gnorm_max_p, int64_t n, int d, int dp4, int64_t row_offset,
+                                                          float e_rel, int ngroup, int k, unsigned long long* __restrict__ out_key,
+                                                          int* __restrict__ ok) {
+    const int q = blockIdx.x, lane = threadIdx.x;
+    const int cnt = counts[q];
+    const int have = cnt < kListCap ? cnt : kListCap;
+    const unsigned long long* L = lists + (size_t)q * kListCap;
+    // the K-th smallest list entry (keys are unique: the row is part of the key)
+    unsigned long long prev = 0, kth = kKeyNone;
+    int found = 0;
+    for (int r = 0; r < k; ++r) {
+        unsigned long long m = kKeyNone;
+        for (int i = lane; i < have; i += 64) {
+            const unsigned long long v = L[i];
+            if ((r == 0 || v > prev) && v < m) m = v;
+        }
+        m = fir::wave_min_u64(m);
+        if (m == kKeyNone) break;
+        prev = m;
+        kth = m;
+        ++found;
+    }
+    const float qn = qnorm[q], gmax = gnorm_max_p[0];
+    const float E = e_rel * (qn + gmax) / (float)d;                   // see k_gemm_rerank
+    const float pk = found == k ? fir::f32_from_orderable((uint32_t)(kth >> 32)) : __builtin_huge_valf();   // a short list is re-ranked whole
+    float win = pk + 2.0f * E * (float)d;
+    win += fabsf(win) * 1e-6f;
+    const float* qv = queries + (size_t)q * d;
+    unsigned long long best[kTopKMax];
+#pragma unroll
+    for (int i = 0; i < kTopKMax; ++i) best[i] = kKeyNone;
+    float p_out = __builtin_huge_valf();            // smallest proxy NOT re-ranked
+    int reranked = 0;
+    extern __shared__ __attribute__((aligned(16))) float4 crow[];     // [ngroup][dp4] candidate rows, then [dp4] the query
+    float4* qrow = crow + (size_t)ngroup * dp4;
+    for (int c = lane; c < dp4 * 4; c += 64) ((float*)qrow)[c] = c < d ? qv[c] : 0.0f;
+    __syncthreads();
+    for (int base = 0; base < have; base += 64) {
+        const int i = base + lane;
+        const unsigned long long v = i < have ? L[i] : kKeyNone;
+        const float p = fir::f32_from_orderable((uint32_t)(v >> 32));
+        const bool in = i < have && p <= win;
+        if (i < have && !in) p_out = fminf(p_out, p);
+        unsigned long long mask = __ballot(in);
+        reranked += __popcll(mask);
+        while (mask) {                                                  // wave-uniform
+            unsigned long long mine = kKeyNone;
+            int ng = 0;
+            for (int g = 0; g < ngroup; ++g) {
+                if (mask) {
+                    const int src = __ffsll((long long)mask) - 1;
+                    mask &= mask - 1;
+                    const unsigned long long cv = __shfl((unsigned long long)v, src, 64);
+                    const int64_t row = (int64_t)(uint32_t)(cv & 0xFFFFFFFFull);
+                    const float4* gr = gal4 + (size_t)(row >> 6) * dp4 * 64 + (row & 63);
+                    for (int c = lane; c < dp4; c += 64) crow[(size_t)g * dp4 + c] = gr[(size_t)c * 64];
+                    if (lane == g) mine = cv;
+                    ++ng;
+                }
+            }
+            __syncthreads();
+            if (lane < ng) {
+                const float4* my = crow + (size_t)lane * dp4;
+                float acc = 0.0f;
+                for (int c = 0; c < dp4; ++c) {
+                    const float4 g4 = my[c], q4 = qrow[c];
+                    acc = fir::accum<fir::kL2>(acc, q4.x, g4.x);
+                    acc = fir::accum<fir::kL2>(acc, q4.y, g4.y);
+                    acc = fir::accum<fir::kL2>(acc, q4.z, g4.z);
+                    acc = fir::accum<fir::kL2>(acc, q4.w, g4.w);
+                }
+                const float dist = acc / (float)d;
+                if (dist < fir::kNotFound) {
+                    const int64_t row = (int64_t)(uint32_t)(mine & 0xFFFFFFFFull);
+                    unsigned long long key = fir::key_pack(dist, (uint32_t)(row + row_offset));
+#pragma unroll
+                    for (int j = 0; j < kTopKMax; ++j) {                // sorted insert
+                        const bool sw = key < best[j];
+                        const unsigned long long t = best[j];
+                        best[j] = sw ? key : t;
+                        key = sw ? t : key;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) p_out = fminf(p_out, __shfl_xor(p_out, off, 64));
+    unsigned long long kth_exact = kKeyNone;
+    for (int r = 0; r < k; ++r) {
+        const unsigned long long m = fir::wave_min_u64(best[0]);
+        if (lane == 0) out_key[(size_t)q * k + r] = m;
+        kth_exact = m;
+        if (m != kKeyNone && best[0] == m) {                            // exactly one lane holds it
+#pragma unroll
+            for (int j = 0; j + 1 < kTopKMax; ++j) best[j] = best[j + 1];
+            best[kTopKMax - 1] = kKeyNone;
+        }
+    }
+    if (lane == 0) {
+        bool certified = false;
+        if (cnt <= kListCap) {                      // nothing below tau was dropped from the list
+            const float t = tau[q];
+            const float p_excl = t != t ? t : fminf(p_out, t);      // a NaN bound must not certify anything
+            const float lower = (qn + p_excl) / (float)d - E;
+            // fewer than K rows found so far: any row below 100000 outside the re-ranked set would belong to the answer
+            const float bd = kth_exact != kKeyNone ? fir::f32_from_orderable((uint32_t)(kth_exact >> 32)) : fir::kNotFound;
             certified = lower > bd;                 // false for NaN
             if (n <= reranked) certified = true;    // every row was re-ranked
         }
@@ -1259,7 +1385,7 @@ int fir_gemm_create_ex(fir_gallery* g, int32_t precision, fir_gemm** out) {
     m->rt_sample_rows = (int)std::min<int64_t>(np, std::max<int64_t>(kMinSampleRows, np / 16));
     if (e == hipSuccess) e = hipMalloc((void**)&m->sample, (size_t)kPasses * kQT * m->sample_rows * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&m->fbq, (size_t)kQT * m->v.d * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc((void**)&m->fbkeys, kQT * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void**)&m->fbkeys, (size_t)kQT * kTopKMax * sizeof(unsigned long long));
     const int lds_bytes = precision == FIR_GEMM_F32 ? (kQT / 32) * std::min(m->dq8, kSlab8) * 64 * (int)sizeof(float4)
                                                     : (kQT / 32) * std::min(m->dk16, kSlab16) * 128 * (int)sizeof(uint4);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
@@ -1273,6 +1399,8 @@ int fir_gemm_create_ex(fir_gallery* g, int32_t precision, fir_gemm** out) {
         if (m->rerank_group < 1) { delete m; return gemm_fail(FIR_ERR_ARG, "rows of %d features are too long for the matrix-core path's re-rank", m->v.d); }
         if (e == hipSuccess && (size_t)(m->rerank_group + 1) * row_bytes > 64 * 1024)
             e = hipFuncSetAttribute((const void*)k_gemm_rerank, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRerankLdsMax);
+        if (e == hipSuccess && (size_t)(m->rerank_group + 1) * row_bytes > 64 * 1024)
+            e = hipFuncSetAttribute((const void*)k_gemm_rerank_topk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRerankLdsMax);
     }
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy_f16<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kHalfLds);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy_f16<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kHalfLds);
@@ -1354,15 +1482,22 @@ int fir_gemm_stats(const fir_gemm* m, int64_t* passes, int64_t* fallback_queries
 
 // d_queries / d_keys: device pointers. All passes are queued first; the certificates of the whole batch are read
 // back with ONE stream synchronisation, then the uncertified queries (if any) go through the exact scan.
-int fir_gemm_search_top1_keys_dev(fir_gemm* m, const float* d_queries, int32_t qb, uint64_t* d_keys, void* stream) {
+}  // extern "C"
+
+// The K nearest rows of every query, K = 1 (fir_gemm_search_top1_keys_dev) or 2..kTopKMax (fir_gemm_search_topk_keys_dev):
+// d_keys[q * k + r], ascending.
+static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, uint64_t* d_keys, void* stream) {
     if (!m || !d_keys || (qb > 0 && !d_queries)) return gemm_fail(FIR_ERR_ARG, "NULL argument");
     if (qb < 0) return gemm_fail(FIR_ERR_ARG, "qb < 0");
+    if (k < 1 || k > kTopKMax) return gemm_fail(FIR_ERR_ARG, "k=%d outside [1,%d]", k, kTopKMax);
     if (qb == 0) return FIR_OK;
     GEMM_HIP(hipSetDevice(m->v.device));
     hipStream_t st = stream ? (hipStream_t)stream : m->v.stream;
     const int d = m->v.d;
     const int64_t n = m->v.n;
-    if (n == 0) return fir_search_top1_exact_keys_dev_(m->g, d_queries, qb, 0, 0, d_keys, st);
+    if (n == 0)
+        return k == 1 ? fir_search_top1_exact_keys_dev_(m->g, d_queries, qb, 0, 0, d_keys, st)
+                      : fir_search_topk_exact_keys_dev_(m->g, d_queries, qb, k, d_keys, st);
     if ((size_t)qb > m->ok_cap) {
         if (m->ok) GEMM_HIP(hipFree(m->ok));
         m->ok = nullptr;
@@ -1395,10 +1530,12 @@ int fir_gemm_search_top1_keys_dev(fir_gemm* m, const float* d_queries, int32_t q
         FIR_RT_PICK(8) FIR_RT_PICK(16) FIR_RT_PICK(32)
 #undef FIR_RT_PICK
     }
-    const bool rt_flow = rt_main != nullptr;        // sample pass + tau through the register-tile kernel (smallest sampled proxy + one window)
+    // sample pass + tau through the register-tile kernel (smallest sampled proxy + one window): top-1 only -- the K-th best
+    // needs an order statistic of the sample, which the block-minimum sample + k_gemm_tau give
+    const bool rt_flow = rt_main != nullptr && k == 1;
     // the full pass: both kernels run at ~1 KiB of LDS traffic per MFMA and within 7 % of each other (profiles/r02_gemm_kernel_choice.txt):
     // register tile ahead up to 256 features, LDS tile ahead at 512
-    const bool rt_full = rt_flow && (m->regtile > 0 || (m->regtile < 0 && m->dk16 <= 16));
+    const bool rt_full = rt_main != nullptr && (m->regtile > 0 || (m->regtile < 0 && m->dk16 <= 16));
     auto prep = [&](int sb) -> int {
         hipStream_t ps = m->side;
         const int q0 = sb * kPasses * kQT;
@@ -1440,7 +1577,7 @@ int fir_gemm_search_top1_keys_dev(fir_gemm* m, const float* d_queries, int32_t q
                 hipLaunchKernelGGL((k_gemm_proxy_f16<0, 0>), sgrid, dim3(kGemmBlock), kHalfLds, ps, m->gh, m->gnorm, m->qbf[b], m->qinv[b], n, (int64_t)0,
                                    (int64_t)sample_rows, m->dk16, m->tau[b], m->lists[b], m->counts[b], m->sample, sample_rows, 0, 1);
             hipLaunchKernelGGL(k_gemm_tau, dim3(pairs * 2 * kQT), dim3(256), 0, ps, m->sample, (sample_rows + 31) / 32, m->tau[b], nq, m->qnorm[b], m->gmax,
-                               e_rel, 2 * kQT);
+                               e_rel, 2 * kQT, k > 1 ? 1 : 0);
             }
         } else {
             hipLaunchKernelGGL(k_gemm_qnorm, dim3(np * kQT), dim3(64), 0, ps, dq, nq, d, m->qnorm[b]);
@@ -1455,7 +1592,8 @@ int fir_gemm_search_top1_keys_dev(fir_gemm* m, const float* d_queries, int32_t q
                 hipLaunchKernelGGL(k_gemm_proxy_bf16<0>, dim3(sample_grid, np), dim3(128), 0, ps, m->gb, m->gnorm, m->qbf[b], n, (int64_t)0,
                                    (int64_t)sample_rows, m->dk16, m->tau[b], m->lists[b], m->counts[b], m->sample, sample_rows);
             }
-            hipLaunchKernelGGL(k_gemm_tau, dim3(np * kQT), dim3(256), 0, ps, m->sample, sample_rows, m->tau[b], 0x7FFFFFFF, m->qnorm[b], m->gmax, e_rel);
+            hipLaunchKernelGGL(k_gemm_tau, dim3(np * kQT), dim3(256), 0, ps, m->sample, sample_rows, m->tau[b], 0x7FFFFFFF, m->qnorm[b], m->gmax, e_rel, 1,
+                               k > 1 ? 1 : 0);
         }
         GEMM_HIP(hipGetLastError());
         GEMM_HIP(hipEventRecord(m->prep_done[b], ps));
@@ -1550,9 +1688,14 @@ int fir_gemm_search_top1_keys_dev(fir_gemm* m, const float* d_queries, int32_t q
         GEMM_HIP(hipEventRecord(m->main_done[b], st));
         // exact re-rank + certificate of this super-batch on the side stream, under the next one's full pass
         GEMM_HIP(hipStreamWaitEvent(m->side, m->main_done[b], 0));
-        hipLaunchKernelGGL(k_gemm_rerank, dim3(nq), dim3(64), (size_t)(m->rerank_group + 1) * m->dp4 * sizeof(float4), m->side, m->lists[b], m->counts[b], m->tau[b],
-                           m->gal4, dq, m->qnorm[b], m->gmax, n, d, m->dp4, m->v.row_offset, e_rel, m->rerank_group, (unsigned long long*)d_keys + q0,
-                           m->ok + q0);
+        if (k == 1)
+            hipLaunchKernelGGL(k_gemm_rerank, dim3(nq), dim3(64), (size_t)(m->rerank_group + 1) * m->dp4 * sizeof(float4), m->side, m->lists[b], m->counts[b],
+                               m->tau[b], m->gal4, dq, m->qnorm[b], m->gmax, n, d, m->dp4, m->v.row_offset, e_rel, m->rerank_group,
+                               (unsigned long long*)d_keys + q0, m->ok + q0);
+        else
+            hipLaunchKernelGGL(k_gemm_rerank_topk, dim3(nq), dim3(64), (size_t)(m->rerank_group + 1) * m->dp4 * sizeof(float4), m->side, m->lists[b],
+                               m->counts[b], m->tau[b], m->gal4, dq, m->qnorm[b], m->gmax, n, d, m->dp4, m->v.row_offset, e_rel, m->rerank_group, k,
+                               (unsigned long long*)d_keys + (size_t)q0 * k, m->ok + q0);
         GEMM_HIP(hipEventRecord(m->rerank_done[b], m->side));
         m->passes += np;
     }
@@ -1570,12 +1713,23 @@ int fir_gemm_search_top1_keys_dev(fir_gemm* m, const float* d_queries, int32_t q
         const int nf = (int)std::min<size_t>(kQT, which.size() - f0);
         for (int i = 0; i < nf; ++i)
             GEMM_HIP(hipMemcpyAsync(m->fbq + (size_t)i * d, d_queries + (size_t)which[f0 + i] * d, (size_t)d * sizeof(float), hipMemcpyDeviceToDevice, st));
-        int rc = fir_search_top1_exact_keys_dev_(m->g, m->fbq, nf, 0, 0, (uint64_t*)m->fbkeys, st);
+        int rc = k == 1 ? fir_search_top1_exact_keys_dev_(m->g, m->fbq, nf, 0, 0, (uint64_t*)m->fbkeys, st)
+                        : fir_search_topk_exact_keys_dev_(m->g, m->fbq, nf, k, (uint64_t*)m->fbkeys, st);
         if (rc) return rc;
         for (int i = 0; i < nf; ++i)
-            GEMM_HIP(hipMemcpyAsync(d_keys + which[f0 + i], m->fbkeys + i, sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
+            GEMM_HIP(hipMemcpyAsync(d_keys + (size_t)which[f0 + i] * k, m->fbkeys + (size_t)i * k, (size_t)k * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
     }
     return FIR_OK;
+}
+
+extern "C" {
+
+int fir_gemm_search_top1_keys_dev(fir_gemm* m, const float* d_queries, int32_t qb, uint64_t* d_keys, void* stream) {
+    return gemm_search(m, d_queries, qb, 1, d_keys, stream);
+}
+
+int fir_gemm_search_topk_keys_dev(fir_gemm* m, const float* d_queries, int32_t qb, int32_t k, uint64_t* d_keys, void* stream) {
+    return gemm_search(m, d_queries, qb, k, d_keys, stream);
 }
 
 }  // extern "C"

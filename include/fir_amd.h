@@ -251,6 +251,11 @@ int fir_gemm_create(fir_gallery* g, fir_gemm** out);   /* = fir_gemm_create_ex(g
 int fir_gemm_create_ex(fir_gallery* g, int32_t precision, fir_gemm** out);
 int fir_gemm_destroy(fir_gemm* m);
 int fir_gemm_search_top1_keys_dev(fir_gemm* m, const float* d_queries, int32_t qb, uint64_t* d_keys, void* stream);
+/* The k nearest rows (2 <= k <= 8; k = 1 is the call above): d_keys[q * k + r], ascending, the keys fir_search_topk_keys_dev
+ * gives. The bound of the append pass is an order statistic of a row sample plus one rounding window; the re-rank window hangs
+ * on the k-th smallest proxy and the certificate is taken against the k-th exact distance. fir_search_topk[_keys_dev] route
+ * whole-range L2 batches here under the same rule as the top-1 calls (fir_gallery_set_large_batch_mfma). */
+int fir_gemm_search_topk_keys_dev(fir_gemm* m, const float* d_queries, int32_t qb, int32_t k, uint64_t* d_keys, void* stream);
 /* fir_search_top1 and fir_search_top1_keys_dev send L2 whole-range batches through this path BY DEFAULT when the batch
  * has >= 128 queries and the gallery >= 65536 rows (created on first use; costs the extra fp16 gallery copy, n*d*2
  * bytes; identical keys). min_queries > 0: the caller's threshold instead (any gallery size); 0: never, frees the copy

@@ -80,6 +80,19 @@ def test_planted_rows_shards_topk_and_mfma_agree(fir, oracle, n):
         gm.search_top1_keys_dev(q.data_ptr(), 16, k2.data_ptr(), stream=st.cuda_stream)
         st.synchronize()
         assert np.array_equal(k2.cpu().numpy().view(np.uint64), whole)
+        # ... and the same top-5 keys as the exact top-K scan, 256 queries (rows of the gallery, perturbed)
+        qk = x[torch.arange(256, device="cuda") * (n // 256)] * 0.98 + x[:256] * 0.02
+        qk = (qk / qk.norm(dim=1, keepdim=True)).contiguous()
+        km = torch.empty((256, 5), device="cuda", dtype=torch.int64)
+        ke = torch.empty((256, 5), device="cuda", dtype=torch.int64)
+        gm.search_topk_keys_dev(qk.data_ptr(), 256, 5, km.data_ptr(), stream=st.cuda_stream)
+        g.set_large_batch_mfma(0)
+        g.search_topk_keys_dev(qk.data_ptr(), 256, 5, ke.data_ptr(), stream=st.cuda_stream)
+        g.set_large_batch_mfma(-1)
+        st.synchronize()
+        assert torch.equal(km, ke)
+        assert gm.stats()["fallback_queries"] <= 64
+        del qk, km, ke
         gm.close()
         g.close()
         # two row shards with offsets: the minimum of their keys is the whole gallery's answer

@@ -252,3 +252,53 @@ def test_class_ordered_gallery_is_sampled_across_all_classes(fir):
     (idx, dist), (eidx, edist), st = run_both(fir, rows, q)
     assert np.array_equal(idx, eidx) and np.array_equal(dist.view(np.uint32), edist.view(np.uint32))
     assert st["fallback_queries"] == 0
+
+
+@pytest.mark.parametrize("n,d,qb", [(70000, 64, 300), (66000, 512, 200), (80000, 200, 129)])
+def test_topk_through_the_matrix_cores_equals_the_exact_scan(fir, oracle, n, d, qb):
+    """fir_search_topk on >= 128 whole-range L2 queries over >= 65536 rows takes the fp16 nomination pass with the re-rank
+    window hung on the K-th smallest proxy and the certificate against the K-th exact distance: the keys of the exact
+    top-K scan (set_large_batch_mfma(0)) for every K, with ties inside the list and at the K-th place, and the oracle's."""
+    rows = synth.make_gallery(n % 97, n, d, 0)
+    q, _ = synth.make_queries(n % 97, rows, qb, 0)
+    rows[200:205] = rows[n - 10]                      # six equal rows
+    q[1] = rows[n - 10]
+    for k in (2, 5, 8):
+        with fir.Gallery(rows, None, 0, 0) as g:
+            a = g.search_topk(q, k)
+            g.set_large_batch_mfma(0)
+            e = g.search_topk(q, k)
+        assert np.array_equal(a[0], e[0]), k
+        assert np.array_equal(a[1].view(np.uint32), e[1].view(np.uint32)), k
+        assert list(a[0][1][: min(k, 6)]) == [200, 201, 202, 203, 204, n - 10][: min(k, 6)]
+        for j in (0, 1, qb - 1):
+            ei, ed = oracle.topk(rows, q[j], 0, d, k, 0)
+            assert np.array_equal(a[0][j], ei) and np.array_equal(a[1][j].view(np.uint32), ed.view(np.uint32))
+
+
+def test_topk_matrix_cores_on_a_clustered_gallery_and_by_handle(fir):
+    """Near-duplicate rows (600 identities x ~117 images each): dozens of rows within the rounding window of the K-th best;
+    what the certificate cannot prove goes to the exact scan -- same keys either way. Also through fir_gemm_search_topk_keys_dev
+    directly, with its fallback count."""
+    rng = np.random.default_rng(5)
+    n, d, k = 70000, 128, 5
+    centres = synth.make_gallery(3, 600, d, 0)
+    rows = centres[np.arange(n) % 600] + rng.normal(0, 2e-4, (n, d)).astype(np.float32)
+    rows = (rows / np.linalg.norm(rows, axis=1, keepdims=True)).astype(np.float32)
+    q = rows[rng.integers(0, n, 256)] + rng.normal(0, 1e-4, (256, d)).astype(np.float32)
+    q = np.ascontiguousarray(q, np.float32)
+    dev = torch.device("cuda", 0)
+    with fir.Gallery(rows, None, 0, 0) as g:
+        a = g.search_topk(q, k)
+        g.set_large_batch_mfma(0)
+        e = g.search_topk(q, k)
+        tq = torch.from_numpy(q).to(dev)
+        keys = torch.empty(q.shape[0] * k, dtype=torch.int64, device=dev)
+        with fir.GemmSearch(g, 2) as m:
+            m.search_topk_keys_dev(tq.data_ptr(), q.shape[0], k, keys.data_ptr())
+            torch.cuda.synchronize()
+            st = m.stats()
+        hidx, hdist = fir.keys_unpack(keys.cpu().numpy().view(np.uint64))
+    assert np.array_equal(a[0], e[0]) and np.array_equal(a[1].view(np.uint32), e[1].view(np.uint32))
+    assert np.array_equal(hidx.reshape(-1, k), e[0]) and np.array_equal(hdist.reshape(-1, k).view(np.uint32), e[1].view(np.uint32))
+    assert st["fallback_queries"] <= 256
