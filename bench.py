@@ -531,6 +531,18 @@ def other_scans(fir, g, q, keys, dev, ws, n, d):
         k5 = torch.empty((qb, 5), device=dev, dtype=torch.int64)
         also = {"l2_top5_queries_per_s": rate(lambda: g.search_topk_keys_dev(q.data_ptr(), qb, 5, k5.data_ptr(), stream=stream), qb, 2)}
         also["l2_top5_first_column_is_top1"] = bool(torch.equal(k5[:, 0], keys[:qb]))
+        # the whole query batch through the default dispatch (matrix-core nomination + exact re-rank of the K-th window), and
+        # the exact top-K scan on the first 256 of them
+        qall = q.shape[0]
+        k5a = torch.empty((qall, 5), device=dev, dtype=torch.int64)
+        r5a = rate(lambda: g.search_topk_keys_dev(q.data_ptr(), qall, 5, k5a.data_ptr(), stream=stream), qall, 2)
+        path5 = g.last_dispatch()["path"]
+        g.set_large_batch_mfma(0)
+        r5e = rate(lambda: g.search_topk_keys_dev(q.data_ptr(), qb, 5, k5.data_ptr(), stream=stream), qb, 1)
+        g.set_large_batch_mfma(-1)
+        also["l2_top5_whole_batch"] = {"query_batch": qall, "queries_per_s": r5a, "path": path5, "exact_topk_scan_queries_per_s": r5e,
+                                       "identical_keys_to_exact_topk_scan": bool(torch.equal(k5a[:qb], k5))}
+        del k5a
         # the exact scan with 16 queries per gallery pass: more queries/s, but bound by the f32 vector pipes (3 un-fused ops per
         # feature and query), not by HBM
         k16 = torch.empty(qb, device=dev, dtype=torch.int64)
