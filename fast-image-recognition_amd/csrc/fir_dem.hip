@@ -197,36 +197,40 @@ __global__ void k_dem_lik_fix(const float* __restrict__ table, int n, int used, 
 // fetch the row's float4s side by side (one memory latency instead of d/4 in a row -- the call is latency, not bandwidth),
 // park them in LDS next to the query (read ONCE per workgroup: on small calls it sits in pinned host memory), and lane j
 // then runs the reference's loop for candidate j in feature order (fir::accum, un-fused).
-// Dynamic LDS: (1 + 4 * cpw) * dp4 float4.
+// Rows longer than `span` float4s go through LDS in pieces of `span` (the sums carry over in the lanes' registers).
+// Dynamic LDS: (1 + 4 * cpw) * span float4.
 template <int METRIC>
 __global__ void __launch_bounds__(kBlock) k_rows_dist(const float4* __restrict__ gal4, int dp4, int64_t n, const float* __restrict__ queries, int d,
-                                                      const int32_t* __restrict__ rows, int m, int start, int end, float* __restrict__ out, int cpw) {
+                                                      const int32_t* __restrict__ rows, int m, int start, int end, float* __restrict__ out, int cpw,
+                                                      int span) {
     extern __shared__ __attribute__((aligned(16))) float4 rsm[];
     float* qs = (float*)rsm;
     const int q = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int k = threadIdx.x; k < dp4 * 4; k += kBlock) qs[k] = k < d ? queries[(size_t)q * d + k] : 0.0f;
-    float4* mine = rsm + dp4 + (size_t)wave * cpw * dp4;
+    float4* mine = rsm + span + (size_t)wave * cpw * span;
     const int k0 = (blockIdx.x * (kBlock / 64) + wave) * cpw;
     const int c0 = start >> 2, c1 = (end - 1) >> 2;
-    for (int j = 0; j < cpw; ++j) {
-        const int k = k0 + j;
-        const int64_t row = k < m ? (int64_t)rows[(size_t)q * m + k] : -1;
-        if (row < 0 || row >= n) continue;                     // wave-uniform
-        const float4* __restrict__ base = gal4 + (size_t)(row >> 6) * dp4 * 64 + (row & 63);
-        for (int c = c0 + lane; c <= c1; c += 64) mine[(size_t)j * dp4 + c] = base[(size_t)c * 64];
-    }
-    __syncthreads();
-    if (lane < cpw && k0 + lane < m) {
-        const int64_t row = rows[(size_t)q * m + k0 + lane];
-        float dist = fir::kNotFound;
-        if (row >= 0 && row < n) {
-            const float* __restrict__ gv = (const float*)(mine + (size_t)lane * dp4);
-            float acc = 0.0f;
-            for (int f = start; f < end; ++f) acc = fir::accum<METRIC>(acc, qs[f], gv[f]);
-            dist = acc / (float)(end - start);
+    const int64_t my_row = lane < cpw && k0 + lane < m ? (int64_t)rows[(size_t)q * m + k0 + lane] : -1;
+    const bool my_valid = my_row >= 0 && my_row < n;
+    float acc = 0.0f;
+    for (int cb = c0; cb <= c1; cb += span) {
+        const int ce = min(c1, cb + span - 1);                   // chunks [cb, ce] of this piece
+        for (int k = cb * 4 + threadIdx.x; k < (ce + 1) * 4; k += kBlock) qs[k - cb * 4] = k < d ? queries[(size_t)q * d + k] : 0.0f;
+        for (int j = 0; j < cpw; ++j) {
+            const int k = k0 + j;
+            const int64_t row = k < m ? (int64_t)rows[(size_t)q * m + k] : -1;
+            if (row < 0 || row >= n) continue;                     // wave-uniform
+            const float4* __restrict__ base = gal4 + (size_t)(row >> 6) * dp4 * 64 + (row & 63);
+            for (int c = cb + lane; c <= ce; c += 64) mine[(size_t)j * span + (c - cb)] = base[(size_t)c * 64];
         }
-        out[(size_t)q * m + k0 + lane] = dist;
+        __syncthreads();
+        if (my_valid) {
+            const float* __restrict__ gv = (const float*)(mine + (size_t)lane * span);
+            const int f0 = max(start, cb * 4), f1 = min(end, (ce + 1) * 4);
+            for (int f = f0; f < f1; ++f) acc = fir::accum<METRIC>(acc, qs[f - cb * 4], gv[f - cb * 4]);
+        }
+        __syncthreads();
     }
+    if (lane < cpw && k0 + lane < m) out[(size_t)q * m + k0 + lane] = my_valid ? acc / (float)(end - start) : fir::kNotFound;
 }
 
 // One thread, queued behind the kernels of a small host-pointer call whose results went to pinned host memory: the call's
@@ -518,14 +522,15 @@ int fir_rows_distances(fir_gallery* g, const float* queries, int32_t qb, const i
     int rc = fir_gallery_info(g, nullptr, nullptr, &metric, nullptr);
     if (rc) return rc;
     DEM_HIP(hipSetDevice(v.device));
-    // candidates per wave: 4 while the workgroup's 1 + 16 rows fit 64 KiB of LDS (d <= 960), else 1 (d <= 3276)
+    // candidates per wave: 4 while the workgroup's 1 + 16 rows fit 64 KiB of LDS (d <= 960), else 1; rows beyond 2 048 features
+    // go through LDS in pieces of 512 float4
     const int cpw = (size_t)17 * dp4 * 16 <= 64 * 1024 ? 4 : 1;
-    const size_t lds = (size_t)(1 + (kBlock / 64) * cpw) * dp4 * 16;
-    if (lds > 64 * 1024) return dem_fail(FIR_ERR_ARG, "rows of %d features do not fit the candidate kernel's LDS", v.d);
+    const int span = std::min(dp4, 512);
+    const size_t lds = (size_t)(1 + (kBlock / 64) * cpw) * span * 16;
     const int per_block = (kBlock / 64) * cpw;
     const dim3 grid((m + per_block - 1) / per_block, qb);
 #define FIR_ROWS_LAUNCH(M, Q, R, O)                                                                                                       \
-    hipLaunchKernelGGL(k_rows_dist<M>, grid, dim3(kBlock), lds, v.stream, (const float4*)gal4, dp4, v.n, Q, v.d, R, m, start_pos, end_pos, O, cpw)
+    hipLaunchKernelGGL(k_rows_dist<M>, grid, dim3(kBlock), lds, v.stream, (const float4*)gal4, dp4, v.n, Q, v.d, R, m, start_pos, end_pos, O, cpw, span)
 #define FIR_ROWS_BY_METRIC(Q, R, O)                                                                                                       \
     do {                                                                                                                                  \
         if (metric == FIR_METRIC_L2) FIR_ROWS_LAUNCH(fir::kL2, Q, R, O);                                                                  \
