@@ -68,6 +68,7 @@ SYMBOLS = [
     ("fir_gemm_create", C.c_int, [_vp, C.POINTER(_vp)]),
     ("fir_gemm_create_ex", C.c_int, [_vp, C.c_int32, C.POINTER(_vp)]),
     ("fir_gemm_destroy", C.c_int, [_vp]),
+    ("fir_gemm_create_range", C.c_int, [_vp, C.c_int32, C.c_int32, C.POINTER(_vp)]),
     ("fir_gemm_search_top1_keys_dev", C.c_int, [_vp, _vp, C.c_int32, _vp, _vp]),
     ("fir_gemm_search_topk_keys_dev", C.c_int, [_vp, _vp, C.c_int32, C.c_int32, _vp, _vp]),
     ("fir_gemm_stats", C.c_int, [_vp, _i64p, _i64p]),
@@ -483,10 +484,10 @@ class GemmSearch:
 
     F32, BF16_SPLIT, F16 = 0, 1, 2
 
-    def __init__(self, gallery, precision=2):
+    def __init__(self, gallery, precision=2, end=0):
         self._g = gallery           # keeps the gallery alive
         self._h = _vp()
-        _check(lib().fir_gemm_create_ex(gallery._h, precision, C.byref(self._h)))
+        _check(lib().fir_gemm_create_range(gallery._h, precision, end, C.byref(self._h)))   # end: a feature prefix [0, end), 0 = whole rows
 
     def close(self):
         if self._h:

@@ -91,6 +91,7 @@ struct fir_gallery {
     // L2 whole-range batches of at least this many queries go through fir_gemm_* (same keys): -1 = automatic
     // (kAutoMfmaQueries queries against at least kAutoMfmaRows rows), 0 = never, > 0 = the caller's threshold
     int large_batch_min = -1;
+    fir_gemm* gemm_prefix = nullptr; int gemm_prefix_end = 0;   // the matrix-core state of the last feature prefix [0, end) asked for ("BF, 64" / "BF, 256")
     bool gemm_failed = false; // automatic mode: the matrix-core path could not be set up for this shape (rows too long): scan
     fir_gemm* gemm = nullptr; // created on first use
     fir_dispatch_info last{}; // dominant kernel of the most recent search
@@ -247,7 +248,9 @@ int top1_qpp(const fir_gallery* g, int qb, int cap) {
 constexpr int kAutoMfmaQueries = 128;
 constexpr int64_t kAutoMfmaRows = 65536;
 bool wants_mfma(const fir_gallery* g, int32_t qb, int32_t start, int32_t end) {
-    if (g->metric != FIR_METRIC_L2 || start != 0 || end != g->d || g->n <= 0 || g->tiles_limit > 0) return false;
+    // the whole row, or a prefix of whole 16-feature k-blocks (>= 64 features: below that the scan's prefix pass is cheap)
+    if (g->metric != FIR_METRIC_L2 || start != 0 || g->n <= 0 || g->tiles_limit > 0) return false;
+    if (end != g->d && (end < 64 || end % 16 != 0)) return false;
     if (g->large_batch_min == 0 || g->gemm_failed) return false;
     if (g->large_batch_min > 0) return qb >= g->large_batch_min;
     return qb >= kAutoMfmaQueries && g->n >= kAutoMfmaRows && g->qpp == 0;     // a pinned queries-per-pass asks for the scan
@@ -911,6 +914,7 @@ int fir_gallery_destroy(fir_gallery* g) {
     (void)hipSetDevice(g->device);
     if (g->stream) (void)hipStreamSynchronize(g->stream);
     if (g->gemm) { fir_gemm_destroy(g->gemm); g->gemm = nullptr; }
+    if (g->gemm_prefix) { fir_gemm_destroy(g->gemm_prefix); g->gemm_prefix = nullptr; }
     for (hipEvent_t e : g->ev) (void)hipEventDestroy(e);
     (void)hipFree(g->gal4); (void)hipFree(g->cls); (void)hipFree(g->qt); (void)hipFree(g->dq); (void)hipFree(g->dkeys);
     (void)hipFree(g->part); (void)hipFree(g->dout); (void)hipFree(g->didx); (void)hipFree(g->range); (void)hipFree(g->one_keys);
@@ -942,6 +946,7 @@ int fir_gallery_set_large_batch_mfma(fir_gallery* g, int32_t min_queries) {
     g->large_batch_min = min_queries < 0 ? -1 : min_queries;
     g->gemm_failed = false;
     if (min_queries == 0 && g->gemm) { fir_gemm_destroy(g->gemm); g->gemm = nullptr; }
+    if (min_queries == 0 && g->gemm_prefix) { fir_gemm_destroy(g->gemm_prefix); g->gemm_prefix = nullptr; }
     return FIR_OK;
 }
 
@@ -951,6 +956,7 @@ int fir_gallery_set_row_offset(fir_gallery* g, int64_t first_global_row) {
         return fail(FIR_ERR_ARG, "row offset %lld + n does not fit 32-bit indices", (long long)first_global_row);
     g->row_offset = first_global_row;
     if (g->gemm) { fir_gemm_destroy(g->gemm); g->gemm = nullptr; }   // it caches the offset; rebuilt on next use
+    if (g->gemm_prefix) { fir_gemm_destroy(g->gemm_prefix); g->gemm_prefix = nullptr; }
     return FIR_OK;
 }
 
@@ -979,32 +985,43 @@ int fir_feature_distance(const float* lhs, const float* rhs, int32_t len, int32_
 
 namespace {
 // The matrix-core path for this call, if it applies: 0 = done, 1 = take the scan, < 0 = error.
-int ensure_gemm(fir_gallery* g);
+int ensure_gemm(fir_gallery* g, int32_t end, fir_gemm** m);
 }  // namespace
 namespace {
 int try_mfma_topk_impl(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start, int32_t end, int32_t k, uint64_t* d_keys, hipStream_t st) {
     if (k < 2 || !wants_mfma(g, qb, start, end)) return 1;       // K = 1 callers use the top-1 entry points
-    const int rc = ensure_gemm(g);
+    fir_gemm* m = nullptr;
+    const int rc = ensure_gemm(g, end, &m);
     if (rc) return rc;
-    return fir_gemm_search_topk_keys_dev(g->gemm, d_queries, qb, k, d_keys, st);
+    return fir_gemm_search_topk_keys_dev(m, d_queries, qb, k, d_keys, st);
 }
-// 0 = the handle has its fir_gemm, 1 = this shape stays with the scan, < 0 = error
-int ensure_gemm(fir_gallery* g) {
-    if (g->gemm) return 0;
-    const int rc = fir_gemm_create(g, &g->gemm);
-    if (rc) {
-        g->gemm = nullptr;
-        if (g->large_batch_min > 0 || rc != FIR_ERR_ARG) return rc;    // asked for explicitly, or a real failure
-        g->gemm_failed = true;                                           // automatic: this shape stays with the scan
-        return 1;
+// 0 = *m is the handle's fir_gemm for features [0, end), 1 = this shape stays with the scan, < 0 = error
+int ensure_gemm(fir_gallery* g, int32_t end, fir_gemm** m) {
+    const bool whole = end == g->d;
+    fir_gemm*& slot = whole ? g->gemm : g->gemm_prefix;
+    if (!whole && slot && g->gemm_prefix_end != end) {          // another prefix than last time: its fragments replace the old ones
+        fir_gemm_destroy(slot);
+        slot = nullptr;
     }
+    if (!slot) {
+        const int rc = fir_gemm_create_range(g, FIR_GEMM_F16, whole ? 0 : end, &slot);
+        if (rc) {
+            slot = nullptr;
+            if (g->large_batch_min > 0 || rc != FIR_ERR_ARG) return rc;    // asked for explicitly, or a real failure
+            g->gemm_failed = true;                                           // automatic: this shape stays with the scan
+            return 1;
+        }
+        if (!whole) g->gemm_prefix_end = end;
+    }
+    *m = slot;
     return 0;
 }
 int try_mfma(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start, int32_t end, uint64_t* d_keys, hipStream_t st) {
     if (!wants_mfma(g, qb, start, end)) return 1;
-    const int rc = ensure_gemm(g);
+    fir_gemm* m = nullptr;
+    const int rc = ensure_gemm(g, end, &m);
     if (rc) return rc;
-    return fir_gemm_search_top1_keys_dev(g->gemm, d_queries, qb, d_keys, st);
+    return fir_gemm_search_top1_keys_dev(m, d_queries, qb, d_keys, st);
 }
 }  // namespace
 namespace {
@@ -1013,12 +1030,15 @@ int try_mfma_topk(fir_gallery* g, const float* d_queries, int32_t qb, int32_t st
 }
 }  // namespace
 
-int fir_search_topk_exact_keys_dev_(fir_gallery* g, const float* d_queries, int32_t qb, int32_t k, uint64_t* d_keys, void* stream) {
+int fir_search_topk_exact_keys_dev_(fir_gallery* g, const float* d_queries, int32_t qb, int32_t end_pos, int32_t k, uint64_t* d_keys, void* stream) {
     if (!g || !d_keys || (qb > 0 && !d_queries)) return fail(FIR_ERR_ARG, "NULL argument");
     if (qb <= 0) return qb < 0 ? fail(FIR_ERR_ARG, "qb < 0") : FIR_OK;
     if (k < 1 || k > kKMax) return fail(FIR_ERR_ARG, "k=%d outside [1,%d]", k, kKMax);
+    int32_t start_pos = 0;
+    const int rc = check_range(g, start_pos, end_pos);
+    if (rc) return rc;
     FIR_HIP(hipSetDevice(g->device));
-    return topk_dev(g, d_queries, qb, 0, g->d, k, d_keys, stream ? (hipStream_t)stream : g->stream, true, false);
+    return topk_dev(g, d_queries, qb, 0, end_pos, k, d_keys, stream ? (hipStream_t)stream : g->stream, true, false);
 }
 
 int fir_search_top1_keys_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start_pos, int32_t end_pos,

@@ -628,7 +628,8 @@ __global__ void __launch_bounds__(256) k_gemm_absmax(const float4* __restrict__ 
 
 // tiled f32 gallery * scale (a power of two) -> gh[(rb * dk16 + kb)][lane] (uint4 = 8 fp16), round to nearest even
 __global__ void __launch_bounds__(256) k_gemm_pack_gallery_f16(const float4* __restrict__ gal4, int64_t n, int dp4, int dk16, float scale,
-                                                                uint4* __restrict__ gh) {
+                                                                uint4* __restrict__ gh, int kmax) {
+    // kmax: features [0, kmax) of every row are packed, the rest of the fragments is zero (kmax = dp4 * 4: the whole row)
     const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;      // (rb, kb, lane)
     const int64_t rblocks = (n + 31) / 32;
     if (o >= rblocks * dk16 * 64) return;
@@ -643,7 +644,7 @@ __global__ void __launch_bounds__(256) k_gemm_pack_gallery_f16(const float4* __r
     for (int j = 0; j < 8; ++j) {
         const int k = 16 * kb + 8 * h + j;
         float x = 0.f;
-        if (row < n && k < dp4 * 4) {
+        if (row < n && k < kmax) {
             const float4 g = gal4[((row >> 6) * dp4 + (k >> 2)) * 64 + (row & 63)];
             x = (k & 3) == 0 ? g.x : (k & 3) == 1 ? g.y : (k & 3) == 2 ? g.z : g.w;
         }
@@ -659,13 +660,13 @@ __global__ void __launch_bounds__(256) k_gemm_pack_gallery_f16(const float4* __r
 // A query whose scale would leave [2^-100, 2^100], or with a non-finite value, gets qinv = NaN: every proxy is then NaN,
 // nothing is certified and the exact scan answers it.
 __global__ void __launch_bounds__(64) k_gemm_qprep_f16(const float* __restrict__ q, int nq, int d, int gallery_exp, float* __restrict__ qnorm,
-                                                        float* __restrict__ qmul, float* __restrict__ qinv) {
+                                                        float* __restrict__ qmul, float* __restrict__ qinv, int qstride) {
     const int qi = blockIdx.x;
     float s = 0.f, m = 0.f;
     bool bad = false;
     if (qi < nq)
         for (int k = threadIdx.x; k < d; k += 64) {
-            const float x = q[(size_t)qi * d + k];
+            const float x = q[(size_t)qi * qstride + k];
             s += x * x;
             m = fmaxf(m, fabsf(x));
             bad = bad || !(fabsf(x) < __builtin_huge_valf());
@@ -689,7 +690,8 @@ __global__ void __launch_bounds__(64) k_gemm_qprep_f16(const float* __restrict__
 }
 
 // queries * qmul -> qh[((pair * 4 + jb) * dk16 + kb)][lane] (uint4 = 8 fp16); blockIdx.y = pair of 64-query passes
-__global__ void __launch_bounds__(256) k_gemm_pack_queries_f16(const float* q, int nq, int d, int dk16, const float* __restrict__ qmul, uint4* qh) {
+__global__ void __launch_bounds__(256) k_gemm_pack_queries_f16(const float* q, int nq, int d, int dk16, const float* __restrict__ qmul, uint4* qh,
+                                                                int qstride) {
     const int q_base = (int)blockIdx.y * 2 * kQT;
     qh += (size_t)blockIdx.y * 4 * dk16 * 64;
     const int o = blockIdx.x * 256 + threadIdx.x;
@@ -703,7 +705,7 @@ __global__ void __launch_bounds__(256) k_gemm_pack_queries_f16(const float* q, i
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int k = 16 * kb + 8 * h + j;
-        const float x = (qi < nq && k < d) ? q[(size_t)qi * d + k] : 0.f;
+        const float x = (qi < nq && k < d) ? q[(size_t)qi * qstride + k] : 0.f;
         v[j] = (_Float16)(x * mul);
     }
     uint4 u;
@@ -1052,7 +1054,7 @@ __global__ void __launch_bounds__(64) k_gemm_rerank(const unsigned long long* __
                                                      const float* __restrict__ tau, const float4* __restrict__ gal4,
                                                      const float* __restrict__ queries, const float* __restrict__ qnorm,
                                                      const float* __restrict__ gnorm_max_p, int64_t n, int d, int dp4, int64_t row_offset, float e_rel,
-                                                     int ngroup, unsigned long long* __restrict__ out_key, int* __restrict__ ok) {
+                                                     int ngroup, unsigned long long* __restrict__ out_key, int* __restrict__ ok, int qstride) {
     const int q = blockIdx.x, lane = threadIdx.x;
     const int cnt = counts[q];
     const int have = cnt < kListCap ? cnt : kListCap;
@@ -1073,7 +1075,8 @@ __global__ void __launch_bounds__(64) k_gemm_rerank(const unsigned long long* __
     const float p1 = kmin != kKeyNone ? fir::f32_from_orderable((uint32_t)(kmin >> 32)) : __builtin_huge_valf();
     float win = p1 + 2.0f * E * (float)d;
     win += fabsf(win) * 1e-6f;
-    const float* qv = queries + (size_t)q * d;
+    const float* qv = queries + (size_t)q * qstride;
+    const int d4 = (d + 3) >> 2;                                  // float4 chunks of the compared features (a prefix of the row when d < its length)
     unsigned long long best = kKeyNone;
     float p_out = __builtin_huge_valf();            // smallest proxy NOT re-ranked
     int reranked = 0;
@@ -1101,7 +1104,7 @@ __global__ void __launch_bounds__(64) k_gemm_rerank(const unsigned long long* __
                     const unsigned long long cv = __shfl((unsigned long long)v, src, 64);
                     const int64_t row = (int64_t)(uint32_t)(cv & 0xFFFFFFFFull);
                     const float4* gr = gal4 + (size_t)(row >> 6) * dp4 * 64 + (row & 63);
-                    for (int c = lane; c < dp4; c += 64) crow[(size_t)g * dp4 + c] = gr[(size_t)c * 64];
+                    for (int c = lane; c < d4; c += 64) crow[(size_t)g * dp4 + c] = gr[(size_t)c * 64];
                     if (lane == g) mine = cv;
                     ++ng;
                 }
@@ -1110,7 +1113,7 @@ __global__ void __launch_bounds__(64) k_gemm_rerank(const unsigned long long* __
             if (lane < ng) {
                 const float4* my = crow + (size_t)lane * dp4;
                 float acc = 0.0f;
-                for (int c = 0; c < dp4; ++c) {
+                for (int c = 0; c < d4; ++c) {
                     const float4 g4 = my[c], q4 = qrow[c];
                     acc = fir::accum<fir::kL2>(acc, q4.x, g4.x);
                     acc = fir::accum<fir::kL2>(acc, q4.y, g4.y);
@@ -1157,7 +1160,7 @@ __global__ void __launch_bounds__(64) k_gemm_rerank_topk(const unsigned long lon
                                                           const float* __restrict__ queries, const float* __restrict__ qnorm,
                                                           const float* __restrict__ gnorm_max_p, int64_t n, int d, int dp4, int64_t row_offset,
                                                           float e_rel, int ngroup, int k, unsigned long long* __restrict__ out_key,
-                                                          int* __restrict__ ok) {
+                                                          int* __restrict__ ok, int qstride) {
     const int q = blockIdx.x, lane = threadIdx.x;
     const int cnt = counts[q];
     const int have = cnt < kListCap ? cnt : kListCap;
@@ -1182,7 +1185,8 @@ __global__ void __launch_bounds__(64) k_gemm_rerank_topk(const unsigned long lon
     const float pk = found == k ? fir::f32_from_orderable((uint32_t)(kth >> 32)) : __builtin_huge_valf();   // a short list is re-ranked whole
     float win = pk + 2.0f * E * (float)d;
     win += fabsf(win) * 1e-6f;
-    const float* qv = queries + (size_t)q * d;
+    const float* qv = queries + (size_t)q * qstride;
+    const int d4 = (d + 3) >> 2;                                  // float4 chunks of the compared features (a prefix of the row when d < its length)
     unsigned long long best[kTopKMax];
 #pragma unroll
     for (int i = 0; i < kTopKMax; ++i) best[i] = kKeyNone;
@@ -1210,7 +1214,7 @@ __global__ void __launch_bounds__(64) k_gemm_rerank_topk(const unsigned long lon
                     const unsigned long long cv = __shfl((unsigned long long)v, src, 64);
                     const int64_t row = (int64_t)(uint32_t)(cv & 0xFFFFFFFFull);
                     const float4* gr = gal4 + (size_t)(row >> 6) * dp4 * 64 + (row & 63);
-                    for (int c = lane; c < dp4; c += 64) crow[(size_t)g * dp4 + c] = gr[(size_t)c * 64];
+                    for (int c = lane; c < d4; c += 64) crow[(size_t)g * dp4 + c] = gr[(size_t)c * 64];
                     if (lane == g) mine = cv;
                     ++ng;
                 }
@@ -1219,7 +1223,7 @@ __global__ void __launch_bounds__(64) k_gemm_rerank_topk(const unsigned long lon
             if (lane < ng) {
                 const float4* my = crow + (size_t)lane * dp4;
                 float acc = 0.0f;
-                for (int c = 0; c < dp4; ++c) {
+                for (int c = 0; c < d4; ++c) {
                     const float4 g4 = my[c], q4 = qrow[c];
                     acc = fir::accum<fir::kL2>(acc, q4.x, g4.x);
                     acc = fir::accum<fir::kL2>(acc, q4.y, g4.y);
@@ -1271,11 +1275,11 @@ __global__ void __launch_bounds__(64) k_gemm_rerank_topk(const unsigned long lon
 }
 
 // gnorm[row] = |g|^2 (one thread per row; any summation order is covered by the certificate's E).
-__global__ void __launch_bounds__(256) k_gemm_row_norms(const float4* __restrict__ gal4, int64_t n, int dp4, float* __restrict__ gnorm) {
+__global__ void __launch_bounds__(256) k_gemm_row_norms(const float4* __restrict__ gal4, int64_t n, int dp4, float* __restrict__ gnorm, int d4) {
     const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (row >= n) return;
     float s = 0.f;
-    for (int c = 0; c < dp4; ++c) {
+    for (int c = 0; c < d4; ++c) {
         const float4 g = gal4[((row >> 6) * dp4 + c) * 64 + (row & 63)];
         s += g.x * g.x + g.y * g.y + g.z * g.z + g.w * g.w;
     }
@@ -1300,6 +1304,7 @@ struct fir_gemm {
     fir_gallery_view v;
     const float4* gal4 = nullptr;
     int dp4 = 0, dq8 = 0;
+    int feat = 0;               // features compared: the gallery's d, or a prefix [0, feat) of every row (fir_gemm_create_range); v.d stays the row length
     int precision = 0;          // 0: f32 MFMA, 1: bf16 split (hi.hi + hi.lo + lo.hi), 2: one fp16 term
     uint4* gh = nullptr;        // fp16 fragments (precision 2)
     int gallery_exp = 0;        // fp16: the gallery was multiplied by 2^gallery_exp
@@ -1339,9 +1344,11 @@ struct fir_gemm {
 
 extern "C" {
 
-int fir_gemm_create(fir_gallery* g, fir_gemm** out) { return fir_gemm_create_ex(g, FIR_GEMM_F16, out); }
+int fir_gemm_create(fir_gallery* g, fir_gemm** out) { return fir_gemm_create_range(g, FIR_GEMM_F16, 0, out); }
 
-int fir_gemm_create_ex(fir_gallery* g, int32_t precision, fir_gemm** out) {
+int fir_gemm_create_ex(fir_gallery* g, int32_t precision, fir_gemm** out) { return fir_gemm_create_range(g, precision, 0, out); }
+
+int fir_gemm_create_range(fir_gallery* g, int32_t precision, int32_t end_pos, fir_gemm** out) {
     if (!g || !out) return gemm_fail(FIR_ERR_ARG, "NULL argument");
     if (precision != FIR_GEMM_F32 && precision != FIR_GEMM_BF16_SPLIT && precision != FIR_GEMM_F16)
         return gemm_fail(FIR_ERR_ARG, "bad precision %d", precision);
@@ -1353,10 +1360,18 @@ int fir_gemm_create_ex(fir_gallery* g, int32_t precision, fir_gemm** out) {
     if (fir_gallery_view_(g, &m->v) != FIR_OK || fir_gallery_tiled_(g, &gp, &m->dp4) != FIR_OK) { delete m; return gemm_fail(FIR_ERR_ARG, "bad gallery"); }
     m->gal4 = (const float4*)gp;
     m->precision = precision;
+    // a prefix [0, end_pos) of every row (the reference's "BF, 64" / "BF, 256" classifiers, ImageTesting.cpp:526-529): its own
+    // fp16 fragments and row norms; whole 16-feature k-blocks, fp16 form only
+    m->feat = end_pos > 0 && end_pos < m->v.d ? end_pos : m->v.d;
+    if (end_pos < 0 || end_pos > m->v.d || (m->feat != m->v.d && (m->feat % 16 != 0 || precision != FIR_GEMM_F16))) {
+        const int dd = m->v.d;
+        delete m;
+        return gemm_fail(FIR_ERR_ARG, "feature prefix [0,%d) of %d: multiples of 16 inside the row, fp16 form only", end_pos, dd);
+    }
     if (const char* w = std::getenv("FIR_GEMM_WIDE")) m->wide = std::atoi(w) != 0;   // experiments: 0 = one pass per gallery read
-    m->dq8 = (m->v.d + 31) / 32 * 4;     // feature groups of 8, padded to a multiple of 4 groups (zeros)
-    m->dk16 = (m->v.d + 127) / 128 * 8;  // k-blocks of 16, padded to a multiple of 8 (the paired-pass kernel's double-buffer unit)
-    if (precision == FIR_GEMM_F16) m->dk16 = (m->v.d + 16 * kRing - 1) / (16 * kRing) * kRing;   // ... to whole double-buffer units
+    m->dq8 = (m->feat + 31) / 32 * 4;     // feature groups of 8, padded to a multiple of 4 groups (zeros)
+    m->dk16 = (m->feat + 127) / 128 * 8;  // k-blocks of 16, padded to a multiple of 8 (the paired-pass kernel's double-buffer unit)
+    if (precision == FIR_GEMM_F16) m->dk16 = (m->feat + 16 * kRing - 1) / (16 * kRing) * kRing;   // ... to whole double-buffer units
     hipError_t e = hipSetDevice(m->v.device);
     const int64_t rblocks = (std::max<int64_t>(m->v.n, 1) + 31) / 32;
     const int64_t np = std::max<int64_t>(m->v.n, 1);
@@ -1419,7 +1434,7 @@ int fir_gemm_create_ex(fir_gallery* g, int32_t precision, fir_gemm** out) {
             const int64_t totalb = rblocks * m->dk16 * 64;
             hipLaunchKernelGGL(k_gemm_pack_gallery_bf16, dim3((unsigned)((totalb + 255) / 256)), dim3(256), 0, m->v.stream, m->gal4, m->v.n, m->dp4,
                                m->dk16, m->gb);
-            hipLaunchKernelGGL(k_gemm_row_norms, dim3((unsigned)((m->v.n + 255) / 256)), dim3(256), 0, m->v.stream, m->gal4, m->v.n, m->dp4, m->gnorm);
+            hipLaunchKernelGGL(k_gemm_row_norms, dim3((unsigned)((m->v.n + 255) / 256)), dim3(256), 0, m->v.stream, m->gal4, m->v.n, m->dp4, m->gnorm, (m->feat + 3) / 4);
         }
         if (precision == FIR_GEMM_F16) {
             // one power-of-two scale for the whole gallery: its largest |value| lands in [2^13, 2^14)
@@ -1435,8 +1450,8 @@ int fir_gemm_create_ex(fir_gallery* g, int32_t precision, fir_gemm** out) {
             const float scale = (m->gallery_exp >= -100 && m->gallery_exp <= 100) ? std::ldexp(1.0f, m->gallery_exp) : 0.f;
             const int64_t totalh = rblocks * m->dk16 * 64;
             hipLaunchKernelGGL(k_gemm_pack_gallery_f16, dim3((unsigned)((totalh + 255) / 256)), dim3(256), 0, m->v.stream, m->gal4, m->v.n, m->dp4,
-                               m->dk16, scale, m->gh);
-            hipLaunchKernelGGL(k_gemm_row_norms, dim3((unsigned)((m->v.n + 255) / 256)), dim3(256), 0, m->v.stream, m->gal4, m->v.n, m->dp4, m->gnorm);
+                               m->dk16, scale, m->gh, m->feat == m->v.d ? m->dp4 * 4 : m->feat);
+            hipLaunchKernelGGL(k_gemm_row_norms, dim3((unsigned)((m->v.n + 255) / 256)), dim3(256), 0, m->v.stream, m->gal4, m->v.n, m->dp4, m->gnorm, (m->feat + 3) / 4);
         }
         const int64_t total = precision == FIR_GEMM_F32 ? rblocks * m->dq8 * 64 : 0;
         if (total > 0)
@@ -1493,11 +1508,12 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
     if (qb == 0) return FIR_OK;
     GEMM_HIP(hipSetDevice(m->v.device));
     hipStream_t st = stream ? (hipStream_t)stream : m->v.stream;
-    const int d = m->v.d;
+    const int d = m->feat;          // features compared
+    const int qs = m->v.d;          // floats between consecutive queries (and gallery rows): the whole row
     const int64_t n = m->v.n;
     if (n == 0)
-        return k == 1 ? fir_search_top1_exact_keys_dev_(m->g, d_queries, qb, 0, 0, d_keys, st)
-                      : fir_search_topk_exact_keys_dev_(m->g, d_queries, qb, k, d_keys, st);
+        return k == 1 ? fir_search_top1_exact_keys_dev_(m->g, d_queries, qb, 0, d, d_keys, st)
+                      : fir_search_topk_exact_keys_dev_(m->g, d_queries, qb, d, k, d_keys, st);
     if ((size_t)qb > m->ok_cap) {
         if (m->ok) GEMM_HIP(hipFree(m->ok));
         m->ok = nullptr;
@@ -1542,13 +1558,13 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
         const int nq = std::min(kPasses * kQT, qb - q0);
         const int np = (nq + kQT - 1) / kQT;
         const int b = sb & 1;
-        const float* dq = d_queries + (size_t)q0 * d;
+        const float* dq = d_queries + (size_t)q0 * qs;
         if (m->precision == FIR_GEMM_F16) {
             const int pairs = (np + 1) / 2;                      // 128 queries per gallery read; a half-filled pair is zero-padded
-            hipLaunchKernelGGL(k_gemm_qprep_f16, dim3(pairs * 2 * kQT), dim3(64), 0, ps, dq, nq, d, m->gallery_exp, m->qnorm[b], m->qmul[b], m->qinv[b]);
+            hipLaunchKernelGGL(k_gemm_qprep_f16, dim3(pairs * 2 * kQT), dim3(64), 0, ps, dq, nq, d, m->gallery_exp, m->qnorm[b], m->qmul[b], m->qinv[b], qs);
             GEMM_HIP(hipMemsetAsync(m->counts[b], 0, (size_t)pairs * 2 * kQT * sizeof(int), ps));
             hipLaunchKernelGGL(k_gemm_pack_queries_f16, dim3((4 * m->dk16 * 64 + 255) / 256, pairs), dim3(256), 0, ps, dq, nq, d, m->dk16, m->qmul[b],
-                               m->qbf[b]);
+                               m->qbf[b], qs);
             if (rt_flow) {
                 // the smallest proxy of a row sample per query (register-tile kernel over rows [0, rt_sample_rows)), tau = that + one window
                 GEMM_HIP(hipMemsetD32Async((hipDeviceptr_t)m->smin[b], (int)0xFF800000u, (size_t)pairs * 2 * kQT, ps));
@@ -1606,7 +1622,7 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
         const int nq = std::min(kPasses * kQT, qb - q0);
         const int np = (nq + kQT - 1) / kQT;
         const int b = sb & 1;
-        const float* dq = d_queries + (size_t)q0 * d;
+        const float* dq = d_queries + (size_t)q0 * qs;
         if (sb + 1 < nsb && (rcp = prep(sb + 1))) return rcp;
         GEMM_HIP(hipStreamWaitEvent(st, m->prep_done[b], 0));
         // ---- the full pass(es) over the gallery: the launch fir_profile_read times and fir_gallery_last_dispatch names ----
@@ -1691,11 +1707,11 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
         if (k == 1)
             hipLaunchKernelGGL(k_gemm_rerank, dim3(nq), dim3(64), (size_t)(m->rerank_group + 1) * m->dp4 * sizeof(float4), m->side, m->lists[b], m->counts[b],
                                m->tau[b], m->gal4, dq, m->qnorm[b], m->gmax, n, d, m->dp4, m->v.row_offset, e_rel, m->rerank_group,
-                               (unsigned long long*)d_keys + q0, m->ok + q0);
+                               (unsigned long long*)d_keys + q0, m->ok + q0, qs);
         else
             hipLaunchKernelGGL(k_gemm_rerank_topk, dim3(nq), dim3(64), (size_t)(m->rerank_group + 1) * m->dp4 * sizeof(float4), m->side, m->lists[b],
                                m->counts[b], m->tau[b], m->gal4, dq, m->qnorm[b], m->gmax, n, d, m->dp4, m->v.row_offset, e_rel, m->rerank_group, k,
-                               (unsigned long long*)d_keys + (size_t)q0 * k, m->ok + q0);
+                               (unsigned long long*)d_keys + (size_t)q0 * k, m->ok + q0, qs);
         GEMM_HIP(hipEventRecord(m->rerank_done[b], m->side));
         m->passes += np;
     }
@@ -1712,9 +1728,9 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
     for (size_t f0 = 0; f0 < which.size(); f0 += kQT) {
         const int nf = (int)std::min<size_t>(kQT, which.size() - f0);
         for (int i = 0; i < nf; ++i)
-            GEMM_HIP(hipMemcpyAsync(m->fbq + (size_t)i * d, d_queries + (size_t)which[f0 + i] * d, (size_t)d * sizeof(float), hipMemcpyDeviceToDevice, st));
-        int rc = k == 1 ? fir_search_top1_exact_keys_dev_(m->g, m->fbq, nf, 0, 0, (uint64_t*)m->fbkeys, st)
-                        : fir_search_topk_exact_keys_dev_(m->g, m->fbq, nf, k, (uint64_t*)m->fbkeys, st);
+            GEMM_HIP(hipMemcpyAsync(m->fbq + (size_t)i * qs, d_queries + (size_t)which[f0 + i] * qs, (size_t)qs * sizeof(float), hipMemcpyDeviceToDevice, st));
+        int rc = k == 1 ? fir_search_top1_exact_keys_dev_(m->g, m->fbq, nf, 0, d, (uint64_t*)m->fbkeys, st)
+                        : fir_search_topk_exact_keys_dev_(m->g, m->fbq, nf, d, k, (uint64_t*)m->fbkeys, st);
         if (rc) return rc;
         for (int i = 0; i < nf; ++i)
             GEMM_HIP(hipMemcpyAsync(d_keys + (size_t)which[f0 + i] * k, m->fbkeys + (size_t)i * k, (size_t)k * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));

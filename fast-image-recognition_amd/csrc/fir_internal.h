@@ -52,8 +52,8 @@ extern "C" int fir_gallery_wait_ticket_(fir_gallery* g, volatile uint64_t* flag,
 extern "C" int fir_search_top1_exact_keys_dev_(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start_pos, int32_t end_pos,
                                                uint64_t* d_keys, void* stream);
 
-// ... and the exact K-nearest-rows forms (whole feature range), never through fir_gemm_*.
-extern "C" int fir_search_topk_exact_keys_dev_(fir_gallery* g, const float* d_queries, int32_t qb, int32_t k, uint64_t* d_keys, void* stream);
+// ... and the exact K-nearest-rows form over features [0, end_pos), never through fir_gemm_*.
+extern "C" int fir_search_topk_exact_keys_dev_(fir_gallery* g, const float* d_queries, int32_t qb, int32_t end_pos, int32_t k, uint64_t* d_keys, void* stream);
 
 // fir_profile_enable / fir_profile_read / fir_gallery_last_dispatch for kernels launched by the other translation units:
 // an event pair around ONE launch on `st` (no-ops unless profiling is on), and the record of the call's dominant kernel.

@@ -249,6 +249,10 @@ enum {
 };
 int fir_gemm_create(fir_gallery* g, fir_gemm** out);   /* = fir_gemm_create_ex(g, FIR_GEMM_F16, out) */
 int fir_gemm_create_ex(fir_gallery* g, int32_t precision, fir_gemm** out);
+/* ... over a feature prefix [0, end_pos) of every row (0 or d: the whole row): end_pos a multiple of 16, FIR_GEMM_F16 only.
+ * The reference's "BF, 64" / "BF, 256" classifiers (ImageTesting.cpp:526-529) compare prefixes; the search entry points
+ * route such batches here by themselves (start_pos == 0, end_pos % 16 == 0, end_pos >= 64, same thresholds). */
+int fir_gemm_create_range(fir_gallery* g, int32_t precision, int32_t end_pos, fir_gemm** out);
 int fir_gemm_destroy(fir_gemm* m);
 int fir_gemm_search_top1_keys_dev(fir_gemm* m, const float* d_queries, int32_t qb, uint64_t* d_keys, void* stream);
 /* The k nearest rows (2 <= k <= 8; k = 1 is the call above): d_keys[q * k + r], ascending, the keys fir_search_topk_keys_dev

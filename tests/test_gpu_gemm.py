@@ -302,3 +302,34 @@ def test_topk_matrix_cores_on_a_clustered_gallery_and_by_handle(fir):
     assert np.array_equal(a[0], e[0]) and np.array_equal(a[1].view(np.uint32), e[1].view(np.uint32))
     assert np.array_equal(hidx.reshape(-1, k), e[0]) and np.array_equal(hdist.reshape(-1, k).view(np.uint32), e[1].view(np.uint32))
     assert st["fallback_queries"] <= 256
+
+
+@pytest.mark.parametrize("n,d,end", [(70000, 512, 64), (70000, 512, 256), (66000, 200, 128), (70000, 1536, 64)])
+def test_feature_prefixes_through_the_matrix_cores(fir, oracle, n, d, end):
+    """The reference's "BF, 64" / "BF, 256" classifiers compare a prefix [0, end) of every row (ImageTesting.cpp:526-529). Large
+    batches of such calls take the matrix cores too (own fp16 fragments and norms of the prefix): the exact scan's keys, for
+    top-1 and top-K, ties and all; another prefix replaces the cached one; prefixes that are not whole k-blocks stay with the scan."""
+    rows = synth.make_gallery(end, n, d, 0)
+    q, _ = synth.make_queries(end, rows, 200, 0)
+    rows[300, :end] = rows[n - 5, :end]               # equal on the prefix, different beyond it
+    q[2] = rows[n - 5]
+    with fir.Gallery(rows, None, 0, 0) as g:
+        a = g.search_top1(q, 0, end)
+        da = g.last_dispatch()
+        a5 = g.search_topk(q, 5, 0, end)
+        w = g.search_top1(q)                          # the whole row in between
+        other = 128 if end != 128 else 64
+        b = g.search_top1(q, 0, other)
+        odd = g.search_top1(q, 0, end + 4)            # not a multiple of 16
+        assert g.last_dispatch()["path"] == "scan"
+        g.set_large_batch_mfma(0)
+        e = g.search_top1(q, 0, end)
+        e5 = g.search_topk(q, 5, 0, end)
+        ew = g.search_top1(q)
+        eb = g.search_top1(q, 0, other)
+    assert da["path"] == "mfma"
+    for x, y in ((a, e), (a5, e5), (w, ew), (b, eb)):
+        assert np.array_equal(x[0], y[0]) and np.array_equal(x[1].view(np.uint32), y[1].view(np.uint32))
+    assert a[0][2] == 300 and odd[0].shape == (200,)
+    for j in (0, 2, 199):
+        assert (a[0][j], a[1][j]) == oracle.recognize_bf(rows, q[j], 0, end, 0)
