@@ -984,17 +984,6 @@ int fir_feature_distance(const float* lhs, const float* rhs, int32_t len, int32_
 }
 
 namespace {
-// The matrix-core path for this call, if it applies: 0 = done, 1 = take the scan, < 0 = error.
-int ensure_gemm(fir_gallery* g, int32_t end, fir_gemm** m);
-}  // namespace
-namespace {
-int try_mfma_topk_impl(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start, int32_t end, int32_t k, uint64_t* d_keys, hipStream_t st) {
-    if (k < 2 || !wants_mfma(g, qb, start, end)) return 1;       // K = 1 callers use the top-1 entry points
-    fir_gemm* m = nullptr;
-    const int rc = ensure_gemm(g, end, &m);
-    if (rc) return rc;
-    return fir_gemm_search_topk_keys_dev(m, d_queries, qb, k, d_keys, st);
-}
 // 0 = *m is the handle's fir_gemm for features [0, end), 1 = this shape stays with the scan, < 0 = error
 int ensure_gemm(fir_gallery* g, int32_t end, fir_gemm** m) {
     const bool whole = end == g->d;
@@ -1016,6 +1005,7 @@ int ensure_gemm(fir_gallery* g, int32_t end, fir_gemm** m) {
     *m = slot;
     return 0;
 }
+// The matrix-core path for this call, if it applies: 0 = done, 1 = take the scan, < 0 = error.
 int try_mfma(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start, int32_t end, uint64_t* d_keys, hipStream_t st) {
     if (!wants_mfma(g, qb, start, end)) return 1;
     fir_gemm* m = nullptr;
@@ -1023,10 +1013,12 @@ int try_mfma(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start, 
     if (rc) return rc;
     return fir_gemm_search_top1_keys_dev(m, d_queries, qb, d_keys, st);
 }
-}  // namespace
-namespace {
 int try_mfma_topk(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start, int32_t end, int32_t k, uint64_t* d_keys, hipStream_t st) {
-    return try_mfma_topk_impl(g, d_queries, qb, start, end, k, d_keys, st);
+    if (k < 2 || !wants_mfma(g, qb, start, end)) return 1;       // K = 1 callers use the top-1 entry points
+    fir_gemm* m = nullptr;
+    const int rc = ensure_gemm(g, end, &m);
+    if (rc) return rc;
+    return fir_gemm_search_topk_keys_dev(m, d_queries, qb, k, d_keys, st);
 }
 }  // namespace
 

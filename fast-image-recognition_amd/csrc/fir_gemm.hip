@@ -1398,6 +1398,8 @@ int fir_gemm_create_range(fir_gallery* g, int32_t precision, int32_t end_pos, fi
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking);
     m->sample_rows = (int)std::min<int64_t>(np, std::max<int64_t>(kMinSampleRows, np / 64));
     m->rt_sample_rows = (int)std::min<int64_t>(np, std::max<int64_t>(kMinSampleRows, np / 16));
+    if (const char* w = std::getenv("FIR_GEMM_SAMPLE_DIV"))      // experiments
+        m->rt_sample_rows = (int)std::min<int64_t>(np, std::max<int64_t>(kMinSampleRows, np / std::max(1, std::atoi(w))));
     if (e == hipSuccess) e = hipMalloc((void**)&m->sample, (size_t)kPasses * kQT * m->sample_rows * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&m->fbq, (size_t)kQT * m->v.d * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&m->fbkeys, (size_t)kQT * kTopKMax * sizeof(unsigned long long));
@@ -1410,11 +1412,13 @@ int fir_gemm_create_range(fir_gallery* g, int32_t precision, int32_t end_pos, fi
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy_bf16_wide, hipFuncAttributeMaxDynamicSharedMemorySize, kWideLds);
     {   // the re-rank keeps the query and up to kRerankGroup candidate rows in LDS
         const size_t row_bytes = (size_t)m->dp4 * sizeof(float4);
-        m->rerank_group = (int)std::min<size_t>(kRerankGroup, kRerankLdsMax / row_bytes > 1 ? kRerankLdsMax / row_bytes - 1 : 0);
+        size_t want_group = kRerankGroup;
+        if (const char* w = std::getenv("FIR_GEMM_RERANK_GROUP")) want_group = (size_t)std::max(1, std::min(64, std::atoi(w)));      // experiments
+        m->rerank_group = (int)std::min<size_t>(want_group, kRerankLdsMax / row_bytes > 1 ? kRerankLdsMax / row_bytes - 1 : 0);
         if (m->rerank_group < 1) { delete m; return gemm_fail(FIR_ERR_ARG, "rows of %d features are too long for the matrix-core path's re-rank", m->v.d); }
-        if (e == hipSuccess && (size_t)(m->rerank_group + 1) * row_bytes > 64 * 1024)
+        if (e == hipSuccess && (size_t)(m->rerank_group + 1) * row_bytes > 48 * 1024)
             e = hipFuncSetAttribute((const void*)k_gemm_rerank, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRerankLdsMax);
-        if (e == hipSuccess && (size_t)(m->rerank_group + 1) * row_bytes > 64 * 1024)
+        if (e == hipSuccess && (size_t)(m->rerank_group + 1) * row_bytes > 48 * 1024)
             e = hipFuncSetAttribute((const void*)k_gemm_rerank_topk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRerankLdsMax);
     }
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy_f16<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kHalfLds);
