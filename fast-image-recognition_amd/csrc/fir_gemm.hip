@@ -1081,7 +1081,8 @@ __global__ void __launch_bounds__(64) k_gemm_rerank(const unsigned long long* __
     float p_out = __builtin_huge_valf();            // smallest proxy NOT re-ranked
     int reranked = 0;
     extern __shared__ __attribute__((aligned(16))) float4 crow[];     // [ngroup][dp4]: candidate rows, loaded by the whole wave
-    float4* qrow = crow + (size_t)ngroup * dp4;                 // [dp4]: the query, zero-padded like the gallery rows (a (0-0)^2 term adds +0)
+    const int cs = dp4 | 1;                                       // candidate-row stride in LDS, odd: the lanes' rows start in different banks
+    float4* qrow = crow + (size_t)ngroup * cs;                 // [dp4]: the query, zero-padded like the gallery rows (a (0-0)^2 term adds +0)
     for (int k = lane; k < dp4 * 4; k += 64) ((float*)qrow)[k] = k < d ? qv[k] : 0.0f;
     __syncthreads();
     for (int base = 0; base < have; base += 64) {
@@ -1104,14 +1105,14 @@ __global__ void __launch_bounds__(64) k_gemm_rerank(const unsigned long long* __
                     const unsigned long long cv = __shfl((unsigned long long)v, src, 64);
                     const int64_t row = (int64_t)(uint32_t)(cv & 0xFFFFFFFFull);
                     const float4* gr = gal4 + (size_t)(row >> 6) * dp4 * 64 + (row & 63);
-                    for (int c = lane; c < d4; c += 64) crow[(size_t)g * dp4 + c] = gr[(size_t)c * 64];
+                    for (int c = lane; c < d4; c += 64) crow[(size_t)g * cs + c] = gr[(size_t)c * 64];
                     if (lane == g) mine = cv;
                     ++ng;
                 }
             }
             __syncthreads();
             if (lane < ng) {
-                const float4* my = crow + (size_t)lane * dp4;
+                const float4* my = crow + (size_t)lane * cs;
                 float acc = 0.0f;
                 for (int c = 0; c < d4; ++c) {
                     const float4 g4 = my[c], q4 = qrow[c];
@@ -1193,7 +1194,8 @@ __global__ void __launch_bounds__(64) k_gemm_rerank_topk(const unsigned long lon
     float p_out = __builtin_huge_valf();            // smallest proxy NOT re-ranked
     int reranked = 0;
     extern __shared__ __attribute__((aligned(16))) float4 crow[];     // [ngroup][dp4] candidate rows, then [dp4] the query
-    float4* qrow = crow + (size_t)ngroup * dp4;
+    const int cs = dp4 | 1;                                       // candidate-row stride in LDS, odd: the lanes' rows start in different banks
+    float4* qrow = crow + (size_t)ngroup * cs;
     for (int c = lane; c < dp4 * 4; c += 64) ((float*)qrow)[c] = c < d ? qv[c] : 0.0f;
     __syncthreads();
     for (int base = 0; base < have; base += 64) {
@@ -1214,14 +1216,14 @@ __global__ void __launch_bounds__(64) k_gemm_rerank_topk(const unsigned long lon
                     const unsigned long long cv = __shfl((unsigned long long)v, src, 64);
                     const int64_t row = (int64_t)(uint32_t)(cv & 0xFFFFFFFFull);
                     const float4* gr = gal4 + (size_t)(row >> 6) * dp4 * 64 + (row & 63);
-                    for (int c = lane; c < d4; c += 64) crow[(size_t)g * dp4 + c] = gr[(size_t)c * 64];
+                    for (int c = lane; c < d4; c += 64) crow[(size_t)g * cs + c] = gr[(size_t)c * 64];
                     if (lane == g) mine = cv;
                     ++ng;
                 }
             }
             __syncthreads();
             if (lane < ng) {
-                const float4* my = crow + (size_t)lane * dp4;
+                const float4* my = crow + (size_t)lane * cs;
                 float acc = 0.0f;
                 for (int c = 0; c < d4; ++c) {
                     const float4 g4 = my[c], q4 = qrow[c];
@@ -1411,7 +1413,7 @@ int fir_gemm_create_range(fir_gallery* g, int32_t precision, int32_t end_pos, fi
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy_bf16<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy_bf16_wide, hipFuncAttributeMaxDynamicSharedMemorySize, kWideLds);
     {   // the re-rank keeps the query and up to kRerankGroup candidate rows in LDS
-        const size_t row_bytes = (size_t)m->dp4 * sizeof(float4);
+        const size_t row_bytes = (size_t)(m->dp4 + 1) * sizeof(float4);
         size_t want_group = kRerankGroup;
         if (const char* w = std::getenv("FIR_GEMM_RERANK_GROUP")) want_group = (size_t)std::max(1, std::min(64, std::atoi(w)));      // experiments
         m->rerank_group = (int)std::min<size_t>(want_group, kRerankLdsMax / row_bytes > 1 ? kRerankLdsMax / row_bytes - 1 : 0);
@@ -1707,16 +1709,17 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
         }
         GEMM_HIP(hipEventRecord(m->main_done[b], st));
         // exact re-rank + certificate of this super-batch on the side stream, under the next one's full pass
+        hipStream_t rs = m->side;
         GEMM_HIP(hipStreamWaitEvent(m->side, m->main_done[b], 0));
         if (k == 1)
-            hipLaunchKernelGGL(k_gemm_rerank, dim3(nq), dim3(64), (size_t)(m->rerank_group + 1) * m->dp4 * sizeof(float4), m->side, m->lists[b], m->counts[b],
+            hipLaunchKernelGGL(k_gemm_rerank, dim3(nq), dim3(64), (size_t)(m->rerank_group + 1) * (m->dp4 + 1) * sizeof(float4), rs, m->lists[b], m->counts[b],
                                m->tau[b], m->gal4, dq, m->qnorm[b], m->gmax, n, d, m->dp4, m->v.row_offset, e_rel, m->rerank_group,
                                (unsigned long long*)d_keys + q0, m->ok + q0, qs);
         else
-            hipLaunchKernelGGL(k_gemm_rerank_topk, dim3(nq), dim3(64), (size_t)(m->rerank_group + 1) * m->dp4 * sizeof(float4), m->side, m->lists[b],
+            hipLaunchKernelGGL(k_gemm_rerank_topk, dim3(nq), dim3(64), (size_t)(m->rerank_group + 1) * (m->dp4 + 1) * sizeof(float4), rs, m->lists[b],
                                m->counts[b], m->tau[b], m->gal4, dq, m->qnorm[b], m->gmax, n, d, m->dp4, m->v.row_offset, e_rel, m->rerank_group, k,
                                (unsigned long long*)d_keys + (size_t)q0 * k, m->ok + q0, qs);
-        GEMM_HIP(hipEventRecord(m->rerank_done[b], m->side));
+        GEMM_HIP(hipEventRecord(m->rerank_done[b], rs));
         m->passes += np;
     }
     GEMM_HIP(hipStreamWaitEvent(st, m->rerank_done[(nsb - 1) & 1], 0));   // join the side stream (it is in order: the last re-rank is the last thing on it)
