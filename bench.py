@@ -87,7 +87,7 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rows", type=int, default=1_000_000)
     ap.add_argument("--dim", type=int, default=512)
-    ap.add_argument("--batch", type=int, default=16384, help="query vectors per step of the headline loop")
+    ap.add_argument("--batch", type=int, default=32768, help="query vectors per step of the headline loop")
     ap.add_argument("--scan-batch", type=int, default=256, help="query vectors per step of the exact-scan loop (the HBM roofline)")
     ap.add_argument("--qpp", type=int, default=0, help="queries per gallery pass of the exact scan (0 = library default)")
     ap.add_argument("--waves", type=int, default=0)
