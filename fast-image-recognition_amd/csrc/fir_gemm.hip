@@ -1054,7 +1054,7 @@ __global__ void __launch_bounds__(64) k_gemm_rerank(const unsigned long long* __
                                                      const float* __restrict__ tau, const float4* __restrict__ gal4,
                                                      const float* __restrict__ queries, const float* __restrict__ qnorm,
                                                      const float* __restrict__ gnorm_max_p, int64_t n, int d, int dp4, int64_t row_offset, float e_rel,
-                                                     int ngroup, unsigned long long* __restrict__ out_key, int* __restrict__ ok, int qstride) {
+                                                     int ngroup, unsigned long long* __restrict__ out_key, int* __restrict__ ok, int qstride, const float4* __restrict__ rowmajor) {
     const int q = blockIdx.x, lane = threadIdx.x;
     const int cnt = counts[q];
     const int have = cnt < kListCap ? cnt : kListCap;
@@ -1104,8 +1104,13 @@ __global__ void __launch_bounds__(64) k_gemm_rerank(const unsigned long long* __
                     mask &= mask - 1;
                     const unsigned long long cv = __shfl((unsigned long long)v, src, 64);
                     const int64_t row = (int64_t)(uint32_t)(cv & 0xFFFFFFFFull);
-                    const float4* gr = gal4 + (size_t)(row >> 6) * dp4 * 64 + (row & 63);
-                    for (int c = lane; c < d4; c += 64) crow[(size_t)g * cs + c] = gr[(size_t)c * 64];
+                    if (rowmajor) {                                     // the row-major shadow copy: one contiguous row, coalesced
+                        const float4* gr = rowmajor + (size_t)row * d4;
+                        for (int c = lane; c < d4; c += 64) crow[(size_t)g * cs + c] = gr[c];
+                    } else {                                            // the tiled gallery: 16 bytes per KiB
+                        const float4* gr = gal4 + (size_t)(row >> 6) * dp4 * 64 + (row & 63);
+                        for (int c = lane; c < d4; c += 64) crow[(size_t)g * cs + c] = gr[(size_t)c * 64];
+                    }
                     if (lane == g) mine = cv;
                     ++ng;
                 }
@@ -1161,7 +1166,7 @@ __global__ void __launch_bounds__(64) k_gemm_rerank_topk(const unsigned long lon
                                                           const float* __restrict__ queries, const float* __restrict__ qnorm,
                                                           const float* __restrict__ gnorm_max_p, int64_t n, int d, int dp4, int64_t row_offset,
                                                           float e_rel, int ngroup, int k, unsigned long long* __restrict__ out_key,
-                                                          int* __restrict__ ok, int qstride) {
+                                                          int* __restrict__ ok, int qstride, const float4* __restrict__ rowmajor) {
     const int q = blockIdx.x, lane = threadIdx.x;
     const int cnt = counts[q];
     const int have = cnt < kListCap ? cnt : kListCap;
@@ -1215,8 +1220,13 @@ __global__ void __launch_bounds__(64) k_gemm_rerank_topk(const unsigned long lon
                     mask &= mask - 1;
                     const unsigned long long cv = __shfl((unsigned long long)v, src, 64);
                     const int64_t row = (int64_t)(uint32_t)(cv & 0xFFFFFFFFull);
-                    const float4* gr = gal4 + (size_t)(row >> 6) * dp4 * 64 + (row & 63);
-                    for (int c = lane; c < d4; c += 64) crow[(size_t)g * cs + c] = gr[(size_t)c * 64];
+                    if (rowmajor) {                                     // the row-major shadow copy: one contiguous row, coalesced
+                        const float4* gr = rowmajor + (size_t)row * d4;
+                        for (int c = lane; c < d4; c += 64) crow[(size_t)g * cs + c] = gr[c];
+                    } else {                                            // the tiled gallery: 16 bytes per KiB
+                        const float4* gr = gal4 + (size_t)(row >> 6) * dp4 * 64 + (row & 63);
+                        for (int c = lane; c < d4; c += 64) crow[(size_t)g * cs + c] = gr[(size_t)c * 64];
+                    }
                     if (lane == g) mine = cv;
                     ++ng;
                 }
@@ -1276,6 +1286,25 @@ __global__ void __launch_bounds__(64) k_gemm_rerank_topk(const unsigned long lon
     }
 }
 
+// rowmajor[row * d4 + c] = chunk c of row `row`: the re-rank's copy of the compared features. A row of the tiled gallery is d4
+// separate 16-byte pieces 1 KiB apart (~4x its size in 64-byte sectors per gather); here it is one contiguous run.
+__global__ void __launch_bounds__(256) k_gemm_untile(const float4* __restrict__ gal4, int64_t n, int dp4, int d4, float4* __restrict__ rowmajor) {
+    // one workgroup per (tile of 64 rows, group of 32 chunks): read coalesced along the rows, written coalesced along the chunks
+    __shared__ float4 t[32][65];
+    const int64_t tile = blockIdx.x;
+    const int c0 = blockIdx.y * 32;
+    for (int i = threadIdx.x; i < 32 * 64; i += 256) {
+        const int c = i >> 6, r = i & 63;
+        if (c0 + c < d4) t[c][r] = gal4[((size_t)tile * dp4 + c0 + c) * 64 + r];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 32; i += 256) {
+        const int r = i >> 5, c = i & 31;
+        const int64_t row = tile * 64 + r;
+        if (row < n && c0 + c < d4) rowmajor[(size_t)row * d4 + c0 + c] = t[c][r];
+    }
+}
+
 // gnorm[row] = |g|^2 (one thread per row; any summation order is covered by the certificate's E).
 __global__ void __launch_bounds__(256) k_gemm_row_norms(const float4* __restrict__ gal4, int64_t n, int dp4, float* __restrict__ gnorm, int d4) {
     const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -1309,6 +1338,7 @@ struct fir_gemm {
     int feat = 0;               // features compared: the gallery's d, or a prefix [0, feat) of every row (fir_gemm_create_range); v.d stays the row length
     int precision = 0;          // 0: f32 MFMA, 1: bf16 split (hi.hi + hi.lo + lo.hi), 2: one fp16 term
     uint4* gh = nullptr;        // fp16 fragments (precision 2)
+    float4* rowmajor = nullptr; // row-major f32 copy of the compared features for the re-rank's gathers (absent when HBM is short: the tiled gallery serves)
     int gallery_exp = 0;        // fp16: the gallery was multiplied by 2^gallery_exp
     float* qmul[2] = {nullptr, nullptr};
     float* qinv[2] = {nullptr, nullptr};
@@ -1464,6 +1494,27 @@ int fir_gemm_create_range(fir_gallery* g, int32_t precision, int32_t end_pos, fi
         hipLaunchKernelGGL(k_gemm_pack_gallery, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, m->v.stream, m->gal4, m->v.n, m->dp4, m->dq8,
                            m->gm, m->gnorm);
         hipLaunchKernelGGL(k_gemm_max, dim3(1), dim3(256), 0, m->v.stream, m->gnorm, m->v.n, m->gmax);
+        // The re-rank's row-major copy of the compared features, when it leaves at least three times its size of HBM free
+        // (FIR_GEMM_ROWMAJOR=0 / 1: never / whenever it can be allocated)
+        {
+            const int d4 = (m->feat + 3) / 4;
+            const size_t want = (size_t)m->v.n * d4 * sizeof(float4);
+            size_t free_b = 0, total_b = 0;
+            int mode = -1;
+            if (const char* w = std::getenv("FIR_GEMM_ROWMAJOR")) mode = std::atoi(w);
+            const bool room = hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b >= 4 * want;
+            if (mode != 0 && (room || mode > 0) && hipMalloc((void**)&m->rowmajor, want) == hipSuccess) {
+                const int64_t tiles = (m->v.n + 63) / 64;
+                for (int64_t t0 = 0; t0 < tiles; t0 += 65535 * 16) {      // gridDim.x limit: slabs of tiles
+                    const int64_t nt = std::min<int64_t>(tiles - t0, 65535 * 16);
+                    hipLaunchKernelGGL(k_gemm_untile, dim3((unsigned)nt, (unsigned)((d4 + 31) / 32)), dim3(256), 0, m->v.stream, m->gal4 + (size_t)t0 * m->dp4 * 64,
+                                       m->v.n - t0 * 64, m->dp4, d4, m->rowmajor + (size_t)t0 * 64 * d4);
+                }
+            } else {
+                (void)hipGetLastError();
+                m->rowmajor = nullptr;
+            }
+        }
         e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(m->v.stream);
     }
@@ -1488,7 +1539,7 @@ int fir_gemm_destroy(fir_gemm* m) {
         if (m->prep_done[b]) (void)hipEventDestroy(m->prep_done[b]);
     }
     if (m->queries_ready) (void)hipEventDestroy(m->queries_ready);
-    (void)hipFree(m->gm); (void)hipFree(m->gb); (void)hipFree(m->gh); (void)hipFree(m->gnorm); (void)hipFree(m->gmax); (void)hipFree(m->sample); (void)hipFree(m->ok);
+    (void)hipFree(m->gm); (void)hipFree(m->gb); (void)hipFree(m->gh); (void)hipFree(m->rowmajor); (void)hipFree(m->gnorm); (void)hipFree(m->gmax); (void)hipFree(m->sample); (void)hipFree(m->ok);
     (void)hipFree(m->fbq); (void)hipFree(m->fbkeys);
     delete m;
     return FIR_OK;
@@ -1714,11 +1765,11 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
         if (k == 1)
             hipLaunchKernelGGL(k_gemm_rerank, dim3(nq), dim3(64), (size_t)(m->rerank_group + 1) * (m->dp4 + 1) * sizeof(float4), rs, m->lists[b], m->counts[b],
                                m->tau[b], m->gal4, dq, m->qnorm[b], m->gmax, n, d, m->dp4, m->v.row_offset, e_rel, m->rerank_group,
-                               (unsigned long long*)d_keys + q0, m->ok + q0, qs);
+                               (unsigned long long*)d_keys + q0, m->ok + q0, qs, m->rowmajor);
         else
             hipLaunchKernelGGL(k_gemm_rerank_topk, dim3(nq), dim3(64), (size_t)(m->rerank_group + 1) * (m->dp4 + 1) * sizeof(float4), rs, m->lists[b],
                                m->counts[b], m->tau[b], m->gal4, dq, m->qnorm[b], m->gmax, n, d, m->dp4, m->v.row_offset, e_rel, m->rerank_group, k,
-                               (unsigned long long*)d_keys + (size_t)q0 * k, m->ok + q0, qs);
+                               (unsigned long long*)d_keys + (size_t)q0 * k, m->ok + q0, qs, m->rowmajor);
         GEMM_HIP(hipEventRecord(m->rerank_done[b], rs));
         m->passes += np;
     }
