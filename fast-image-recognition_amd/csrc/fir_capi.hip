@@ -996,8 +996,8 @@ int ensure_gemm(fir_gallery* g, int32_t end, fir_gemm** m) {
         const int rc = fir_gemm_create_range(g, FIR_GEMM_F16, whole ? 0 : end, &slot);
         if (rc) {
             slot = nullptr;
-            if (g->large_batch_min > 0 || rc != FIR_ERR_ARG) return rc;    // asked for explicitly, or a real failure
-            g->gemm_failed = true;                                           // automatic: this shape stays with the scan
+            if (g->large_batch_min > 0 || (rc != FIR_ERR_ARG && rc != FIR_ERR_NOMEM)) return rc;    // asked for explicitly, or a real failure
+            g->gemm_failed = true;                                           // automatic: this shape (or this much HBM) stays with the scan
             return 1;
         }
         if (!whole) g->gemm_prefix_end = end;
