@@ -1367,7 +1367,7 @@ struct fir_gemm {
     int streamed = -1;                    // fp16: query slabs through the LDS double buffer (-1: when the tile does not fit, d > 512)
     bool wide = true;                     // bf16: pairs of passes through k_gemm_proxy_bf16_wide (FIR_GEMM_WIDE=0 turns it off)
     unsigned int* smin[2] = {nullptr, nullptr};   // register-tile flow: smallest sampled proxy per query (orderable bits)
-    int rt_sample_rows = 0;                // ... over this many rows (n / 16)
+    int rt_sample_rows = 0;                // ... over this many rows (n / 32)
     int regtile = -1;                     // fp16 full pass through the register-tile kernel: -1 = where it measured faster (rows up to 256 features), 0 / 1 = never / wherever it exists (FIR_GEMM_REGTILE)                  // fp16 full pass: query fragments in registers, gallery through the LDS-DMA ring (FIR_GEMM_REGTILE=0: the LDS-tile kernel)
     int share_max = 8;                    // fp16: up to this many pairs of passes (x 128 queries) read the gallery together in one launch (FIR_GEMM_SHARE; 0 = the old one-pair-at-a-time grid)
 };
@@ -1429,7 +1429,7 @@ int fir_gemm_create_range(fir_gallery* g, int32_t precision, int32_t end_pos, fi
     if (e == hipSuccess) e = hipEventCreateWithFlags(&m->queries_ready, hipEventDisableTiming);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking);
     m->sample_rows = (int)std::min<int64_t>(np, std::max<int64_t>(kMinSampleRows, np / 64));
-    m->rt_sample_rows = (int)std::min<int64_t>(np, std::max<int64_t>(kMinSampleRows, np / 16));
+    m->rt_sample_rows = (int)std::min<int64_t>(np, std::max<int64_t>(kMinSampleRows, np / 32));    // n/16 .. n/48 measured: 1.022 / 1.038 / 1.028 M queries/s at 1M x 512
     if (const char* w = std::getenv("FIR_GEMM_SAMPLE_DIV"))      // experiments
         m->rt_sample_rows = (int)std::min<int64_t>(np, std::max<int64_t>(kMinSampleRows, np / std::max(1, std::atoi(w))));
     if (e == hipSuccess) e = hipMalloc((void**)&m->sample, (size_t)kPasses * kQT * m->sample_rows * sizeof(float));
