@@ -42,7 +42,7 @@ constexpr int kGemmMinBlocks = kGemmBlock <= 512 ? 2 : 1;
 constexpr int kQT = 64;                // queries per pass (2 accumulator tiles of 32 per wave)
 constexpr int kSlab8 = 64;             // query features staged in LDS at a time, in groups of 8 (512 features)
 constexpr int kSlab16 = 32;            // bf16 variant: k-blocks of 16 features staged at a time (512 features)
-constexpr int kPasses = 16;            // 64-query passes per super-batch (one set of launches, one set of scratch): 1024 queries
+constexpr int kPasses = 32;            // 64-query passes per super-batch (one set of launches, one set of scratch): 2048 queries
 constexpr int kCand = 8;               // tau = the kCand-th smallest SAMPLED proxy (so ~kCand * n / sample rows get appended)
 constexpr int kRerankGroup = 8;         // candidate rows staged in LDS at a time by the re-rank (fewer when rows are longer than ~4000 features)
 constexpr size_t kRerankLdsMax = 144 * 1024;
@@ -1369,7 +1369,7 @@ struct fir_gemm {
     unsigned int* smin[2] = {nullptr, nullptr};   // register-tile flow: smallest sampled proxy per query (orderable bits)
     int rt_sample_rows = 0;                // ... over this many rows (n / 32)
     int regtile = -1;                     // fp16 full pass through the register-tile kernel: -1 = where it measured faster (rows up to 256 features), 0 / 1 = never / wherever it exists (FIR_GEMM_REGTILE)                  // fp16 full pass: query fragments in registers, gallery through the LDS-DMA ring (FIR_GEMM_REGTILE=0: the LDS-tile kernel)
-    int share_max = 8;                    // fp16: up to this many pairs of passes (x 128 queries) read the gallery together in one launch (FIR_GEMM_SHARE; 0 = the old one-pair-at-a-time grid)
+    int share_max = 16;                   // fp16: up to this many pairs of passes (x 128 queries) read the gallery together in one launch (FIR_GEMM_SHARE; 0 = the old one-pair-at-a-time grid)
 };
 
 
@@ -1461,7 +1461,7 @@ int fir_gemm_create_range(fir_gallery* g, int32_t precision, int32_t end_pos, fi
                        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy_f16_regtile<D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RegTile<D>::lds_bytes);
     FIR_RT_ATTR(8) FIR_RT_ATTR(16) FIR_RT_ATTR(32)
 #undef FIR_RT_ATTR
-    if (const char* w = std::getenv("FIR_GEMM_SHARE")) m->share_max = std::max(0, std::min(8, std::atoi(w)));
+    if (const char* w = std::getenv("FIR_GEMM_SHARE")) m->share_max = std::max(0, std::min(16, std::atoi(w)));
     if (const char* w = std::getenv("FIR_GEMM_REGTILE")) m->regtile = std::atoi(w);
     if (const char* w = std::getenv("FIR_GEMM_STREAMED")) m->streamed = std::atoi(w);   // experiments: 0 / 1 force the form, -1 = by row length
     if (e == hipSuccess && m->v.n > 0) {
@@ -1687,7 +1687,8 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
             const int pairs = (np + 1) / 2;
             const bool streamed = m->streamed >= 0 ? m->streamed != 0 : m->dk16 > kSlabH;
             const int64_t rblocks = (n + 31) / 32;
-            const int share_cap = m->share_max > 0 ? m->share_max : 8;
+            // rows longer than the LDS tile (query slabs streamed per unit): 16 readers of one range drift apart, 8 measured better
+            const int share_cap = m->share_max > 0 ? (streamed ? std::min(m->share_max, 8) : m->share_max) : 16;
             int nlaunch = 0, p_first = 1;
             for (int p0 = 0; p0 < pairs;) {
                 int P = 1;
