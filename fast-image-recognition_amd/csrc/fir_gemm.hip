@@ -42,7 +42,7 @@ constexpr int kGemmMinBlocks = kGemmBlock <= 512 ? 2 : 1;
 constexpr int kQT = 64;                // queries per pass (2 accumulator tiles of 32 per wave)
 constexpr int kSlab8 = 64;             // query features staged in LDS at a time, in groups of 8 (512 features)
 constexpr int kSlab16 = 32;            // bf16 variant: k-blocks of 16 features staged at a time (512 features)
-constexpr int kPasses = 32;            // 64-query passes per super-batch (one set of launches, one set of scratch): 2048 queries
+constexpr int kPasses = 128;           // 64-query passes per super-batch at most (one set of launches, one set of scratch): 8192 queries
 constexpr int kCand = 8;               // tau = the kCand-th smallest SAMPLED proxy (so ~kCand * n / sample rows get appended)
 constexpr int kRerankGroup = 8;         // candidate rows staged in LDS at a time by the re-rank (fewer when rows are longer than ~4000 features)
 constexpr size_t kRerankLdsMax = 144 * 1024;
@@ -1432,7 +1432,6 @@ int fir_gemm_create_range(fir_gallery* g, int32_t precision, int32_t end_pos, fi
     m->rt_sample_rows = (int)std::min<int64_t>(np, std::max<int64_t>(kMinSampleRows, np / 32));    // n/16 .. n/48 measured: 1.022 / 1.038 / 1.028 M queries/s at 1M x 512
     if (const char* w = std::getenv("FIR_GEMM_SAMPLE_DIV"))      // experiments
         m->rt_sample_rows = (int)std::min<int64_t>(np, std::max<int64_t>(kMinSampleRows, np / std::max(1, std::atoi(w))));
-    if (e == hipSuccess) e = hipMalloc((void**)&m->sample, (size_t)kPasses * kQT * m->sample_rows * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&m->fbq, (size_t)kQT * m->v.d * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&m->fbkeys, (size_t)kQT * kTopKMax * sizeof(unsigned long long));
     const int lds_bytes = precision == FIR_GEMM_F32 ? (kQT / 32) * std::min(m->dq8, kSlab8) * 64 * (int)sizeof(float4)
@@ -1587,7 +1586,12 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
     const int grid = m->v.cus;      // one 512-thread workgroup per CU
     const int sample_rows = m->sample_rows;
     const int sample_grid = (sample_rows + 63) / 64;
-    const int nsb = (qb + kPasses * kQT - 1) / (kPasses * kQT);      // super-batch = up to kPasses passes of 64 queries in ONE set of launches
+    // super-batch = the queries of ONE set of launches (preparation, full passes, re-rank): up to kPasses passes of 64 queries. Large
+    // sets amortise the boundaries between full passes (where the small kernels run: they cannot share a CU with a full-pass
+    // workgroup), but a call needs a few super-batches for its preparation / re-rank to overlap anything: a quarter of the call,
+    // in whole 1 024-query launches
+    const int sbq = std::min(kPasses * kQT, std::max(1024, (qb / 4 + 1023) / 1024 * 1024));
+    const int nsb = (qb + sbq - 1) / sbq;
     // Two streams. `st` carries only the full passes over the gallery, back to back; `side` carries everything small:
     // the preparation of super-batch i+1 (query norms / scales / fragments, the sample pass, tau) and the exact re-rank +
     // certificate of super-batch i, both under super-batch i's (or i+1's) full pass. Order on `side`:
@@ -1609,10 +1613,15 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
     // the full pass: both kernels run at ~1 KiB of LDS traffic per MFMA and within 7 % of each other (profiles/r02_gemm_kernel_choice.txt):
     // register tile ahead up to 256 features, LDS tile ahead at 512
     const bool rt_full = rt_main != nullptr && (m->regtile > 0 || (m->regtile < 0 && m->dk16 <= 16));
+    if (!rt_flow && !m->sample) {
+        // the sample of the order-statistic flow, on first use: one block minimum per 32 sampled rows and query (fp16), every proxy (f32 / bf16)
+        const size_t per_query = m->precision == FIR_GEMM_F16 ? (size_t)(m->sample_rows + 31) / 32 : (size_t)m->sample_rows;
+        GEMM_HIP(hipMalloc((void**)&m->sample, (size_t)kPasses * kQT * per_query * sizeof(float)));
+    }
     auto prep = [&](int sb) -> int {
         hipStream_t ps = m->side;
-        const int q0 = sb * kPasses * kQT;
-        const int nq = std::min(kPasses * kQT, qb - q0);
+        const int q0 = sb * sbq;
+        const int nq = std::min(sbq, qb - q0);
         const int np = (nq + kQT - 1) / kQT;
         const int b = sb & 1;
         const float* dq = d_queries + (size_t)q0 * qs;
@@ -1675,8 +1684,8 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
     int rcp = prep(0);
     if (rcp) return rcp;
     for (int sb = 0; sb < nsb; ++sb) {
-        const int q0 = sb * kPasses * kQT;
-        const int nq = std::min(kPasses * kQT, qb - q0);
+        const int q0 = sb * sbq;
+        const int nq = std::min(sbq, qb - q0);
         const int np = (nq + kQT - 1) / kQT;
         const int b = sb & 1;
         const float* dq = d_queries + (size_t)q0 * qs;
