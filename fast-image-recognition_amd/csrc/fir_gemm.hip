@@ -1706,12 +1706,12 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
                 p0 += P;
                 ++nlaunch;
             }
-            // algorithmic bytes: the fp16 fragments once per group of pairs that reads them together (once per pair without sharing),
-            // every pair's query tile and keys
-            const double bytes = (m->share_max > 0 ? nlaunch : pairs) * ((double)rblocks * m->dk16 * 1024.0) + pairs * (4.0 * m->dk16 * 1024.0 + 128.0 * 8.0);
-            const double flops = 2.0 * (double)n * d * 128.0 * pairs;
-            int rc2 = fir_gallery_profile_begin_(m->g, st);
-            if (rc2) return rc2;
+            // algorithmic bytes of ONE launch (what fir_profile_read's event pairs bracket): the fp16 fragments once for the pairs that
+            // read them together (once per pair without sharing), every pair's query tile and keys
+            auto launch_bytes = [&](int P) { return (m->share_max > 0 ? 1 : P) * ((double)rblocks * m->dk16 * 1024.0) + P * (4.0 * m->dk16 * 1024.0 + 128.0 * 8.0); };
+            const double bytes = launch_bytes(p_first);
+            const double flops = 2.0 * (double)n * d * 128.0 * p_first;
+            int rc2 = FIR_OK;
             bool used_rt = false;
             size_t used_rt_lds = 0;
             // the pairs of the super-batch read the gallery together, a power of two (<= share_max) of them per launch
@@ -1722,6 +1722,7 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
                 const dim3 g1 = share > 0 ? dim3(grid, 1) : dim3(grid, P);
                 const int nt = (share <= 1) ? 1 : 0;
                 const size_t qo = (size_t)p0;
+                if ((rc2 = fir_gallery_profile_begin_(m->g, st))) return rc2;
                 if (rt_full && share > 0 && grid / 8 >= share) {
                     hipLaunchKernelGGL(rt_main, dim3(grid), dim3(512), rt_lds, st, m->gh, m->gnorm, m->qbf[b] + qo * 4 * m->dk16 * 64, m->qinv[b] + qo * 2 * kQT, n, n, 1,
                                        m->tau[b] + qo * 2 * kQT, m->lists[b] + qo * 2 * kQT * kListCap, m->counts[b] + qo * 2 * kQT, m->smin[b] + qo * 2 * kQT, share, nt);
@@ -1735,9 +1736,9 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
                     hipLaunchKernelGGL((k_gemm_proxy_f16<1, 0>), g1, dim3(kGemmBlock), kHalfLds, st, m->gh, m->gnorm, m->qbf[b] + qo * 4 * m->dk16 * 64, m->qinv[b] + qo * 2 * kQT,
                                        n, (int64_t)0, n, m->dk16, m->tau[b] + qo * 2 * kQT, m->lists[b] + qo * 2 * kQT * kListCap, m->counts[b] + qo * 2 * kQT, m->sample,
                                        sample_rows, share, nt);
+                if ((rc2 = fir_gallery_profile_end_(m->g, st, launch_bytes(P)))) return rc2;
                 p0 += P;
             }
-            if ((rc2 = fir_gallery_profile_end_(m->g, st, bytes))) return rc2;
             if (used_rt) {
                 char nm[64];
                 std::snprintf(nm, sizeof nm, "fir::k_gemm_proxy_f16_regtile<%d, false>", m->dk16);
