@@ -1418,7 +1418,7 @@ int fir_gemm_create_range(fir_gallery* g, int32_t precision, int32_t end_pos, fi
         if (e == hipSuccess) e = hipMalloc((void**)&m->qnorm[b], kPasses * kQT * sizeof(float));
         if (e == hipSuccess) e = hipMalloc((void**)&m->qmul[b], kPasses * kQT * sizeof(float));
         if (e == hipSuccess) e = hipMalloc((void**)&m->qinv[b], kPasses * kQT * sizeof(float));
-        if (e == hipSuccess) e = hipMalloc((void**)&m->smin[b], kPasses * kQT * sizeof(unsigned int));
+        if (e == hipSuccess) e = hipMalloc((void**)&m->smin[b], (size_t)kRtSubsets * kPasses * kQT * sizeof(unsigned int));   // top-K: one minimum per subset
         if (e == hipSuccess) e = hipMalloc((void**)&m->tau[b], kPasses * kQT * sizeof(float));
         if (e == hipSuccess) e = hipMalloc((void**)&m->lists[b], (size_t)kPasses * kQT * kListCap * sizeof(unsigned long long));
         if (e == hipSuccess) e = hipMalloc((void**)&m->counts[b], kPasses * kQT * sizeof(int));
@@ -1599,7 +1599,7 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
     GEMM_HIP(hipEventRecord(m->queries_ready, st));
     GEMM_HIP(hipStreamWaitEvent(m->side, m->queries_ready, 0));
     // the register-tile flow (fir_gemm_regtile.h) for fp16 galleries whose rows fit the compute waves' registers
-    typedef void (*rt_fn)(const uint4*, const float*, const uint4*, const float*, int64_t, int64_t, int, const float*, unsigned long long*, int*, unsigned int*, int, int);
+    typedef void (*rt_fn)(const uint4*, const float*, const uint4*, const float*, int64_t, int64_t, int, const float*, unsigned long long*, int*, unsigned int*, int, int, int);
     rt_fn rt_main = nullptr, rt_sample = nullptr;
     size_t rt_lds = 0;
     if (m->precision == FIR_GEMM_F16 && m->share_max > 0 && (grid & 7) == 0 && grid >= 8) {
@@ -1607,9 +1607,10 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
         FIR_RT_PICK(8) FIR_RT_PICK(16) FIR_RT_PICK(32)
 #undef FIR_RT_PICK
     }
-    // sample pass + tau through the register-tile kernel (smallest sampled proxy + one window): top-1 only -- the K-th best
-    // needs an order statistic of the sample, which the block-minimum sample + k_gemm_tau give
-    const bool rt_flow = rt_main != nullptr && k == 1;
+    // sample pass + tau through the register-tile kernel: the smallest sampled proxy + one window (top-1), the K-th smallest of 64
+    // disjoint subsets' minima + one window (top-K); other row lengths: the block-minimum sample + k_gemm_tau
+    const bool rt_flow = rt_main != nullptr;
+    const int sub_stride = k > 1 ? kPasses * kQT : 0;      // top-K: the sample as kRtSubsets subset minima per query (k_gemm_tau_kmin)
     // the full pass: both kernels run at ~1 KiB of LDS traffic per MFMA and within 7 % of each other (profiles/r02_gemm_kernel_choice.txt):
     // register tile ahead up to 256 features, LDS tile ahead at 512
     const bool rt_full = rt_main != nullptr && (m->regtile > 0 || (m->regtile < 0 && m->dk16 <= 16));
@@ -1633,7 +1634,7 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
                                m->qbf[b], qs);
             if (rt_flow) {
                 // the smallest proxy of a row sample per query (register-tile kernel over rows [0, rt_sample_rows)), tau = that + one window
-                GEMM_HIP(hipMemsetD32Async((hipDeviceptr_t)m->smin[b], (int)0xFF800000u, (size_t)pairs * 2 * kQT, ps));
+                GEMM_HIP(hipMemsetD32Async((hipDeviceptr_t)m->smin[b], (int)0xFF800000u, sub_stride ? (size_t)kRtSubsets * sub_stride : (size_t)pairs * 2 * kQT, ps));
                 for (int p0 = 0; p0 < pairs;) {
                     int P = 1;
                     while (P * 2 <= pairs - p0 && P * 2 <= m->share_max) P *= 2;
@@ -1643,10 +1644,14 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
                     const int rb_stride = (int)std::max<int64_t>(1, ((n + 31) / 32) / sample_blocks);
                     hipLaunchKernelGGL(rt_sample, dim3(grid), dim3(512), rt_lds, ps, m->gh, m->gnorm, m->qbf[b] + qo * 4 * m->dk16 * 64, m->qinv[b] + qo * 2 * kQT, n,
                                        sample_blocks * 32, rb_stride, m->tau[b] + qo * 2 * kQT, m->lists[b] + qo * 2 * kQT * kListCap, m->counts[b] + qo * 2 * kQT,
-                                       m->smin[b] + qo * 2 * kQT, P, P <= 1 ? 1 : 0);
+                                       m->smin[b] + qo * 2 * kQT, P, P <= 1 ? 1 : 0, sub_stride);
                     p0 += P;
                 }
-                hipLaunchKernelGGL(k_gemm_tau_min, dim3((pairs * 2 * kQT + 255) / 256), dim3(256), 0, ps, m->smin[b], m->tau[b], pairs * 2 * kQT, nq, m->qnorm[b], m->gmax, e_rel);
+                if (sub_stride)
+                    hipLaunchKernelGGL(k_gemm_tau_kmin, dim3((pairs * 2 * kQT + 255) / 256), dim3(256), 0, ps, m->smin[b], sub_stride, k, m->tau[b], pairs * 2 * kQT, nq,
+                                       m->qnorm[b], m->gmax, e_rel);
+                else
+                    hipLaunchKernelGGL(k_gemm_tau_min, dim3((pairs * 2 * kQT + 255) / 256), dim3(256), 0, ps, m->smin[b], m->tau[b], pairs * 2 * kQT, nq, m->qnorm[b], m->gmax, e_rel);
             } else {
             const int wpb = kGemmBlock / 64;
             const int sample_wgs = (int)((((int64_t)sample_rows + 31) / 32 + wpb - 1) / wpb);
@@ -1725,7 +1730,7 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
                 if ((rc2 = fir_gallery_profile_begin_(m->g, st))) return rc2;
                 if (rt_full && share > 0 && grid / 8 >= share) {
                     hipLaunchKernelGGL(rt_main, dim3(grid), dim3(512), rt_lds, st, m->gh, m->gnorm, m->qbf[b] + qo * 4 * m->dk16 * 64, m->qinv[b] + qo * 2 * kQT, n, n, 1,
-                                       m->tau[b] + qo * 2 * kQT, m->lists[b] + qo * 2 * kQT * kListCap, m->counts[b] + qo * 2 * kQT, m->smin[b] + qo * 2 * kQT, share, nt);
+                                       m->tau[b] + qo * 2 * kQT, m->lists[b] + qo * 2 * kQT * kListCap, m->counts[b] + qo * 2 * kQT, m->smin[b] + qo * 2 * kQT, share, nt, 0);
                     used_rt = true;
                     used_rt_lds = rt_lds;
                 } else if (streamed)

@@ -69,7 +69,10 @@ __device__ __forceinline__ void rt_dma4(const float* g, uint32_t lds_byte) {    
 template <int DKB, bool SAMPLE>
 __global__ void __launch_bounds__(512, 1) k_gemm_proxy_f16_regtile(const uint4* __restrict__ gh, const float* __restrict__ gnorm, const uint4* qh,
                                                                     const float* __restrict__ qinv, int64_t n, int64_t rows, int rb_stride, const float* tau,
-                                                                    unsigned long long* lists, int* counts, unsigned int* smin, int share, int nt) {
+                                                                    unsigned long long* lists, int* counts, unsigned int* smin, int share, int nt,
+                                                                    int sub_stride = 0) {
+    // sub_stride (SAMPLE, top-K): the sample is kept as kRtSubsets disjoint subsets' minima, smin[subset * sub_stride + query] -- the K-th
+    // smallest of them is at or above the K-th smallest proxy of all rows (k_gemm_tau_kmin). 0: one minimum per query (top-1).
     using RT = RegTile<DKB>;
     constexpr int CK = RT::CK, CPR = RT::CPR, P = RT::P;
     constexpr int dbg = FIR_RT_DBG;
@@ -144,6 +147,7 @@ __global__ void __launch_bounds__(512, 1) k_gemm_proxy_f16_regtile(const uint4* 
     const float m2 = 2.0f * qinv[q];
     const float tq = SAMPLE ? 0.0f : (dbg & 1) ? -__builtin_huge_valf() : tau[q];
     float smallest = __builtin_huge_valf();                        // SAMPLE: running minimum of this lane's proxies
+    float sm1 = __builtin_huge_valf(), sm2 = __builtin_huge_valf(), sm3 = __builtin_huge_valf();   // ... of row blocks 1, 2, 3 mod 4 (sub_stride != 0; `smallest` then: 0 mod 4)
     __syncthreads();                                               // staging counters zeroed
     f32x16 acc = {0.f}, prev = {0.f};
     // gallery fragments come out of LDS kRtDepth k-blocks ahead of the MFMA that uses them, across chunk borders: the wave
@@ -211,7 +215,15 @@ __global__ void __launch_bounds__(512, 1) k_gemm_proxy_f16_regtile(const uint4* 
                     for (int r = 0; r < 16; ++r)
                         if (rbs * 32 + 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2) < n) mn = fminf(mn, pv[r]);
                 }
-                smallest = fminf(smallest, mn);
+                if (sub_stride) {
+                    const int sub = (i - 1) & 3;
+                    smallest = sub == 0 ? fminf(smallest, mn) : smallest;
+                    sm1 = sub == 1 ? fminf(sm1, mn) : sm1;
+                    sm2 = sub == 2 ? fminf(sm2, mn) : sm2;
+                    sm3 = sub == 3 ? fminf(sm3, mn) : sm3;
+                } else {
+                    smallest = fminf(smallest, mn);
+                }
             } else if (__builtin_amdgcn_ballot_w64(mn < tq) != 0) { // rare (a few per cent of the row blocks): some lane holds a row below its query's tau
                 const int64_t rb = rb_first + i - 1;
                 unsigned hm = 0;                                    // this lane's rows below tau, bit r = accumulator register r
@@ -246,6 +258,18 @@ __global__ void __launch_bounds__(512, 1) k_gemm_proxy_f16_regtile(const uint4* 
         acc = f32x16{0.f};
     }
     if (SAMPLE) {
+        if (sub_stride) {
+            // 16 row ranges x 4 row-block residues = kRtSubsets subsets (more ranges wrap around: unions of disjoint sets)
+            float v[4] = {smallest, sm1, sm2, sm3};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float o = __shfl_xor(v[t], 32, 64);           // the two half-waves hold the same 32 queries
+                v[t] = fminf(v[t], o);
+                if (lane < 32 && v[t] < __builtin_huge_valf())
+                    atomicMin(&smin[(size_t)(((range & 15) << 2) + t) * sub_stride + q], fir::f32_orderable(v[t]));
+            }
+            return;
+        }
         const float o = __shfl_xor(smallest, 32, 64);               // the two half-waves hold the same 32 queries
         smallest = fminf(smallest, o);
         if (lane < 32 && smallest < __builtin_huge_valf()) atomicMin(&smin[q], fir::f32_orderable(smallest));
@@ -268,6 +292,42 @@ __global__ void __launch_bounds__(512, 1) k_gemm_proxy_f16_regtile(const uint4* 
 // that was not appended has p >= tau, i.e. a reference distance >= (|q|^2 + p_s + 2.5 E d)/d - E, while the winner's is
 // <= (|q|^2 + p_s)/d + E. About n / sample_rows + (rows inside the window) rows pass per query -- tens, not hundreds, which
 // is what keeps the append path out of the full pass's way.
+constexpr int kRtSubsets = 64;
+// Top-K form of k_gemm_tau_min: the sample arrives as kRtSubsets disjoint subsets' minima per query; K of them are at or below the
+// K-th smallest of these minima, so at least K rows of the gallery are: tau = that + one window appends every row that can be
+// among the K nearest, and leaves room for the certificate of rank K. (With K << kRtSubsets the K smallest sampled proxies sit
+// in different subsets almost always: the bound is within a rank or two of the K-th smallest of the whole sample.)
+__global__ void __launch_bounds__(256) k_gemm_tau_kmin(const unsigned int* __restrict__ smin, int sub_stride, int k, float* __restrict__ tau,
+                                                        int nq_total, int nq_valid, const float* __restrict__ qnorm,
+                                                        const float* __restrict__ gnorm_max_p, float e_rel) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= nq_total) return;
+    if (q >= nq_valid) { tau[q] = -__builtin_huge_valf(); return; }
+    unsigned int best[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) best[i] = 0xFFFFFFFFu;
+    for (int s = 0; s < kRtSubsets; ++s) {
+        unsigned int v = smin[(size_t)s * sub_stride + q];
+        if (v == 0xFF800000u) continue;                                    // an empty subset (+inf preset)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const bool sw = v < best[i];
+            const unsigned int t = best[i];
+            best[i] = sw ? v : t;
+            v = sw ? t : v;
+        }
+    }
+    unsigned int kth = 0xFFFFFFFFu;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) kth = i == k - 1 ? best[i] : kth;
+    float t = __builtin_huge_valf();                                      // fewer than K sampled subsets: everything passes, the list cap decides
+    if (kth != 0xFFFFFFFFu) {
+        const float v = fir::f32_from_orderable(kth) + 2.5f * e_rel * (qnorm[q] + gnorm_max_p[0]);
+        t = v + fabsf(v) * 1e-6f + 1e-30f;
+    }
+    tau[q] = t;
+}
+
 __global__ void __launch_bounds__(256) k_gemm_tau_min(const unsigned int* __restrict__ smin, float* __restrict__ tau, int nq_total, int nq_valid,
                                                        const float* __restrict__ qnorm, const float* __restrict__ gnorm_max_p, float e_rel) {
     const int q = blockIdx.x * 256 + threadIdx.x;
