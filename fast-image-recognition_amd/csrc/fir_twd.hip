@@ -377,12 +377,7 @@ __global__ void __launch_bounds__(kBlock) k_twd_proposed(const float* __restrict
     }
 }
 
-// ---- the same classifier with the rows of a query split over gridDim.x workgroups (large galleries) ----
-// Three small launches per chunk c, all queued up front (a finished query's workgroups return at once):
-//   k_twd_prop_min    distances[j] += chunk distance over the alive rows; each segment's first minimum -> part[c][q][b]
-//   k_twd_prop_prune  (every workgroup folds the segments' minima itself) rows above bestDist / threshold die, the
-//                     survivors of another class than the best row's are counted into cnt[c][q]
-//   k_twd_prop_step   one thread per query: the reference's loop bookkeeping (bestInd, break conditions, num_of_unreliable)
+// ---- the same classifier with the rows of a query split over gridDim.x workgroups (large galleries): k_twd_prop_chunk ----
 struct PropState {
     int bestInd, unreliable, used, done;
 };
@@ -400,74 +395,90 @@ __device__ __forceinline__ DI prop_fold(const DI* __restrict__ parts, int nseg) 
     }
     return w;
 }
-__global__ void __launch_bounds__(kBlock) k_twd_prop_min(const float* __restrict__ cd, int nq, int c, double* __restrict__ acc,
-                                                          const uint8_t* __restrict__ alive, int n, int seg_rows,
-                                                          const PropState* __restrict__ state, DI* __restrict__ part) {
+// The reference's loop bookkeeping for one chunk j whose segment minima (fold w) and surviving-other-class count are complete.
+__device__ __forceinline__ void prop_advance(PropState& st, int j, const DI w, int others) {
+    if (st.done) return;
+    ++st.used;
+    if (w.i >= 0) st.bestInd = w.i;                                                 // :255-258
+    if (st.bestInd < 0) st.done = 1;
+    else if (1 + others == 1) st.done = 1;                                          // num_of_variants == 1 (:265,285)
+    else if (j == 0) ++st.unreliable;                                               // :287-288
+}
+// Launch c of nchunks + 1 (c = 0 .. nchunks), gridDim.x segments per query (blockIdx.y):
+//   * every workgroup brings the query's state up to chunk c - 2 (whose minima and counts are complete) from the state launch
+//     c - 1 left in s_in, workgroup 0 leaves it in s_out for launch c + 1 (two buffers: the others still read s_in);
+//   * a finished query's workgroups return; the others PRUNE chunk c - 1 in their segment (rows above bestDist / threshold
+//     die, the survivors of another class than the best row's are counted into cnt[c - 1]) ...
+//   * ... and, speculatively -- whether chunk c - 1 ended the loop is only known once every segment has counted -- take the
+//     segment's first minimum of chunk c over the rows still alive (launch c + 1 drops it when the loop had ended).
+// One launch per chunk instead of three.
+__global__ void __launch_bounds__(kBlock) k_twd_prop_chunk(const float* __restrict__ cd, int nq, int c, int nchunks, double* __restrict__ acc,
+                                                            uint8_t* __restrict__ alive, const int32_t* __restrict__ cls, int n, int seg_rows,
+                                                            double threshold, const PropState* __restrict__ s_in, PropState* __restrict__ s_out,
+                                                            DI* __restrict__ part, int* __restrict__ cnt) {
     __shared__ DI red[kBlock / 64];
-    const int q = blockIdx.y, b = blockIdx.x;
-    if (state[q].done) return;
+    __shared__ DI best_s;
+    __shared__ int others_s, go_s, best_ind_s;
+    const int q = blockIdx.y, b = blockIdx.x, nseg = gridDim.x;
     double* a = acc + (size_t)q * n;
-    const uint8_t* live = alive + (size_t)q * n;
+    uint8_t* live = alive + (size_t)q * n;
+    const int row_begin = b * seg_rows, row_end = min(n, (b + 1) * seg_rows);
+    if (c > 0) {
+        if (threadIdx.x == 0) {
+            PropState st = s_in[q];
+            if (c >= 2) prop_advance(st, c - 2, prop_fold(part + ((size_t)(c - 2) * nq + q) * nseg, nseg), cnt[(size_t)(c - 2) * nq + q]);
+            if (b == 0) s_out[q] = st;
+            int go = !st.done;
+            if (go) {
+                const DI w = prop_fold(part + ((size_t)(c - 1) * nq + q) * nseg, nseg);
+                const int bestInd = w.i >= 0 ? w.i : st.bestInd;                    // :255-258
+                if (bestInd < 0) go = 0;                                            // the reference breaks before pruning
+                best_s = w;
+                best_ind_s = bestInd;
+            }
+            go_s = go;
+            others_s = 0;
+        }
+        __syncthreads();
+        if (!go_s) return;
+        const double dist_threshold = best_s.d * threshold;                         // :263
+        const int bestClass = cls[best_ind_s];
+        int others = 0;
+        for (int row = row_begin + threadIdx.x; row < row_end; row += kBlock) {
+            if (c > 1 && !live[row]) continue;
+            if (a[row] > dist_threshold) live[row] = 0;                             // :268-269
+            else {
+                if (c == 1) live[row] = 1;                                          // (the first prune writes every flag: the workspace comes uninitialised)
+                if (cls[row] != bestClass) ++others;                                // :270-271
+            }
+        }
+        atomicAdd(&others_s, others);
+        __syncthreads();
+        if (threadIdx.x == 0 && others_s) atomicAdd(&cnt[(size_t)(c - 1) * nq + q], others_s);
+        if (c >= nchunks) return;
+    }
     const float* dc = cd + ((size_t)c * nq + q) * n;
-    const int row_end = min(n, (b + 1) * seg_rows);
     DI m;
-    m.d = 100000.0;
+    m.d = 100000.0;                                                                 // bestDist = 100000 per chunk (:230)
     m.i = -1;
-    for (int row = b * seg_rows + threadIdx.x; row < row_end; row += kBlock) {
+    for (int row = row_begin + threadIdx.x; row < row_end; row += kBlock) {         // the thread that pruned a row is the one that reads its flag
         if (c > 0 && !live[row]) continue;                                          // :236-241 (every row is alive in the first chunk)
         const double v = (c > 0 ? a[row] : 0.0) + (double)dc[row];                  // distances[j] += ... (:250)
         a[row] = v;
         if (v < m.d) { m.d = v; m.i = row; }
     }
     const DI w = block_argmin(m, red);
-    if (threadIdx.x == 0) part[((size_t)c * nq + q) * gridDim.x + b] = w;
+    if (threadIdx.x == 0) part[((size_t)c * nq + q) * nseg + b] = w;
 }
-__global__ void __launch_bounds__(kBlock) k_twd_prop_prune(int nq, int c, const double* __restrict__ acc, uint8_t* __restrict__ alive,
-                                                            const int32_t* __restrict__ cls, int n, int seg_rows, double threshold,
-                                                            const PropState* __restrict__ state, const DI* __restrict__ part,
-                                                            int* __restrict__ cnt) {
-    __shared__ DI best_s;
-    __shared__ int others_s;
-    const int q = blockIdx.y, b = blockIdx.x;
-    if (state[q].done) return;
-    if (threadIdx.x == 0) { best_s = prop_fold(part + ((size_t)c * nq + q) * gridDim.x, gridDim.x); others_s = 0; }
-    __syncthreads();
-    const DI w = best_s;
-    const int bestInd = w.i >= 0 ? w.i : state[q].bestInd;                          // :255-258
-    if (bestInd < 0) return;                                                        // the reference breaks before pruning
-    const double dist_threshold = w.d * threshold;                                  // :263
-    const int bestClass = cls[bestInd];
-    const double* a = acc + (size_t)q * n;
-    uint8_t* live = alive + (size_t)q * n;
-    const int row_end = min(n, (b + 1) * seg_rows);
-    int others = 0;
-    for (int row = b * seg_rows + threadIdx.x; row < row_end; row += kBlock) {
-        if (c > 0 && !live[row]) continue;
-        if (a[row] > dist_threshold) live[row] = 0;                                 // :268-269
-        else {
-            if (c == 0) live[row] = 1;
-            if (cls[row] != bestClass) ++others;                                    // :270-271
-        }
-    }
-    atomicAdd(&others_s, others);
-    __syncthreads();
-    if (threadIdx.x == 0 && others_s) atomicAdd(&cnt[(size_t)c * nq + q], others_s);
-}
-__global__ void k_twd_prop_step(int nq, int c, int nseg, const DI* __restrict__ part, const int* __restrict__ cnt, const int32_t* __restrict__ cls,
-                                PropState* __restrict__ state, int32_t* __restrict__ class_out, int32_t* __restrict__ unreliable_out,
-                                int32_t* __restrict__ chunks_out) {
+// After launch nchunks: the last two chunks' bookkeeping and the outputs, one thread per query.
+__global__ void k_twd_prop_finish(int nq, int nchunks, int nseg, const DI* __restrict__ part, const int* __restrict__ cnt, const int32_t* __restrict__ cls,
+                                  const PropState* __restrict__ s_in, int32_t* __restrict__ class_out, int32_t* __restrict__ unreliable_out,
+                                  int32_t* __restrict__ chunks_out) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nq) return;
-    PropState st = state[q];
-    if (!st.done) {
-        ++st.used;
-        const DI w = prop_fold(part + ((size_t)c * nq + q) * nseg, nseg);
-        if (w.i >= 0) st.bestInd = w.i;                                             // :255-258
-        if (st.bestInd < 0) st.done = 1;
-        else if (1 + cnt[(size_t)c * nq + q] == 1) st.done = 1;                     // num_of_variants == 1 (:265,285)
-        else if (c == 0) ++st.unreliable;                                           // :287-288
-        state[q] = st;
-    }
+    PropState st = s_in[q];                                                         // the state up to chunk nchunks - 2
+    const int j = nchunks - 1;
+    prop_advance(st, j, prop_fold(part + ((size_t)j * nq + q) * nseg, nseg), cnt[(size_t)j * nq + q]);
     class_out[q] = st.bestInd >= 0 ? cls[st.bestInd] : -1;
     unreliable_out[q] = st.unreliable;
     chunks_out[q] = st.used;
@@ -629,10 +640,10 @@ int fir_twd_proposed(fir_gallery* g, const float* queries, int32_t qb, int32_t r
     const int nseg_want = n > 16384 ? std::min(256, (n + 8191) / 8192) : 1;
     const int seg_rows = nseg_want > 1 ? ((n + nseg_want - 1) / nseg_want + 255) / 256 * 256 : n;
     const int nseg = nseg_want > 1 ? (n + seg_rows - 1) / seg_rows : 1;
-    TWD_SLOT(pws, 7, (size_t)batch * sizeof(PropState) + (size_t)nchunks * batch * sizeof(int) + (size_t)nchunks * batch * nseg * sizeof(DI) + 64);
+    TWD_SLOT(pws, 7, (size_t)2 * batch * sizeof(PropState) + (size_t)nchunks * batch * sizeof(int) + (size_t)nchunks * batch * nseg * sizeof(DI) + 64);
     DI* ppart = pws.as<DI>();
     PropState* pstate = (PropState*)(ppart + (size_t)nchunks * batch * nseg);
-    int* pcnt = (int*)(pstate + batch);
+    int* pcnt = (int*)(pstate + 2 * batch);
     for (int q0 = 0; q0 < qb; q0 += batch) {
         const int nq = std::min(batch, qb - q0);
         int32_t h_res[3 * kBatch];
@@ -657,16 +668,15 @@ int fir_twd_proposed(fir_gallery* g, const float* queries, int32_t qb, int32_t r
                                    self_publish ? (int32_t*)pin_res : (int32_t*)nullptr, kBatch, self_publish ? pin_res + 2 * kBatch : (uint64_t*)nullptr,
                                    ticket);
             } else {
-                hipLaunchKernelGGL(k_twd_prop_init, dim3((nq + 63) / 64), dim3(64), 0, v.stream, pstate, nq);
+                // nchunks + 1 launches + the finish (three launches per chunk before); the two state buffers swap roles every launch
+                hipLaunchKernelGGL(k_twd_prop_init, dim3((2 * batch + 63) / 64), dim3(64), 0, v.stream, pstate, 2 * batch);
                 TWD_HIP(hipMemsetAsync(pcnt, 0, (size_t)nchunks * nq * sizeof(int), v.stream));
-                for (int c = 0; c < nchunks; ++c) {
-                    hipLaunchKernelGGL(k_twd_prop_min, dim3(nseg, nq), dim3(kBlock), 0, v.stream, cd.as<float>(), nq, c, acc.as<double>(),
-                                       alive.as<uint8_t>(), n, seg_rows, pstate, ppart);
-                    hipLaunchKernelGGL(k_twd_prop_prune, dim3(nseg, nq), dim3(kBlock), 0, v.stream, nq, c, acc.as<double>(), alive.as<uint8_t>(),
-                                       v.cls, n, seg_rows, 1.0 / threshold, pstate, ppart, pcnt);
-                    hipLaunchKernelGGL(k_twd_prop_step, dim3((nq + 63) / 64), dim3(64), 0, v.stream, nq, c, nseg, ppart, pcnt, v.cls, pstate, dcls,
-                                       dunrel, dchunks);
-                }
+                for (int c = 0; c <= nchunks; ++c)
+                    hipLaunchKernelGGL(k_twd_prop_chunk, dim3(nseg, nq), dim3(kBlock), 0, v.stream, cd.as<float>(), nq, c, nchunks, acc.as<double>(),
+                                       alive.as<uint8_t>(), v.cls, n, seg_rows, 1.0 / threshold, pstate + (size_t)((c + 1) & 1) * batch,
+                                       pstate + (size_t)(c & 1) * batch, ppart, pcnt);
+                hipLaunchKernelGGL(k_twd_prop_finish, dim3((nq + 63) / 64), dim3(64), 0, v.stream, nq, nchunks, nseg, ppart, pcnt, v.cls,
+                                   pstate + (size_t)(nchunks & 1) * batch, dcls, dunrel, dchunks);
             }
             TWD_HIP(hipGetLastError());
             if (pinned) {
