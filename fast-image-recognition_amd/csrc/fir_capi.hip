@@ -1030,7 +1030,10 @@ int fir_search_topk_exact_keys_dev_(fir_gallery* g, const float* d_queries, int3
     const int rc = check_range(g, start_pos, end_pos);
     if (rc) return rc;
     FIR_HIP(hipSetDevice(g->device));
-    return topk_dev(g, d_queries, qb, 0, end_pos, k, d_keys, stream ? (hipStream_t)stream : g->stream, true, false);
+    const fir_dispatch_info saved = g->last;          // the caller's dispatch record stays the matrix-core pass's, not this fallback's
+    const int rc2 = topk_dev(g, d_queries, qb, 0, end_pos, k, d_keys, stream ? (hipStream_t)stream : g->stream, true, false);
+    g->last = saved;
+    return rc2;
 }
 
 int fir_search_top1_keys_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start_pos, int32_t end_pos,

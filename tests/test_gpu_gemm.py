@@ -113,13 +113,17 @@ def test_host_call_auto_dispatch(fir):
         g.set_large_batch_mfma(128)
         b = g.search_top1(q)             # 300 >= 128: GEMM path
         c = g.search_top1(q[:50])        # below the threshold: exact scan
-        d = g.search_top1(q, 0, 64)      # a sub-range: exact scan
+        d = g.search_top1(q, 0, 64)      # a feature prefix of whole k-blocks: the matrix cores too (its own fp16 copy)
         g.set_row_offset(1000)           # the cached GEMM state follows the offset
         e = g.search_top1(q)
         g.set_large_batch_mfma(0)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
     assert np.array_equal(a[0][:50], c[0])
     assert d[0].shape == (300,)
+    with fir.Gallery(rows, None, 0, 0) as g2:
+        g2.set_large_batch_mfma(0)
+        d_scan = g2.search_top1(q, 0, 64)
+    assert np.array_equal(d[0], d_scan[0]) and np.array_equal(d[1].view(np.uint32), d_scan[1].view(np.uint32))
     assert np.array_equal(e[0], a[0] + 1000) and np.array_equal(e[1].view(np.uint32), a[1].view(np.uint32))
 
 
@@ -333,3 +337,26 @@ def test_feature_prefixes_through_the_matrix_cores(fir, oracle, n, d, end):
     assert a[0][2] == 300 and odd[0].shape == (200,)
     for j in (0, 2, 199):
         assert (a[0][j], a[1][j]) == oracle.recognize_bf(rows, q[j], 0, end, 0)
+
+
+def test_topk_matrix_cores_with_hostile_rows_and_queries(fir):
+    """Top-K through the matrix cores with a NaN row, a NaN query, an all-zero query, a query of huge values and more exact
+    duplicates of the best row than K: whatever the certificate cannot prove goes to the exact top-K scan -- same keys."""
+    n, d, k = 70000, 128, 5
+    rows = synth.make_gallery(31, n, d, 0)
+    q, _ = synth.make_queries(31, rows, 160, 0)
+    rows[123] = np.nan
+    for r in (9, 500, 501, 40000, 69999, 69998, 31):     # seven copies of one row
+        rows[r] = rows[7777]
+    q[0] = rows[7777]
+    q[1] = np.nan
+    q[2] = 0.0
+    q[3] = q[3] * np.float32(3.0e18)
+    q[4] = rows[123 + 1]
+    with fir.Gallery(rows, None, 0, 0) as g:
+        a = g.search_topk(q, k)
+        assert g.last_dispatch()["path"] == "mfma"
+        g.set_large_batch_mfma(0)
+        e = g.search_topk(q, k)
+    assert np.array_equal(a[0], e[0]) and np.array_equal(a[1].view(np.uint32), e[1].view(np.uint32))
+    assert list(a[0][0]) == [9, 31, 500, 501, 7777]
