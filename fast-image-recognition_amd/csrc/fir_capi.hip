@@ -1006,11 +1006,14 @@ int ensure_gemm(fir_gallery* g, int32_t end, fir_gemm** m) {
     return 0;
 }
 // The matrix-core path for this call, if it applies: 0 = done, 1 = take the scan, < 0 = error.
-int try_mfma(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start, int32_t end, uint64_t* d_keys, hipStream_t st) {
+int try_mfma(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start, int32_t end, uint64_t* d_keys, hipStream_t st,
+             const float* h_queries = nullptr) {
+    // h_queries: the queries are still on the host and d_queries is the (writable) device buffer they are staged through
     if (!wants_mfma(g, qb, start, end)) return 1;
     fir_gemm* m = nullptr;
     const int rc = ensure_gemm(g, end, &m);
     if (rc) return rc;
+    if (h_queries) return fir_gemm_search_staged_(m, h_queries, (float*)d_queries, qb, 1, d_keys, st);
     return fir_gemm_search_top1_keys_dev(m, d_queries, qb, d_keys, st);
 }
 int try_mfma_topk(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start, int32_t end, int32_t k, uint64_t* d_keys, hipStream_t st) {
@@ -1235,10 +1238,13 @@ int fir_search_top1(fir_gallery* g, const float* queries, int32_t qb, int32_t st
     }
     if ((rc = grow(g->dq, g->dq_cap, (size_t)qb * g->d))) return rc;
     if ((rc = grow(g->dkeys, g->dkeys_cap, (size_t)qb))) return rc;
-    FIR_HIP(hipMemcpyAsync(g->dq, queries, (size_t)qb * g->d * sizeof(float), hipMemcpyHostToDevice, g->stream));
-    // large L2 whole-range batches go through the matrix cores (same keys, fir_gemm.hip) unless switched off
-    rc = try_mfma(g, g->dq, qb, start_pos, end_pos, g->dkeys, g->stream);
-    if (rc > 0) rc = top1_dev(g, g->dq, qb, start_pos, end_pos, g->dkeys, g->stream);
+    // large L2 batches go through the matrix cores (same keys, fir_gemm.hip) unless switched off; their queries are uploaded
+    // super-batch by super-batch under the passes of the one before
+    rc = try_mfma(g, g->dq, qb, start_pos, end_pos, g->dkeys, g->stream, queries);
+    if (rc > 0) {
+        FIR_HIP(hipMemcpyAsync(g->dq, queries, (size_t)qb * g->d * sizeof(float), hipMemcpyHostToDevice, g->stream));
+        rc = top1_dev(g, g->dq, qb, start_pos, end_pos, g->dkeys, g->stream);
+    }
     if (rc) return rc;
     std::vector<uint64_t> keys((size_t)qb);
     FIR_HIP(hipMemcpyAsync(keys.data(), g->dkeys, (size_t)qb * sizeof(uint64_t), hipMemcpyDeviceToHost, g->stream));
@@ -1317,8 +1323,18 @@ int fir_search_topk(fir_gallery* g, const float* queries, int32_t qb, int32_t st
         return fir_keys_unpack(hk, qb * k, idx, dist);
     }
     if ((rc = grow(g->dq, g->dq_cap, (size_t)qb * g->d))) return rc;
-    FIR_HIP(hipMemcpyAsync(g->dq, queries, (size_t)qb * g->d * sizeof(float), hipMemcpyHostToDevice, g->stream));
-    if ((rc = topk_dev(g, g->dq, qb, start_pos, end_pos, k, g->dkeys, g->stream))) return rc;
+    // large L2 batches: the matrix cores, the queries uploaded super-batch by super-batch under the passes (as fir_search_top1)
+    rc = 1;
+    if (k >= 2 && wants_mfma(g, qb, start_pos, end_pos)) {
+        fir_gemm* m = nullptr;
+        rc = ensure_gemm(g, end_pos, &m);
+        if (rc == 0) rc = fir_gemm_search_staged_(m, queries, g->dq, qb, k, g->dkeys, g->stream);
+        if (rc < 0) return rc;
+    }
+    if (rc > 0) {
+        FIR_HIP(hipMemcpyAsync(g->dq, queries, (size_t)qb * g->d * sizeof(float), hipMemcpyHostToDevice, g->stream));
+        if ((rc = topk_dev(g, g->dq, qb, start_pos, end_pos, k, g->dkeys, g->stream))) return rc;
+    }
     std::vector<uint64_t> keys((size_t)qb * k);
     FIR_HIP(hipMemcpyAsync(keys.data(), g->dkeys, keys.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, g->stream));
     FIR_HIP(hipStreamSynchronize(g->stream));

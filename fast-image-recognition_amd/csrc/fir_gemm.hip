@@ -1358,6 +1358,8 @@ struct fir_gemm {
     hipStream_t side = nullptr;
     hipEvent_t main_done[2] = {nullptr, nullptr}, rerank_done[2] = {nullptr, nullptr}, prep_done[2] = {nullptr, nullptr};
     hipEvent_t queries_ready = nullptr;
+    hipStream_t copy = nullptr;           // host-pointer calls: the queries of super-batch i + 1 are uploaded under super-batch i's full passes
+    hipEvent_t copy_done[2] = {nullptr, nullptr};
     int* ok = nullptr; size_t ok_cap = 0;  // certificate flags of one call
     int sample_rows = 0;
     float* fbq = nullptr;                 // fallback queries (device)
@@ -1428,6 +1430,8 @@ int fir_gemm_create_range(fir_gallery* g, int32_t precision, int32_t end_pos, fi
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&m->queries_ready, hipEventDisableTiming);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->copy, hipStreamNonBlocking);
+    for (int b = 0; b < 2 && e == hipSuccess; ++b) e = hipEventCreateWithFlags(&m->copy_done[b], hipEventDisableTiming);
     m->sample_rows = (int)std::min<int64_t>(np, std::max<int64_t>(kMinSampleRows, np / 64));
     m->rt_sample_rows = (int)std::min<int64_t>(np, std::max<int64_t>(kMinSampleRows, np / 32));    // n/16 .. n/48 measured: 1.022 / 1.038 / 1.028 M queries/s at 1M x 512
     if (const char* w = std::getenv("FIR_GEMM_SAMPLE_DIV"))      // experiments
@@ -1540,6 +1544,8 @@ int fir_gemm_destroy(fir_gemm* m) {
     if (m->queries_ready) (void)hipEventDestroy(m->queries_ready);
     (void)hipFree(m->gm); (void)hipFree(m->gb); (void)hipFree(m->gh); (void)hipFree(m->rowmajor); (void)hipFree(m->gnorm); (void)hipFree(m->gmax); (void)hipFree(m->sample); (void)hipFree(m->ok);
     (void)hipFree(m->fbq); (void)hipFree(m->fbkeys);
+        if (m->copy) { (void)hipStreamSynchronize(m->copy); (void)hipStreamDestroy(m->copy); }
+    for (int b = 0; b < 2; ++b) if (m->copy_done[b]) (void)hipEventDestroy(m->copy_done[b]);
     delete m;
     return FIR_OK;
 }
@@ -1557,7 +1563,9 @@ int fir_gemm_stats(const fir_gemm* m, int64_t* passes, int64_t* fallback_queries
 
 // The K nearest rows of every query, K = 1 (fir_gemm_search_top1_keys_dev) or 2..kTopKMax (fir_gemm_search_topk_keys_dev):
 // d_keys[q * k + r], ascending.
-static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, uint64_t* d_keys, void* stream) {
+static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, uint64_t* d_keys, void* stream, const float* h_queries = nullptr) {
+    // h_queries: the queries are still in host memory; d_queries is the device buffer they go to, one super-batch at a time,
+    // each upload queued (on its own stream) right before that super-batch's preparation
     if (!m || !d_keys || (qb > 0 && !d_queries)) return gemm_fail(FIR_ERR_ARG, "NULL argument");
     if (qb < 0) return gemm_fail(FIR_ERR_ARG, "qb < 0");
     if (k < 1 || k > kTopKMax) return gemm_fail(FIR_ERR_ARG, "k=%d outside [1,%d]", k, kTopKMax);
@@ -1567,6 +1575,7 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
     const int d = m->feat;          // features compared
     const int qs = m->v.d;          // floats between consecutive queries (and gallery rows): the whole row
     const int64_t n = m->v.n;
+    if (n == 0 && h_queries) GEMM_HIP(hipMemcpyAsync((void*)d_queries, h_queries, (size_t)qb * qs * sizeof(float), hipMemcpyHostToDevice, st));
     if (n == 0)
         return k == 1 ? fir_search_top1_exact_keys_dev_(m->g, d_queries, qb, 0, d, d_keys, st)
                       : fir_search_topk_exact_keys_dev_(m->g, d_queries, qb, d, k, d_keys, st);
@@ -1623,6 +1632,11 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
         hipStream_t ps = m->side;
         const int q0 = sb * sbq;
         const int nq = std::min(sbq, qb - q0);
+        if (h_queries) {
+            GEMM_HIP(hipMemcpyAsync((void*)(d_queries + (size_t)q0 * qs), h_queries + (size_t)q0 * qs, (size_t)nq * qs * sizeof(float), hipMemcpyHostToDevice, m->copy));
+            GEMM_HIP(hipEventRecord(m->copy_done[sb & 1], m->copy));
+            GEMM_HIP(hipStreamWaitEvent(ps, m->copy_done[sb & 1], 0));
+        }
         const int np = (nq + kQT - 1) / kQT;
         const int b = sb & 1;
         const float* dq = d_queries + (size_t)q0 * qs;
@@ -1820,6 +1834,13 @@ int fir_gemm_search_top1_keys_dev(fir_gemm* m, const float* d_queries, int32_t q
 
 int fir_gemm_search_topk_keys_dev(fir_gemm* m, const float* d_queries, int32_t qb, int32_t k, uint64_t* d_keys, void* stream) {
     return gemm_search(m, d_queries, qb, k, d_keys, stream);
+}
+
+// Host-pointer form for fir_search_top1 / fir_search_topk: h_queries -> d_stage (qb rows of the gallery's length) super-batch by
+// super-batch, under the full passes of the one before; keys as the device-pointer forms.
+int fir_gemm_search_staged_(fir_gemm* m, const float* h_queries, float* d_stage, int32_t qb, int32_t k, uint64_t* d_keys, void* stream) {
+    if (!h_queries || !d_stage) return gemm_fail(FIR_ERR_ARG, "NULL argument");
+    return gemm_search(m, d_stage, qb, k, d_keys, stream, h_queries);
 }
 
 }  // extern "C"

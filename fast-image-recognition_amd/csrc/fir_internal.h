@@ -62,6 +62,11 @@ extern "C" int fir_gallery_profile_end_(fir_gallery* g, void* st, double bytes_a
 extern "C" void fir_gallery_note_dispatch_(fir_gallery* g, const void* fn, const char* name, int first, int gx, int gy, int block, size_t dyn_lds,
                                            int qpp, double bytes, double flops);
 
+struct fir_gemm;
+// fir_gemm_search_top1 / _topk_keys_dev for queries still in host memory: uploaded into d_stage one super-batch at a time, each
+// upload under the previous super-batch's full passes.
+extern "C" int fir_gemm_search_staged_(fir_gemm* m, const float* h_queries, float* d_stage, int32_t qb, int32_t k, uint64_t* d_keys, void* stream);
+
 struct fir_cls;
 extern "C" int fir_cls_pnn_scores_dev_(fir_cls* c, const double* queries, int32_t qb, double var, double** d_scores, void** stream, int32_t* max_batch);
 extern "C" int fir_cls_knn_nearest_dev_(fir_cls* c, const double* queries, int32_t qb, int32_t k, double** d_lists, void** stream, int32_t* max_batch);
