@@ -253,7 +253,13 @@ bool wants_mfma(const fir_gallery* g, int32_t qb, int32_t start, int32_t end) {
     if (end != g->d && (end < 64 || end % 16 != 0)) return false;
     if (g->large_batch_min == 0 || g->gemm_failed) return false;
     if (g->large_batch_min > 0) return qb >= g->large_batch_min;
-    return qb >= kAutoMfmaQueries && g->n >= kAutoMfmaRows && g->qpp == 0;     // a pinned queries-per-pass asks for the scan
+    if (g->n < kAutoMfmaRows || g->qpp != 0) return false;                     // a pinned queries-per-pass asks for the scan
+    // Smaller batches on larger galleries: a matrix-core call costs ~125 us + 0.1 us per MB of compared rows whatever the batch
+    // (up to 128 queries), the scan 0.15 us per MB for every 8 queries. Measured at d = 512 (one MI355X, device pointers):
+    // 1M rows 8 / 16 / 64 queries: scan 397 / 750 / 2583 us, matrix cores 347 / 336 / 343; 100 000 rows 16 / 32 / 64: 108 / 283 /
+    // 445 against 146 / 148 / 159; 65 536 rows 32 / 64: 134 / 429 against 133 / 148.
+    const double mb = (double)g->n * (double)end * 4.0 / 1.0e6;
+    return qb >= kAutoMfmaQueries || (qb >= 32 && mb >= 128.0) || (qb >= 16 && mb >= 800.0) || (qb >= 8 && mb >= 2000.0);
 }
 
 void note_dispatch(fir_gallery* g, const void* fn, const char* name, int launches_add, int gx, int gy, int block, size_t dyn_lds, int qpp,

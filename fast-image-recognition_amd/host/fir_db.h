@@ -97,7 +97,7 @@ public:
 inline void invalidate(const std::vector<ImageInfo>& dbImages) { GalleryCache::invalidate(dbImages); }
 
 // Galleries uploaded from now on: fir_gallery_set_large_batch_mfma(min_queries). The library's default (-1) already sends
-// whole-range L2 batches of >= 128 test images against >= 65536 rows through the matrix-core path (same answers);
+// whole-range L2 batches of >= 128 test images against >= 65536 rows (fewer on larger galleries) through the matrix-core path (same answers);
 // > 0 sets another threshold, 0 switches the path off.
 void set_large_batch_mfma(int min_queries);
 void set_device(int device);   // default 0

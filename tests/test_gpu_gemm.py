@@ -360,3 +360,27 @@ def test_topk_matrix_cores_with_hostile_rows_and_queries(fir):
         e = g.search_topk(q, k)
     assert np.array_equal(a[0], e[0]) and np.array_equal(a[1].view(np.uint32), e[1].view(np.uint32))
     assert list(a[0][0]) == [9, 31, 500, 501, 7777]
+
+
+def test_default_dispatch_takes_small_batches_on_large_galleries(fir):
+    """The automatic threshold falls with the size of the gallery (a matrix-core call costs about the same from 8 to 128
+    queries, the scan one gallery pass per 8): 32 queries from 128 MB of compared rows on, 16 from 0.8 GB, 8 from 2 GB. Same keys."""
+    dev = torch.device("cuda", 0)
+    d = 512
+    for n, qb, want in ((70_000, 32, "mfma"), (70_000, 16, "scan"), (400_000, 16, "mfma"), (400_000, 8, "scan"), (1_000_000, 8, "mfma")):
+        x = torch.rand((n, d), device=dev)
+        x = (x / x.norm(dim=1, keepdim=True)).contiguous()
+        q = (x[:: n // qb][:qb] * 0.97 + x[1: qb + 1] * 0.03).contiguous()
+        g = fir.Gallery(dev_ptr=x.data_ptr(), n=n, d=d, metric=0, device=0)
+        k1 = torch.empty(qb, dtype=torch.int64, device=dev)
+        k2 = torch.empty(qb, dtype=torch.int64, device=dev)
+        g.search_top1_keys_dev(q.data_ptr(), qb, k1.data_ptr())
+        g.sync()
+        assert g.last_dispatch()["path"] == want, (n, qb)
+        g.set_large_batch_mfma(0)
+        g.search_top1_keys_dev(q.data_ptr(), qb, k2.data_ptr())
+        g.sync()
+        assert torch.equal(k1, k2), (n, qb)
+        g.close()
+        del x, q
+    torch.cuda.empty_cache()
