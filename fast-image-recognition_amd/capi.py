@@ -71,6 +71,7 @@ SYMBOLS = [
     ("fir_gemm_create_range", C.c_int, [_vp, C.c_int32, C.c_int32, C.POINTER(_vp)]),
     ("fir_gemm_search_top1_keys_dev", C.c_int, [_vp, _vp, C.c_int32, _vp, _vp]),
     ("fir_gemm_search_topk_keys_dev", C.c_int, [_vp, _vp, C.c_int32, C.c_int32, _vp, _vp]),
+    ("fir_gemm_search_few_keys_dev", C.c_int, [_vp, _vp, C.c_int32, _vp, _vp]),
     ("fir_gemm_stats", C.c_int, [_vp, _i64p, _i64p]),
     ("fir_dem_pivot_table", C.c_int, [_vp, C.c_int32, C.c_int32, _vp, _vp, _vp, _i32p]),
     ("fir_dem_create", C.c_int, [_vp, C.c_int32, C.c_int32, C.POINTER(_vp)]),
@@ -508,6 +509,9 @@ class GemmSearch:
 
     def search_top1_keys_dev(self, q_ptr, qb, keys_ptr, stream=None):
         _check(lib().fir_gemm_search_top1_keys_dev(self._h, _vp(q_ptr), qb, _vp(keys_ptr), _vp(stream) if stream else None))
+
+    def search_few_keys_dev(self, q_ptr, qb, keys_ptr, stream=None):
+        _check(lib().fir_gemm_search_few_keys_dev(self._h, _vp(q_ptr), qb, _vp(keys_ptr), _vp(stream) if stream else None))
 
     def search_topk_keys_dev(self, q_ptr, qb, k, keys_ptr, stream=None):
         _check(lib().fir_gemm_search_topk_keys_dev(self._h, _vp(q_ptr), qb, k, _vp(keys_ptr), _vp(stream) if stream else None))

@@ -262,6 +262,17 @@ bool wants_mfma(const fir_gallery* g, int32_t qb, int32_t start, int32_t end) {
     return qb >= kAutoMfmaQueries || (qb >= 32 && mb >= 128.0) || (qb >= 16 && mb >= 800.0) || (qb >= 8 && mb >= 2000.0);
 }
 
+// ONE query against rows far beyond the caches (automatic mode only): the nomination scan over the fp16 copy
+// (fir_gemm_search_few_keys_dev) reads half the bytes of the exact scan's pass and costs ~65 us more around it: 1M x 512 (2 GB)
+// 332 -> 253 us, 1M x 1280 790 -> 550 us, 300 000 x 512 116 -> 173 us (not taken). With 2 queries the two forms tie, from 3 on
+// the dot products (v_dot2 + one LDS read per query and fragment) cost more than the bytes saved: those stay with the f32 scan.
+bool wants_few(const fir_gallery* g, int32_t qb, int32_t start, int32_t end) {
+    if (g->metric != FIR_METRIC_L2 || start != 0 || g->n < kAutoMfmaRows || g->tiles_limit > 0 || g->qpp != 0 || g->profiling) return false;
+    if (end != g->d && (end < 64 || end % 16 != 0)) return false;
+    if (g->large_batch_min >= 0 || g->gemm_failed) return false;
+    return qb == 1 && (double)g->n * (double)end * 4.0 >= 1500.0e6;
+}
+
 void note_dispatch(fir_gallery* g, const void* fn, const char* name, int launches_add, int gx, int gy, int block, size_t dyn_lds, int qpp,
                    double bytes, double flops, int path) {
     fir_dispatch_info& L = g->last;
@@ -1015,6 +1026,12 @@ int ensure_gemm(fir_gallery* g, int32_t end, fir_gemm** m) {
 int try_mfma(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start, int32_t end, uint64_t* d_keys, hipStream_t st,
              const float* h_queries = nullptr) {
     // h_queries: the queries are still on the host and d_queries is the (writable) device buffer they are staged through
+    if (!h_queries && wants_few(g, qb, start, end)) {
+        fir_gemm* mf = nullptr;
+        const int rcf = ensure_gemm(g, end, &mf);
+        if (rcf) return rcf;
+        return fir_gemm_search_few_keys_dev(mf, d_queries, qb, d_keys, st);
+    }
     if (!wants_mfma(g, qb, start, end)) return 1;
     fir_gemm* m = nullptr;
     const int rc = ensure_gemm(g, end, &m);
@@ -1234,7 +1251,9 @@ int fir_search_top1(fir_gallery* g, const float* queries, int32_t qb, int32_t st
             if (rc < 0) return rc;
             if (rc == FIR_OK) return fir_keys_unpack(hk, 1, idx, dist);
         }
-        if ((rc = top1_dev(g, hq, qb, start_pos, end_pos, g->dkeys, g->stream))) return rc;
+        rc = try_mfma(g, hq, qb, start_pos, end_pos, g->dkeys, g->stream);              // (the few-query form on large galleries; else 1)
+        if (rc < 0) return rc;
+        if (rc > 0 && (rc = top1_dev(g, hq, qb, start_pos, end_pos, g->dkeys, g->stream))) return rc;
         const uint64_t ticket = qb <= kBlock && !g->profiling ? ++g->one_ticket : 0;     // one block publishes: the host can wait on its ticket
         hipLaunchKernelGGL(k_publish_keys, dim3((qb + kBlock - 1) / kBlock), dim3(kBlock), 0, g->stream, g->dkeys, qb, hk, ticket);
         FIR_HIP(hipGetLastError());

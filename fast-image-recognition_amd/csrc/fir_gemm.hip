@@ -1156,6 +1156,89 @@ __global__ void __launch_bounds__(64) k_gemm_rerank(const unsigned long long* __
     }
 }
 
+// ---- calls of 1..8 queries against a gallery that does not fit the caches ----
+// Such a call is one gallery pass whatever it computes, so it is bound by the bytes of that pass: the exact f32 scan reads n*d*4
+// (337 us at 1M x 512), this nomination scan reads the fp16 copy, n*d*2. No matrix cores (eight queries would fill 1/16 of a
+// tile): v_dot2c_f32_f16 on the same fragments, lane l = row l & 31, k-half l >> 5. Every proxy is written out (n floats per
+// query) together with the smallest one per query; tau = smallest proxy of ALL rows + one window (k_gemm_tau_min), the rows
+// below it are collected (k_gemm_select) and re-ranked exactly with the usual certificate (k_gemm_rerank) -- which holds by
+// construction here: every excluded row is a full window above the smallest proxy.
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+template <int NQ>
+__global__ void __launch_bounds__(256) k_gemm_scan_f16(const uint4* __restrict__ gh, const float* __restrict__ gnorm, const uint4* __restrict__ qh,
+                                                        const float* __restrict__ qinv, int64_t n, int dk16, float* __restrict__ proxies,
+                                                        unsigned int* __restrict__ smin) {
+    extern __shared__ __attribute__((aligned(16))) uint4 qsf[];           // [k-block][k-half][query]
+    for (int idx = threadIdx.x; idx < dk16 * 2 * NQ; idx += blockDim.x) {
+        const int i = idx % NQ, h = (idx / NQ) & 1, kb = idx / (2 * NQ);
+        qsf[idx] = qh[(size_t)kb * 64 + 32 * h + i];                      // queries 0..7 sit in query block 0 of the pair's fragments
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, h = lane >> 5;
+    const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int64_t nrb = (n + 31) / 32;
+    float m2[NQ], smallest[NQ];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) { m2[i] = 2.0f * qinv[i]; smallest[i] = __builtin_huge_valf(); }
+    for (int64_t rb = gw; rb < nrb; rb += nw) {
+        const uint4* a = gh + (size_t)rb * dk16 * 64 + lane;
+        float acc[NQ];
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) acc[i] = 0.f;
+        for (int kb0 = 0; kb0 < dk16; kb0 += 8) {                          // dk16 is a multiple of 8
+            uint4 g[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) g[u] = ld_nt(a + (size_t)(kb0 + u) * 64);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                f16x2 gv[4];
+                __builtin_memcpy(gv, &g[u], 16);
+#pragma unroll
+                for (int i = 0; i < NQ; ++i) {
+                    const uint4 qq = qsf[((kb0 + u) * 2 + h) * NQ + i];
+                    f16x2 qv[4];
+                    __builtin_memcpy(qv, &qq, 16);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[i] = __builtin_amdgcn_fdot2(gv[t], qv[t], acc[i], false);
+                }
+            }
+        }
+        const int64_t row = rb * 32 + (lane & 31);
+        const float gn = row < n ? gnorm[row] : 0.f;
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const float dot = acc[i] + __shfl_xor(acc[i], 32, 64);        // the two k-halves of the row
+            if (lane < 32 && row < n) {
+                const float p = __builtin_fmaf(-m2[i], dot, gn);
+                proxies[(size_t)i * n + row] = p;
+                smallest[i] = fminf(smallest[i], p);                       // NaN never enters
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        float v = smallest[i];
+#pragma unroll
+        for (int off = 16; off >= 1; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
+        if (lane == 0 && v < __builtin_huge_valf()) atomicMin(&smin[i], fir::f32_orderable(v));
+    }
+}
+
+// lists[q] <- every row whose proxy is below tau[q] (blockIdx.y = query)
+__global__ void __launch_bounds__(256) k_gemm_select(const float* __restrict__ proxies, int64_t n, const float* __restrict__ tau,
+                                                      unsigned long long* __restrict__ lists, int* __restrict__ counts) {
+    const int q = blockIdx.y;
+    const float tq = tau[q];
+    const float* p = proxies + (size_t)q * n;
+    for (int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x; row < n; row += (int64_t)gridDim.x * 256) {
+        const float v = p[row];
+        if (v < tq) {
+            const int slot = atomicAdd(&counts[q], 1);
+            if (slot < kListCap) lists[(size_t)q * kListCap + slot] = fir::key_pack(v, (uint32_t)row);
+        }
+    }
+}
+
 // The K nearest rows (K <= kTopKMax) from the same lists: as k_gemm_rerank with the window hung on the K-th smallest proxy
 // of the list, every lane keeping the K smallest exact keys it computed, K rounds of wave-minimum at the end, and the
 // certificate taken against the K-th exact distance: no row outside the re-ranked set can be among the K nearest, nor tie
@@ -1338,6 +1421,7 @@ struct fir_gemm {
     int feat = 0;               // features compared: the gallery's d, or a prefix [0, feat) of every row (fir_gemm_create_range); v.d stays the row length
     int precision = 0;          // 0: f32 MFMA, 1: bf16 split (hi.hi + hi.lo + lo.hi), 2: one fp16 term
     uint4* gh = nullptr;        // fp16 fragments (precision 2)
+    float* proxies = nullptr;   // few-query calls: every row's proxy, 8 x n floats (allocated on first use)
     float4* rowmajor = nullptr; // row-major f32 copy of the compared features for the re-rank's gathers (absent when HBM is short: the tiled gallery serves)
     int gallery_exp = 0;        // fp16: the gallery was multiplied by 2^gallery_exp
     float* qmul[2] = {nullptr, nullptr};
@@ -1542,7 +1626,7 @@ int fir_gemm_destroy(fir_gemm* m) {
         if (m->prep_done[b]) (void)hipEventDestroy(m->prep_done[b]);
     }
     if (m->queries_ready) (void)hipEventDestroy(m->queries_ready);
-    (void)hipFree(m->gm); (void)hipFree(m->gb); (void)hipFree(m->gh); (void)hipFree(m->rowmajor); (void)hipFree(m->gnorm); (void)hipFree(m->gmax); (void)hipFree(m->sample); (void)hipFree(m->ok);
+    (void)hipFree(m->gm); (void)hipFree(m->gb); (void)hipFree(m->gh); (void)hipFree(m->rowmajor); (void)hipFree(m->proxies); (void)hipFree(m->gnorm); (void)hipFree(m->gmax); (void)hipFree(m->sample); (void)hipFree(m->ok);
     (void)hipFree(m->fbq); (void)hipFree(m->fbkeys);
         if (m->copy) { (void)hipStreamSynchronize(m->copy); (void)hipStreamDestroy(m->copy); }
     for (int b = 0; b < 2; ++b) if (m->copy_done[b]) (void)hipEventDestroy(m->copy_done[b]);
@@ -1834,6 +1918,58 @@ int fir_gemm_search_top1_keys_dev(fir_gemm* m, const float* d_queries, int32_t q
 
 int fir_gemm_search_topk_keys_dev(fir_gemm* m, const float* d_queries, int32_t qb, int32_t k, uint64_t* d_keys, void* stream) {
     return gemm_search(m, d_queries, qb, k, d_keys, stream);
+}
+
+// 1..8 queries against a gallery too large for the caches: one pass over the fp16 copy (k_gemm_scan_f16), the rows within one
+// window of the smallest proxy of ALL rows, exact re-rank, certificate; everything on `stream`, one synchronisation.
+int fir_gemm_search_few_keys_dev(fir_gemm* m, const float* d_queries, int32_t qb, uint64_t* d_keys, void* stream) {
+    if (!m || !d_keys || !d_queries) return gemm_fail(FIR_ERR_ARG, "NULL argument");
+    if (qb < 1 || qb > 8) return gemm_fail(FIR_ERR_ARG, "qb=%d outside [1,8]", qb);
+    if (m->precision != FIR_GEMM_F16) return gemm_fail(FIR_ERR_ARG, "the few-query form needs the fp16 copy");
+    GEMM_HIP(hipSetDevice(m->v.device));
+    hipStream_t st = stream ? (hipStream_t)stream : m->v.stream;
+    const int d = m->feat, qs = m->v.d;
+    const int64_t n = m->v.n;
+    if (n == 0) return fir_search_top1_exact_keys_dev_(m->g, d_queries, qb, 0, d, d_keys, st);
+    if (!m->proxies) GEMM_HIP(hipMalloc((void**)&m->proxies, (size_t)8 * n * sizeof(float)));
+    if (m->ok_cap < 1024) {
+        if (m->ok) GEMM_HIP(hipFree(m->ok));
+        m->ok = nullptr;
+        GEMM_HIP(hipMalloc((void**)&m->ok, 1024 * sizeof(int)));
+        m->ok_cap = 1024;
+    }
+    const float e_rel = 8.0f * (float)d * 5.9604645e-8f + 9.765625e-4f * 1.0625f;     // as gemm_search (one fp16 term)
+    const int b = 0;
+    hipLaunchKernelGGL(k_gemm_qprep_f16, dim3(2 * kQT), dim3(64), 0, st, d_queries, qb, d, m->gallery_exp, m->qnorm[b], m->qmul[b], m->qinv[b], qs);
+    GEMM_HIP(hipMemsetAsync(m->counts[b], 0, 2 * kQT * sizeof(int), st));
+    hipLaunchKernelGGL(k_gemm_pack_queries_f16, dim3((4 * m->dk16 * 64 + 255) / 256, 1), dim3(256), 0, st, d_queries, qb, d, m->dk16, m->qmul[b], m->qbf[b], qs);
+    GEMM_HIP(hipMemsetD32Async((hipDeviceptr_t)m->smin[b], (int)0xFF800000u, 2 * kQT, st));
+    const int nqt = qb <= 1 ? 1 : qb <= 2 ? 2 : qb <= 4 ? 4 : 8;
+    const dim3 grid((unsigned)std::min<int64_t>((int64_t)m->v.cus * 8, ((n + 31) / 32 + 3) / 4));
+    const size_t lds = (size_t)m->dk16 * 2 * nqt * sizeof(uint4);
+#define FIR_FEW(NQ) hipLaunchKernelGGL(k_gemm_scan_f16<NQ>, grid, dim3(256), lds, st, m->gh, m->gnorm, m->qbf[b], m->qinv[b], n, m->dk16, m->proxies, m->smin[b])
+    if (nqt == 1) FIR_FEW(1); else if (nqt == 2) FIR_FEW(2); else if (nqt == 4) FIR_FEW(4); else FIR_FEW(8);
+#undef FIR_FEW
+    fir_gallery_note_dispatch_(m->g, nqt == 1 ? (const void*)k_gemm_scan_f16<1> : nqt == 2 ? (const void*)k_gemm_scan_f16<2> : nqt == 4 ? (const void*)k_gemm_scan_f16<4>
+                                                                                                                                             : (const void*)k_gemm_scan_f16<8>,
+                               "fir::k_gemm_scan_f16", 1, (int)grid.x, 1, 256, lds, nqt, (double)((n + 31) / 32) * m->dk16 * 1024.0 + (double)nqt * n * 4.0,
+                               2.0 * (double)n * d * nqt);
+    hipLaunchKernelGGL(k_gemm_tau_min, dim3(1), dim3(256), 0, st, m->smin[b], m->tau[b], 2 * kQT, qb, m->qnorm[b], m->gmax, e_rel);
+    hipLaunchKernelGGL(k_gemm_select, dim3((unsigned)std::min<int64_t>(1024, (n + 255) / 256), qb), dim3(256), 0, st, m->proxies, n, m->tau[b], m->lists[b], m->counts[b]);
+    hipLaunchKernelGGL(k_gemm_rerank, dim3(qb), dim3(64), (size_t)(m->rerank_group + 1) * (m->dp4 + 1) * sizeof(float4), st, m->lists[b], m->counts[b], m->tau[b], m->gal4,
+                       d_queries, m->qnorm[b], m->gmax, n, d, m->dp4, m->v.row_offset, e_rel, m->rerank_group, (unsigned long long*)d_keys, m->ok, qs, m->rowmajor);
+    GEMM_HIP(hipGetLastError());
+    int h_ok[8];
+    GEMM_HIP(hipMemcpyAsync(h_ok, m->ok, (size_t)qb * sizeof(int), hipMemcpyDeviceToHost, st));
+    GEMM_HIP(hipStreamSynchronize(st));
+    m->passes += 1;
+    for (int i = 0; i < qb; ++i) {
+        if (h_ok[i]) continue;
+        ++m->fallbacks;
+        const int rc = fir_search_top1_exact_keys_dev_(m->g, d_queries + (size_t)i * qs, 1, 0, d, d_keys + i, st);
+        if (rc) return rc;
+    }
+    return FIR_OK;
 }
 
 // Host-pointer form for fir_search_top1 / fir_search_topk: h_queries -> d_stage (qb rows of the gallery's length) super-batch by

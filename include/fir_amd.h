@@ -255,6 +255,11 @@ int fir_gemm_create_ex(fir_gallery* g, int32_t precision, fir_gemm** out);
 int fir_gemm_create_range(fir_gallery* g, int32_t precision, int32_t end_pos, fir_gemm** out);
 int fir_gemm_destroy(fir_gemm* m);
 int fir_gemm_search_top1_keys_dev(fir_gemm* m, const float* d_queries, int32_t qb, uint64_t* d_keys, void* stream);
+/* 1..8 queries: one pass over the fp16 copy with v_dot2 (no matrix cores), the rows within one rounding window of the smallest proxy of
+ * ALL rows re-ranked exactly, same certificate, same keys. Half the bytes of the exact scan's pass: the search entry points route
+ * ONE-query L2 calls here when the compared rows are >= 1.5 GB (332 -> 253 us for one query against 1M x 512; with two queries the
+ * forms tie, beyond that the f32 scan is faster). */
+int fir_gemm_search_few_keys_dev(fir_gemm* m, const float* d_queries, int32_t qb, uint64_t* d_keys, void* stream);
 /* The k nearest rows (2 <= k <= 8; k = 1 is the call above): d_keys[q * k + r], ascending, the keys fir_search_topk_keys_dev
  * gives. The bound of the append pass is an order statistic of a row sample plus one rounding window; the re-rank window hangs
  * on the k-th smallest proxy and the certificate is taken against the k-th exact distance. fir_search_topk[_keys_dev] route

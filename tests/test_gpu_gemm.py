@@ -384,3 +384,60 @@ def test_default_dispatch_takes_small_batches_on_large_galleries(fir):
         g.close()
         del x, q
     torch.cuda.empty_cache()
+
+
+def test_few_queries_on_a_large_gallery_take_the_fp16_nomination_scan(fir):
+    """ONE L2 query against >= 1.5 GB of rows: one pass over the fp16 copy (k_gemm_scan_f16: v_dot2, no matrix cores), every row
+    within one rounding window of the smallest proxy of ALL rows re-ranked exactly -- the exact scan's key, with an exact duplicate
+    (lowest row wins), a near-duplicate one ulp away, a NaN query, through device and host pointers; and the same form by handle
+    for up to 8 queries."""
+    dev = torch.device("cuda", 0)
+    n, d = 800_000, 512
+    x = torch.rand((n, d), device=dev)
+    x = (x / x.norm(dim=1, keepdim=True)).contiguous()
+    x[650_000] = x[777]                                    # exact duplicate: row 777 wins
+    x[123_456] = x[999]
+    x[123_456, 3] = torch.nextafter(x[999, 3], torch.tensor(2.0, device=dev))
+    q = (x[torch.tensor([777, 999, 5, 799_999, 64, 100_001, 7], device=dev)] * 0.99 + x[:7] * 0.01).contiguous()
+    q[0] = x[777]
+    q[1] = x[999]
+    q = torch.cat([q, torch.full((1, d), float("nan"), device=dev)]).contiguous()
+    g = fir.Gallery(dev_ptr=x.data_ptr(), n=n, d=d, metric=0, device=0)
+    k1 = torch.empty(1, dtype=torch.int64, device=dev)
+    k2 = torch.empty(1, dtype=torch.int64, device=dev)
+    for i in range(8):
+        qi = q[i:i + 1].contiguous()
+        g.set_large_batch_mfma(-1)
+        g.search_top1_keys_dev(qi.data_ptr(), 1, k1.data_ptr())
+        g.sync()
+        dsp = g.last_dispatch()
+        assert dsp["path"] == "mfma" and "k_gemm_scan_f16" in dsp["kernel"], dsp
+        hidx, hdist = g.search_top1(qi.cpu().numpy())               # host pointers: the same form
+        assert "k_gemm_scan_f16" in g.last_dispatch()["kernel"]
+        g.search_top1_keys_dev(q.data_ptr(), 2, torch.empty(2, dtype=torch.int64, device=dev).data_ptr())
+        g.sync()
+        assert g.last_dispatch()["path"] == "scan"                   # two queries: the f32 scan
+        g.set_large_batch_mfma(0)
+        g.search_top1_keys_dev(qi.data_ptr(), 1, k2.data_ptr())
+        g.sync()
+        assert g.last_dispatch()["path"] == "scan"
+        assert torch.equal(k1, k2), i
+        idx, dist = fir.keys_unpack(k2.cpu().numpy().view(np.uint64))
+        assert np.array_equal(hidx, idx) and np.array_equal(hdist.view(np.uint32), dist.view(np.uint32))
+        if i == 0:
+            assert idx[0] == 777 and dist[0] == 0
+        if i == 1:
+            assert idx[0] == 999
+    with fir.GemmSearch(g, 2) as m:
+        for qb in (2, 3, 5, 8):
+            kq = torch.empty(qb, dtype=torch.int64, device=dev)
+            eq = torch.empty(qb, dtype=torch.int64, device=dev)
+            m.search_few_keys_dev(q.data_ptr(), qb, kq.data_ptr())
+            torch.cuda.synchronize()
+            g.search_top1_keys_dev(q.data_ptr(), qb, eq.data_ptr())   # (the matrix-core path is off: the exact scan)
+            g.sync()
+            assert torch.equal(kq, eq), qb
+        assert m.stats()["fallback_queries"] <= 1                     # the NaN query
+    g.close()
+    del x
+    torch.cuda.empty_cache()
