@@ -257,9 +257,16 @@ bool wants_mfma(const fir_gallery* g, int32_t qb, int32_t start, int32_t end) {
     // Smaller batches on larger galleries: a matrix-core call costs ~125 us + 0.1 us per MB of compared rows whatever the batch
     // (up to 128 queries), the scan 0.15 us per MB for every 8 queries. Measured at d = 512 (one MI355X, device pointers):
     // 1M rows 8 / 16 / 64 queries: scan 397 / 750 / 2583 us, matrix cores 347 / 336 / 343; 100 000 rows 16 / 32 / 64: 108 / 283 /
-    // 445 against 146 / 148 / 159; 65 536 rows 32 / 64: 134 / 429 against 133 / 148.
+    // 445 against 146 / 148 / 159; 65 536 rows 32 / 64: 134 / 429 against 133 / 148; 1M rows 2 / 4 / 7 queries: 349 / 353 / 1016 against ~345.
     const double mb = (double)g->n * (double)end * 4.0 / 1.0e6;
-    return qb >= kAutoMfmaQueries || (qb >= 32 && mb >= 128.0) || (qb >= 16 && mb >= 800.0) || (qb >= 8 && mb >= 2000.0);
+    if (qb >= kAutoMfmaQueries || (qb >= 32 && mb >= 128.0)) return true;
+    if (qb < 2 || mb < 300.0) return false;
+    // 2..31 queries over rows streamed from HBM: the scan takes one pass per power-of-two group of up to 8 queries (3 queries: 2 + 1,
+    // 7: 4 + 2 + 1), ~10 us + 0.185 us per MB each (397 us for 8 queries, 1016 us for 7 at 1M x 512); the matrix-core call ~125 us +
+    // 0.105 us per MB for anything up to 128 queries (347 us there)
+    const int passes = qb / 8 + __builtin_popcount((unsigned)qb & 7u);
+    if (passes == 1 && qb < 8) return false;                   // 2 or 4 queries: one narrow pass (349 / 353 us), a tie -- the scan needs no fp16 copy
+    return 125.0 + 0.105 * mb < passes * (10.0 + 0.185 * mb);
 }
 
 // ONE query against rows far beyond the caches (automatic mode only): the nomination scan over the fp16 copy

@@ -363,11 +363,13 @@ def test_topk_matrix_cores_with_hostile_rows_and_queries(fir):
 
 
 def test_default_dispatch_takes_small_batches_on_large_galleries(fir):
-    """The automatic threshold falls with the size of the gallery (a matrix-core call costs about the same from 8 to 128
-    queries, the scan one gallery pass per 8): 32 queries from 128 MB of compared rows on, 16 from 0.8 GB, 8 from 2 GB. Same keys."""
+    """The automatic threshold falls with the size of the gallery (a matrix-core call costs about the same from 2 to 128
+    queries, the scan one gallery pass per power-of-two group of up to 8): 32 queries from 128 MB of compared rows on, fewer where
+    the cost model says so (7 = 4 + 2 + 1 queries are three scan passes). Same keys."""
     dev = torch.device("cuda", 0)
     d = 512
-    for n, qb, want in ((70_000, 32, "mfma"), (70_000, 16, "scan"), (400_000, 16, "mfma"), (400_000, 8, "scan"), (1_000_000, 8, "mfma")):
+    for n, qb, want in ((70_000, 32, "mfma"), (70_000, 16, "scan"), (400_000, 16, "mfma"), (400_000, 8, "scan"), (400_000, 7, "mfma"),
+                        (1_000_000, 8, "mfma"), (1_000_000, 3, "mfma"), (1_000_000, 4, "scan")):
         x = torch.rand((n, d), device=dev)
         x = (x / x.norm(dim=1, keepdim=True)).contiguous()
         q = (x[:: n // qb][:qb] * 0.97 + x[1: qb + 1] * 0.03).contiguous()
@@ -416,7 +418,7 @@ def test_few_queries_on_a_large_gallery_take_the_fp16_nomination_scan(fir):
         assert "k_gemm_scan_f16" in g.last_dispatch()["kernel"]
         g.search_top1_keys_dev(q.data_ptr(), 2, torch.empty(2, dtype=torch.int64, device=dev).data_ptr())
         g.sync()
-        assert g.last_dispatch()["path"] == "scan"                   # two queries: the f32 scan
+        assert g.last_dispatch()["path"] == "scan"                   # two queries (one scan pass, 1.6 GB): the f32 scan
         g.set_large_batch_mfma(0)
         g.search_top1_keys_dev(qi.data_ptr(), 1, k2.data_ptr())
         g.sync()
