@@ -243,8 +243,7 @@ int top1_qpp(const fir_gallery* g, int qb, int cap) {
 
 // Automatic matrix-core dispatch (fir_gallery_set_large_batch_mfma): measured on MI355X, 1M x 512: 256 queries 444k/s
 // against 26k/s through the exact scan, identical keys (profiles/); below ~64k rows the gallery is cache-resident and the
-// scan's 16-queries-per-pass form is within reach of it, and the fixed cost of the path (sample pass, re-rank,
-// certificate read-back) is not amortised.
+// scan's 16-queries-per-pass form is within reach of it for small batches: a cost model of the two forms decides there.
 constexpr int kAutoMfmaQueries = 128;
 constexpr int64_t kAutoMfmaRows = 65536;
 bool wants_mfma(const fir_gallery* g, int32_t qb, int32_t start, int32_t end) {
@@ -253,7 +252,21 @@ bool wants_mfma(const fir_gallery* g, int32_t qb, int32_t start, int32_t end) {
     if (end != g->d && (end < 64 || end % 16 != 0)) return false;
     if (g->large_batch_min == 0 || g->gemm_failed) return false;
     if (g->large_batch_min > 0) return qb >= g->large_batch_min;
-    if (g->n < kAutoMfmaRows || g->qpp != 0) return false;                     // a pinned queries-per-pass asks for the scan
+    if (g->qpp != 0) return false;                                              // a pinned queries-per-pass asks for the scan
+    if (g->n < kAutoMfmaRows) {
+        // Cache-resident galleries: the scan folds its 16-query passes into one launch, ~40 us + (2 us + 0.25 us per MB) per pass;
+        // the matrix-core call ~125 us (225 us with rows longer than 512 features: streamed query slabs) + 0.06 (0.12) us per MB and
+        // 128 queries. Measured (us, scan / matrix cores): 40 000 x 512: 128 queries 329 / 140, 1 024: 1 568 / 178; 16 384 x 512:
+        // 128: 121 / 135, 256: 234 / 138, 1 024: 788 / 155; 8 192 x 512: 256: 105 / 133, 1 024: 303 / 145; 30 000 x 1536: 128:
+        // 589 / 387, 1 024: 4 036 / 496; 3 030 x 1536 (the reference's gallery): 256: 136 / 270, 1 024: 377 / 346. The matrix cores
+        // are taken where the model gives them 15 % or more.
+        if (g->n < 2048 || qb < 64) return false;
+        const double mbs = (double)g->n * (double)end * 4.0 / 1.0e6;
+        const bool streamed = end > 512;
+        const double mfma_us = (streamed ? 225.0 : 125.0) + (double)((qb + 127) / 128) * (streamed ? 0.12 : 0.06) * mbs;
+        const double scan_us = 40.0 + (double)((qb + 15) / 16) * (2.0 + 0.25 * mbs);
+        return mfma_us * 1.15 < scan_us;
+    }
     // Smaller batches on larger galleries: a matrix-core call costs ~125 us + 0.1 us per MB of compared rows whatever the batch
     // (up to 128 queries), the scan 0.15 us per MB for every 8 queries. Measured at d = 512 (one MI355X, device pointers):
     // 1M rows 8 / 16 / 64 queries: scan 397 / 750 / 2583 us, matrix cores 347 / 336 / 343; 100 000 rows 16 / 32 / 64: 108 / 283 /

@@ -443,3 +443,20 @@ def test_few_queries_on_a_large_gallery_take_the_fp16_nomination_scan(fir):
     g.close()
     del x
     torch.cuda.empty_cache()
+
+
+def test_default_dispatch_on_cache_resident_galleries(fir, oracle):
+    """Below 65 536 rows a cost model of the two forms decides (the scan folds its 16-query passes into one launch): large batches take
+    the matrix cores down to a few thousand rows, small ones and the reference's own gallery size with a few hundred queries stay
+    with the scan. Same keys either way, the oracle's on a sample."""
+    for n, d, qb, want in ((40000, 512, 128, "mfma"), (40000, 512, 32, "scan"), (16384, 512, 1024, "mfma"), (16384, 512, 128, "scan"),
+                           (3030, 1536, 256, "scan"), (3030, 1536, 2000, "mfma"), (1500, 512, 2000, "scan")):
+        rows = synth.make_gallery(n % 89, n, d, 0)
+        q, _ = synth.make_queries(n % 89, rows, qb, 0)
+        with fir.Gallery(rows, None, 0, 0) as g:
+            a = g.search_top1(q)
+            assert g.last_dispatch()["path"] == want, (n, d, qb)
+            g.set_large_batch_mfma(0)
+            e = g.search_top1(q)
+        assert np.array_equal(a[0], e[0]) and np.array_equal(a[1].view(np.uint32), e[1].view(np.uint32)), (n, d, qb)
+        assert (a[0][0], a[1][0]) == oracle.recognize_bf(rows, q[0], 0, d, 0)
