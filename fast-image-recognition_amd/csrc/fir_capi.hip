@@ -92,6 +92,7 @@ struct fir_gallery {
     // (kAutoMfmaQueries queries against at least kAutoMfmaRows rows), 0 = never, > 0 = the caller's threshold
     int large_batch_min = -1;
     fir_gemm* gemm_prefix = nullptr; int gemm_prefix_end = 0;   // the matrix-core state of the last feature prefix [0, end) asked for ("BF, 64" / "BF, 256")
+    int small_hits = 0, few_hits = 0;   // automatic mode: calls so far that would have profited from a matrix-core state not built yet (see ensure_gemm)
     bool gemm_failed = false; // automatic mode: the matrix-core path could not be set up for this shape (rows too long): scan
     fir_gemm* gemm = nullptr; // created on first use
     fir_dispatch_info last{}; // dominant kernel of the most recent search
@@ -1022,9 +1023,14 @@ int fir_feature_distance(const float* lhs, const float* rhs, int32_t len, int32_
 
 namespace {
 // 0 = *m is the handle's fir_gemm for features [0, end), 1 = this shape stays with the scan, < 0 = error
-int ensure_gemm(fir_gallery* g, int32_t end, fir_gemm** m) {
+int ensure_gemm(fir_gallery* g, int32_t end, fir_gemm** m, int* warm = nullptr, int warm_calls = 0) {
+    // warm / warm_calls (automatic dispatch of cases that save tens to hundreds of microseconds per call: cache-resident galleries,
+    // one-query calls): the state -- an fp16 copy, scratch, and the first time in a process ~12 ms of kernel loading -- is only built for
+    // a gallery that keeps getting such calls; the first warm_calls of them take the scan (a test harness that makes ONE batched call
+    // against a 3 030-row gallery would pay 16 ms to save 2)
     const bool whole = end == g->d;
     fir_gemm*& slot = whole ? g->gemm : g->gemm_prefix;
+    if (warm && !(slot && (whole || g->gemm_prefix_end == end)) && g->large_batch_min < 0 && ++*warm <= warm_calls) return 1;
     if (!whole && slot && g->gemm_prefix_end != end) {          // another prefix than last time: its fragments replace the old ones
         fir_gemm_destroy(slot);
         slot = nullptr;
@@ -1048,13 +1054,13 @@ int try_mfma(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start, 
     // h_queries: the queries are still on the host and d_queries is the (writable) device buffer they are staged through
     if (!h_queries && wants_few(g, qb, start, end)) {
         fir_gemm* mf = nullptr;
-        const int rcf = ensure_gemm(g, end, &mf);
+        const int rcf = ensure_gemm(g, end, &mf, &g->few_hits, 16);
         if (rcf) return rcf;
         return fir_gemm_search_few_keys_dev(mf, d_queries, qb, d_keys, st);
     }
     if (!wants_mfma(g, qb, start, end)) return 1;
     fir_gemm* m = nullptr;
-    const int rc = ensure_gemm(g, end, &m);
+    const int rc = g->n < kAutoMfmaRows ? ensure_gemm(g, end, &m, &g->small_hits, 3) : ensure_gemm(g, end, &m);
     if (rc) return rc;
     if (h_queries) return fir_gemm_search_staged_(m, h_queries, (float*)d_queries, qb, 1, d_keys, st);
     return fir_gemm_search_top1_keys_dev(m, d_queries, qb, d_keys, st);
@@ -1062,7 +1068,7 @@ int try_mfma(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start, 
 int try_mfma_topk(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start, int32_t end, int32_t k, uint64_t* d_keys, hipStream_t st) {
     if (k < 2 || !wants_mfma(g, qb, start, end)) return 1;       // K = 1 callers use the top-1 entry points
     fir_gemm* m = nullptr;
-    const int rc = ensure_gemm(g, end, &m);
+    const int rc = g->n < kAutoMfmaRows ? ensure_gemm(g, end, &m, &g->small_hits, 3) : ensure_gemm(g, end, &m);
     if (rc) return rc;
     return fir_gemm_search_topk_keys_dev(m, d_queries, qb, k, d_keys, st);
 }
@@ -1372,7 +1378,7 @@ int fir_search_topk(fir_gallery* g, const float* queries, int32_t qb, int32_t st
     rc = 1;
     if (k >= 2 && wants_mfma(g, qb, start_pos, end_pos)) {
         fir_gemm* m = nullptr;
-        rc = ensure_gemm(g, end_pos, &m);
+        rc = g->n < kAutoMfmaRows ? ensure_gemm(g, end_pos, &m, &g->small_hits, 3) : ensure_gemm(g, end_pos, &m);
         if (rc == 0) rc = fir_gemm_search_staged_(m, queries, g->dq, qb, k, g->dkeys, g->stream);
         if (rc < 0) return rc;
     }

@@ -257,7 +257,7 @@ int fir_gemm_destroy(fir_gemm* m);
 int fir_gemm_search_top1_keys_dev(fir_gemm* m, const float* d_queries, int32_t qb, uint64_t* d_keys, void* stream);
 /* 1..8 queries: one pass over the fp16 copy with v_dot2 (no matrix cores), the rows within one rounding window of the smallest proxy of
  * ALL rows re-ranked exactly, same certificate, same keys. Half the bytes of the exact scan's pass: the search entry points route
- * ONE-query L2 calls here when the compared rows are >= 1.5 GB (332 -> 253 us for one query against 1M x 512; with two queries the
+ * ONE-query L2 calls here when the compared rows are >= 1.5 GB, from the gallery's 17th such call on (332 -> 253 us for one query against 1M x 512; with two queries the
  * forms tie, beyond that the f32 scan is faster). */
 int fir_gemm_search_few_keys_dev(fir_gemm* m, const float* d_queries, int32_t qb, uint64_t* d_keys, void* stream);
 /* The k nearest rows (2 <= k <= 8; k = 1 is the call above): d_keys[q * k + r], ascending, the keys fir_search_topk_keys_dev
@@ -267,7 +267,8 @@ int fir_gemm_search_few_keys_dev(fir_gemm* m, const float* d_queries, int32_t qb
 int fir_gemm_search_topk_keys_dev(fir_gemm* m, const float* d_queries, int32_t qb, int32_t k, uint64_t* d_keys, void* stream);
 /* fir_search_top1 and fir_search_top1_keys_dev send L2 whole-range batches through this path BY DEFAULT when the batch
  * has >= 128 queries and the gallery >= 65536 rows (smaller, cache-resident galleries: where a cost model of the two forms gives the
- * matrix cores 15 % or more -- e.g. 128 queries against 40 000 x 512, 1 024 against 8 192 x 512; fewer queries on larger galleries: 32 from 128 MB of compared rows on; from 300 MB on wherever a cost model of the two forms says so -- 3, 5, 6, 7 queries are two or three scan passes -- down to 3 queries) (created on first use; costs the extra fp16 gallery copy, n*d*2
+ * matrix cores 15 % or more -- e.g. 128 queries against 40 000 x 512, 1 024 against 8 192 x 512 --, from the gallery's fourth such
+ * call on; fewer queries on larger galleries: 32 from 128 MB of compared rows on; from 300 MB on wherever a cost model of the two forms says so -- 3, 5, 6, 7 queries are two or three scan passes -- down to 3 queries) (created on first use; costs the extra fp16 gallery copy, n*d*2
  * bytes; identical keys). min_queries > 0: the caller's threshold instead (any gallery size); 0: never, frees the copy
  * (the exact streaming scan answers everything); < 0: back to the default. */
 int fir_gallery_set_large_batch_mfma(fir_gallery* g, int32_t min_queries);
