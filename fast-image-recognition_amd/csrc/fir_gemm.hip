@@ -974,6 +974,7 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16(const uint4* _
 #undef FIR_H_LD
 }
 
+#include "fir_gemm_f16x.h"
 #include "fir_gemm_regtile.h"
 
 // tau[q] = kCand-th smallest sampled proxy, nudged up so that ties with it are appended too. One block per
@@ -1455,6 +1456,9 @@ struct fir_gemm {
     unsigned int* smin[2] = {nullptr, nullptr};   // register-tile flow: smallest sampled proxy per query (orderable bits)
     int rt_sample_rows = 0;                // ... over this many rows (n / 32)
     int regtile = -1;                     // fp16 full pass through the register-tile kernel: -1 = where it measured faster (rows up to 256 features), 0 / 1 = never / wherever it exists (FIR_GEMM_REGTILE)                  // fp16 full pass: query fragments in registers, gallery through the LDS-DMA ring (FIR_GEMM_REGTILE=0: the LDS-tile kernel)
+    int mfma16 = 0;                       // fp16: both operands in the 16-row fragment order, every pass on v_mfma_f32_16x16x32_f16 (fir_gemm_f16x.h): the default since it was
+                                          // measured against the 32x32x16 kernels at the same wave tile (profiles/r03_mfma_shape_ab.txt); FIR_GEMM_MFMA16=0 brings those back
+    int stagger = 0;                      // mfma16 experiment: the second wave of every SIMD starts half a unit late (FIR_GEMM_STAGGER)
     int share_max = 16;                   // fp16: up to this many pairs of passes (x 128 queries) read the gallery together in one launch (FIR_GEMM_SHARE; 0 = the old one-pair-at-a-time grid)
 };
 
@@ -1548,6 +1552,15 @@ int fir_gemm_create_range(fir_gallery* g, int32_t precision, int32_t end_pos, fi
                        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy_f16_regtile<D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RegTile<D>::lds_bytes);
     FIR_RT_ATTR(8) FIR_RT_ATTR(16) FIR_RT_ATTR(32)
 #undef FIR_RT_ATTR
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy_f16x<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kHalfLds);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy_f16x<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kHalfLds);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy_f16x<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kHalfLds);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy_f16x<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kHalfLds);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy_f16x<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kHalfLds);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy_f16x<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kHalfLds);
+    m->mfma16 = precision == FIR_GEMM_F16;
+    if (const char* w = std::getenv("FIR_GEMM_MFMA16")) m->mfma16 = std::atoi(w) != 0 && precision == FIR_GEMM_F16;
+    if (const char* w = std::getenv("FIR_GEMM_STAGGER")) m->stagger = std::atoi(w) != 0;
     if (const char* w = std::getenv("FIR_GEMM_SHARE")) m->share_max = std::max(0, std::min(16, std::atoi(w)));
     if (const char* w = std::getenv("FIR_GEMM_REGTILE")) m->regtile = std::atoi(w);
     if (const char* w = std::getenv("FIR_GEMM_STREAMED")) m->streamed = std::atoi(w);   // experiments: 0 / 1 force the form, -1 = by row length
@@ -1572,6 +1585,10 @@ int fir_gemm_create_range(fir_gallery* g, int32_t precision, int32_t end_pos, fi
             else m->gallery_exp = h_max > 0.f ? 1000 : 0;      // non-finite gallery value: every query is left to the exact scan
             const float scale = (m->gallery_exp >= -100 && m->gallery_exp <= 100) ? std::ldexp(1.0f, m->gallery_exp) : 0.f;
             const int64_t totalh = rblocks * m->dk16 * 64;
+            if (m->mfma16)
+                hipLaunchKernelGGL(k_gemm_pack_gallery_f16x, dim3((unsigned)((totalh + 255) / 256)), dim3(256), 0, m->v.stream, m->gal4, m->v.n, m->dp4,
+                                   m->dk16, scale, m->gh, m->feat == m->v.d ? m->dp4 * 4 : m->feat);
+            else
             hipLaunchKernelGGL(k_gemm_pack_gallery_f16, dim3((unsigned)((totalh + 255) / 256)), dim3(256), 0, m->v.stream, m->gal4, m->v.n, m->dp4,
                                m->dk16, scale, m->gh, m->feat == m->v.d ? m->dp4 * 4 : m->feat);
             hipLaunchKernelGGL(k_gemm_row_norms, dim3((unsigned)((m->v.n + 255) / 256)), dim3(256), 0, m->v.stream, m->gal4, m->v.n, m->dp4, m->gnorm, (m->feat + 3) / 4);
@@ -1695,14 +1712,16 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
     typedef void (*rt_fn)(const uint4*, const float*, const uint4*, const float*, int64_t, int64_t, int, const float*, unsigned long long*, int*, unsigned int*, int, int, int);
     rt_fn rt_main = nullptr, rt_sample = nullptr;
     size_t rt_lds = 0;
-    if (m->precision == FIR_GEMM_F16 && m->share_max > 0 && (grid & 7) == 0 && grid >= 8) {
+    if (m->precision == FIR_GEMM_F16 && !m->mfma16 && m->share_max > 0 && (grid & 7) == 0 && grid >= 8) {
 #define FIR_RT_PICK(D) if (m->dk16 == D) { rt_main = k_gemm_proxy_f16_regtile<D, false>; rt_sample = k_gemm_proxy_f16_regtile<D, true>; rt_lds = RegTile<D>::lds_bytes; }
         FIR_RT_PICK(8) FIR_RT_PICK(16) FIR_RT_PICK(32)
 #undef FIR_RT_PICK
     }
     // sample pass + tau through the register-tile kernel: the smallest sampled proxy + one window (top-1), the K-th smallest of 64
     // disjoint subsets' minima + one window (top-K); other row lengths: the block-minimum sample + k_gemm_tau
-    const bool rt_flow = rt_main != nullptr;
+    // the same flow on the 16-row fragment order: k_gemm_proxy_f16x<2, *> is its sample pass, for any row length
+    const bool x_flow = m->precision == FIR_GEMM_F16 && m->mfma16 && m->share_max > 0 && (grid & 7) == 0 && grid >= 8;
+    const bool rt_flow = rt_main != nullptr || x_flow;
     const int sub_stride = k > 1 ? kPasses * kQT : 0;      // top-K: the sample as kRtSubsets subset minima per query (k_gemm_tau_kmin)
     // the full pass: both kernels run at ~1 KiB of LDS traffic per MFMA and within 7 % of each other (profiles/r02_gemm_kernel_choice.txt):
     // register tile ahead up to 256 features, LDS tile ahead at 512
@@ -1728,6 +1747,10 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
             const int pairs = (np + 1) / 2;                      // 128 queries per gallery read; a half-filled pair is zero-padded
             hipLaunchKernelGGL(k_gemm_qprep_f16, dim3(pairs * 2 * kQT), dim3(64), 0, ps, dq, nq, d, m->gallery_exp, m->qnorm[b], m->qmul[b], m->qinv[b], qs);
             GEMM_HIP(hipMemsetAsync(m->counts[b], 0, (size_t)pairs * 2 * kQT * sizeof(int), ps));
+            if (m->mfma16)
+                hipLaunchKernelGGL(k_gemm_pack_queries_f16x, dim3((4 * m->dk16 * 64 + 255) / 256, pairs), dim3(256), 0, ps, dq, nq, d, m->dk16, m->qmul[b],
+                                   m->qbf[b], qs);
+            else
             hipLaunchKernelGGL(k_gemm_pack_queries_f16, dim3((4 * m->dk16 * 64 + 255) / 256, pairs), dim3(256), 0, ps, dq, nq, d, m->dk16, m->qmul[b],
                                m->qbf[b], qs);
             if (rt_flow) {
@@ -1740,6 +1763,17 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
                     // every rb_stride-th row block: the sample is spread over the whole gallery
                     const int64_t sample_blocks = ((int64_t)m->rt_sample_rows + 31) / 32;
                     const int rb_stride = (int)std::max<int64_t>(1, ((n + 31) / 32) / sample_blocks);
+                    if (x_flow) {
+                        const bool xs = m->dk16 > kSlabH || m->streamed > 0;
+                        if (xs)
+                            hipLaunchKernelGGL((k_gemm_proxy_f16x<2, 1>), dim3(grid), dim3(kGemmBlock), kHalfLds, ps, m->gh, m->gnorm, m->qbf[b] + qo * 4 * m->dk16 * 64,
+                                               m->qinv[b] + qo * 2 * kQT, n, (int64_t)0, sample_blocks * 32, m->dk16, m->tau[b], m->lists[b], m->counts[b], (float*)nullptr,
+                                               0, P, P <= 1 ? 1 : 0, rb_stride, m->smin[b] + qo * 2 * kQT, sub_stride);
+                        else
+                            hipLaunchKernelGGL((k_gemm_proxy_f16x<2, 0>), dim3(grid), dim3(kGemmBlock), kHalfLds, ps, m->gh, m->gnorm, m->qbf[b] + qo * 4 * m->dk16 * 64,
+                                               m->qinv[b] + qo * 2 * kQT, n, (int64_t)0, sample_blocks * 32, m->dk16, m->tau[b], m->lists[b], m->counts[b], (float*)nullptr,
+                                               0, P, P <= 1 ? 1 : 0, rb_stride, m->smin[b] + qo * 2 * kQT, sub_stride);
+                    } else
                     hipLaunchKernelGGL(rt_sample, dim3(grid), dim3(512), rt_lds, ps, m->gh, m->gnorm, m->qbf[b] + qo * 4 * m->dk16 * 64, m->qinv[b] + qo * 2 * kQT, n,
                                        sample_blocks * 32, rb_stride, m->tau[b] + qo * 2 * kQT, m->lists[b] + qo * 2 * kQT * kListCap, m->counts[b] + qo * 2 * kQT,
                                        m->smin[b] + qo * 2 * kQT, P, P <= 1 ? 1 : 0, sub_stride);
@@ -1753,9 +1787,15 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
             } else {
             const int wpb = kGemmBlock / 64;
             const int sample_wgs = (int)((((int64_t)sample_rows + 31) / 32 + wpb - 1) / wpb);
-            const bool streamed = m->streamed >= 0 ? m->streamed != 0 : m->dk16 > kSlabH;
+            const bool streamed = m->mfma16 ? (m->dk16 > kSlabH || m->streamed > 0) : (m->streamed >= 0 ? m->streamed != 0 : m->dk16 > kSlabH);
             const dim3 sgrid(std::min(sample_wgs, grid), pairs);
-            if (streamed)
+            if (m->mfma16 && streamed)
+                hipLaunchKernelGGL((k_gemm_proxy_f16x<0, 1>), sgrid, dim3(kGemmBlock), kHalfLds, ps, m->gh, m->gnorm, m->qbf[b], m->qinv[b], n, (int64_t)0,
+                                   (int64_t)sample_rows, m->dk16, m->tau[b], m->lists[b], m->counts[b], m->sample, sample_rows, 0, 1, 1, (unsigned int*)nullptr, 0);
+            else if (m->mfma16)
+                hipLaunchKernelGGL((k_gemm_proxy_f16x<0, 0>), sgrid, dim3(kGemmBlock), kHalfLds, ps, m->gh, m->gnorm, m->qbf[b], m->qinv[b], n, (int64_t)0,
+                                   (int64_t)sample_rows, m->dk16, m->tau[b], m->lists[b], m->counts[b], m->sample, sample_rows, 0, 1, 1, (unsigned int*)nullptr, 0);
+            else if (streamed)
                 hipLaunchKernelGGL((k_gemm_proxy_f16<0, 1>), sgrid, dim3(kGemmBlock), kHalfLds, ps, m->gh, m->gnorm, m->qbf[b], m->qinv[b], n, (int64_t)0,
                                    (int64_t)sample_rows, m->dk16, m->tau[b], m->lists[b], m->counts[b], m->sample, sample_rows, 0, 1);
             else
@@ -1797,7 +1837,7 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
         // ---- the full pass(es) over the gallery: the launch fir_profile_read times and fir_gallery_last_dispatch names ----
         if (m->precision == FIR_GEMM_F16) {
             const int pairs = (np + 1) / 2;
-            const bool streamed = m->streamed >= 0 ? m->streamed != 0 : m->dk16 > kSlabH;
+            const bool streamed = m->mfma16 ? (m->dk16 > kSlabH || m->streamed > 0) : (m->streamed >= 0 ? m->streamed != 0 : m->dk16 > kSlabH);
             const int64_t rblocks = (n + 31) / 32;
             // rows longer than the LDS tile (query slabs streamed per unit): 16 readers of one range drift apart, 8 measured better
             const int share_cap = m->share_max > 0 ? (streamed ? std::min(m->share_max, 8) : m->share_max) : 16;
@@ -1831,7 +1871,15 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
                                        m->tau[b] + qo * 2 * kQT, m->lists[b] + qo * 2 * kQT * kListCap, m->counts[b] + qo * 2 * kQT, m->smin[b] + qo * 2 * kQT, share, nt, 0);
                     used_rt = true;
                     used_rt_lds = rt_lds;
-                } else if (streamed)
+                } else if (m->mfma16 && streamed)
+                    hipLaunchKernelGGL((k_gemm_proxy_f16x<1, 1>), g1, dim3(kGemmBlock), kHalfLds, st, m->gh, m->gnorm, m->qbf[b] + qo * 4 * m->dk16 * 64, m->qinv[b] + qo * 2 * kQT,
+                                       n, (int64_t)0, n, m->dk16, m->tau[b] + qo * 2 * kQT, m->lists[b] + qo * 2 * kQT * kListCap, m->counts[b] + qo * 2 * kQT, m->sample,
+                                       sample_rows, share, nt, 1, (unsigned int*)nullptr, 0);
+                else if (m->mfma16)
+                    hipLaunchKernelGGL((k_gemm_proxy_f16x<1, 0>), g1, dim3(kGemmBlock), kHalfLds, st, m->gh, m->gnorm, m->qbf[b] + qo * 4 * m->dk16 * 64, m->qinv[b] + qo * 2 * kQT,
+                                       n, (int64_t)0, n, m->dk16, m->tau[b] + qo * 2 * kQT, m->lists[b] + qo * 2 * kQT * kListCap, m->counts[b] + qo * 2 * kQT, m->sample,
+                                       sample_rows, share, nt | (m->stagger ? 2 : 0), 1, (unsigned int*)nullptr, 0);
+                else if (streamed)
                     hipLaunchKernelGGL((k_gemm_proxy_f16<1, 1>), g1, dim3(kGemmBlock), kHalfLds, st, m->gh, m->gnorm, m->qbf[b] + qo * 4 * m->dk16 * 64, m->qinv[b] + qo * 2 * kQT,
                                        n, (int64_t)0, n, m->dk16, m->tau[b] + qo * 2 * kQT, m->lists[b] + qo * 2 * kQT * kListCap, m->counts[b] + qo * 2 * kQT, m->sample,
                                        sample_rows, share, nt);
@@ -1848,8 +1896,10 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
                 const void* fp = (const void*)rt_main;
                 fir_gallery_note_dispatch_(m->g, fp, nm, sb == 0, grid, nlaunch, 512, used_rt_lds, 128 * p_first, bytes, flops);
             } else
-            fir_gallery_note_dispatch_(m->g, streamed ? (const void*)k_gemm_proxy_f16<1, 1> : (const void*)k_gemm_proxy_f16<1, 0>,
-                                       streamed ? "fir::k_gemm_proxy_f16<1, 1>" : "fir::k_gemm_proxy_f16<1, 0>", sb == 0, grid, m->share_max > 0 ? nlaunch : pairs, kGemmBlock, kHalfLds,
+            fir_gallery_note_dispatch_(m->g, m->mfma16 ? (streamed ? (const void*)k_gemm_proxy_f16x<1, 1> : (const void*)k_gemm_proxy_f16x<1, 0>)
+                                                       : (streamed ? (const void*)k_gemm_proxy_f16<1, 1> : (const void*)k_gemm_proxy_f16<1, 0>),
+                                       m->mfma16 ? (streamed ? "fir::k_gemm_proxy_f16x<1, 1>" : "fir::k_gemm_proxy_f16x<1, 0>")
+                                                 : (streamed ? "fir::k_gemm_proxy_f16<1, 1>" : "fir::k_gemm_proxy_f16<1, 0>"), sb == 0, grid, m->share_max > 0 ? nlaunch : pairs, kGemmBlock, kHalfLds,
                                        m->share_max > 0 ? 128 * p_first : 128, bytes, flops);
         } else if (m->precision == FIR_GEMM_F32) {
             hipLaunchKernelGGL(k_gemm_proxy<1>, dim3(grid, np), dim3(kGemmBlock), lds, st, m->gm, m->gnorm, m->qm[b], n, (int64_t)0, n, m->dq8,
@@ -1942,12 +1992,14 @@ int fir_gemm_search_few_keys_dev(fir_gemm* m, const float* d_queries, int32_t qb
     const int b = 0;
     hipLaunchKernelGGL(k_gemm_qprep_f16, dim3(2 * kQT), dim3(64), 0, st, d_queries, qb, d, m->gallery_exp, m->qnorm[b], m->qmul[b], m->qinv[b], qs);
     GEMM_HIP(hipMemsetAsync(m->counts[b], 0, 2 * kQT * sizeof(int), st));
-    hipLaunchKernelGGL(k_gemm_pack_queries_f16, dim3((4 * m->dk16 * 64 + 255) / 256, 1), dim3(256), 0, st, d_queries, qb, d, m->dk16, m->qmul[b], m->qbf[b], qs);
+    if (m->mfma16) hipLaunchKernelGGL(k_gemm_pack_queries_f16x, dim3((4 * m->dk16 * 64 + 255) / 256, 1), dim3(256), 0, st, d_queries, qb, d, m->dk16, m->qmul[b], m->qbf[b], qs);
+    else hipLaunchKernelGGL(k_gemm_pack_queries_f16, dim3((4 * m->dk16 * 64 + 255) / 256, 1), dim3(256), 0, st, d_queries, qb, d, m->dk16, m->qmul[b], m->qbf[b], qs);
     GEMM_HIP(hipMemsetD32Async((hipDeviceptr_t)m->smin[b], (int)0xFF800000u, 2 * kQT, st));
     const int nqt = qb <= 1 ? 1 : qb <= 2 ? 2 : qb <= 4 ? 4 : 8;
     const dim3 grid((unsigned)std::min<int64_t>((int64_t)m->v.cus * 8, ((n + 31) / 32 + 3) / 4));
     const size_t lds = (size_t)m->dk16 * 2 * nqt * sizeof(uint4);
-#define FIR_FEW(NQ) hipLaunchKernelGGL(k_gemm_scan_f16<NQ>, grid, dim3(256), lds, st, m->gh, m->gnorm, m->qbf[b], m->qinv[b], n, m->dk16, m->proxies, m->smin[b])
+#define FIR_FEW(NQ) do { if (m->mfma16) hipLaunchKernelGGL(k_gemm_scan_f16x<NQ>, grid, dim3(256), lds, st, m->gh, m->gnorm, m->qbf[b], m->qinv[b], n, m->dk16, m->proxies, m->smin[b]); \
+                         else hipLaunchKernelGGL(k_gemm_scan_f16<NQ>, grid, dim3(256), lds, st, m->gh, m->gnorm, m->qbf[b], m->qinv[b], n, m->dk16, m->proxies, m->smin[b]); } while (0)
     if (nqt == 1) FIR_FEW(1); else if (nqt == 2) FIR_FEW(2); else if (nqt == 4) FIR_FEW(4); else FIR_FEW(8);
 #undef FIR_FEW
     fir_gallery_note_dispatch_(m->g, nqt == 1 ? (const void*)k_gemm_scan_f16<1> : nqt == 2 ? (const void*)k_gemm_scan_f16<2> : nqt == 4 ? (const void*)k_gemm_scan_f16<4>

@@ -1,0 +1,401 @@
+// fir_gemm_f16x.h -- the LDS-tile pass of the fp16 matrix-core path on v_mfma_f32_16x16x32_f16 (included by fir_gemm.hip,
+// inside its anonymous namespace). Same per-wave output tile as k_gemm_proxy_f16 (32 rows x 128 queries), same bytes per
+// MFMA cycle from LDS and from the gallery stream; what differs is the MFMA shape, which the chip clocks differently under
+// load (MI355X_MICROARCH.md, DVFS give-back item 7: build both at the same output tile per wave, keep the faster by wall
+// on random data). fir_gemm::mfma16 selects it; the fragment order of both operands is then the "16-row" one:
+//
+//   gallery  gh[(rb * dk16 + 2 * kk + s) * 64 + l]   row 32 rb + 16 s + (l & 15),   features 32 kk + 8 (l >> 4) + 0..7
+//   queries  qh[((pair * 8 + jb) * dk32 + kk) * 64 + l]   query 128 pair + 16 jb + (l & 15),   the same features
+//
+// (dk32 = dk16 / 2; a row block is still dk16 consecutive one-KiB pieces, so the gallery stream and its double buffer are
+// addressed exactly as in k_gemm_proxy_f16.) Accumulator tile (s, jb): f32x4, lane l holds query 16 jb + (l & 15) against
+// rows 16 s + 4 (l >> 4) + 0..3 of the block.
+#pragma once
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// rows of the tiled f32 gallery * scale -> 16-row fragment order (see above); kmax as k_gemm_pack_gallery_f16
+__global__ void __launch_bounds__(256) k_gemm_pack_gallery_f16x(const float4* __restrict__ gal4, int64_t n, int dp4, int dk16, float scale,
+                                                                 uint4* __restrict__ gh, int kmax) {
+    const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;      // (rb, piece, lane)
+    const int64_t rblocks = (n + 31) / 32;
+    if (o >= rblocks * dk16 * 64) return;
+    const int l = (int)(o & 63);
+    const int64_t t = o >> 6;
+    const int piece = (int)(t % dk16);
+    const int64_t rb = t / dk16;
+    const int kk = piece >> 1, s = piece & 1;
+    const int64_t row = rb * 32 + 16 * s + (l & 15);
+    f16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = 32 * kk + 8 * (l >> 4) + j;
+        float x = 0.f;
+        if (row < n && k < kmax) {
+            const float4 g = gal4[((row >> 6) * dp4 + (k >> 2)) * 64 + (row & 63)];
+            x = (k & 3) == 0 ? g.x : (k & 3) == 1 ? g.y : (k & 3) == 2 ? g.z : g.w;
+        }
+        v[j] = (_Float16)(x * scale);
+    }
+    uint4 u;
+    __builtin_memcpy(&u, &v, 16);
+    gh[o] = u;
+}
+
+// queries * qmul -> 16-row fragment order; blockIdx.y = pair of 64-query passes
+__global__ void __launch_bounds__(256) k_gemm_pack_queries_f16x(const float* q, int nq, int d, int dk16, const float* __restrict__ qmul, uint4* qh,
+                                                                 int qstride) {
+    const int dk32 = dk16 >> 1;
+    const int q_base = (int)blockIdx.y * 2 * kQT;
+    qh += (size_t)blockIdx.y * 8 * dk32 * 64;
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= 8 * dk32 * 64) return;
+    const int l = o & 63;
+    const int t = o >> 6;
+    const int kk = t % dk32, jb = t / dk32;
+    const int qi = q_base + jb * 16 + (l & 15);
+    const float mul = qi < nq ? qmul[qi] : 0.f;
+    f16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = 32 * kk + 8 * (l >> 4) + j;
+        const float x = (qi < nq && k < d) ? q[(size_t)qi * qstride + k] : 0.f;
+        v[j] = (_Float16)(x * mul);
+    }
+    uint4 u;
+    __builtin_memcpy(&u, &v, 16);
+    qh[o] = u;
+}
+
+// One wave: 32 rows x 128 queries. Parameters, grid shapes and the `share` placement as k_gemm_proxy_f16.
+// MODE 0: one minimum per (row block, query) of rows [row_begin, row_end) -> sample (the order-statistic flow, k_gemm_tau);
+// MODE 1: the full pass, every row below tau is appended; MODE 2: the sample of the smallest-proxy flow -- row blocks
+// 0, rb_stride, 2 rb_stride, ... of the gallery ((row_end - row_begin) / 32 of them, spread over all of it: the reference's
+// galleries are ordered by class), smin[q] <- the smallest proxy seen (fir::f32_orderable bits, atomicMin, caller presets +inf);
+// with sub_stride != 0 (top-K) as kRtSubsets disjoint subsets' minima, smin[subset * sub_stride + q] (k_gemm_tau_kmin).
+// A unit is kRing = 8 gallery pieces = four 32-feature steps; per step two A fragments (the row halves) against eight B
+// fragments: sixteen MFMAs of 16 cycles. The eight B fragments are ONE register set that rolls: fragment j is re-read for
+// the next step right behind the two MFMAs that used it, fourteen MFMAs before its next use.
+// Bit 1 of `nt_flags` (experiment, FIR_GEMM_STAGGER): waves 4-7 -- the partners of waves 0-3 on their SIMDs -- run half a unit of
+// throw-away MFMAs first, so that partners do not reach their epilogues and their end-of-unit waits together. Bit 0: the
+// gallery stream is read once per launch (non-temporal loads).
+template <int MODE, int STREAMED>
+__global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* __restrict__ gh, const float* __restrict__ gnorm, const uint4* qh,
+                                                                    const float* __restrict__ qinv, int64_t n, int64_t row_begin, int64_t row_end,
+                                                                    int dk16, const float* tau, unsigned long long* lists, int* counts,
+                                                                    float* sample, int sample_rows, int share, int nt_flags,
+                                                                    int rb_stride, unsigned int* smin, int sub_stride) {
+    extern __shared__ __attribute__((aligned(16))) uint4 lqx[];
+    const int nt = nt_flags & 1;
+    __shared__ float tau_s[2 * kQT], qinv_s[2 * kQT];
+    int pair_of_wg = (int)blockIdx.y;
+    int64_t rg_first = blockIdx.x, rg_step = gridDim.x, rg_last = -1;
+    int range = (int)blockIdx.x;
+    if (share > 0) {
+        const int w = (int)blockIdx.x, xcd = w & 7, slot = w >> 3;
+        const int ranges = ((int)gridDim.x >> 3) / share * 8;
+        range = xcd + 8 * (slot / share);
+        if (range >= ranges) return;                                       // uniform per workgroup
+        pair_of_wg = slot % share;
+        const int64_t nrg_all = (((row_end + 31) / 32 - row_begin / 32) + (blockDim.x >> 6) - 1) / (blockDim.x >> 6);
+        rg_first = nrg_all * range / ranges;
+        rg_last = nrg_all * (range + 1) / ranges;
+        rg_step = 1;
+    }
+    const int dk32 = dk16 >> 1;
+    {
+        const size_t pr = (size_t)pair_of_wg;
+        qh += pr * 8 * dk32 * 64;
+        qinv += pr * 2 * kQT;
+        tau += pr * 2 * kQT;
+        lists += pr * 2 * kQT * kListCap;
+        counts += pr * 2 * kQT;
+        if (MODE == 0) sample += pr * 2 * kQT * ((sample_rows + 31) / 32);
+        if (MODE == 2) smin += pr * 2 * kQT;
+    }
+    const int64_t rbs = MODE == 2 ? rb_stride : 1;                        // gallery row blocks per row block of the pass
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wpb = blockDim.x >> 6;
+    if (threadIdx.x < 2 * kQT) {
+        tau_s[threadIdx.x] = MODE == 1 ? tau[threadIdx.x] : 0.f;
+        qinv_s[threadIdx.x] = qinv[threadIdx.x];
+    }
+    const int64_t rb_begin = row_begin / 32, rb_end = (row_end + 31) / 32;
+    const int64_t nrg = (rb_end - rb_begin + wpb - 1) / wpb;
+    const int units = dk16 / kRing;
+    const int64_t rg_end = rg_last >= 0 ? rg_last : nrg;
+    int64_t rg = rg_first;
+    if (rg >= rg_end) return;                        // uniform per workgroup
+#define FIR_X_LD(P) (nt ? ld_nt(P) : *(P))
+#define FIR_X_BLOCK(RG) (gh + (size_t)(((rb_begin + (RG) * wpb + wave) < rb_end ? (rb_begin + (RG) * wpb + wave) : rb_end - 1) * rbs) * dk16 * 64 + lane)
+    const uint4* a_cur = FIR_X_BLOCK(rg);
+    uint4 cur[kRing], nxt[kRing];
+#pragma unroll
+    for (int u = 0; u < kRing; ++u) cur[u] = FIR_X_LD(a_cur + (size_t)u * 64);
+    constexpr int kUnitsPerSlab = kSlabH / kRing;                         // units of the LDS-resident tile (512 features)
+    const bool resident = !STREAMED;                                      // (the caller streams whatever does not fit: dk16 > kSlabH)
+    // STREAMED: the 32 pieces (step t, query block jb) of unit hq -> LDS buffer bsel, four per wave
+    auto request_piece = [&](int hq, int bsel, int piece) {
+        uint4* dst = lqx + (size_t)bsel * 4 * kRing * 64;
+        const int jb = piece >> 2, t = piece & 3;
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(qh + ((size_t)jb * dk32 + (size_t)hq * 4 + t) * 64 + lane),
+                                         (void __attribute__((address_space(3)))*)(dst + (size_t)(t * 8 + jb) * 64), 16, 0, 0);
+    };
+    auto request_slab = [&](int hq, int bsel) {
+        const int per_wave = 4 * kRing / wpb;
+        for (int c = 0; c < per_wave; ++c) request_piece(hq, bsel, wave * per_wave + c);
+    };
+    int tsel = 0;
+    if (STREAMED) {
+        request_slab(0, 0);
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+    } else {
+        // LDS image: step-major, the eight query blocks of a step side by side -- (kk * 8 + jb) * 1 KiB
+        for (int i = threadIdx.x; i < 8 * dk32 * 64; i += blockDim.x) {
+            const int jb = i / (dk32 * 64), r = i - jb * dk32 * 64;
+            lqx[(size_t)((r >> 6) * 8 + jb) * 64 + (r & 63)] = qh[(size_t)jb * dk32 * 64 + r];
+        }
+        __syncthreads();
+    }
+    float smallest[8];                               // MODE 2: running minima of this lane's eight queries
+#pragma unroll
+    for (int j = 0; j < 8; ++j) smallest[j] = __builtin_huge_valf();
+    uint4 B[8];
+    if (resident) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) B[j] = lqx[lane + j * 64];
+    }
+    if ((nt_flags & 2) && resident && wave >= wpb / 2) {
+        // half a unit of MFMAs whose result goes nowhere the kernel's outputs are computed from: it only delays this wave
+        f32x4 junk = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 32; ++r) junk = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_f16x8(B[r & 7]), as_f16x8(B[(r + 1) & 7]), junk, 0, 0, 0);
+        asm volatile("" ::"v"(junk));
+    }
+    for (; rg < rg_end; rg += rg_step) {
+        const int64_t rbp = rb_begin + rg * wpb + wave;   // row block of the pass ...
+        const int64_t rb = rbp * rbs;                     // ... and of the gallery
+        const bool active = rbp < rb_end;
+        const int64_t rgn = rg + rg_step;
+        const uint4* a_nxt = FIR_X_BLOCK(rgn < rg_end ? rgn : rg);
+        f32x4 acc[2][8];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[s][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float4 gns[2];                               // squared norms of rows 16 s + 4 (lane >> 4) + 0..3 of the block
+        const bool full_block = active && rbp * 32 >= row_begin && rbp * 32 + 32 <= row_end && rb * 32 + 32 <= n && (MODE != 0 || rb * 32 + 32 <= sample_rows);
+        // MODE 2, sub_stride: sixteen row ranges x four waves = kRtSubsets disjoint subsets (more ranges wrap around: unions of disjoint sets)
+        unsigned int* smin_blk = MODE == 2 ? smin + (size_t)(((range & 15) << 2) + (wave & 3)) * sub_stride : nullptr;
+        auto unit = [&](uint4 (&C)[kRing], uint4 (&N)[kRing], int h) {
+            const uint4* src = h + 1 < units ? a_cur + (size_t)(h + 1) * kRing * 64 : a_nxt;
+            const uint4* bq = STREAMED ? lqx + lane + (size_t)tsel * 4 * kRing * 64 : lqx + lane + (size_t)(h % kUnitsPerSlab) * kRing * 4 * 64;
+            if (!resident) {                         // first, so that their latency passes under the issue of the loads below
+#pragma unroll
+                for (int j = 0; j < 8; ++j) B[j] = bq[j * 64];
+            }
+            if (nt) {
+#pragma unroll
+                for (int u = 0; u < kRing; ++u) N[u] = ld_nt(src + (size_t)u * 64);
+            } else {
+#pragma unroll
+                for (int u = 0; u < kRing; ++u) N[u] = src[(size_t)u * 64];
+            }
+            if (h == units - 1 && full_block) {
+                const float4* gp = (const float4*)(gnorm + rb * 32 + 4 * (lane >> 4));
+                gns[0] = gp[0];
+                gns[1] = gp[4];
+            }
+            const uint4* bq_after = lqx + lane + (size_t)((h + 1 < units ? h + 1 : 0) % kUnitsPerSlab) * kRing * 4 * 64;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const uint4* bn = t + 1 < 4 ? bq + (size_t)(t + 1) * 8 * 64 : bq_after;
+                const bool pre = t + 1 < 4 || resident;
+                const f16x8 a0 = as_f16x8(C[2 * t]), a1 = as_f16x8(C[2 * t + 1]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const f16x8 b = as_f16x8(B[j]);
+                    acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b, acc[0][j], 0, 0, 0);
+                    acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b, acc[1][j], 0, 0, 0);
+                    if (pre) B[j] = bn[j * 64];
+                    __builtin_amdgcn_sched_barrier(0);            // the re-read stays right behind its fragment's last use
+                }
+                // STREAMED: this wave's four pieces of the NEXT unit's query slab, one behind each step's MFMAs (a request holds the
+                // issuing wave for 60-180 cycles: spread out, the SIMD's other wave covers them); the buffer's last readers passed
+                // the barrier that ended the previous unit
+                if (STREAMED && 4 * kRing / wpb == 4) request_piece(h + 1 < units ? h + 1 : 0, tsel ^ 1, wave * 4 + t);
+            }
+            if (STREAMED && 4 * kRing / wpb != 4) request_slab(h + 1 < units ? h + 1 : 0, tsel ^ 1);
+            if (STREAMED) {
+                __builtin_amdgcn_s_waitcnt(0);
+                __syncthreads();
+                tsel ^= 1;
+            }
+        };
+        int h = 0;
+        for (; h + 1 < units; h += 2) {
+            unit(cur, nxt, h);
+            unit(nxt, cur, h + 1);
+        }
+        if (h < units) {
+            unit(cur, nxt, h);
+#pragma unroll
+            for (int u = 0; u < kRing; ++u) cur[u] = nxt[u];
+        }
+        a_cur = a_nxt;
+        if (!active) continue;
+        if (full_block) {
+#pragma unroll
+            for (int jb = 0; jb < 8; ++jb) {
+                const int q = jb * 16 + (lane & 15);
+                const float m2 = 2.0f * qinv_s[q];
+                const float tq = tau_s[q];
+                float pv[8];
+                float mn = __builtin_huge_valf();
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const float gnv[4] = {gns[s].x, gns[s].y, gns[s].z, gns[s].w};
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        pv[4 * s + reg] = __builtin_fmaf(-m2, acc[s][jb][reg], gnv[reg]);
+                        mn = fminf(mn, pv[4 * s + reg]);                   // NaN never enters, like k_gemm_tau's ordering
+                    }
+                }
+                if (MODE == 1) {
+                    if (mn < tq) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            if (pv[i] < tq) {
+                                const int64_t row = rb * 32 + 16 * (i >> 2) + 4 * (lane >> 4) + (i & 3);
+                                const int slot = atomicAdd(&counts[q], 1);
+                                if (slot < kListCap) lists[(size_t)q * kListCap + slot] = fir::key_pack(pv[i], (uint32_t)row);
+                            }
+                        }
+                    }
+                } else if (MODE == 2 && !sub_stride) {
+                    smallest[jb] = fminf(smallest[jb], mn);
+                } else {
+                    float o = __shfl_xor(mn, 16, 64);
+                    mn = o < mn ? o : mn;
+                    o = __shfl_xor(mn, 32, 64);
+                    mn = o < mn ? o : mn;
+                    if (MODE == 0) { if (lane < 16) sample[(size_t)(rb - rb_begin) * (2 * kQT) + q] = mn; }
+                    else if (lane < 16 && mn < __builtin_huge_valf()) atomicMin(&smin_blk[q], fir::f32_orderable(mn));
+                }
+            }
+            continue;
+        }
+        // a block that straddles the end of the rows (or of the sample): row by row
+#pragma unroll
+        for (int jb = 0; jb < 8; ++jb) {
+            const int q = jb * 16 + (lane & 15);
+            const float m2 = 2.0f * qinv_s[q];
+            const float tq = tau_s[q];
+            float mn = __builtin_huge_valf();
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int64_t row = rb * 32 + 16 * (i >> 2) + 4 * (lane >> 4) + (i & 3);
+                if (row >= n || (MODE != 2 && (row < row_begin || row >= row_end))) continue;
+                const float p = __builtin_fmaf(-m2, acc[i >> 2][jb][i & 3], gnorm[row]);
+                if (MODE == 0) {
+                    if (row < sample_rows) mn = p < mn ? p : mn;
+                } else if (MODE == 2) {
+                    mn = p < mn ? p : mn;
+                } else if (p < tq) {
+                    const int slot = atomicAdd(&counts[q], 1);
+                    if (slot < kListCap) lists[(size_t)q * kListCap + slot] = fir::key_pack(p, (uint32_t)row);
+                }
+            }
+            if (MODE == 2 && !sub_stride) {
+                smallest[jb] = fminf(smallest[jb], mn);
+            } else if (MODE != 1) {
+                float o = __shfl_xor(mn, 16, 64);
+                mn = o < mn ? o : mn;
+                o = __shfl_xor(mn, 32, 64);
+                mn = o < mn ? o : mn;
+                if (MODE == 0) { if (lane < 16) sample[(size_t)(rb - rb_begin) * (2 * kQT) + q] = mn; }
+                else if (lane < 16 && mn < __builtin_huge_valf()) atomicMin(&smin_blk[q], fir::f32_orderable(mn));
+            }
+        }
+    }
+    if (MODE == 2 && !sub_stride) {
+#pragma unroll
+        for (int jb = 0; jb < 8; ++jb) {
+            float v = smallest[jb];
+            v = fminf(v, __shfl_xor(v, 16, 64));
+            v = fminf(v, __shfl_xor(v, 32, 64));
+            if (lane < 16 && v < __builtin_huge_valf()) atomicMin(&smin[jb * 16 + lane], fir::f32_orderable(v));
+        }
+    }
+#undef FIR_X_BLOCK
+#undef FIR_X_LD
+}
+
+// k_gemm_scan_f16 (the one-to-eight-query nomination scan, below in fir_gemm.hip) on the 16-row fragment order: lane l of
+// piece 2 kk + s holds row 16 s + (l & 15), feature quarter l >> 4 of step kk.
+typedef _Float16 f16x2x __attribute__((ext_vector_type(2)));
+template <int NQ>
+__global__ void __launch_bounds__(256) k_gemm_scan_f16x(const uint4* __restrict__ gh, const float* __restrict__ gnorm, const uint4* __restrict__ qh,
+                                                         const float* __restrict__ qinv, int64_t n, int dk16, float* __restrict__ proxies,
+                                                         unsigned int* __restrict__ smin) {
+    extern __shared__ __attribute__((aligned(16))) uint4 qsx[];           // [step][feature quarter][query]
+    const int dk32 = dk16 >> 1;
+    for (int idx = threadIdx.x; idx < dk32 * 4 * NQ; idx += blockDim.x) {
+        const int i = idx % NQ, qt = (idx / NQ) & 3, kk = idx / (4 * NQ);
+        qsx[idx] = qh[(size_t)kk * 64 + 16 * qt + i];                     // queries 0..7 sit in query block 0 of the pair's fragments
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, qt = lane >> 4;
+    const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int64_t nrb = (n + 31) / 32;
+    float m2[NQ], smallest[NQ];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) { m2[i] = 2.0f * qinv[i]; smallest[i] = __builtin_huge_valf(); }
+    for (int64_t rb = gw; rb < nrb; rb += nw) {
+        const uint4* a = gh + (size_t)rb * dk16 * 64 + lane;
+        float acc[2][NQ];
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) acc[0][i] = acc[1][i] = 0.f;
+        for (int kb0 = 0; kb0 < dk16; kb0 += 8) {                          // dk16 is a multiple of 8
+            uint4 g[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) g[u] = ld_nt(a + (size_t)(kb0 + u) * 64);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                f16x2x gv[4];
+                __builtin_memcpy(gv, &g[u], 16);
+#pragma unroll
+                for (int i = 0; i < NQ; ++i) {
+                    const uint4 qq = qsx[(((kb0 + u) >> 1) * 4 + qt) * NQ + i];
+                    f16x2x qv[4];
+                    __builtin_memcpy(qv, &qq, 16);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[u & 1][i] = __builtin_amdgcn_fdot2(gv[t], qv[t], acc[u & 1][i], false);
+                }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int64_t row = rb * 32 + 16 * s + (lane & 15);
+            const float gn = row < n ? gnorm[row] : 0.f;
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                float dot = acc[s][i] + __shfl_xor(acc[s][i], 16, 64);    // the four feature quarters of the row
+                dot += __shfl_xor(dot, 32, 64);
+                if (lane < 16 && row < n) {
+                    const float p = __builtin_fmaf(-m2[i], dot, gn);
+                    proxies[(size_t)i * n + row] = p;
+                    smallest[i] = fminf(smallest[i], p);                   // NaN never enters
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        float v = smallest[i];
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
+        if (lane == 0 && v < __builtin_huge_valf()) atomicMin(&smin[i], fir::f32_orderable(v));
+    }
+}
