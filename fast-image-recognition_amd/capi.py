@@ -360,7 +360,8 @@ def comm_unique_id():
 
 class ShardOpts(C.Structure):
     _fields_ = [("struct_bytes", C.c_int32), ("shards_per_device", C.c_int32), ("first_global_row", C.c_int64), ("comm_id", _vp),
-                ("proc_rank", C.c_int32), ("nprocs", C.c_int32), ("rows_on_device", C.c_int32), ("reserved", C.c_int32), ("total_rows", C.c_int64)]
+                ("proc_rank", C.c_int32), ("nprocs", C.c_int32), ("rows_on_device", C.c_int32), ("reserved", C.c_int32), ("total_rows", C.c_int64),
+                ("timeout_ms", C.c_int32), ("fail_shard", C.c_int32), ("fail_step", C.c_int32), ("reserved2", C.c_int32)]
 
 
 class _BorrowedGallery(Gallery):
@@ -379,7 +380,8 @@ class ShardedGallery:
     the ranks' keys are reduced by RCCL inside the library (include/fir_amd.h)."""
 
     def __init__(self, rows=None, class_no=None, metric=METRIC_L2, devices=(0,), shards_per_device=1, *, first_global_row=0,
-                 comm_id=None, proc_rank=0, nprocs=1, dev_ptr=None, n=None, d=None, dev_class_ptr=None):
+                 comm_id=None, proc_rank=0, nprocs=1, dev_ptr=None, n=None, d=None, dev_class_ptr=None, timeout_ms=0, fail_shard=0,
+                 fail_step=0):
         self._h = _vp()
         devs = np.ascontiguousarray(list(devices), dtype=np.int32)
         o = ShardOpts()
@@ -389,6 +391,7 @@ class ShardedGallery:
         self._id = C.create_string_buffer(comm_id, COMM_ID_BYTES) if comm_id is not None else None
         o.comm_id = C.cast(self._id, _vp) if self._id is not None else None
         o.proc_rank, o.nprocs = proc_rank, nprocs
+        o.timeout_ms, o.fail_shard, o.fail_step = timeout_ms, fail_shard, fail_step
         if dev_ptr is not None:
             o.rows_on_device = 1
             rp, cp = _vp(dev_ptr), (_vp(dev_class_ptr) if dev_class_ptr else None)
@@ -691,7 +694,7 @@ class ShardedClsModel:
     """Owns one fir_cls_sharded handle: the PNN training set split by rows over `devices` (x shards_per_device), class
     scores added across shards on the device and across ranks by RCCL (ncclAllReduce(ncclSum, ncclDouble))."""
 
-    def __init__(self, train_rows, train_class, num_classes, avg, devices=(0,), shards_per_device=1):
+    def __init__(self, train_rows, train_class, num_classes, avg, devices=(0,), shards_per_device=1, *, timeout_ms=0, fail_shard=0, fail_step=0):
         tr = np.ascontiguousarray(train_rows, dtype=np.float64)
         tc = np.ascontiguousarray(train_class, dtype=np.int32)
         av = np.ascontiguousarray(avg, dtype=np.float64)
@@ -699,6 +702,7 @@ class ShardedClsModel:
         o = ShardOpts()
         o.struct_bytes = C.sizeof(ShardOpts)
         o.shards_per_device = shards_per_device
+        o.timeout_ms, o.fail_shard, o.fail_step = timeout_ms, fail_shard, fail_step
         self._h = _vp()
         self.nt, self.d = tr.shape
         self.num_classes = int(num_classes)

@@ -1459,10 +1459,22 @@ struct fir_gemm {
     int mfma16 = 0;                       // fp16: both operands in the 16-row fragment order, every pass on v_mfma_f32_16x16x32_f16 (fir_gemm_f16x.h): the default since it was
                                           // measured against the 32x32x16 kernels at the same wave tile (profiles/r03_mfma_shape_ab.txt); FIR_GEMM_MFMA16=0 brings those back
     int stagger = 0;                      // mfma16 experiment: the second wave of every SIMD starts half a unit late (FIR_GEMM_STAGGER)
+    int share_streamed = 8;               // ... of them when the query slabs are streamed (FIR_GEMM_SHARE_STREAMED)
     int share_max = 16;                   // fp16: up to this many pairs of passes (x 128 queries) read the gallery together in one launch (FIR_GEMM_SHARE; 0 = the old one-pair-at-a-time grid)
 };
 
 
+
+// the 16-row kernels by (mode, query slabs streamed, odd number of units per row block)
+typedef void (*fir_x_fn)(const uint4*, const float*, const uint4*, const float*, int64_t, int64_t, int64_t, int, const float*, unsigned long long*, int*, float*,
+                         int, int, int, int, unsigned int*, int);
+static fir_x_fn pick_x(int mode, bool streamed, bool odd) {
+    if (mode == 1) return streamed ? (odd ? k_gemm_proxy_f16x<1, 1, 1> : k_gemm_proxy_f16x<1, 1, 0>) : (odd ? k_gemm_proxy_f16x<1, 0, 1> : k_gemm_proxy_f16x<1, 0, 0>);
+    return streamed ? (odd ? k_gemm_proxy_f16x<2, 1, 1> : k_gemm_proxy_f16x<2, 1, 0>) : (odd ? k_gemm_proxy_f16x<2, 0, 1> : k_gemm_proxy_f16x<2, 0, 0>);
+}
+static const char* name_x(bool streamed, bool odd) {
+    return streamed ? (odd ? "fir::k_gemm_proxy_f16x<1, 1, 1>" : "fir::k_gemm_proxy_f16x<1, 1, 0>") : (odd ? "fir::k_gemm_proxy_f16x<1, 0, 1>" : "fir::k_gemm_proxy_f16x<1, 0, 0>");
+}
 
 extern "C" {
 
@@ -1552,16 +1564,16 @@ int fir_gemm_create_range(fir_gallery* g, int32_t precision, int32_t end_pos, fi
                        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy_f16_regtile<D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RegTile<D>::lds_bytes);
     FIR_RT_ATTR(8) FIR_RT_ATTR(16) FIR_RT_ATTR(32)
 #undef FIR_RT_ATTR
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy_f16x<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kHalfLds);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy_f16x<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kHalfLds);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy_f16x<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kHalfLds);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy_f16x<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kHalfLds);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy_f16x<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kHalfLds);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy_f16x<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kHalfLds);
+#define FIR_X_ATTR(M, S, O) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy_f16x<M, S, O>, hipFuncAttributeMaxDynamicSharedMemorySize, kHalfLds);
+    FIR_X_ATTR(1, 0, 0) FIR_X_ATTR(1, 0, 1) FIR_X_ATTR(1, 1, 0) FIR_X_ATTR(1, 1, 1) FIR_X_ATTR(2, 0, 0) FIR_X_ATTR(2, 0, 1) FIR_X_ATTR(2, 1, 0) FIR_X_ATTR(2, 1, 1)
+#undef FIR_X_ATTR
     m->mfma16 = precision == FIR_GEMM_F16;
     if (const char* w = std::getenv("FIR_GEMM_MFMA16")) m->mfma16 = std::atoi(w) != 0 && precision == FIR_GEMM_F16;
     if (const char* w = std::getenv("FIR_GEMM_STAGGER")) m->stagger = std::atoi(w) != 0;
+    if (const char* w = std::getenv("FIR_GEMM_SHARE_STREAMED")) m->share_streamed = std::max(1, std::min(16, std::atoi(w)));
     if (const char* w = std::getenv("FIR_GEMM_SHARE")) m->share_max = std::max(0, std::min(16, std::atoi(w)));
+    // the 16-row kernels always run the smallest-proxy sample flow with its XCD-shared launches: one workgroup per CU, CUs in eights
+    if (m->mfma16 && !(m->share_max > 0 && (m->v.cus & 7) == 0 && m->v.cus >= 8)) m->mfma16 = 0;
     if (const char* w = std::getenv("FIR_GEMM_REGTILE")) m->regtile = std::atoi(w);
     if (const char* w = std::getenv("FIR_GEMM_STREAMED")) m->streamed = std::atoi(w);   // experiments: 0 / 1 force the form, -1 = by row length
     if (e == hipSuccess && m->v.n > 0) {
@@ -1765,14 +1777,9 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
                     const int rb_stride = (int)std::max<int64_t>(1, ((n + 31) / 32) / sample_blocks);
                     if (x_flow) {
                         const bool xs = m->dk16 > kSlabH || m->streamed > 0;
-                        if (xs)
-                            hipLaunchKernelGGL((k_gemm_proxy_f16x<2, 1>), dim3(grid), dim3(kGemmBlock), kHalfLds, ps, m->gh, m->gnorm, m->qbf[b] + qo * 4 * m->dk16 * 64,
-                                               m->qinv[b] + qo * 2 * kQT, n, (int64_t)0, sample_blocks * 32, m->dk16, m->tau[b], m->lists[b], m->counts[b], (float*)nullptr,
-                                               0, P, P <= 1 ? 1 : 0, rb_stride, m->smin[b] + qo * 2 * kQT, sub_stride);
-                        else
-                            hipLaunchKernelGGL((k_gemm_proxy_f16x<2, 0>), dim3(grid), dim3(kGemmBlock), kHalfLds, ps, m->gh, m->gnorm, m->qbf[b] + qo * 4 * m->dk16 * 64,
-                                               m->qinv[b] + qo * 2 * kQT, n, (int64_t)0, sample_blocks * 32, m->dk16, m->tau[b], m->lists[b], m->counts[b], (float*)nullptr,
-                                               0, P, P <= 1 ? 1 : 0, rb_stride, m->smin[b] + qo * 2 * kQT, sub_stride);
+                        hipLaunchKernelGGL(pick_x(2, xs, (m->dk16 / kRing) & 1), dim3(grid), dim3(kGemmBlock), kHalfLds, ps, m->gh, m->gnorm, m->qbf[b] + qo * 4 * m->dk16 * 64,
+                                           m->qinv[b] + qo * 2 * kQT, n, (int64_t)0, sample_blocks * 32, m->dk16, m->tau[b], m->lists[b], m->counts[b], (float*)nullptr,
+                                           0, P, P <= 1 ? 1 : 0, rb_stride, m->smin[b] + qo * 2 * kQT, sub_stride);
                     } else
                     hipLaunchKernelGGL(rt_sample, dim3(grid), dim3(512), rt_lds, ps, m->gh, m->gnorm, m->qbf[b] + qo * 4 * m->dk16 * 64, m->qinv[b] + qo * 2 * kQT, n,
                                        sample_blocks * 32, rb_stride, m->tau[b] + qo * 2 * kQT, m->lists[b] + qo * 2 * kQT * kListCap, m->counts[b] + qo * 2 * kQT,
@@ -1789,13 +1796,7 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
             const int sample_wgs = (int)((((int64_t)sample_rows + 31) / 32 + wpb - 1) / wpb);
             const bool streamed = m->mfma16 ? (m->dk16 > kSlabH || m->streamed > 0) : (m->streamed >= 0 ? m->streamed != 0 : m->dk16 > kSlabH);
             const dim3 sgrid(std::min(sample_wgs, grid), pairs);
-            if (m->mfma16 && streamed)
-                hipLaunchKernelGGL((k_gemm_proxy_f16x<0, 1>), sgrid, dim3(kGemmBlock), kHalfLds, ps, m->gh, m->gnorm, m->qbf[b], m->qinv[b], n, (int64_t)0,
-                                   (int64_t)sample_rows, m->dk16, m->tau[b], m->lists[b], m->counts[b], m->sample, sample_rows, 0, 1, 1, (unsigned int*)nullptr, 0);
-            else if (m->mfma16)
-                hipLaunchKernelGGL((k_gemm_proxy_f16x<0, 0>), sgrid, dim3(kGemmBlock), kHalfLds, ps, m->gh, m->gnorm, m->qbf[b], m->qinv[b], n, (int64_t)0,
-                                   (int64_t)sample_rows, m->dk16, m->tau[b], m->lists[b], m->counts[b], m->sample, sample_rows, 0, 1, 1, (unsigned int*)nullptr, 0);
-            else if (streamed)
+            if (streamed)
                 hipLaunchKernelGGL((k_gemm_proxy_f16<0, 1>), sgrid, dim3(kGemmBlock), kHalfLds, ps, m->gh, m->gnorm, m->qbf[b], m->qinv[b], n, (int64_t)0,
                                    (int64_t)sample_rows, m->dk16, m->tau[b], m->lists[b], m->counts[b], m->sample, sample_rows, 0, 1);
             else
@@ -1840,7 +1841,7 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
             const bool streamed = m->mfma16 ? (m->dk16 > kSlabH || m->streamed > 0) : (m->streamed >= 0 ? m->streamed != 0 : m->dk16 > kSlabH);
             const int64_t rblocks = (n + 31) / 32;
             // rows longer than the LDS tile (query slabs streamed per unit): 16 readers of one range drift apart, 8 measured better
-            const int share_cap = m->share_max > 0 ? (streamed ? std::min(m->share_max, 8) : m->share_max) : 16;
+            const int share_cap = m->share_max > 0 ? (streamed ? std::min(m->share_max, m->share_streamed) : m->share_max) : 16;
             int nlaunch = 0, p_first = 1;
             for (int p0 = 0; p0 < pairs;) {
                 int P = 1;
@@ -1871,14 +1872,10 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
                                        m->tau[b] + qo * 2 * kQT, m->lists[b] + qo * 2 * kQT * kListCap, m->counts[b] + qo * 2 * kQT, m->smin[b] + qo * 2 * kQT, share, nt, 0);
                     used_rt = true;
                     used_rt_lds = rt_lds;
-                } else if (m->mfma16 && streamed)
-                    hipLaunchKernelGGL((k_gemm_proxy_f16x<1, 1>), g1, dim3(kGemmBlock), kHalfLds, st, m->gh, m->gnorm, m->qbf[b] + qo * 4 * m->dk16 * 64, m->qinv[b] + qo * 2 * kQT,
-                                       n, (int64_t)0, n, m->dk16, m->tau[b] + qo * 2 * kQT, m->lists[b] + qo * 2 * kQT * kListCap, m->counts[b] + qo * 2 * kQT, m->sample,
-                                       sample_rows, share, nt, 1, (unsigned int*)nullptr, 0);
-                else if (m->mfma16)
-                    hipLaunchKernelGGL((k_gemm_proxy_f16x<1, 0>), g1, dim3(kGemmBlock), kHalfLds, st, m->gh, m->gnorm, m->qbf[b] + qo * 4 * m->dk16 * 64, m->qinv[b] + qo * 2 * kQT,
-                                       n, (int64_t)0, n, m->dk16, m->tau[b] + qo * 2 * kQT, m->lists[b] + qo * 2 * kQT * kListCap, m->counts[b] + qo * 2 * kQT, m->sample,
-                                       sample_rows, share, nt | (m->stagger ? 2 : 0), 1, (unsigned int*)nullptr, 0);
+                } else if (m->mfma16)
+                    hipLaunchKernelGGL(pick_x(1, streamed, (m->dk16 / kRing) & 1), g1, dim3(kGemmBlock), kHalfLds, st, m->gh, m->gnorm, m->qbf[b] + qo * 4 * m->dk16 * 64,
+                                       m->qinv[b] + qo * 2 * kQT, n, (int64_t)0, n, m->dk16, m->tau[b] + qo * 2 * kQT, m->lists[b] + qo * 2 * kQT * kListCap,
+                                       m->counts[b] + qo * 2 * kQT, m->sample, sample_rows, share, nt | (m->stagger ? 2 : 0), 1, (unsigned int*)nullptr, 0);
                 else if (streamed)
                     hipLaunchKernelGGL((k_gemm_proxy_f16<1, 1>), g1, dim3(kGemmBlock), kHalfLds, st, m->gh, m->gnorm, m->qbf[b] + qo * 4 * m->dk16 * 64, m->qinv[b] + qo * 2 * kQT,
                                        n, (int64_t)0, n, m->dk16, m->tau[b] + qo * 2 * kQT, m->lists[b] + qo * 2 * kQT * kListCap, m->counts[b] + qo * 2 * kQT, m->sample,
@@ -1896,9 +1893,9 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
                 const void* fp = (const void*)rt_main;
                 fir_gallery_note_dispatch_(m->g, fp, nm, sb == 0, grid, nlaunch, 512, used_rt_lds, 128 * p_first, bytes, flops);
             } else
-            fir_gallery_note_dispatch_(m->g, m->mfma16 ? (streamed ? (const void*)k_gemm_proxy_f16x<1, 1> : (const void*)k_gemm_proxy_f16x<1, 0>)
+            fir_gallery_note_dispatch_(m->g, m->mfma16 ? (const void*)pick_x(1, streamed, (m->dk16 / kRing) & 1)
                                                        : (streamed ? (const void*)k_gemm_proxy_f16<1, 1> : (const void*)k_gemm_proxy_f16<1, 0>),
-                                       m->mfma16 ? (streamed ? "fir::k_gemm_proxy_f16x<1, 1>" : "fir::k_gemm_proxy_f16x<1, 0>")
+                                       m->mfma16 ? name_x(streamed, (m->dk16 / kRing) & 1)
                                                  : (streamed ? "fir::k_gemm_proxy_f16<1, 1>" : "fir::k_gemm_proxy_f16<1, 0>"), sb == 0, grid, m->share_max > 0 ? nlaunch : pairs, kGemmBlock, kHalfLds,
                                        m->share_max > 0 ? 128 * p_first : 128, bytes, flops);
         } else if (m->precision == FIR_GEMM_F32) {

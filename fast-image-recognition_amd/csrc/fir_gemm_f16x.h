@@ -11,6 +11,7 @@
 // addressed exactly as in k_gemm_proxy_f16.) Accumulator tile (s, jb): f32x4, lane l holds query 16 jb + (l & 15) against
 // rows 16 s + 4 (l >> 4) + 0..3 of the block.
 #pragma once
+#include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -68,7 +69,11 @@ __global__ void __launch_bounds__(256) k_gemm_pack_queries_f16x(const float* q, 
 }
 
 // One wave: 32 rows x 128 queries. Parameters, grid shapes and the `share` placement as k_gemm_proxy_f16.
-// MODE 0: one minimum per (row block, query) of rows [row_begin, row_end) -> sample (the order-statistic flow, k_gemm_tau);
+// ODD = units (of kRing pieces) per row block is odd: only then do the two gallery buffers end a row block in swapped roles
+// and need a copy; with the even form compiled separately the common row lengths (256, 512, 1280 features) carry neither the
+// copy nor the merge point the compiler hung an s_waitcnt vmcnt(0) on.
+// MODE 0: one minimum per (row block, query) of rows [row_begin, row_end) -> sample (the order-statistic flow, k_gemm_tau; not
+// instantiated any more: the 16-row kernels always run the smallest-proxy flow);
 // MODE 1: the full pass, every row below tau is appended; MODE 2: the sample of the smallest-proxy flow -- row blocks
 // 0, rb_stride, 2 rb_stride, ... of the gallery ((row_end - row_begin) / 32 of them, spread over all of it: the reference's
 // galleries are ordered by class), smin[q] <- the smallest proxy seen (fir::f32_orderable bits, atomicMin, caller presets +inf);
@@ -79,7 +84,7 @@ __global__ void __launch_bounds__(256) k_gemm_pack_queries_f16x(const float* q, 
 // Bit 1 of `nt_flags` (experiment, FIR_GEMM_STAGGER): waves 4-7 -- the partners of waves 0-3 on their SIMDs -- run half a unit of
 // throw-away MFMAs first, so that partners do not reach their epilogues and their end-of-unit waits together. Bit 0: the
 // gallery stream is read once per launch (non-temporal loads).
-template <int MODE, int STREAMED>
+template <int MODE, int STREAMED, int ODD>
 __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* __restrict__ gh, const float* __restrict__ gnorm, const uint4* qh,
                                                                     const float* __restrict__ qinv, int64_t n, int64_t row_begin, int64_t row_end,
                                                                     int dk16, const float* tau, unsigned long long* lists, int* counts,
@@ -114,7 +119,7 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
         if (MODE == 2) smin += pr * 2 * kQT;
     }
     const int64_t rbs = MODE == 2 ? rb_stride : 1;                        // gallery row blocks per row block of the pass
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wpb = blockDim.x >> 6;
     if (threadIdx.x < 2 * kQT) {
         tau_s[threadIdx.x] = MODE == 1 ? tau[threadIdx.x] : 0.f;
@@ -134,21 +139,34 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
     for (int u = 0; u < kRing; ++u) cur[u] = FIR_X_LD(a_cur + (size_t)u * 64);
     constexpr int kUnitsPerSlab = kSlabH / kRing;                         // units of the LDS-resident tile (512 features)
     const bool resident = !STREAMED;                                      // (the caller streams whatever does not fit: dk16 > kSlabH)
-    // STREAMED: the 32 pieces (step t, query block jb) of unit hq -> LDS buffer bsel, four per wave
-    auto request_piece = [&](int hq, int bsel, int piece) {
-        uint4* dst = lqx + (size_t)bsel * 4 * kRing * 64;
-        const int jb = piece >> 2, t = piece & 3;
-        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(qh + ((size_t)jb * dk32 + (size_t)hq * 4 + t) * 64 + lane),
-                                         (void __attribute__((address_space(3)))*)(dst + (size_t)(t * 8 + jb) * 64), 16, 0, 0);
+    // STREAMED (rows longer than the 512 features whose 128-query tile fits LDS): the query fragments go through a ring of FOUR
+    // 32-KiB LDS slots of one unit (four steps x eight query blocks) each. Units are numbered c = 0, 1, 2, ... over the whole walk of
+    // the workgroup (slab of unit c: c mod units); slot c & 3 holds unit c. The slab of unit c + 3 is requested DURING unit c -- this
+    // wave's four one-KiB pieces by LDS-DMA, one behind each step's MFMAs (a request holds the issuing wave for 60-180 cycles: spread
+    // out, the SIMD's other wave covers them) -- into the slot unit c - 1 was read from, which every wave left before the barrier
+    // that ended unit c - 1. At the end of unit c every wave waits for its pieces of unit c + 2 (requested a whole unit earlier:
+    // vmcnt(12) = this unit's eight gallery loads and four requests may stay in flight) and ONE barrier publishes them; so the
+    // fragments of unit c + 1's first step, which the rolling re-read fetches during unit c's last step, were published one barrier
+    // earlier, and the fragment pipeline runs on through unit borders as in the resident form -- the barrier no longer drains it.
+    // The requests are inline assembly: the compiler orders every LDS read behind a pending LDS-DMA it knows about with
+    // s_waitcnt vmcnt(0), and it cannot see that ring slots do not alias. Its own counted waits for the gallery loads stay
+    // correct with requests it does not know in the queue: vmcnt(N) leaves the N YOUNGEST operations outstanding, whatever they are.
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(void __attribute__((address_space(3)))*)lqx;
+    auto request_piece = [&](int hq, int slot, int i) {              // piece i of this wave: (step i, query block `wave`) of slab hq
+        const uint4* src = qh + ((size_t)wave * dk32 + (size_t)hq * 4 + i) * 64 + lane;
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)slot * (4 * kRing * 1024) + (uint32_t)(i * 8 + wave) * 1024);
+        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(src) : "memory");
     };
-    auto request_slab = [&](int hq, int bsel) {
-        const int per_wave = 4 * kRing / wpb;
-        for (int c = 0; c < per_wave; ++c) request_piece(hq, bsel, wave * per_wave + c);
-    };
-    int tsel = 0;
+    int ring_c = 0, hq3 = 0;                         // unit counter of the walk; slab index of unit ring_c + 3
     if (STREAMED) {
-        request_slab(0, 0);
-        __builtin_amdgcn_s_waitcnt(0);
+        int hq = 0;
+        for (int cc = 0; cc < 3; ++cc) {             // units 0, 1, 2 before the walk starts
+#pragma unroll
+            for (int i = 0; i < 4; ++i) request_piece(hq, cc, i);
+            hq = hq + 1 == units ? 0 : hq + 1;
+        }
+        hq3 = hq;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // (also the prologue's gallery loads: once per kernel)
         __syncthreads();
     } else {
         // LDS image: step-major, the eight query blocks of a step side by side -- (kk * 8 + jb) * 1 KiB
@@ -161,11 +179,9 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
     float smallest[8];                               // MODE 2: running minima of this lane's eight queries
 #pragma unroll
     for (int j = 0; j < 8; ++j) smallest[j] = __builtin_huge_valf();
-    uint4 B[8];
-    if (resident) {
+    uint4 B[8];                                      // the fragments of the first step of the first unit (slot 0 / the resident tile's start)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) B[j] = lqx[lane + j * 64];
-    }
+    for (int j = 0; j < 8; ++j) B[j] = lqx[lane + j * 64];
     if ((nt_flags & 2) && resident && wave >= wpb / 2) {
         // half a unit of MFMAs whose result goes nowhere the kernel's outputs are computed from: it only delays this wave
         f32x4 junk = {0.f, 0.f, 0.f, 0.f};
@@ -179,22 +195,15 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
         const bool active = rbp < rb_end;
         const int64_t rgn = rg + rg_step;
         const uint4* a_nxt = FIR_X_BLOCK(rgn < rg_end ? rgn : rg);
-        f32x4 acc[2][8];
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[s][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 acc[2][8];                             // (first written by the MFMAs of the row block's first step, against a zero C operand)
         float4 gns[2];                               // squared norms of rows 16 s + 4 (lane >> 4) + 0..3 of the block
         const bool full_block = active && rbp * 32 >= row_begin && rbp * 32 + 32 <= row_end && rb * 32 + 32 <= n && (MODE != 0 || rb * 32 + 32 <= sample_rows);
         // MODE 2, sub_stride: sixteen row ranges x four waves = kRtSubsets disjoint subsets (more ranges wrap around: unions of disjoint sets)
         unsigned int* smin_blk = MODE == 2 ? smin + (size_t)(((range & 15) << 2) + (wave & 3)) * sub_stride : nullptr;
-        auto unit = [&](uint4 (&C)[kRing], uint4 (&N)[kRing], int h) {
+        auto unit = [&](uint4 (&C)[kRing], uint4 (&N)[kRing], int h, auto first_tag) {
+            constexpr bool kFirst = decltype(first_tag)::value;      // the first unit of the row block: its first step starts the sums
             const uint4* src = h + 1 < units ? a_cur + (size_t)(h + 1) * kRing * 64 : a_nxt;
-            const uint4* bq = STREAMED ? lqx + lane + (size_t)tsel * 4 * kRing * 64 : lqx + lane + (size_t)(h % kUnitsPerSlab) * kRing * 4 * 64;
-            if (!resident) {                         // first, so that their latency passes under the issue of the loads below
-#pragma unroll
-                for (int j = 0; j < 8; ++j) B[j] = bq[j * 64];
-            }
+            const uint4* bq = STREAMED ? lqx + lane + (size_t)(ring_c & 3) * 4 * kRing * 64 : lqx + lane + (size_t)(h % kUnitsPerSlab) * kRing * 4 * 64;
             if (nt) {
 #pragma unroll
                 for (int u = 0; u < kRing; ++u) N[u] = ld_nt(src + (size_t)u * 64);
@@ -207,41 +216,45 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
                 gns[0] = gp[0];
                 gns[1] = gp[4];
             }
-            const uint4* bq_after = lqx + lane + (size_t)((h + 1 < units ? h + 1 : 0) % kUnitsPerSlab) * kRing * 4 * 64;
+            const uint4* bq_after = STREAMED ? lqx + lane + (size_t)((ring_c + 1) & 3) * 4 * kRing * 64
+                                             : lqx + lane + (size_t)((h + 1 < units ? h + 1 : 0) % kUnitsPerSlab) * kRing * 4 * 64;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const uint4* bn = t + 1 < 4 ? bq + (size_t)(t + 1) * 8 * 64 : bq_after;
-                const bool pre = t + 1 < 4 || resident;
                 const f16x8 a0 = as_f16x8(C[2 * t]), a1 = as_f16x8(C[2 * t + 1]);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const f16x8 b = as_f16x8(B[j]);
-                    acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b, acc[0][j], 0, 0, 0);
-                    acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b, acc[1][j], 0, 0, 0);
-                    if (pre) B[j] = bn[j * 64];
+                    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                    acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b, kFirst && t == 0 ? zero : acc[0][j], 0, 0, 0);
+                    acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b, kFirst && t == 0 ? zero : acc[1][j], 0, 0, 0);
+                    B[j] = bn[j * 64];
                     __builtin_amdgcn_sched_barrier(0);            // the re-read stays right behind its fragment's last use
                 }
-                // STREAMED: this wave's four pieces of the NEXT unit's query slab, one behind each step's MFMAs (a request holds the
-                // issuing wave for 60-180 cycles: spread out, the SIMD's other wave covers them); the buffer's last readers passed
-                // the barrier that ended the previous unit
-                if (STREAMED && 4 * kRing / wpb == 4) request_piece(h + 1 < units ? h + 1 : 0, tsel ^ 1, wave * 4 + t);
+                if (STREAMED) request_piece(hq3, (ring_c + 3) & 3, t);      // unit ring_c + 3's slab, into the slot unit ring_c - 1 has left
             }
-            if (STREAMED && 4 * kRing / wpb != 4) request_slab(h + 1 < units ? h + 1 : 0, tsel ^ 1);
             if (STREAMED) {
-                __builtin_amdgcn_s_waitcnt(0);
-                __syncthreads();
-                tsel ^= 1;
+                asm volatile("s_waitcnt vmcnt(12)" ::: "memory");          // this wave's pieces of unit ring_c + 2 have landed ...
+                __builtin_amdgcn_s_barrier();                               // ... and everyone's: published
+                ++ring_c;
+                hq3 = hq3 + 1 == units ? 0 : hq3 + 1;
             }
         };
-        int h = 0;
-        for (; h + 1 < units; h += 2) {
-            unit(cur, nxt, h);
-            unit(nxt, cur, h + 1);
-        }
-        if (h < units) {
-            unit(cur, nxt, h);
+        if (!ODD) {
+            unit(cur, nxt, 0, std::true_type());
+            unit(nxt, cur, 1, std::false_type());
+            for (int h = 2; h < units; h += 2) {
+                unit(cur, nxt, h, std::false_type());
+                unit(nxt, cur, h + 1, std::false_type());
+            }
+        } else {
+            unit(cur, nxt, 0, std::true_type());
+            for (int h = 1; h + 1 < units; h += 2) {
+                unit(nxt, cur, h, std::false_type());
+                unit(cur, nxt, h + 1, std::false_type());
+            }
 #pragma unroll
-            for (int u = 0; u < kRing; ++u) cur[u] = nxt[u];
+            for (int u = 0; u < kRing; ++u) cur[u] = nxt[u];         // an odd number of units: the next row block's first unit sits in nxt
         }
         a_cur = a_nxt;
         if (!active) continue;

@@ -14,12 +14,30 @@
 //     to the others out of band, and every process passes it in fir_shard_opts.
 // Several logical shards per device (shards_per_device) exist so that the whole path -- split, per-shard scan,
 // on-device minimum, RCCL call -- can be exercised on a one-GPU box.
+//
+// Failure semantics: the reference's convention is "-1, never block" (ann.cpp:113-126, ImageTesting.cpp:63). A collective
+// in which one rank does not take part blocks every other rank for good, so no rank ever leaves a call between two
+// collectives of it:
+//   * buffers grow in an AGREED step: the rank tries its allocations, then a one-int ncclAllReduce(ncclMin) of the local
+//     status (on a word allocated when the communicator was made) tells every rank whether all of them have their
+//     buffers; the step runs only in calls that have to grow something, which are the same calls on every rank (the
+//     capacities depend on the sequence of batch shapes only);
+//   * a rank whose scans fail afterwards still enters the exchange, with neutral keys (FIR_KEY_NONE / +0 sums) and a
+//     poisoned status element that travels behind the payload (min / gather / sum like the payload itself): every rank
+//     returns the same FIR_ERR_* from that call;
+//   * every wait on a stream that carries a collective is bounded (fir_shard_opts.timeout_ms, default 120 s) and polls
+//     ncclCommGetAsyncError; an error or the time-out aborts the communicator (ncclCommAbort);
+//   * after any such failure the handle is dead: later calls return FIR_ERR_STATE at once on every rank (they have all
+//     seen the failure), fir_sharded_destroy still frees it, and a fresh handle works.
+// fir_shard_opts.fail_shard / fail_step inject a failure for the tests.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <stdint.h>
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
@@ -73,15 +91,26 @@ __global__ void __launch_bounds__(256) k_shard_min_keys(const uint64_t* __restri
 
 // out[q][0..k) = the k smallest of parts[p][q][0..k), p < nparts, ascending. Every part is ascending and keys are unique
 // (global row index in the low word), FIR_KEY_NONE sorts last: exactly fir_search_topk over the union of the parts.
-__global__ void __launch_bounds__(64) k_shard_merge_topk(const uint64_t* __restrict__ parts, int nparts, int qb, int k, uint64_t* __restrict__ out) {
+// stride: elements from one part to the next (qb * k, or qb * k + 1 when a status element rides behind every part: then
+// status_out <- the minimum of those elements).
+__global__ void __launch_bounds__(64) k_shard_merge_topk(const uint64_t* __restrict__ parts, int nparts, int qb, int k, uint64_t* __restrict__ out,
+                                                          size_t stride, uint64_t* __restrict__ status_out) {
     const int q = blockIdx.x * 64 + threadIdx.x;
+    if (status_out && q == 0) {
+        uint64_t m = kKeyNone;
+        for (int p = 0; p < nparts; ++p) {
+            const uint64_t v = parts[(size_t)p * stride + (size_t)qb * k];
+            m = v < m ? v : m;
+        }
+        *status_out = m;
+    }
     if (q >= qb) return;
     uint64_t prev = 0;
     bool first = true;
     for (int j = 0; j < k; ++j) {           // j-th smallest = the smallest key greater than the previous pick
         uint64_t m = kKeyNone;
         for (int p = 0; p < nparts; ++p) {
-            const uint64_t* L = parts + ((size_t)p * qb + q) * k;
+            const uint64_t* L = parts + (size_t)p * stride + (size_t)q * k;
             for (int i = 0; i < k; ++i) {
                 const uint64_t v = L[i];
                 if ((first || v > prev) && v < m) m = v;
@@ -163,6 +192,22 @@ struct DevCtx {
     Worker* worker = nullptr;
     std::vector<hipEvent_t> evs;                          // pairs around the RCCL calls (profiling, device slot 0)
     size_t ev_used = 0;
+    int32_t* status = nullptr;                            // device: [0] the agreed-growth word, [1] sticky status of the asynchronous calls
+    int32_t* h_status = nullptr;                          // pinned host: [0] what this rank contributes, [1] what came back, [2] sticky read-back
+};
+
+// What the ranks of a handle have to agree on to stay out of each other's way (see "Failure semantics" above).
+struct Health {
+    std::atomic<bool> dead{false};   // a collective failed or a peer reported an error: no further collective is attempted
+    std::atomic<int> dead_code{0};
+    int timeout_ms = 120000;         // bound of every wait behind a collective
+    int fail_shard = 0;              // test hook: 1-based local shard whose step fails, 0 = none
+    int fail_step = 0;               // 1 = its scan (after the agreed growth), 2 = its device's buffer growth
+    void apply(const fir_shard_opts& o) {
+        if (o.timeout_ms > 0) timeout_ms = o.timeout_ms;
+        fail_shard = o.fail_shard;
+        fail_step = o.fail_step;
+    }
 };
 
 template <typename T>
@@ -177,6 +222,86 @@ int grow_dev(T*& p, size_t& cap, size_t need) {
     return FIR_OK;
 }
 
+int peer_failed(int code) {
+    const char* what = code == FIR_ERR_NOMEM ? "allocation failed" : code == FIR_ERR_HIP ? "a HIP call failed" : code == FIR_ERR_COMM ? "an RCCL call failed"
+                                                                                                                                    : "its step failed";
+    return sh_fail(code < 0 ? code : FIR_ERR_COMM, "a rank of the sharded handle reported an error (%s): the call fails on every rank and the handle is closed for further calls", what);
+}
+
+// Abort this device's communicator (a blocked collective returns) and mark the handle dead.
+int comm_dead(DevCtx& dc, Health& hl, int code, const char* why) {
+    hl.dead = true;
+    hl.dead_code = code;
+    if (dc.comm) { (void)ncclCommAbort(dc.comm); dc.comm = nullptr; }
+    return sh_fail(code, "sharded handle: %s; the communicator was aborted and the handle is closed for further calls", why);
+}
+
+// hipStreamSynchronize with a bound: polls the stream and the communicator's asynchronous error state.
+int wait_stream(DevCtx& dc, hipStream_t st, Health& hl) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int spins = 0;; ++spins) {
+        const hipError_t q = hipStreamQuery(st);
+        if (q == hipSuccess) return FIR_OK;
+        if (q != hipErrorNotReady) { (void)hipGetLastError(); return comm_dead(dc, hl, FIR_ERR_HIP, hipGetErrorString(q)); }
+        if (dc.comm && (spins & 63) == 63) {
+            ncclResult_t ar = ncclSuccess;
+            if (ncclCommGetAsyncError(dc.comm, &ar) == ncclSuccess && ar != ncclSuccess && ar != ncclInProgress)
+                return comm_dead(dc, hl, FIR_ERR_COMM, ncclGetErrorString(ar));
+        }
+        if (spins > 2000) {
+            if (std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() > hl.timeout_ms)
+                return comm_dead(dc, hl, FIR_ERR_COMM, "a collective did not complete within the time-out (a peer is gone or never entered it)");
+            std::this_thread::sleep_for(std::chrono::microseconds(20));
+        }
+    }
+}
+
+// Every rank contributes its local status (FIR_OK or a negative FIR_ERR_*); all of them get the minimum.
+int agree(DevCtx& dc, hipStream_t st, Health& hl, int local_rc, int* agreed) {
+    if (!dc.comm) return sh_fail(FIR_ERR_STATE, "sharded handle: no communicator");
+    dc.h_status[0] = local_rc;
+    hipError_t e = hipMemcpyAsync(dc.status, dc.h_status, sizeof(int32_t), hipMemcpyHostToDevice, st);
+    ncclResult_t nr = e == hipSuccess ? ncclAllReduce(dc.status, dc.status, 1, ncclInt32, ncclMin, dc.comm, st) : ncclSuccess;
+    if (e == hipSuccess && nr == ncclSuccess) e = hipMemcpyAsync(dc.h_status + 1, dc.status, sizeof(int32_t), hipMemcpyDeviceToHost, st);
+    if (e != hipSuccess) return comm_dead(dc, hl, FIR_ERR_HIP, hipGetErrorString(e));
+    if (nr != ncclSuccess) return comm_dead(dc, hl, FIR_ERR_COMM, ncclGetErrorString(nr));
+    const int rc = wait_stream(dc, st, hl);
+    if (rc) return rc;
+    *agreed = dc.h_status[1];
+    return FIR_OK;
+}
+
+// The agreed growth step of a call: `need` says whether this call grows anything on this rank (the same answer on every
+// rank), `alloc` tries the allocations. Everyone leaves with the same verdict.
+int grow_agreed(DevCtx& dc, hipStream_t st, Health& hl, bool need, bool inject, const std::function<int()>& alloc) {
+    if (!need) return FIR_OK;
+    int r = inject ? sh_fail(FIR_ERR_NOMEM, "injected allocation failure (fir_shard_opts.fail_step = 2)") : alloc();
+    char mine[512];
+    if (r) { strncpy(mine, fir_last_error(), sizeof(mine) - 1); mine[sizeof(mine) - 1] = 0; }
+    int all = FIR_OK;
+    const int ra = agree(dc, st, hl, r, &all);
+    if (ra) return ra;
+    if (all == FIR_OK) return FIR_OK;
+    hl.dead = true;
+    hl.dead_code = all;
+    if (r) { fir_set_last_error_(mine); return r; }       // this rank's own error text
+    return peer_failed(all);
+}
+
+constexpr uint64_t kStatusOk = kKeyNone;                  // the element behind a key payload: all ones = every rank was fine
+__host__ __device__ inline uint64_t status_key(int rc) { return rc == FIR_OK ? kStatusOk : (uint64_t)(uint32_t)(1000 + rc); }   // smaller = worse under ncclMin
+inline int status_code(uint64_t v) { return v == kStatusOk ? FIR_OK : (int)(int64_t)v - 1000; }
+
+__global__ void k_shard_set_u64(uint64_t* p, uint64_t v) { *p = v; }
+__global__ void k_shard_set_i32(int32_t* p, int32_t v) { *p = v; }
+__global__ void k_shard_set_f64(double* p, double v) { *p = v; }
+// sticky[0] = min(sticky[0], status of the exchange just finished) -- the asynchronous device-pointer call's record
+__global__ void k_shard_note_status(const uint64_t* __restrict__ st, int32_t* __restrict__ sticky) {
+    const uint64_t v = *st;
+    const int32_t c = v == kKeyNone ? 0 : (int32_t)(int64_t)v - 1000;
+    if (c < *sticky) *sticky = c;
+}
+
 }  // namespace
 
 struct fir_sharded {
@@ -188,12 +313,13 @@ struct fir_sharded {
     std::vector<Shard> shards;
     void* pin = nullptr;  size_t pin_cap = 0;      // pinned host staging: queries in, keys / classes out
     bool profiling = false;
+    Health health;
 };
 
 namespace {
 
 int setup_devices(std::vector<DevCtx>& devs, const int32_t* devices, int ndev, int nranks, int first_rank, const void* comm_id);
-void teardown_devices(std::vector<DevCtx>& devs);
+void teardown_devices(std::vector<DevCtx>& devs, bool dead = false);
 
 // Run fn(slot) for every device: inline for one device, on the per-device worker threads otherwise.
 int run_all(std::vector<DevCtx>& devs, const std::function<int(int)>& fn);
@@ -240,17 +366,43 @@ int check_range(const fir_sharded* h, int32_t& start, int32_t& end) {
     return FIR_OK;
 }
 
+// The buffers of one call on one device, grown in the call's agreed step: queries (host-pointer form), the shards' partial
+// keys, the reduced keys + status element, the gathered keys of all ranks (top-K) and the winners' classes + status element.
+struct CallBuffers { size_t dq, parts, keys, gath, cls; };
+CallBuffers call_buffers(const fir_sharded* h, const DevCtx& dc, int32_t qb, int32_t k, bool host_queries, bool classes) {
+    const size_t per = (size_t)qb * k;
+    return {host_queries ? (size_t)qb * h->d : 0, per * std::max<size_t>(dc.shards.size(), 1), per + 1,
+            k > 1 ? (per + 1) * (size_t)h->nranks : 0, classes ? (size_t)qb + 1 : 0};
+}
+bool call_grows(const DevCtx& dc, const CallBuffers& b) {
+    return b.dq > dc.dq_cap || b.parts > dc.parts_cap || b.keys > dc.keys_cap || b.gath > dc.gath_cap || b.cls > dc.cls_cap;
+}
+int call_alloc(DevCtx& dc, const CallBuffers& b) {
+    int rc;
+    if ((rc = grow_dev(dc.dq, dc.dq_cap, b.dq))) return rc;
+    if ((rc = grow_dev(dc.parts, dc.parts_cap, b.parts))) return rc;
+    if ((rc = grow_dev(dc.keys, dc.keys_cap, b.keys))) return rc;
+    if ((rc = grow_dev(dc.gath, dc.gath_cap, b.gath))) return rc;
+    return grow_dev(dc.cls, dc.cls_cap, b.cls);
+}
+bool inject_here(const fir_sharded* h, const DevCtx& dc, int step) {
+    if (h->health.fail_step != step || h->health.fail_shard <= 0) return false;
+    for (int si : dc.shards)
+        if (si == h->health.fail_shard - 1) return true;
+    return false;
+}
+
 // The keys of one device: every shard it holds scans the batch (K keys per query, K = 1: top-1), then the minimum /
-// K-way merge over those shards lands in dc.keys.
+// K-way merge over those shards lands in dc.keys[0, qb * k). Buffers exist (call_alloc).
 int device_keys(fir_sharded* h, int slot, const float* d_queries, int32_t qb, int32_t start, int32_t end, int32_t k, hipStream_t st) {
     DevCtx& dc = h->devs[slot];
     const size_t per = (size_t)qb * k;
     int rc;
-    if ((rc = grow_dev(dc.parts, dc.parts_cap, per * std::max<size_t>(dc.shards.size(), 1)))) return rc;
-    if ((rc = grow_dev(dc.keys, dc.keys_cap, per))) return rc;
     int live = 0;
     for (size_t i = 0; i < dc.shards.size(); ++i) {
         Shard& s = h->shards[dc.shards[i]];
+        if (h->health.fail_step == 1 && h->health.fail_shard - 1 == dc.shards[i])
+            return sh_fail(FIR_ERR_NOMEM, "injected scan failure on shard %d (fir_shard_opts.fail_step = 1)", dc.shards[i]);
         if (!s.g) continue;
         uint64_t* out = dc.parts + (size_t)live * per;
         rc = k == 1 ? fir_search_top1_keys_dev(s.g, d_queries, qb, start, end, out, st)
@@ -260,55 +412,68 @@ int device_keys(fir_sharded* h, int slot, const float* d_queries, int32_t qb, in
     }
     if (live == 0) hipLaunchKernelGGL(k_shard_fill_u64, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, st, dc.keys, (int)per, kKeyNone);
     else if (k == 1) hipLaunchKernelGGL(k_shard_min_keys, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, st, dc.parts, live, (int)per, dc.keys);
-    else hipLaunchKernelGGL(k_shard_merge_topk, dim3((qb + 63) / 64), dim3(64), 0, st, dc.parts, live, qb, k, dc.keys);
+    else hipLaunchKernelGGL(k_shard_merge_topk, dim3((qb + 63) / 64), dim3(64), 0, st, dc.parts, live, qb, k, dc.keys, per, (uint64_t*)nullptr);
     SH_HIP(hipGetLastError());
     return FIR_OK;
 }
 
-// The exchange step over all ranks, on `st`, result in `keys` (in place).
-int exchange_keys(fir_sharded* h, int slot, uint64_t* keys, int32_t qb, int32_t k, hipStream_t st) {
+// The exchange step over all ranks, on `st`, result in dc.keys (in place); dc.keys[qb * k] carries local_rc in and the worst
+// status of all ranks out. A rank whose scans failed contributes FIR_KEY_NONE keys. Errors here kill the communicator.
+int exchange_keys(fir_sharded* h, int slot, int32_t qb, int32_t k, hipStream_t st, int local_rc) {
     DevCtx& dc = h->devs[slot];
+    uint64_t* keys = dc.keys;
     const size_t per = (size_t)qb * k;
     const bool prof = h->profiling && slot == 0;
+    if (local_rc) hipLaunchKernelGGL(k_shard_fill_u64, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, st, keys, (int)per, kKeyNone);
+    hipLaunchKernelGGL(k_shard_set_u64, dim3(1), dim3(1), 0, st, keys + per, status_key(local_rc));
     if (prof) {
         if (dc.ev_used + 2 > dc.evs.size())
             for (int i = 0; i < 64; ++i) {
                 hipEvent_t e;
-                SH_HIP(hipEventCreate(&e));
+                if (hipEventCreate(&e) != hipSuccess) break;
                 dc.evs.push_back(e);
             }
-        SH_HIP(hipEventRecord(dc.evs[dc.ev_used], st));
+        if (dc.ev_used + 2 <= dc.evs.size()) (void)hipEventRecord(dc.evs[dc.ev_used], st);
     }
+    ncclResult_t nr;
     if (k == 1) {
-        SH_NCCL(ncclAllReduce(keys, keys, per, ncclUint64, ncclMin, dc.comm, st));
+        nr = ncclAllReduce(keys, keys, per + 1, ncclUint64, ncclMin, dc.comm, st);
     } else {
-        int rc;
-        if ((rc = grow_dev(dc.gath, dc.gath_cap, per * (size_t)h->nranks))) return rc;
-        SH_NCCL(ncclAllGather(keys, dc.gath, per, ncclUint64, dc.comm, st));
-        hipLaunchKernelGGL(k_shard_merge_topk, dim3((qb + 63) / 64), dim3(64), 0, st, dc.gath, h->nranks, qb, k, keys);
-        SH_HIP(hipGetLastError());
+        nr = ncclAllGather(keys, dc.gath, per + 1, ncclUint64, dc.comm, st);
+        if (nr == ncclSuccess)
+            hipLaunchKernelGGL(k_shard_merge_topk, dim3((qb + 63) / 64), dim3(64), 0, st, dc.gath, h->nranks, qb, k, keys, per + 1, keys + per);
     }
-    if (prof) {
-        SH_HIP(hipEventRecord(dc.evs[dc.ev_used + 1], st));
+    if (nr != ncclSuccess) return comm_dead(dc, h->health, FIR_ERR_COMM, ncclGetErrorString(nr));
+    if (prof && dc.ev_used + 2 <= dc.evs.size()) {
+        (void)hipEventRecord(dc.evs[dc.ev_used + 1], st);
         dc.ev_used += 2;
     }
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return comm_dead(dc, h->health, FIR_ERR_HIP, hipGetErrorString(e));
     return FIR_OK;
 }
 
-// class of every winning row: the rank that holds the row knows it, everyone else contributes INT32_MAX
-int device_classes(fir_sharded* h, int slot, const uint64_t* keys, int32_t qb, hipStream_t st) {
+// class of every winning row: the rank that holds the row knows it, everyone else contributes INT32_MAX; dc.cls[qb] is the
+// status element (INT32_MAX = fine, a negative FIR_ERR_* otherwise: the minimum finds it)
+int device_classes(fir_sharded* h, int slot, const uint64_t* keys, int32_t qb, hipStream_t st, int local_rc) {
     DevCtx& dc = h->devs[slot];
-    int rc;
-    if ((rc = grow_dev(dc.cls, dc.cls_cap, (size_t)qb))) return rc;
     hipLaunchKernelGGL(k_shard_fill_i32, dim3((qb + 255) / 256), dim3(256), 0, st, dc.cls, qb, 0x7FFFFFFF);
-    for (int si : dc.shards) {
-        const Shard& s = h->shards[si];
-        if (!s.g || !s.cls) continue;
-        hipLaunchKernelGGL(k_shard_class_owned, dim3((qb + 255) / 256), dim3(256), 0, st, keys, qb, s.cls, s.lo, s.hi, dc.cls);
-    }
-    SH_HIP(hipGetLastError());
-    SH_NCCL(ncclAllReduce(dc.cls, dc.cls, (size_t)qb, ncclInt32, ncclMin, dc.comm, st));
+    hipLaunchKernelGGL(k_shard_set_i32, dim3(1), dim3(1), 0, st, dc.cls + qb, local_rc ? local_rc : 0x7FFFFFFF);
+    if (!local_rc)
+        for (int si : dc.shards) {
+            const Shard& s = h->shards[si];
+            if (!s.g || !s.cls) continue;
+            hipLaunchKernelGGL(k_shard_class_owned, dim3((qb + 255) / 256), dim3(256), 0, st, keys, qb, s.cls, s.lo, s.hi, dc.cls);
+        }
+    const ncclResult_t nr = ncclAllReduce(dc.cls, dc.cls, (size_t)qb + 1, ncclInt32, ncclMin, dc.comm, st);
+    if (nr != ncclSuccess) return comm_dead(dc, h->health, FIR_ERR_COMM, ncclGetErrorString(nr));
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return comm_dead(dc, h->health, FIR_ERR_HIP, hipGetErrorString(e));
     return FIR_OK;
+}
+
+int dead_handle(const Health& hl) {
+    return sh_fail(FIR_ERR_STATE, "this sharded handle is closed: an earlier call failed on some rank (code %d); destroy it and create a fresh one", hl.dead_code.load());
 }
 
 // Host-pointer search: queries go to every device from pinned memory, keys (and classes) come back from device slot 0.
@@ -318,32 +483,69 @@ int search_host(fir_sharded* h, const float* queries, int32_t qb, int32_t start,
     if (qb < 0) return sh_fail(FIR_ERR_ARG, "qb < 0");
     if (k < 1 || k > 8) return sh_fail(FIR_ERR_ARG, "k=%d outside [1,8]", k);
     if (class_out && !h->has_labels) return sh_fail(FIR_ERR_STATE, "the sharded gallery was created without class labels");
+    if (h->health.dead) return dead_handle(h->health);
     if (qb == 0) return FIR_OK;
     int rc = check_range(h, start, end);
     if (rc) return rc;
-    const size_t qbytes = (size_t)qb * h->d * sizeof(float), kbytes = (size_t)qb * k * sizeof(uint64_t);
-    if ((rc = ensure_pin(h, qbytes + kbytes + (size_t)qb * sizeof(int32_t)))) return rc;
-    float* hq = (float*)h->pin;
-    uint64_t* hk = (uint64_t*)((char*)h->pin + qbytes);
-    int32_t* hc = (int32_t*)((char*)h->pin + qbytes + kbytes);
-    std::memcpy(hq, queries, qbytes);
+    // (argument errors above are the same on every rank: nobody has entered a collective yet)
+    const size_t per = (size_t)qb * k;
+    const size_t qbytes = (size_t)qb * h->d * sizeof(float), kbytes = (per + 1) * sizeof(uint64_t), cbytes = ((size_t)qb + 1) * sizeof(int32_t);
+    // the pinned staging area is part of the agreed growth as well: slot 0 tries it inside the step
+    float* hq = nullptr;
+    uint64_t* hk = nullptr;
+    int32_t* hc = nullptr;
+    std::mutex pin_mu;
+    std::condition_variable pin_cv;
+    bool pin_ready = false;
+    int pin_rc = FIR_OK;
+    const bool pin_grows = qbytes + kbytes + cbytes > h->pin_cap;            // read before slot 0 changes it: the same answer for every slot
     rc = run_all(h, [&](int slot) -> int {
         DevCtx& dc = h->devs[slot];
         SH_HIP(hipSetDevice(dc.device));
-        int r;
-        if ((r = grow_dev(dc.dq, dc.dq_cap, (size_t)qb * h->d))) return r;
-        SH_HIP(hipMemcpyAsync(dc.dq, hq, qbytes, hipMemcpyHostToDevice, dc.stream));
-        if ((r = device_keys(h, slot, dc.dq, qb, start, end, k, dc.stream))) return r;
-        if ((r = exchange_keys(h, slot, dc.keys, qb, k, dc.stream))) return r;
-        if (class_out && (r = device_classes(h, slot, dc.keys, qb, dc.stream))) return r;
+        const CallBuffers nb = call_buffers(h, dc, qb, k, true, class_out != nullptr);
+        int r = grow_agreed(dc, dc.stream, h->health, call_grows(dc, nb) || pin_grows, inject_here(h, dc, 2), [&]() -> int {
+            int ra = call_alloc(dc, nb);
+            if (slot == 0 && !ra) ra = ensure_pin(h, qbytes + kbytes + cbytes);
+            return ra;
+        });
         if (slot == 0) {
-            SH_HIP(hipMemcpyAsync(hk, dc.keys, kbytes, hipMemcpyDeviceToHost, dc.stream));
-            if (class_out) SH_HIP(hipMemcpyAsync(hc, dc.cls, (size_t)qb * sizeof(int32_t), hipMemcpyDeviceToHost, dc.stream));
+            // the other devices of this process read the queries from the staging area slot 0 has just made sure of
+            if (!r) {
+                hq = (float*)h->pin;
+                hk = (uint64_t*)((char*)h->pin + qbytes);
+                hc = (int32_t*)((char*)h->pin + qbytes + kbytes);
+                std::memcpy(hq, queries, qbytes);
+            }
+            { std::lock_guard<std::mutex> lk(pin_mu); pin_ready = true; pin_rc = r; }
+            pin_cv.notify_all();
+        } else {
+            std::unique_lock<std::mutex> lk(pin_mu);
+            pin_cv.wait(lk, [&] { return pin_ready; });
+            if (!r && pin_rc) r = pin_rc;          // (an agreed failure has r != 0 everywhere already)
         }
-        SH_HIP(hipStreamSynchronize(dc.stream));
+        if (r) return r;
+        // from here on every rank takes part in every collective of the call, whatever happens to it
+        int local = FIR_OK;
+        char mine[512] = "";
+        if (hipMemcpyAsync(dc.dq, hq, qbytes, hipMemcpyHostToDevice, dc.stream) != hipSuccess) local = sh_fail(FIR_ERR_HIP, "query upload failed");
+        if (!local) local = device_keys(h, slot, dc.dq, qb, start, end, k, dc.stream);
+        if (local) { strncpy(mine, fir_last_error(), sizeof(mine) - 1); (void)hipGetLastError(); }
+        if ((r = exchange_keys(h, slot, qb, k, dc.stream, local))) return r;
+        if (class_out && (r = device_classes(h, slot, dc.keys, qb, dc.stream, local))) return r;
+        if (slot == 0) {
+            (void)hipMemcpyAsync(hk, dc.keys, kbytes, hipMemcpyDeviceToHost, dc.stream);
+            if (class_out) (void)hipMemcpyAsync(hc, dc.cls, cbytes, hipMemcpyDeviceToHost, dc.stream);
+        } else {
+            (void)hipMemcpyAsync(dc.h_status + 1, dc.keys + per, sizeof(int32_t), hipMemcpyDeviceToHost, dc.stream);   // low word of the status element
+        }
+        if ((r = wait_stream(dc, dc.stream, h->health))) return r;
+        if (local) { h->health.dead = true; h->health.dead_code = local; fir_set_last_error_(mine); return local; }
         return FIR_OK;
     });
-    if (rc) return rc;
+    if (rc) { h->health.dead = true; if (!h->health.dead_code.load()) h->health.dead_code = rc; return rc; }
+    int all = status_code(hk[per]);
+    if (!all && class_out && hc[qb] != 0x7FFFFFFF) all = hc[qb];
+    if (all) { h->health.dead = true; h->health.dead_code = all; return peer_failed(all); }
     if (class_out)
         for (int i = 0; i < qb; ++i) class_out[i] = hc[i] == 0x7FFFFFFF ? -1 : hc[i];     // ImageTesting.cpp:63: no row found -> -1
     if (idx || dist) return fir_keys_unpack(hk, qb * k, idx, dist);
@@ -365,20 +567,43 @@ int setup_devices(std::vector<DevCtx>& devs, const int32_t* devices, int ndev, i
         SH_HIP(hipSetDevice(dc.device));
         SH_HIP(hipStreamCreateWithFlags(&dc.stream, hipStreamNonBlocking));
     }
-    // RCCL writes its version banner to STDOUT when a process's first communicator comes up. The callers of this library print
-    // results there (the reference's harnesses, whose output must stay diffable): file descriptor 1 points at stderr while the
-    // communicator is created.
-    std::fflush(stdout);
-    const int saved_stdout = dup(1);
-    if (saved_stdout >= 0) (void)dup2(2, 1);
-    ncclResult_t nr = ncclGroupStart();
-    for (int s = 0; s < ndev && nr == ncclSuccess; ++s) {
-        (void)hipSetDevice(devs[(size_t)s].device);
-        nr = ncclCommInitRank(&devs[(size_t)s].comm, nranks, id, first_rank + s);
+    for (int s = 0; s < ndev; ++s) {
+        DevCtx& dc = devs[(size_t)s];
+        SH_HIP(hipSetDevice(dc.device));
+        SH_HIP(hipMalloc((void**)&dc.status, 4 * sizeof(int32_t)));
+        SH_HIP(hipMemset(dc.status, 0, 4 * sizeof(int32_t)));
+        SH_HIP(hipHostMalloc((void**)&dc.h_status, 8 * sizeof(int32_t), hipHostMallocPortable));
+        std::memset(dc.h_status, 0, 8 * sizeof(int32_t));
     }
-    if (nr == ncclSuccess) nr = ncclGroupEnd(); else (void)ncclGroupEnd();
-    std::fflush(stdout);
-    if (saved_stdout >= 0) { (void)dup2(saved_stdout, 1); (void)close(saved_stdout); }
+    // RCCL writes its version banner to STDOUT when a process's FIRST communicator comes up. The callers of this library print
+    // results there (the reference's harnesses, whose output must stay diffable): for that one creation -- serialised by a
+    // process-wide mutex -- file descriptor 1 points at stderr. Later communicators print nothing and touch no descriptor.
+    static std::mutex banner_mu;
+    static bool banner_done = false;
+    ncclResult_t nr;
+    {
+        std::unique_lock<std::mutex> lk(banner_mu);
+        const bool first = !banner_done;
+        int saved_stdout = -1;
+        if (first) {
+            std::fflush(stdout);
+            saved_stdout = dup(1);
+            if (saved_stdout >= 0) (void)dup2(2, 1);
+        } else {
+            lk.unlock();
+        }
+        nr = ncclGroupStart();
+        for (int s = 0; s < ndev && nr == ncclSuccess; ++s) {
+            (void)hipSetDevice(devs[(size_t)s].device);
+            nr = ncclCommInitRank(&devs[(size_t)s].comm, nranks, id, first_rank + s);
+        }
+        if (nr == ncclSuccess) nr = ncclGroupEnd(); else (void)ncclGroupEnd();
+        if (first) {
+            std::fflush(stdout);
+            if (saved_stdout >= 0) { (void)dup2(saved_stdout, 1); (void)close(saved_stdout); }
+            banner_done = true;
+        }
+    }
     if (nr != ncclSuccess) return sh_fail(FIR_ERR_COMM, "RCCL communicator of %d ranks: %s", nranks, ncclGetErrorString(nr));
     if (ndev > 1)
         for (int s = 0; s < ndev; ++s) {
@@ -390,7 +615,7 @@ int setup_devices(std::vector<DevCtx>& devs, const int32_t* devices, int ndev, i
     return FIR_OK;
 }
 
-void teardown_devices(std::vector<DevCtx>& devs) {
+void teardown_devices(std::vector<DevCtx>& devs, bool dead) {
     for (DevCtx& dc : devs) {
         if (dc.worker) {
             { std::lock_guard<std::mutex> lk(dc.worker->mu); dc.worker->quit = true; }
@@ -400,8 +625,10 @@ void teardown_devices(std::vector<DevCtx>& devs) {
             dc.worker = nullptr;
         }
         (void)hipSetDevice(dc.device);
-        if (dc.stream) (void)hipStreamSynchronize(dc.stream);
-        if (dc.comm) (void)ncclCommDestroy(dc.comm);
+        if (dc.stream && !dead) (void)hipStreamSynchronize(dc.stream);
+        if (dc.comm) { if (dead) (void)ncclCommAbort(dc.comm); else (void)ncclCommDestroy(dc.comm); }
+        (void)hipFree(dc.status);
+        if (dc.h_status) (void)hipHostFree(dc.h_status);
         (void)hipFree(dc.dq); (void)hipFree(dc.parts); (void)hipFree(dc.keys); (void)hipFree(dc.gath); (void)hipFree(dc.cls);
         for (hipEvent_t e : dc.evs) (void)hipEventDestroy(e);
         if (dc.stream) (void)hipStreamDestroy(dc.stream);
@@ -456,15 +683,23 @@ __global__ void __launch_bounds__(64) k_shard_argmax_first(const double* __restr
 }
 
 // merged[q][c][0..k) = the k smallest of parts[p][q][c][0..k), p < nparts (every part ascending, DBL_MAX = no such row)
-__global__ void __launch_bounds__(256) k_shard_merge_knn(const double* __restrict__ parts, int nparts, int64_t qc /* qb * C */, int k, double* __restrict__ merged) {
+// stride: doubles from one part to the next (qc * k, or qc * k + 1 with a status element behind every part: then
+// status_out <- the largest of those elements; 0 = every rank was fine)
+__global__ void __launch_bounds__(256) k_shard_merge_knn(const double* __restrict__ parts, int nparts, int64_t qc /* qb * C */, int k, double* __restrict__ merged,
+                                                          size_t stride, double* __restrict__ status_out) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (status_out && i == 0) {
+        double m = 0.0;
+        for (int p = 0; p < nparts; ++p) m = fmax(m, parts[(size_t)p * stride + (size_t)qc * k]);
+        *status_out = m;
+    }
     if (i >= qc) return;
     double best[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) best[j] = 1.7976931348623157e308;
     for (int p = 0; p < nparts; ++p)
         for (int j = 0; j < k; ++j) {
-            double v = parts[((size_t)p * qc + i) * k + j];
+            double v = parts[(size_t)p * stride + (size_t)i * k + j];
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
                 const bool sw = v < best[t];
@@ -508,7 +743,9 @@ struct fir_cls_sharded {
     std::vector<int32_t*> best;                            // per device
     std::vector<int32_t*> class_count;                     // per device: training rows per class over ALL shards and ranks
     std::vector<double*> knn;      size_t knn_cap = 0;     // per device: [shards here + nranks][qb][C][k] lists being merged
+    size_t best_cap = 0;                                   // per device: ints in best[]
     void* pin = nullptr;  size_t pin_cap = 0;
+    Health health;
 };
 
 extern "C" {
@@ -524,7 +761,7 @@ int fir_cls_sharded_destroy(fir_cls_sharded* h) {
         if (s < h->class_count.size()) (void)hipFree(h->class_count[s]);
         if (s < h->knn.size()) (void)hipFree(h->knn[s]);
     }
-    teardown_devices(h->devs);
+    teardown_devices(h->devs, h->health.dead);
     if (h->pin) (void)hipHostFree(h->pin);
     delete h;
     return FIR_OK;
@@ -543,6 +780,7 @@ int fir_cls_create_sharded(const double* train_rows, int64_t nt, int32_t d, cons
     fir_cls_sharded* h = new (std::nothrow) fir_cls_sharded();
     if (!h) return sh_fail(FIR_ERR_NOMEM, "host allocation failed");
     h->d = d; h->num_classes = num_classes; h->ndev = ndev; h->nranks = o.nprocs * ndev; h->nt_local = nt;
+    h->health.apply(o);
     h->devs.resize((size_t)ndev);
     h->acc.assign((size_t)ndev, nullptr);
     h->best.assign((size_t)ndev, nullptr);
@@ -574,8 +812,7 @@ int fir_cls_create_sharded(const double* train_rows, int64_t nt, int32_t d, cons
             if (slot == 0) SH_HIP(hipMemcpyAsync(cc, cnt.data(), (size_t)num_classes * sizeof(int32_t), hipMemcpyHostToDevice, dc.stream));
             else SH_HIP(hipMemsetAsync(cc, 0, (size_t)num_classes * sizeof(int32_t), dc.stream));      // this process's rows are counted once
             SH_NCCL(ncclAllReduce(cc, cc, (size_t)num_classes, ncclInt32, ncclSum, dc.comm, dc.stream));
-            SH_HIP(hipStreamSynchronize(dc.stream));
-            return FIR_OK;
+            return wait_stream(dc, dc.stream, h->health);
         });
     }
     if (rc) { fir_cls_sharded_destroy(h); return rc; }
@@ -583,10 +820,19 @@ int fir_cls_create_sharded(const double* train_rows, int64_t nt, int32_t d, cons
     return FIR_OK;
 }
 
+// a part of this device whose step is made to fail (test hook), by its index among all parts of the handle
+static bool cls_inject(const fir_cls_sharded* h, int part_index, int step) { return h->health.fail_step == step && h->health.fail_shard - 1 == part_index; }
+static bool cls_inject_dev(const fir_cls_sharded* h, int slot, int step) {
+    for (size_t i = 0; i < h->parts.size(); ++i)
+        if (h->parts[i].slot == slot && cls_inject(h, (int)i, step)) return true;
+    return false;
+}
+
 int fir_cls_sharded_knn_predict(fir_cls_sharded* h, const double* queries, int32_t qb, int32_t k, int32_t* best_class) {
     if (!h || !best_class || (qb > 0 && !queries)) return sh_fail(FIR_ERR_ARG, "NULL argument");
     if (qb < 0) return sh_fail(FIR_ERR_ARG, "qb < 0");
     if (k < 1 || k > 8) return sh_fail(FIR_ERR_ARG, "k=%d outside [1,8]", k);
+    if (h->health.dead) return dead_handle(h->health);
     if (qb == 0) return FIR_OK;
     int32_t maxb = 1 << 30;
     for (auto& p : h->parts)
@@ -606,62 +852,82 @@ int fir_cls_sharded_knn_predict(fir_cls_sharded* h, const double* queries, int32
         for (auto& p : h->parts) np += (p.slot == s && p.c) ? 1 : 0;
         max_parts = std::max(max_parts, np);
     }
-    const size_t need = per * (max_parts + 1 + (size_t)h->nranks + 1);
-    if (need > h->knn_cap || !h->best[0]) {
-        for (int s = 0; s < h->ndev; ++s) {
-            SH_HIP(hipSetDevice(h->devs[(size_t)s].device));
-            if (h->knn[(size_t)s]) SH_HIP(hipFree(h->knn[(size_t)s]));
-            h->knn[(size_t)s] = nullptr;
-            SH_HIP(hipMalloc((void**)&h->knn[(size_t)s], need * sizeof(double)));
-            if (!h->best[(size_t)s]) SH_HIP(hipMalloc((void**)&h->best[(size_t)s], (size_t)4096 * sizeof(int32_t)));
-        }
-        h->knn_cap = need;
-    }
-    if ((size_t)qb * sizeof(int32_t) > h->pin_cap) {
-        if (h->pin) SH_HIP(hipHostFree(h->pin));
-        h->pin = nullptr; h->pin_cap = 0;
-        SH_HIP(hipHostMalloc(&h->pin, (size_t)4096 * sizeof(int32_t), hipHostMallocPortable));
-        h->pin_cap = (size_t)4096 * sizeof(int32_t);
-    }
-    int32_t* hb = (int32_t*)h->pin;
+    // [max_parts] shard tables | their merge + status element | [nranks] gathered tables + status elements | the merge over the ranks + status
+    const size_t need = per * max_parts + (per + 1) + (per + 1) * (size_t)h->nranks + (per + 1);
+    const size_t pin_need = ((size_t)qb + 2) * sizeof(int32_t) + sizeof(double);
+    const bool grows = need > h->knn_cap || (size_t)qb > h->best_cap || pin_need > h->pin_cap;     // the same answer on every rank
+    const size_t new_best = std::max<size_t>(4096, (size_t)qb);
     const int64_t qc = (int64_t)qb * h->num_classes;
     int rc = run_all(h->devs, [&](int slot) -> int {
         DevCtx& dc = h->devs[(size_t)slot];
         SH_HIP(hipSetDevice(dc.device));
+        int r = grow_agreed(dc, dc.stream, h->health, grows, cls_inject_dev(h, slot, 2), [&]() -> int {
+            if (need > h->knn_cap) {
+                if (h->knn[(size_t)slot]) SH_HIP(hipFree(h->knn[(size_t)slot]));
+                h->knn[(size_t)slot] = nullptr;
+                SH_HIP(hipMalloc((void**)&h->knn[(size_t)slot], need * sizeof(double)));
+            }
+            if ((size_t)qb > h->best_cap) {
+                if (h->best[(size_t)slot]) SH_HIP(hipFree(h->best[(size_t)slot]));
+                h->best[(size_t)slot] = nullptr;
+                SH_HIP(hipMalloc((void**)&h->best[(size_t)slot], new_best * sizeof(int32_t)));
+            }
+            if (slot == 0 && pin_need > h->pin_cap) {
+                if (h->pin) SH_HIP(hipHostFree(h->pin));
+                h->pin = nullptr; h->pin_cap = 0;
+                SH_HIP(hipHostMalloc(&h->pin, std::max<size_t>(pin_need, 4096 * sizeof(int32_t) + 64), hipHostMallocPortable));
+                h->pin_cap = std::max<size_t>(pin_need, 4096 * sizeof(int32_t) + 64);
+            }
+            return FIR_OK;
+        });
+        if (r) return r;
         double* parts = h->knn[(size_t)slot];                                 // [max_parts] tables of the shards held here
-        double* mine = parts + per * max_parts;                               // their merge
-        double* gath = mine + per;                                            // [nranks] tables
-        double* all = gath + per * (size_t)h->nranks;                         // the merge over the ranks
+        double* mine = parts + per * max_parts;                               // their merge (+ status element)
+        double* gath = mine + per + 1;                                        // [nranks] tables (+ status elements)
+        double* all = gath + (per + 1) * (size_t)h->nranks;                   // the merge over the ranks (+ the worst status)
         int np = 0;
-        for (auto& p : h->parts) {
-            if (p.slot != slot || !p.c) continue;
+        int local = FIR_OK;
+        char mine_err[512] = "";
+        for (size_t pi = 0; pi < h->parts.size() && !local; ++pi) {
+            auto& p = h->parts[pi];
+            if (p.slot != slot) continue;
+            if (cls_inject(h, (int)pi, 1)) { local = sh_fail(FIR_ERR_NOMEM, "injected scan failure on training-set shard %d (fir_shard_opts.fail_step = 1)", (int)pi); break; }
+            if (!p.c) continue;
             double* dl = nullptr;
             void* st = nullptr;
-            const int r = fir_cls_knn_nearest_dev_(p.c, queries, qb, k, &dl, &st, nullptr);
-            if (r) return r;
-            SH_HIP(hipStreamSynchronize((hipStream_t)st));
-            SH_HIP(hipMemcpyAsync(parts + per * (size_t)np, dl, per * sizeof(double), hipMemcpyDeviceToDevice, dc.stream));
+            local = fir_cls_knn_nearest_dev_(p.c, queries, qb, k, &dl, &st, nullptr);
+            if (local) break;
+            if (hipStreamSynchronize((hipStream_t)st) != hipSuccess ||
+                hipMemcpyAsync(parts + per * (size_t)np, dl, per * sizeof(double), hipMemcpyDeviceToDevice, dc.stream) != hipSuccess)
+                local = sh_fail(FIR_ERR_HIP, "copying a shard's k-nearest table failed");
             ++np;
         }
-        hipLaunchKernelGGL(k_shard_merge_knn, dim3((unsigned)((qc + 255) / 256)), dim3(256), 0, dc.stream, parts, np, qc, k, mine);   // np == 0: all DBL_MAX
-        SH_HIP(hipGetLastError());
-        SH_NCCL(ncclAllGather(mine, gath, per, ncclDouble, dc.comm, dc.stream));
-        hipLaunchKernelGGL(k_shard_merge_knn, dim3((unsigned)((qc + 255) / 256)), dim3(256), 0, dc.stream, gath, h->nranks, qc, k, all);
+        if (local) { strncpy(mine_err, fir_last_error(), sizeof(mine_err) - 1); (void)hipGetLastError(); np = 0; }
+        hipLaunchKernelGGL(k_shard_merge_knn, dim3((unsigned)((qc + 255) / 256)), dim3(256), 0, dc.stream, parts, np, qc, k, mine, per, (double*)nullptr);   // np == 0: all DBL_MAX
+        hipLaunchKernelGGL(k_shard_set_f64, dim3(1), dim3(1), 0, dc.stream, mine + per, local ? (double)(-local) : 0.0);
+        const ncclResult_t nr = ncclAllGather(mine, gath, per + 1, ncclDouble, dc.comm, dc.stream);
+        if (nr != ncclSuccess) return comm_dead(dc, h->health, FIR_ERR_COMM, ncclGetErrorString(nr));
+        hipLaunchKernelGGL(k_shard_merge_knn, dim3((unsigned)((qc + 255) / 256)), dim3(256), 0, dc.stream, gath, h->nranks, qc, k, all, per + 1, all + per);
         hipLaunchKernelGGL(k_shard_knn_vote, dim3((qb + 63) / 64), dim3(64), 0, dc.stream, all, qb, h->num_classes, k, h->class_count[(size_t)slot],
                            h->best[(size_t)slot]);
-        SH_HIP(hipGetLastError());
-        if (slot == 0) SH_HIP(hipMemcpyAsync(hb, h->best[0], (size_t)qb * sizeof(int32_t), hipMemcpyDeviceToHost, dc.stream));
-        SH_HIP(hipStreamSynchronize(dc.stream));
+        double* hst = slot == 0 ? (double*)((char*)h->pin + (((size_t)qb * sizeof(int32_t) + 7) & ~(size_t)7)) : (double*)(dc.h_status + 4);
+        (void)hipMemcpyAsync(hst, all + per, sizeof(double), hipMemcpyDeviceToHost, dc.stream);
+        if (slot == 0) (void)hipMemcpyAsync(h->pin, h->best[0], (size_t)qb * sizeof(int32_t), hipMemcpyDeviceToHost, dc.stream);
+        if ((r = wait_stream(dc, dc.stream, h->health))) return r;
+        if (local) { h->health.dead = true; h->health.dead_code = local; fir_set_last_error_(mine_err); return local; }
+        if (*hst != 0.0) { h->health.dead = true; h->health.dead_code = -(int)*hst; return peer_failed(-(int)*hst); }
         return FIR_OK;
     });
-    if (rc) return rc;
-    std::memcpy(best_class, hb, (size_t)qb * sizeof(int32_t));
+    if (grows && !h->health.dead) { h->knn_cap = std::max(h->knn_cap, need); h->best_cap = std::max(h->best_cap, new_best); }
+    if (rc) { h->health.dead = true; if (!h->health.dead_code.load()) h->health.dead_code = rc; return rc; }
+    std::memcpy(best_class, h->pin, (size_t)qb * sizeof(int32_t));
     return FIR_OK;
 }
 
 int fir_cls_sharded_pnn_predict(fir_cls_sharded* h, const double* queries, int32_t qb, double var, double* scores, int32_t* best_class) {
     if (!h || (qb > 0 && !queries)) return sh_fail(FIR_ERR_ARG, "NULL argument");
     if (qb < 0) return sh_fail(FIR_ERR_ARG, "qb < 0");
+    if (h->health.dead) return dead_handle(h->health);
     if (qb == 0) return FIR_OK;
     // internal batches: what every shard's distance table allows (fir_cls_pnn_scores_dev_)
     int32_t maxb = 1 << 30;
@@ -677,55 +943,71 @@ int fir_cls_sharded_pnn_predict(fir_cls_sharded* h, const double* queries, int32
         return FIR_OK;
     }
     const size_t nsc = (size_t)qb * h->num_classes;
-    if (nsc > h->acc_cap) {
-        for (int s = 0; s < h->ndev; ++s) {
-            SH_HIP(hipSetDevice(h->devs[(size_t)s].device));
-            if (h->acc[(size_t)s]) SH_HIP(hipFree(h->acc[(size_t)s]));
-            if (h->best[(size_t)s]) SH_HIP(hipFree(h->best[(size_t)s]));
-            h->acc[(size_t)s] = nullptr; h->best[(size_t)s] = nullptr;
-            SH_HIP(hipMalloc((void**)&h->acc[(size_t)s], nsc * sizeof(double)));
-            SH_HIP(hipMalloc((void**)&h->best[(size_t)s], (size_t)maxb * sizeof(int32_t)));
-        }
-        h->acc_cap = nsc;
-    }
-    const size_t need = nsc * sizeof(double) + (size_t)qb * sizeof(int32_t);
-    if (need > h->pin_cap) {
-        if (h->pin) SH_HIP(hipHostFree(h->pin));
-        h->pin = nullptr; h->pin_cap = 0;
-        SH_HIP(hipHostMalloc(&h->pin, need, hipHostMallocPortable));
-        h->pin_cap = need;
-    }
-    double* hs = (double*)h->pin;
-    int32_t* hb = (int32_t*)((char*)h->pin + nsc * sizeof(double));
+    const size_t pin_need = (nsc + 1) * sizeof(double) + (size_t)qb * sizeof(int32_t);
+    const bool grows = nsc + 1 > h->acc_cap || (size_t)qb > h->best_cap || pin_need > h->pin_cap;      // the same answer on every rank
+    const size_t new_best = std::max<size_t>(4096, (size_t)qb);
     int rc = run_all(h->devs, [&](int slot) -> int {
         DevCtx& dc = h->devs[(size_t)slot];
         SH_HIP(hipSetDevice(dc.device));
+        int r = grow_agreed(dc, dc.stream, h->health, grows, cls_inject_dev(h, slot, 2), [&]() -> int {
+            if (nsc + 1 > h->acc_cap) {
+                if (h->acc[(size_t)slot]) SH_HIP(hipFree(h->acc[(size_t)slot]));
+                h->acc[(size_t)slot] = nullptr;
+                SH_HIP(hipMalloc((void**)&h->acc[(size_t)slot], (nsc + 1) * sizeof(double)));
+            }
+            if ((size_t)qb > h->best_cap) {
+                if (h->best[(size_t)slot]) SH_HIP(hipFree(h->best[(size_t)slot]));
+                h->best[(size_t)slot] = nullptr;
+                SH_HIP(hipMalloc((void**)&h->best[(size_t)slot], new_best * sizeof(int32_t)));
+            }
+            if (slot == 0 && pin_need > h->pin_cap) {
+                if (h->pin) SH_HIP(hipHostFree(h->pin));
+                h->pin = nullptr; h->pin_cap = 0;
+                SH_HIP(hipHostMalloc(&h->pin, pin_need, hipHostMallocPortable));
+                h->pin_cap = pin_need;
+            }
+            return FIR_OK;
+        });
+        if (r) return r;
         double* acc = h->acc[(size_t)slot];
         int first = 1;
-        for (auto& p : h->parts) {
-            if (p.slot != slot || !p.c) continue;
+        int local = FIR_OK;
+        char mine_err[512] = "";
+        for (size_t pi = 0; pi < h->parts.size() && !local; ++pi) {
+            auto& p = h->parts[pi];
+            if (p.slot != slot) continue;
+            if (cls_inject(h, (int)pi, 1)) { local = sh_fail(FIR_ERR_NOMEM, "injected scan failure on training-set shard %d (fir_shard_opts.fail_step = 1)", (int)pi); break; }
+            if (!p.c) continue;
             double* ds = nullptr;
             void* st = nullptr;
-            const int r = fir_cls_pnn_scores_dev_(p.c, queries, qb, var, &ds, &st, nullptr);
-            if (r) return r;
-            SH_HIP(hipStreamSynchronize((hipStream_t)st));          // the shard's own stream: its scores are complete
+            local = fir_cls_pnn_scores_dev_(p.c, queries, qb, var, &ds, &st, nullptr);
+            if (local) break;
+            if (hipStreamSynchronize((hipStream_t)st) != hipSuccess) { local = sh_fail(FIR_ERR_HIP, "a shard's class scores did not complete"); break; }   // the shard's own stream
             hipLaunchKernelGGL(k_shard_add_f64, dim3((unsigned)((nsc + 255) / 256)), dim3(256), 0, dc.stream, acc, ds, (int64_t)nsc, first);
             first = 0;
         }
-        if (first) SH_HIP(hipMemsetAsync(acc, 0, nsc * sizeof(double), dc.stream));     // a device without rows adds nothing
-        SH_HIP(hipGetLastError());
-        SH_NCCL(ncclAllReduce(acc, acc, nsc, ncclDouble, ncclSum, dc.comm, dc.stream));
+        if (local) { strncpy(mine_err, fir_last_error(), sizeof(mine_err) - 1); (void)hipGetLastError(); }
+        if (first || local) (void)hipMemsetAsync(acc, 0, nsc * sizeof(double), dc.stream);     // a device without rows (or whose step failed) adds nothing
+        hipLaunchKernelGGL(k_shard_set_f64, dim3(1), dim3(1), 0, dc.stream, acc + nsc, local ? 1.0 : 0.0);   // the status element: the sum counts the ranks that failed
+        const ncclResult_t nr = ncclAllReduce(acc, acc, nsc + 1, ncclDouble, ncclSum, dc.comm, dc.stream);
+        if (nr != ncclSuccess) return comm_dead(dc, h->health, FIR_ERR_COMM, ncclGetErrorString(nr));
         hipLaunchKernelGGL(k_shard_argmax_first, dim3(qb), dim3(64), 0, dc.stream, acc, h->num_classes, h->best[(size_t)slot]);
+        double* hst = slot == 0 ? (double*)h->pin + nsc : (double*)(dc.h_status + 4);
         if (slot == 0) {
-            if (scores) SH_HIP(hipMemcpyAsync(hs, acc, nsc * sizeof(double), hipMemcpyDeviceToHost, dc.stream));
-            SH_HIP(hipMemcpyAsync(hb, h->best[0], (size_t)qb * sizeof(int32_t), hipMemcpyDeviceToHost, dc.stream));
+            (void)hipMemcpyAsync(h->pin, acc, (nsc + 1) * sizeof(double), hipMemcpyDeviceToHost, dc.stream);
+            (void)hipMemcpyAsync((char*)h->pin + (nsc + 1) * sizeof(double), h->best[0], (size_t)qb * sizeof(int32_t), hipMemcpyDeviceToHost, dc.stream);
+        } else {
+            (void)hipMemcpyAsync(hst, acc + nsc, sizeof(double), hipMemcpyDeviceToHost, dc.stream);
         }
-        SH_HIP(hipStreamSynchronize(dc.stream));
+        if ((r = wait_stream(dc, dc.stream, h->health))) return r;
+        if (local) { h->health.dead = true; h->health.dead_code = local; fir_set_last_error_(mine_err); return local; }
+        if (*hst != 0.0) { h->health.dead = true; h->health.dead_code = FIR_ERR_COMM; return peer_failed(FIR_ERR_COMM); }
         return FIR_OK;
     });
-    if (rc) return rc;
-    if (scores) std::memcpy(scores, hs, nsc * sizeof(double));
-    if (best_class) std::memcpy(best_class, hb, (size_t)qb * sizeof(int32_t));
+    if (grows && !h->health.dead) { h->acc_cap = std::max(h->acc_cap, nsc + 1); h->best_cap = std::max(h->best_cap, new_best); }
+    if (rc) { h->health.dead = true; if (!h->health.dead_code.load()) h->health.dead_code = rc; return rc; }
+    if (scores) std::memcpy(scores, h->pin, nsc * sizeof(double));
+    if (best_class) std::memcpy(best_class, (char*)h->pin + (nsc + 1) * sizeof(double), (size_t)qb * sizeof(int32_t));
     return FIR_OK;
 }
 
@@ -743,7 +1025,7 @@ int fir_sharded_destroy(fir_sharded* h) {
     if (!h) return FIR_OK;
     for (Shard& s : h->shards)
         if (s.g) fir_gallery_destroy(s.g);
-    teardown_devices(h->devs);
+    teardown_devices(h->devs, h->health.dead);
     if (h->pin) (void)hipHostFree(h->pin);
     delete h;
     return FIR_OK;
@@ -779,6 +1061,8 @@ int fir_gallery_create_sharded_ex(const float* rows, int64_t n, int32_t d, const
     h->d = d; h->metric = metric; h->n_local = n; h->first_row = o.first_global_row;
     h->ndev = ndev; h->spd = spd; h->nranks = nprocs * ndev; h->rank0 = proc * ndev;
     h->has_labels = class_no != nullptr;
+    h->health.apply(o);
+    if (h->health.fail_shard < 0 || h->health.fail_shard > ndev * spd) { delete h; return sh_fail(FIR_ERR_ARG, "fail_shard = %d of %d shards", o.fail_shard, ndev * spd); }
     h->devs.resize((size_t)ndev);
     int rc = FIR_OK;
     auto bail = [&](int code) { fir_sharded_destroy(h); return code; };
@@ -866,23 +1150,38 @@ int fir_sharded_search_top1_keys_dev(fir_sharded* h, const float* d_queries, int
     if (!h || !d_keys || (qb > 0 && !d_queries)) return sh_fail(FIR_ERR_ARG, "NULL argument");
     if (h->ndev != 1) return sh_fail(FIR_ERR_STATE, "device-pointer calls need a one-device handle (one process per GPU); this one lists %d", h->ndev);
     if (qb < 0) return sh_fail(FIR_ERR_ARG, "qb < 0");
+    if (h->health.dead) return dead_handle(h->health);
     if (qb == 0) return FIR_OK;
     int rc = check_range(h, start_pos, end_pos);
     if (rc) return rc;
     DevCtx& dc = h->devs[0];
     SH_HIP(hipSetDevice(dc.device));
     hipStream_t st = stream ? (hipStream_t)stream : dc.stream;
-    if ((rc = device_keys(h, 0, d_queries, qb, start_pos, end_pos, 1, st))) return rc;
-    if ((rc = exchange_keys(h, 0, dc.keys, qb, 1, st))) return rc;
-    SH_HIP(hipMemcpyAsync(d_keys, dc.keys, (size_t)qb * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
+    const CallBuffers nb = call_buffers(h, dc, qb, 1, false, false);
+    if ((rc = grow_agreed(dc, st, h->health, call_grows(dc, nb), inject_here(h, dc, 2), [&]() -> int { return call_alloc(dc, nb); }))) return rc;
+    // every rank enters the exchange; one whose scans failed sends FIR_KEY_NONE keys and a poisoned status element, returns its
+    // error here, and the others find it in fir_sharded_sync (the call is asynchronous: nobody waits for the exchange here)
+    int local = device_keys(h, 0, d_queries, qb, start_pos, end_pos, 1, st);
+    char mine[512] = "";
+    if (local) { strncpy(mine, fir_last_error(), sizeof(mine) - 1); (void)hipGetLastError(); }
+    if ((rc = exchange_keys(h, 0, qb, 1, st, local))) return rc;
+    hipLaunchKernelGGL(k_shard_note_status, dim3(1), dim3(1), 0, st, dc.keys + qb, dc.status + 1);
+    (void)hipMemcpyAsync(d_keys, dc.keys, (size_t)qb * sizeof(uint64_t), hipMemcpyDeviceToDevice, st);
+    if (local) { h->health.dead = true; h->health.dead_code = local; fir_set_last_error_(mine); return local; }
+    SH_HIP(hipGetLastError());
     return FIR_OK;
 }
 
 int fir_sharded_sync(fir_sharded* h) {
     if (!h) return sh_fail(FIR_ERR_ARG, "handle is NULL");
+    if (h->health.dead) return dead_handle(h->health);
     for (DevCtx& dc : h->devs) {
         SH_HIP(hipSetDevice(dc.device));
-        SH_HIP(hipStreamSynchronize(dc.stream));
+        int rc = wait_stream(dc, dc.stream, h->health);
+        if (rc) return rc;
+        // the asynchronous calls' record: the worst status any exchange since the last sync came back with
+        SH_HIP(hipMemcpy(dc.h_status + 2, dc.status + 1, sizeof(int32_t), hipMemcpyDeviceToHost));
+        if (dc.h_status[2] < 0) { h->health.dead = true; h->health.dead_code = dc.h_status[2]; return peer_failed(dc.h_status[2]); }
     }
     return FIR_OK;
 }

@@ -206,4 +206,10 @@ private:
     fir_dem* dem;
 };
 
+// The names BASELINE.json's north_star uses for the two abstract interfaces: the ImageTesting-side `Classifier`
+// (ImageTesting.cpp:35-49: train(vector<ImageInfo>*), recognize(ImageInfo&) -> class) and the ann-side
+// `ClassificationMethod` (ann.h:9-39: recognize(ImageInfo&) -> row index, testSetRecognition, getThreshold).
+using ImageClassifier = Classifier;
+using ImageRecognizer = ClassificationMethod;
+
 #endif  // FIR_CLASSIFIERS_H

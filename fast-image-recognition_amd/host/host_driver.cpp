@@ -53,7 +53,7 @@ int main(int argc, char** argv) {
         ConventionalTWDClassifier diff(C, ConventionalTWDClassifier::TWD_Type::DistDiff, 0.003);
         ConventionalTWDClassifier ratio(C, ConventionalTWDClassifier::TWD_Type::DistRatio, 0.7);
         ProposedTWDClassifier p32(C, 32, 0.7), p64(C, 64, 0.7);
-        Classifier* twd[5] = {&post, &diff, &ratio, &p32, &p64};
+        ImageClassifier* twd[5] = {&post, &diff, &ratio, &p32, &p64};   // (north_star's name for ImageTesting.cpp:35-49 `Classifier`)
         const char* keys[5] = {"twd_post", "twd_diff", "twd_ratio", "twd_p32", "twd_p64"};
         for (int i = 0; i < 5; ++i) {
             twd[i]->train(&dbImages);

@@ -298,7 +298,19 @@ typedef struct fir_shard_opts {
     int32_t rows_on_device;     /* 1: rows / class_no are device pointers on devices[0] (one-entry device list only)     */
     int32_t reserved;
     int64_t total_rows;         /* fir_cls_create_sharded with comm_id: training rows over ALL processes (PNN divisor); 0 = n */
+    int32_t timeout_ms;         /* bound of every wait behind a collective (0: 120 000). When it passes, or RCCL reports an
+                                 * asynchronous error, the communicator is aborted and the call returns FIR_ERR_COMM          */
+    int32_t fail_shard;         /* test hook: 1-based index of the local shard whose step fails with FIR_ERR_NOMEM (0: none)  */
+    int32_t fail_step;          /* ... 1: its scan, after the buffers were agreed on; 2: the buffer growth of its device      */
+    int32_t reserved2;
 } fir_shard_opts;
+/* Failure semantics of every sharded handle (the reference's convention is "-1, never block", ann.cpp:113-126): a call in which
+ * ANY rank fails -- an allocation, a scan, an RCCL call, a peer that never shows up within timeout_ms -- returns a negative
+ * FIR_ERR_* on EVERY rank and never blocks for longer than the time-out: buffers grow in a step the ranks agree on (one-int
+ * ncclAllReduce), a rank whose scans fail still enters the exchange with neutral keys and a poisoned status element, waits are
+ * bounded and poll ncclCommGetAsyncError, a broken communicator is aborted. The handle is then closed: further calls return
+ * FIR_ERR_STATE at once; fir_sharded_destroy / fir_cls_sharded_destroy free it and a fresh handle works. For the asynchronous
+ * device-pointer call the failing rank gets its error from the call itself, the others from fir_sharded_sync. */
 int fir_comm_unique_id(void* id_out /* [FIR_COMM_ID_BYTES] */);
 /* Single process, all rows, one shard per listed device. devices[ndev]: HIP device indices, no repeats. */
 int fir_gallery_create_sharded(const float* rows, int64_t n, int32_t d, const int32_t* class_no, int32_t metric,

@@ -128,3 +128,58 @@ def test_argument_errors(fir):
             s.search_top1(rows[:3], 4, 2)
         with pytest.raises(fir.FirError):
             s.search_topk(rows[:3], 9)
+
+
+@pytest.mark.parametrize("step", [1, 2])
+def test_a_failing_shard_fails_the_call_on_every_entry_point_and_never_blocks(fir, oracle, step):
+    """Failure semantics (include/fir_amd.h, 'Failure semantics of every sharded handle'; the reference's "-1, never block",
+    ann.cpp:113-126): shard 3 of 8 is made to fail -- its scan after the buffers were agreed on (step 1: the rank still enters
+    the exchange, with FIR_KEY_NONE keys and a poisoned status element) or its device's buffer growth (step 2: the one-int
+    status all-reduce of the agreed growth step). The call returns the shard's error code instead of hanging, the handle is
+    closed (FIR_ERR_STATE at once), destroying it works, and a fresh handle answers like the unsharded one."""
+    n, d = 4099, 128
+    rows = synth.make_gallery(57, n, d, L2)
+    labels = synth.make_labels(n, 17)
+    q, _ = synth.make_queries(57, rows, 11, L2)
+    calls = [lambda s: s.search_top1(q), lambda s: s.search_topk(q, 5), lambda s: s.classify_top1(q)]
+    for call in calls:
+        with fir.ShardedGallery(rows, labels, fir.METRIC_L2, devices=[0], shards_per_device=8, fail_shard=4, fail_step=step, timeout_ms=20000) as s:
+            with pytest.raises(fir.FirError) as e:
+                call(s)
+            assert e.value.code == -3, (e.value.code, str(e.value))            # FIR_ERR_NOMEM, the injected error
+            for again in calls:                                               # closed: no collective is attempted any more
+                with pytest.raises(fir.FirError) as e2:
+                    again(s)
+                assert e2.value.code == -5                                    # FIR_ERR_STATE
+    with fir.ShardedGallery(rows, labels, fir.METRIC_L2, devices=[0], shards_per_device=8) as s:     # a fresh handle works
+        idx, dist = s.search_top1(q)
+        cls, _, _ = s.classify_top1(q)
+    eidx, edist = oracle.top1_batch(rows, q, 0, d, L2)
+    assert np.array_equal(idx, eidx) and np.array_equal(bits(dist), bits(edist))
+    assert np.array_equal(cls, np.where(eidx >= 0, labels[np.maximum(eidx, 0)], -1))
+
+
+def test_a_failing_shard_in_the_asynchronous_device_pointer_call(fir):
+    """fir_sharded_search_top1_keys_dev returns before the exchange has run: the failing rank gets its error from the call, the
+    exchange still happens (nobody is left waiting in it), and fir_sharded_sync reports the closed handle."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda", 0)
+    n, d, qb = 5000, 64, 16
+    rows = synth.make_gallery(58, n, d, L2)
+    q, _ = synth.make_queries(58, rows, qb, L2)
+    rt, qt = torch.from_numpy(rows).to(dev), torch.from_numpy(q).to(dev)
+    keys = torch.empty(qb, device=dev, dtype=torch.int64)
+    with fir.ShardedGallery(dev_ptr=rt.data_ptr(), n=n, d=d, metric=fir.METRIC_L2, devices=[0], shards_per_device=4, fail_shard=2, fail_step=1) as s:
+        with pytest.raises(fir.FirError) as e:
+            s.search_top1_keys_dev(qt.data_ptr(), qb, keys.data_ptr())
+        assert e.value.code == -3
+        with pytest.raises(fir.FirError) as e2:
+            s.sync()
+        assert e2.value.code == -5
+    with fir.ShardedGallery(dev_ptr=rt.data_ptr(), n=n, d=d, metric=fir.METRIC_L2, devices=[0], shards_per_device=4) as s:
+        s.search_top1_keys_dev(qt.data_ptr(), qb, keys.data_ptr())
+        s.sync()
+    with fir.Gallery(rows, None, fir.METRIC_L2, 0) as g:
+        idx0, _ = g.search_top1(q)
+    idx, _ = fir.keys_unpack(keys.cpu().numpy().view(np.uint64))
+    assert np.array_equal(idx, idx0)

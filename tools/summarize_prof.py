@@ -20,7 +20,7 @@ def main():
                                       "grid": r["Grid_Size"], "wg": r["Workgroup_Size"]}
         out = []
         for (kn, cn), v in sorted(agg.items()):
-            if not kn.startswith(("void fir::", "fir::", "(anonymous namespace)::k_")):
+            if not kn.startswith(("void fir::", "fir::", "(anonymous namespace)::k_", "void (anonymous namespace)::k_")):
                 continue
             e = {"kernel": kn, "counter": cn, "dispatches": len(v), "avg": sum(v) / len(v), "min": min(v), "max": max(v), **meta[kn]}
             if cn == "FETCH_SIZE" and "k_scan" in kn:
