@@ -87,7 +87,7 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rows", type=int, default=1_000_000)
     ap.add_argument("--dim", type=int, default=512)
-    ap.add_argument("--batch", type=int, default=32768, help="query vectors per step of the headline loop")
+    ap.add_argument("--batch", type=int, default=131072, help="query vectors per step of the headline loop (131 072: the driver's 20 steps then time > 2 s of GPU work)")
     ap.add_argument("--scan-batch", type=int, default=256, help="query vectors per step of the exact-scan loop (the HBM roofline)")
     ap.add_argument("--qpp", type=int, default=0, help="queries per gallery pass of the exact scan (0 = library default)")
     ap.add_argument("--waves", type=int, default=0)
@@ -95,9 +95,12 @@ def parse_args(argv=None):
     ap.add_argument("--no-extras", "--no-mfma", dest="no_extras", action="store_true",
                     help="only the two timed loops: skip the config-2/3 scans, the K3 classifiers and config 4")
     ap.add_argument("--config4-rows", type=int, default=10_000_000, help="rows of the config-4 gallery (0 = skip)")
+    ap.add_argument("--config5-dim", type=int, default=1280, help="row length of the config-5 gallery (BASELINE configs[4]; 0 = skip)")
+    ap.add_argument("--extra-batch", type=int, default=32768, help="query vectors per call of the config-4 / config-5 / other-scan blocks")
     ap.add_argument("--no-verify", action="store_true", help="skip the exact-scan verification of the WHOLE headline batch outside the timed regions (profiling runs: "
                                                               "the kernel table then holds the two timed loops only); the first scan-batch queries are still compared")
     ap.add_argument("--pmc-child", action="store_true", help="internal: this process IS the counter pass (no nested pass, short run)")
+    ap.add_argument("--pmc-config2", action="store_true", help="internal (counter pass): run the 100k x 512 cold / warm sequence first")
     ap.add_argument("--no-pmc", action="store_true", help="do not start the rocprofv3 counter pass; report the recorded one")
     ap.add_argument("--force-dist", action="store_true", help="one rank, but through the sharded handle and its RCCL communicator")
     ap.add_argument("--shards-per-device", type=int, default=1, help="logical shards per rank (exercises the split on few GPUs)")
@@ -305,6 +308,9 @@ def main():
     d = args.dim
     work_stream = torch.cuda.Stream(device=dev)   # all timed work runs on one explicit (non-default) stream
 
+    if args.pmc_child and args.pmc_config2:
+        pmc_config2_sequence(fir, dev, work_stream, d)
+
     def fence():
         torch.cuda.synchronize()
         if dist is not None:
@@ -352,6 +358,7 @@ def main():
             p.profile_enable(True)
         if m.sh is not None:
             m.sh.profile_enable(True)
+        fb0 = sum(p.mfma_stats()["fallback_queries"] for p in m.parts)
         t0 = time.perf_counter()
         for _ in range(steps):
             m.step(q, qb, keys)
@@ -364,6 +371,7 @@ def main():
         if m.sh is not None:
             m.sh.profile_enable(False)
         disp = m.g.last_dispatch()
+        disp["fallback_queries"] = sum(p.mfma_stats()["fallback_queries"] for p in m.parts) - fb0     # queries of the timed steps the certificate sent to the exact scan
         return elapsed, kernel_ms, exch_ms, disp
 
     n, qb = args.rows, args.batch
@@ -379,6 +387,7 @@ def main():
     elapsed, k_ms, x_ms, disp = timed_loop(m, q, qb, keys, args.steps, args.warmup)
     keys_default = keys.clone()
     head = {"elapsed": elapsed, "kernel_ms": k_ms, "exch_ms": x_ms, "disp": disp}
+    mem_report = m.g.memory_bytes()            # fir_gallery_memory_bytes: the tiled rows and what the default dispatch added to them
 
     # ---- the exact streaming scan, matrix-core path off: the metric's HBM clause ----
     sqb = min(args.scan_batch, qb)
@@ -408,7 +417,8 @@ def main():
     cfg2 = None
     k3 = None
     if world == 1 and not args.no_extras and not args.pmc_child:
-        also = other_scans(fir, m.g, q, keys_default, dev, work_stream, n, d)
+        xb = min(args.extra_batch, qb)
+        also = other_scans(fir, m.g, q[:xb], keys_default[:xb], dev, work_stream, n, d)
         k3 = k3_classifiers(fir, dev, args)
         if small_src is not None:
             cfg2 = config2(fir, small_src, q, dev, work_stream, d)
@@ -426,6 +436,11 @@ def main():
     cfg4 = None
     if args.config4_rows > 0 and not args.no_extras and not args.pmc_child:
         cfg4 = config4(args, build, make_queries, timed_loop, fir, dev, world)
+
+    # ---- BASELINE config 5: 1M x 1280 (EfficientNet-B7 width), matrix-core nomination + exact re-rank vs the memory-bound scan ----
+    cfg5 = None
+    if world == 1 and args.config5_dim > 0 and not args.no_extras and not args.pmc_child:
+        cfg5 = config5(args, fir, dev, work_stream)
 
     out = None
     if rank == 0:
@@ -476,6 +491,8 @@ def main():
                 "path_note": "fp16 MFMA (one term, power-of-two-scaled operands, 128 queries per gallery read) nominates rows, the reference's f32 arithmetic re-ranks every row "
                              "inside the rounding window, a rounding-error certificate proves the rest cannot win, uncertified queries go through the exact scan" if hd["path"] == "mfma" else "exact streaming scan",
                 "identical_keys_to_exact_scan": identical,
+                "fallback_queries_in_timed_steps": hd.get("fallback_queries"),
+                "hbm_bytes_held": mem_report,
                 "planted_queries_found": planted_ok,
                 "row_sharding": f"{world} rank(s) x {args.shards_per_device} shard(s), {m_n} rows on this rank",
                 "key_exchange": ("RCCL ncclAllReduce(ncclMin, ncclUint64) issued by libfir_amd.so (fir_sharded_search_top1_keys_dev)" if m.in_library_rccl
@@ -487,12 +504,13 @@ def main():
                                "exchange_us_per_step": float(np.mean(s_x_ms) * 1e3) if len(s_x_ms) else None},
                 "kl_note": "KL top-1 identity is tolerance-graded (device v_log_f32 vs glibc logf: distances within 1e-5 relative, same winner unless the runner-up is closer than that); L2 and chi-square are bit-exact",
                 "other_scans_same_gallery": also,
-                "config2_100kx512": cfg2,
+                "config2_100kx512": dict(cfg2, dram_bytes_cold_vs_warm=traffic.get("config2")) if cfg2 else None,
                 "k3_float64_classifiers": k3,
             },
             "roofline": roofline,
             "roofline_mfma": roofline_mfma,
             "config4": cfg4,
+            "config5": cfg5,
         }
         if also:
             out["roofline_chi2"] = also.pop("roofline_chi2", None)
@@ -617,6 +635,32 @@ def config2(fir, src, q, dev, ws, d):
             out[f"batch_{qb}"] = {"exact_scan_queries_per_s": r_scan, "exact_scan_kernel": dsp["kernel"], "exact_scan_queries_per_pass": dsp["queries_per_pass"],
                                   "default_dispatch_queries_per_s": r_def, "default_dispatch_path": dd["path"], "default_dispatch_kernel": dd["kernel"],
                                   "identical_keys": bool(torch.equal(ks, k))}
+        # one 16-query pass of the exact scan from cold caches (right behind a 512 MiB write elsewhere) and warm, by the library's HIP events:
+        # the 204.8 MB gallery fits the 256 MiB Infinity Cache, a warm pass is served from it
+        flush = torch.empty(128 * 1024 * 1024, device=dev, dtype=torch.float32)
+        k = torch.empty(16, device=dev, dtype=torch.int64)
+        g.set_large_batch_mfma(0)
+        g.search_top1_keys_dev(q.data_ptr(), 16, k.data_ptr(), stream=stream)
+        g.profile_enable(True)
+        cold, warm = [], []
+        for rep in range(3):
+            flush.fill_(float(rep))
+            torch.cuda.synchronize()
+            g.profile_read()
+            g.search_top1_keys_dev(q.data_ptr(), 16, k.data_ptr(), stream=stream)
+            torch.cuda.synchronize()
+            cold.append(float(g.profile_read()[0].sum()))
+            for _ in range(3):
+                g.search_top1_keys_dev(q.data_ptr(), 16, k.data_ptr(), stream=stream)
+            torch.cuda.synchronize()
+            warm.append(float(np.median(g.profile_read()[0])))
+        g.profile_enable(False)
+        dsp = g.last_dispatch()
+        gb = src.shape[0] * d * 4 / 1e9
+        out["cold_vs_warm_pass_us"] = {"kernel": dsp["kernel"], "queries": 16, "cold_us": float(np.median(cold)) * 1e3, "warm_us": float(np.median(warm)) * 1e3,
+                                       "cold_GBps": gb / (float(np.median(cold)) * 1e-3), "warm_GBps": gb / (float(np.median(warm)) * 1e-3),
+                                       "note": "one gallery pass (204.8 MB); cold = first pass after a 512 MiB write to another buffer (rows come from HBM), warm = the passes after it (rows come from the Infinity Cache / L2)"}
+        del flush
         g.close()
     return out
 
@@ -656,13 +700,92 @@ def k3_classifiers(fir, dev, args):
     return out
 
 
+def config5(args, fir, dev, ws):
+    """BASELINE configs[4] / BASELINE.md section 3 row GPU-GEMM: L2 top-1 over a 1M x 1280 gallery (EfficientNet-B7 width), the MFMA
+    nomination + exact f32 re-rank + certificate path against the memory-bound exact scan, Qb in {8, 32, 256, 4096, 32768}:
+    queries/s of both forms, what the default dispatch picks, the crossover batch, identical keys, uncertified (fallback) queries,
+    and the roofline object of the dominant kernel at the largest batch (flops per launch / the library's HIP-event kernel time)."""
+    n, d = args.rows, args.config5_dim
+    stream = ws.cuda_stream
+    rows = torch.empty((n, d), device=dev, dtype=torch.float32)
+    for c in range((n + CHUNK_ROWS - 1) // CHUNK_ROWS):
+        r0 = c * CHUNK_ROWS
+        rows[r0:r0 + CHUNK_ROWS] = gen_chunk(c + 7000, min(CHUNK_ROWS, n - r0), d, dev)
+    qmax = min(args.extra_batch, 32768)
+    gq = torch.Generator(device=dev)
+    gq.manual_seed(5151)
+    fresh = torch.rand((qmax, d), generator=gq, device=dev)
+    planted = (torch.arange(qmax, device=dev) * 977 + 11) % n
+    pert = (rows[planted] + (torch.rand((qmax, d), generator=gq, device=dev) - 0.5) * 0.05 * rows[:4096].mean()).clamp_min(0)
+    q = torch.where((torch.arange(qmax, device=dev) % 2 == 0)[:, None], fresh, pert)
+    q = (q / q.norm(dim=1, keepdim=True)).contiguous()
+    del fresh, pert
+    out = {"workload": f"{n}x{d} f32 gallery (BASELINE configs[4]), L2 top-1, device-pointer calls", "batches": {}}
+    with torch.cuda.stream(ws):
+        g = fir.Gallery(dev_ptr=rows.data_ptr(), n=n, d=d, metric=fir.METRIC_L2, device=dev.index, stream=stream)
+        del rows
+        torch.cuda.empty_cache()
+        crossover = None
+        ident_all = True
+        for qb in (8, 32, 256, 4096, qmax):
+            k_scan = torch.empty(qb, device=dev, dtype=torch.int64)
+            k_mfma = torch.empty(qb, device=dev, dtype=torch.int64)
+            k_def = torch.empty(qb, device=dev, dtype=torch.int64)
+            g.set_large_batch_mfma(0)
+            r_scan = rate(lambda: g.search_top1_keys_dev(q.data_ptr(), qb, k_scan.data_ptr(), stream=stream), qb, 1 if qb > 4096 else 3)
+            g.set_large_batch_mfma(1)                 # every batch through the matrix cores
+            r_mfma = rate(lambda: g.search_top1_keys_dev(q.data_ptr(), qb, k_mfma.data_ptr(), stream=stream), qb, 5)
+            g.set_large_batch_mfma(-1)                # the library's own choice
+            fb0 = g.mfma_stats()["fallback_queries"]
+            r_def = rate(lambda: g.search_top1_keys_dev(q.data_ptr(), qb, k_def.data_ptr(), stream=stream), qb, 5)
+            dd = g.last_dispatch()
+            same = bool(torch.equal(k_scan, k_mfma)) and bool(torch.equal(k_scan, k_def))
+            ident_all = ident_all and same
+            if crossover is None and r_mfma > r_scan:
+                crossover = qb
+            out["batches"][str(qb)] = {"exact_scan_queries_per_s": r_scan, "matrix_core_queries_per_s": r_mfma, "default_dispatch_queries_per_s": r_def,
+                                       "default_dispatch_path": dd["path"], "default_dispatch_kernel": dd["kernel"], "identical_keys": same,
+                                       "fallback_queries_per_call": (g.mfma_stats()["fallback_queries"] - fb0) / 6.0}
+        # the dominant kernel at the largest batch, timed by the library's HIP events
+        qb = qmax
+        k_def = torch.empty(qb, device=dev, dtype=torch.int64)
+        g.profile_enable(True)
+        g.profile_read()
+        t0 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            g.search_top1_keys_dev(q.data_ptr(), qb, k_def.data_ptr(), stream=stream)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        ms, _ = g.profile_read()
+        g.profile_enable(False)
+        dd = g.last_dispatch()
+        mem = g.memory_bytes()
+        g.close()
+    if len(ms) and dd["path"] == "mfma":
+        avg = float(np.mean(ms))
+        tf = dd["flops_per_launch"] / (avg * 1e-3) / 1e12
+        gbs = dd["bytes_per_launch"] / (avg * 1e-3) / 1e9
+        out["roofline_mfma"] = {"bound": "mfma", "flops_per_launch": dd["flops_per_launch"], "achieved_tflops": tf, "peak_tflops": PEAK_MFMA_F16_TFLOPS,
+                                "frac_of_mfma_peak": tf / PEAK_MFMA_F16_TFLOPS, "stream_GBps": gbs, "frac_of_hbm_peak": gbs / 8000.0, "kernel": dd["kernel"],
+                                "kernel_avg_ms": avg, "launches_timed": int(len(ms)), "grid": dd["grid"], "block": dd["block"],
+                                "lds_bytes_per_workgroup": dd["lds_bytes"], "vgprs": dd["vgprs"], "queries_per_gallery_read": dd["queries_per_pass"],
+                                "bytes_per_launch": dd["bytes_per_launch"], "queries_per_s_whole_call": qb / dt,
+                                "kernel_time_share_of_call": float(np.sum(ms)) / (dt * reps * 1e3)}
+    out["crossover_query_batch"] = crossover          # the smallest measured batch at which the matrix-core form beats the exact scan
+    out["identical_keys_at_every_batch"] = ident_all
+    out["hbm_bytes_held"] = mem
+    torch.cuda.empty_cache()
+    return out
+
+
 def config4(args, build, make_queries, timed_loop, fir, dev, world):
     n4 = args.config4_rows
     steps = max(3, args.steps // 4)
     m, lo, hi, shard = build(n4)
     del shard
     torch.cuda.empty_cache()
-    qb = args.batch
+    qb = min(args.batch, args.extra_batch)
     q, planted = make_queries(qb, n4)
     keys = torch.empty(qb, device=dev, dtype=torch.int64)
     el, k_ms, x_ms, disp = timed_loop(m, q, qb, keys, steps, 1)
@@ -689,6 +812,43 @@ def config4(args, build, make_queries, timed_loop, fir, dev, world):
     return out
 
 
+def pmc_config2_sequence(fir, dev, ws, d):
+    """Counter pass only (BASELINE.md section 3 / SURVEY 8d: "100k x 512 fits Infinity Cache -> report rocprof DRAM bytes, cold vs
+    warm"): a 100 000 x 512 gallery, 256 queries through the exact scan and 4 096 through the default dispatch, each once from cold
+    caches -- right behind a 512 MiB write to another buffer -- and three times warm. The segments are delimited by marker
+    launches the parent recognises by kernel name: a 512 MiB float64 fill (the flush) and an 8-element int16 fill."""
+    n2 = 100_000
+    src = torch.cat([gen_chunk(c + 9000, CHUNK_ROWS, d, dev) for c in range(-(-n2 // CHUNK_ROWS))])[:n2].contiguous()
+    gq = torch.Generator(device=dev)
+    gq.manual_seed(2222)
+    q = torch.rand((4096, d), generator=gq, device=dev)
+    q = (q / q.norm(dim=1, keepdim=True)).contiguous()
+    big = torch.empty(64 * 1024 * 1024, device=dev, dtype=torch.float64)      # 512 MiB
+    small = torch.empty(8, device=dev, dtype=torch.int16)
+    k = torch.empty(4096, device=dev, dtype=torch.int64)
+    stream = ws.cuda_stream
+    with torch.cuda.stream(ws):
+        g = fir.Gallery(dev_ptr=src.data_ptr(), n=n2, d=d, metric=fir.METRIC_L2, device=dev.index, stream=stream)
+        for mode, qb in ((0, 256), (-1, 4096)):
+            g.set_large_batch_mfma(mode)
+            for _ in range(2):                       # set-up: code objects, scratch, the fp16 state
+                g.search_top1_keys_dev(q.data_ptr(), qb, k.data_ptr(), stream=stream)
+            torch.cuda.synchronize()
+            big.fill_(1.0)                           # marker + flush
+            torch.cuda.synchronize()
+            g.search_top1_keys_dev(q.data_ptr(), qb, k.data_ptr(), stream=stream)      # cold
+            torch.cuda.synchronize()
+            small.fill_(1)                           # marker
+            for _ in range(3):                       # warm
+                g.search_top1_keys_dev(q.data_ptr(), qb, k.data_ptr(), stream=stream)
+            torch.cuda.synchronize()
+            small.fill_(2)                           # marker
+            torch.cuda.synchronize()
+        g.close()
+    del big, src
+    torch.cuda.empty_cache()
+
+
 def pmc_traffic(args, n, d, world):
     """HBM bytes per launch of the two dominant kernels from the PMC counters: FETCH_SIZE (rocprofv3 unit: KiB) x 1024 x 2, as
     MI355X_MICROARCH.md prescribes for 16 B/lane streams on gfx950, averaged over the launches. Counters cannot be
@@ -706,28 +866,58 @@ def pmc_traffic(args, n, d, world):
         out_dir = tempfile.mkdtemp(prefix="fir_pmc_")
         cmd = ["rocprofv3", "--pmc", "FETCH_SIZE", "--output-format", "csv", "-d", out_dir, "-o", "pmc", "--",
                sys.executable, os.path.abspath(__file__), "--pmc-child", "--steps", "3", "--warmup", "1", "--rows", str(n), "--dim", str(d),
-               "--batch", str(args.batch), "--scan-batch", str(args.scan_batch), "--cpu-seconds", "0", "--no-extras"]
+               "--batch", str(min(args.batch, 32768)), "--scan-batch", str(args.scan_batch), "--cpu-seconds", "0", "--no-extras"]
+        if not args.no_extras and d == 512:
+            cmd += ["--pmc-config2"]
         if args.qpp:
             cmd += ["--qpp", str(args.qpp)]
         try:
             subprocess.run(cmd, cwd=out_dir, env=dict(os.environ, TMPDIR=out_dir), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
                            timeout=200, check=True)
             vals = {"scan": [], "mfma": []}
+            seg, seg_bytes = -1, {}                  # config-2 sequence: segment number (bumped by every marker launch) -> FETCH_SIZE of the library's kernels in it
             for f in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
-                for r in csv.DictReader(open(f)):
-                    if r["Counter_Name"] != "FETCH_SIZE":
+                rows_csv = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == "FETCH_SIZE"]
+                rows_csv.sort(key=lambda r: int(r.get("Dispatch_Id", 0)))
+                is_marker = lambda kn: "FillFunctor<double>" in kn or "FillFunctor<short>" in kn
+                has_cfg2 = sum(1 for r in rows_csv if is_marker(r["Kernel_Name"])) >= 6      # the config-2 sequence ran first (six marker launches)
+                for r in rows_csv:
+                    kn = r["Kernel_Name"]
+                    if is_marker(kn):
+                        seg += 1
                         continue
-                    if "k_scan_l2" in r["Kernel_Name"]:
+                    mine = "fir::" in kn or "(anonymous namespace)::k_" in kn
+                    if has_cfg2 and seg <= 4:        # segments 0 / 1: scan cold / warm, 2: matrix-core set-up, 3 / 4: default dispatch cold / warm (-1: the scan's set-up)
+                        if mine and seg >= 0:
+                            seg_bytes[seg] = seg_bytes.get(seg, 0.0) + float(r["Counter_Value"]) * 1024 * 2
+                        continue                     # (the config-2 launches are not the headline's)
+                    if "k_scan_l2" in kn:
                         vals["scan"].append(float(r["Counter_Value"]))
-                    elif "k_gemm_proxy_f16" in r["Kernel_Name"] and ("<1," in r["Kernel_Name"] or "false>" in r["Kernel_Name"]):
+                    elif "k_gemm_proxy_f16" in kn and ("<1," in kn or "false>" in kn):
                         vals["mfma"].append(float(r["Counter_Value"]))
+            cfg2 = None
+            if all(i in seg_bytes for i in (0, 1, 3, 4)):
+                alg = 100_000 * 512 * 4.0
+                cfg2 = {"what": "bytes requested beyond L2 (PMC FETCH_SIZE x 1024 x 2, all of the library's kernels of the call) per call over a 100 000 x 512 gallery: cold = "
+                                "first call after a 512 MiB write to another buffer, warm = mean of the three calls after it; the gallery is 204.8 MB of f32 rows "
+                                "(+ 102.4 MB of fp16 fragments for the default dispatch) against 256 MiB of Infinity Cache. FETCH_SIZE is taken at the L2's "
+                                "memory-side interface and counts Infinity-Cache hits like HBM reads (MI355X_MICROARCH.md, HBM): cold and warm read the same here, and "
+                                "rocprofv3 -L offers no counter behind the Infinity Cache on this image -- what separates them is the pass time, `cold_vs_warm_pass_us`",
+                        "exact_scan_256_queries": {"cold": seg_bytes[0], "warm": seg_bytes[1] / 3.0, "algorithmic_gallery_bytes": alg,
+                                                   "gallery_passes_per_call": 16},
+                        "default_dispatch_4096_queries": {"cold": seg_bytes[3], "warm": seg_bytes[4] / 3.0, "algorithmic_fragment_bytes": alg / 2}}
             if vals["scan"] or vals["mfma"]:
                 res = {k: (sum(v) / len(v) * 1024 * 2 if v else None) for k, v in vals.items()}
                 res["how"] = f"rocprofv3 --pmc FETCH_SIZE child pass of this run ({len(vals['scan'])} scan, {len(vals['mfma'])} matrix-core launches), KiB x 1024 x 2"
+                res["config2"] = cfg2
                 return res
         except Exception:
             pass
         finally:
+            keep = os.environ.get("FIR_BENCH_KEEP_PMC")          # debugging: a directory that receives the counter pass's CSV files
+            if keep:
+                for f in glob.glob(os.path.join(out_dir, "**", "*.csv"), recursive=True):
+                    shutil.copy(f, os.path.join(keep, os.path.basename(f)))
             shutil.rmtree(out_dir, ignore_errors=True)
     path = os.path.join(ROOT, "profiles", "r01_rocprofv3_pmc_fetch_size.json")
     if os.path.exists(path) and (n, d, world, args.scan_batch) == (1_000_000, 512, 1, 256):

@@ -17,6 +17,9 @@ from .capi import (  # noqa: F401
     METRIC_CHI2,
     METRIC_KL,
     METRIC_L2,
+    SHADOW_ALL,
+    SHADOW_FP16,
+    SHADOW_NONE,
     ShardedClsModel,
     ShardedGallery,
     comm_unique_id,

@@ -107,6 +107,9 @@ SYMBOLS = [
     ("fir_gallery_set_tuning", C.c_int, [_vp, C.c_int32, C.c_int32]),
     ("fir_gallery_value_range", C.c_int, [_vp, _i32p, _i32p]),
     ("fir_gallery_get_tuning", C.c_int, [_vp, _i32p, _i32p, _i32p]),
+    ("fir_gallery_mfma_stats", C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    ("fir_gallery_memory_bytes", C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    ("fir_gallery_set_shadow_copies", C.c_int, [_vp, C.c_int32]),
 ]
 
 _lib = None
@@ -181,7 +184,10 @@ def keys_unpack(keys):
 class DispatchInfo(C.Structure):
     _fields_ = [("struct_bytes", C.c_int32), ("path", C.c_int32), ("kernel", C.c_char * 160), ("launches", C.c_int32), ("grid_x", C.c_int32),
                 ("grid_y", C.c_int32), ("block", C.c_int32), ("lds_bytes", C.c_int32), ("vgprs", C.c_int32), ("queries_per_pass", C.c_int32),
-                ("bytes_per_launch", C.c_double), ("flops_per_launch", C.c_double)]
+                ("bytes_per_launch", C.c_double), ("flops_per_launch", C.c_double), ("warmup_calls_left", C.c_int32), ("reserved", C.c_int32)]
+
+
+SHADOW_NONE, SHADOW_FP16, SHADOW_ALL = 0, 1, 2
 
 
 class Gallery:
@@ -233,6 +239,19 @@ class Gallery:
 
     def set_large_batch_mfma(self, min_queries):
         _check(lib().fir_gallery_set_large_batch_mfma(self._h, min_queries))
+
+    def set_shadow_copies(self, mode):
+        _check(lib().fir_gallery_set_shadow_copies(self._h, mode))
+
+    def mfma_stats(self):
+        a, b = C.c_int64(), C.c_int64()
+        _check(lib().fir_gallery_mfma_stats(self._h, C.byref(a), C.byref(b)))
+        return {"passes": a.value, "fallback_queries": b.value}
+
+    def memory_bytes(self):
+        t, f, r, sc = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+        _check(lib().fir_gallery_memory_bytes(self._h, C.byref(t), C.byref(f), C.byref(r), C.byref(sc)))
+        return {"tiled": t.value, "fp16_fragments": f.value, "rowmajor_shadow": r.value, "scratch": sc.value}
 
     def value_range(self):
         """(every gallery value in the plain range, every query value of the last search too) -- chi-square / KL scans
@@ -345,7 +364,7 @@ class Gallery:
         _check(lib().fir_gallery_last_dispatch(self._h, C.byref(o)))
         return {"path": "mfma" if o.path == 1 else "scan", "kernel": o.kernel.decode(), "launches": o.launches, "grid": [o.grid_x, o.grid_y],
                 "block": o.block, "lds_bytes": o.lds_bytes, "vgprs": o.vgprs, "queries_per_pass": o.queries_per_pass,
-                "bytes_per_launch": o.bytes_per_launch, "flops_per_launch": o.flops_per_launch}
+                "bytes_per_launch": o.bytes_per_launch, "flops_per_launch": o.flops_per_launch, "warmup_calls_left": o.warmup_calls_left}
 
 
 COMM_ID_BYTES = 128

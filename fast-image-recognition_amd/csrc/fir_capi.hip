@@ -91,7 +91,12 @@ struct fir_gallery {
     // L2 whole-range batches of at least this many queries go through fir_gemm_* (same keys): -1 = automatic
     // (kAutoMfmaQueries queries against at least kAutoMfmaRows rows), 0 = never, > 0 = the caller's threshold
     int large_batch_min = -1;
-    fir_gemm* gemm_prefix = nullptr; int gemm_prefix_end = 0;   // the matrix-core state of the last feature prefix [0, end) asked for ("BF, 64" / "BF, 256")
+    // the matrix-core states of the last TWO feature prefixes [0, end) asked for: the reference's harness alternates "BF, 64" and
+    // "BF, 256" (ImageTesting.cpp:526-529); one slot would rebuild fragments and scratch on every call
+    struct PrefixSlot { fir_gemm* m = nullptr; int end = 0; uint64_t used = 0; } gemm_prefix[2];
+    uint64_t prefix_clock = 0;
+    int warm_left = 0;                  // fir_dispatch_info::warmup_calls_left of the most recent call
+    int shadow_mode = FIR_SHADOW_ALL;   // which copies of the gallery the automatic dispatch may keep next to the tiled f32 rows (fir_gallery_set_shadow_copies)
     int small_hits = 0, few_hits = 0;   // automatic mode: calls so far that would have profited from a matrix-core state not built yet (see ensure_gemm)
     bool gemm_failed = false; // automatic mode: the matrix-core path could not be set up for this shape (rows too long): scan
     fir_gemm* gemm = nullptr; // created on first use
@@ -288,7 +293,7 @@ bool wants_mfma(const fir_gallery* g, int32_t qb, int32_t start, int32_t end) {
 // 332 -> 253 us, 1M x 1280 790 -> 550 us, 300 000 x 512 116 -> 173 us (not taken). With 2 queries the two forms tie, from 3 on
 // the dot products (v_dot2 + one LDS read per query and fragment) cost more than the bytes saved: those stay with the f32 scan.
 bool wants_few(const fir_gallery* g, int32_t qb, int32_t start, int32_t end) {
-    if (g->metric != FIR_METRIC_L2 || start != 0 || g->n < kAutoMfmaRows || g->tiles_limit > 0 || g->qpp != 0 || g->profiling) return false;
+    if (g->metric != FIR_METRIC_L2 || start != 0 || g->n < kAutoMfmaRows || g->tiles_limit > 0 || g->qpp != 0 || g->few_hits < 0) return false;
     if (end != g->d && (end < 64 || end % 16 != 0)) return false;
     if (g->large_batch_min >= 0 || g->gemm_failed) return false;
     return qb == 1 && (double)g->n * (double)end * 4.0 >= 1500.0e6;
@@ -952,7 +957,7 @@ int fir_gallery_destroy(fir_gallery* g) {
     (void)hipSetDevice(g->device);
     if (g->stream) (void)hipStreamSynchronize(g->stream);
     if (g->gemm) { fir_gemm_destroy(g->gemm); g->gemm = nullptr; }
-    if (g->gemm_prefix) { fir_gemm_destroy(g->gemm_prefix); g->gemm_prefix = nullptr; }
+    for (auto& ps : g->gemm_prefix) if (ps.m) { fir_gemm_destroy(ps.m); ps.m = nullptr; ps.end = 0; }
     for (hipEvent_t e : g->ev) (void)hipEventDestroy(e);
     (void)hipFree(g->gal4); (void)hipFree(g->cls); (void)hipFree(g->qt); (void)hipFree(g->dq); (void)hipFree(g->dkeys);
     (void)hipFree(g->part); (void)hipFree(g->dout); (void)hipFree(g->didx); (void)hipFree(g->range); (void)hipFree(g->one_keys);
@@ -984,7 +989,46 @@ int fir_gallery_set_large_batch_mfma(fir_gallery* g, int32_t min_queries) {
     g->large_batch_min = min_queries < 0 ? -1 : min_queries;
     g->gemm_failed = false;
     if (min_queries == 0 && g->gemm) { fir_gemm_destroy(g->gemm); g->gemm = nullptr; }
-    if (min_queries == 0 && g->gemm_prefix) { fir_gemm_destroy(g->gemm_prefix); g->gemm_prefix = nullptr; }
+    if (min_queries == 0) for (auto& ps : g->gemm_prefix) if (ps.m) { fir_gemm_destroy(ps.m); ps.m = nullptr; ps.end = 0; }
+    return FIR_OK;
+}
+
+int fir_gallery_mfma_stats(fir_gallery* g, int64_t* passes, int64_t* fallback_queries) {
+    if (!g) return fail(FIR_ERR_ARG, "gallery is NULL");
+    int64_t p = 0, f = 0, a = 0, b = 0;
+    if (g->gemm && fir_gemm_stats(g->gemm, &a, &b) == FIR_OK) { p += a; f += b; }
+    for (auto& ps : g->gemm_prefix)
+        if (ps.m && fir_gemm_stats(ps.m, &a, &b) == FIR_OK) { p += a; f += b; }
+    if (passes) *passes = p;
+    if (fallback_queries) *fallback_queries = f;
+    return FIR_OK;
+}
+
+int fir_gallery_memory_bytes(fir_gallery* g, int64_t* tiled, int64_t* fp16_fragments, int64_t* rowmajor_shadow, int64_t* scratch) {
+    if (!g) return fail(FIR_ERR_ARG, "gallery is NULL");
+    int64_t fr = 0, rm = 0, sc = 0, a = 0, b = 0, c = 0;
+    if (g->gemm) { fir_gemm_memory_bytes_(g->gemm, &a, &b, &c); fr += a; rm += b; sc += c; }
+    for (auto& ps : g->gemm_prefix)
+        if (ps.m) { fir_gemm_memory_bytes_(ps.m, &a, &b, &c); fr += a; rm += b; sc += c; }
+    sc += (int64_t)(g->qt_cap * sizeof(float) + g->dq_cap * sizeof(float) + g->dkeys_cap * sizeof(uint64_t) + g->part_cap * sizeof(uint64_t) +
+                    g->dout_cap * sizeof(float) + g->didx_cap * sizeof(int32_t));
+    for (size_t i = 0; i < 16; ++i) sc += (int64_t)g->scratch_cap[i];
+    if (tiled) *tiled = (int64_t)g->tiles * fir::kTileRows * (int64_t)((g->d + 3) / 4) * 16 + (g->cls ? (int64_t)g->n * 4 : 0);
+    if (fp16_fragments) *fp16_fragments = fr;
+    if (rowmajor_shadow) *rowmajor_shadow = rm;
+    if (scratch) *scratch = sc;
+    return FIR_OK;
+}
+
+int fir_gallery_set_shadow_copies(fir_gallery* g, int32_t mode) {
+    if (!g) return fail(FIR_ERR_ARG, "gallery is NULL");
+    if (mode != FIR_SHADOW_NONE && mode != FIR_SHADOW_FP16 && mode != FIR_SHADOW_ALL) return fail(FIR_ERR_ARG, "shadow mode %d", mode);
+    if (mode != g->shadow_mode) {
+        if (g->gemm) { fir_gemm_destroy(g->gemm); g->gemm = nullptr; }
+        for (auto& ps : g->gemm_prefix) if (ps.m) { fir_gemm_destroy(ps.m); ps.m = nullptr; ps.end = 0; }
+        g->gemm_failed = false;
+    }
+    g->shadow_mode = mode;
     return FIR_OK;
 }
 
@@ -994,7 +1038,7 @@ int fir_gallery_set_row_offset(fir_gallery* g, int64_t first_global_row) {
         return fail(FIR_ERR_ARG, "row offset %lld + n does not fit 32-bit indices", (long long)first_global_row);
     g->row_offset = first_global_row;
     if (g->gemm) { fir_gemm_destroy(g->gemm); g->gemm = nullptr; }   // it caches the offset; rebuilt on next use
-    if (g->gemm_prefix) { fir_gemm_destroy(g->gemm_prefix); g->gemm_prefix = nullptr; }
+    for (auto& ps : g->gemm_prefix) if (ps.m) { fir_gemm_destroy(ps.m); ps.m = nullptr; ps.end = 0; }
     return FIR_OK;
 }
 
@@ -1029,22 +1073,38 @@ int ensure_gemm(fir_gallery* g, int32_t end, fir_gemm** m, int* warm = nullptr, 
     // a gallery that keeps getting such calls; the first warm_calls of them take the scan (a test harness that makes ONE batched call
     // against a 3 030-row gallery would pay 16 ms to save 2)
     const bool whole = end == g->d;
-    fir_gemm*& slot = whole ? g->gemm : g->gemm_prefix;
-    if (warm && !(slot && (whole || g->gemm_prefix_end == end)) && g->large_batch_min < 0 && ++*warm <= warm_calls) return 1;
-    if (!whole && slot && g->gemm_prefix_end != end) {          // another prefix than last time: its fragments replace the old ones
+    if (g->shadow_mode == FIR_SHADOW_NONE && g->large_batch_min <= 0) return 1;     // the caller forbade every copy: the scan
+    fir_gallery::PrefixSlot* ps = nullptr;
+    if (!whole) {
+        for (auto& c : g->gemm_prefix) if (c.m && c.end == end) ps = &c;
+        if (!ps) {                                                  // the free slot, else the one used longest ago
+            ps = &g->gemm_prefix[0];
+            for (auto& c : g->gemm_prefix) if (!c.m) { ps = &c; break; } else if (c.used < ps->used) ps = &c;
+        }
+    }
+    fir_gemm*& slot = whole ? g->gemm : ps->m;
+    const bool have = slot && (whole || ps->end == end);
+    if (warm && !have && g->large_batch_min < 0) {
+        ++*warm;
+        g->warm_left = *warm <= warm_calls ? warm_calls - *warm + 1 : 0;
+        if (*warm <= warm_calls) return 1;
+    }
+    if (!whole && slot && ps->end != end) {                         // a third prefix: its fragments replace the least recently used ones
         fir_gemm_destroy(slot);
         slot = nullptr;
+        ps->end = 0;
     }
     if (!slot) {
-        const int rc = fir_gemm_create_range(g, FIR_GEMM_F16, whole ? 0 : end, &slot);
+        const int rc = fir_gemm_create_range_ex_(g, FIR_GEMM_F16, whole ? 0 : end, g->shadow_mode == FIR_SHADOW_FP16 ? 0 : -1, &slot);
         if (rc) {
             slot = nullptr;
             if (g->large_batch_min > 0 || (rc != FIR_ERR_ARG && rc != FIR_ERR_NOMEM)) return rc;    // asked for explicitly, or a real failure
             g->gemm_failed = true;                                           // automatic: this shape (or this much HBM) stays with the scan
             return 1;
         }
-        if (!whole) g->gemm_prefix_end = end;
+        if (!whole) ps->end = end;
     }
+    if (!whole) ps->used = ++g->prefix_clock;
     *m = slot;
     return 0;
 }
@@ -1056,7 +1116,10 @@ int try_mfma(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start, 
         fir_gemm* mf = nullptr;
         const int rcf = ensure_gemm(g, end, &mf, &g->few_hits, 16);
         if (rcf) return rcf;
-        return fir_gemm_search_few_keys_dev(mf, d_queries, qb, d_keys, st);
+        const int rcs = fir_gemm_search_few_keys_dev(mf, d_queries, qb, d_keys, st);
+        if (rcs != FIR_ERR_NOMEM) return rcs;
+        g->few_hits = -(1 << 30);          // no room for the proxy table: this gallery's one-query calls stay with the exact scan
+        return 1;
     }
     if (!wants_mfma(g, qb, start, end)) return 1;
     fir_gemm* m = nullptr;
@@ -1098,6 +1161,7 @@ int fir_search_top1_keys_dev(fir_gallery* g, const float* d_queries, int32_t qb,
     FIR_HIP(hipSetDevice(g->device));
     hipStream_t st = stream ? (hipStream_t)stream : g->stream;
     g->call_launches = 0;
+    g->warm_left = 0;
     rc = try_mfma(g, d_queries, qb, start_pos, end_pos, d_keys, st);
     if (rc <= 0) return rc;
     return top1_dev(g, d_queries, qb, start_pos, end_pos, d_keys, st);
@@ -1149,6 +1213,7 @@ int fir_gallery_last_dispatch(fir_gallery* g, fir_dispatch_info* out) {
     if (out->struct_bytes < 8 || out->struct_bytes > (int32_t)sizeof(fir_dispatch_info)) return fail(FIR_ERR_ARG, "fir_dispatch_info.struct_bytes = %d", out->struct_bytes);
     const int32_t nb = out->struct_bytes;
     fir_dispatch_info tmp = g->last;
+    tmp.warmup_calls_left = g->warm_left;
     tmp.struct_bytes = nb;
     std::memcpy(out, &tmp, (size_t)nb);
     return FIR_OK;
@@ -1384,7 +1449,7 @@ int fir_search_topk(fir_gallery* g, const float* queries, int32_t qb, int32_t st
     }
     if (rc > 0) {
         FIR_HIP(hipMemcpyAsync(g->dq, queries, (size_t)qb * g->d * sizeof(float), hipMemcpyHostToDevice, g->stream));
-        if ((rc = topk_dev(g, g->dq, qb, start_pos, end_pos, k, g->dkeys, g->stream))) return rc;
+        if ((rc = topk_dev(g, g->dq, qb, start_pos, end_pos, k, g->dkeys, g->stream, true, false))) return rc;   // (the matrix cores were consulted above)
     }
     std::vector<uint64_t> keys((size_t)qb * k);
     FIR_HIP(hipMemcpyAsync(keys.data(), g->dkeys, keys.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, g->stream));

@@ -1422,7 +1422,9 @@ struct fir_gemm {
     int feat = 0;               // features compared: the gallery's d, or a prefix [0, feat) of every row (fir_gemm_create_range); v.d stays the row length
     int precision = 0;          // 0: f32 MFMA, 1: bf16 split (hi.hi + hi.lo + lo.hi), 2: one fp16 term
     uint4* gh = nullptr;        // fp16 fragments (precision 2)
-    float* proxies = nullptr;   // few-query calls: every row's proxy, 8 x n floats (allocated on first use)
+    float* proxies = nullptr;   // few-query calls: every row's proxy, proxies_nq x n floats (grown on first use)
+    int proxies_nq = 0;
+    int lists_cap = 0;          // queries the candidate lists / counts of one scratch set are sized for (grown to the super-batch in use)
     float4* rowmajor = nullptr; // row-major f32 copy of the compared features for the re-rank's gathers (absent when HBM is short: the tiled gallery serves)
     int gallery_exp = 0;        // fp16: the gallery was multiplied by 2^gallery_exp
     float* qmul[2] = {nullptr, nullptr};
@@ -1482,7 +1484,25 @@ int fir_gemm_create(fir_gallery* g, fir_gemm** out) { return fir_gemm_create_ran
 
 int fir_gemm_create_ex(fir_gallery* g, int32_t precision, fir_gemm** out) { return fir_gemm_create_range(g, precision, 0, out); }
 
-int fir_gemm_create_range(fir_gallery* g, int32_t precision, int32_t end_pos, fir_gemm** out) {
+int fir_gemm_create_range(fir_gallery* g, int32_t precision, int32_t end_pos, fir_gemm** out) { return fir_gemm_create_range_ex_(g, precision, end_pos, -1, out); }
+
+void fir_gemm_memory_bytes_(const fir_gemm* m, int64_t* fragments, int64_t* rowmajor, int64_t* scratch) {
+    const int64_t rblocks = (std::max<int64_t>(m->v.n, 1) + 31) / 32, np = std::max<int64_t>(m->v.n, 1);
+    const int64_t fr = m->gh ? rblocks * m->dk16 * 1024 : m->gb ? rblocks * m->dk16 * 2048 : m->gm ? rblocks * m->dq8 * 1024 : 0;
+    const int64_t rm = m->rowmajor ? m->v.n * (int64_t)((m->feat + 3) / 4) * 16 : 0;
+    int64_t sc = np * 4 + 16;                                                                     // row norms, their maximum
+    sc += 2 * ((int64_t)m->lists_cap * kListCap * 8 + (int64_t)m->lists_cap * 4);                 // candidate lists and counts
+    sc += 2 * (m->precision == FIR_GEMM_F32 ? (int64_t)kPasses * (kQT / 32) * m->dq8 * 1024
+                                            : (int64_t)kPasses * (kQT / 32) * m->dk16 * (m->precision == FIR_GEMM_BF16_SPLIT ? 2048 : 1024));   // query fragments
+    sc += 2 * (int64_t)kPasses * kQT * 4 * 4 + 2 * (int64_t)kRtSubsets * kPasses * kQT * 4;      // per-query scalars, subset minima
+    sc += (int64_t)m->ok_cap * 4 + (int64_t)kQT * m->v.d * 4 + (int64_t)kQT * kTopKMax * 8;
+    if (m->proxies) sc += (int64_t)m->proxies_nq * np * 4;
+    if (fragments) *fragments = fr;
+    if (rowmajor) *rowmajor = rm;
+    if (scratch) *scratch = sc;
+}
+
+int fir_gemm_create_range_ex_(fir_gallery* g, int32_t precision, int32_t end_pos, int32_t rowmajor_mode, fir_gemm** out) {
     if (!g || !out) return gemm_fail(FIR_ERR_ARG, "NULL argument");
     if (precision != FIR_GEMM_F32 && precision != FIR_GEMM_BF16_SPLIT && precision != FIR_GEMM_F16)
         return gemm_fail(FIR_ERR_ARG, "bad precision %d", precision);
@@ -1515,15 +1535,14 @@ int fir_gemm_create_range(fir_gallery* g, int32_t precision, int32_t end_pos, fi
     if (e == hipSuccess) e = hipMalloc((void**)&m->gnorm, (size_t)np * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&m->gmax, 16);
     for (int b = 0; b < 2; ++b) {
-        if (e == hipSuccess) e = hipMalloc((void**)&m->qm[b], (size_t)kPasses * (kQT / 32) * m->dq8 * 64 * sizeof(float4));
-        if (e == hipSuccess) e = hipMalloc((void**)&m->qbf[b], (size_t)kPasses * (kQT / 32) * m->dk16 * 128 * sizeof(uint4));
+        if (e == hipSuccess && precision == FIR_GEMM_F32) e = hipMalloc((void**)&m->qm[b], (size_t)kPasses * (kQT / 32) * m->dq8 * 64 * sizeof(float4));
+        if (e == hipSuccess && precision != FIR_GEMM_F32)
+            e = hipMalloc((void**)&m->qbf[b], (size_t)kPasses * (kQT / 32) * m->dk16 * (precision == FIR_GEMM_BF16_SPLIT ? 128 : 64) * sizeof(uint4));
         if (e == hipSuccess) e = hipMalloc((void**)&m->qnorm[b], kPasses * kQT * sizeof(float));
         if (e == hipSuccess) e = hipMalloc((void**)&m->qmul[b], kPasses * kQT * sizeof(float));
         if (e == hipSuccess) e = hipMalloc((void**)&m->qinv[b], kPasses * kQT * sizeof(float));
         if (e == hipSuccess) e = hipMalloc((void**)&m->smin[b], (size_t)kRtSubsets * kPasses * kQT * sizeof(unsigned int));   // top-K: one minimum per subset
         if (e == hipSuccess) e = hipMalloc((void**)&m->tau[b], kPasses * kQT * sizeof(float));
-        if (e == hipSuccess) e = hipMalloc((void**)&m->lists[b], (size_t)kPasses * kQT * kListCap * sizeof(unsigned long long));
-        if (e == hipSuccess) e = hipMalloc((void**)&m->counts[b], kPasses * kQT * sizeof(int));
         if (e == hipSuccess) e = hipEventCreateWithFlags(&m->main_done[b], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&m->rerank_done[b], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&m->prep_done[b], hipEventDisableTiming);
@@ -1616,8 +1635,8 @@ int fir_gemm_create_range(fir_gallery* g, int32_t precision, int32_t end_pos, fi
             const int d4 = (m->feat + 3) / 4;
             const size_t want = (size_t)m->v.n * d4 * sizeof(float4);
             size_t free_b = 0, total_b = 0;
-            int mode = -1;
-            if (const char* w = std::getenv("FIR_GEMM_ROWMAJOR")) mode = std::atoi(w);
+            int mode = rowmajor_mode;
+            if (const char* w = std::getenv("FIR_GEMM_ROWMAJOR")) { if (mode < 0) mode = std::atoi(w); }
             const bool room = hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b >= 4 * want;
             if (mode != 0 && (room || mode > 0) && hipMalloc((void**)&m->rowmajor, want) == hipSuccess) {
                 const int64_t tiles = (m->v.n + 63) / 64;
@@ -1714,6 +1733,24 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
     // in whole 1 024-query launches
     const int sbq = std::min(kPasses * kQT, std::max(1024, (qb / 4 + 1023) / 1024 * 1024));
     const int nsb = (qb + sbq - 1) / sbq;
+    {   // candidate lists and counts: sized by the super-batch in use (whole 128-query pairs), not by the largest one possible --
+        // a cache-resident gallery that gets 128-query calls holds 8 MiB of lists, not 512
+        const int need = (std::min(sbq, qb) + 2 * kQT - 1) / (2 * kQT) * (2 * kQT);
+        if (need > m->lists_cap) {
+            GEMM_HIP(hipStreamSynchronize(st));
+            GEMM_HIP(hipStreamSynchronize(m->side));
+            for (int b = 0; b < 2; ++b) {
+                (void)hipFree(m->lists[b]); (void)hipFree(m->counts[b]);
+                m->lists[b] = nullptr; m->counts[b] = nullptr;
+            }
+            m->lists_cap = 0;
+            for (int b = 0; b < 2; ++b) {
+                GEMM_HIP(hipMalloc((void**)&m->lists[b], (size_t)need * kListCap * sizeof(unsigned long long)));
+                GEMM_HIP(hipMalloc((void**)&m->counts[b], (size_t)need * sizeof(int)));
+            }
+            m->lists_cap = need;
+        }
+    }
     // Two streams. `st` carries only the full passes over the gallery, back to back; `side` carries everything small:
     // the preparation of super-batch i+1 (query norms / scales / fragments, the sample pass, tau) and the exact re-rank +
     // certificate of super-batch i, both under super-batch i's (or i+1's) full pass. Order on `side`:
@@ -1978,7 +2015,26 @@ int fir_gemm_search_few_keys_dev(fir_gemm* m, const float* d_queries, int32_t qb
     const int d = m->feat, qs = m->v.d;
     const int64_t n = m->v.n;
     if (n == 0) return fir_search_top1_exact_keys_dev_(m->g, d_queries, qb, 0, d, d_keys, st);
-    if (!m->proxies) GEMM_HIP(hipMalloc((void**)&m->proxies, (size_t)8 * n * sizeof(float)));
+    const int nqt = qb <= 1 ? 1 : qb <= 2 ? 2 : qb <= 4 ? 4 : 8;
+    if (nqt > m->proxies_nq) {
+        if (m->proxies) GEMM_HIP(hipFree(m->proxies));
+        m->proxies = nullptr;
+        m->proxies_nq = 0;
+        GEMM_HIP(hipMalloc((void**)&m->proxies, (size_t)nqt * n * sizeof(float)));     // (FIR_ERR_NOMEM: the caller takes the exact scan)
+        m->proxies_nq = nqt;
+    }
+    if (m->lists_cap < 2 * kQT) {
+        for (int bb = 0; bb < 2; ++bb) {
+            (void)hipFree(m->lists[bb]); (void)hipFree(m->counts[bb]);
+            m->lists[bb] = nullptr; m->counts[bb] = nullptr;
+        }
+        m->lists_cap = 0;
+        for (int bb = 0; bb < 2; ++bb) {
+            GEMM_HIP(hipMalloc((void**)&m->lists[bb], (size_t)2 * kQT * kListCap * sizeof(unsigned long long)));
+            GEMM_HIP(hipMalloc((void**)&m->counts[bb], (size_t)2 * kQT * sizeof(int)));
+        }
+        m->lists_cap = 2 * kQT;
+    }
     if (m->ok_cap < 1024) {
         if (m->ok) GEMM_HIP(hipFree(m->ok));
         m->ok = nullptr;
@@ -1992,12 +2048,16 @@ int fir_gemm_search_few_keys_dev(fir_gemm* m, const float* d_queries, int32_t qb
     if (m->mfma16) hipLaunchKernelGGL(k_gemm_pack_queries_f16x, dim3((4 * m->dk16 * 64 + 255) / 256, 1), dim3(256), 0, st, d_queries, qb, d, m->dk16, m->qmul[b], m->qbf[b], qs);
     else hipLaunchKernelGGL(k_gemm_pack_queries_f16, dim3((4 * m->dk16 * 64 + 255) / 256, 1), dim3(256), 0, st, d_queries, qb, d, m->dk16, m->qmul[b], m->qbf[b], qs);
     GEMM_HIP(hipMemsetD32Async((hipDeviceptr_t)m->smin[b], (int)0xFF800000u, 2 * kQT, st));
-    const int nqt = qb <= 1 ? 1 : qb <= 2 ? 2 : qb <= 4 ? 4 : 8;
     const dim3 grid((unsigned)std::min<int64_t>((int64_t)m->v.cus * 8, ((n + 31) / 32 + 3) / 4));
     const size_t lds = (size_t)m->dk16 * 2 * nqt * sizeof(uint4);
 #define FIR_FEW(NQ) do { if (m->mfma16) hipLaunchKernelGGL(k_gemm_scan_f16x<NQ>, grid, dim3(256), lds, st, m->gh, m->gnorm, m->qbf[b], m->qinv[b], n, m->dk16, m->proxies, m->smin[b]); \
                          else hipLaunchKernelGGL(k_gemm_scan_f16<NQ>, grid, dim3(256), lds, st, m->gh, m->gnorm, m->qbf[b], m->qinv[b], n, m->dk16, m->proxies, m->smin[b]); } while (0)
-    if (nqt == 1) FIR_FEW(1); else if (nqt == 2) FIR_FEW(2); else if (nqt == 4) FIR_FEW(4); else FIR_FEW(8);
+    {
+        int rcp = fir_gallery_profile_begin_(m->g, st);              // (no-ops unless profiling is on: a profiled run takes the same path as an unprofiled one)
+        if (rcp) return rcp;
+        if (nqt == 1) FIR_FEW(1); else if (nqt == 2) FIR_FEW(2); else if (nqt == 4) FIR_FEW(4); else FIR_FEW(8);
+        if ((rcp = fir_gallery_profile_end_(m->g, st, (double)((n + 31) / 32) * m->dk16 * 1024.0 + (double)nqt * n * 4.0))) return rcp;
+    }
 #undef FIR_FEW
     fir_gallery_note_dispatch_(m->g, nqt == 1 ? (const void*)k_gemm_scan_f16<1> : nqt == 2 ? (const void*)k_gemm_scan_f16<2> : nqt == 4 ? (const void*)k_gemm_scan_f16<4>
                                                                                                                                              : (const void*)k_gemm_scan_f16<8>,

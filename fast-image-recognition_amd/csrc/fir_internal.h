@@ -67,6 +67,12 @@ struct fir_gemm;
 // upload under the previous super-batch's full passes.
 extern "C" int fir_gemm_search_staged_(fir_gemm* m, const float* h_queries, float* d_stage, int32_t qb, int32_t k, uint64_t* d_keys, void* stream);
 
+// fir_gemm_create_range with the re-rank's row-major shadow copy decided by the caller: -1 = when HBM has room for it (or as
+// FIR_GEMM_ROWMAJOR says), 0 = never, 1 = whenever it can be allocated.
+extern "C" int fir_gemm_create_range_ex_(fir_gallery* g, int32_t precision, int32_t end_pos, int32_t rowmajor_mode, fir_gemm** out);
+// device bytes one matrix-core state holds: the fp16 (bf16 / f32) fragment copy, the row-major shadow, everything else (scratch)
+extern "C" void fir_gemm_memory_bytes_(const fir_gemm* m, int64_t* fragments, int64_t* rowmajor, int64_t* scratch);
+
 struct fir_cls;
 extern "C" int fir_cls_pnn_scores_dev_(fir_cls* c, const double* queries, int32_t qb, double var, double** d_scores, void** stream, int32_t* max_batch);
 extern "C" int fir_cls_knn_nearest_dev_(fir_cls* c, const double* queries, int32_t qb, int32_t k, double** d_lists, void** stream, int32_t* max_batch);

@@ -274,6 +274,18 @@ int fir_gemm_search_topk_keys_dev(fir_gemm* m, const float* d_queries, int32_t q
 int fir_gallery_set_large_batch_mfma(fir_gallery* g, int32_t min_queries);
 /* passes = 64-query GEMM passes run so far, fallback_queries = queries answered by the exact scan instead. */
 int fir_gemm_stats(const fir_gemm* m, int64_t* passes, int64_t* fallback_queries);
+/* The same counters for the matrix-core states a gallery's AUTOMATIC dispatch has built (whole rows and feature prefixes),
+ * summed: fallback_queries = queries it could not certify and sent through the exact scan (results identical either way). */
+int fir_gallery_mfma_stats(fir_gallery* g, int64_t* passes, int64_t* fallback_queries);
+/* HBM held by a gallery handle, in bytes: the tiled f32 rows (+ labels), the fp16 fragment copies the automatic dispatch has
+ * made (0.5 x the rows each; one per feature prefix in use), the row-major f32 shadow copies the exact re-rank gathers from
+ * (1 x the rows; made only when four times their size was free), and all other scratch. Any pointer may be NULL. */
+int fir_gallery_memory_bytes(fir_gallery* g, int64_t* tiled, int64_t* fp16_fragments, int64_t* rowmajor_shadow, int64_t* scratch);
+/* Which copies of the gallery the automatic dispatch may keep next to the tiled rows: FIR_SHADOW_ALL (default), FIR_SHADOW_FP16
+ * (fragments only: the re-rank gathers from the tiled rows), FIR_SHADOW_NONE (none: every call takes the exact scan, like
+ * fir_gallery_set_large_batch_mfma(g, 0)). Takes effect for states built afterwards; existing ones are dropped. */
+enum { FIR_SHADOW_NONE = 0, FIR_SHADOW_FP16 = 1, FIR_SHADOW_ALL = 2 };
+int fir_gallery_set_shadow_copies(fir_gallery* g, int32_t mode);
 
 /* ---- one gallery sharded by rows over several GPUs (BASELINE.json configs[3]) -----------------
  * The reference is single threaded and single device; this is how BruteForce::recognize (ann.cpp:113-126) and
@@ -381,6 +393,10 @@ typedef struct fir_dispatch_info {
     int32_t queries_per_pass; /* queries that share one read of the gallery */
     double bytes_per_launch;  /* algorithmic HBM bytes of one launch */
     double flops_per_launch;  /* matrix-core path: 2 * rows * d * queries of one launch; 0 for the scan */
+    int32_t warmup_calls_left; /* automatic dispatch, small-saving cases (cache-resident galleries, one-query calls): the matrix-core
+                               * state is built only for a gallery that keeps getting such calls; > 0 = this call was one of the
+                               * first few and took the scan, this many more will; 0 = steady state */
+    int32_t reserved;
 } fir_dispatch_info;
 int fir_gallery_last_dispatch(fir_gallery* g, fir_dispatch_info* out);
 

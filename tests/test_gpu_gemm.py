@@ -465,3 +465,39 @@ def test_default_dispatch_on_cache_resident_galleries(fir, oracle):
             e = g.search_top1(q)
         assert np.array_equal(a[0], e[0]) and np.array_equal(a[1].view(np.uint32), e[1].view(np.uint32)), (n, d, qb)
         assert (a[0][0], a[1][0]) == oracle.recognize_bf(rows, q[0], 0, d, 0)
+
+
+def test_memory_report_shadow_modes_and_the_two_prefix_states(fir):
+    """fir_gallery_memory_bytes / fir_gallery_set_shadow_copies / fir_gallery_mfma_stats: the automatic dispatch's
+    copies are reported and can be forbidden; alternating prefixes [0, 64) and [0, 256) -- the reference's "BF, 64" / "BF, 256"
+    classifiers, ImageTesting.cpp:526-529 -- keep both matrix-core states instead of rebuilding one slot on every call; the
+    candidate lists are sized by the batches actually seen. Keys stay the exact scan's in every mode."""
+    n, d, qb = 70000, 320, 192
+    rows = synth.make_gallery(71, n, d, 0)
+    q, _ = synth.make_queries(71, rows, qb, 0)
+    with fir.Gallery(rows, None, 0, 0) as g:
+        g.set_large_batch_mfma(0)
+        ref = {end: g.search_top1(q, 0, end) for end in (64, 256)}
+        g.set_large_batch_mfma(-1)
+        mem0 = g.memory_bytes()
+        assert mem0["tiled"] >= n * d * 4 and mem0["fp16_fragments"] == 0 and mem0["rowmajor_shadow"] == 0
+        for mode, want_shadow in ((fir.SHADOW_ALL, True), (fir.SHADOW_FP16, False)):
+            g.set_shadow_copies(mode)
+            for rep in range(3):
+                for end in (64, 256):
+                    idx, dist = g.search_top1(q, 0, end)
+                    assert g.last_dispatch()["path"] == "mfma"
+                    assert np.array_equal(idx, ref[end][0]) and np.array_equal(dist.view(np.uint32), ref[end][1].view(np.uint32))
+            mem = g.memory_bytes()
+            # both prefix states are alive: two fragment copies, padded to 128-feature units ([0, 64) -> 128, [0, 256) -> 256)
+            assert n * (256 + 128) * 2 <= mem["fp16_fragments"] <= n * (256 + 128) * 2 * 1.01 + 4096, mem
+            assert (mem["rowmajor_shadow"] >= n * (256 + 64) * 4) == want_shadow, mem
+            assert mem["scratch"] < 96 << 20, mem            # two states with lists for 256 queries each (8 MiB), not for 8192 (512 MiB each)
+            st = g.mfma_stats()
+            assert st["passes"] > 0 and st["fallback_queries"] <= 8
+        passes_before = g.mfma_stats()["passes"]
+        g.set_shadow_copies(fir.SHADOW_NONE)
+        idx, dist = g.search_top1(q, 0, 256)
+        assert g.last_dispatch()["path"] == "scan" and np.array_equal(idx, ref[256][0])
+        assert np.array_equal(dist.view(np.uint32), ref[256][1].view(np.uint32))
+        assert g.memory_bytes()["fp16_fragments"] == 0 and g.mfma_stats()["passes"] == 0 and passes_before > 0
