@@ -107,6 +107,8 @@ SYMBOLS = [
     ("fir_gallery_set_tuning", C.c_int, [_vp, C.c_int32, C.c_int32]),
     ("fir_gallery_value_range", C.c_int, [_vp, _i32p, _i32p]),
     ("fir_gallery_get_tuning", C.c_int, [_vp, _i32p, _i32p, _i32p]),
+    ("fir_cls_profile_enable", C.c_int, [_vp, C.c_int32]),
+    ("fir_cls_profile_read", C.c_int, [_vp, _vp, C.c_int32, _i32p, C.POINTER(C.c_double), C.c_char_p, C.c_int32]),
     ("fir_gallery_mfma_stats", C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("fir_gallery_memory_bytes", C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("fir_gallery_set_shadow_copies", C.c_int, [_vp, C.c_int32]),
@@ -671,6 +673,16 @@ class ClsModel:
     def _q(self, queries):
         q = np.ascontiguousarray(queries, dtype=np.float64).reshape(-1, self.d)
         return q, q.ctypes.data_as(_vp)
+
+    def profile_enable(self, on=True):
+        _check(lib().fir_cls_profile_enable(self._h, 1 if on else 0))
+
+    def profile_read(self, cap=4096):
+        ms = np.empty(cap, np.float32)
+        cnt, nb = C.c_int32(), C.c_double()
+        name = C.create_string_buffer(64)
+        _check(lib().fir_cls_profile_read(self._h, ms.ctypes.data_as(_vp), cap, C.byref(cnt), C.byref(nb), name, 64))
+        return ms[: min(cnt.value, cap)].copy(), nb.value, name.value.decode()
 
     def set_total_training_size(self, total):
         _check(lib().fir_cls_set_total_training_size(self._h, int(total)))

@@ -18,6 +18,7 @@
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -134,6 +135,116 @@ __global__ void __launch_bounds__(kBlock) k_cls_scan(const double2* __restrict__
         }
       }
     }
+}
+
+// ---- the whole-range scan of a training set streamed from HBM (K3 at scale: 1M x 512 doubles = 4.1 GB per pass) ----
+// k_cls_scan above is the compiler-scheduled form: four double2 loads in flight per lane and the query values through the
+// scalar cache -- eight queries x 512 features x 8 B = 32 KiB per tile against a 16 KiB scalar cache that every wave of the
+// CU walks at its own pace: the same thrash profiles/r01_sweep_notes.md found in k_scan_l2_fast. At eight queries per pass it
+// reached 47 % of the HBM rate with the f64 pipes a third busy. This is k_scan_l2_lds's structure in double precision:
+//   * the query tile (8 queries x dp2 * 2 features, q - avg) sits in LDS, [feature][query]; a feature's eight values are four
+//     ds_read_b128 at one address for all lanes (a broadcast), read one feature ahead of the arithmetic;
+//   * the training rows stream tile -> VGPR with non-temporal 16-byte loads, a register double buffer of U double2 per lane
+//     (U = 8: 8 KiB per wave in flight behind the group being consumed);
+//   * per (feature, query): v_add_f64 (the subtraction), v_mul_f64, v_add_f64 -- un-fused, in feature order, exactly the
+//     reference's evaluation order (classification.cpp:132-141): the sums are the same bits as k_cls_scan's and the oracle's;
+//   * all query tiles of a call go into ONE launch (blockIdx.y = tile of eight queries): consecutive passes run back to back
+//     on the chip instead of draining at a launch boundary each.
+// Padding features (k >= d) are +0 on both sides: diff * diff = +0 added to a non-negative sum leaves its bits alone.
+// Dynamic LDS: (dp2 * 2 + 1) * 8 doubles.
+__device__ __forceinline__ double2 cls_ld_nt(const double2* p) {
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    const v2d v = __builtin_nontemporal_load((const v2d*)p);
+    return make_double2(v.x, v.y);
+}
+template <int kClsU>
+__global__ void __launch_bounds__(kBlock, 4) k_cls_scan_lds(const double2* __restrict__ gal2, const double* __restrict__ qn_tiles, int64_t nt, int tiles,
+                                                             int dp2, int waves, int nq_total, double* __restrict__ sums_base) {
+    extern __shared__ __attribute__((aligned(16))) double2 lqd[];          // [(feature k) * 4 + i] = queries 2i, 2i + 1 of feature k
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const int kk = dp2 * 2;
+    {
+        const double2* src = (const double2*)(qn_tiles + (size_t)blockIdx.y * kk * 8);
+        const int n2 = kk * 4;
+        for (int i = threadIdx.x; i < n2 + 4; i += kBlock) lqd[i] = i < n2 ? src[i] : make_double2(0.0, 0.0);
+        __syncthreads();
+    }
+    // (as k_scan_l2_lds: an LDS base the compiler cannot prove uniform keeps the reads on one address register + immediate offsets)
+    int zero_v;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(zero_v));
+    const double2* lq = lqd + zero_v;
+    const int q0 = (int)blockIdx.y * 8;
+    const int nq = nq_total - q0 < 8 ? nq_total - q0 : 8;
+    double* sums = sums_base + (size_t)q0 * nt;
+    for (int t = gw; t < tiles; t += waves) {
+        const double2* p = gal2 + (size_t)t * dp2 * 64 + lane;
+        double acc[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] = 0.0;
+        double2 cur[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) cur[i] = lq[i];
+        // one chunk (two features) of this lane against the eight queries; the LDS reads run one feature ahead
+        auto chunk = [&](const double2 g, int c) {
+            const double gv[2] = {g.x, g.y};
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                double2 nx[4];
+                const int k1 = c * 2 + j + 1;                                   // (past the last feature: the zeroed slack)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) nx[i] = lq[k1 * 4 + i];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const double d0 = gv[j] - cur[i].x;                         // classification.cpp:132-137
+                    const double d1 = gv[j] - cur[i].y;
+                    acc[2 * i] = acc[2 * i] + d0 * d0;                          // :141
+                    acc[2 * i + 1] = acc[2 * i + 1] + d1 * d1;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) cur[i] = nx[i];
+            }
+        };
+        int c = 0;
+        const int ng = dp2 / kClsU;
+        double2 g[kClsU];
+        if (ng > 0) {
+#pragma unroll
+            for (int u = 0; u < kClsU; ++u) g[u] = cls_ld_nt(p + (size_t)u * 64);
+        }
+        for (int gi = 0; gi < ng; ++gi, c += kClsU) {
+            double2 nxg[kClsU];
+            const int gn = gi + 1 < ng ? gi + 1 : gi;                           // the last group re-reads itself (keeps the loop branch-free)
+#pragma unroll
+            for (int u = 0; u < kClsU; ++u) nxg[u] = cls_ld_nt(p + (size_t)(gn * kClsU + u) * 64);
+#pragma unroll
+            for (int u = 0; u < kClsU; ++u) chunk(g[u], c + u);
+#pragma unroll
+            for (int u = 0; u < kClsU; ++u) g[u] = nxg[u];
+        }
+        for (; c < dp2; ++c) chunk(cls_ld_nt(p + (size_t)c * 64), c);
+        const int64_t row = (int64_t)t * kTileRows + lane;
+        if (row < nt) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (q < nq) sums[(size_t)q * nt + row] = acc[q];
+        }
+    }
+}
+
+// queries[nq][d] -> tiles of eight: qn[tile][k][8] = q[k] - avg[k], zero padded (the query side of normalize(), :135)
+__global__ void __launch_bounds__(kBlock) k_cls_prep_query_tiles(const double* __restrict__ q, int nq, int d, int dp2, const double* __restrict__ avg,
+                                                                  double* __restrict__ qn) {
+    const int kk = dp2 * 2;
+    const int64_t o = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t ntile = (nq + 7) / 8;
+    if (o >= ntile * kk * 8) return;
+    const int qi8 = (int)(o & 7);
+    const int k = (int)((o >> 3) % kk);
+    const int64_t tile = (o >> 3) / kk;
+    const int64_t qi = tile * 8 + qi8;
+    qn[o] = (qi < nq && k < d) ? q[qi * d + k] - avg[k] : 0.0;
 }
 
 // The same sums for ONE query (the reference's predict() per test vector, ~3 000 x 256 training rows): such a call is
@@ -502,13 +613,18 @@ struct fir_cls {
     int32_t* class_off = nullptr;
     hipStream_t stream = nullptr;
     double* dq = nullptr; size_t dq_cap = 0;
-    double* qn = nullptr;
+    double* qn = nullptr; size_t qn_cap = 0;
     double* sums = nullptr; size_t sums_cap = 0;
     double* scores = nullptr; size_t scores_cap = 0;
     int32_t* best = nullptr; size_t best_cap = 0;
     void* pin = nullptr;              // pinned, device-visible staging of small calls: queries in, classes (+ chunk counts) out
     unsigned long long ticket = 0;    // one-query calls so far: the word the host waits for
     double total_training_size = 0;   // 0: nt. PNNwithClustering keeps the full size as denominator (classification.cpp:390,393)
+    bool profiling = false;           // fir_cls_profile_enable: HIP event pairs around the launches of the distance scan
+    std::vector<hipEvent_t> ev;
+    size_t ev_used = 0;
+    double last_bytes = 0.0;          // algorithmic bytes of the last timed launch
+    char last_kernel[64] = "";
 };
 
 extern "C" void fir_set_last_error_(const char* msg);   // fir_capi.hip: feeds fir_last_error()
@@ -532,6 +648,26 @@ int cls_fail(int code, const char* fmt, ...) {
         if (e_ != hipSuccess) return cls_fail(e_ == hipErrorOutOfMemory ? FIR_ERR_NOMEM : FIR_ERR_HIP,        \
                                               "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
+
+// HIP event pair around one launch of the distance scan (no-ops unless fir_cls_profile_enable is on)
+void cls_prof(fir_cls* c, int end, double bytes, const char* kernel) {
+    if (!c->profiling) return;
+    if (!end && c->ev_used + 2 > c->ev.size())
+        for (int i = 0; i < 64; ++i) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return;
+            c->ev.push_back(e);
+        }
+    if (c->ev_used + 2 > c->ev.size()) return;
+    if (!end) {
+        (void)hipEventRecord(c->ev[c->ev_used], c->stream);
+    } else {
+        (void)hipEventRecord(c->ev[c->ev_used + 1], c->stream);
+        c->ev_used += 2;
+        c->last_bytes = bytes;
+        if (kernel) std::snprintf(c->last_kernel, sizeof c->last_kernel, "%s", kernel);
+    }
+}
 
 template <typename T>
 int cls_grow(T*& p, size_t& cap, size_t need) {
@@ -606,6 +742,27 @@ int cls_scan(fir_cls* c, const double* queries, int32_t qb) {
     if (qb == 1 && !big) {
         hipLaunchKernelGGL(k_cls_scan_one, dim3(waves / 4), dim3(kBlock), (size_t)kk * sizeof(double), c->stream, c->gal2, dq, c->avg, c->nt,
                            (int)c->tiles, c->dp2, c->d, waves, 0, c->dp2, c->sums, c->dp2, (int64_t)0);
+        CLS_HIP(hipGetLastError());
+        return FIR_OK;
+    }
+    const size_t lds_tile = (size_t)(kk + 1) * 8 * sizeof(double);
+    if (big && lds_tile <= 64 * 1024) {
+        // the LDS-tile scan: every tile of eight queries in ONE launch (blockIdx.y), at most 64 tiles per launch
+        const int ntile = (qb + 7) / 8;
+        if ((rc = cls_grow(c->qn, c->qn_cap, (size_t)ntile * kk * 8))) return rc;
+        hipLaunchKernelGGL(k_cls_prep_query_tiles, dim3((unsigned)(((size_t)ntile * kk * 8 + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, dq, qb, c->d,
+                           c->dp2, c->avg, c->qn);
+        // four waves per SIMD (launch bounds; 33 KiB of LDS per workgroup at d = 512). Measured at 1M x 512, eight passes per launch
+        // (profiles/r03_k3_sweep.txt): 16 / 12 / 8 waves per CU 5.65 / 5.78 / 5.95 ms; 4 or 8 double2 in flight per lane the same, 16 spills
+        const int wv = (int)std::min<int64_t>(std::max<int64_t>((c->tiles + 3) / 4 * 4, 4), (int64_t)c->cus * 16);
+        for (int t0 = 0; t0 < ntile; t0 += 64) {
+            const int tn = std::min(64, ntile - t0);
+            cls_prof(c, 0, 0.0, nullptr);
+            hipLaunchKernelGGL(k_cls_scan_lds<8>, dim3(wv / 4, tn), dim3(kBlock), lds_tile, c->stream, c->gal2, c->qn + (size_t)t0 * kk * 8, c->nt, (int)c->tiles,
+                               c->dp2, wv, qb - t0 * 8, c->sums + (size_t)t0 * 8 * c->nt);
+            // algorithmic bytes of the launch: every tile of eight queries reads the training rows once (+ its query tile, + the sums it writes)
+            cls_prof(c, 1, (double)tn * ((double)c->tiles * 64.0 * c->dp2 * 16.0 + (double)kk * 64.0 + 8.0 * 8.0 * (double)c->nt), "fir::k_cls_scan_lds");
+        }
         CLS_HIP(hipGetLastError());
         return FIR_OK;
     }
@@ -684,6 +841,7 @@ static int cls_create(const double* train_rows, bool rows_on_device, int64_t nt,
     if (e == hipSuccess) e = hipMalloc((void**)&c->gal2, g2 * sizeof(double2));
     if (e == hipSuccess) e = hipMalloc((void**)&c->avg, (size_t)d * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&c->qn, (size_t)c->dp2 * 2 * kQBBig * sizeof(double));
+    if (e == hipSuccess) c->qn_cap = (size_t)c->dp2 * 2 * kQBBig;
     if (e == hipSuccess) e = hipMalloc((void**)&c->class_off, ((size_t)num_classes + 1) * sizeof(int32_t));
     if (e == hipSuccess) e = hipMemcpy(c->avg, avg, (size_t)d * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(c->class_off, off.data(), off.size() * sizeof(int32_t), hipMemcpyHostToDevice);
@@ -711,10 +869,35 @@ int fir_cls_set_total_training_size(fir_cls* c, int64_t total) {
     return FIR_OK;
 }
 
+int fir_cls_profile_enable(fir_cls* c, int32_t on) {
+    if (!c) return cls_fail(FIR_ERR_ARG, "NULL argument");
+    c->profiling = on != 0;
+    c->ev_used = 0;
+    return FIR_OK;
+}
+
+int fir_cls_profile_read(fir_cls* c, float* ms, int32_t cap, int32_t* count, double* bytes_per_launch, char* kernel, int32_t kernel_cap) {
+    if (!c) return cls_fail(FIR_ERR_ARG, "NULL argument");
+    CLS_HIP(hipSetDevice(c->device));
+    const int32_t have = (int32_t)(c->ev_used / 2);
+    for (int32_t i = 0; i < have; ++i) {
+        CLS_HIP(hipEventSynchronize(c->ev[2 * (size_t)i + 1]));
+        float t = 0.f;
+        CLS_HIP(hipEventElapsedTime(&t, c->ev[2 * (size_t)i], c->ev[2 * (size_t)i + 1]));
+        if (ms && i < cap) ms[i] = t;
+    }
+    if (count) *count = have;
+    if (bytes_per_launch) *bytes_per_launch = c->last_bytes;
+    if (kernel && kernel_cap > 0) std::snprintf(kernel, (size_t)kernel_cap, "%s", c->last_kernel);
+    c->ev_used = 0;
+    return FIR_OK;
+}
+
 int fir_cls_destroy(fir_cls* c) {
     if (!c) return FIR_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     (void)hipFree(c->gal2); (void)hipFree(c->avg); (void)hipFree(c->class_off); (void)hipFree(c->dq); (void)hipFree(c->qn);
     (void)hipFree(c->sums); (void)hipFree(c->scores); (void)hipFree(c->best);
     if (c->pin) (void)hipHostFree(c->pin);

@@ -160,6 +160,11 @@ int fir_cls_create(const double* train_rows, int64_t nt, int32_t d, const int32_
 int fir_cls_create_dev(const double* d_train_rows, int64_t nt, int32_t d, const int32_t* train_class, int32_t num_classes,
                        const double* avg, int32_t device, fir_cls** out);
 int fir_cls_destroy(fir_cls* c);
+/* HIP event pairs around the launches of the float64 distance scan (on the handle's stream); fir_cls_profile_read waits for
+ * them and returns their durations (ms) since the previous read, the algorithmic bytes of the last one (training rows once per
+ * tile of eight queries + the query tiles + the sums written) and the kernel's name. */
+int fir_cls_profile_enable(fir_cls* c, int32_t on);
+int fir_cls_profile_read(fir_cls* c, float* ms, int32_t cap, int32_t* count, double* bytes_per_launch, char* kernel, int32_t kernel_cap);
 /* PNNwithClusteringClassifier::predict (classification.cpp:389-428) runs the PNN over the medoid rows
  * only but still divides by the FULL training size: set it here (0 = the number of rows held). */
 int fir_cls_set_total_training_size(fir_cls* c, int64_t total);
