@@ -501,3 +501,49 @@ def test_memory_report_shadow_modes_and_the_two_prefix_states(fir):
         assert g.last_dispatch()["path"] == "scan" and np.array_equal(idx, ref[256][0])
         assert np.array_equal(dist.view(np.uint32), ref[256][1].view(np.uint32))
         assert g.memory_bytes()["fp16_fragments"] == 0 and g.mfma_stats()["passes"] == 0 and passes_before > 0
+
+
+def _coherent_rounding_fixture(n_random=6000, d=512, seed=91):
+    """A near-tie the fp16 proxy orders the WRONG way by almost the whole error bound: every component of row A (and of the query)
+    is 1 + 0.499 * 2^-10 -- rounds DOWN to 1 in fp16 -- and every component of row B is 1 + 0.501 * 2^-10 -- rounds UP to 1 + 2^-10.
+    A is the query itself (distance exactly 0), B lies 2e-9 / d away; but B's proxy is LOWER than A's by 2 * 2^-10 * |q||g| * 0.998
+    (all 2 d rounding errors have the same sign), 0.77 of the rounding window 2 E d the re-rank allows for. Random rows far away
+    fill the rest of the gallery (values in [0, 1): the power-of-two scale is the same as for A and B)."""
+    rng = np.random.default_rng(seed)
+    rows = rng.random((n_random, d), dtype=np.float32)
+    a = np.full(d, np.float32(1.0) + np.float32(0.499 * 2.0 ** -10), np.float32)
+    b = np.full(d, np.float32(1.0) + np.float32(0.501 * 2.0 ** -10), np.float32)
+    ia, ib = n_random // 3, 2 * n_random // 3 + 5
+    rows[ia], rows[ib] = a, b
+    q = np.vstack([a] + [rows[i] * np.float32(0.999) for i in (7, 99, 1234)] + [rng.random(d, dtype=np.float32) for _ in range(60)]).astype(np.float32)
+    return rows, q, ia, ib
+
+
+def test_the_certificate_bound_is_needed_and_a_shrunken_one_is_caught(fir, oracle, monkeypatch):
+    """the suite must be able to SEE an unsound error bound. With the bound as derived the
+    coherent-rounding near-tie is answered exactly (both rows are inside the rounding window, both are re-ranked, the reference's
+    first minimum wins); with FIR_GEMM_EREL_SCALE=0.25 -- an audit knob that multiplies the certificate's E -- row A falls out of
+    the window, the certificate 'proves' B and the call returns the wrong row WITHOUT falling back: exactly the failure the bound
+    exists to prevent, and this test goes red if it ever stops being detected."""
+    rows, q, ia, ib = _coherent_rounding_fixture()
+    d = rows.shape[1]
+    dev = torch.device("cuda", 0)
+    tq = torch.from_numpy(q).to(dev)
+    keys = torch.empty(q.shape[0], dtype=torch.int64, device=dev)
+    with fir.Gallery(rows, None, 0, 0) as g:
+        g.set_large_batch_mfma(0)
+        eidx, edist = g.search_top1(q)
+        assert eidx[0] == ia and edist[0] == 0.0 and (eidx[0], edist[0]) == oracle.recognize_bf(rows, q[0], 0, d, 0)
+        got = {}
+        for scale in ("1", "0.25", "0"):
+            monkeypatch.setenv("FIR_GEMM_EREL_SCALE", scale)
+            with fir.GemmSearch(g, 2) as m:
+                m.search_top1_keys_dev(tq.data_ptr(), q.shape[0], keys.data_ptr())
+                torch.cuda.synchronize()
+                got[scale] = (fir.keys_unpack(keys.cpu().numpy().view(np.uint64)), m.stats()["fallback_queries"])
+        monkeypatch.delenv("FIR_GEMM_EREL_SCALE")
+    (idx, dist), fb = got["1"]
+    assert np.array_equal(idx, eidx) and np.array_equal(dist.view(np.uint32), edist.view(np.uint32)) and fb <= 2
+    for scale in ("0.25", "0"):
+        (idx_s, dist_s), fb_s = got[scale]
+        assert idx_s[0] == ib and dist_s[0] > 0.0, (scale, idx_s[0], dist_s[0], fb_s)      # the wrong row, certified: the shrunken bound is unsound and it shows
