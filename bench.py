@@ -902,7 +902,7 @@ def pmc_traffic(args, n, d, world):
                         continue                     # (the config-2 launches are not the headline's)
                     if "k_scan_l2" in kn:
                         vals["scan"].append(float(r["Counter_Value"]))
-                    elif "k_gemm_proxy_f16" in kn and ("<1," in kn or "false>" in kn):
+                    elif "k_gemm_proxy_f16" in kn and ("<1," in kn or "<3," in kn or "false>" in kn):
                         vals["mfma"].append(float(r["Counter_Value"]))
             cfg2 = None
             if all(i in seg_bytes for i in (0, 1, 3, 4)):

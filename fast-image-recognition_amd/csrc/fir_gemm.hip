@@ -1412,6 +1412,25 @@ __global__ void k_gemm_max(const float* __restrict__ gnorm, int64_t n, float* __
     if (threadIdx.x == 0) out[0] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
+// The adaptive flow (k_gemm_proxy_f16x<3, *>): per query the rounding window (2.5 E d, as k_gemm_tau_min) and the start value of
+// T -- +inf, or 0 for the padding queries of a half-filled pair (nothing is ever below it) ...
+__global__ void __launch_bounds__(256) k_gemm_adapt_init(float* __restrict__ win, unsigned int* __restrict__ t_bits, int nq_total, int nq_valid,
+                                                          const float* __restrict__ qnorm, const float* __restrict__ gnorm_max_p, float e_rel) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= nq_total) return;
+    if (q >= nq_valid) { win[q] = 0.f; t_bits[q] = 0u; return; }
+    const float w = 2.5f * e_rel * (qnorm[q] + gnorm_max_p[0]);
+    win[q] = w + fabsf(w) * 1e-6f + 1e-30f;                   // (a NaN window: T never falls, nothing is certified)
+    t_bits[q] = 0x7F800000u;
+}
+// ... and, after the pass, the bound the re-rank's certificate gets: every row that was not appended has a proxy >= tau
+__global__ void __launch_bounds__(256) k_gemm_adapt_final(const unsigned int* __restrict__ t_bits, const float* __restrict__ qnorm, float* __restrict__ tau,
+                                                           int nq_total, int nq_valid) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= nq_total) return;
+    tau[q] = q < nq_valid ? __uint_as_float(t_bits[q]) - qnorm[q] : -__builtin_huge_valf();      // the same subtraction the kernel compares against
+}
+
 }  // namespace
 
 struct fir_gemm {
@@ -1460,6 +1479,10 @@ struct fir_gemm {
     int regtile = -1;                     // fp16 full pass through the register-tile kernel: -1 = where it measured faster (rows up to 256 features), 0 / 1 = never / wherever it exists (FIR_GEMM_REGTILE)                  // fp16 full pass: query fragments in registers, gallery through the LDS-DMA ring (FIR_GEMM_REGTILE=0: the LDS-tile kernel)
     int mfma16 = 0;                       // fp16: both operands in the 16-row fragment order, every pass on v_mfma_f32_16x16x32_f16 (fir_gemm_f16x.h): the default since it was
                                           // measured against the 32x32x16 kernels at the same wave tile (profiles/r03_mfma_shape_ab.txt); FIR_GEMM_MFMA16=0 brings those back
+    int adaptive = -1;                    // 16-row top-1 flow: the append threshold is found during the full pass (k_gemm_proxy_f16x<3, *>), no sample pass: -1 = where it measured
+                                          // faster (rows of 512 features and more: profiles/r03_adaptive_threshold.txt), 0 / 1 = never / always (FIR_GEMM_ADAPTIVE)
+    float* awin[2] = {nullptr, nullptr};  // ... its per-query windows
+    unsigned int* aT[2] = {nullptr, nullptr};   // ... and the ranks' shared T (float bits)
     float erel_scale = 1.0f;              // AUDIT KNOB, never set in production: the certificate's relative error bound is multiplied by this (FIR_GEMM_EREL_SCALE);
                                           // tests/test_gpu_gemm.py shows that a bound shrunk to a quarter returns a wrong row on a crafted near-tie, i.e. that the suite can see an unsound bound
     int stagger = 0;                      // mfma16 experiment: the second wave of every SIMD starts half a unit late (FIR_GEMM_STAGGER)
@@ -1474,9 +1497,11 @@ typedef void (*fir_x_fn)(const uint4*, const float*, const uint4*, const float*,
                          int, int, int, int, unsigned int*, int);
 static fir_x_fn pick_x(int mode, bool streamed, bool odd) {
     if (mode == 1) return streamed ? (odd ? k_gemm_proxy_f16x<1, 1, 1> : k_gemm_proxy_f16x<1, 1, 0>) : (odd ? k_gemm_proxy_f16x<1, 0, 1> : k_gemm_proxy_f16x<1, 0, 0>);
+    if (mode == 3) return streamed ? (odd ? k_gemm_proxy_f16x<3, 1, 1> : k_gemm_proxy_f16x<3, 1, 0>) : (odd ? k_gemm_proxy_f16x<3, 0, 1> : k_gemm_proxy_f16x<3, 0, 0>);
     return streamed ? (odd ? k_gemm_proxy_f16x<2, 1, 1> : k_gemm_proxy_f16x<2, 1, 0>) : (odd ? k_gemm_proxy_f16x<2, 0, 1> : k_gemm_proxy_f16x<2, 0, 0>);
 }
-static const char* name_x(bool streamed, bool odd) {
+static const char* name_x(bool streamed, bool odd, bool adaptive = false) {
+    if (adaptive) return streamed ? (odd ? "fir::k_gemm_proxy_f16x<3, 1, 1>" : "fir::k_gemm_proxy_f16x<3, 1, 0>") : (odd ? "fir::k_gemm_proxy_f16x<3, 0, 1>" : "fir::k_gemm_proxy_f16x<3, 0, 0>");
     return streamed ? (odd ? "fir::k_gemm_proxy_f16x<1, 1, 1>" : "fir::k_gemm_proxy_f16x<1, 1, 0>") : (odd ? "fir::k_gemm_proxy_f16x<1, 0, 1>" : "fir::k_gemm_proxy_f16x<1, 0, 0>");
 }
 
@@ -1545,6 +1570,8 @@ int fir_gemm_create_range_ex_(fir_gallery* g, int32_t precision, int32_t end_pos
         if (e == hipSuccess) e = hipMalloc((void**)&m->qinv[b], kPasses * kQT * sizeof(float));
         if (e == hipSuccess) e = hipMalloc((void**)&m->smin[b], (size_t)kRtSubsets * kPasses * kQT * sizeof(unsigned int));   // top-K: one minimum per subset
         if (e == hipSuccess) e = hipMalloc((void**)&m->tau[b], kPasses * kQT * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc((void**)&m->awin[b], kPasses * kQT * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc((void**)&m->aT[b], kPasses * kQT * sizeof(unsigned int));
         if (e == hipSuccess) e = hipEventCreateWithFlags(&m->main_done[b], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&m->rerank_done[b], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&m->prep_done[b], hipEventDisableTiming);
@@ -1587,11 +1614,13 @@ int fir_gemm_create_range_ex_(fir_gallery* g, int32_t precision, int32_t end_pos
 #undef FIR_RT_ATTR
 #define FIR_X_ATTR(M, S, O) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy_f16x<M, S, O>, hipFuncAttributeMaxDynamicSharedMemorySize, kHalfLds);
     FIR_X_ATTR(1, 0, 0) FIR_X_ATTR(1, 0, 1) FIR_X_ATTR(1, 1, 0) FIR_X_ATTR(1, 1, 1) FIR_X_ATTR(2, 0, 0) FIR_X_ATTR(2, 0, 1) FIR_X_ATTR(2, 1, 0) FIR_X_ATTR(2, 1, 1)
+    FIR_X_ATTR(3, 0, 0) FIR_X_ATTR(3, 0, 1) FIR_X_ATTR(3, 1, 0) FIR_X_ATTR(3, 1, 1)
 #undef FIR_X_ATTR
     m->mfma16 = precision == FIR_GEMM_F16;
     if (const char* w = std::getenv("FIR_GEMM_MFMA16")) m->mfma16 = std::atoi(w) != 0 && precision == FIR_GEMM_F16;
     if (const char* w = std::getenv("FIR_GEMM_STAGGER")) m->stagger = std::atoi(w) != 0;
     if (const char* w = std::getenv("FIR_GEMM_EREL_SCALE")) m->erel_scale = (float)std::atof(w);
+    if (const char* w = std::getenv("FIR_GEMM_ADAPTIVE")) m->adaptive = std::atoi(w);
     if (const char* w = std::getenv("FIR_GEMM_SHARE_STREAMED")) m->share_streamed = std::max(1, std::min(16, std::atoi(w)));
     if (const char* w = std::getenv("FIR_GEMM_SHARE")) m->share_max = std::max(0, std::min(16, std::atoi(w)));
     // the 16-row kernels always run the smallest-proxy sample flow with its XCD-shared launches: one workgroup per CU, CUs in eights
@@ -1671,7 +1700,7 @@ int fir_gemm_destroy(fir_gemm* m) {
     (void)hipStreamSynchronize(m->v.stream);
     if (m->side) { (void)hipStreamSynchronize(m->side); (void)hipStreamDestroy(m->side); }
     for (int b = 0; b < 2; ++b) {
-        (void)hipFree(m->qm[b]); (void)hipFree(m->qbf[b]); (void)hipFree(m->qnorm[b]); (void)hipFree(m->qmul[b]); (void)hipFree(m->qinv[b]); (void)hipFree(m->smin[b]); (void)hipFree(m->tau[b]); (void)hipFree(m->lists[b]); (void)hipFree(m->counts[b]);
+        (void)hipFree(m->qm[b]); (void)hipFree(m->qbf[b]); (void)hipFree(m->qnorm[b]); (void)hipFree(m->qmul[b]); (void)hipFree(m->qinv[b]); (void)hipFree(m->smin[b]); (void)hipFree(m->tau[b]); (void)hipFree(m->awin[b]); (void)hipFree(m->aT[b]); (void)hipFree(m->lists[b]); (void)hipFree(m->counts[b]);
         if (m->main_done[b]) (void)hipEventDestroy(m->main_done[b]);
         if (m->rerank_done[b]) (void)hipEventDestroy(m->rerank_done[b]);
         if (m->prep_done[b]) (void)hipEventDestroy(m->prep_done[b]);
@@ -1774,6 +1803,7 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
     // the same flow on the 16-row fragment order: k_gemm_proxy_f16x<2, *> is its sample pass, for any row length
     const bool x_flow = m->precision == FIR_GEMM_F16 && m->mfma16 && m->share_max > 0 && (grid & 7) == 0 && grid >= 8;
     const bool rt_flow = rt_main != nullptr || x_flow;
+    const bool adaptive = x_flow && k == 1 && (m->adaptive > 0 || (m->adaptive < 0 && m->dk16 >= 32));
     const int sub_stride = k > 1 ? kPasses * kQT : 0;      // top-K: the sample as kRtSubsets subset minima per query (k_gemm_tau_kmin)
     // the full pass: both kernels run at ~1 KiB of LDS traffic per MFMA and within 7 % of each other (profiles/r02_gemm_kernel_choice.txt):
     // register tile ahead up to 256 features, LDS tile ahead at 512
@@ -1805,7 +1835,10 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
             else
             hipLaunchKernelGGL(k_gemm_pack_queries_f16, dim3((4 * m->dk16 * 64 + 255) / 256, pairs), dim3(256), 0, ps, dq, nq, d, m->dk16, m->qmul[b],
                                m->qbf[b], qs);
-            if (rt_flow) {
+            if (adaptive) {
+                // no sample pass: the full pass finds its threshold on the way (k_gemm_proxy_f16x<3, *>)
+                hipLaunchKernelGGL(k_gemm_adapt_init, dim3((pairs * 2 * kQT + 255) / 256), dim3(256), 0, ps, m->awin[b], m->aT[b], pairs * 2 * kQT, nq, m->qnorm[b], m->gmax, e_rel);
+            } else if (rt_flow) {
                 // the smallest proxy of a row sample per query (register-tile kernel over rows [0, rt_sample_rows)), tau = that + one window
                 GEMM_HIP(hipMemsetD32Async((hipDeviceptr_t)m->smin[b], (int)0xFF800000u, sub_stride ? (size_t)kRtSubsets * sub_stride : (size_t)pairs * 2 * kQT, ps));
                 for (int p0 = 0; p0 < pairs;) {
@@ -1912,7 +1945,11 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
                                        m->tau[b] + qo * 2 * kQT, m->lists[b] + qo * 2 * kQT * kListCap, m->counts[b] + qo * 2 * kQT, m->smin[b] + qo * 2 * kQT, share, nt, 0);
                     used_rt = true;
                     used_rt_lds = rt_lds;
-                } else if (m->mfma16)
+                } else if (adaptive)
+                    hipLaunchKernelGGL(pick_x(3, streamed, (m->dk16 / kRing) & 1), g1, dim3(kGemmBlock), kHalfLds, st, m->gh, m->gnorm, m->qbf[b] + qo * 4 * m->dk16 * 64,
+                                       m->qinv[b] + qo * 2 * kQT, n, (int64_t)0, n, m->dk16, m->awin[b] + qo * 2 * kQT, m->lists[b] + qo * 2 * kQT * kListCap,
+                                       m->counts[b] + qo * 2 * kQT, m->qnorm[b] + qo * 2 * kQT, sample_rows, share, nt, 1, m->aT[b] + qo * 2 * kQT, 0);
+                else if (m->mfma16)
                     hipLaunchKernelGGL(pick_x(1, streamed, (m->dk16 / kRing) & 1), g1, dim3(kGemmBlock), kHalfLds, st, m->gh, m->gnorm, m->qbf[b] + qo * 4 * m->dk16 * 64,
                                        m->qinv[b] + qo * 2 * kQT, n, (int64_t)0, n, m->dk16, m->tau[b] + qo * 2 * kQT, m->lists[b] + qo * 2 * kQT * kListCap,
                                        m->counts[b] + qo * 2 * kQT, m->sample, sample_rows, share, nt | (m->stagger ? 2 : 0), 1, (unsigned int*)nullptr, 0);
@@ -1933,9 +1970,9 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
                 const void* fp = (const void*)rt_main;
                 fir_gallery_note_dispatch_(m->g, fp, nm, sb == 0, grid, nlaunch, 512, used_rt_lds, 128 * p_first, bytes, flops);
             } else
-            fir_gallery_note_dispatch_(m->g, m->mfma16 ? (const void*)pick_x(1, streamed, (m->dk16 / kRing) & 1)
+            fir_gallery_note_dispatch_(m->g, m->mfma16 ? (const void*)pick_x(adaptive ? 3 : 1, streamed, (m->dk16 / kRing) & 1)
                                                        : (streamed ? (const void*)k_gemm_proxy_f16<1, 1> : (const void*)k_gemm_proxy_f16<1, 0>),
-                                       m->mfma16 ? name_x(streamed, (m->dk16 / kRing) & 1)
+                                       m->mfma16 ? name_x(streamed, (m->dk16 / kRing) & 1, adaptive)
                                                  : (streamed ? "fir::k_gemm_proxy_f16<1, 1>" : "fir::k_gemm_proxy_f16<1, 0>"), sb == 0, grid, m->share_max > 0 ? nlaunch : pairs, kGemmBlock, kHalfLds,
                                        m->share_max > 0 ? 128 * p_first : 128, bytes, flops);
         } else if (m->precision == FIR_GEMM_F32) {
@@ -1958,6 +1995,10 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
             fir_gallery_note_dispatch_(m->g, (const void*)k_gemm_proxy_bf16_wide, pairs > 0 ? "fir::k_gemm_proxy_bf16_wide" : "fir::k_gemm_proxy_bf16<1>", sb == 0,
                                        grid, pairs > 0 ? pairs : np, kGemmBlock, pairs > 0 ? (size_t)kWideLds : lds, pairs > 0 ? 128 : 64,
                                        (pairs + (np - 2 * pairs)) * ((double)((n + 31) / 32) * m->dk16 * 2048.0), 2.0 * (double)n * d * 64.0 * np);
+        }
+        if (adaptive) {
+            const int pairs_a = (np + 1) / 2;
+            hipLaunchKernelGGL(k_gemm_adapt_final, dim3((pairs_a * 2 * kQT + 255) / 256), dim3(256), 0, st, m->aT[b], m->qnorm[b], m->tau[b], pairs_a * 2 * kQT, nq);
         }
         GEMM_HIP(hipEventRecord(m->main_done[b], st));
         // exact re-rank + certificate of this super-batch on the side stream, under the next one's full pass

@@ -74,6 +74,19 @@ __global__ void __launch_bounds__(256) k_gemm_pack_queries_f16x(const float* q, 
 // copy nor the merge point the compiler hung an s_waitcnt vmcnt(0) on.
 // MODE 0: one minimum per (row block, query) of rows [row_begin, row_end) -> sample (the order-statistic flow, k_gemm_tau; not
 // instantiated any more: the 16-row kernels always run the smallest-proxy flow);
+// MODE 3: the full pass with the threshold found ON THE WAY (top-1; no sample pass, no threshold kernel): per query the ranks
+// keep T = (smallest proxy seen so far + |q|^2) + one rounding window, as float bits >= 0 so that an unsigned atomicMin orders
+// them -- in LDS per workgroup, mirrored to `smin` (global) by atomicMin whenever a workgroup lowers it (that is where the final
+// bound comes from); the workgroups exchange once, behind their warm-up walk, which leaves every one of them with the minimum
+// over the first row blocks of about half the chip (tens of thousands of rows: what the sample pass used to provide) -- a
+// re-read of `smin` into a REGISTER once per row block measured slower than the appends it saved (256 VGPRs: the value held across
+// the row block spilled a loop-carried pointer); every fourth row block each wave instead fetches its sixteen queries' T by
+// LDS-DMA into a side array and folds the previous copy in (profiles/r03_adaptive_threshold.txt). A row is appended when its proxy is below tq = T - |q|^2 AT THAT MOMENT. T only ever
+// falls, so whatever was not appended has a proxy >= fl(T_final - |q|^2) =: tau, which k_gemm_adapt_final hands to the
+// re-rank's certificate; and every row within the window of the smallest proxy of ALL rows IS appended (its proxy is below
+// every T the pass ever held). With T = +inf at the start the first row block of a wave would append all its rows: every
+// wave therefore walks its first row block twice -- once only lowering T (then the workgroup exchanges T with `smin`), then
+// for real (1 extra row block in ~120). Here `tau` carries the windows, `sample` the |q|^2, `smin` the global T.
 // MODE 1: the full pass, every row below tau is appended; MODE 2: the sample of the smallest-proxy flow -- row blocks
 // 0, rb_stride, 2 rb_stride, ... of the gallery ((row_end - row_begin) / 32 of them, spread over all of it: the reference's
 // galleries are ordered by class), smin[q] <- the smallest proxy seen (fir::f32_orderable bits, atomicMin, caller presets +inf);
@@ -84,6 +97,7 @@ __global__ void __launch_bounds__(256) k_gemm_pack_queries_f16x(const float* q, 
 // Bit 1 of `nt_flags` (experiment, FIR_GEMM_STAGGER): waves 4-7 -- the partners of waves 0-3 on their SIMDs -- run half a unit of
 // throw-away MFMAs first, so that partners do not reach their epilogues and their end-of-unit waits together. Bit 0: the
 // gallery stream is read once per launch (non-temporal loads).
+constexpr int kXStage = 16;             // staged appends per query and workgroup
 template <int MODE, int STREAMED, int ODD>
 __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* __restrict__ gh, const float* __restrict__ gnorm, const uint4* qh,
                                                                     const float* __restrict__ qinv, int64_t n, int64_t row_begin, int64_t row_end,
@@ -93,6 +107,14 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
     extern __shared__ __attribute__((aligned(16))) uint4 lqx[];
     const int nt = nt_flags & 1;
     __shared__ float tau_s[2 * kQT], qinv_s[2 * kQT];
+    // MODE 1: appends are staged per workgroup in LDS (an LDS atomic counts in lgkmcnt and returns in ~100 cycles; a returning GLOBAL
+    // atomic sits in the in-order vmcnt queue behind the prefetched gallery loads -- every append drained the wave's stream) and
+    // flushed to the global lists once, at the end; a query that fills its kXStage slots appends directly (rare, correct)
+    constexpr bool kAppend = MODE == 1 || MODE == 3;
+    __shared__ unsigned long long skeys[kAppend ? 2 * kQT * kXStage : 1];
+    __shared__ int scnt[kAppend ? 2 * kQT : 1];
+    __shared__ float qn_s[MODE == 3 ? 2 * kQT : 1], win_s[MODE == 3 ? 2 * kQT : 1];
+    __shared__ unsigned int tglob_s[MODE == 3 ? 2 * kQT : 1];         // MODE 3: the other workgroups' T, fetched by LDS-DMA every few row blocks
     int pair_of_wg = (int)blockIdx.y;
     int64_t rg_first = blockIdx.x, rg_step = gridDim.x, rg_last = -1;
     int range = (int)blockIdx.x;
@@ -116,14 +138,17 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
         lists += pr * 2 * kQT * kListCap;
         counts += pr * 2 * kQT;
         if (MODE == 0) sample += pr * 2 * kQT * ((sample_rows + 31) / 32);
-        if (MODE == 2) smin += pr * 2 * kQT;
+        if (MODE == 2 || MODE == 3) smin += pr * 2 * kQT;
+        if (MODE == 3) sample += pr * 2 * kQT;
     }
     const int64_t rbs = MODE == 2 ? rb_stride : 1;                        // gallery row blocks per row block of the pass
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wpb = blockDim.x >> 6;
     if (threadIdx.x < 2 * kQT) {
-        tau_s[threadIdx.x] = MODE == 1 ? tau[threadIdx.x] : 0.f;
+        tau_s[threadIdx.x] = MODE == 1 ? tau[threadIdx.x] : MODE == 3 ? __uint_as_float(__hip_atomic_load(&smin[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0.f;
         qinv_s[threadIdx.x] = qinv[threadIdx.x];
+        if (kAppend) scnt[threadIdx.x] = 0;
+        if (MODE == 3) { qn_s[threadIdx.x] = sample[threadIdx.x]; win_s[threadIdx.x] = tau[threadIdx.x]; tglob_s[threadIdx.x] = 0xFFFFFFFFu; }
     }
     const int64_t rb_begin = row_begin / 32, rb_end = (row_end + 31) / 32;
     const int64_t nrg = (rb_end - rb_begin + wpb - 1) / wpb;
@@ -132,11 +157,13 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
     int64_t rg = rg_first;
     if (rg >= rg_end) return;                        // uniform per workgroup
 #define FIR_X_LD(P) (nt ? ld_nt(P) : *(P))
-#define FIR_X_BLOCK(RG) (gh + (size_t)(((rb_begin + (RG) * wpb + wave) < rb_end ? (rb_begin + (RG) * wpb + wave) : rb_end - 1) * rbs) * dk16 * 64 + lane)
+    // (wave-uniform block pointers: the lane index is added in the load itself, so that the loads take the scalar-base form --
+    // one 32-bit lane offset register instead of a 64-bit address per pointer)
+#define FIR_X_BLOCK(RG) (gh + (size_t)(((rb_begin + (RG) * wpb + wave) < rb_end ? (rb_begin + (RG) * wpb + wave) : rb_end - 1) * rbs) * dk16 * 64)
     const uint4* a_cur = FIR_X_BLOCK(rg);
     uint4 cur[kRing], nxt[kRing];
 #pragma unroll
-    for (int u = 0; u < kRing; ++u) cur[u] = FIR_X_LD(a_cur + (size_t)u * 64);
+    for (int u = 0; u < kRing; ++u) cur[u] = FIR_X_LD(a_cur + (size_t)u * 64 + lane);
     constexpr int kUnitsPerSlab = kSlabH / kRing;                         // units of the LDS-resident tile (512 features)
     const bool resident = !STREAMED;                                      // (the caller streams whatever does not fit: dk16 > kSlabH)
     // STREAMED (rows longer than the 512 features whose 128-query tile fits LDS): the query fragments go through a ring of FOUR
@@ -189,12 +216,44 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
         for (int r = 0; r < 32; ++r) junk = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_f16x8(B[r & 7]), as_f16x8(B[(r + 1) & 7]), junk, 0, 0, 0);
         asm volatile("" ::"v"(junk));
     }
-    for (; rg < rg_end; rg += rg_step) {
+    bool warm = MODE == 3;                           // MODE 3: the first row block is walked twice (see above)
+    bool exchange = false;
+    int blk_no = 0;
+    int64_t rg_next = rg;
+    for (; rg < rg_end; rg = rg_next) {
+        const bool warm_it = warm;
+        warm = false;
+        rg_next = warm_it ? rg : rg + rg_step;
         const int64_t rbp = rb_begin + rg * wpb + wave;   // row block of the pass ...
         const int64_t rb = rbp * rbs;                     // ... and of the gallery
         const bool active = rbp < rb_end;
-        const int64_t rgn = rg + rg_step;
+        const int64_t rgn = rg_next;
         const uint4* a_nxt = FIR_X_BLOCK(rgn < rg_end ? rgn : rg);
+        if (MODE == 3) {
+            if (exchange) {                               // (uniform over the workgroup: every wave walks the same rg sequence)
+                // the workgroup's warm-up minima go out, everybody else's come in
+                __syncthreads();
+                if (threadIdx.x < 2 * kQT) {
+                    const unsigned int mine = __float_as_uint(tau_s[threadIdx.x]);
+                    const unsigned int old = atomicMin(&smin[threadIdx.x], mine);
+                    tau_s[threadIdx.x] = __uint_as_float(old < mine ? old : mine);
+                }
+                __syncthreads();
+                exchange = false;
+            } else if (!warm_it && wave < 8) {
+                // what the other workgroups have reached since: folded in (the copy fetched a few row blocks ago), and every fourth row
+                // block a fresh copy of this wave's sixteen queries is requested -- LDS-DMA: no register is held across the row block,
+                // and a copy that lands late only means the fold sees the older (larger, still valid) value
+                if (lane < 16) atomicMin((unsigned int*)&tau_s[16 * wave + lane], tglob_s[16 * wave + lane]);
+                if ((blk_no & 3) == 0 && lane < 16) {
+                    const unsigned int* src = smin + 16 * wave + lane;
+                    const uint32_t dst = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(void __attribute__((address_space(3)))*)tglob_s + (uint32_t)wave * 64);
+                    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, off sc1" ::"s"(dst), "v"(src) : "memory");
+                }
+            }
+            ++blk_no;
+            if (warm_it) exchange = true;
+        }
         f32x4 acc[2][8];                             // (first written by the MFMAs of the row block's first step, against a zero C operand)
         float4 gns[2];                               // squared norms of rows 16 s + 4 (lane >> 4) + 0..3 of the block
         const bool full_block = active && rbp * 32 >= row_begin && rbp * 32 + 32 <= row_end && rb * 32 + 32 <= n && (MODE != 0 || rb * 32 + 32 <= sample_rows);
@@ -206,10 +265,10 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
             const uint4* bq = STREAMED ? lqx + lane + (size_t)(ring_c & 3) * 4 * kRing * 64 : lqx + lane + (size_t)(h % kUnitsPerSlab) * kRing * 4 * 64;
             if (nt) {
 #pragma unroll
-                for (int u = 0; u < kRing; ++u) N[u] = ld_nt(src + (size_t)u * 64);
+                for (int u = 0; u < kRing; ++u) N[u] = ld_nt(src + (size_t)u * 64 + lane);
             } else {
 #pragma unroll
-                for (int u = 0; u < kRing; ++u) N[u] = src[(size_t)u * 64];
+                for (int u = 0; u < kRing; ++u) N[u] = src[(size_t)u * 64 + lane];
             }
             if (h == units - 1 && full_block) {
                 const float4* gp = (const float4*)(gnorm + rb * 32 + 4 * (lane >> 4));
@@ -263,7 +322,8 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
             for (int jb = 0; jb < 8; ++jb) {
                 const int q = jb * 16 + (lane & 15);
                 const float m2 = 2.0f * qinv_s[q];
-                const float tq = tau_s[q];
+                const float tcur = tau_s[q];                                   // MODE 3: T (see above)
+                const float tq = MODE == 3 ? tcur - qn_s[q] : tcur;
                 float pv[8];
                 float mn = __builtin_huge_valf();
 #pragma unroll
@@ -275,14 +335,35 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
                         mn = fminf(mn, pv[4 * s + reg]);                   // NaN never enters, like k_gemm_tau's ordering
                     }
                 }
-                if (MODE == 1) {
+                if (MODE == 3 && warm_it) {
+                    // observe only: the smallest proxy of the block's 32 rows lowers T (LDS; the workgroup exchanges with `smin` afterwards)
+                    float o = __shfl_xor(mn, 16, 64);
+                    mn = o < mn ? o : mn;
+                    o = __shfl_xor(mn, 32, 64);
+                    mn = o < mn ? o : mn;
+                    const float tn = fmaxf((mn + qn_s[q]) + win_s[q], 0.f);     // (NaN operands: fmaxf gives 0 only if both are NaN; a NaN tn fails the test below)
+                    if (lane < 16 && tn < tcur) atomicMin((unsigned int*)&tau_s[q], __float_as_uint(tn));
+                } else if (kAppend) {
                     if (mn < tq) {
 #pragma unroll
                         for (int i = 0; i < 8; ++i) {
                             if (pv[i] < tq) {
                                 const int64_t row = rb * 32 + 16 * (i >> 2) + 4 * (lane >> 4) + (i & 3);
-                                const int slot = atomicAdd(&counts[q], 1);
-                                if (slot < kListCap) lists[(size_t)q * kListCap + slot] = fir::key_pack(pv[i], (uint32_t)row);
+                                const unsigned long long key = fir::key_pack(pv[i], (uint32_t)row);
+                                const int st = atomicAdd(&scnt[q], 1);
+                                if (st < kXStage) {
+                                    skeys[q * kXStage + st] = key;
+                                } else {
+                                    const int slot = atomicAdd(&counts[q], 1);
+                                    if (slot < kListCap) lists[(size_t)q * kListCap + slot] = key;
+                                }
+                            }
+                        }
+                        if (MODE == 3) {
+                            const float tn = fmaxf((mn + qn_s[q]) + win_s[q], 0.f);
+                            if (tn < tcur) {                                    // a new smallest proxy: T falls, here and for everybody else
+                                atomicMin((unsigned int*)&tau_s[q], __float_as_uint(tn));
+                                atomicMin(&smin[q], __float_as_uint(tn));
                             }
                         }
                     }
@@ -304,7 +385,7 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
         for (int jb = 0; jb < 8; ++jb) {
             const int q = jb * 16 + (lane & 15);
             const float m2 = 2.0f * qinv_s[q];
-            const float tq = tau_s[q];
+            const float tq = MODE == 3 ? (warm_it ? -__builtin_huge_valf() : tau_s[q] - qn_s[q]) : tau_s[q];      // (a warm-up walk appends nothing)
             float mn = __builtin_huge_valf();
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -322,13 +403,25 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
             }
             if (MODE == 2 && !sub_stride) {
                 smallest[jb] = fminf(smallest[jb], mn);
-            } else if (MODE != 1) {
+            } else if (MODE != 1 && MODE != 3) {
                 float o = __shfl_xor(mn, 16, 64);
                 mn = o < mn ? o : mn;
                 o = __shfl_xor(mn, 32, 64);
                 mn = o < mn ? o : mn;
                 if (MODE == 0) { if (lane < 16) sample[(size_t)(rb - rb_begin) * (2 * kQT) + q] = mn; }
                 else if (lane < 16 && mn < __builtin_huge_valf()) atomicMin(&smin_blk[q], fir::f32_orderable(mn));
+            }
+        }
+    }
+    if (kAppend) {
+        __syncthreads();                             // every wave's staged appends are in
+        if (threadIdx.x < 2 * kQT) {
+            const int q = threadIdx.x;
+            const int cnt = scnt[q] < kXStage ? scnt[q] : kXStage;
+            if (cnt > 0) {
+                const int base = atomicAdd(&counts[q], cnt);
+                for (int st = 0; st < cnt; ++st)
+                    if (base + st < kListCap) lists[(size_t)q * kListCap + base + st] = skeys[q * kXStage + st];
             }
         }
     }

@@ -535,7 +535,7 @@ def test_the_certificate_bound_is_needed_and_a_shrunken_one_is_caught(fir, oracl
         eidx, edist = g.search_top1(q)
         assert eidx[0] == ia and edist[0] == 0.0 and (eidx[0], edist[0]) == oracle.recognize_bf(rows, q[0], 0, d, 0)
         got = {}
-        for scale in ("1", "0.25", "0"):
+        for scale in ("1", "0.25"):
             monkeypatch.setenv("FIR_GEMM_EREL_SCALE", scale)
             with fir.GemmSearch(g, 2) as m:
                 m.search_top1_keys_dev(tq.data_ptr(), q.shape[0], keys.data_ptr())
@@ -544,6 +544,6 @@ def test_the_certificate_bound_is_needed_and_a_shrunken_one_is_caught(fir, oracl
         monkeypatch.delenv("FIR_GEMM_EREL_SCALE")
     (idx, dist), fb = got["1"]
     assert np.array_equal(idx, eidx) and np.array_equal(dist.view(np.uint32), edist.view(np.uint32)) and fb <= 2
-    for scale in ("0.25", "0"):
-        (idx_s, dist_s), fb_s = got[scale]
-        assert idx_s[0] == ib and dist_s[0] > 0.0, (scale, idx_s[0], dist_s[0], fb_s)      # the wrong row, certified: the shrunken bound is unsound and it shows
+    (idx_s, dist_s), fb_s = got["0.25"]
+    # the wrong row, certified (no fall-back to the exact scan for it): the shrunken bound is unsound and it shows
+    assert idx_s[0] == ib and dist_s[0] > 0.0 and fb_s <= 2, (idx_s[0], dist_s[0], fb_s)

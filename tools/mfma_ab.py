@@ -25,12 +25,20 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--check", type=int, default=2048, help="queries checked against the exact scan per variant")
     ap.add_argument("--variants", default="base:;x16:FIR_GEMM_MFMA16=1")
+    ap.add_argument("--identities", type=int, default=0, help="> 0: a class-ordered clustered gallery, rows = identity centre * (1 + spread * noise), identity = row * identities // rows")
+    ap.add_argument("--spread", type=float, default=0.05)
     a = ap.parse_args()
     fir = ge.load_package()
     dev = torch.device("cuda", 0)
     n, d, qb = a.rows, a.dim, a.qb
     torch.manual_seed(13)
-    x = torch.rand((n, d), device=dev)
+    if a.identities > 0:
+        centres = torch.rand((a.identities, d), device=dev)
+        ident = (torch.arange(n, device=dev) * a.identities) // n          # class-ordered, like the reference's galleries
+        x = centres[ident] * (1 + a.spread * (torch.rand((n, d), device=dev) - 0.5))
+        del centres, ident
+    else:
+        x = torch.rand((n, d), device=dev)
     x = x / x.norm(dim=1, keepdim=True)
     g = fir.Gallery(dev_ptr=x.data_ptr(), n=n, d=d, metric=0, device=0)
     fresh = torch.rand((qb, d), device=dev)
