@@ -1479,8 +1479,8 @@ struct fir_gemm {
     int regtile = -1;                     // fp16 full pass through the register-tile kernel: -1 = where it measured faster (rows up to 256 features), 0 / 1 = never / wherever it exists (FIR_GEMM_REGTILE)                  // fp16 full pass: query fragments in registers, gallery through the LDS-DMA ring (FIR_GEMM_REGTILE=0: the LDS-tile kernel)
     int mfma16 = 0;                       // fp16: both operands in the 16-row fragment order, every pass on v_mfma_f32_16x16x32_f16 (fir_gemm_f16x.h): the default since it was
                                           // measured against the 32x32x16 kernels at the same wave tile (profiles/r03_mfma_shape_ab.txt); FIR_GEMM_MFMA16=0 brings those back
-    int adaptive = -1;                    // 16-row top-1 flow: the append threshold is found during the full pass (k_gemm_proxy_f16x<3, *>), no sample pass: -1 = where it measured
-                                          // faster (rows of 512 features and more: profiles/r03_adaptive_threshold.txt), 0 / 1 = never / always (FIR_GEMM_ADAPTIVE)
+    int adaptive = 1;                     // 16-row top-1 flow: the append threshold is found during the full pass (k_gemm_proxy_f16x<3, *>), no sample pass
+                                          // (profiles/r03_adaptive_threshold.txt); FIR_GEMM_ADAPTIVE=0: the sample flow
     float* awin[2] = {nullptr, nullptr};  // ... its per-query windows
     unsigned int* aT[2] = {nullptr, nullptr};   // ... and the ranks' shared T (float bits)
     float erel_scale = 1.0f;              // AUDIT KNOB, never set in production: the certificate's relative error bound is multiplied by this (FIR_GEMM_EREL_SCALE);
@@ -1803,7 +1803,7 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
     // the same flow on the 16-row fragment order: k_gemm_proxy_f16x<2, *> is its sample pass, for any row length
     const bool x_flow = m->precision == FIR_GEMM_F16 && m->mfma16 && m->share_max > 0 && (grid & 7) == 0 && grid >= 8;
     const bool rt_flow = rt_main != nullptr || x_flow;
-    const bool adaptive = x_flow && k == 1 && (m->adaptive > 0 || (m->adaptive < 0 && m->dk16 >= 32));
+    const bool adaptive = x_flow && k == 1 && m->adaptive > 0;
     const int sub_stride = k > 1 ? kPasses * kQT : 0;      // top-K: the sample as kRtSubsets subset minima per query (k_gemm_tau_kmin)
     // the full pass: both kernels run at ~1 KiB of LDS traffic per MFMA and within 7 % of each other (profiles/r02_gemm_kernel_choice.txt):
     // register tile ahead up to 256 features, LDS tile ahead at 512

@@ -244,9 +244,14 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
                 // what the other workgroups have reached since: folded in (the copy fetched a few row blocks ago), and every fourth row
                 // block a fresh copy of this wave's sixteen queries is requested -- LDS-DMA: no register is held across the row block,
                 // and a copy that lands late only means the fold sees the older (larger, still valid) value
-                if (lane < 16) atomicMin((unsigned int*)&tau_s[16 * wave + lane], tglob_s[16 * wave + lane]);
+                // (the query index goes through an opaque zero defined HERE: otherwise the compiler hoists the three addresses out of
+                // the row loop and, at 256 registers, spills them -- a scratch reload and a full vmcnt wait at the head of every row block)
+                int zl;
+                asm volatile("v_mov_b32 %0, 0" : "=v"(zl));
+                const int ql = 16 * wave + lane + zl;
+                if (lane < 16) atomicMin((unsigned int*)&tau_s[ql], tglob_s[ql]);
                 if ((blk_no & 3) == 0 && lane < 16) {
-                    const unsigned int* src = smin + 16 * wave + lane;
+                    const unsigned int* src = smin + ql;
                     const uint32_t dst = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(void __attribute__((address_space(3)))*)tglob_s + (uint32_t)wave * 64);
                     asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, off sc1" ::"s"(dst), "v"(src) : "memory");
                 }
