@@ -24,6 +24,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "../../include/fir_amd.h"
@@ -1803,7 +1804,22 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
     // the same flow on the 16-row fragment order: k_gemm_proxy_f16x<2, *> is its sample pass, for any row length
     const bool x_flow = m->precision == FIR_GEMM_F16 && m->mfma16 && m->share_max > 0 && (grid & 7) == 0 && grid >= 8;
     const bool rt_flow = rt_main != nullptr || x_flow;
-    const bool adaptive = x_flow && k == 1 && m->adaptive > 0;
+    // The adaptive threshold needs every workgroup to see enough rows for the bounds to travel: with the rows of a pair cut into
+    // (CUs / pairs per launch) ranges, that is (row groups) * (pairs per launch) / CUs row groups per workgroup. Below a dozen (a
+    // cache-resident gallery, or one pair over 256 ranges of 100 000 rows) every workgroup is still in its loose early phase when
+    // it ends -- 1 000-2 400 appended rows per query measured at 100k x 512 with 256 queries, against ~20 through the sample
+    // flow, 13 % fewer queries/s -- so such super-batches keep the sample flow.
+    auto adaptive_for = [&](int nq_sb) -> bool {
+        if (!(x_flow && k == 1 && m->adaptive > 0)) return false;
+        if (m->adaptive > 1) return true;                                   // FIR_GEMM_ADAPTIVE=2: always
+        const int pairs_sb = ((nq_sb + kQT - 1) / kQT + 1) / 2;
+        const bool str = m->dk16 > kSlabH || m->streamed > 0;
+        int P = 1;
+        while (P * 2 <= pairs_sb && P * 2 <= (str ? std::min(m->share_max, m->share_streamed) : m->share_max)) P *= 2;
+        const int64_t row_groups = ((n + 31) / 32 + kGemmBlock / 64 - 1) / (kGemmBlock / 64);
+        return row_groups * P / std::max(grid, 1) >= 12;
+    };
+    const int adapt_dbg = std::getenv("FIR_GEMM_ADAPT_DBG") ? (std::atoi(std::getenv("FIR_GEMM_ADAPT_DBG")) & 3) << 2 : 0;   // experiments: 1 = no refresh, 2 = no exchange
     const int sub_stride = k > 1 ? kPasses * kQT : 0;      // top-K: the sample as kRtSubsets subset minima per query (k_gemm_tau_kmin)
     // the full pass: both kernels run at ~1 KiB of LDS traffic per MFMA and within 7 % of each other (profiles/r02_gemm_kernel_choice.txt):
     // register tile ahead up to 256 features, LDS tile ahead at 512
@@ -1835,6 +1851,7 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
             else
             hipLaunchKernelGGL(k_gemm_pack_queries_f16, dim3((4 * m->dk16 * 64 + 255) / 256, pairs), dim3(256), 0, ps, dq, nq, d, m->dk16, m->qmul[b],
                                m->qbf[b], qs);
+            const bool adaptive = adaptive_for(nq);
             if (adaptive) {
                 // no sample pass: the full pass finds its threshold on the way (k_gemm_proxy_f16x<3, *>)
                 hipLaunchKernelGGL(k_gemm_adapt_init, dim3((pairs * 2 * kQT + 255) / 256), dim3(256), 0, ps, m->awin[b], m->aT[b], pairs * 2 * kQT, nq, m->qnorm[b], m->gmax, e_rel);
@@ -1907,6 +1924,7 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
         const int b = sb & 1;
         const float* dq = d_queries + (size_t)q0 * qs;
         if (sb + 1 < nsb && (rcp = prep(sb + 1))) return rcp;
+        const bool adaptive = adaptive_for(nq);
         GEMM_HIP(hipStreamWaitEvent(st, m->prep_done[b], 0));
         // ---- the full pass(es) over the gallery: the launch fir_profile_read times and fir_gallery_last_dispatch names ----
         if (m->precision == FIR_GEMM_F16) {
@@ -1948,7 +1966,7 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
                 } else if (adaptive)
                     hipLaunchKernelGGL(pick_x(3, streamed, (m->dk16 / kRing) & 1), g1, dim3(kGemmBlock), kHalfLds, st, m->gh, m->gnorm, m->qbf[b] + qo * 4 * m->dk16 * 64,
                                        m->qinv[b] + qo * 2 * kQT, n, (int64_t)0, n, m->dk16, m->awin[b] + qo * 2 * kQT, m->lists[b] + qo * 2 * kQT * kListCap,
-                                       m->counts[b] + qo * 2 * kQT, m->qnorm[b] + qo * 2 * kQT, sample_rows, share, nt, 1, m->aT[b] + qo * 2 * kQT, 0);
+                                       m->counts[b] + qo * 2 * kQT, m->qnorm[b] + qo * 2 * kQT, sample_rows, share, nt | adapt_dbg, 1, m->aT[b] + qo * 2 * kQT, 0);
                 else if (m->mfma16)
                     hipLaunchKernelGGL(pick_x(1, streamed, (m->dk16 / kRing) & 1), g1, dim3(kGemmBlock), kHalfLds, st, m->gh, m->gnorm, m->qbf[b] + qo * 4 * m->dk16 * 64,
                                        m->qinv[b] + qo * 2 * kQT, n, (int64_t)0, n, m->dk16, m->tau[b] + qo * 2 * kQT, m->lists[b] + qo * 2 * kQT * kListCap,
@@ -2020,6 +2038,41 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
     std::vector<int> h_ok((size_t)qb);
     GEMM_HIP(hipMemcpyAsync(h_ok.data(), m->ok, (size_t)qb * sizeof(int), hipMemcpyDeviceToHost, st));
     GEMM_HIP(hipStreamSynchronize(st));
+    if (std::getenv("FIR_GEMM_DEBUG_COUNTS")) {       // experiments: appended rows per query of the last super-batch
+        const int nql = std::min(sbq, qb - (nsb - 1) * sbq);
+        std::vector<int> hc((size_t)nql);
+        GEMM_HIP(hipMemcpy(hc.data(), m->counts[(nsb - 1) & 1], (size_t)nql * sizeof(int), hipMemcpyDeviceToHost));
+        long long sum = 0;
+        int mx = 0;
+        for (int v : hc) { sum += v; mx = std::max(mx, v); }
+        std::vector<float> ht((size_t)nql);
+        GEMM_HIP(hipMemcpy(ht.data(), m->tau[(nsb - 1) & 1], (size_t)nql * sizeof(float), hipMemcpyDeviceToHost));
+        double ts = 0;
+        int ninf = 0;
+        for (float v : ht) { if (v < 1e30f) ts += v; else ++ninf; }
+        std::fprintf(stderr, "fir_gemm: appended rows per query (last super-batch of %d): mean %.1f, max %d; tau: mean %.6f, %d not finite\n", nql, (double)sum / nql, mx,
+                     ts / std::max(1, nql - ninf), ninf);
+        // the uncertified queries of that super-batch: list length, bound, smallest proxy in the list
+        const int q0l = (nsb - 1) * sbq;
+        int shown = 0;
+        for (int i = 0; i < nql && shown < 8; ++i) {
+            if (h_ok[(size_t)(q0l + i)]) continue;
+            const int cnt = std::min(hc[(size_t)i], kListCap);
+            std::vector<unsigned long long> hl((size_t)std::max(cnt, 1));
+            if (cnt > 0) GEMM_HIP(hipMemcpy(hl.data(), m->lists[(nsb - 1) & 1] + (size_t)i * kListCap, (size_t)cnt * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            unsigned long long mn = ~0ull;
+            for (int j = 0; j < cnt; ++j) mn = std::min(mn, hl[(size_t)j]);
+            uint32_t ob = (uint32_t)(mn >> 32);
+            uint32_t fb = (ob & 0x80000000u) ? (ob ^ 0x80000000u) : ~ob;
+            float pmin;
+            std::memcpy(&pmin, &fb, 4);
+            float hqn = 0.f;
+            GEMM_HIP(hipMemcpy(&hqn, m->qnorm[(nsb - 1) & 1] + i, 4, hipMemcpyDeviceToHost));
+            std::fprintf(stderr, "  uncertified query %d: %d appended, tau %.7f, smallest proxy in list %.7f (row %u), |q|^2 %.6f\n", q0l + i, hc[(size_t)i], ht[(size_t)i], pmin,
+                         (unsigned)(mn & 0xFFFFFFFFu), hqn);
+            ++shown;
+        }
+    }
     // uncertified queries: the exact streaming scan answers them, kQT at a time
     std::vector<int> which;
     for (int i = 0; i < qb; ++i)

@@ -79,9 +79,10 @@ __global__ void __launch_bounds__(256) k_gemm_pack_queries_f16x(const float* q, 
 // them -- in LDS per workgroup, mirrored to `smin` (global) by atomicMin whenever a workgroup lowers it (that is where the final
 // bound comes from); the workgroups exchange once, behind their warm-up walk, which leaves every one of them with the minimum
 // over the first row blocks of about half the chip (tens of thousands of rows: what the sample pass used to provide) -- a
-// re-read of `smin` into a REGISTER once per row block measured slower than the appends it saved (256 VGPRs: the value held across
-// the row block spilled a loop-carried pointer); every fourth row block each wave instead fetches its sixteen queries' T by
-// LDS-DMA into a side array and folds the previous copy in (profiles/r03_adaptive_threshold.txt). A row is appended when its proxy is below tq = T - |q|^2 AT THAT MOMENT. T only ever
+// re-read of `smin` into a register held across the row block measured slower than the appends it saved (256 VGPRs: it spilled a
+// loop-carried pointer), and loads of `smin` -- plain, sc1 or LDS-DMA -- turned out to be served from stale lines of the XCD's own
+// L2; each wave therefore posts-and-fetches its sixteen queries' T with ONE returning atomicMin on a thinning schedule
+// (profiles/r03_adaptive_threshold.txt). A row is appended when its proxy is below tq = T - |q|^2 AT THAT MOMENT. T only ever
 // falls, so whatever was not appended has a proxy >= fl(T_final - |q|^2) =: tau, which k_gemm_adapt_final hands to the
 // re-rank's certificate; and every row within the window of the smallest proxy of ALL rows IS appended (its proxy is below
 // every T the pass ever held). With T = +inf at the start the first row block of a wave would append all its rows: every
@@ -114,7 +115,10 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
     __shared__ unsigned long long skeys[kAppend ? 2 * kQT * kXStage : 1];
     __shared__ int scnt[kAppend ? 2 * kQT : 1];
     __shared__ float qn_s[MODE == 3 ? 2 * kQT : 1], win_s[MODE == 3 ? 2 * kQT : 1];
-    __shared__ unsigned int tglob_s[MODE == 3 ? 2 * kQT : 1];         // MODE 3: the other workgroups' T, fetched by LDS-DMA every few row blocks
+    // MODE 3: tq_s = T - |q|^2 as the hot path compares it, rewritten by whoever lowers T (tau_s holds T itself). A racing store may leave
+    // the value of an OLDER (larger) T: harmless -- any T the pass ever held is >= the final one, so whatever fails the test against
+    // it has a proxy >= fl(T_final - |q|^2), the bound the certificate is given
+    __shared__ float tq_s[MODE == 3 ? 2 * kQT : 1];
     int pair_of_wg = (int)blockIdx.y;
     int64_t rg_first = blockIdx.x, rg_step = gridDim.x, rg_last = -1;
     int range = (int)blockIdx.x;
@@ -145,10 +149,14 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wpb = blockDim.x >> 6;
     if (threadIdx.x < 2 * kQT) {
-        tau_s[threadIdx.x] = MODE == 1 ? tau[threadIdx.x] : MODE == 3 ? __uint_as_float(__hip_atomic_load(&smin[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0.f;
+        tau_s[threadIdx.x] = MODE == 1 ? tau[threadIdx.x] : MODE == 3 ? __uint_as_float(atomicMin(&smin[threadIdx.x], 0xFFFFFFFFu)) : 0.f;    // (MODE 3: an atomic, see the refresh below)
         qinv_s[threadIdx.x] = qinv[threadIdx.x];
         if (kAppend) scnt[threadIdx.x] = 0;
-        if (MODE == 3) { qn_s[threadIdx.x] = sample[threadIdx.x]; win_s[threadIdx.x] = tau[threadIdx.x]; tglob_s[threadIdx.x] = 0xFFFFFFFFu; }
+        if (MODE == 3) {
+            qn_s[threadIdx.x] = sample[threadIdx.x];
+            win_s[threadIdx.x] = tau[threadIdx.x];
+            tq_s[threadIdx.x] = tau_s[threadIdx.x] - qn_s[threadIdx.x];
+        }
     }
     const int64_t rb_begin = row_begin / 32, rb_end = (row_end + 31) / 32;
     const int64_t nrg = (rb_end - rb_begin + wpb - 1) / wpb;
@@ -235,25 +243,27 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
                 __syncthreads();
                 if (threadIdx.x < 2 * kQT) {
                     const unsigned int mine = __float_as_uint(tau_s[threadIdx.x]);
-                    const unsigned int old = atomicMin(&smin[threadIdx.x], mine);
+                    const unsigned int old = (nt_flags & 8) ? mine : atomicMin(&smin[threadIdx.x], mine);
                     tau_s[threadIdx.x] = __uint_as_float(old < mine ? old : mine);
+                    tq_s[threadIdx.x] = tau_s[threadIdx.x] - qn_s[threadIdx.x];
                 }
                 __syncthreads();
                 exchange = false;
-            } else if (!warm_it && wave < 8) {
-                // what the other workgroups have reached since: folded in (the copy fetched a few row blocks ago), and every fourth row
-                // block a fresh copy of this wave's sixteen queries is requested -- LDS-DMA: no register is held across the row block,
-                // and a copy that lands late only means the fold sees the older (larger, still valid) value
-                // (the query index goes through an opaque zero defined HERE: otherwise the compiler hoists the three addresses out of
-                // the row loop and, at 256 registers, spills them -- a scratch reload and a full vmcnt wait at the head of every row block)
-                int zl;
-                asm volatile("v_mov_b32 %0, 0" : "=v"(zl));
-                const int ql = 16 * wave + lane + zl;
-                if (lane < 16) atomicMin((unsigned int*)&tau_s[ql], tglob_s[ql]);
-                if ((blk_no & 3) == 0 && lane < 16) {
-                    const unsigned int* src = smin + ql;
-                    const uint32_t dst = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(void __attribute__((address_space(3)))*)tglob_s + (uint32_t)wave * 64);
-                    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, off sc1" ::"s"(dst), "v"(src) : "memory");
+            } else if (!warm_it && wave < 8 && !(nt_flags & 4)) {
+                // What the other workgroups have reached since. Only ATOMICS read `smin`: they execute at the memory side, so what they
+                // return is the value every XCD's updates have been folded into -- a load, even an sc1 one, can be served by a line this
+                // XCD's L2 took in earlier (measured: whole XCDs' workgroups never saw the others' bounds and appended 16 rows each per
+                // query, 4 000+ per query with one pair over 256 row ranges). One returning atomicMin posts this wave's sixteen
+                // queries' T and fetches the global one; its result is used at once (nothing is held across the row block -- at 256
+                // registers that spills), on a schedule that thins out: row blocks 2, 3, 4, 6, 8, 12, 16, 24, ... (T settles early).
+                const int v = blk_no >> __builtin_ctz((unsigned)blk_no | 0x40000000u);
+                if ((v == 1 || v == 3) && lane < 16) {
+                    int zl;                                   // (an opaque zero: keeps the addresses from being hoisted out of the row loop and spilled)
+                    asm volatile("v_mov_b32 %0, 0" : "=v"(zl));
+                    const int ql = 16 * wave + lane + zl;
+                    const unsigned int mine = __float_as_uint(tau_s[ql]);
+                    const unsigned int old = atomicMin(&smin[ql], mine);
+                    if (old < mine && old < atomicMin((unsigned int*)&tau_s[ql], old)) tq_s[ql] = __uint_as_float(old) - qn_s[ql];
                 }
             }
             ++blk_no;
@@ -327,8 +337,7 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
             for (int jb = 0; jb < 8; ++jb) {
                 const int q = jb * 16 + (lane & 15);
                 const float m2 = 2.0f * qinv_s[q];
-                const float tcur = tau_s[q];                                   // MODE 3: T (see above)
-                const float tq = MODE == 3 ? tcur - qn_s[q] : tcur;
+                const float tq = MODE == 3 ? (warm_it ? 0.f : tq_s[q]) : tau_s[q];
                 float pv[8];
                 float mn = __builtin_huge_valf();
 #pragma unroll
@@ -347,7 +356,7 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
                     o = __shfl_xor(mn, 32, 64);
                     mn = o < mn ? o : mn;
                     const float tn = fmaxf((mn + qn_s[q]) + win_s[q], 0.f);     // (NaN operands: fmaxf gives 0 only if both are NaN; a NaN tn fails the test below)
-                    if (lane < 16 && tn < tcur) atomicMin((unsigned int*)&tau_s[q], __float_as_uint(tn));
+                    if (lane < 16 && tn < tau_s[q]) atomicMin((unsigned int*)&tau_s[q], __float_as_uint(tn));
                 } else if (kAppend) {
                     if (mn < tq) {
 #pragma unroll
@@ -366,8 +375,8 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
                         }
                         if (MODE == 3) {
                             const float tn = fmaxf((mn + qn_s[q]) + win_s[q], 0.f);
-                            if (tn < tcur) {                                    // a new smallest proxy: T falls, here and for everybody else
-                                atomicMin((unsigned int*)&tau_s[q], __float_as_uint(tn));
+                            if (tn < tau_s[q]) {                                // a new smallest proxy: T falls, here and for everybody else
+                                if (__float_as_uint(tn) < atomicMin((unsigned int*)&tau_s[q], __float_as_uint(tn))) tq_s[q] = tn - qn_s[q];
                                 atomicMin(&smin[q], __float_as_uint(tn));
                             }
                         }
@@ -390,7 +399,7 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
         for (int jb = 0; jb < 8; ++jb) {
             const int q = jb * 16 + (lane & 15);
             const float m2 = 2.0f * qinv_s[q];
-            const float tq = MODE == 3 ? (warm_it ? -__builtin_huge_valf() : tau_s[q] - qn_s[q]) : tau_s[q];      // (a warm-up walk appends nothing)
+            const float tq = MODE == 3 ? (warm_it ? -__builtin_huge_valf() : tq_s[q]) : tau_s[q];      // (a warm-up walk appends nothing)
             float mn = __builtin_huge_valf();
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
