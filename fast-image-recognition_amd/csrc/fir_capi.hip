@@ -267,7 +267,9 @@ bool wants_mfma(const fir_gallery* g, int32_t qb, int32_t start, int32_t end) {
         // 589 / 387, 1 024: 4 036 / 496; 3 030 x 1536 (the reference's gallery): 256: 136 / 270, 1 024: 377 / 346. The matrix cores
         // are taken where the model gives them 15 % or more.
         if (g->n < 2048 || qb < 64) return false;
-        const double mbs = (double)g->n * (double)end * 4.0 / 1.0e6;
+        // (the constants were measured on a 256-CU MI355X; the per-MB terms -- bandwidth and matrix-core time -- scale with the CU count
+        // of the device the gallery lives on, the fixed terms -- launches, synchronisation -- do not)
+        const double mbs = (double)g->n * (double)end * 4.0 / 1.0e6 * (256.0 / std::max(g->cus, 1));
         const bool streamed = end > 512;
         const double mfma_us = (streamed ? 225.0 : 125.0) + (double)((qb + 127) / 128) * (streamed ? 0.12 : 0.06) * mbs;
         const double scan_us = 40.0 + (double)((qb + 15) / 16) * (2.0 + 0.25 * mbs);
@@ -277,7 +279,7 @@ bool wants_mfma(const fir_gallery* g, int32_t qb, int32_t start, int32_t end) {
     // (up to 128 queries), the scan 0.15 us per MB for every 8 queries. Measured at d = 512 (one MI355X, device pointers):
     // 1M rows 8 / 16 / 64 queries: scan 397 / 750 / 2583 us, matrix cores 347 / 336 / 343; 100 000 rows 16 / 32 / 64: 108 / 283 /
     // 445 against 146 / 148 / 159; 65 536 rows 32 / 64: 134 / 429 against 133 / 148; 1M rows 2 / 4 / 7 queries: 349 / 353 / 1016 against ~345.
-    const double mb = (double)g->n * (double)end * 4.0 / 1.0e6;
+    const double mb = (double)g->n * (double)end * 4.0 / 1.0e6 * (256.0 / std::max(g->cus, 1));     // (scaled as above)
     if (qb >= kAutoMfmaQueries || (qb >= 32 && mb >= 128.0)) return true;
     if (qb < 2 || mb < 300.0) return false;
     // 2..31 queries over rows streamed from HBM: the scan takes one pass per power-of-two group of up to 8 queries (3 queries: 2 + 1,
