@@ -95,6 +95,8 @@ struct fir_gallery {
     // "BF, 256" (ImageTesting.cpp:526-529); one slot would rebuild fragments and scratch on every call
     struct PrefixSlot { fir_gemm* m = nullptr; int end = 0; uint64_t used = 0; } gemm_prefix[2];
     uint64_t prefix_clock = 0;
+    float* rowsum = nullptr; size_t rowsum_cap = 0;    // chi-square nomination (kChi2Harm): per-row sums over [rs_start, rs_end) + their maximum (rowsum[n])
+    int rs_start = -1, rs_end = -1;
     int warm_left = 0;                  // fir_dispatch_info::warmup_calls_left of the most recent call
     int shadow_mode = FIR_SHADOW_ALL;   // which copies of the gallery the automatic dispatch may keep next to the tiled f32 rows (fir_gallery_set_shadow_copies)
     int small_hits = 0, few_hits = 0;   // automatic mode: calls so far that would have profited from a matrix-core state not built yet (see ensure_gemm)
@@ -542,9 +544,20 @@ int topk_lists_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t s
     // re-ranked with the reference's arithmetic before the K smallest are taken: the same keys as the exact scan, about twice
     // as fast. Every row whose reference distance is <= the unwidened threshold is appended (approx <= exact (1 + eps)), and
     // the K-th smallest reference distance is <= that threshold (K sample rows are), so the K best are all in the list.
-    static const bool no_nominate = std::getenv("FIR_NO_CHI2_NOMINATION") != nullptr;      // experiments
+    const bool no_nominate = std::getenv("FIR_NO_CHI2_NOMINATION") != nullptr;      // experiments
     const bool nominate = g->metric == kChi2 && g->gallery_plain && !no_nominate && (size_t)g->d * sizeof(float) <= 48 * 1024;
-    const float tau_scale = nominate ? 1.0f + 1.5f * (2.0f * (float)(end - start) + 16.0f) * 5.9604645e-8f : 1.0f;
+    // Two nomination metrics. kChi2Approx: (l - r)^2 * rcp(l + r), within (2 nf + 8) 2^-24 RELATIVE of the reference's value (all
+    // terms >= 0), 5.5-6.6 issue slots per element. kChi2Harm (default): chi2 = sum(l) + sum(r) - 4 sum_k 1/(1/l_k + 1/r_k) -- per
+    // element one packed add, one reciprocal, one packed add = 3 issue slots, 1/r computed once per gallery value and pass. Its
+    // error is relative to sum(l) + sum(r), not to chi2: every harmonic term is within 1.5 * 2^-22 of the real one (1/l: IEEE
+    // division, 1/r and the outer reciprocal: 1 ulp each, one add), the f32 sums of nf non-negative terms add nf * 2^-24 each
+    // (harmonic terms <= (l + r)/4, so 4 * their sum <= sum(l) + sum(r)), the reference's own chain (nf + 3) 2^-24 of chi2 <=
+    // sum(l) + sum(r):  |harmonic form - reference| <= B = (3 nf + 11) 2^-24 (sum(l) + max_rows sum(r)) / nf.  The threshold is
+    // widened by 1.5 B (k_query_sums_widen): every row whose reference distance is within the unwidened one is appended.
+    const char* form_env = std::getenv("FIR_CHI2_NOMINATION");                                   // experiments / tests: 1 = kChi2Approx
+    const int chi2_form = form_env ? std::atoi(form_env) : 2;
+    const bool harm = nominate && chi2_form == 2;
+    const float tau_scale = nominate && !harm ? 1.0f + 1.5f * (2.0f * (float)(end - start) + 16.0f) * 5.9604645e-8f : 1.0f;
     const int qpad = (qb + 7) / 8 * 8;
     void *p_skeys = nullptr, *p_small = nullptr, *p_lists = nullptr;
     int rc;
@@ -557,6 +570,20 @@ int topk_lists_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t s
     int32_t* flag = counts + qpad;
     uint64_t* lists = (uint64_t*)p_lists;
     if ((rc = grow(g->qt, g->qt_cap, (size_t)qpad * g->dp4 * 4 + 64))) return rc;      // before anything is queued on it
+    float* sq = nullptr;
+    if (harm) {
+        void* p_sq = nullptr;
+        if ((rc = fir_gallery_scratch_(g, 15, (size_t)qpad * sizeof(float), &p_sq))) return rc;
+        sq = (float*)p_sq;
+        if (g->rs_start != start || g->rs_end != end || !g->rowsum) {
+            if ((rc = grow(g->rowsum, g->rowsum_cap, (size_t)g->n + 4))) return rc;
+            FIR_HIP(hipMemsetAsync(g->rowsum + g->n, 0, 4 * sizeof(float), st));
+            hipLaunchKernelGGL(k_row_sums, dim3((unsigned)((g->n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, g->gal4, g->n, g->dp4, start, end, g->rowsum,
+                               (unsigned int*)(g->rowsum + g->n));
+            g->rs_start = start;
+            g->rs_end = end;
+        }
+    }
     // 1. nearest row inside each of k disjoint groups of sample tiles (k top-1 scans, each over all the queries): the
     //    largest of the k distances is a threshold at least k rows pass; about 2.3 * n * k / rows_sampled rows will
     const int64_t want_rows = std::max<int64_t>(16384, (int64_t)g->n * k / 256);
@@ -571,9 +598,15 @@ int topk_lists_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t s
     if (rc) return rc;
     FIR_HIP(hipMemsetAsync(flag, 0, 4, st));
     hipLaunchKernelGGL(k_topk_tau, dim3((qpad + 63) / 64), dim3(64), 0, st, skeys, qb, qpad, k, tau, counts, flag, tau_scale);
+    if (harm) {
+        const float nf = (float)(end - start);
+        hipLaunchKernelGGL(k_query_sums_widen, dim3(qpad), dim3(64), 0, st, d_queries, qb, g->d, start, end, sq, tau, (const unsigned int*)(g->rowsum + g->n),
+                           (3.0f * nf + 11.0f) * 5.9604645e-8f / nf);
+    }
     // 2. the append scan over the whole gallery: 8 queries per tile, every tile of the call in one launch (blockIdx.y)
     const int kk = g->dp4 * 4;
     scan_fn fn = fast ? (scan_fn)k_scan_l2_lds<1, FIR_FAST_U, FIR_FAST_WPS, true>
+                      : harm ? (scan_fn)k_scan<8, kChi2Harm, kU, kEpiAppend, kKMax, kWpsPlain>
                       : nominate ? (scan_fn)k_scan<8, kChi2Approx, kU, kEpiAppend, kKMax, kWpsPlain>
                       : g->metric == kL2 ? (scan_fn)k_scan<8, kL2, kU, kEpiAppend, kKMax, kWps>
                       : g->metric == kChi2 ? (scan_fn)k_scan<8, kChi2, kU, kEpiAppend, kKMax, kWps>
@@ -589,7 +622,7 @@ int topk_lists_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t s
         const int live = std::max(0, std::min(qb - q0, ny * 8));
         float* qt = g->qt + (size_t)q0 * kk;
         hipLaunchKernelGGL(k_transpose_queries, dim3((unsigned)(((int64_t)kk * 8 * ny + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
-                           d_queries + (size_t)q0 * g->d, live, g->d, g->dp4, 8, qt, (uint64_t*)nullptr, 0, g->range, next_serial(g));
+                           d_queries + (size_t)q0 * g->d, live, g->d, g->dp4, 8, qt, (uint64_t*)nullptr, 0, g->range, next_serial(g), harm ? 1 : 0);
         ScanArgs a{};
         a.range = g->range;
         a.serial = g->q_serial;
@@ -609,6 +642,8 @@ int topk_lists_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t s
         a.qt_stride = (int64_t)kk * 8;
         a.nt = gallery_bytes(g) > kL2ResidentBytes ? 1 : 0;
         a.flag = flag;
+        a.sg = g->rowsum;
+        a.sq = harm ? sq + q0 : nullptr;
         hipLaunchKernelGGL(fn, dim3(waves / 4, ny), dim3(kBlock), lds_bytes, st, a);
         if (fn_plain) hipLaunchKernelGGL(fn_plain, dim3(waves / 4, ny), dim3(kBlock), lds_bytes, st, a);
     }
@@ -962,7 +997,7 @@ int fir_gallery_destroy(fir_gallery* g) {
     for (auto& ps : g->gemm_prefix) if (ps.m) { fir_gemm_destroy(ps.m); ps.m = nullptr; ps.end = 0; }
     for (hipEvent_t e : g->ev) (void)hipEventDestroy(e);
     (void)hipFree(g->gal4); (void)hipFree(g->cls); (void)hipFree(g->qt); (void)hipFree(g->dq); (void)hipFree(g->dkeys);
-    (void)hipFree(g->part); (void)hipFree(g->dout); (void)hipFree(g->didx); (void)hipFree(g->range); (void)hipFree(g->one_keys);
+    (void)hipFree(g->part); (void)hipFree(g->dout); (void)hipFree(g->didx); (void)hipFree(g->range); (void)hipFree(g->one_keys); (void)hipFree(g->rowsum);
     if (g->pin) (void)hipHostFree(g->pin);
     for (void* p : g->scratch) if (p) (void)hipFree(p);
     if (g->stream) (void)hipStreamDestroy(g->stream);

@@ -89,6 +89,8 @@ struct ScanArgs {
     const int32_t* range; // chi-square / KL: range[0] != 0 = some gallery value is outside in_plain_range(), range[1] = serial
     int32_t serial;       // of the last query transposition that met one; NULL or a match = IEEE division sequence
     int32_t* flag;        // kChi2Approx (nomination scan): raised when the operands are not all in the plain range -- the caller falls back
+    const float* sg;      // kChi2Harm: sg[row] = sum of the row's values over [start, end) ...
+    const float* sq;      // ... sq[query] = the same for the queries of the call (indexed like tau)
 };
 
 template <int QB, int METRIC, int U>
@@ -102,6 +104,29 @@ struct TileAcc {
     }
     static __device__ __forceinline__ void chunk(float (&acc)[QB], const float4 g, const float (&sq)[kSq]) {
         const float gv[4] = {g.x, g.y, g.z, g.w};
+        if constexpr (METRIC == kChi2Harm && (QB % 2) == 0) {
+            // chi-square = sum(l) + sum(r) - 4 sum_k 1/(1/l_k + 1/r_k): per gallery value ONE reciprocal shared by the QB queries, per
+            // (value, query) a packed add, a reciprocal and a packed add: 3 issue slots per element (kChi2Approx: 5.5-6.6). sq holds
+            // 1/l (+inf for l = 0 and for padding: the term is then 1/inf = +0, as the reference skips l + r = 0).
+            typedef float f2v __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float v = __builtin_amdgcn_rcpf(gv[j]);
+                const f2v v2 = {v, v};
+#pragma unroll
+                for (int p = 0; p < QB / 2; ++p) {
+                    const f2v u2 = {sq[j * QB + 2 * p], sq[j * QB + 2 * p + 1]};
+                    const f2v t2 = u2 + v2;
+                    const f2v r2 = {__builtin_amdgcn_rcpf(t2.x), __builtin_amdgcn_rcpf(t2.y)};
+                    f2v a2 = {acc[2 * p], acc[2 * p + 1]};
+                    a2 = a2 + r2;
+                    acc[2 * p] = a2.x;
+                    acc[2 * p + 1] = a2.y;
+                }
+                if constexpr (QB >= 4) __builtin_amdgcn_sched_barrier(0);
+            }
+            return;
+        }
         if constexpr (METRIC == kChi2Approx && (QB % 2) == 0) {
             // the nomination metric two queries at a time: v_pk_add (l - r, by neg), v_pk_add (l + r), 2 v_max, 2 v_rcp, v_pk_mul x 2,
             // v_pk_add = 5.5 issue slots per element (the scalar form the compiler finds: 7.2; the exact division sequence: 11)
@@ -174,7 +199,7 @@ __global__ void __launch_bounds__(kBlock, WPS) k_scan(const ScanArgs a) {
         // chi-square / KL come as a pair of launches: the kernel whose arithmetic matches the operands of this call runs
         // (every value in the plain range -> the kChi2InRange / kKLInRange form, fir_common.h), the other one returns here
         const bool plain = a.range != nullptr && a.range[0] == 0 && a.range[1] != a.serial;
-        if constexpr (METRIC == kChi2Approx) {
+        if constexpr (METRIC == kChi2Approx || METRIC == kChi2Harm) {
             // launched alone; its error bound needs non-negative, normal operands: otherwise the caller's exact path answers
             if (!plain) {
                 if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && a.flag) atomicOr(a.flag, 1);
@@ -268,7 +293,8 @@ __global__ void __launch_bounds__(kBlock, WPS) k_scan(const ScanArgs a) {
         if (row < a.n) {
 #pragma unroll
             for (int q = 0; q < QB; ++q) {
-                const float dist = acc[q] / fcount;                      // db_features.cpp:40
+                float dist = acc[q] / fcount;                            // db_features.cpp:40
+                if constexpr (METRIC == kChi2Harm) dist = ((a.sq[(size_t)blockIdx.y * QB + q] + a.sg[row]) - 4.0f * acc[q]) / fcount;
                 if constexpr (EPI == kEpiTop1) {
                     if (dist < best_d[q]) { best_d[q] = dist; best_i[q] = (int32_t)row; }   // db_features.cpp:329-332
                 } else if constexpr (EPI == kEpiTopK) {
@@ -868,9 +894,10 @@ __global__ void __launch_bounds__(kBlock) k_retile(const float* __restrict__ row
 // Queries past nq and features past d are zero. keys[0..nkeys) (may be NULL) are preset to "no row yet" on the way:
 // the top-1 scans that follow only ever lower them.
 // range[1] = serial when a query value outside in_plain_range() goes by (serial numbers the transpositions of a handle).
+// recip != 0 (kChi2Harm): the tile holds 1 / value (+inf for 0 and for the padding), the range check still sees the value.
 __global__ void __launch_bounds__(kBlock) k_transpose_queries(const float* __restrict__ q, int nq, int d, int dp4, int QB,
                                                                float* __restrict__ qt, uint64_t* __restrict__ keys, int nkeys,
-                                                               int32_t* __restrict__ range = nullptr, int serial = 0) {
+                                                               int32_t* __restrict__ range = nullptr, int serial = 0, int recip = 0) {
     const int kk = dp4 * 4;
     const int64_t total = (int64_t)((nq + QB - 1) / QB) * kk * QB;
     const int64_t o = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -885,7 +912,47 @@ __global__ void __launch_bounds__(kBlock) k_transpose_queries(const float* __res
     const int qq = tile * QB + qi;
     const float v = (qq < nq && k < d) ? q[(int64_t)qq * d + k] : 0.0f;
     if (range && !in_plain_range(v)) range[1] = serial;
-    qt[((int64_t)tile * kk + k) * QB + qi] = v;
+    qt[((int64_t)tile * kk + k) * QB + qi] = recip ? 1.0f / v : v;
+}
+
+// kChi2Harm: sg[row] = sum of the row's values over features [start, end) (one lane per row, tiled layout), smax[0] = their
+// largest (float bits, atomicMax: the sums are non-negative for the plain-range galleries the metric is used on)
+__global__ void __launch_bounds__(kBlock) k_row_sums(const float4* __restrict__ gal4, int64_t n, int dp4, int start, int end, float* __restrict__ sg,
+                                                      unsigned int* __restrict__ smax) {
+    const int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    float s = 0.0f;
+    if (row < n) {
+        const float4* p = gal4 + (size_t)(row >> 6) * dp4 * 64 + (row & 63);
+        for (int c = start >> 2; c <= (end - 1) >> 2; ++c) {
+            const float4 g = p[(size_t)c * 64];
+            const float gv[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = c * 4 + j;
+                if (k >= start && k < end) s += gv[j];
+            }
+        }
+        sg[row] = s;
+    }
+    float m = s;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(smax, __float_as_uint(m));
+}
+// sq[q] = sum of query q over [start, end); tau[q] += 1.5 * B, B = coef * (sq[q] + smax) the bound on |harmonic form - reference|
+// (fir_capi.hip, topk_lists_dev): every row whose reference distance is <= the unwidened threshold passes the widened one
+__global__ void __launch_bounds__(64) k_query_sums_widen(const float* __restrict__ q, int nq, int d, int start, int end, float* __restrict__ sq,
+                                                         float* __restrict__ tau, const unsigned int* __restrict__ smax, float coef) {
+    const int qi = blockIdx.x;
+    float s = 0.0f;
+    if (qi < nq)
+        for (int k = start + threadIdx.x; k < end; k += 64) s += q[(size_t)qi * d + k];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (threadIdx.x == 0) {
+        sq[qi] = s;
+        if (qi < nq && tau[qi] >= 0.0f) tau[qi] += 1.5f * coef * (s + __uint_as_float(smax[0]));
+    }
 }
 
 // feature_distance for one pair (db_features.cpp:22-42): one lane, sequential, exact order.

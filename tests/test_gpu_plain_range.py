@@ -71,13 +71,17 @@ def test_l2_galleries_report_the_range_too(fir):
         assert g.value_range() == (True, True)
 
 
-def test_chi2_nomination_scan_returns_the_exact_scans_keys(fir, oracle):
-    """Chi-square batches over a large plain-range gallery take a nomination scan (1-ulp reciprocal) + exact re-rank by default
+@pytest.mark.parametrize("form", ["2", "1"])
+def test_chi2_nomination_scan_returns_the_exact_scans_keys(fir, oracle, form, monkeypatch):
+    """form 2 (default): the harmonic form chi2 = sum(l) + sum(r) - 4 sum 1/(1/l_k + 1/r_k), one reciprocal per element and query, threshold
+    widened ADDITIVELY by its error bound; form 1: (l - r)^2 * rcp(l + r), threshold widened relatively (FIR_CHI2_NOMINATION).
+    Chi-square batches over a large plain-range gallery take a nomination scan (1-ulp reciprocal) + exact re-rank by default
     (fir_capi.hip: topk_lists_dev). Keys must be the exact scan's bit for bit -- top-1 and top-5, whole range and a sub-range,
     with exact duplicates (ties by row) and near-ties one ulp apart -- and the oracle's on a sample. A negative value in a
     query leaves the plain range: the exact path answers that call."""
     import synth
 
+    monkeypatch.setenv("FIR_CHI2_NOMINATION", form)
     n, d, qb = 70000, 128, 40
     rows = synth.make_gallery(61, n, d, 1)
     q, _ = synth.make_queries(61, rows, qb, 1)
