@@ -1,0 +1,44 @@
+#!/bin/bash
+# Hardware counters of the matrix-core nomination kernel at the headline shape (1M x 512, 32 768-query calls), in separate
+# rocprofv3 --pmc passes (never combined with a trace domain), merged into one JSON -> gpurun_out/pmc_gemm_f16x.json
+# usage: bash tools/pmc_gemm.sh [dim]
+set -e -o pipefail
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+D=${1:-512}
+mkdir -p "$R/gpurun_out"
+cd /tmp && export TMPDIR=/tmp
+i=0
+for SET in "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" \
+           "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU" \
+           "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM" \
+           "SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_LDS_BANK_CONFLICT SQ_INSTS_MFMA SQ_ACTIVE_INST_LDS" \
+           "FETCH_SIZE TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum"; do
+  i=$((i+1))
+  rm -rf "$R/gpurun_out/pmc_gemm_$i"
+  timeout -k 10 240 rocprofv3 --pmc $SET --output-format csv -d "$R/gpurun_out/pmc_gemm_$i" -o p -- python3 "$R/tools/mfma_ab.py" --dim "$D" --rounds 2 --check 0 --variants "default:" > "$R/gpurun_out/pmc_gemm_$i.log" 2>&1 || { echo "pass $i failed"; tail -3 "$R/gpurun_out/pmc_gemm_$i.log"; continue; }
+  F=$(find "$R/gpurun_out/pmc_gemm_$i" -name 'p_counter_collection.csv' | head -1)
+  python3 "$R/tools/summarize_prof.py" "$F" "$R/gpurun_out/pmc_gemm_$i.json"
+done
+python3 - "$R" <<'PY'
+import json, sys, glob
+R = sys.argv[1]
+out = {}
+for f in sorted(glob.glob(R + "/gpurun_out/pmc_gemm_[0-9].json")):
+    for e in json.load(open(f)):
+        if "k_gemm_proxy_f16x" not in e["kernel"]:
+            continue
+        k = out.setdefault(e["kernel"][:80], {"meta": {m: e[m] for m in ("vgpr", "sgpr", "lds", "grid", "wg")}, "counters": {}})
+        k["counters"][e["counter"]] = {"avg": e["avg"], "min": e["min"], "max": e["max"], "dispatches": e["dispatches"]}
+for k, v in out.items():
+    c = {n: x["avg"] for n, x in v["counters"].items()}
+    d = {}
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "SQ_BUSY_CYCLES" in c:
+        d["mfma_busy_over_sq_busy_x4"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (4 * c["SQ_BUSY_CYCLES"]) if c["SQ_BUSY_CYCLES"] else None
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c:
+        d["mfma_busy_cycles_per_simd_over_gui_active"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / c["GRBM_GUI_ACTIVE"]
+    if "FETCH_SIZE" in c:
+        d["fetch_KiB_per_launch_raw"] = c["FETCH_SIZE"]
+    v["derived"] = d
+json.dump(out, open(R + "/gpurun_out/pmc_gemm_f16x.json", "w"), indent=1)
+print(json.dumps({k: v["derived"] for k, v in out.items()}, indent=1))
+PY
