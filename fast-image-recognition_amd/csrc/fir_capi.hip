@@ -82,6 +82,7 @@ struct fir_gallery {
     // pinned, device-visible host staging of the small host-pointer calls: queries go in, packed keys come out, with
     // no copy engine in between (the kernels read / write it over PCIe) and one stream synchronisation per call
     void* pin = nullptr;
+    uint64_t counters[4] = {};  // fir_gallery_next_counter_
     void* scratch[16] = {};   size_t scratch_cap[16] = {};   // fir_gallery_scratch_ (classifier entry points in the other translation units)
 
     int qpp = 0;              // queries per gallery pass; 0 = automatic (effective_qpp)
@@ -812,7 +813,7 @@ extern "C" {
 const char* fir_last_error(void) { return g_err; }
 int fir_gallery_view_(fir_gallery* g, fir_gallery_view* out) {
     if (!g || !out) return FIR_ERR_ARG;
-    out->device = g->device; out->cus = g->cus; out->n = g->n; out->d = g->d; out->row_offset = g->row_offset;
+    out->device = g->device; out->cus = g->cus; out->n = g->n; out->d = g->d; out->metric = g->metric; out->row_offset = g->row_offset;
     out->cls = g->cls; out->stream = g->stream;
     return FIR_OK;
 }
@@ -1354,6 +1355,7 @@ int fir_gallery_pin_(fir_gallery* g, void** base, size_t* query_bytes, uint64_t*
     return FIR_OK;
 }
 uint64_t fir_gallery_next_ticket_(fir_gallery* g) { return ++g->one_ticket; }
+uint64_t fir_gallery_next_counter_(fir_gallery* g, int slot) { return g->counters[slot & 3]++; }
 int fir_gallery_wait_ticket_(fir_gallery* g, volatile uint64_t* flag, uint64_t ticket) { return wait_ticket(g, flag, ticket); }
 
 int fir_search_top1(fir_gallery* g, const float* queries, int32_t qb, int32_t start_pos, int32_t end_pos, int32_t* idx,

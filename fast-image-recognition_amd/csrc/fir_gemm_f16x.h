@@ -222,6 +222,8 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
         f32x4 junk = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int r = 0; r < 32; ++r) junk = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_f16x8(B[r & 7]), as_f16x8(B[(r + 1) & 7]), junk, 0, 0, 0);
+        if (nt_flags & 32)                               // (FIR_GEMM_STAGGER=2: half a row block at 512 features instead of half a unit)
+            for (int r = 0; r < 96; ++r) junk = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_f16x8(B[r & 7]), as_f16x8(B[(r + 1) & 7]), junk, 0, 0, 0);
         asm volatile("" ::"v"(junk));
     }
     bool warm = MODE == 3;                           // MODE 3: the first row block is walked twice (see above)
@@ -314,6 +316,7 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
                 hq3 = hq3 + 1 == units ? 0 : hq3 + 1;
             }
         };
+        if (nt_flags & 16) __builtin_amdgcn_s_setprio(2);       // (experiment, FIR_GEMM_PRIO: the wave in its MFMA phase goes ahead of its partner's epilogue)
         if (!ODD) {
             unit(cur, nxt, 0, std::true_type());
             unit(nxt, cur, 1, std::false_type());
@@ -331,6 +334,7 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
             for (int u = 0; u < kRing; ++u) cur[u] = nxt[u];         // an odd number of units: the next row block's first unit sits in nxt
         }
         a_cur = a_nxt;
+        if (nt_flags & 16) __builtin_amdgcn_s_setprio(0);
         if (!active) continue;
         if (full_block) {
 #pragma unroll

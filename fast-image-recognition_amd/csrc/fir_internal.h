@@ -11,6 +11,7 @@ struct fir_gallery_view {
     int cus;
     int64_t n;
     int d;
+    int metric;             // FIR_METRIC_*
     int64_t row_offset;
     const int32_t* cls;     // device, may be NULL
     hipStream_t stream;     // the handle's own stream
@@ -23,6 +24,8 @@ extern "C" int fir_gallery_tiled_(fir_gallery* g, const void** gal4, int* dp4); 
 // (the per-call hipMalloc / hipFree pairs of the classifier entry points cost more than their kernels on small galleries).
 // Slots 0-7: fir_twd.hip, 8-11: fir_dem.hip.
 extern "C" int fir_gallery_scratch_(fir_gallery* g, int slot, size_t bytes, void** out);
+// Per-handle call counters of the other translation units (slot 0: fir_twd.hip's fused classifier): returns the value before the increment.
+extern "C" uint64_t fir_gallery_next_counter_(fir_gallery* g, int slot);
 
 // d_out[(ci * qb + q) * n + row] = distance(query q, row) over sub-range ci = [start + ci*step, start + (ci+1)*step), for
 // every sub-range of [start, end): ONE gallery pass (k_scan_subranges) when step is a multiple of 32 features, one

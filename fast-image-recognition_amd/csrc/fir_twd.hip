@@ -18,10 +18,12 @@
 #include <cstring>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "../../include/fir_amd.h"
 #include "fir_internal.h"
+#include "fir_common.h"
 
 namespace {
 
@@ -484,6 +486,268 @@ __global__ void k_twd_prop_finish(int nq, int nchunks, int nseg, const DI* __res
     chunks_out[q] = st.used;
 }
 
+// ---- the same classifier as ONE launch per call (few queries): k_twd_prop_fused ----
+// The forms above read n x 4 bytes per query and chunk that a scan wrote just before, and the split form is one launch per
+// chunk. Here the chunk distances never leave the registers: blockIdx.y = query, the query's rows are dealt tile by tile
+// (64 rows, lane = row: the tiled f32 gallery of fir_kernels.h) to the gridDim.x * 8 waves of its workgroups, T tiles per
+// wave, and every lane keeps its rows' running double sums, class labels and alive bits for the whole call. Per chunk c the
+// workgroups of a query meet ONCE:
+//   before the meeting   each lane adds the chunk's distance (the reference's float loop and division, db_features.cpp:22-42)
+//                        to its alive rows' sums; the workgroup's smallest sum goes into slot[c].vmin (atomic, memory side);
+//   after it             everybody knows bestDist of chunk c, prunes its own rows against bestDist * threshold (:256-266),
+//                        posts the class range of its survivors and -- the workgroup(s) that hold the minimum -- the first row
+//                        at it with its class, and goes on to chunk c + 1 SPECULATIVELY: whether chunk c ended the loop
+//                        (num_of_variants == 1: every survivor has the best row's class, :278) is known at the NEXT meeting, when
+//                        slot[c]'s class range and best row are complete. A chunk's distances are only computed for tiles that
+//                        still have a row alive -- what the reference's classifier is about.
+// Everything the workgroups exchange goes through returning 64-bit atomics (the XCDs' L2s are not coherent with each other, and
+// plain or sc1 loads of a word other workgroups update by atomics have been seen served from stale lines: fir_gemm_f16x.h),
+// complemented where a minimum is wanted so that every word is a maximum over zero-initialised memory. A meeting is an
+// arrival counter polled by one lane per workgroup with an atomic, BOUNDED by wall time: the grid is sized to be co-resident
+// (at most one workgroup per CU), and should a workgroup nevertheless not arrive within kFusedPatienceTicks the call gives
+// up (chunks = -1) and the host takes the launch-per-chunk path -- no wave can wait for ever.
+// The state of the call after this one (the other parity block) is cleared here, by atomics as well.
+constexpr int kFusedBlock = 512;
+constexpr int kFusedMaxChunks = 64;
+constexpr int kFusedMaxQueries = 8;
+constexpr unsigned long long kFusedPatienceTicks = 25000000ull;     // wall_clock64() runs at 100 MHz: 0.25 s
+struct FusedSlot {
+    unsigned long long vmin, best, cmin, cmax;    // ~orderable(min sum); ~((row << 32) | class); ~(ord(class) + 1); ord(class) + 1
+};
+struct FusedState {
+    unsigned int ctr, done;
+    unsigned long long pad;
+    FusedSlot slot[kFusedMaxChunks];
+};
+__device__ __forceinline__ unsigned long long ord64(double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double ord64_back(unsigned long long o) {
+    const unsigned long long b = (o >> 63) ? (o & 0x7FFFFFFFFFFFFFFFull) : ~o;
+    return __longlong_as_double((long long)b);
+}
+__device__ __forceinline__ unsigned long long atomic_max_read(unsigned long long* p, unsigned long long v) {
+    return __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// A zero the compiler cannot see: an atomic maximum with a KNOWN zero is turned into an sc1 load, and what is wanted here is the
+// value at the memory side.
+__device__ __forceinline__ unsigned int opaque_zero() {
+    unsigned int z;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+    return z;
+}
+
+template <int METRIC, int T>
+__global__ void __launch_bounds__(kFusedBlock) k_twd_prop_fused(const float4* __restrict__ gal4, int dp4, int n, int tiles,
+                                                                 const int32_t* __restrict__ cls, const float* queries, int qstride,
+                                                                 int reduced, int nchunks, double threshold /* 1/th */, FusedState* state,
+                                                                 int parity, int32_t* __restrict__ class_out,
+                                                                 int32_t* __restrict__ unreliable_out, int32_t* __restrict__ chunks_out,
+                                                                 int32_t* host_res, int host_stride, uint64_t* host_ticket, uint64_t ticket) {
+    constexpr int kWaves = kFusedBlock / 64;
+    __shared__ __attribute__((aligned(16))) float qs[kLastFeature];    // the query's 256 compared features: ONE read of (pinned host) memory per workgroup
+    __shared__ unsigned long long red_key[kWaves];
+    __shared__ unsigned int red_row[kWaves], red_cmin[kWaves], red_cmax[kWaves];
+    __shared__ unsigned long long got[4];
+    __shared__ int fail_s;
+    const int q = blockIdx.y, b = blockIdx.x, G = gridDim.x, nq = gridDim.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    FusedState* S = state + (size_t)q * 2 + parity;
+    if (b == 0) {   // the next call's state (nothing of this launch touches it): all of it, whatever this call's queries and chunks
+        constexpr int words = (int)(sizeof(FusedState) / 4);
+        for (int qq = q; qq < kFusedMaxQueries; qq += nq) {
+            unsigned int* other = (unsigned int*)(state + (size_t)qq * 2 + (parity ^ 1));
+            for (int i = threadIdx.x; i < words; i += kFusedBlock) __hip_atomic_fetch_and(other + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    const float* qrow = queries + (size_t)q * qstride;
+    if (threadIdx.x < kLastFeature) qs[threadIdx.x] = qrow[threadIdx.x];
+    if (threadIdx.x == 0) fail_s = 0;
+    const int W = G * kWaves, w = b * kWaves + wave;
+    const int r4 = reduced >> 2;
+    const float fcount = (float)reduced;                               // db_features.cpp:40
+    double a[T];
+    int cl[T];
+    unsigned int alive = 0;
+#pragma unroll
+    for (int i = 0; i < T; ++i) {
+        const int t = w + i * W;
+        const int64_t row = (int64_t)t * 64 + lane;
+        a[i] = 0.0;                                                    // :210
+        cl[i] = 0;
+        if (t < tiles && row < n) { alive |= 1u << i; cl[i] = cls[row]; }   // :217
+    }
+    __syncthreads();
+    // distances of chunk c for the rows still alive, added to their sums; the workgroup's smallest sum (and its first row) to
+    // thread 0, which returns ~orderable (0 = no row below 100000) and the row
+    auto chunk = [&](int c, const float* qv, unsigned int& row_out) -> unsigned long long {
+        double md = 100000.0;                                          // bestDist = 100000 per chunk (:225)
+        int mrow = -1;
+#pragma unroll
+        for (int i = 0; i < T; ++i) {
+            if (!__builtin_amdgcn_ballot_w64((alive >> i) & 1u)) continue;      // wave-uniform: nothing of this tile is alive
+            const int t = w + i * W;
+            const float4* tp = gal4 + ((size_t)t * dp4 + (size_t)c * r4) * 64 + lane;
+            float acc = 0.0f;
+            for (int k0 = 0; k0 < r4; k0 += 8) {
+                float4 g[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (k0 + u < r4) g[u] = tp[(size_t)(k0 + u) * 64];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (k0 + u < r4) {
+                        const float4 l = *(const float4*)(qv + 4 * (k0 + u));
+                        acc = fir::accum<METRIC>(acc, l.x, g[u].x);
+                        acc = fir::accum<METRIC>(acc, l.y, g[u].y);
+                        acc = fir::accum<METRIC>(acc, l.z, g[u].z);
+                        acc = fir::accum<METRIC>(acc, l.w, g[u].w);
+                    }
+                }
+            }
+            if ((alive >> i) & 1u) {
+                const double v = a[i] + (double)(acc / fcount);        // distances[j] += distance(...) (:243)
+                a[i] = v;
+                if (v < md) { md = v; mrow = t * 64 + lane; }         // rows ascend with i: strict '<' keeps the first (:248)
+            }
+        }
+        unsigned long long key = mrow >= 0 ? ord64(md) : ~0ull;
+        unsigned int row = (unsigned int)mrow;
+        const unsigned long long wk = fir::wave_min_u64(key);
+        row = key == wk ? row : 0xFFFFFFFFu;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const unsigned int o = __shfl_xor(row, off, 64);
+            row = o < row ? o : row;
+        }
+        __syncthreads();
+        if (lane == 0) { red_key[wave] = wk; red_row[wave] = row; }
+        __syncthreads();
+        unsigned long long bk = red_key[0];
+        unsigned int br = red_row[0];
+#pragma unroll
+        for (int i = 1; i < kWaves; ++i)
+            if (red_key[i] < bk || (red_key[i] == bk && red_row[i] < br)) { bk = red_key[i]; br = red_row[i]; }
+        row_out = br;
+        return br == 0xFFFFFFFFu ? 0ull : ~bk;
+    };
+    unsigned int my_row = 0xFFFFFFFFu;
+    unsigned long long my_vmin = chunk(0, qs, my_row);
+    if (threadIdx.x == 0 && my_vmin) (void)atomic_max_read(&S->slot[0].vmin, my_vmin);      // (returning: it has been performed when the wait below ends)
+    int bestCls = -1, unreliable = 0, used = 0, failed = 0;
+    bool has_best = false;
+    for (int c = 0;; ++c) {
+        // ---- meeting c: every workgroup of the query has posted chunk c's minimum and chunk c - 1's survivors ----
+        if (threadIdx.x == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this workgroup's posts have returned
+            const unsigned int target = (unsigned int)G * (unsigned int)(c + 1);
+            unsigned int seen = __hip_atomic_fetch_add(&S->ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+            if (c < nchunks || b == 0) {                               // (after the last chunk only workgroup 0 has anything left to do)
+                unsigned long long t0 = 0;
+                for (unsigned int polls = 1; seen < target; ++polls) {
+                    __builtin_amdgcn_s_sleep(1);
+                    seen = __hip_atomic_fetch_max(&S->ctr, opaque_zero(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((polls & 15u) == 0u && seen < target) {        // (the clock is a scalar memory read: not on every poll)
+                        const unsigned long long now = wall_clock64();
+                        if (!t0) t0 = now;
+                        else if (now - t0 > kFusedPatienceTicks) { fail_s = 1; break; }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (c == nchunks && b != 0) return;
+        if (fail_s) { failed = 1; break; }
+        if (threadIdx.x < 4) {
+            unsigned long long* p = threadIdx.x == 0 ? &S->slot[c < nchunks ? c : 0].vmin
+                                  : threadIdx.x == 1 ? &S->slot[c > 0 ? c - 1 : 0].best
+                                  : threadIdx.x == 2 ? &S->slot[c > 0 ? c - 1 : 0].cmin : &S->slot[c > 0 ? c - 1 : 0].cmax;
+            got[threadIdx.x] = atomic_max_read(p, (unsigned long long)opaque_zero());
+        }
+        __syncthreads();
+        const unsigned long long g_vmin = got[0], g_best = got[1], g_cmin = got[2], g_cmax = got[3];
+        if (c > 0) {
+            // chunk c - 1's bookkeeping (:248-281), its best row and its survivors now being complete
+            ++used;
+            if (g_best) {
+                const unsigned long long kb = ~g_best;
+                bestCls = (int)(unsigned int)kb;
+                has_best = true;
+            }
+            const unsigned long long oc = (unsigned long long)((unsigned int)bestCls ^ 0x80000000u) + 1ull;
+            const bool others = g_cmax != 0ull && !(g_cmax == oc && ~g_cmin == oc);      // a survivor of another class than the best row's
+            if (!others) break;                                        // num_of_variants == 1 (:278)
+            if (c == 1) unreliable = 1;                                // :280-281
+            if (c == nchunks) break;
+        }
+        const bool has_c = g_vmin != 0ull;
+        if (!has_best && !has_c) { ++used; break; }                    // bestInd == -1: the reference would index dbImages[-1]; answered -1, like the other forms
+        const double best_d = has_c ? ord64_back(~g_vmin) : 100000.0;
+        const double dist_threshold = best_d * threshold;              // :256
+        // prune (:260-266); the class range of what survives; the first row at the minimum
+        unsigned int cmin = 0xFFFFFFFFu, cmax = 0u;
+        bool any = false;
+#pragma unroll
+        for (int i = 0; i < T; ++i) {
+            if ((alive >> i) & 1u) {
+                if (a[i] > dist_threshold) alive &= ~(1u << i);
+                else {
+                    const unsigned int oc = (unsigned int)cl[i] ^ 0x80000000u;
+                    cmin = oc < cmin ? oc : cmin;
+                    cmax = oc > cmax ? oc : cmax;
+                    any = true;
+                }
+            }
+        }
+        const bool wave_any = __builtin_amdgcn_ballot_w64(any) != 0;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const unsigned int o1 = __shfl_xor(cmin, off, 64), o2 = __shfl_xor(cmax, off, 64);
+            cmin = o1 < cmin ? o1 : cmin;
+            cmax = o2 > cmax ? o2 : cmax;
+        }
+        if (lane == 0) { red_cmin[wave] = wave_any ? cmin : 0xFFFFFFFFu; red_cmax[wave] = cmax; red_row[wave] = wave_any ? 1u : 0u; }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            unsigned int mn = 0xFFFFFFFFu, mx = 0u, anyw = 0u;
+#pragma unroll
+            for (int i = 0; i < kWaves; ++i) {
+                mn = red_cmin[i] < mn ? red_cmin[i] : mn;
+                mx = red_cmax[i] > mx ? red_cmax[i] : mx;
+                anyw |= red_row[i];
+            }
+            if (threadIdx.x == 0) {
+                if (has_c && my_vmin == g_vmin) (void)atomic_max_read(&S->slot[c].best, ~(((unsigned long long)my_row << 32) | (unsigned int)cls[my_row]));
+            } else if (anyw) {
+                if (threadIdx.x == 1) (void)atomic_max_read(&S->slot[c].cmin, ~((unsigned long long)mn + 1ull));
+                else (void)atomic_max_read(&S->slot[c].cmax, (unsigned long long)mx + 1ull);
+            }
+        }
+        __syncthreads();
+        if (c + 1 < nchunks) {
+            my_vmin = chunk(c + 1, qs + (c + 1) * reduced, my_row);
+            if (threadIdx.x == 0 && my_vmin) (void)atomic_max_read(&S->slot[c + 1].vmin, my_vmin);
+        }
+    }
+    if (b != 0 || threadIdx.x != 0) return;
+    const int cl_out = failed ? -1 : has_best ? bestCls : -1;
+    const int used_out = failed ? -1 : used;
+    class_out[q] = cl_out;
+    unreliable_out[q] = unreliable;
+    chunks_out[q] = used_out;
+    if (host_res) {
+        host_res[q] = cl_out;
+        host_res[host_stride + q] = unreliable;
+        host_res[2 * host_stride + q] = used_out;
+        __threadfence_system();
+        // the query whose workgroup 0 comes last publishes the ticket (every query's verdict is in host memory by then)
+        FusedState* S0 = state + parity;
+        if (__hip_atomic_fetch_add(&S0->done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u == (unsigned int)nq)
+            __hip_atomic_store(host_ticket, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // Queries per internal batch: as many as keep the per-batch distance tables under `budget` bytes (a multiple of 8, <= kBatch).
 int batch_for(int64_t n, size_t bytes_per_query_row, size_t budget = (size_t)512 << 20) {
     const size_t per_query = (size_t)std::max<int64_t>(n, 1) * bytes_per_query_row;
@@ -627,23 +891,31 @@ int fir_twd_proposed(fir_gallery* g, const float* queries, int32_t qb, int32_t r
     if (kLastFeature % reduced_features_count != 0)
         return twd_fail(FIR_ERR_ARG, "reduced_features_count=%d must divide %d", reduced_features_count, kLastFeature);
     const int nchunks = kLastFeature / reduced_features_count;
-    const int batch = std::min(batch_for(n, (size_t)nchunks * 4 + 9, (size_t)1 << 30), std::max(8, (qb + 7) / 8 * 8));
+    // Few queries: ONE launch per internal batch (k_twd_prop_fused). FIR_TWD_FUSED=0 never, 2 = whatever the batch (tests).
+    const char* fenv = std::getenv("FIR_TWD_FUSED");
+    const int fmode = fenv ? std::atoi(fenv) : 1;
+    const int64_t tiles = ((int64_t)n + 63) / 64;
+    bool fused = fmode != 0 && n > 0 && (fmode == 2 || qb <= kFusedMaxQueries) && (v.metric == 0 || v.metric == 1) &&
+                 reduced_features_count % 4 == 0 && reduced_features_count <= 128 && nchunks <= kFusedMaxChunks;
+    const int fq = std::min(qb, kFusedMaxQueries);                       // queries per fused launch
+    int fG = 0, fT = 0;
+    if (fused) {
+        // at most one workgroup per CU over all the queries of a launch: the workgroups of a query wait for each other
+        fG = (int)std::max<int64_t>(1, std::min<int64_t>(std::max(1, v.cus / fq), (tiles + 7) / 8));
+        const int64_t need = (tiles + (int64_t)fG * 8 - 1) / ((int64_t)fG * 8);
+        fT = need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : need <= 8 ? 8 : need <= 16 ? 16 : 0;
+        if (!fT) fused = false;
+    }
+    const int batch = fused ? 8 : std::min(batch_for(n, (size_t)nchunks * 4 + 9, (size_t)1 << 30), std::max(8, (qb + 7) / 8 * 8));
     TWD_SLOT(dq, 0, (size_t)batch * v.d * 4);
-    TWD_SLOT(cd, 4, (size_t)nchunks * batch * std::max(n, 1) * 4);
-    TWD_SLOT(acc, 5, (size_t)batch * std::max(n, 1) * 8);
-    TWD_SLOT(alive, 6, (size_t)batch * std::max(n, 1));
     TWD_SLOT(dres, 3, (size_t)3 * kBatch * 4);                 // class, unreliable, chunks
     int32_t* dcls = dres.as<int32_t>();
     int32_t* dunrel = dcls + kBatch;
     int32_t* dchunks = dcls + 2 * kBatch;
-    // large galleries: the rows of every query are split over `nseg` workgroups, three small launches per chunk
+    // large galleries: the rows of every query are split over `nseg` workgroups, one launch per chunk
     const int nseg_want = n > 16384 ? std::min(256, (n + 8191) / 8192) : 1;
     const int seg_rows = nseg_want > 1 ? ((n + nseg_want - 1) / nseg_want + 255) / 256 * 256 : n;
     const int nseg = nseg_want > 1 ? (n + seg_rows - 1) / seg_rows : 1;
-    TWD_SLOT(pws, 7, (size_t)2 * batch * sizeof(PropState) + (size_t)nchunks * batch * sizeof(int) + (size_t)nchunks * batch * nseg * sizeof(DI) + 64);
-    DI* ppart = pws.as<DI>();
-    PropState* pstate = (PropState*)(ppart + (size_t)nchunks * batch * nseg);
-    int* pcnt = (int*)(pstate + 2 * batch);
     for (int q0 = 0; q0 < qb; q0 += batch) {
         const int nq = std::min(batch, qb - q0);
         int32_t h_res[3 * kBatch];
@@ -658,37 +930,78 @@ int fir_twd_proposed(fir_gallery* g, const float* queries, int32_t qb, int32_t r
             const float* qsrc = dq.as<float>();
             if (pinned) { std::memcpy(pin_base, queries + (size_t)q0 * v.d, (size_t)nq * v.d * 4); qsrc = (const float*)pin_base; }
             else TWD_HIP(hipMemcpyAsync(dq.p, queries + (size_t)q0 * v.d, (size_t)nq * v.d * 4, hipMemcpyHostToDevice, v.stream));
-            // all chunk distances cd[c][slot][n] from ONE pass over features [0, 256)
-            if ((rc = fir_subrange_distances_dev_(g, qsrc, nq, 0, kLastFeature, reduced_features_count, cd.as<float>(), v.stream))) return rc;
-            const bool self_publish = pinned && nq == 1 && nseg == 1;    // the deciding workgroup writes verdict and ticket itself
-            const uint64_t ticket = pinned ? fir_gallery_next_ticket_(g) : 0;
-            if (nseg == 1) {
-                hipLaunchKernelGGL(k_twd_proposed, dim3(nq), dim3(kBlock), 0, v.stream, cd.as<float>(), nq, nchunks, acc.as<double>(),
-                                   alive.as<uint8_t>(), v.cls, n, 1.0 / threshold, dcls, dunrel, dchunks,
-                                   self_publish ? (int32_t*)pin_res : (int32_t*)nullptr, kBatch, self_publish ? pin_res + 2 * kBatch : (uint64_t*)nullptr,
-                                   ticket);
-            } else {
-                // nchunks + 1 launches + the finish (three launches per chunk before); the two state buffers swap roles every launch
-                hipLaunchKernelGGL(k_twd_prop_init, dim3((2 * batch + 63) / 64), dim3(64), 0, v.stream, pstate, 2 * batch);
-                TWD_HIP(hipMemsetAsync(pcnt, 0, (size_t)nchunks * nq * sizeof(int), v.stream));
-                for (int c = 0; c <= nchunks; ++c)
-                    hipLaunchKernelGGL(k_twd_prop_chunk, dim3(nseg, nq), dim3(kBlock), 0, v.stream, cd.as<float>(), nq, c, nchunks, acc.as<double>(),
-                                       alive.as<uint8_t>(), v.cls, n, seg_rows, 1.0 / threshold, pstate + (size_t)((c + 1) & 1) * batch,
-                                       pstate + (size_t)(c & 1) * batch, ppart, pcnt);
-                hipLaunchKernelGGL(k_twd_prop_finish, dim3((nq + 63) / 64), dim3(64), 0, v.stream, nq, nchunks, nseg, ppart, pcnt, v.cls,
-                                   pstate + (size_t)(nchunks & 1) * batch, dcls, dunrel, dchunks);
-            }
-            TWD_HIP(hipGetLastError());
-            if (pinned) {
-                if (!self_publish) {
-                    hipLaunchKernelGGL(k_twd_publish, dim3(1), dim3(256), 0, v.stream, dcls, 3 * kBatch, (int32_t*)pin_res, pin_res + 2 * kBatch, ticket);
-                    TWD_HIP(hipGetLastError());
+            bool answered = false;
+            if (fused) {
+                TWD_SLOT(fst, 2, (size_t)2 * kFusedMaxQueries * sizeof(FusedState));
+                const void* gal4 = nullptr;
+                int dp4 = 0;
+                if ((rc = fir_gallery_tiled_(g, &gal4, &dp4))) return twd_fail(rc, "no tiled gallery");
+                const int parity = (int)(fir_gallery_next_counter_(g, 0) & 1);
+                const uint64_t ticket = pinned ? fir_gallery_next_ticket_(g) : 0;
+                typedef void (*fused_fn)(const float4*, int, int, int, const int32_t*, const float*, int, int, int, double, FusedState*, int, int32_t*,
+                                         int32_t*, int32_t*, int32_t*, int, uint64_t*, uint64_t);
+                fused_fn fn = nullptr;
+#define FIR_FUSED_PICK(M)                                                                                              \
+    fn = fT == 1 ? k_twd_prop_fused<M, 1> : fT == 2 ? k_twd_prop_fused<M, 2> : fT == 4 ? k_twd_prop_fused<M, 4>        \
+       : fT == 8 ? k_twd_prop_fused<M, 8> : k_twd_prop_fused<M, 16>
+                if (v.metric == 0) { FIR_FUSED_PICK(fir::kL2); } else { FIR_FUSED_PICK(fir::kChi2); }
+#undef FIR_FUSED_PICK
+                hipLaunchKernelGGL(fn, dim3(fG, nq), dim3(kFusedBlock), 0, v.stream, (const float4*)gal4, dp4, n, (int)tiles, v.cls, qsrc, v.d,
+                                   reduced_features_count, nchunks, 1.0 / threshold, fst.as<FusedState>(), parity, dcls, dunrel, dchunks,
+                                   pinned ? (int32_t*)pin_res : (int32_t*)nullptr, kBatch, pinned ? pin_res + 2 * kBatch : (uint64_t*)nullptr, ticket);
+                TWD_HIP(hipGetLastError());
+                if (pinned) {
+                    if ((rc = fir_gallery_wait_ticket_(g, pin_res + 2 * kBatch, ticket))) return rc;
+                    std::memcpy(h_res, pin_res, sizeof(h_res));
+                } else {
+                    TWD_HIP(hipMemcpyAsync(h_res, dres.p, sizeof(h_res), hipMemcpyDeviceToHost, v.stream));
+                    TWD_HIP(hipStreamSynchronize(v.stream));
                 }
-                if ((rc = fir_gallery_wait_ticket_(g, pin_res + 2 * kBatch, ticket))) return rc;
-                std::memcpy(h_res, pin_res, sizeof(h_res));
-            } else {
-                TWD_HIP(hipMemcpyAsync(h_res, dres.p, sizeof(h_res), hipMemcpyDeviceToHost, v.stream));
-                TWD_HIP(hipStreamSynchronize(v.stream));
+                answered = true;
+                for (int i = 0; i < nq; ++i) answered = answered && h_chunks[i] >= 0;      // -1: the workgroups did not meet in time
+                if (!answered) TWD_HIP(hipStreamSynchronize(v.stream));
+            }
+            if (!answered) {
+                const int ob = std::max(8, (nq + 7) / 8 * 8);
+                TWD_SLOT(cd, 4, (size_t)nchunks * ob * std::max(n, 1) * 4);
+                TWD_SLOT(acc, 5, (size_t)ob * std::max(n, 1) * 8);
+                TWD_SLOT(alive, 6, (size_t)ob * std::max(n, 1));
+                TWD_SLOT(pws, 7, (size_t)2 * ob * sizeof(PropState) + (size_t)nchunks * ob * sizeof(int) + (size_t)nchunks * ob * nseg * sizeof(DI) + 64);
+                DI* ppart = pws.as<DI>();
+                PropState* pstate = (PropState*)(ppart + (size_t)nchunks * ob * nseg);
+                int* pcnt = (int*)(pstate + 2 * ob);
+                // all chunk distances cd[c][slot][n] from ONE pass over features [0, 256)
+                if ((rc = fir_subrange_distances_dev_(g, qsrc, nq, 0, kLastFeature, reduced_features_count, cd.as<float>(), v.stream))) return rc;
+                const bool self_publish = pinned && nq == 1 && nseg == 1;    // the deciding workgroup writes verdict and ticket itself
+                const uint64_t ticket = pinned ? fir_gallery_next_ticket_(g) : 0;
+                if (nseg == 1) {
+                    hipLaunchKernelGGL(k_twd_proposed, dim3(nq), dim3(kBlock), 0, v.stream, cd.as<float>(), nq, nchunks, acc.as<double>(),
+                                       alive.as<uint8_t>(), v.cls, n, 1.0 / threshold, dcls, dunrel, dchunks,
+                                       self_publish ? (int32_t*)pin_res : (int32_t*)nullptr, kBatch,
+                                       self_publish ? pin_res + 2 * kBatch : (uint64_t*)nullptr, ticket);
+                } else {
+                    // nchunks + 1 launches + the finish (three launches per chunk before); the two state buffers swap roles every launch
+                    hipLaunchKernelGGL(k_twd_prop_init, dim3((2 * ob + 63) / 64), dim3(64), 0, v.stream, pstate, 2 * ob);
+                    TWD_HIP(hipMemsetAsync(pcnt, 0, (size_t)nchunks * nq * sizeof(int), v.stream));
+                    for (int c = 0; c <= nchunks; ++c)
+                        hipLaunchKernelGGL(k_twd_prop_chunk, dim3(nseg, nq), dim3(kBlock), 0, v.stream, cd.as<float>(), nq, c, nchunks, acc.as<double>(),
+                                           alive.as<uint8_t>(), v.cls, n, seg_rows, 1.0 / threshold, pstate + (size_t)((c + 1) & 1) * ob,
+                                           pstate + (size_t)(c & 1) * ob, ppart, pcnt);
+                    hipLaunchKernelGGL(k_twd_prop_finish, dim3((nq + 63) / 64), dim3(64), 0, v.stream, nq, nchunks, nseg, ppart, pcnt, v.cls,
+                                       pstate + (size_t)(nchunks & 1) * ob, dcls, dunrel, dchunks);
+                }
+                TWD_HIP(hipGetLastError());
+                if (pinned) {
+                    if (!self_publish) {
+                        hipLaunchKernelGGL(k_twd_publish, dim3(1), dim3(256), 0, v.stream, dcls, 3 * kBatch, (int32_t*)pin_res, pin_res + 2 * kBatch, ticket);
+                        TWD_HIP(hipGetLastError());
+                    }
+                    if ((rc = fir_gallery_wait_ticket_(g, pin_res + 2 * kBatch, ticket))) return rc;
+                    std::memcpy(h_res, pin_res, sizeof(h_res));
+                } else {
+                    TWD_HIP(hipMemcpyAsync(h_res, dres.p, sizeof(h_res), hipMemcpyDeviceToHost, v.stream));
+                    TWD_HIP(hipStreamSynchronize(v.stream));
+                }
             }
         }
         for (int i = 0; i < nq; ++i) {

@@ -89,3 +89,101 @@ def test_argument_errors(fir):
             g.twd_conventional(q, 4, 0, 0.24)               # top-5 posteriors need >= 5 classes
         with pytest.raises(fir.FirError):
             g.twd_proposed(q, 48, 0.7)                      # 48 does not divide 256
+
+
+class _FusedMode:
+    """FIR_TWD_FUSED for the calls inside: 0 = the launch-per-chunk forms, 1 = automatic (up to 8 queries per call go through
+    k_twd_prop_fused), 2 = the fused form whatever the batch (8 queries per launch)."""
+
+    def __init__(self, mode):
+        self.mode = str(mode)
+
+    def __enter__(self):
+        self.old = os.environ.get("FIR_TWD_FUSED")
+        os.environ["FIR_TWD_FUSED"] = self.mode
+
+    def __exit__(self, *a):
+        if self.old is None:
+            os.environ.pop("FIR_TWD_FUSED", None)
+        else:
+            os.environ["FIR_TWD_FUSED"] = self.old
+
+
+def _proposed_all_forms(g, q, fc, th):
+    out = []
+    for mode in (0, 1, 2):
+        with _FusedMode(mode):
+            out.append(tuple(np.asarray(x).tolist() for x in g.twd_proposed(q, fc, th)))
+    return out
+
+
+@pytest.mark.parametrize("n,ncls,metric", [(70, 5, gc.L2), (3000, 37, gc.L2), (8192, 11, gc.L2), (20001, 40, gc.L2), (100000, 101, gc.L2),
+                                           (5000, 23, gc.CHI2), (40000, 64, gc.CHI2)])
+def test_proposed_twd_as_one_launch_matches_the_oracle_and_the_other_forms(fir, oracle, n, ncls, metric):
+    """k_twd_prop_fused (the chunk distances stay in registers, the workgroups of a query meet once per chunk) against the
+    oracle and against the launch-per-chunk forms: class, unreliable flag and the number of chunks used, for thresholds
+    that stop after one chunk, after a few, and never (th = 0.3: every chunk; th = 1.5: even the best row is pruned)."""
+    rows, cls, q, _ = gc.twd_case(seed=31 + n % 11, n=n, d=256, n_classes=ncls)
+    if metric == gc.CHI2:
+        rows = np.abs(rows) + np.float32(1e-3)
+        q = np.abs(q) + np.float32(1e-3)
+    q = np.concatenate([q[:5], q[5:8] * np.float32(0.05) + rows[[1, n // 2, n - 1]] * np.float32(0.95)])    # 8 queries, three of them next to a row
+    with fir.Gallery(rows, cls, metric, 0) as g:
+        for (fc, th) in [(32, 0.7), (64, 0.95), (16, 0.3), (128, 0.7), (32, 1.5), (4, 0.9)]:
+            if n >= 40000 and fc == 4:
+                continue                                              # (64 oracle chunks over 100k rows: seconds per query, covered below 40k)
+            exp = [oracle.twd_proposed(rows, cls, qi, fc, th, metric) for qi in q]
+            exp = ([e[0] for e in exp], [e[1] for e in exp], [e[2] for e in exp])
+            for form, got in zip(("per-chunk", "auto", "fused"), _proposed_all_forms(g, q, fc, th)):
+                assert got == exp, (form, fc, th)
+            with _FusedMode(1):
+                c1, u1, k1 = g.twd_proposed(q[6:7], fc, th)             # the one-query call (all CUs on one query)
+            assert (int(c1[0]), int(u1[0]), int(k1[0])) == (exp[0][6], exp[1][6], exp[2][6]), (fc, th)
+
+
+def test_proposed_twd_fused_ties_duplicates_and_rows_nothing_qualifies(fir, oracle):
+    """Equal sums in different workgroups (duplicated rows far apart: the FIRST row is the best one and its class decides),
+    a gallery whose every distance is above the reference's 100000 start value (bestInd stays -1: class -1 after one chunk),
+    NaN rows (never the best, never pruned, counted as survivors of their class)."""
+    rows, cls, q, _ = gc.twd_case(seed=44, n=30000, d=256, n_classes=50)
+    q = q[:4].copy()
+    dup = rows[17].copy()
+    for r in (17, 9000, 9001, 29999):
+        rows[r] = dup
+    cls[17], cls[9000], cls[9001], cls[29999] = 3, 4, 3, 5
+    q[0] = dup
+    q[1] = dup * np.float32(1.001)
+    with fir.Gallery(rows, cls, gc.L2, 0) as g:
+        for (fc, th) in [(32, 0.7), (64, 0.999), (32, 1.0)]:
+            exp = [oracle.twd_proposed(rows, cls, qi, fc, th) for qi in q]
+            exp = ([e[0] for e in exp], [e[1] for e in exp], [e[2] for e in exp])
+            for form, got in zip(("per-chunk", "auto", "fused"), _proposed_all_forms(g, q, fc, th)):
+                assert got == exp, (form, fc, th)
+    rows2 = rows.copy()
+    rows2[5] = np.nan
+    rows2[12345, 40] = np.nan
+    with fir.Gallery(rows2, cls, gc.L2, 0) as g:
+        exp = [oracle.twd_proposed(rows2, cls, qi, 32, 0.7) for qi in q]
+        exp = ([e[0] for e in exp], [e[1] for e in exp], [e[2] for e in exp])
+        for form, got in zip(("per-chunk", "auto", "fused"), _proposed_all_forms(g, q, 32, 0.7)):
+            assert got == exp, form
+    far = np.full((700, 256), 3.0e4, np.float32)                       # every chunk distance is 9e8 > 100000
+    with fir.Gallery(far, np.arange(700, dtype=np.int32) % 7, gc.L2, 0) as g:
+        forms = _proposed_all_forms(g, np.zeros((2, 256), np.float32), 32, 0.7)
+        assert forms[0] == forms[1] == forms[2] == ([-1, -1], [0, 0], [1, 1])
+
+
+def test_proposed_twd_fused_many_calls_in_a_row(fir, oracle):
+    """The two state blocks of the fused form alternate from call to call and each call clears the other one: a few hundred calls
+    with changing chunk counts, one and several queries, against the oracle."""
+    rows, cls, q, _ = gc.twd_case(seed=52, n=12000, d=256, n_classes=30)
+    rng = np.random.default_rng(5)
+    with fir.Gallery(rows, cls, gc.L2, 0) as g, _FusedMode(1):
+        for it in range(150):
+            fc = (8, 32, 64, 128)[it % 4]
+            th = (0.7, 0.95, 0.4)[it % 3]
+            nq = 1 + it % 5
+            qq = q[rng.integers(0, len(q), nq)] * np.float32(0.5) + rows[rng.integers(0, len(rows), nq)] * np.float32(0.5)
+            c, u, k = g.twd_proposed(qq, fc, th)
+            exp = [oracle.twd_proposed(rows, cls, qi, fc, th) for qi in qq]
+            assert (list(c), list(u), list(k)) == ([e[0] for e in exp], [e[1] for e in exp], [e[2] for e in exp]), (it, fc, th)

@@ -48,11 +48,12 @@ def main():
     del fresh, pert
     st = torch.cuda.Stream()
     nchk = min(a.check, qb)
-    kref = torch.empty(nchk, device=dev, dtype=torch.int64)
-    with torch.cuda.stream(st):
-        g.set_large_batch_mfma(0)
-        g.search_top1_keys_dev(q.data_ptr(), nchk, kref.data_ptr(), stream=st.cuda_stream)
-        g.set_large_batch_mfma(-1)
+    kref = torch.empty(max(nchk, 1), device=dev, dtype=torch.int64)[:nchk]
+    if nchk > 0:
+        with torch.cuda.stream(st):
+            g.set_large_batch_mfma(0)
+            g.search_top1_keys_dev(q.data_ptr(), nchk, kref.data_ptr(), stream=st.cuda_stream)
+            g.set_large_batch_mfma(-1)
     torch.cuda.synchronize()
     variants = []
     for spec in a.variants.split(";"):

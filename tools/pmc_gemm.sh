@@ -12,7 +12,8 @@ for SET in "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTI
            "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU" \
            "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM" \
            "SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_LDS_BANK_CONFLICT SQ_INSTS_MFMA SQ_ACTIVE_INST_LDS" \
-           "FETCH_SIZE TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum"; do
+           "FETCH_SIZE TCC_EA0_RDREQ_sum" \
+           "TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
   rm -rf "$R/gpurun_out/pmc_gemm_$i"
   timeout -k 10 240 rocprofv3 --pmc $SET --output-format csv -d "$R/gpurun_out/pmc_gemm_$i" -o p -- python3 "$R/tools/mfma_ab.py" --dim "$D" --rounds 2 --check 0 --variants "default:" > "$R/gpurun_out/pmc_gemm_$i.log" 2>&1 || { echo "pass $i failed"; tail -3 "$R/gpurun_out/pmc_gemm_$i.log"; continue; }

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""One TWD call repeated (for `rocprofv3 --kernel-trace --stats`). usage: python tools/twd_probe.py [rows] [dim] [queries] [conv|prop]"""
+"""One TWD call repeated (for `rocprofv3 --kernel-trace --stats`). usage: python tools/twd_probe.py [rows] [dim] [queries] [conv|prop|prop_all]
+(prop: a query next to a gallery row, the loop ends after the first chunk; prop_all: fresh random queries, distances concentrated: no chunk leaves one class, all 8 chunks)"""
 import gc
 import os
 import sys
@@ -21,6 +22,9 @@ rows = rng.random((n, d), dtype=np.float32)
 rows /= np.linalg.norm(rows, axis=1, keepdims=True)
 cls = (np.arange(n) // 30 % 101).astype(np.int32)
 q = rows[:qb] * np.float32(0.9) + rows[64:64 + qb] * np.float32(0.1)
+if which == "prop_all":
+    q = rng.random((qb, d), dtype=np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
 g = fir.Gallery(rows, cls, 0, 0)
 fn = (lambda: g.twd_conventional(q, 101, 0, 0.24, 64)) if which == "conv" else (lambda: g.twd_proposed(q, 32, 0.7))
 for _ in range(5):
@@ -30,5 +34,8 @@ for _ in range(100):
     t0 = time.perf_counter()
     fn()
     ts.append((time.perf_counter() - t0) * 1e6)
-print(f"{n}x{d} qb={qb} {which}: median {np.median(ts):.1f} us/call")
+extra = ""
+if which != "conv":
+    extra = f"  chunks used {g.twd_proposed(q, 32, 0.7)[2].tolist()[:4]}  FIR_TWD_FUSED={os.environ.get('FIR_TWD_FUSED', '(auto)')}"
+print(f"{n}x{d} qb={qb} {which}: median {np.median(ts):.1f} us/call" + extra)
 g.close()
