@@ -459,7 +459,8 @@ int top1_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start, 
     // chi-square batches over a large plain-range gallery: nomination scan + exact re-rank (topk_lists_dev with K = 1), the same
     // keys at about twice the rate; it synchronises `st` once (it has to know that no list overflowed) and leaves the call to the
     // exact scan below when it cannot answer (operands outside the plain range, list overflow)
-    if (g->metric == kChi2 && g->gallery_plain && g->tiles_limit == 0 && !g->quiet && !g->profiling && qb >= 8 && g->n >= 65536 && g->qpp == 0) {
+    if ((g->metric == kChi2 || g->metric == kKL) && g->gallery_plain && g->tiles_limit == 0 && !g->quiet && !g->profiling && qb >= 8 && g->n >= 65536 &&
+        g->qpp == 0) {
         int rc0 = FIR_OK;
         for (int q0 = 0; q0 < qb && rc0 == FIR_OK; q0 += 1024)       // candidate lists are 32 KiB per query: bounded scratch for any qb
             rc0 = topk_lists_dev(g, d_queries + (size_t)q0 * g->d, std::min(1024, qb - q0), start, end, 1, d_keys + q0, st);
@@ -547,6 +548,16 @@ int topk_lists_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t s
     // the K-th smallest reference distance is <= that threshold (K sample rows are), so the K best are all in the list.
     const bool no_nominate = std::getenv("FIR_NO_CHI2_NOMINATION") != nullptr;      // experiments
     const bool nominate = g->metric == kChi2 && g->gallery_plain && !no_nominate && (size_t)g->d * sizeof(float) <= 48 * 1024;
+    // KL over a plain-range gallery, the entropy form: KL = ln2 (Lq + Lg - E), Lq = sum(l log2 l + l), Lg the same over the row (both
+    // added up in double once per query / per row), E = sum_k s_k log2 s_k with s_k = l_k + r_k the only sum the scan runs: a packed
+    // add, a v_log_f32 and a packed fma per (value, query) = 3 issue slots instead of the ~35 of two quotients and two logarithms.
+    // Error against the reference's float value, u = 2^-24, S = sum(l) + sum(r), |log2 s_k| <= 26 in the plain range:
+    //   rounding of s_k: (26 + log2 e) u s_k;  v_log_f32, 1 ulp of a value below 32: 32 u s_k;  the fmas of a 4 U-term group and
+    //   the tail / edge terms: <= 64 * 26.1 u S;  the nf / (4 U) group sums: (nf / 32) 26.1 u S;  Lq, Lg to float and the two
+    //   combining operations: <= 85 u S;  the reference's own chain (two products and two adds per feature, |terms| <= S): (2 nf + 8) u S
+    //   |entropy form - reference| <= B = [ln2 (26.1 (64 + nf / 32) + 150) + 2 nf + 8] 2^-24 (sum(l) + max_rows sum(r)) / nf.
+    // The threshold is widened by 1.5 B (k_query_entropy_widen), the appended rows are re-ranked with the exact scan's arithmetic.
+    const bool klent = g->metric == kKL && g->gallery_plain && !no_nominate && (size_t)g->d * sizeof(float) <= 48 * 1024 && FIR_U == 8;
     // Two nomination metrics. kChi2Approx: (l - r)^2 * rcp(l + r), within (2 nf + 8) 2^-24 RELATIVE of the reference's value (all
     // terms >= 0), 5.5-6.6 issue slots per element. kChi2Harm (default): chi2 = sum(l) + sum(r) - 4 sum_k 1/(1/l_k + 1/r_k) -- per
     // element one packed add, one reciprocal, one packed add = 3 issue slots, 1/r computed once per gallery value and pass. Its
@@ -572,15 +583,15 @@ int topk_lists_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t s
     uint64_t* lists = (uint64_t*)p_lists;
     if ((rc = grow(g->qt, g->qt_cap, (size_t)qpad * g->dp4 * 4 + 64))) return rc;      // before anything is queued on it
     float* sq = nullptr;
-    if (harm) {
+    if (harm || klent) {
         void* p_sq = nullptr;
         if ((rc = fir_gallery_scratch_(g, 15, (size_t)qpad * sizeof(float), &p_sq))) return rc;
         sq = (float*)p_sq;
         if (g->rs_start != start || g->rs_end != end || !g->rowsum) {
             if ((rc = grow(g->rowsum, g->rowsum_cap, (size_t)g->n + 4))) return rc;
             FIR_HIP(hipMemsetAsync(g->rowsum + g->n, 0, 4 * sizeof(float), st));
-            hipLaunchKernelGGL(k_row_sums, dim3((unsigned)((g->n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, g->gal4, g->n, g->dp4, start, end, g->rowsum,
-                               (unsigned int*)(g->rowsum + g->n));
+            hipLaunchKernelGGL(klent ? k_row_entropy : k_row_sums, dim3((unsigned)((g->n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, g->gal4, g->n, g->dp4,
+                               start, end, g->rowsum, (unsigned int*)(g->rowsum + g->n));
             g->rs_start = start;
             g->rs_end = end;
         }
@@ -604,15 +615,21 @@ int topk_lists_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t s
         hipLaunchKernelGGL(k_query_sums_widen, dim3(qpad), dim3(64), 0, st, d_queries, qb, g->d, start, end, sq, tau, (const unsigned int*)(g->rowsum + g->n),
                            (3.0f * nf + 11.0f) * 5.9604645e-8f / nf);
     }
+    if (klent) {
+        const float nf = (float)(end - start);
+        hipLaunchKernelGGL(k_query_entropy_widen, dim3(qpad), dim3(64), 0, st, d_queries, qb, g->d, start, end, sq, tau, (const unsigned int*)(g->rowsum + g->n),
+                           (0.6932f * (26.1f * (64.0f + nf / 32.0f) + 150.0f) + 2.0f * nf + 8.0f) * 5.9604645e-8f / nf);
+    }
     // 2. the append scan over the whole gallery: 8 queries per tile, every tile of the call in one launch (blockIdx.y)
     const int kk = g->dp4 * 4;
     scan_fn fn = fast ? (scan_fn)k_scan_l2_lds<1, FIR_FAST_U, FIR_FAST_WPS, true>
+                      : klent ? (scan_fn)k_scan<8, kKLEnt, kU, kEpiAppend, kKMax, kWpsPlain>
                       : harm ? (scan_fn)k_scan<8, kChi2Harm, kU, kEpiAppend, kKMax, kWpsPlain>
                       : nominate ? (scan_fn)k_scan<8, kChi2Approx, kU, kEpiAppend, kKMax, kWpsPlain>
                       : g->metric == kL2 ? (scan_fn)k_scan<8, kL2, kU, kEpiAppend, kKMax, kWps>
                       : g->metric == kChi2 ? (scan_fn)k_scan<8, kChi2, kU, kEpiAppend, kKMax, kWps>
                                            : (scan_fn)k_scan<8, kKL, kU, kEpiAppend, kKMax, kWps>;
-    const scan_fn fn_plain = nominate ? nullptr
+    const scan_fn fn_plain = nominate || klent ? nullptr
                            : g->metric == kChi2 ? (scan_fn)k_scan<8, kChi2InRange, kU, kEpiAppend, kKMax, kWpsPlain>
                            : g->metric == kKL ? (scan_fn)k_scan<8, kKLInRange, kU, kEpiAppend, kKMax, kWpsPlain> : nullptr;   // see run_pass
     int max_waves = max_waves_for(g, fn, lds_bytes);
@@ -623,7 +640,7 @@ int topk_lists_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t s
         const int live = std::max(0, std::min(qb - q0, ny * 8));
         float* qt = g->qt + (size_t)q0 * kk;
         hipLaunchKernelGGL(k_transpose_queries, dim3((unsigned)(((int64_t)kk * 8 * ny + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
-                           d_queries + (size_t)q0 * g->d, live, g->d, g->dp4, 8, qt, (uint64_t*)nullptr, 0, g->range, next_serial(g), harm ? 1 : 0);
+                           d_queries + (size_t)q0 * g->d, live, g->d, g->dp4, 8, qt, (uint64_t*)nullptr, 0, g->range, next_serial(g), harm ? 1 : klent ? 2 : 0);
         ScanArgs a{};
         a.range = g->range;
         a.serial = g->q_serial;
@@ -644,11 +661,14 @@ int topk_lists_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t s
         a.nt = gallery_bytes(g) > kL2ResidentBytes ? 1 : 0;
         a.flag = flag;
         a.sg = g->rowsum;
-        a.sq = harm ? sq + q0 : nullptr;
+        a.sq = harm || klent ? sq + q0 : nullptr;
         hipLaunchKernelGGL(fn, dim3(waves / 4, ny), dim3(kBlock), lds_bytes, st, a);
         if (fn_plain) hipLaunchKernelGGL(fn_plain, dim3(waves / 4, ny), dim3(kBlock), lds_bytes, st, a);
     }
     // 3. (nomination) the reference's distance of every appended row, keys rewritten in place
+    if (klent)
+        hipLaunchKernelGGL(k_list_rerank<kKLInRange>, dim3(qb), dim3(kBlock), (size_t)g->d * sizeof(float), st, lists, counts, kListCap, g->gal4, g->dp4, g->n,
+                           g->row_offset, d_queries, g->d, start, end);
     if (nominate)
         hipLaunchKernelGGL(k_list_rerank<kChi2>, dim3(qb), dim3(kBlock), (size_t)g->d * sizeof(float), st, lists, counts, kListCap, g->gal4, g->dp4, g->n,
                            g->row_offset, d_queries, g->d, start, end);

@@ -14,7 +14,8 @@ constexpr uint64_t kKeyNone = 0xFFFFFFFFFFFFFFFFull;
 enum { kL2 = 0, kChi2 = 1, kKL = 2,
        kChi2InRange = 3, kKLInRange = 4,     // kernel-internal: the same arithmetic for operands known to be 0 or in [2^-26, 2^16]
        kChi2Approx = 5,                      // kernel-internal: chi-square with a 1-ulp reciprocal, NOMINATES rows only (fir_capi.hip: topk_lists_dev)
-       kChi2Harm = 6 };                      // kernel-internal: chi-square as sum(l) + sum(r) - 4 sum 1/(1/l + 1/r): the scan adds up the harmonic terms, NOMINATES only
+       kChi2Harm = 6,                        // kernel-internal: chi-square as sum(l) + sum(r) - 4 sum 1/(1/l + 1/r): the scan adds up the harmonic terms, NOMINATES only
+       kKLEnt = 7 };                         // kernel-internal: KL as ln2 (sum(l log2 l + l) + sum(r log2 r + r) - sum (l + r) log2 (l + r)): the scan adds up the last sum, NOMINATES only
 enum { kEpiTop1 = 0, kEpiTopK = 1, kEpiStore = 2, kEpiAppend = 3 };
 
 typedef const float __attribute__((address_space(4)))* sfloat_p;  // constant AS => s_load when uniform
@@ -110,6 +111,12 @@ __device__ __forceinline__ float accum(float acc, float l, float r) {
     else if constexpr (METRIC == kChi2Harm) {
         // l = 1 / (query value) (+inf for 0), r = gallery value: one harmonic term l_k r_k / (l_k + r_k) = 1 / (1/l_k + 1/r_k)
         return acc + __builtin_amdgcn_rcpf(l + __builtin_amdgcn_rcpf(r));
+    }
+    else if constexpr (METRIC == kKLEnt) {
+        // l = query value + 2^-100 (k_transpose_queries: l + r > 0 also where both are 0, and the term is then -100 * 2^-100),
+        // r = gallery value: one term (l + r) log2 (l + r) of the entropy form, v_log_f32 is the base-2 logarithm
+        const float s = l + r;
+        return __builtin_fmaf(s, __builtin_amdgcn_logf(s), acc);
     }
     else if constexpr (METRIC == kChi2InRange) {
         const float df = l - r;

@@ -1486,6 +1486,7 @@ struct fir_gemm {
     unsigned int* aT[2] = {nullptr, nullptr};   // ... and the ranks' shared T (float bits)
     float erel_scale = 1.0f;              // AUDIT KNOB, never set in production: the certificate's relative error bound is multiplied by this (FIR_GEMM_EREL_SCALE);
                                           // tests/test_gpu_gemm.py shows that a bound shrunk to a quarter returns a wrong row on a crafted near-tie, i.e. that the suite can see an unsound bound
+    int no_block_bound = 0;               // A/B: the append forms compute all eight proxies of every query block (FIR_GEMM_NO_BLOCK_BOUND)
     int prio = 0;                         // mfma16 experiment: s_setprio 2 around the MFMA phase of a row block (FIR_GEMM_PRIO)
     int stagger = 0;                      // mfma16 experiment: the second wave of every SIMD starts half a unit late (FIR_GEMM_STAGGER)
     int share_streamed = 8;               // ... of them when the query slabs are streamed (FIR_GEMM_SHARE_STREAMED)
@@ -1622,6 +1623,7 @@ int fir_gemm_create_range_ex_(fir_gallery* g, int32_t precision, int32_t end_pos
     if (const char* w = std::getenv("FIR_GEMM_MFMA16")) m->mfma16 = std::atoi(w) != 0 && precision == FIR_GEMM_F16;
     if (const char* w = std::getenv("FIR_GEMM_STAGGER")) m->stagger = std::atoi(w);     // 1 = half a unit, 2 = half a row block at 512 features
     if (const char* w = std::getenv("FIR_GEMM_PRIO")) m->prio = std::atoi(w) != 0;
+    if (const char* w = std::getenv("FIR_GEMM_NO_BLOCK_BOUND")) m->no_block_bound = std::atoi(w) != 0;
     if (const char* w = std::getenv("FIR_GEMM_EREL_SCALE")) m->erel_scale = (float)std::atof(w);
     if (const char* w = std::getenv("FIR_GEMM_ADAPTIVE")) m->adaptive = std::atoi(w);
     if (const char* w = std::getenv("FIR_GEMM_SHARE_STREAMED")) m->share_streamed = std::max(1, std::min(16, std::atoi(w)));
@@ -1968,11 +1970,11 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
                 } else if (adaptive)
                     hipLaunchKernelGGL(pick_x(3, streamed, (m->dk16 / kRing) & 1), g1, dim3(kGemmBlock), kHalfLds, st, m->gh, m->gnorm, m->qbf[b] + qo * 4 * m->dk16 * 64,
                                        m->qinv[b] + qo * 2 * kQT, n, (int64_t)0, n, m->dk16, m->awin[b] + qo * 2 * kQT, m->lists[b] + qo * 2 * kQT * kListCap,
-                                       m->counts[b] + qo * 2 * kQT, m->qnorm[b] + qo * 2 * kQT, sample_rows, share, nt | adapt_dbg | (m->stagger ? 2 : 0) | (m->stagger > 1 ? 32 : 0) | (m->prio ? 16 : 0), 1, m->aT[b] + qo * 2 * kQT, 0);
+                                       m->counts[b] + qo * 2 * kQT, m->qnorm[b] + qo * 2 * kQT, sample_rows, share, nt | adapt_dbg | (m->stagger ? 2 : 0) | (m->stagger > 1 ? 32 : 0) | (m->prio ? 16 : 0) | (m->no_block_bound ? 64 : 0), 1, m->aT[b] + qo * 2 * kQT, 0);
                 else if (m->mfma16)
                     hipLaunchKernelGGL(pick_x(1, streamed, (m->dk16 / kRing) & 1), g1, dim3(kGemmBlock), kHalfLds, st, m->gh, m->gnorm, m->qbf[b] + qo * 4 * m->dk16 * 64,
                                        m->qinv[b] + qo * 2 * kQT, n, (int64_t)0, n, m->dk16, m->tau[b] + qo * 2 * kQT, m->lists[b] + qo * 2 * kQT * kListCap,
-                                       m->counts[b] + qo * 2 * kQT, m->sample, sample_rows, share, nt | (m->stagger ? 2 : 0) | (m->stagger > 1 ? 32 : 0) | (m->prio ? 16 : 0), 1, (unsigned int*)nullptr, 0);
+                                       m->counts[b] + qo * 2 * kQT, m->sample, sample_rows, share, nt | (m->stagger ? 2 : 0) | (m->stagger > 1 ? 32 : 0) | (m->prio ? 16 : 0) | (m->no_block_bound ? 64 : 0), 1, (unsigned int*)nullptr, 0);
                 else if (streamed)
                     hipLaunchKernelGGL((k_gemm_proxy_f16<1, 1>), g1, dim3(kGemmBlock), kHalfLds, st, m->gh, m->gnorm, m->qbf[b] + qo * 4 * m->dk16 * 64, m->qinv[b] + qo * 2 * kQT,
                                        n, (int64_t)0, n, m->dk16, m->tau[b] + qo * 2 * kQT, m->lists[b] + qo * 2 * kQT * kListCap, m->counts[b] + qo * 2 * kQT, m->sample,

@@ -127,6 +127,27 @@ struct TileAcc {
             }
             return;
         }
+        if constexpr (METRIC == kKLEnt && (QB % 2) == 0) {
+            // sum_k (l_k + r_k) log2 (l_k + r_k) two queries at a time: v_pk_add, two v_log_f32, v_pk_fma = 3 issue slots per
+            // (value, query) (the exact form: two quotients and two logarithms, ~35)
+            typedef float f2v __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f2v g2 = {gv[j], gv[j]};
+#pragma unroll
+                for (int p = 0; p < QB / 2; ++p) {
+                    const f2v l2 = {sq[j * QB + 2 * p], sq[j * QB + 2 * p + 1]};
+                    const f2v s2 = l2 + g2;
+                    const f2v lg = {__builtin_amdgcn_logf(s2.x), __builtin_amdgcn_logf(s2.y)};
+                    f2v a2 = {acc[2 * p], acc[2 * p + 1]};
+                    a2 = __builtin_elementwise_fma(s2, lg, a2);
+                    acc[2 * p] = a2.x;
+                    acc[2 * p + 1] = a2.y;
+                }
+                if constexpr (QB >= 4) __builtin_amdgcn_sched_barrier(0);
+            }
+            return;
+        }
         if constexpr (METRIC == kChi2Approx && (QB % 2) == 0) {
             // the nomination metric two queries at a time: v_pk_add (l - r, by neg), v_pk_add (l + r), 2 v_max, 2 v_rcp, v_pk_mul x 2,
             // v_pk_add = 5.5 issue slots per element (the scalar form the compiler finds: 7.2; the exact division sequence: 11)
@@ -165,6 +186,23 @@ struct TileAcc {
     // QP = plain pointer into LDS: broadcast ds_reads, in-order and counted, scheduled by the compiler.
     template <typename QP>
     static __device__ __forceinline__ void group(float (&acc)[QB], const float4 (&g)[U], QP qc, int c) {
+        if constexpr (METRIC == kKLEnt) {
+            // the entropy terms are large next to the distance they cancel to: a group's 4 U terms are added up on their own and
+            // join the running sum once -- 4 U + nf / (4 U) roundings of the sum's magnitude on a value's way instead of nf
+            float part[QB];
+#pragma unroll
+            for (int q = 0; q < QB; ++q) part[q] = 0.0f;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float cur[kSq];
+                load_sq(cur, qc, c + u);
+                chunk(part, g[u], cur);
+                if constexpr (sizeof(QP) == sizeof(sfloat_p) && __is_same(QP, sfloat_p)) __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int q = 0; q < QB; ++q) acc[q] += part[q];
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             float cur[kSq];
@@ -199,7 +237,7 @@ __global__ void __launch_bounds__(kBlock, WPS) k_scan(const ScanArgs a) {
         // chi-square / KL come as a pair of launches: the kernel whose arithmetic matches the operands of this call runs
         // (every value in the plain range -> the kChi2InRange / kKLInRange form, fir_common.h), the other one returns here
         const bool plain = a.range != nullptr && a.range[0] == 0 && a.range[1] != a.serial;
-        if constexpr (METRIC == kChi2Approx || METRIC == kChi2Harm) {
+        if constexpr (METRIC == kChi2Approx || METRIC == kChi2Harm || METRIC == kKLEnt) {
             // launched alone; its error bound needs non-negative, normal operands: otherwise the caller's exact path answers
             if (!plain) {
                 if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && a.flag) atomicOr(a.flag, 1);
@@ -295,6 +333,7 @@ __global__ void __launch_bounds__(kBlock, WPS) k_scan(const ScanArgs a) {
             for (int q = 0; q < QB; ++q) {
                 float dist = acc[q] / fcount;                            // db_features.cpp:40
                 if constexpr (METRIC == kChi2Harm) dist = ((a.sq[(size_t)blockIdx.y * QB + q] + a.sg[row]) - 4.0f * acc[q]) / fcount;
+                if constexpr (METRIC == kKLEnt) dist = (0.693147181f * ((a.sq[(size_t)blockIdx.y * QB + q] + a.sg[row]) - acc[q])) / fcount;
                 if constexpr (EPI == kEpiTop1) {
                     if (dist < best_d[q]) { best_d[q] = dist; best_i[q] = (int32_t)row; }   // db_features.cpp:329-332
                 } else if constexpr (EPI == kEpiTopK) {
@@ -894,7 +933,8 @@ __global__ void __launch_bounds__(kBlock) k_retile(const float* __restrict__ row
 // Queries past nq and features past d are zero. keys[0..nkeys) (may be NULL) are preset to "no row yet" on the way:
 // the top-1 scans that follow only ever lower them.
 // range[1] = serial when a query value outside in_plain_range() goes by (serial numbers the transpositions of a handle).
-// recip != 0 (kChi2Harm): the tile holds 1 / value (+inf for 0 and for the padding), the range check still sees the value.
+// recip == 1 (kChi2Harm): the tile holds 1 / value (+inf for 0 and for the padding), the range check still sees the value;
+// recip == 2 (kKLEnt): value + 2^-100 (the value itself unless it is 0: plain-range values are 0 or >= 2^-26).
 __global__ void __launch_bounds__(kBlock) k_transpose_queries(const float* __restrict__ q, int nq, int d, int dp4, int QB,
                                                                float* __restrict__ qt, uint64_t* __restrict__ keys, int nkeys,
                                                                int32_t* __restrict__ range = nullptr, int serial = 0, int recip = 0) {
@@ -912,7 +952,7 @@ __global__ void __launch_bounds__(kBlock) k_transpose_queries(const float* __res
     const int qq = tile * QB + qi;
     const float v = (qq < nq && k < d) ? q[(int64_t)qq * d + k] : 0.0f;
     if (range && !in_plain_range(v)) range[1] = serial;
-    qt[((int64_t)tile * kk + k) * QB + qi] = recip ? 1.0f / v : v;
+    qt[((int64_t)tile * kk + k) * QB + qi] = recip == 1 ? 1.0f / v : recip == 2 ? v + 0x1p-100f : v;
 }
 
 // kChi2Harm: sg[row] = sum of the row's values over features [start, end) (one lane per row, tiled layout), smax[0] = their
@@ -938,6 +978,49 @@ __global__ void __launch_bounds__(kBlock) k_row_sums(const float4* __restrict__ 
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
     if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(smax, __float_as_uint(m));
+}
+// kKLEnt: sg[row] = sum over [start, end) of r log2 r + r (0 for r = 0; added up in double, stored as float), smax[0] = the largest
+// plain row sum (float bits, atomicMax) -- what the nomination's error bound is relative to, as for kChi2Harm
+__global__ void __launch_bounds__(kBlock) k_row_entropy(const float4* __restrict__ gal4, int64_t n, int dp4, int start, int end, float* __restrict__ sg,
+                                                         unsigned int* __restrict__ smax) {
+    const int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    float s = 0.0f;
+    if (row < n) {
+        const float4* p = gal4 + (size_t)(row >> 6) * dp4 * 64 + (row & 63);
+        double e = 0.0;
+        for (int c = start >> 2; c <= (end - 1) >> 2; ++c) {
+            const float4 g = p[(size_t)c * 64];
+            const float gv[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = c * 4 + j;
+                if (k >= start && k < end && gv[j] > 0.0f) { s += gv[j]; e += (double)gv[j] * log2((double)gv[j]) + (double)gv[j]; }
+            }
+        }
+        sg[row] = (float)e;
+    }
+    float m = s;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(smax, __float_as_uint(m));
+}
+// ... and the same for the queries of a call; tau[q] += 1.5 * B, B = coef * (sum(l) + smax) the bound on |entropy form - reference|
+__global__ void __launch_bounds__(64) k_query_entropy_widen(const float* __restrict__ q, int nq, int d, int start, int end, float* __restrict__ sq,
+                                                            float* __restrict__ tau, const unsigned int* __restrict__ smax, float coef) {
+    const int qi = blockIdx.x;
+    float s = 0.0f;
+    double e = 0.0;
+    if (qi < nq)
+        for (int k = start + threadIdx.x; k < end; k += 64) {
+            const float v = q[(size_t)qi * d + k];
+            if (v > 0.0f) { s += v; e += (double)v * log2((double)v) + (double)v; }
+        }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { s += __shfl_xor(s, off, 64); e += __shfl_xor(e, off, 64); }
+    if (threadIdx.x == 0) {
+        sq[qi] = (float)e;
+        if (qi < nq && tau[qi] >= 0.0f) tau[qi] += 1.5f * coef * (s + __uint_as_float(smax[0]));
+    }
 }
 // sq[q] = sum of query q over [start, end); tau[q] += 1.5 * B, B = coef * (sq[q] + smax) the bound on |harmonic form - reference|
 // (fir_capi.hip, topk_lists_dev): every row whose reference distance is <= the unwidened threshold passes the widened one

@@ -109,3 +109,44 @@ def test_chi2_nomination_scan_returns_the_exact_scans_keys(fir, oracle, form, mo
         assert np.array_equal(a5[0][i], ei) and np.array_equal(a5[1][i].view(np.uint32), ed.view(np.uint32))
     oi, od = oracle.recognize_bf(rows, qn[0], 0, d, 1)
     assert n1[0][0] == oi and np.float32(n1[1][0]).view(np.uint32) == np.float32(od).view(np.uint32)
+
+
+def test_kl_nomination_scan_returns_the_exact_scans_keys(fir, oracle, monkeypatch):
+    """KL batches over a large plain-range gallery: the nomination scan adds up (l + r) log2 (l + r) only (kKLEnt: the other two
+    sums of KL = ln2 (sum(l log2 l + l) + sum(r log2 r + r) - sum (l + r) log2 (l + r)) belong to the query and to the row), the
+    threshold is widened by the form's error bound and the appended rows are re-ranked with the exact scan's arithmetic
+    (fir_capi.hip: topk_lists_dev). Keys must be the exact scan's bit for bit -- top-1 and top-5, whole range and a sub-range, with
+    exact duplicates (ties by row), zeros on both sides and a near-tie -- and the oracle's within the KL tolerance on a sample."""
+    import synth
+
+    n, d, qb = 70000, 128, 40
+    rows = synth.make_gallery(71, n, d, 2)
+    q, _ = synth.make_queries(71, rows, qb, 2)
+    rows[:, 5] = 0                                    # zeros on both sides: the term is skipped by the reference
+    q[:, 5] = 0
+    rows[1000:1100, 9] = 0
+    q[7, 11] = 0
+    rows[n - 3] = rows[17]
+    q[2] = rows[17]                                   # exact tie (distance 0): first row wins
+    rows[5000] = rows[4000]
+    rows[5000, 7] = np.nextafter(rows[5000, 7], np.float32(1))     # near-tie one ulp apart
+    q[3] = 0.5 * (rows[4000] + rows[123])
+    with fir.Gallery(rows, None, fir.METRIC_KL, 0) as g:
+        a1 = g.search_top1(q)                         # default dispatch: nomination
+        a5 = g.search_topk(q, 5)
+        s1 = g.search_top1(q, 32, 96)
+        monkeypatch.setenv("FIR_NO_CHI2_NOMINATION", "1")
+        e1 = g.search_top1(q)
+        e5 = g.search_topk(q, 5)
+        es1 = g.search_top1(q, 32, 96)
+        monkeypatch.delenv("FIR_NO_CHI2_NOMINATION")
+    assert np.array_equal(a1[0], e1[0]) and np.array_equal(a1[1].view(np.uint32), e1[1].view(np.uint32))
+    assert np.array_equal(s1[0], es1[0]) and np.array_equal(s1[1].view(np.uint32), es1[1].view(np.uint32))
+    assert np.array_equal(a5[0], e5[0]) and np.array_equal(a5[1].view(np.uint32), e5[1].view(np.uint32))
+    assert np.array_equal(a5[0][:, 0], a1[0]) and a1[0][2] == 17
+    for i in (0, 2, 7, 11, 39):
+        ei, ed = oracle.topk(rows, q[i], 0, d, 5, 2)
+        assert np.allclose(a5[1][i], ed, rtol=1e-5, atol=1e-9)          # device log vs glibc logf: the KL tolerance of test_gpu_golden
+        gaps = np.diff(ed) > 4e-5 * np.abs(ed[1:])
+        if gaps.all():
+            assert np.array_equal(a5[0][i], ei)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Chi-square top-1 / top-5 over a 1M x 512 L1-normalised gallery (BASELINE config 3): exact scan vs the two nomination forms.
-usage: python tools/chi2_bench.py [--rows 1000000] [--dim 512] [--qb 256]"""
+usage: python tools/chi2_bench.py [--rows 1000000] [--dim 512] [--qb 256] [--metric 1|2]   (2 = KL: exact scan vs the entropy-form nomination)"""
 import argparse, os, sys, time
 import numpy as np
 import torch
@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--rows", type=int, default=1_000_000)
     ap.add_argument("--dim", type=int, default=512)
     ap.add_argument("--qb", type=int, default=256)
+    ap.add_argument("--metric", type=int, default=1)
     a = ap.parse_args()
     fir = ge.load_package()
     dev = torch.device("cuda", 0)
@@ -35,7 +36,7 @@ def main():
     pert = x[(torch.arange(a.qb, device=dev) * 977 + 11) % a.rows] * (1 + 0.05 * (torch.rand((a.qb, a.dim), device=dev) - 0.5))
     q = torch.where((torch.arange(a.qb, device=dev) % 2 == 0)[:, None], fresh, pert)
     q = (q / q.sum(dim=1, keepdim=True)).contiguous()
-    g = fir.Gallery(dev_ptr=x.data_ptr(), n=a.rows, d=a.dim, metric=1, device=0)
+    g = fir.Gallery(dev_ptr=x.data_ptr(), n=a.rows, d=a.dim, metric=a.metric, device=0)
     k1 = torch.empty(a.qb, device=dev, dtype=torch.int64)
     k5 = torch.empty(a.qb * 5, device=dev, dtype=torch.int64)
     ref1 = torch.empty(a.qb, device=dev, dtype=torch.int64)
@@ -45,7 +46,7 @@ def main():
     r5 = rate(lambda: g.search_topk_keys_dev(q.data_ptr(), a.qb, 5, ref5.data_ptr()), a.qb, 1)
     print(f"exact scan        top-1 {r1:9.0f} q/s   top-5 {r5:9.0f} q/s", flush=True)
     del os.environ["FIR_NO_CHI2_NOMINATION"]
-    for form, name in (("1", "(l-r)^2 rcp(l+r) "), ("2", "harmonic form    ")):
+    for form, name in ((("1", "(l-r)^2 rcp(l+r) "), ("2", "harmonic form    ")) if a.metric == 1 else (("2", "entropy form     "),)):
         os.environ["FIR_CHI2_NOMINATION"] = form
         r1 = rate(lambda: g.search_top1_keys_dev(q.data_ptr(), a.qb, k1.data_ptr()), a.qb)
         r5 = rate(lambda: g.search_topk_keys_dev(q.data_ptr(), a.qb, 5, k5.data_ptr()), a.qb)

@@ -33,12 +33,25 @@ for f in sorted(glob.glob(R + "/gpurun_out/pmc_gemm_[0-9].json")):
 for k, v in out.items():
     c = {n: x["avg"] for n, x in v["counters"].items()}
     d = {}
-    if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "SQ_BUSY_CYCLES" in c:
-        d["mfma_busy_over_sq_busy_x4"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (4 * c["SQ_BUSY_CYCLES"]) if c["SQ_BUSY_CYCLES"] else None
+    # GRBM_GUI_ACTIVE is summed over the 8 XCDs; SQ_VALU_MFMA_BUSY_CYCLES over the 1024 SIMDs (cycles); SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* in quad-cycles
+    if "GRBM_GUI_ACTIVE" in c:
+        d["kernel_cycles"] = c["GRBM_GUI_ACTIVE"] / 8
     if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c:
-        d["mfma_busy_cycles_per_simd_over_gui_active"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / c["GRBM_GUI_ACTIVE"]
+        d["mfma_pipe_busy_fraction"] = (c["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024) / (c["GRBM_GUI_ACTIVE"] / 8)
+    if "SQ_INSTS_MFMA" in c:
+        m = c["SQ_INSTS_MFMA"]
+        d["mfma_per_launch"] = m
+        for n_ in ("SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_INSTS_VMEM"):
+            if n_ in c:
+                d[n_.lower() + "_per_mfma"] = (c[n_] - (m if n_ == "SQ_INSTS_VALU" else 0)) / m
+    if "SQ_WAVE_CYCLES" in c:
+        for n_ in ("SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_LDS"):
+            if n_ in c:
+                d[n_.lower() + "_over_wave_cycles"] = c[n_] / c["SQ_WAVE_CYCLES"]
     if "FETCH_SIZE" in c:
-        d["fetch_KiB_per_launch_raw"] = c["FETCH_SIZE"]
+        d["hbm_bytes_per_launch_fetch_size_x1024_x2"] = c["FETCH_SIZE"] * 1024 * 2
+    if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c:
+        d["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
     v["derived"] = d
 json.dump(out, open(R + "/gpurun_out/pmc_gemm_f16x.json", "w"), indent=1)
 print(json.dumps({k: v["derived"] for k, v in out.items()}, indent=1))
