@@ -589,13 +589,17 @@ def other_scans(fir, g, q, keys, dev, ws, n, d):
             plain = g.value_range()
             k32x = k32.clone()
             r5 = rate(lambda: g.search_topk_keys_dev(q32.data_ptr(), 32, 5, k32_5.data_ptr(), stream=stream), 32, 2)
-            # the library's default dispatch for this batch (chi-square: nomination scan + exact re-rank; KL: the exact scan again)
+            # the library's default dispatch for this batch (chi-square: harmonic-form nomination scan + exact re-rank; KL: entropy-form nomination + exact re-rank)
             q256 = q[:256].clamp_min(0.0)
             q256 = torch.where(q256 < 1e-4 / 13.0, torch.zeros_like(q256), q256).contiguous()
             k256 = torch.empty(256, device=dev, dtype=torch.int64)
             r1d = rate(lambda: g.search_top1_keys_dev(q256.data_ptr(), 256, k256.data_ptr(), stream=stream), 256, 2)
+            k256_5 = torch.empty((256, 5), device=dev, dtype=torch.int64)
+            r5d = rate(lambda: g.search_topk_keys_dev(q256.data_ptr(), 256, 5, k256_5.data_ptr(), stream=stream), 256, 2)
             also[f"{name}_top1_default_dispatch_queries_per_s_batch256"] = r1d
             also[f"{name}_top1_default_dispatch_equals_exact_scan"] = bool(torch.equal(k256[:32], k32x))
+            also[f"{name}_top5_default_dispatch_queries_per_s_batch256"] = r5d
+            also[f"{name}_top5_default_dispatch_first_column_is_exact_top1"] = bool(torch.equal(k256_5[:32, 0], k32x))
             also[f"{name}_top1_queries_per_s"] = r1
             also[f"{name}_top5_queries_per_s"] = r5
             also[f"{name}_top5_first_column_is_top1"] = bool(torch.equal(k32_5[:, 0], k32))

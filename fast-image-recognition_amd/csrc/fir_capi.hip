@@ -97,7 +97,7 @@ struct fir_gallery {
     struct PrefixSlot { fir_gemm* m = nullptr; int end = 0; uint64_t used = 0; } gemm_prefix[2];
     uint64_t prefix_clock = 0;
     float* rowsum = nullptr; size_t rowsum_cap = 0;    // chi-square nomination (kChi2Harm): per-row sums over [rs_start, rs_end) + their maximum (rowsum[n])
-    int rs_start = -1, rs_end = -1;
+    int rs_start = -1, rs_end = -1, rs_metric = -1;   // (what g->rowsum holds: row sums for chi-square, row entropies for KL)
     int warm_left = 0;                  // fir_dispatch_info::warmup_calls_left of the most recent call
     int shadow_mode = FIR_SHADOW_ALL;   // which copies of the gallery the automatic dispatch may keep next to the tiled f32 rows (fir_gallery_set_shadow_copies)
     int small_hits = 0, few_hits = 0;   // automatic mode: calls so far that would have profited from a matrix-core state not built yet (see ensure_gemm)
@@ -106,6 +106,7 @@ struct fir_gallery {
     fir_dispatch_info last{}; // dominant kernel of the most recent search
     int call_launches = 0;    // scan launches of the current call (note_dispatch)
     bool quiet = false;       // scans on behalf of another path (the matrix-core path's uncertified queries): not recorded, not timed
+    int sample_groups = 0; int64_t sample_group_stride = 0;   // run_pass (generic k_scan, top-1): ScanArgs::groups / group_stride
     int64_t tiles_limit = 0, tile_begin = 0;  // tiles_limit > 0: scans cover tiles [tile_begin, tile_begin + tiles_limit) only (row samples of the top-K threshold)
     int max_tiles_per_launch = 64;   // query tiles (gallery passes) folded into one launch of the hand-scheduled kernels
 
@@ -401,10 +402,14 @@ int run_pass(fir_gallery* g, hipStream_t st, int epi, const float* d_queries, in
     }
     int max_waves = max_waves_for(g, fn, lds_bytes);
     if (fn_plain) max_waves = std::min(max_waves, max_waves_for(g, fn_plain, lds_bytes));
-    const int waves = g->waves_req > 0 ? std::min(g->waves_req, max_waves) : pick_waves(g->tiles, max_waves, g->cus * 4);
+    int waves = g->waves_req > 0 ? std::min(g->waves_req, max_waves) : pick_waves(g->tiles, max_waves, g->cus * 4);
+    const int groups = epi == kEpiTop1 && g->sample_groups > 1 && g->metric != kL2 ? g->sample_groups : 0;
+    if (groups) waves = std::max(4 * groups, waves / (4 * groups) * (4 * groups));      // a wave's tiles all belong to one group
     g->last_waves = waves;
     if (waves_used) *waves_used = waves;
     ScanArgs a{};
+    a.groups = groups;
+    a.group_stride = g->sample_group_stride;
     a.qt = qt;
     const int64_t tile0 = g->tiles_limit > 0 ? std::min<int64_t>(g->tile_begin, g->tiles) : 0;
     const int64_t tiles = g->tiles_limit > 0 ? std::min<int64_t>(g->tiles_limit, g->tiles - tile0) : g->tiles;
@@ -559,18 +564,21 @@ int topk_lists_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t s
     // The threshold is widened by 1.5 B (k_query_entropy_widen), the appended rows are re-ranked with the exact scan's arithmetic.
     const bool klent = g->metric == kKL && g->gallery_plain && !no_nominate && (size_t)g->d * sizeof(float) <= 48 * 1024 && FIR_U == 8;
     // Two nomination metrics. kChi2Approx: (l - r)^2 * rcp(l + r), within (2 nf + 8) 2^-24 RELATIVE of the reference's value (all
-    // terms >= 0), 5.5-6.6 issue slots per element. kChi2Harm (default): chi2 = sum(l) + sum(r) - 4 sum_k 1/(1/l_k + 1/r_k) -- per
-    // element one packed add, one reciprocal, one packed add = 3 issue slots, 1/r computed once per gallery value and pass. Its
-    // error is relative to sum(l) + sum(r), not to chi2: every harmonic term is within 1.5 * 2^-22 of the real one (1/l: IEEE
-    // division, 1/r and the outer reciprocal: 1 ulp each, one add), the f32 sums of nf non-negative terms add nf * 2^-24 each
-    // (harmonic terms <= (l + r)/4, so 4 * their sum <= sum(l) + sum(r)), the reference's own chain (nf + 3) 2^-24 of chi2 <=
-    // sum(l) + sum(r):  |harmonic form - reference| <= B = (3 nf + 11) 2^-24 (sum(l) + max_rows sum(r)) / nf.  The threshold is
-    // widened by 1.5 B (k_query_sums_widen): every row whose reference distance is within the unwidened one is appended.
+    // terms >= 0), 5.5-6.6 issue slots per element. kChi2Harm (default): chi2 = sum(l) + sum(r) - 4 sum_k 1/(1/l_k + 1/r_k), two
+    // terms per reciprocal, 1/A + 1/B = (A + B) / (A B) with A = 1/l_k + 1/r_k: 2.25 issue slots per element, 1/r computed once per
+    // gallery value and pass. Its error is relative to sum(l) + sum(r), not to chi2, u = 2^-24: 1/l (IEEE division) u, 1/r (v_rcp_f32,
+    // 1 ulp) 2 u, so A and B within 3 u, A + B 4 u, A B 7 u, its reciprocal 9 u, the pair of terms (4 + 9 + 1) u = 14 u of its value;
+    // harmonic terms <= (l + r)/4, so 4 * their sum <= sum(l) + sum(r): 14 u (sum(l) + sum(r)); the fma chain of nf / 2 non-negative
+    // terms adds nf u / 2, the two plain sums nf u each, the reference's own chain (nf + 3) u of chi2 <= sum(l) + sum(r):
+    //   |harmonic form - reference| <= B = (3 nf + 19) 2^-24 (sum(l) + max_rows sum(r)) / nf.
+    // The threshold is widened by 1.5 B (k_query_sums_widen): every row whose reference distance is within the unwidened one is appended.
     const char* form_env = std::getenv("FIR_CHI2_NOMINATION");                                   // experiments / tests: 1 = kChi2Approx
     const int chi2_form = form_env ? std::atoi(form_env) : 2;
     const bool harm = nominate && chi2_form == 2;
     const float tau_scale = nominate && !harm ? 1.0f + 1.5f * (2.0f * (float)(end - start) + 16.0f) * 5.9604645e-8f : 1.0f;
-    const int qpad = (qb + 7) / 8 * 8;
+    // the two cheap nomination forms take two tiles of 8 queries per gallery read (k_nominate): whole pairs of tiles
+    const int nh = (harm || klent) && !std::getenv("FIR_NOMINATE_ONE_TILE") ? 2 : 1;
+    const int qpad = (qb + 8 * nh - 1) / (8 * nh) * (8 * nh);
     void *p_skeys = nullptr, *p_small = nullptr, *p_lists = nullptr;
     int rc;
     if ((rc = fir_gallery_scratch_(g, 12, (size_t)qb * k * 8, &p_skeys))) return rc;
@@ -587,23 +595,36 @@ int topk_lists_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t s
         void* p_sq = nullptr;
         if ((rc = fir_gallery_scratch_(g, 15, (size_t)qpad * sizeof(float), &p_sq))) return rc;
         sq = (float*)p_sq;
-        if (g->rs_start != start || g->rs_end != end || !g->rowsum) {
+        if (g->rs_start != start || g->rs_end != end || g->rs_metric != g->metric || !g->rowsum) {
             if ((rc = grow(g->rowsum, g->rowsum_cap, (size_t)g->n + 4))) return rc;
             FIR_HIP(hipMemsetAsync(g->rowsum + g->n, 0, 4 * sizeof(float), st));
             hipLaunchKernelGGL(klent ? k_row_entropy : k_row_sums, dim3((unsigned)((g->n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, g->gal4, g->n, g->dp4,
                                start, end, g->rowsum, (unsigned int*)(g->rowsum + g->n));
             g->rs_start = start;
             g->rs_end = end;
+            g->rs_metric = g->metric;
         }
     }
     // 1. nearest row inside each of k disjoint groups of sample tiles (k top-1 scans, each over all the queries): the
     //    largest of the k distances is a threshold at least k rows pass; about 2.3 * n * k / rows_sampled rows will
     const int64_t want_rows = std::max<int64_t>(16384, (int64_t)g->n * k / 256);
     const int64_t group_tiles = std::max<int64_t>(1, std::min<int64_t>(g->tiles / k, (want_rows / k + kTileRows - 1) / kTileRows));
-    for (int i = 0; i < k && !rc; ++i) {
-        g->tile_begin = i * group_tiles;
-        g->tiles_limit = group_tiles;
-        rc = top1_dev(g, d_queries, qb, start, end, skeys + (size_t)i * qb, st);
+    if (k > 1 && g->metric != kL2) {
+        // chi-square / KL: the K samples in ONE launch -- sample tile t belongs to group t mod K, a wave reports into its group's keys
+        // (K launches of group_tiles tiles each leave most of the chip idle: a tile is one wave's serial work)
+        FIR_HIP(hipMemsetAsync(skeys, 0xFF, (size_t)qb * k * 8, st));
+        g->tile_begin = 0;
+        g->tiles_limit = group_tiles * k;
+        g->sample_groups = k;
+        g->sample_group_stride = qb;
+        rc = top1_dev(g, d_queries, qb, start, end, skeys, st);
+        g->sample_groups = 0;
+    } else {
+        for (int i = 0; i < k && !rc; ++i) {
+            g->tile_begin = i * group_tiles;
+            g->tiles_limit = group_tiles;
+            rc = top1_dev(g, d_queries, qb, start, end, skeys + (size_t)i * qb, st);
+        }
     }
     g->tiles_limit = 0;
     g->tile_begin = 0;
@@ -613,7 +634,7 @@ int topk_lists_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t s
     if (harm) {
         const float nf = (float)(end - start);
         hipLaunchKernelGGL(k_query_sums_widen, dim3(qpad), dim3(64), 0, st, d_queries, qb, g->d, start, end, sq, tau, (const unsigned int*)(g->rowsum + g->n),
-                           (3.0f * nf + 11.0f) * 5.9604645e-8f / nf);
+                           (3.0f * nf + 19.0f) * 5.9604645e-8f / nf);
     }
     if (klent) {
         const float nf = (float)(end - start);
@@ -632,11 +653,13 @@ int topk_lists_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t s
     const scan_fn fn_plain = nominate || klent ? nullptr
                            : g->metric == kChi2 ? (scan_fn)k_scan<8, kChi2InRange, kU, kEpiAppend, kKMax, kWpsPlain>
                            : g->metric == kKL ? (scan_fn)k_scan<8, kKLInRange, kU, kEpiAppend, kKMax, kWpsPlain> : nullptr;   // see run_pass
+    if (nh == 2) fn = klent ? (scan_fn)k_nominate<kKLEnt, 2, kU, kWpsPlain> : (scan_fn)k_nominate<kChi2Harm, 2, kU, kWpsPlain>;
     int max_waves = max_waves_for(g, fn, lds_bytes);
     if (fn_plain) max_waves = std::min(max_waves, max_waves_for(g, fn_plain, lds_bytes));
     const int waves = g->waves_req > 0 ? std::min(g->waves_req, max_waves) : pick_waves(g->tiles, max_waves, g->cus * 4);
-    for (int q0 = 0; q0 < qpad; q0 += 8 * g->max_tiles_per_launch) {
-        const int ny = std::min(g->max_tiles_per_launch, (qpad - q0) / 8);
+    const int tiles_per_launch = nh == 2 ? std::max(2, g->max_tiles_per_launch & ~1) : g->max_tiles_per_launch;
+    for (int q0 = 0; q0 < qpad; q0 += 8 * tiles_per_launch) {
+        const int ny = std::min(tiles_per_launch, (qpad - q0) / 8);
         const int live = std::max(0, std::min(qb - q0, ny * 8));
         float* qt = g->qt + (size_t)q0 * kk;
         hipLaunchKernelGGL(k_transpose_queries, dim3((unsigned)(((int64_t)kk * 8 * ny + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
@@ -662,7 +685,7 @@ int topk_lists_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t s
         a.flag = flag;
         a.sg = g->rowsum;
         a.sq = harm || klent ? sq + q0 : nullptr;
-        hipLaunchKernelGGL(fn, dim3(waves / 4, ny), dim3(kBlock), lds_bytes, st, a);
+        hipLaunchKernelGGL(fn, dim3(waves / 4, ny / nh), dim3(kBlock), lds_bytes, st, a);
         if (fn_plain) hipLaunchKernelGGL(fn_plain, dim3(waves / 4, ny), dim3(kBlock), lds_bytes, st, a);
     }
     // 3. (nomination) the reference's distance of every appended row, keys rewritten in place

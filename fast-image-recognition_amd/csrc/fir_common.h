@@ -109,7 +109,8 @@ __device__ __forceinline__ float accum(float acc, float l, float r) {
         return acc + (df * df) * __builtin_amdgcn_rcpf(s);
     }
     else if constexpr (METRIC == kChi2Harm) {
-        // l = 1 / (query value) (+inf for 0), r = gallery value: one harmonic term l_k r_k / (l_k + r_k) = 1 / (1/l_k + 1/r_k)
+        // l = 1 / (query value) (2^60 for 0), r = gallery value: one harmonic term l_k r_k / (l_k + r_k) = 1 / (1/l_k + 1/r_k)
+        // (range edges only: whole chunks take TileAcc::chunk's two-terms-per-reciprocal form)
         return acc + __builtin_amdgcn_rcpf(l + __builtin_amdgcn_rcpf(r));
     }
     else if constexpr (METRIC == kKLEnt) {

@@ -91,6 +91,8 @@ struct ScanArgs {
     int32_t* flag;        // kChi2Approx (nomination scan): raised when the operands are not all in the plain range -- the caller falls back
     const float* sg;      // kChi2Harm: sg[row] = sum of the row's values over [start, end) ...
     const float* sq;      // ... sq[query] = the same for the queries of the call (indexed like tau)
+    int32_t groups;       // k_scan, top-1 epilogue, > 1: the tiles form `groups` disjoint sets (tile index mod groups; a.waves is a multiple of it, so
+    int64_t group_stride; // a wave stays inside one set) and set s reports into keys + s * group_stride: the K row samples of topk_lists_dev in ONE launch
 };
 
 template <int QB, int METRIC, int U>
@@ -105,21 +107,28 @@ struct TileAcc {
     static __device__ __forceinline__ void chunk(float (&acc)[QB], const float4 g, const float (&sq)[kSq]) {
         const float gv[4] = {g.x, g.y, g.z, g.w};
         if constexpr (METRIC == kChi2Harm && (QB % 2) == 0) {
-            // chi-square = sum(l) + sum(r) - 4 sum_k 1/(1/l_k + 1/r_k): per gallery value ONE reciprocal shared by the QB queries, per
-            // (value, query) a packed add, a reciprocal and a packed add: 3 issue slots per element (kChi2Approx: 5.5-6.6). sq holds
-            // 1/l (+inf for l = 0 and for padding: the term is then 1/inf = +0, as the reference skips l + r = 0).
+            // chi-square = sum(l) + sum(r) - 4 sum_k 1/(1/l_k + 1/r_k). With A = 1/l_j + 1/r_j and B the same for feature j + 1, the two
+            // harmonic terms share ONE reciprocal: 1/A + 1/B = (A + B) / (A B) -- per pair of features and pair of queries four packed
+            // adds / multiplies, two v_rcp_f32 and one packed fma = 2.25 issue slots per (value, query) (one reciprocal per term: 3;
+            // kChi2Approx: 5.5-6.6), plus 1/r once per gallery value and pass. sq holds 1/l, 2^60 for l = 0 and for the padding, and 1/r
+            // is held to 2^60 as well: the term is then <= 2^-60 where the reference skips l + r = 0 (inf would make A B rcp(A B) a NaN);
+            // plain-range operands keep A B within [2^-30, 2^122].
             typedef float f2v __attribute__((ext_vector_type(2)));
+            float v[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float v = __builtin_amdgcn_rcpf(gv[j]);
-                const f2v v2 = {v, v};
+            for (int j = 0; j < 4; ++j) v[j] = __builtin_fminf(__builtin_amdgcn_rcpf(gv[j]), 0x1p60f);
+#pragma unroll
+            for (int j = 0; j < 4; j += 2) {
+                const f2v va = {v[j], v[j]}, vb = {v[j + 1], v[j + 1]};
 #pragma unroll
                 for (int p = 0; p < QB / 2; ++p) {
-                    const f2v u2 = {sq[j * QB + 2 * p], sq[j * QB + 2 * p + 1]};
-                    const f2v t2 = u2 + v2;
-                    const f2v r2 = {__builtin_amdgcn_rcpf(t2.x), __builtin_amdgcn_rcpf(t2.y)};
+                    const f2v ua = {sq[j * QB + 2 * p], sq[j * QB + 2 * p + 1]};
+                    const f2v ub = {sq[(j + 1) * QB + 2 * p], sq[(j + 1) * QB + 2 * p + 1]};
+                    const f2v A = ua + va, B = ub + vb;
+                    const f2v S = A + B, P = A * B;
+                    const f2v R = {__builtin_amdgcn_rcpf(P.x), __builtin_amdgcn_rcpf(P.y)};
                     f2v a2 = {acc[2 * p], acc[2 * p + 1]};
-                    a2 = a2 + r2;
+                    a2 = __builtin_elementwise_fma(S, R, a2);
                     acc[2 * p] = a2.x;
                     acc[2 * p + 1] = a2.y;
                 }
@@ -363,7 +372,7 @@ __global__ void __launch_bounds__(kBlock, WPS) k_scan(const ScanArgs a) {
     }
 
     if constexpr (EPI == kEpiTop1) {
-        uint64_t* keys = a.keys + (size_t)blockIdx.y * QB;
+        uint64_t* keys = a.keys + (size_t)blockIdx.y * QB + (a.groups > 1 ? (size_t)(gw % a.groups) * a.group_stride : 0);
 #pragma unroll
         for (int q = 0; q < QB; ++q) {
             uint64_t key = best_i[q] >= 0 ? key_pack(best_d[q], (uint32_t)((int64_t)best_i[q] + a.row_offset)) : kKeyNone;
@@ -450,6 +459,88 @@ __global__ void __launch_bounds__(kBlock, WPS) k_scan_subranges(const ScanArgs a
 #pragma unroll
                 for (int q = 0; q < QB; ++q)
                     if (q < a.nq) a.out[((size_t)ci * a.k + q) * a.out_stride + row] = acc[q] / fcount;
+            }
+        }
+    }
+}
+
+// The nomination scans of topk_lists_dev (kChi2Harm, kKLEnt; append epilogue only) with NH tiles of 8 queries per gallery read:
+// at 2.25-3 issue slots per (value, query) an 8-query pass over 1M x 512 takes 0.44 ms = 4.7 TB/s of gallery -- the memory system,
+// not the vector pipes, is then what a pass waits for; every load group is therefore used for NH query tiles in turn (their values
+// still come through the scalar cache, 32 SGPRs per chunk at a time; blockIdx.y = group of NH consecutive tiles).
+template <int METRIC, int NH, int U, int WPS>
+__global__ void __launch_bounds__(kBlock, WPS) k_nominate(const ScanArgs a) {
+    constexpr int QB = 8;
+    const bool plain = a.range != nullptr && a.range[0] == 0 && a.range[1] != a.serial;
+    if (!plain) {       // the error bounds need non-negative, normal operands: otherwise the caller's exact path answers
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && a.flag) atomicOr(a.flag, 1);
+        return;
+    }
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    sfloat_p qc[NH];
+    float tau[NH][QB];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+        qc[h] = (sfloat_p)(uintptr_t)(a.qt + ((size_t)blockIdx.y * NH + h) * a.qt_stride);
+#pragma unroll
+        for (int q = 0; q < QB; ++q) tau[h][q] = a.tau[((size_t)blockIdx.y * NH + h) * QB + q];
+    }
+    const int c_lo = (a.start + 3) >> 2, c_hi = a.end >> 2;
+    const float fcount = (float)(a.end - a.start);
+    const int ng = c_lo <= c_hi ? (c_hi - c_lo) / U : 0;
+    const int c_end = c_lo + ng * U;
+    for (int t = gw; t < a.tiles; t += a.waves) {
+        const float4* tile = a.gal4 + (size_t)t * a.dp4 * 64 + lane;
+        float acc[NH][QB];
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+#pragma unroll
+            for (int q = 0; q < QB; ++q) acc[h][q] = 0.0f;
+        if (c_lo > c_hi) {
+            const float4 g = tile[(size_t)(a.start >> 2) * 64];
+#pragma unroll
+            for (int h = 0; h < NH; ++h) TileAcc<QB, METRIC, U>::masked(acc[h], g, qc[h], a.start >> 2, a.start, a.end);
+        } else {
+            if ((a.start & 3) != 0) {
+                const float4 g = tile[(size_t)(c_lo - 1) * 64];
+#pragma unroll
+                for (int h = 0; h < NH; ++h) TileAcc<QB, METRIC, U>::masked(acc[h], g, qc[h], c_lo - 1, a.start, a.end);
+            }
+            const float4* p = tile + (size_t)c_lo * 64;
+            for (int gi = 0; gi < ng; ++gi) {
+                float4 g[U];
+                ld_gallery_group<U>(g, p + (size_t)(gi * U) * 64, a.nt != 0);
+#pragma unroll
+                for (int h = 0; h < NH; ++h) TileAcc<QB, METRIC, U>::group(acc[h], g, qc[h], c_lo + gi * U);
+            }
+            for (int c = c_end; c < c_hi; ++c) {
+                const float4 g = tile[(size_t)c * 64];
+#pragma unroll
+                for (int h = 0; h < NH; ++h) TileAcc<QB, METRIC, U>::masked(acc[h], g, qc[h], c, a.start, a.end);
+            }
+            if ((a.end & 3) != 0) {
+                const float4 g = tile[(size_t)c_hi * 64];
+#pragma unroll
+                for (int h = 0; h < NH; ++h) TileAcc<QB, METRIC, U>::masked(acc[h], g, qc[h], c_hi, a.start, a.end);
+            }
+        }
+        const int64_t row = (int64_t)t * kTileRows + lane;
+        if (row < a.n) {
+            const float sgr = a.sg[row];
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+#pragma unroll
+                for (int q = 0; q < QB; ++q) {
+                    const size_t qy = ((size_t)blockIdx.y * NH + h) * QB + q;
+                    float dist;
+                    if constexpr (METRIC == kChi2Harm) dist = ((a.sq[qy] + sgr) - 4.0f * acc[h][q]) / fcount;
+                    else dist = (0.693147181f * ((a.sq[qy] + sgr) - acc[h][q])) / fcount;
+                    if (dist <= tau[h][q]) {
+                        const int slot = atomicAdd(&a.counts[qy], 1);
+                        if (slot < a.k) a.keys[qy * a.k + slot] = key_pack(dist, (uint32_t)(row + a.row_offset));
+                    }
+                }
             }
         }
     }
@@ -887,13 +978,23 @@ __global__ void __launch_bounds__(kBlock) k_list_rerank(uint64_t* __restrict__ l
         if (row >= 0 && row < n) {
             const float4* gr = gal4 + (size_t)(row >> 6) * dp4 * 64 + (row & 63);
             float acc = 0.0f;
-            for (int c = start >> 2; c <= (end - 1) >> 2; ++c) {
-                const float4 g4 = gr[(size_t)c * 64];
-                const float gv[4] = {g4.x, g4.y, g4.z, g4.w};
+            // (a lane gathers its row 16 bytes per 4 features: eight loads in flight, the sum itself stays sequential)
+            const int c_first = start >> 2, c_last = (end - 1) >> 2;
+            for (int c0 = c_first; c0 <= c_last; c0 += 8) {
+                float4 g8[8];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int k = c * 4 + j;
-                    if (k >= start && k < end) acc = accum<METRIC>(acc, lq_rr[k], gv[j]);
+                for (int u = 0; u < 8; ++u) g8[u] = gr[(size_t)(c0 + u <= c_last ? c0 + u : c_last) * 64];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int c = c0 + u;
+                    if (c <= c_last) {
+                        const float gv[4] = {g8[u].x, g8[u].y, g8[u].z, g8[u].w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int k = c * 4 + j;
+                            if (k >= start && k < end) acc = accum<METRIC>(acc, lq_rr[k], gv[j]);
+                        }
+                    }
                 }
             }
             const float dist = acc / fcount;
@@ -933,7 +1034,7 @@ __global__ void __launch_bounds__(kBlock) k_retile(const float* __restrict__ row
 // Queries past nq and features past d are zero. keys[0..nkeys) (may be NULL) are preset to "no row yet" on the way:
 // the top-1 scans that follow only ever lower them.
 // range[1] = serial when a query value outside in_plain_range() goes by (serial numbers the transpositions of a handle).
-// recip == 1 (kChi2Harm): the tile holds 1 / value (+inf for 0 and for the padding), the range check still sees the value;
+// recip == 1 (kChi2Harm): the tile holds 1 / value (2^60 for 0 and for the padding), the range check still sees the value;
 // recip == 2 (kKLEnt): value + 2^-100 (the value itself unless it is 0: plain-range values are 0 or >= 2^-26).
 __global__ void __launch_bounds__(kBlock) k_transpose_queries(const float* __restrict__ q, int nq, int d, int dp4, int QB,
                                                                float* __restrict__ qt, uint64_t* __restrict__ keys, int nkeys,
@@ -952,7 +1053,7 @@ __global__ void __launch_bounds__(kBlock) k_transpose_queries(const float* __res
     const int qq = tile * QB + qi;
     const float v = (qq < nq && k < d) ? q[(int64_t)qq * d + k] : 0.0f;
     if (range && !in_plain_range(v)) range[1] = serial;
-    qt[((int64_t)tile * kk + k) * QB + qi] = recip == 1 ? 1.0f / v : recip == 2 ? v + 0x1p-100f : v;
+    qt[((int64_t)tile * kk + k) * QB + qi] = recip == 1 ? fminf(1.0f / v, 0x1p60f) : recip == 2 ? v + 0x1p-100f : v;
 }
 
 // kChi2Harm: sg[row] = sum of the row's values over features [start, end) (one lane per row, tiled layout), smax[0] = their

@@ -144,6 +144,16 @@ def test_kl_nomination_scan_returns_the_exact_scans_keys(fir, oracle, monkeypatc
     assert np.array_equal(s1[0], es1[0]) and np.array_equal(s1[1].view(np.uint32), es1[1].view(np.uint32))
     assert np.array_equal(a5[0], e5[0]) and np.array_equal(a5[1].view(np.uint32), e5[1].view(np.uint32))
     assert np.array_equal(a5[0][:, 0], a1[0]) and a1[0][2] == 17
+    # one handle, the metric switched between calls: the per-row constants of the two nomination forms (row sums / row entropies)
+    # are rebuilt, not reused
+    with fir.Gallery(rows, None, fir.METRIC_CHI2, 0) as g:
+        c1 = g.search_top1(q)
+        g.set_metric(fir.METRIC_KL)
+        k1 = g.search_top1(q)
+        g.set_metric(fir.METRIC_CHI2)
+        c2 = g.search_top1(q)
+    assert np.array_equal(k1[0], e1[0]) and np.array_equal(k1[1].view(np.uint32), e1[1].view(np.uint32))
+    assert np.array_equal(c1[0], c2[0]) and np.array_equal(c1[1].view(np.uint32), c2[1].view(np.uint32))
     for i in (0, 2, 7, 11, 39):
         ei, ed = oracle.topk(rows, q[i], 0, d, 5, 2)
         assert np.allclose(a5[1][i], ed, rtol=1e-5, atol=1e-9)          # device log vs glibc logf: the KL tolerance of test_gpu_golden

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--dim", type=int, default=512)
     ap.add_argument("--qb", type=int, default=256)
     ap.add_argument("--metric", type=int, default=1)
+    ap.add_argument("--only", default="", help="top1 | top5: time only that call, only the default nomination form (for rocprofv3 --kernel-trace --stats)")
     a = ap.parse_args()
     fir = ge.load_package()
     dev = torch.device("cuda", 0)
@@ -41,6 +42,11 @@ def main():
     k5 = torch.empty(a.qb * 5, device=dev, dtype=torch.int64)
     ref1 = torch.empty(a.qb, device=dev, dtype=torch.int64)
     ref5 = torch.empty(a.qb * 5, device=dev, dtype=torch.int64)
+    if a.only:
+        fn = (lambda: g.search_top1_keys_dev(q.data_ptr(), a.qb, k1.data_ptr())) if a.only == "top1" else (lambda: g.search_topk_keys_dev(q.data_ptr(), a.qb, 5, k5.data_ptr()))
+        print(f"{a.only}: {rate(fn, a.qb, 5):9.0f} q/s")
+        g.close()
+        return
     os.environ["FIR_NO_CHI2_NOMINATION"] = "1"
     r1 = rate(lambda: g.search_top1_keys_dev(q.data_ptr(), a.qb, ref1.data_ptr()), a.qb, 1)
     r5 = rate(lambda: g.search_topk_keys_dev(q.data_ptr(), a.qb, 5, ref5.data_ptr()), a.qb, 1)
