@@ -348,8 +348,12 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
                 const float m2 = 2.0f * qinv_s[q];
                 const float tq = MODE == 3 ? (warm_it ? 0.f : tq_s[q]) : tau_s[q];
                 if (kAppend && !(nt_flags & 64) && !(MODE == 3 && warm_it)) {
-                    const float amax = fmaxf(fmaxf(fmaxf(acc[0][jb][0], acc[0][jb][1]), fmaxf(acc[0][jb][2], acc[0][jb][3])),
-                                             fmaxf(fmaxf(acc[1][jb][0], acc[1][jb][1]), fmaxf(acc[1][jb][2], acc[1][jb][3])));
+                    // (v_max3_f32 by hand: fmaxf() on MFMA results makes the compiler quiet every operand first -- eight more instructions)
+                    float amax;
+                    asm("v_max3_f32 %0, %1, %2, %3\n\tv_max3_f32 %0, %0, %4, %5\n\tv_max3_f32 %0, %0, %6, %7\n\tv_max_f32 %0, %0, %8"
+                        : "=&v"(amax)
+                        : "v"(acc[0][jb][0]), "v"(acc[0][jb][1]), "v"(acc[0][jb][2]), "v"(acc[0][jb][3]), "v"(acc[1][jb][0]), "v"(acc[1][jb][1]),
+                          "v"(acc[1][jb][2]), "v"(acc[1][jb][3]));
                     if (!(__builtin_fmaf(-m2, amax, gmin) < tq)) continue;
                 }
                 float pv[8];

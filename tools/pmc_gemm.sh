@@ -13,7 +13,9 @@ for SET in "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTI
            "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM" \
            "SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_LDS_BANK_CONFLICT SQ_INSTS_MFMA SQ_ACTIVE_INST_LDS" \
            "FETCH_SIZE TCC_EA0_RDREQ_sum" \
-           "TCC_HIT_sum TCC_MISS_sum"; do
+           "TCC_HIT_sum TCC_MISS_sum" \
+           "SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_VMEM" \
+           "TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TA_TA_BUSY_sum"; do
   i=$((i+1))
   rm -rf "$R/gpurun_out/pmc_gemm_$i"
   timeout -k 10 240 rocprofv3 --pmc $SET --output-format csv -d "$R/gpurun_out/pmc_gemm_$i" -o p -- python3 "$R/tools/mfma_ab.py" --dim "$D" --rounds 2 --check 0 --variants "default:" > "$R/gpurun_out/pmc_gemm_$i.log" 2>&1 || { echo "pass $i failed"; tail -3 "$R/gpurun_out/pmc_gemm_$i.log"; continue; }
@@ -24,7 +26,7 @@ python3 - "$R" <<'PY'
 import json, sys, glob
 R = sys.argv[1]
 out = {}
-for f in sorted(glob.glob(R + "/gpurun_out/pmc_gemm_[0-9].json")):
+for f in sorted(glob.glob(R + "/gpurun_out/pmc_gemm_[0-9]*.json")):
     for e in json.load(open(f)):
         if "k_gemm_proxy_f16x" not in e["kernel"]:
             continue
@@ -50,6 +52,14 @@ for k, v in out.items():
                 d[n_.lower() + "_over_wave_cycles"] = c[n_] / c["SQ_WAVE_CYCLES"]
     if "FETCH_SIZE" in c:
         d["hbm_bytes_per_launch_fetch_size_x1024_x2"] = c["FETCH_SIZE"] * 1024 * 2
+    if "SQ_INST_LEVEL_VMEM" in c and "SQ_INSTS_VMEM" in c:
+        d["vmem_instruction_latency_level_over_insts"] = c["SQ_INST_LEVEL_VMEM"] / c["SQ_INSTS_VMEM"]
+    if "SQ_INST_LEVEL_LDS" in c and "SQ_INSTS_LDS" in c:
+        d["lds_instruction_latency_level_over_insts"] = c["SQ_INST_LEVEL_LDS"] / c["SQ_INSTS_LDS"]
+    if "TCP_TCC_READ_REQ_LATENCY_sum" in c and "TCP_TCC_READ_REQ_sum" in c and c["TCP_TCC_READ_REQ_sum"]:
+        d["l1_to_l2_read_latency_cycles"] = c["TCP_TCC_READ_REQ_LATENCY_sum"] / c["TCP_TCC_READ_REQ_sum"]
+    if "SQ_WAIT_ANY" in c and "SQ_WAVE_CYCLES" in c:
+        d["sq_wait_any_over_wave_cycles"] = c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]
     if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c:
         d["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
     v["derived"] = d
