@@ -1486,6 +1486,7 @@ struct fir_gemm {
     unsigned int* aT[2] = {nullptr, nullptr};   // ... and the ranks' shared T (float bits)
     float erel_scale = 1.0f;              // AUDIT KNOB, never set in production: the certificate's relative error bound is multiplied by this (FIR_GEMM_EREL_SCALE);
                                           // tests/test_gpu_gemm.py shows that a bound shrunk to a quarter returns a wrong row on a crafted near-tie, i.e. that the suite can see an unsound bound
+    int dbg_skip = 0;                     // timing experiments: bit 0 = no epilogue, bit 1 = no gallery stream, bit 2 = no query-fragment re-reads (FIR_GEMM_DBG_SKIP; wrong answers)
     int no_block_bound = 0;               // A/B: the append forms compute all eight proxies of every query block (FIR_GEMM_NO_BLOCK_BOUND)
     int prio = 0;                         // mfma16 experiment: s_setprio 2 around the MFMA phase of a row block (FIR_GEMM_PRIO)
     int stagger = 0;                      // mfma16 experiment: the second wave of every SIMD starts half a unit late (FIR_GEMM_STAGGER)
@@ -1498,7 +1499,17 @@ struct fir_gemm {
 // the 16-row kernels by (mode, query slabs streamed, odd number of units per row block)
 typedef void (*fir_x_fn)(const uint4*, const float*, const uint4*, const float*, int64_t, int64_t, int64_t, int, const float*, unsigned long long*, int*, float*,
                          int, int, int, int, unsigned int*, int);
-static fir_x_fn pick_x(int mode, bool streamed, bool odd) {
+static fir_x_fn pick_x(int mode, bool streamed, bool odd, int dbg = 0) {
+    if (dbg && mode == 3 && !streamed && !odd) {       // timing experiments (FIR_GEMM_DBG_SKIP): wrong answers
+        switch (dbg & 7) {
+            case 1: return k_gemm_proxy_f16x<3, 0, 0, 1>;
+            case 2: return k_gemm_proxy_f16x<3, 0, 0, 2>;
+            case 3: return k_gemm_proxy_f16x<3, 0, 0, 3>;
+            case 5: return k_gemm_proxy_f16x<3, 0, 0, 5>;
+            case 7: return k_gemm_proxy_f16x<3, 0, 0, 7>;
+            default: break;
+        }
+    }
     if (mode == 1) return streamed ? (odd ? k_gemm_proxy_f16x<1, 1, 1> : k_gemm_proxy_f16x<1, 1, 0>) : (odd ? k_gemm_proxy_f16x<1, 0, 1> : k_gemm_proxy_f16x<1, 0, 0>);
     if (mode == 3) return streamed ? (odd ? k_gemm_proxy_f16x<3, 1, 1> : k_gemm_proxy_f16x<3, 1, 0>) : (odd ? k_gemm_proxy_f16x<3, 0, 1> : k_gemm_proxy_f16x<3, 0, 0>);
     return streamed ? (odd ? k_gemm_proxy_f16x<2, 1, 1> : k_gemm_proxy_f16x<2, 1, 0>) : (odd ? k_gemm_proxy_f16x<2, 0, 1> : k_gemm_proxy_f16x<2, 0, 0>);
@@ -1624,6 +1635,7 @@ int fir_gemm_create_range_ex_(fir_gallery* g, int32_t precision, int32_t end_pos
     if (const char* w = std::getenv("FIR_GEMM_STAGGER")) m->stagger = std::atoi(w);     // 1 = half a unit, 2 = half a row block at 512 features
     if (const char* w = std::getenv("FIR_GEMM_PRIO")) m->prio = std::atoi(w) != 0;
     if (const char* w = std::getenv("FIR_GEMM_NO_BLOCK_BOUND")) m->no_block_bound = std::atoi(w) != 0;
+    if (const char* w = std::getenv("FIR_GEMM_DBG_SKIP")) m->dbg_skip = std::atoi(w) & 7;     // timing experiments only: the answers are wrong
     if (const char* w = std::getenv("FIR_GEMM_EREL_SCALE")) m->erel_scale = (float)std::atof(w);
     if (const char* w = std::getenv("FIR_GEMM_ADAPTIVE")) m->adaptive = std::atoi(w);
     if (const char* w = std::getenv("FIR_GEMM_SHARE_STREAMED")) m->share_streamed = std::max(1, std::min(16, std::atoi(w)));
@@ -1968,7 +1980,7 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
                     used_rt = true;
                     used_rt_lds = rt_lds;
                 } else if (adaptive)
-                    hipLaunchKernelGGL(pick_x(3, streamed, (m->dk16 / kRing) & 1), g1, dim3(kGemmBlock), kHalfLds, st, m->gh, m->gnorm, m->qbf[b] + qo * 4 * m->dk16 * 64,
+                    hipLaunchKernelGGL(pick_x(3, streamed, (m->dk16 / kRing) & 1, m->dbg_skip), g1, dim3(kGemmBlock), kHalfLds, st, m->gh, m->gnorm, m->qbf[b] + qo * 4 * m->dk16 * 64,
                                        m->qinv[b] + qo * 2 * kQT, n, (int64_t)0, n, m->dk16, m->awin[b] + qo * 2 * kQT, m->lists[b] + qo * 2 * kQT * kListCap,
                                        m->counts[b] + qo * 2 * kQT, m->qnorm[b] + qo * 2 * kQT, sample_rows, share, nt | adapt_dbg | (m->stagger ? 2 : 0) | (m->stagger > 1 ? 32 : 0) | (m->prio ? 16 : 0) | (m->no_block_bound ? 64 : 0), 1, m->aT[b] + qo * 2 * kQT, 0);
                 else if (m->mfma16)

@@ -99,7 +99,10 @@ __global__ void __launch_bounds__(256) k_gemm_pack_queries_f16x(const float* q, 
 // throw-away MFMAs first, so that partners do not reach their epilogues and their end-of-unit waits together. Bit 0: the
 // gallery stream is read once per launch (non-temporal loads).
 constexpr int kXStage = 16;             // staged appends per query and workgroup
-template <int MODE, int STREAMED, int ODD>
+// DBG (timing experiments only, FIR_GEMM_DBG_SKIP; own instantiations so that the production kernels' register allocation is not
+// touched -- as runtime flags the two tests made the row loop spill): bit 0 = no epilogue, bit 1 = no gallery stream, bit 2 = no
+// re-read of the query fragments. The answers of such a kernel are wrong.
+template <int MODE, int STREAMED, int ODD, int DBG = 0>
 __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* __restrict__ gh, const float* __restrict__ gnorm, const uint4* qh,
                                                                     const float* __restrict__ qinv, int64_t n, int64_t row_begin, int64_t row_end,
                                                                     int dk16, const float* tau, unsigned long long* lists, int* counts,
@@ -280,7 +283,9 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
             constexpr bool kFirst = decltype(first_tag)::value;      // the first unit of the row block: its first step starts the sums
             const uint4* src = h + 1 < units ? a_cur + (size_t)(h + 1) * kRing * 64 : a_nxt;
             const uint4* bq = STREAMED ? lqx + lane + (size_t)(ring_c & 3) * 4 * kRing * 64 : lqx + lane + (size_t)(h % kUnitsPerSlab) * kRing * 4 * 64;
-            if (nt) {
+            if (DBG & 2) {
+                // (no gallery stream: the next unit multiplies whatever its registers hold)
+            } else if (nt) {
 #pragma unroll
                 for (int u = 0; u < kRing; ++u) N[u] = ld_nt(src + (size_t)u * 64 + lane);
             } else {
@@ -304,7 +309,7 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
                     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
                     acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b, kFirst && t == 0 ? zero : acc[0][j], 0, 0, 0);
                     acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b, kFirst && t == 0 ? zero : acc[1][j], 0, 0, 0);
-                    B[j] = bn[j * 64];
+                    if (!(DBG & 4)) B[j] = bn[j * 64];
                     __builtin_amdgcn_sched_barrier(0);            // the re-read stays right behind its fragment's last use
                 }
                 if (STREAMED) request_piece(hq3, (ring_c + 3) & 3, t);      // unit ring_c + 3's slab, into the slot unit ring_c - 1 has left
@@ -335,6 +340,11 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
         }
         a_cur = a_nxt;
         if (nt_flags & 16) __builtin_amdgcn_s_setprio(0);
+        if (DBG & 1) {                   // (no epilogue: the sums are only kept alive)
+#pragma unroll
+            for (int jb = 0; jb < 8; ++jb) asm volatile("" ::"v"(acc[0][jb]), "v"(acc[1][jb]));
+            continue;
+        }
         if (!active) continue;
         if (full_block) {
             // The append forms look at a query block's eight proxies only when one of them CAN lie below the bound: with m2 > 0,
