@@ -229,6 +229,26 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
             for (int r = 0; r < 96; ++r) junk = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_f16x8(B[r & 7]), as_f16x8(B[(r + 1) & 7]), junk, 0, 0, 0);
         asm volatile("" ::"v"(junk));
     }
+    // The append forms DEFER a full row block's epilogue into the next row block's first step: the first step's MFMAs start the sums
+    // from a zero C operand, so query block j's sixteen sums stay readable until the two MFMAs of index j of that step overwrite
+    // them -- the check of query block j (four v_max3, an fma, a compare; rarely the eight proxies and an append) sits right in
+    // front of them and runs beside the MFMAs of the blocks before it, instead of leaving the matrix pipe to a partner wave that,
+    // alone, waits for its own LDS reads (profiles/r03_gemm_time_decomposition.txt: the epilogue cost 0.18 of 1.56 ms). DBG & 8: the
+    // epilogue where it was, for A/B runs.
+    constexpr bool kDefer = kAppend && !(DBG & 8) && !(DBG & 1);
+    f32x4 acc[2][8];                                 // (first written by the MFMAs of a row block's first step, against a zero C operand)
+    bool pend = false;                               // a full row block's checks are still owed
+    int64_t p_rb = 0;
+    float4 pg[2] = {};
+    float p_gmin = 0.f;
+    float m2r[kDefer ? 8 : 1], tqr[kDefer ? 8 : 1];  // per query block of this lane: 2 / scale, and the bound as of the last row block's end
+    if (kDefer) {
+#pragma unroll
+        for (int jb = 0; jb < 8; ++jb) {
+            m2r[jb] = 2.0f * qinv_s[jb * 16 + (lane & 15)];
+            tqr[jb] = MODE == 3 ? tq_s[jb * 16 + (lane & 15)] : tau_s[jb * 16 + (lane & 15)];
+        }
+    }
     bool warm = MODE == 3;                           // MODE 3: the first row block is walked twice (see above)
     bool exchange = false;
     int blk_no = 0;
@@ -274,11 +294,61 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
             ++blk_no;
             if (warm_it) exchange = true;
         }
-        f32x4 acc[2][8];                             // (first written by the MFMAs of the row block's first step, against a zero C operand)
         float4 gns[2];                               // squared norms of rows 16 s + 4 (lane >> 4) + 0..3 of the block
         const bool full_block = active && rbp * 32 >= row_begin && rbp * 32 + 32 <= row_end && rb * 32 + 32 <= n && (MODE != 0 || rb * 32 + 32 <= sample_rows);
         // MODE 2, sub_stride: sixteen row ranges x four waves = kRtSubsets disjoint subsets (more ranges wrap around: unions of disjoint sets)
         unsigned int* smin_blk = MODE == 2 ? smin + (size_t)(((range & 15) << 2) + (wave & 3)) * sub_stride : nullptr;
+        // one query block of a full row block `rbq` against the bound (the append forms, not the warm-up walk); g0 / g1 / gminq = the
+        // block's row norms and their minimum
+        auto check_jb = [&](int jb, int64_t rbq, const float4 g0, const float4 g1, float gminq) {
+            const int q = jb * 16 + (lane & 15);
+            // (kDefer: the lane's scale and bound come from registers -- an LDS read here would wait, in order, behind the query
+            // fragments just requested for the next step; a bound that is a row block old is a larger one: it appends more, never less)
+            const float m2 = kDefer ? m2r[jb] : 2.0f * qinv_s[q];
+            const float tq = kDefer ? tqr[jb] : MODE == 3 ? tq_s[q] : tau_s[q];
+            if (!(nt_flags & 64)) {
+                // with m2 > 0, fl(gmin - m2 amax) <= fl(gn_r - m2 acc_r) for every row r of the lane (gmin <= gn_r, amax >= acc_r, rounding is
+                // monotone): `lb >= tq` proves that no row of the block is appended -- seven instructions instead of sixteen. NaN sums never
+                // enter amax, as they never enter the minimum below. (v_max3_f32 by hand: fmaxf() on MFMA results quiets every operand first.)
+                float amax;
+                asm("v_max3_f32 %0, %1, %2, %3\n\tv_max3_f32 %0, %0, %4, %5\n\tv_max3_f32 %0, %0, %6, %7\n\tv_max_f32 %0, %0, %8"
+                    : "=&v"(amax)
+                    : "v"(acc[0][jb][0]), "v"(acc[0][jb][1]), "v"(acc[0][jb][2]), "v"(acc[0][jb][3]), "v"(acc[1][jb][0]), "v"(acc[1][jb][1]),
+                      "v"(acc[1][jb][2]), "v"(acc[1][jb][3]));
+                if (!(__builtin_fmaf(-m2, amax, gminq) < tq)) return;
+            }
+            const float gnv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+            float pv[8];
+            float mn = __builtin_huge_valf();
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                pv[i] = __builtin_fmaf(-m2, acc[i >> 2][jb][i & 3], gnv[i]);
+                mn = fminf(mn, pv[i]);                                   // NaN never enters, like k_gemm_tau's ordering
+            }
+            if (mn < tq) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    if (pv[i] < tq) {
+                        const int64_t row = rbq * 32 + 16 * (i >> 2) + 4 * (lane >> 4) + (i & 3);
+                        const unsigned long long key = fir::key_pack(pv[i], (uint32_t)row);
+                        const int st = atomicAdd(&scnt[q], 1);
+                        if (st < kXStage) {
+                            skeys[q * kXStage + st] = key;
+                        } else {
+                            const int slot = atomicAdd(&counts[q], 1);
+                            if (slot < kListCap) lists[(size_t)q * kListCap + slot] = key;
+                        }
+                    }
+                }
+                if (MODE == 3) {
+                    const float tn = fmaxf((mn + qn_s[q]) + win_s[q], 0.f);
+                    if (tn < tau_s[q]) {                                // a new smallest proxy: T falls, here and for everybody else
+                        if (__float_as_uint(tn) < atomicMin((unsigned int*)&tau_s[q], __float_as_uint(tn))) tq_s[q] = tn - qn_s[q];
+                        atomicMin(&smin[q], __float_as_uint(tn));
+                    }
+                }
+            }
+        };
         auto unit = [&](uint4 (&C)[kRing], uint4 (&N)[kRing], int h, auto first_tag) {
             constexpr bool kFirst = decltype(first_tag)::value;      // the first unit of the row block: its first step starts the sums
             const uint4* src = h + 1 < units ? a_cur + (size_t)(h + 1) * kRing * 64 : a_nxt;
@@ -305,6 +375,9 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
                 const f16x8 a0 = as_f16x8(C[2 * t]), a1 = as_f16x8(C[2 * t + 1]);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
+                    if (kDefer && kFirst && t == 0) {
+                        if (pend) check_jb(j, p_rb, pg[0], pg[1], p_gmin);      // the previous row block's sums of query block j, about to be overwritten
+                    }
                     const f16x8 b = as_f16x8(B[j]);
                     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
                     acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b, kFirst && t == 0 ? zero : acc[0][j], 0, 0, 0);
@@ -324,6 +397,7 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
         if (nt_flags & 16) __builtin_amdgcn_s_setprio(2);       // (experiment, FIR_GEMM_PRIO: the wave in its MFMA phase goes ahead of its partner's epilogue)
         if (!ODD) {
             unit(cur, nxt, 0, std::true_type());
+            pend = false;
             unit(nxt, cur, 1, std::false_type());
             for (int h = 2; h < units; h += 2) {
                 unit(cur, nxt, h, std::false_type());
@@ -331,6 +405,7 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
             }
         } else {
             unit(cur, nxt, 0, std::true_type());
+            pend = false;
             for (int h = 1; h + 1 < units; h += 2) {
                 unit(nxt, cur, h, std::false_type());
                 unit(cur, nxt, h + 1, std::false_type());
@@ -347,25 +422,28 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
         }
         if (!active) continue;
         if (full_block) {
-            // The append forms look at a query block's eight proxies only when one of them CAN lie below the bound: with m2 > 0,
-            // fl(gmin - m2 amax) <= fl(gn_r - m2 acc_r) for every row r of the lane (gmin <= gn_r, amax >= acc_r, rounding is monotone),
-            // so `lb >= tq` proves that no row of the block is appended -- seven instructions per query block instead of sixteen.
-            // (NaN sums never enter amax, as they never enter the minimum below: such rows are not appended either way.)
             const float gmin = fminf(fminf(fminf(gns[0].x, gns[0].y), fminf(gns[0].z, gns[0].w)), fminf(fminf(gns[1].x, gns[1].y), fminf(gns[1].z, gns[1].w)));
+            if (kAppend && !(MODE == 3 && warm_it)) {
+                if (kDefer) {
+                    pend = true;                                             // checked in the next row block's first step (or behind the loop)
+                    if (MODE == 3) {
+#pragma unroll
+                        for (int jb = 0; jb < 8; ++jb) tqr[jb] = tq_s[jb * 16 + (lane & 15)];
+                    }
+                    p_rb = rb;
+                    pg[0] = gns[0];
+                    pg[1] = gns[1];
+                    p_gmin = gmin;
+                } else {
+#pragma unroll
+                    for (int jb = 0; jb < 8; ++jb) check_jb(jb, rb, gns[0], gns[1], gmin);
+                }
+                continue;
+            }
 #pragma unroll
             for (int jb = 0; jb < 8; ++jb) {
                 const int q = jb * 16 + (lane & 15);
                 const float m2 = 2.0f * qinv_s[q];
-                const float tq = MODE == 3 ? (warm_it ? 0.f : tq_s[q]) : tau_s[q];
-                if (kAppend && !(nt_flags & 64) && !(MODE == 3 && warm_it)) {
-                    // (v_max3_f32 by hand: fmaxf() on MFMA results makes the compiler quiet every operand first -- eight more instructions)
-                    float amax;
-                    asm("v_max3_f32 %0, %1, %2, %3\n\tv_max3_f32 %0, %0, %4, %5\n\tv_max3_f32 %0, %0, %6, %7\n\tv_max_f32 %0, %0, %8"
-                        : "=&v"(amax)
-                        : "v"(acc[0][jb][0]), "v"(acc[0][jb][1]), "v"(acc[0][jb][2]), "v"(acc[0][jb][3]), "v"(acc[1][jb][0]), "v"(acc[1][jb][1]),
-                          "v"(acc[1][jb][2]), "v"(acc[1][jb][3]));
-                    if (!(__builtin_fmaf(-m2, amax, gmin) < tq)) continue;
-                }
                 float pv[8];
                 float mn = __builtin_huge_valf();
 #pragma unroll
@@ -385,30 +463,6 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
                     mn = o < mn ? o : mn;
                     const float tn = fmaxf((mn + qn_s[q]) + win_s[q], 0.f);     // (NaN operands: fmaxf gives 0 only if both are NaN; a NaN tn fails the test below)
                     if (lane < 16 && tn < tau_s[q]) atomicMin((unsigned int*)&tau_s[q], __float_as_uint(tn));
-                } else if (kAppend) {
-                    if (mn < tq) {
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            if (pv[i] < tq) {
-                                const int64_t row = rb * 32 + 16 * (i >> 2) + 4 * (lane >> 4) + (i & 3);
-                                const unsigned long long key = fir::key_pack(pv[i], (uint32_t)row);
-                                const int st = atomicAdd(&scnt[q], 1);
-                                if (st < kXStage) {
-                                    skeys[q * kXStage + st] = key;
-                                } else {
-                                    const int slot = atomicAdd(&counts[q], 1);
-                                    if (slot < kListCap) lists[(size_t)q * kListCap + slot] = key;
-                                }
-                            }
-                        }
-                        if (MODE == 3) {
-                            const float tn = fmaxf((mn + qn_s[q]) + win_s[q], 0.f);
-                            if (tn < tau_s[q]) {                                // a new smallest proxy: T falls, here and for everybody else
-                                if (__float_as_uint(tn) < atomicMin((unsigned int*)&tau_s[q], __float_as_uint(tn))) tq_s[q] = tn - qn_s[q];
-                                atomicMin(&smin[q], __float_as_uint(tn));
-                            }
-                        }
-                    }
                 } else if (MODE == 2 && !sub_stride) {
                     smallest[jb] = fminf(smallest[jb], mn);
                 } else {
@@ -454,6 +508,48 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
                 else if (lane < 16 && mn < __builtin_huge_valf()) atomicMin(&smin_blk[q], fir::f32_orderable(mn));
             }
         }
+    }
+    if (kDefer && pend) {
+        // the last full row block of this wave (no first step followed it); check_jb is the row loop's lambda -- the same code, here
+        // against the values the loop left behind
+        auto last_jb = [&](int jb) {
+            const int q = jb * 16 + (lane & 15);
+            const float m2 = 2.0f * qinv_s[q];
+            const float tq = MODE == 3 ? tq_s[q] : tau_s[q];
+            const float gnv[8] = {pg[0].x, pg[0].y, pg[0].z, pg[0].w, pg[1].x, pg[1].y, pg[1].z, pg[1].w};
+            float pv[8];
+            float mn = __builtin_huge_valf();
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                pv[i] = __builtin_fmaf(-m2, acc[i >> 2][jb][i & 3], gnv[i]);
+                mn = fminf(mn, pv[i]);
+            }
+            if (mn < tq) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    if (pv[i] < tq) {
+                        const int64_t row = p_rb * 32 + 16 * (i >> 2) + 4 * (lane >> 4) + (i & 3);
+                        const unsigned long long key = fir::key_pack(pv[i], (uint32_t)row);
+                        const int st = atomicAdd(&scnt[q], 1);
+                        if (st < kXStage) {
+                            skeys[q * kXStage + st] = key;
+                        } else {
+                            const int slot = atomicAdd(&counts[q], 1);
+                            if (slot < kListCap) lists[(size_t)q * kListCap + slot] = key;
+                        }
+                    }
+                }
+                if (MODE == 3) {
+                    const float tn = fmaxf((mn + qn_s[q]) + win_s[q], 0.f);
+                    if (tn < tau_s[q]) {
+                        atomicMin((unsigned int*)&tau_s[q], __float_as_uint(tn));
+                        atomicMin(&smin[q], __float_as_uint(tn));
+                    }
+                }
+            }
+        };
+#pragma unroll
+        for (int jb = 0; jb < 8; ++jb) last_jb(jb);
     }
     if (kAppend) {
         __syncthreads();                             // every wave's staged appends are in
