@@ -187,3 +187,41 @@ def test_proposed_twd_fused_many_calls_in_a_row(fir, oracle):
             c, u, k = g.twd_proposed(qq, fc, th)
             exp = [oracle.twd_proposed(rows, cls, qi, fc, th) for qi in qq]
             assert (list(c), list(u), list(k)) == ([e[0] for e in exp], [e[1] for e in exp], [e[2] for e in exp]), (it, fc, th)
+
+
+def test_proposed_twd_fused_beside_a_busy_device(fir, oracle):
+    """The workgroups of k_twd_prop_fused wait for each other: run it while another host thread keeps the device busy with
+    large batched searches on another gallery (its own stream). Every call must come back with the oracle's answer -- through
+    the one-launch form when its workgroups get their CUs in time, through the launch-per-chunk form when they do not."""
+    import threading
+
+    rows, cls, q, _ = gc.twd_case(seed=63, n=40000, d=256, n_classes=50)
+    rng = np.random.default_rng(9)
+    big = rng.random((200000, 128), dtype=np.float32)
+    bq = rng.random((4096, 128), dtype=np.float32)
+    stop = threading.Event()
+    errors = []
+
+    def hammer():
+        try:
+            with fir.Gallery(big, None, gc.L2, 0) as gb:
+                while not stop.is_set():
+                    gb.search_top1(bq)
+        except Exception as e:      # noqa: BLE001 -- reported by the main thread
+            errors.append(e)
+
+    t = threading.Thread(target=hammer)
+    t.start()
+    try:
+        with fir.Gallery(rows, cls, gc.L2, 0) as g, _FusedMode(1):
+            for it in range(60):
+                nq = 1 + it % 3
+                qq = q[rng.integers(0, len(q), nq)] * np.float32(0.6) + rows[rng.integers(0, len(rows), nq)] * np.float32(0.4)
+                fc, th = ((32, 0.7), (64, 0.9), (16, 0.5))[it % 3]
+                c, u, k = g.twd_proposed(qq, fc, th)
+                exp = [oracle.twd_proposed(rows, cls, qi, fc, th) for qi in qq]
+                assert (list(c), list(u), list(k)) == ([e[0] for e in exp], [e[1] for e in exp], [e[2] for e in exp]), (it, fc, th)
+    finally:
+        stop.set()
+        t.join(timeout=60)
+    assert not errors, errors
