@@ -1781,7 +1781,13 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
     // sets amortise the boundaries between full passes (where the small kernels run: they cannot share a CU with a full-pass
     // workgroup), but a call needs a few super-batches for its preparation / re-rank to overlap anything: a quarter of the call,
     // in whole 1 024-query launches
-    const int sbq = std::min(kPasses * kQT, std::max(1024, (qb / 4 + 1023) / 1024 * 1024));
+    // Galleries whose 1 024-query launch is short (n d <= 1.5e8: under ~0.25 ms) take the whole call (up to kPasses passes) as ONE
+    // super-batch: between two super-batches the next one's preparation queues behind the previous one's re-rank, which runs squeezed
+    // between the full pass's workgroups (100 000 x 512, 4 096 queries: ~65 us of bubble per boundary and a re-rank four times
+    // slower than alone, for 110 us launches -- profiles/r03_small_call_timeline.txt)
+    const bool short_launches = (double)n * (double)d <= 1.5e8 && !std::getenv("FIR_GEMM_QUARTERS");
+    const int sbq = short_launches ? std::min(kPasses * kQT, std::max(1024, (qb + 1023) / 1024 * 1024))
+                                   : std::min(kPasses * kQT, std::max(1024, (qb / 4 + 1023) / 1024 * 1024));
     const int nsb = (qb + sbq - 1) / sbq;
     {   // candidate lists and counts: sized by the super-batch in use (whole 128-query pairs), not by the largest one possible --
         // a cache-resident gallery that gets 128-query calls holds 8 MiB of lists, not 512
