@@ -666,6 +666,40 @@ def config2(fir, src, q, dev, ws, d):
                                        "note": "one gallery pass (204.8 MB); cold = first pass after a 512 MiB write to another buffer (rows come from HBM), warm = the passes after it (rows come from the Infinity Cache / L2)"}
         del flush
         g.close()
+    # the proposed three-way-decision classifier (ImageTesting.cpp:207-288) on the same rows, one query per call like the reference's
+    # recognize(): the one-launch form (default) against the launch-per-chunk forms, a query next to a gallery row (the loop ends after
+    # the first 32-feature chunk) and a fresh one (all eight chunks); host pointers in, verdict out, median of 40 calls
+    try:
+        n = src.shape[0]
+        cls_d = ((torch.arange(n, device=dev) // 30) % 1000).to(torch.int32)
+        rows_h = src[:64].cpu().numpy()
+        q_near = (rows_h[:1] * np.float32(0.9) + rows_h[32:33] * np.float32(0.1)).astype(np.float32)
+        q_far = q[:1].cpu().numpy().astype(np.float32)
+        with torch.cuda.stream(ws):
+            gt = fir.Gallery(dev_ptr=src.data_ptr(), n=n, d=d, metric=fir.METRIC_L2, device=dev.index, stream=stream, dev_class_ptr=cls_d.data_ptr())
+        torch.cuda.synchronize()
+        twd = {}
+        old_env = os.environ.get("FIR_TWD_FUSED")
+        for mode, name in (("1", "one_launch"), ("0", "launch_per_chunk")):
+            os.environ["FIR_TWD_FUSED"] = mode
+            for qq, tag in ((q_near, "near_row"), (q_far, "fresh_query")):
+                for _ in range(5):
+                    res = gt.twd_proposed(qq, 32, 0.7)
+                ts = []
+                for _ in range(40):
+                    t0 = time.perf_counter()
+                    res = gt.twd_proposed(qq, 32, 0.7)
+                    ts.append(time.perf_counter() - t0)
+                twd[f"{name}_{tag}"] = {"us_per_call": float(np.median(ts)) * 1e6, "class": int(res[0][0]), "unreliable": int(res[1][0]), "chunks_used": int(res[2][0])}
+        if old_env is None:
+            os.environ.pop("FIR_TWD_FUSED", None)
+        else:
+            os.environ["FIR_TWD_FUSED"] = old_env
+        twd["same_verdicts"] = all(twd[f"one_launch_{t}"][k] == twd[f"launch_per_chunk_{t}"][k] for t in ("near_row", "fresh_query") for k in ("class", "unreliable", "chunks_used"))
+        out["twd_proposed_one_query"] = twd
+        gt.close()
+    except Exception as e:      # noqa: BLE001 -- a side measurement must not take the bench line down
+        out["twd_proposed_one_query"] = {"error": repr(e)}
     return out
 
 
