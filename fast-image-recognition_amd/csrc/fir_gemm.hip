@@ -1501,12 +1501,13 @@ typedef void (*fir_x_fn)(const uint4*, const float*, const uint4*, const float*,
                          int, int, int, int, unsigned int*, int);
 static fir_x_fn pick_x(int mode, bool streamed, bool odd, int dbg = 0) {
     if (dbg && mode == 3 && !streamed && !odd) {       // timing experiments (FIR_GEMM_DBG_SKIP): wrong answers
-        switch (dbg & 15) {
+        switch (dbg & 31) {
             case 1: return k_gemm_proxy_f16x<3, 0, 0, 1>;
             case 2: return k_gemm_proxy_f16x<3, 0, 0, 2>;
             case 3: return k_gemm_proxy_f16x<3, 0, 0, 3>;
             case 5: return k_gemm_proxy_f16x<3, 0, 0, 5>;
             case 7: return k_gemm_proxy_f16x<3, 0, 0, 7>;
+            case 16: return k_gemm_proxy_f16x<3, 0, 0, 16>;     // (not a wrong-answer form either: the gallery pieces of a unit requested two per step instead of in one burst)
             case 8: return k_gemm_proxy_f16x<3, 0, 0, 8>;       // (not a wrong-answer form: the epilogue behind its own row block, for A/B runs)
             default: break;
         }
@@ -1636,7 +1637,7 @@ int fir_gemm_create_range_ex_(fir_gallery* g, int32_t precision, int32_t end_pos
     if (const char* w = std::getenv("FIR_GEMM_STAGGER")) m->stagger = std::atoi(w);     // 1 = half a unit, 2 = half a row block at 512 features
     if (const char* w = std::getenv("FIR_GEMM_PRIO")) m->prio = std::atoi(w) != 0;
     if (const char* w = std::getenv("FIR_GEMM_NO_BLOCK_BOUND")) m->no_block_bound = std::atoi(w) != 0;
-    if (const char* w = std::getenv("FIR_GEMM_DBG_SKIP")) m->dbg_skip = std::atoi(w) & 15;     // timing experiments only: the answers are wrong
+    if (const char* w = std::getenv("FIR_GEMM_DBG_SKIP")) m->dbg_skip = std::atoi(w) & 31;     // timing experiments only: the answers are wrong
     if (const char* w = std::getenv("FIR_GEMM_EREL_SCALE")) m->erel_scale = (float)std::atof(w);
     if (const char* w = std::getenv("FIR_GEMM_ADAPTIVE")) m->adaptive = std::atoi(w);
     if (const char* w = std::getenv("FIR_GEMM_SHARE_STREAMED")) m->share_streamed = std::max(1, std::min(16, std::atoi(w)));

@@ -353,14 +353,17 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
             constexpr bool kFirst = decltype(first_tag)::value;      // the first unit of the row block: its first step starts the sums
             const uint4* src = h + 1 < units ? a_cur + (size_t)(h + 1) * kRing * 64 : a_nxt;
             const uint4* bq = STREAMED ? lqx + lane + (size_t)(ring_c & 3) * 4 * kRing * 64 : lqx + lane + (size_t)(h % kUnitsPerSlab) * kRing * 4 * 64;
-            if (DBG & 2) {
-                // (no gallery stream: the next unit multiplies whatever its registers hold)
-            } else if (nt) {
+            // The next unit's eight gallery pieces are requested in one burst in front of the unit. (DBG & 16, measured and not kept: two per
+            // step, behind the fourth and the eighth pair of MFMAs -- every piece still exactly one unit before its use -- ran 6 % slower at
+            // 512 features and 5 % at 256: profiles/r03_gemm_time_decomposition.txt.)
+            if (!(DBG & 16) && !(DBG & 2)) {
+                if (nt) {
 #pragma unroll
-                for (int u = 0; u < kRing; ++u) N[u] = ld_nt(src + (size_t)u * 64 + lane);
-            } else {
+                    for (int u = 0; u < kRing; ++u) N[u] = ld_nt(src + (size_t)u * 64 + lane);
+                } else {
 #pragma unroll
-                for (int u = 0; u < kRing; ++u) N[u] = src[(size_t)u * 64 + lane];
+                    for (int u = 0; u < kRing; ++u) N[u] = src[(size_t)u * 64 + lane];
+                }
             }
             if (h == units - 1 && full_block) {
                 const float4* gp = (const float4*)(gnorm + rb * 32 + 4 * (lane >> 4));
@@ -383,6 +386,10 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
                     acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b, kFirst && t == 0 ? zero : acc[0][j], 0, 0, 0);
                     acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b, kFirst && t == 0 ? zero : acc[1][j], 0, 0, 0);
                     if (!(DBG & 4)) B[j] = bn[j * 64];
+                    if ((DBG & 16) && !(DBG & 2) && (j == 3 || j == 7)) {
+                        const int u = 2 * t + (j == 7 ? 1 : 0);
+                        N[u] = nt ? ld_nt(src + (size_t)u * 64 + lane) : src[(size_t)u * 64 + lane];
+                    }
                     __builtin_amdgcn_sched_barrier(0);            // the re-read stays right behind its fragment's last use
                 }
                 if (STREAMED) request_piece(hq3, (ring_c + 3) & 3, t);      // unit ring_c + 3's slab, into the slot unit ring_c - 1 has left
