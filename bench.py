@@ -733,15 +733,26 @@ def k3_classifiers(fir, dev, args, qb=64):
         dt = (time.perf_counter() - t0) / 3
         ms, nbytes, kname = m.profile_read()
         cls = res[0] if isinstance(res, tuple) else res
-        passes = -(-qb // 8)                                                              # 8 queries per pass of the f64 scan over an HBM-streamed training set
-        out[name] = {"queries_per_s": qb / dt, "ms_per_call": dt * 1e3, "gallery_passes": passes,
-                     "achieved_GBps": passes * n * d * 8.0 / dt / 1e9, "frac_of_hbm_peak": passes * n * d * 8.0 / dt / 1e9 / 8000.0,
+        # the f64 scan over an HBM-streamed training set: tiles of 8 queries, TWO tiles per read of the rows since round 3 (k_cls_scan_lds<8, 2>;
+        # the library's algorithmic byte count per launch says how many reads a call made)
+        tiles8 = -(-qb // 8)
+        out[name] = {"queries_per_s": qb / dt, "ms_per_call": dt * 1e3, "query_tiles_of_8": tiles8,
                      "class_of_the_planted_centre_found": float(np.mean(cls == pick.cpu().numpy()))}
         if len(ms):
             avg = float(np.mean(ms))
-            out[name]["roofline_k3"] = {"bound": "hbm", "kernel": kname, "kernel_avg_ms": avg, "launches_timed": int(len(ms)), "bytes_per_launch": nbytes,
-                                        "bytes_per_pass": nbytes / passes, "queries_per_pass": 8, "achieved": nbytes / (avg * 1e-3) / 1e9, "peak": 8000.0,
-                                        "unit": "GB/s", "frac": nbytes / (avg * 1e-3) / 1e9 / 8000.0,
+            reads = max(1, int(round(nbytes / (n * d * 8.0))))                                # reads of the 4.1 GB training set per launch
+            q_per_read = 8 * tiles8 / reads
+            # f64 issue model: per (row, feature, query) a subtraction, a multiplication and an addition, un-fused (classification.cpp:132-141):
+            # 3 wave64 f64 instructions per 64 rows; peak = 256 CUs x 4 SIMDs x one wave64 instruction per 4 cycles at 2.4 GHz
+            winst = (n / 64.0) * d * qb * 3.0
+            out[name]["achieved_GBps"] = reads * n * d * 8.0 / dt / 1e9
+            out[name]["frac_of_hbm_peak"] = reads * n * d * 8.0 / dt / 1e9 / 8000.0
+            out[name]["roofline_k3"] = {"bound": "f64 vector issue" if q_per_read > 8 else "hbm", "kernel": kname, "kernel_avg_ms": avg, "launches_timed": int(len(ms)),
+                                        "bytes_per_launch": nbytes, "training_set_reads_per_launch": reads, "queries_per_read": q_per_read,
+                                        "hbm": {"achieved": nbytes / (avg * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": nbytes / (avg * 1e-3) / 1e9 / 8000.0},
+                                        "f64_issue": {"achieved": winst / (avg * 1e-3) / 1e9, "peak": 614.4, "unit": "G wave-instructions/s",
+                                                      "frac": winst / (avg * 1e-3) / 1e9 / 614.4},
+                                        "achieved": nbytes / (avg * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": nbytes / (avg * 1e-3) / 1e9 / 8000.0,
                                         "kernel_time_share_of_call": float(np.sum(ms)) / (dt * 3 * 1e3)}
     m.close()
     return out

@@ -19,6 +19,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -157,53 +158,66 @@ __device__ __forceinline__ double2 cls_ld_nt(const double2* p) {
     const v2d v = __builtin_nontemporal_load((const v2d*)p);
     return make_double2(v.x, v.y);
 }
-template <int kClsU>
-__global__ void __launch_bounds__(kBlock, 4) k_cls_scan_lds(const double2* __restrict__ gal2, const double* __restrict__ qn_tiles, int64_t nt, int tiles,
-                                                             int dp2, int waves, int nq_total, double* __restrict__ sums_base) {
-    extern __shared__ __attribute__((aligned(16))) double2 lqd[];          // [(feature k) * 4 + i] = queries 2i, 2i + 1 of feature k
+// NT = tiles of eight queries per read of the training rows (blockIdx.y = group of NT consecutive tiles): at 8 queries the pass is
+// 0.72 of HBM with the f64 vector pipes about half busy (24 un-fused f64 operations per feature and tile); with two tiles per read
+// the vector pipes become the bound and a query costs about half the time. Every load group is used for the tiles in turn, each
+// with its own sums; per (row, query) the operations and their order are unchanged.
+template <int kClsU, int NT>
+__global__ void __launch_bounds__(kBlock, NT > 1 ? 2 : 4) k_cls_scan_lds(const double2* __restrict__ gal2, const double* __restrict__ qn_tiles, int64_t nt,
+                                                                          int tiles, int dp2, int waves, int nq_total, double* __restrict__ sums_base) {
+    extern __shared__ __attribute__((aligned(16))) double2 lqd[];          // per tile: [(feature k) * 4 + i] = queries 2i, 2i + 1 of feature k
     const int lane = threadIdx.x & 63;
     const int gw = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     const int kk = dp2 * 2;
+    const int n2 = kk * 4;                                                 // double2 per tile (+ 4 of zeroed slack)
+    const int tile0 = (int)blockIdx.y * NT;
+    const int ntiles_total = (nq_total + 7) / 8;
     {
-        const double2* src = (const double2*)(qn_tiles + (size_t)blockIdx.y * kk * 8);
-        const int n2 = kk * 4;
-        for (int i = threadIdx.x; i < n2 + 4; i += kBlock) lqd[i] = i < n2 ? src[i] : make_double2(0.0, 0.0);
+#pragma unroll
+        for (int h = 0; h < NT; ++h) {
+            const bool live = tile0 + h < ntiles_total;
+            const double2* src = (const double2*)(qn_tiles + (size_t)(tile0 + (live ? h : 0)) * kk * 8);
+            for (int i = threadIdx.x; i < n2 + 4; i += kBlock) lqd[(size_t)h * (n2 + 4) + i] = i < n2 ? src[i] : make_double2(0.0, 0.0);
+        }
         __syncthreads();
     }
     // (as k_scan_l2_lds: an LDS base the compiler cannot prove uniform keeps the reads on one address register + immediate offsets)
     int zero_v;
     asm volatile("v_mov_b32 %0, 0" : "=v"(zero_v));
-    const double2* lq = lqd + zero_v;
-    const int q0 = (int)blockIdx.y * 8;
-    const int nq = nq_total - q0 < 8 ? nq_total - q0 : 8;
-    double* sums = sums_base + (size_t)q0 * nt;
+    const double2* lq0 = lqd + zero_v;
     for (int t = gw; t < tiles; t += waves) {
         const double2* p = gal2 + (size_t)t * dp2 * 64 + lane;
-        double acc[8];
+        double acc[NT][8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) acc[q] = 0.0;
-        double2 cur[4];
+        for (int h = 0; h < NT; ++h)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) cur[i] = lq[i];
-        // one chunk (two features) of this lane against the eight queries; the LDS reads run one feature ahead
-        auto chunk = [&](const double2 g, int c) {
-            const double gv[2] = {g.x, g.y};
+            for (int q = 0; q < 8; ++q) acc[h][q] = 0.0;
+        // COUNT chunks (two features each) from chunk c on of this lane against one tile's eight queries; the LDS reads run one feature ahead
+        auto run = [&](double (&a)[8], const double2* lq, const double2* g, int c, auto count_tag) {
+            constexpr int COUNT = decltype(count_tag)::value;
+            double2 cur[4];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                double2 nx[4];
-                const int k1 = c * 2 + j + 1;                                   // (past the last feature: the zeroed slack)
+            for (int i = 0; i < 4; ++i) cur[i] = lq[(c * 2) * 4 + i];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) nx[i] = lq[k1 * 4 + i];
+            for (int u = 0; u < COUNT; ++u) {
+                const double gv[2] = {g[u].x, g[u].y};
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const double d0 = gv[j] - cur[i].x;                         // classification.cpp:132-137
-                    const double d1 = gv[j] - cur[i].y;
-                    acc[2 * i] = acc[2 * i] + d0 * d0;                          // :141
-                    acc[2 * i + 1] = acc[2 * i + 1] + d1 * d1;
+                for (int j = 0; j < 2; ++j) {
+                    double2 nx[4];
+                    const int k1 = (c + u) * 2 + j + 1;                             // (past the last feature: the zeroed slack)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) nx[i] = lq[k1 * 4 + i];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const double d0 = gv[j] - cur[i].x;                         // classification.cpp:132-137
+                        const double d1 = gv[j] - cur[i].y;
+                        a[2 * i] = a[2 * i] + d0 * d0;                              // :141
+                        a[2 * i + 1] = a[2 * i + 1] + d1 * d1;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) cur[i] = nx[i];
                 }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) cur[i] = nx[i];
             }
         };
         int c = 0;
@@ -219,16 +233,26 @@ __global__ void __launch_bounds__(kBlock, 4) k_cls_scan_lds(const double2* __res
 #pragma unroll
             for (int u = 0; u < kClsU; ++u) nxg[u] = cls_ld_nt(p + (size_t)(gn * kClsU + u) * 64);
 #pragma unroll
-            for (int u = 0; u < kClsU; ++u) chunk(g[u], c + u);
+            for (int h = 0; h < NT; ++h) run(acc[h], lq0 + (size_t)h * (n2 + 4), g, c, std::integral_constant<int, kClsU>());
 #pragma unroll
             for (int u = 0; u < kClsU; ++u) g[u] = nxg[u];
         }
-        for (; c < dp2; ++c) chunk(cls_ld_nt(p + (size_t)c * 64), c);
+        for (; c < dp2; ++c) {
+            const double2 gt = cls_ld_nt(p + (size_t)c * 64);
+#pragma unroll
+            for (int h = 0; h < NT; ++h) run(acc[h], lq0 + (size_t)h * (n2 + 4), &gt, c, std::integral_constant<int, 1>());
+        }
         const int64_t row = (int64_t)t * kTileRows + lane;
         if (row < nt) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q)
-                if (q < nq) sums[(size_t)q * nt + row] = acc[q];
+            for (int h = 0; h < NT; ++h) {
+                const int q0 = (tile0 + h) * 8;
+                const int nq = nq_total - q0 < 8 ? nq_total - q0 : 8;
+                double* sums = sums_base + (size_t)q0 * nt;
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (q < nq) sums[(size_t)q * nt + row] = acc[h][q];
+            }
         }
     }
 }
@@ -747,21 +771,38 @@ int cls_scan(fir_cls* c, const double* queries, int32_t qb) {
     }
     const size_t lds_tile = (size_t)(kk + 1) * 8 * sizeof(double);
     if (big && lds_tile <= 64 * 1024) {
-        // the LDS-tile scan: every tile of eight queries in ONE launch (blockIdx.y), at most 64 tiles per launch
+        // the LDS-tile scan: every tile of eight queries in ONE launch (blockIdx.y), at most 64 tiles per launch; two tiles per read of
+        // the training rows when the call has them and both fit LDS (FIR_CLS_ONE_TILE=1: one, for A/B runs)
         const int ntile = (qb + 7) / 8;
         if ((rc = cls_grow(c->qn, c->qn_cap, (size_t)ntile * kk * 8))) return rc;
         hipLaunchKernelGGL(k_cls_prep_query_tiles, dim3((unsigned)(((size_t)ntile * kk * 8 + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, dq, qb, c->d,
                            c->dp2, c->avg, c->qn);
-        // four waves per SIMD (launch bounds; 33 KiB of LDS per workgroup at d = 512). Measured at 1M x 512, eight passes per launch
-        // (profiles/r03_k3_sweep.txt): 16 / 12 / 8 waves per CU 5.65 / 5.78 / 5.95 ms; 4 or 8 double2 in flight per lane the same, 16 spills
-        const int wv = (int)std::min<int64_t>(std::max<int64_t>((c->tiles + 3) / 4 * 4, 4), (int64_t)c->cus * 16);
+        static const bool one_tile = std::getenv("FIR_CLS_ONE_TILE") != nullptr;
+        const bool two = ntile >= 2 && 2 * lds_tile <= 150 * 1024 && !one_tile;
+        if (two) {
+            static bool attr_set[64] = {};                     // (per device: the attribute belongs to the device's copy of the code object)
+            const int dv = c->device & 63;
+            if (!attr_set[dv]) {
+                CLS_HIP(hipFuncSetAttribute((const void*)k_cls_scan_lds<8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+                attr_set[dv] = true;
+            }
+        }
+        // waves per SIMD by launch bounds (one tile per read: four; two tiles: two, 66 KiB of LDS per workgroup at d = 512). Measured at
+        // 1M x 512, eight passes per launch (profiles/r03_k3_sweep.txt): 16 / 12 / 8 waves per CU 5.65 / 5.78 / 5.95 ms with one tile per read
+        const int wv = (int)std::min<int64_t>(std::max<int64_t>((c->tiles + 3) / 4 * 4, 4), (int64_t)c->cus * (two ? 8 : 16));
+        const int per = two ? 2 : 1;
         for (int t0 = 0; t0 < ntile; t0 += 64) {
             const int tn = std::min(64, ntile - t0);
             cls_prof(c, 0, 0.0, nullptr);
-            hipLaunchKernelGGL(k_cls_scan_lds<8>, dim3(wv / 4, tn), dim3(kBlock), lds_tile, c->stream, c->gal2, c->qn + (size_t)t0 * kk * 8, c->nt, (int)c->tiles,
-                               c->dp2, wv, qb - t0 * 8, c->sums + (size_t)t0 * 8 * c->nt);
-            // algorithmic bytes of the launch: every tile of eight queries reads the training rows once (+ its query tile, + the sums it writes)
-            cls_prof(c, 1, (double)tn * ((double)c->tiles * 64.0 * c->dp2 * 16.0 + (double)kk * 64.0 + 8.0 * 8.0 * (double)c->nt), "fir::k_cls_scan_lds");
+            if (two)
+                hipLaunchKernelGGL((k_cls_scan_lds<8, 2>), dim3(wv / 4, (tn + 1) / 2), dim3(kBlock), 2 * lds_tile, c->stream, c->gal2, c->qn + (size_t)t0 * kk * 8, c->nt,
+                                   (int)c->tiles, c->dp2, wv, qb - t0 * 8, c->sums + (size_t)t0 * 8 * c->nt);
+            else
+                hipLaunchKernelGGL((k_cls_scan_lds<8, 1>), dim3(wv / 4, tn), dim3(kBlock), lds_tile, c->stream, c->gal2, c->qn + (size_t)t0 * kk * 8, c->nt,
+                                   (int)c->tiles, c->dp2, wv, qb - t0 * 8, c->sums + (size_t)t0 * 8 * c->nt);
+            // algorithmic bytes of the launch: every read of the training rows serves `per` tiles of eight queries (+ the query tiles, + the sums written)
+            cls_prof(c, 1, (double)((tn + per - 1) / per) * ((double)c->tiles * 64.0 * c->dp2 * 16.0) + (double)tn * ((double)kk * 64.0 + 8.0 * 8.0 * (double)c->nt),
+                     two ? "fir::k_cls_scan_lds<8, 2>" : "fir::k_cls_scan_lds<8, 1>");
         }
         CLS_HIP(hipGetLastError());
         return FIR_OK;
