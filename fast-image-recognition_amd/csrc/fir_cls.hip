@@ -162,12 +162,13 @@ __device__ __forceinline__ double2 cls_ld_nt(const double2* p) {
 // 0.72 of HBM with the f64 vector pipes about half busy (24 un-fused f64 operations per feature and tile); with two tiles per read
 // the vector pipes become the bound and a query costs about half the time. Every load group is used for the tiles in turn, each
 // with its own sums; per (row, query) the operations and their order are unchanged.
-template <int kClsU, int NT>
-__global__ void __launch_bounds__(kBlock, NT > 1 ? 2 : 4) k_cls_scan_lds(const double2* __restrict__ gal2, const double* __restrict__ qn_tiles, int64_t nt,
+// BLOCK = threads per workgroup.
+template <int kClsU, int NT, int BLOCK = kBlock>
+__global__ void __launch_bounds__(BLOCK, NT > 1 ? 2 : 4) k_cls_scan_lds(const double2* __restrict__ gal2, const double* __restrict__ qn_tiles, int64_t nt,
                                                                           int tiles, int dp2, int waves, int nq_total, double* __restrict__ sums_base) {
     extern __shared__ __attribute__((aligned(16))) double2 lqd[];          // per tile: [(feature k) * 4 + i] = queries 2i, 2i + 1 of feature k
     const int lane = threadIdx.x & 63;
-    const int gw = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const int gw = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
     const int kk = dp2 * 2;
     const int n2 = kk * 4;                                                 // double2 per tile (+ 4 of zeroed slack)
     const int tile0 = (int)blockIdx.y * NT;
@@ -177,7 +178,7 @@ __global__ void __launch_bounds__(kBlock, NT > 1 ? 2 : 4) k_cls_scan_lds(const d
         for (int h = 0; h < NT; ++h) {
             const bool live = tile0 + h < ntiles_total;
             const double2* src = (const double2*)(qn_tiles + (size_t)(tile0 + (live ? h : 0)) * kk * 8);
-            for (int i = threadIdx.x; i < n2 + 4; i += kBlock) lqd[(size_t)h * (n2 + 4) + i] = i < n2 ? src[i] : make_double2(0.0, 0.0);
+            for (int i = threadIdx.x; i < n2 + 4; i += BLOCK) lqd[(size_t)h * (n2 + 4) + i] = i < n2 ? src[i] : make_double2(0.0, 0.0);
         }
         __syncthreads();
     }
@@ -777,7 +778,7 @@ int cls_scan(fir_cls* c, const double* queries, int32_t qb) {
         if ((rc = cls_grow(c->qn, c->qn_cap, (size_t)ntile * kk * 8))) return rc;
         hipLaunchKernelGGL(k_cls_prep_query_tiles, dim3((unsigned)(((size_t)ntile * kk * 8 + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, dq, qb, c->d,
                            c->dp2, c->avg, c->qn);
-        static const bool one_tile = std::getenv("FIR_CLS_ONE_TILE") != nullptr;
+        const bool one_tile = std::getenv("FIR_CLS_ONE_TILE") != nullptr;
         const bool two = ntile >= 2 && 2 * lds_tile <= 150 * 1024 && !one_tile;
         if (two) {
             static bool attr_set[64] = {};                     // (per device: the attribute belongs to the device's copy of the code object)
@@ -789,6 +790,7 @@ int cls_scan(fir_cls* c, const double* queries, int32_t qb) {
         }
         // waves per SIMD by launch bounds (one tile per read: four; two tiles: two, 66 KiB of LDS per workgroup at d = 512). Measured at
         // 1M x 512, eight passes per launch (profiles/r03_k3_sweep.txt): 16 / 12 / 8 waves per CU 5.65 / 5.78 / 5.95 ms with one tile per read
+        // (two tiles: 384-thread workgroups -- three waves per SIMD instead of two -- measured slower, 12.1 / 12.9 against 13.5 / 14.6 k q/s)
         const int wv = (int)std::min<int64_t>(std::max<int64_t>((c->tiles + 3) / 4 * 4, 4), (int64_t)c->cus * (two ? 8 : 16));
         const int per = two ? 2 : 1;
         for (int t0 = 0; t0 < ntile; t0 += 64) {

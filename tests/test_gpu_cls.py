@@ -171,6 +171,27 @@ def test_k3_pnn_and_knn_at_120k_rows_against_the_oracle(fir, oracle):
     assert scores.max() > 1e-200                                              # the test is not comparing zeros
 
 
+def test_k3_distance_sums_are_the_same_bits_whatever_the_tiling(fir, oracle, monkeypatch):
+    """The scan over a training set streamed from HBM takes two tiles of eight queries per read of the rows (k_cls_scan_lds<8, 2>),
+    one when the call has a single tile or FIR_CLS_ONE_TILE is set: the per-row sums are the same bits in every case -- 1, 8, 9
+    (a ragged second tile), 24 (an odd number of tiles) and 37 queries -- and the oracle's on sampled rows."""
+    n, d, ncls = 70_000, 512, 100
+    tr, tcls, q = _big_training_set(n, d, ncls, 91)
+    q = np.concatenate([q, q[:13] * 0.5 + tr[:13] * 0.5])[:37]
+    _, _, avg, _ = oracle.train_stats(tr)
+    with fir.ClsModel(tr, tcls, ncls, avg, 0) as m:
+        full = m.distance_sums(q)
+        for nq in (1, 8, 9, 24):
+            part = m.distance_sums(q[:nq])
+            assert np.array_equal(part.view(np.uint64), full[:nq].view(np.uint64)), nq
+    monkeypatch.setenv("FIR_CLS_ONE_TILE", "1")
+    with fir.ClsModel(tr, tcls, ncls, avg, 0) as m:
+        one = m.distance_sums(q)
+    assert np.array_equal(one.view(np.uint64), full.view(np.uint64))
+    _, dist = oracle.knn_predict(tr, tcls, avg, ncls, q[36], 1)
+    assert np.array_equal((full[36] / d).view(np.uint64), dist.view(np.uint64))
+
+
 def test_pnn_over_training_row_shards_inside_the_library(fir, oracle):
     """fir_cls_create_sharded / fir_cls_sharded_pnn_predict: partial class sums over the GLOBAL training-set size, added on the
     device and by ncclAllReduce(ncclSum, ncclDouble). Same classes as the one-handle call, scores within 1e-12 (the order
