@@ -83,7 +83,7 @@ struct fir_gallery {
     // no copy engine in between (the kernels read / write it over PCIe) and one stream synchronisation per call
     void* pin = nullptr;
     uint64_t counters[4] = {};  // fir_gallery_next_counter_
-    void* scratch[16] = {};   size_t scratch_cap[16] = {};   // fir_gallery_scratch_ (classifier entry points in the other translation units)
+    void* scratch[24] = {};   size_t scratch_cap[24] = {};   // fir_gallery_scratch_ (classifier entry points in the other translation units)
 
     int qpp = 0;              // queries per gallery pass; 0 = automatic (effective_qpp)
     int waves_req = 0;        // 0 = automatic
@@ -893,7 +893,7 @@ int fir_runtime_init_(int device) {
     return FIR_OK;
 }
 int fir_gallery_scratch_(fir_gallery* g, int slot, size_t bytes, void** out) {
-    if (!g || !out || slot < 0 || slot >= 16) return fail(FIR_ERR_ARG, "bad scratch request");
+    if (!g || !out || slot < 0 || slot >= 24) return fail(FIR_ERR_ARG, "bad scratch request");
     if (bytes > g->scratch_cap[slot]) {
         if (g->scratch[slot]) FIR_HIP(hipFree(g->scratch[slot]));
         g->scratch[slot] = nullptr;

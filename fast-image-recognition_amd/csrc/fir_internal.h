@@ -20,9 +20,9 @@ extern "C" int fir_gallery_view_(fir_gallery* g, fir_gallery_view* out);
 extern "C" void fir_set_last_error_(const char* msg);
 extern "C" int fir_gallery_tiled_(fir_gallery* g, const void** gal4, int* dp4);   // the tiled f32 gallery (fir_kernels.h layout)
 
-// Device scratch owned by the gallery handle: `slot` in [0, 16), grown on demand, kept until the gallery is destroyed
+// Device scratch owned by the gallery handle: `slot` in [0, 24), grown on demand, kept until the gallery is destroyed
 // (the per-call hipMalloc / hipFree pairs of the classifier entry points cost more than their kernels on small galleries).
-// Slots 0-7: fir_twd.hip, 8-11: fir_dem.hip.
+// Slots 0-7 and 16: fir_twd.hip, 8-11: fir_dem.hip, 12-15: fir_capi.hip.
 extern "C" int fir_gallery_scratch_(fir_gallery* g, int slot, size_t bytes, void** out);
 // Per-handle call counters of the other translation units (slot 0: fir_twd.hip's fused classifier): returns the value before the increment.
 extern "C" uint64_t fir_gallery_next_counter_(fir_gallery* g, int slot);

@@ -748,6 +748,325 @@ __global__ void __launch_bounds__(kFusedBlock) k_twd_prop_fused(const float4* __
     }
 }
 
+// ---- ConventionalTWDClassifier as ONE launch per call (few queries): k_twd_conv_fused ----
+// Same idea as k_twd_prop_fused: both partial distances of a row ([0, reduced) and [reduced, 256)) stay in the registers of the lane
+// that owns it; here workgroup b owns a CONTIGUOUS run of rows (tiles b * 8 T ...: wave w, slot i, lane = row order), because the
+// reference's secondBestDist depends on the scan order (ImageTesting.cpp:123-125). Two meetings:
+//   before the first   every workgroup posts: the packed (distance, row) key of its first minimum (one 64-bit atomic: the stage-1
+//                      distances are floats), its own minimum into slot_m[b], the bit pattern of its smallest second-stage value,
+//                      and (type 0) the posteriors max exp(-100 d) of the classes it saw (global 64-bit atomic max);
+//   between them       everybody knows the best row r* and its class C*. secondBestDist is the distance of the LAST record (strict
+//                      prefix minimum in row order) whose class is not C* -- every record behind it has class C*, so it is the value
+//                      bestDist had at the last class change. A workgroup in front of r* posts the distance of its last LOCAL record of
+//                      another class (prefix minimum over its own rows only) into slot_l[b]: if that one is not a global record,
+//                      no earlier one of the workgroup is (records fall). Whoever holds the smallest second-stage value posts its row;
+//   behind the second  workgroup 0 alone goes on: with P_b = min(100000, m_0 .. m_{b-1}) the last b whose slot_l[b] < P_b gives
+//                      secondBestDist; (type 0) the five largest class posteriors; the reliability test; the second-stage row when it
+//                      fails. It reads every word with an atomic exchange that leaves 0 behind: the state is clean for the next call.
+constexpr int kConvMaxClasses = 7680;
+struct ConvState {
+    unsigned int ctr, pad;
+    unsigned long long key1, v2min, v2row;           // ~key_pack(d1, row); ~ord64(second-stage value); ~row
+    unsigned long long slot_m[256], slot_l[256];     // per workgroup: ~orderable(min d1); ~orderable(d1 of its last local record of another class)
+    unsigned long long gprob[kConvMaxClasses];       // bit patterns of the class posteriors (non-negative doubles order like integers)
+};
+__device__ __forceinline__ unsigned long long xchg0(unsigned long long* p) {
+    return __hip_atomic_exchange(p, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// One meeting of the `G` workgroups of a query (see k_twd_prop_fused): thread 0's posts have returned, it arrives and -- if `wait` --
+// polls until `target` arrivals; returns false when the others did not come in time. Ends on a workgroup barrier.
+__device__ __forceinline__ bool fused_meet(unsigned int* ctr, unsigned int target, bool wait, int* fail_s) {
+    if (threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned int seen = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+        if (wait) {
+            unsigned long long t0 = 0;
+            for (unsigned int polls = 1; seen < target; ++polls) {
+                __builtin_amdgcn_s_sleep(1);
+                seen = __hip_atomic_fetch_max(ctr, opaque_zero(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((polls & 15u) == 0u && seen < target) {
+                    const unsigned long long now = wall_clock64();
+                    if (!t0) t0 = now;
+                    else if (now - t0 > kFusedPatienceTicks) { *fail_s = 1; break; }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    return *fail_s == 0;
+}
+
+template <int METRIC, int T>
+__global__ void __launch_bounds__(kFusedBlock) k_twd_conv_fused(const float4* __restrict__ gal4, int dp4, int n, int tiles, const int32_t* __restrict__ cls,
+                                                                 const float* queries, int qstride, int reduced, int num_classes, int type,
+                                                                 double threshold, ConvState* state, int32_t* __restrict__ class_out,
+                                                                 int32_t* __restrict__ unreliable_out, int32_t* host_res, int host_stride,
+                                                                 uint64_t* host_ticket, uint64_t ticket, unsigned int* done_ctr) {
+    constexpr int kWaves = kFusedBlock / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned long long probabs[];   // type 0: num_classes bit patterns
+    __shared__ __attribute__((aligned(16))) float qs[kLastFeature];
+    __shared__ unsigned long long red_a[kWaves], red_b[kWaves];
+    __shared__ unsigned int red_r[kWaves];
+    __shared__ float red_f[kWaves], red_g[kWaves];
+    __shared__ int red_i[kWaves];
+    __shared__ unsigned long long got[4];
+    __shared__ int fail_s;
+    __shared__ DI red[kWaves];
+    const int q = blockIdx.y, b = blockIdx.x, G = gridDim.x, nq = gridDim.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    ConvState* S = state + q;
+    const float* qrow = queries + (size_t)q * qstride;
+    if (threadIdx.x < kLastFeature) qs[threadIdx.x] = qrow[threadIdx.x];
+    if (threadIdx.x == 0) fail_s = 0;
+    const bool with_prob = type == 0;
+    if (with_prob)
+        for (int c = threadIdx.x; c < num_classes; c += kFusedBlock) probabs[c] = 0ull;
+    __syncthreads();
+    // ---- both partial distances of this lane's rows (db_features.cpp:22-42 over [0, reduced) and [reduced, 256)) ----
+    const int r4 = reduced >> 2;
+    const float f1 = (float)reduced, f2 = (float)(kLastFeature - reduced);
+    float d1[T];
+    double v2[T];
+    int cl[T];
+    unsigned int valid = 0;
+    const int tile_base = (b * kWaves + wave) * T;
+#pragma unroll
+    for (int i = 0; i < T; ++i) {
+        const int t = tile_base + i;
+        const int64_t row = (int64_t)t * 64 + lane;
+        d1[i] = 0.0f; v2[i] = 0.0; cl[i] = 0;
+        if (t >= tiles) continue;                                       // wave-uniform
+        const float4* tp = gal4 + (size_t)t * dp4 * 64 + lane;
+        float a1 = 0.0f, a2 = 0.0f;
+        // the row's 64 chunks of four features, eight at a time, the next eight already requested (a tile is ONE wave's serial work:
+        // what it waits for is memory latency); chunk c belongs to the first stage while c < r4 (wave-uniform)
+        float4 gc[8], gn[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) gc[u] = tp[(size_t)u * 64];
+#pragma unroll
+        for (int k0 = 0; k0 < kLastFeature / 4; k0 += 8) {
+            if (k0 + 8 < kLastFeature / 4) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) gn[u] = tp[(size_t)(k0 + 8 + u) * 64];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float4 l = *(const float4*)(qs + 4 * (k0 + u));
+                if (k0 + u < r4) {
+                    a1 = fir::accum<METRIC>(a1, l.x, gc[u].x); a1 = fir::accum<METRIC>(a1, l.y, gc[u].y);
+                    a1 = fir::accum<METRIC>(a1, l.z, gc[u].z); a1 = fir::accum<METRIC>(a1, l.w, gc[u].w);
+                } else {
+                    a2 = fir::accum<METRIC>(a2, l.x, gc[u].x); a2 = fir::accum<METRIC>(a2, l.y, gc[u].y);
+                    a2 = fir::accum<METRIC>(a2, l.z, gc[u].z); a2 = fir::accum<METRIC>(a2, l.w, gc[u].w);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) gc[u] = gn[u];
+        }
+        if (row < n) {
+            valid |= 1u << i;
+            d1[i] = a1 / f1;                                            // distances[j] (:117)
+            const float tail = (a2 / f2) * (float)(kLastFeature - reduced);          // float * int -> float (:174)
+            v2[i] = ((double)d1[i] * reduced + tail) / kLastFeature;    // :173-174
+            cl[i] = cls[row];
+        }
+    }
+    // ---- what the workgroup posts before the first meeting ----
+    unsigned long long k1 = ~0ull;                                      // first minimum below 100000 (:123: strict '<' from bestDist = 100000)
+    double m2d = 100000.0;                                              // second stage: bestDist = 100000 (:168)
+    unsigned int m2r = 0xFFFFFFFFu;
+    float mloc = __builtin_huge_valf();
+#pragma unroll
+    for (int i = 0; i < T; ++i) {
+        if (!((valid >> i) & 1u)) continue;
+        const unsigned int row = (unsigned int)((tile_base + i) * 64 + lane);
+        if ((double)d1[i] < 100000.0) { const unsigned long long k = fir::key_pack(d1[i], row); k1 = k < k1 ? k : k1; }
+        mloc = d1[i] < mloc ? d1[i] : mloc;                            // (NaN never enters, as it never sets a record)
+        if (v2[i] < m2d) { m2d = v2[i]; m2r = row; }
+        if (with_prob) {
+            const double probab = exp(-(double)d1[i] * 100);           // DIST_WEIGHT = 100 (:113,119)
+            const int c = cl[i];
+            if (c >= 0 && c < num_classes) atomicMax(&probabs[c], (unsigned long long)__double_as_longlong(probab));      // :120-121
+        }
+    }
+    {
+        const unsigned long long wk1 = fir::wave_min_u64(k1);
+        unsigned long long k2 = m2r != 0xFFFFFFFFu ? ord64(m2d) : ~0ull;
+        const unsigned long long wk2 = fir::wave_min_u64(k2);
+        unsigned int r2 = k2 == wk2 ? m2r : 0xFFFFFFFFu;
+        float wm = mloc;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const unsigned int o = __shfl_xor(r2, off, 64);
+            r2 = o < r2 ? o : r2;
+            const float of = __shfl_xor(wm, off, 64);
+            wm = of < wm ? of : wm;
+        }
+        if (lane == 0) { red_a[wave] = wk1; red_b[wave] = wk2; red_r[wave] = r2; red_f[wave] = wm; }
+    }
+    __syncthreads();
+    unsigned long long my_k1 = red_a[0], my_k2 = red_b[0];
+    unsigned int my_r2 = red_r[0];
+    float my_m = red_f[0];
+#pragma unroll
+    for (int i = 1; i < kWaves; ++i) {
+        my_k1 = red_a[i] < my_k1 ? red_a[i] : my_k1;
+        if (red_b[i] < my_k2 || (red_b[i] == my_k2 && red_r[i] < my_r2)) { my_k2 = red_b[i]; my_r2 = red_r[i]; }
+        my_m = red_f[i] < my_m ? red_f[i] : my_m;
+    }
+    if (threadIdx.x == 0) {
+        if (my_k1 != ~0ull) (void)atomic_max_read(&S->key1, ~my_k1);
+        if (my_r2 != 0xFFFFFFFFu) (void)atomic_max_read(&S->v2min, ~my_k2);
+        if (my_m < __builtin_huge_valf()) (void)atomic_max_read(&S->slot_m[b], ~(unsigned long long)fir::f32_orderable(my_m + 0.0f));
+    }
+    if (with_prob)
+        for (int c = threadIdx.x; c < num_classes; c += kFusedBlock)
+            if (probabs[c]) (void)atomic_max_read(&S->gprob[c], probabs[c]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // every thread's posterior posts have returned ...
+    __syncthreads();                                                   // ... before thread 0 arrives for the workgroup
+    bool ok = fused_meet(&S->ctr, (unsigned int)G, true, &fail_s);
+    // ---- between the meetings: r*, C*; the last local record of another class; the second-stage row ----
+    if (ok) {
+        if (threadIdx.x < 2) got[threadIdx.x] = atomic_max_read(threadIdx.x == 0 ? &S->key1 : &S->v2min, (unsigned long long)opaque_zero());
+        __syncthreads();
+        const unsigned long long gk1 = got[0], gk2 = got[1];
+        const bool has_best = gk1 != 0ull;
+        const unsigned int rstar = has_best ? (unsigned int)(~gk1 & 0xFFFFFFFFull) : 0xFFFFFFFFu;
+        if (has_best && type != 0) {
+            const int cstar = cls[rstar];
+            const unsigned int first_row = (unsigned int)(b * kWaves * T) * 64u;
+            if (first_row < rstar) {                                    // (workgroups behind r* have no record in front of it)
+                // wave-exclusive prefix of the waves' minima, then the scan in row order: tile by tile, lanes ascending
+                float carry = __builtin_huge_valf();
+                for (int w = 0; w < wave; ++w) carry = red_f[w] < carry ? red_f[w] : carry;
+                float found_d = 0.0f;
+                int found = 0;
+#pragma unroll
+                for (int i = 0; i < T; ++i) {
+                    const unsigned int row = (unsigned int)((tile_base + i) * 64 + lane);
+                    const bool live = ((valid >> i) & 1u) && d1[i] == d1[i];        // (a NaN distance never sets a record nor lowers bestDist)
+                    const float dv = live ? d1[i] : __builtin_huge_valf();
+                    float excl = __shfl_up(dv, 1, 64);                   // exclusive prefix minimum over the lanes in front
+                    excl = lane == 0 ? __builtin_huge_valf() : excl;
+#pragma unroll
+                    for (int off = 1; off < 64; off <<= 1) {
+                        const float o = __shfl_up(excl, off, 64);
+                        if (lane >= off) excl = o < excl ? o : excl;
+                    }
+                    excl = carry < excl ? carry : excl;
+                    const bool cand = live && dv < excl && cl[i] != cstar && row < rstar;
+                    const unsigned long long bal = __builtin_amdgcn_ballot_w64(cand);
+                    if (bal) {
+                        const int last = 63 - __builtin_clzll(bal);
+                        found_d = __shfl(dv, last, 64);
+                        found = 1;
+                    }
+                    float tm = dv;
+#pragma unroll
+                    for (int off = 32; off >= 1; off >>= 1) { const float o = __shfl_xor(tm, off, 64); tm = o < tm ? o : tm; }
+                    carry = tm < carry ? tm : carry;
+                }
+                if (lane == 0) { red_g[wave] = found_d; red_i[wave] = found; }
+            } else if (lane == 0) red_i[wave] = 0;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                int have = 0;
+                float dl = 0.0f;
+                for (int w = 0; w < kWaves; ++w) if (red_i[w]) { have = 1; dl = red_g[w]; }      // the last wave that found one
+                if (have) (void)atomic_max_read(&S->slot_l[b], ~(unsigned long long)fir::f32_orderable(dl + 0.0f));
+            }
+        }
+        if (threadIdx.x == 0 && gk2 != 0ull && my_r2 != 0xFFFFFFFFu && ~my_k2 == gk2) (void)atomic_max_read(&S->v2row, ~(unsigned long long)my_r2);
+        ok = fused_meet(&S->ctr, 2u * (unsigned int)G, b == 0, &fail_s);
+    }
+    if (b != 0) return;
+    // ---- behind the second meeting: workgroup 0 decides ----
+    int cls_final = -1, reliable = 0, failed = ok ? 0 : 1;
+    if (ok) {
+        __shared__ unsigned long long sm_s[256], sl_s[256];
+        __shared__ double second_s;
+        if (threadIdx.x < 3) got[threadIdx.x] = xchg0(threadIdx.x == 0 ? &S->key1 : threadIdx.x == 1 ? &S->v2min : &S->v2row);
+        for (int i = threadIdx.x; i < G; i += kFusedBlock) { sm_s[i] = xchg0(&S->slot_m[i]); sl_s[i] = xchg0(&S->slot_l[i]); }
+        if (with_prob)
+            for (int c = threadIdx.x; c < num_classes; c += kFusedBlock) probabs[c] = xchg0(&S->gprob[c]);
+        __syncthreads();
+        const unsigned long long gk1 = got[0];
+        const bool has_best = gk1 != 0ull;
+        const unsigned int rstar = has_best ? (unsigned int)(~gk1 & 0xFFFFFFFFull) : 0xFFFFFFFFu;
+        const double best_d = has_best ? (double)fir::f32_from_orderable((uint32_t)(~gk1 >> 32)) : 100000.0;
+        if (threadIdx.x == 0) {
+            double second = 100000.0;                                   // secondBestDist = 100000 (:111)
+            float P = 100000.0f;
+            for (int i = 0; i < G; ++i) {
+                if (sl_s[i]) {
+                    const float dl = fir::f32_from_orderable((uint32_t)~sl_s[i]);
+                    if (dl < P) second = (double)dl;
+                }
+                if (sm_s[i]) { const float m = fir::f32_from_orderable((uint32_t)~sm_s[i]); P = m < P ? m : P; }
+            }
+            second_s = second;
+        }
+        __syncthreads();
+        if (has_best) {
+            if (type == 0) {
+                // sum of the 5 largest class posteriors (:141-146), taken in descending order
+                double sum = 0.0;
+                for (int r = 0; r < 5; ++r) {
+                    DI m;
+                    m.d = __builtin_huge_val();
+                    m.i = -1;
+                    for (int c = threadIdx.x; c < num_classes; c += kFusedBlock) {
+                        const double v = __longlong_as_double((long long)probabs[c]);
+                        if (probabs[c] != ~0ull && (-v < m.d)) { m.d = -v; m.i = c; }
+                    }
+#pragma unroll
+                    for (int off = 32; off >= 1; off >>= 1) {
+                        DI o;
+                        o.d = __shfl_xor(m.d, off, 64);
+                        o.i = __shfl_xor(m.i, off, 64);
+                        if (o.d < m.d || (o.d == m.d && (unsigned)o.i < (unsigned)m.i)) m = o;
+                    }
+                    __syncthreads();
+                    if (lane == 0) red[wave] = m;
+                    __syncthreads();
+                    DI w = red[0];
+#pragma unroll
+                    for (int i = 1; i < kWaves; ++i)
+                        if (red[i].d < w.d || (red[i].d == w.d && (unsigned)red[i].i < (unsigned)w.i)) w = red[i];
+                    sum += -w.d;
+                    __syncthreads();
+                    if (threadIdx.x == 0 && w.i >= 0) probabs[w.i] = ~0ull;             // taken
+                    __syncthreads();
+                }
+                const double max_probab = exp(-best_d * 100) / sum;                     // :130,147
+                reliable = max_probab > threshold;                                      // :148
+            } else if (type == 1) {
+                reliable = (second_s - best_d) > threshold;                             // :158
+            } else {
+                reliable = (best_d / second_s) < threshold;                             // :161
+            }
+        }
+        cls_final = has_best ? cls[rstar] : -1;
+        if (!reliable) {                                                                // second stage (:165-180)
+            const unsigned long long gr = got[2];
+            cls_final = (got[1] != 0ull && gr != 0ull) ? cls[(unsigned int)~gr] : -1;
+        }
+    }
+    if (threadIdx.x != 0) return;
+    (void)__hip_atomic_exchange(&S->ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        // everybody has arrived twice: nobody reads it any more
+    class_out[q] = cls_final;
+    unreliable_out[q] = failed ? 2 : reliable ? 0 : 1;                  // 2: the workgroups did not meet in time -- the host takes the other form
+    if (host_res) {
+        host_res[q] = cls_final;
+        host_res[host_stride + q] = failed ? 2 : reliable ? 0 : 1;
+        __threadfence_system();
+        if (__hip_atomic_fetch_add(done_ctr, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u == (unsigned int)nq) {
+            (void)__hip_atomic_exchange(done_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(host_ticket, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 // Queries per internal batch: as many as keep the per-batch distance tables under `budget` bytes (a multiple of 8, <= kBatch).
 int batch_for(int64_t n, size_t bytes_per_query_row, size_t budget = (size_t)512 << 20) {
     const size_t per_query = (size_t)std::max<int64_t>(n, 1) * bytes_per_query_row;
@@ -815,10 +1134,78 @@ int fir_twd_conventional(fir_gallery* g, const float* queries, int32_t qb, int32
     DI* part2 = part1 + (size_t)batch * nseg_eff;
     S1Chg* chg = (S1Chg*)(part2 + (size_t)batch * nseg_eff);
     unsigned long long* gprob = (unsigned long long*)(chg + (size_t)batch * nseg_eff);
-    for (int q0 = 0; q0 < qb; q0 += batch) {
-        const int nq = std::min(batch, qb - q0);
+    // Few queries: ONE launch per internal batch (k_twd_conv_fused), as for the proposed classifier (FIR_TWD_FUSED).
+    const char* fenv = std::getenv("FIR_TWD_FUSED");
+    const int fmode = fenv ? std::atoi(fenv) : 1;
+    const int64_t tiles64 = ((int64_t)n + 63) / 64;
+    bool fused = fmode != 0 && n > 0 && (fmode == 2 || qb <= kFusedMaxQueries) && (v.metric == 0 || v.metric == 1) && reduced_features_count % 4 == 0 &&
+                 num_classes <= kConvMaxClasses;
+    const int fq = std::min(qb, kFusedMaxQueries);
+    int fG = 0, fT = 0;
+    if (fused) {
+        for (int t : {1, 2, 4, 8, 16}) {
+            const int64_t g_need = (tiles64 + 8 * t - 1) / (8 * t);
+            if (g_need <= std::min(256, std::max(1, v.cus / fq))) { fT = t; fG = (int)g_need; break; }
+        }
+        // every query of a fused launch reads the rows for itself: beyond one tile per wave that costs more than the launches it saves
+        // (100 000 x 512, 8 queries: 146 against 96 us), so several queries go this way only while every wave has a single tile
+        if (!fT || (fq > 1 && fT > 1)) fused = false;
+    }
+    const int fbatch = fused ? kFusedMaxQueries : batch;
+    for (int q0 = 0; q0 < qb; q0 += fbatch) {
+        const int nq = std::min(fbatch, qb - q0);
         int32_t h_res[2 * kBatch];
-        if (n == 0) {
+        bool answered = false;
+        if (fused) {
+            void* pin_base = nullptr; size_t pin_cap = 0; uint64_t* pin_res = nullptr;
+            const bool pinned = fir_gallery_pin_(g, &pin_base, &pin_cap, &pin_res) == FIR_OK && (size_t)nq * v.d * 4 <= pin_cap;
+            const float* qsrc = dq.as<float>();
+            if (pinned) { std::memcpy(pin_base, queries + (size_t)q0 * v.d, (size_t)nq * v.d * 4); qsrc = (const float*)pin_base; }
+            else TWD_HIP(hipMemcpyAsync(dq.p, queries + (size_t)q0 * v.d, (size_t)nq * v.d * 4, hipMemcpyHostToDevice, v.stream));
+            TWD_SLOT(cst, 16, (size_t)kFusedMaxQueries * sizeof(ConvState) + 64);        // (a fresh slot reads as zeros; the kernel leaves it so)
+            ConvState* cstate = cst.as<ConvState>();
+            unsigned int* done_ctr = (unsigned int*)(cstate + kFusedMaxQueries);
+            const void* gal4 = nullptr;
+            int dp4 = 0;
+            if ((rc = fir_gallery_tiled_(g, &gal4, &dp4))) return twd_fail(rc, "no tiled gallery");
+            const uint64_t ticket = pinned ? fir_gallery_next_ticket_(g) : 0;
+            typedef void (*conv_fn)(const float4*, int, int, int, const int32_t*, const float*, int, int, int, int, double, ConvState*, int32_t*, int32_t*, int32_t*,
+                                    int, uint64_t*, uint64_t, unsigned int*);
+            conv_fn fn = nullptr;
+#define FIR_CONV_PICK(M)                                                                                               \
+    fn = fT == 1 ? k_twd_conv_fused<M, 1> : fT == 2 ? k_twd_conv_fused<M, 2> : fT == 4 ? k_twd_conv_fused<M, 4>        \
+       : fT == 8 ? k_twd_conv_fused<M, 8> : k_twd_conv_fused<M, 16>
+            if (v.metric == 0) { FIR_CONV_PICK(fir::kL2); } else { FIR_CONV_PICK(fir::kChi2); }
+#undef FIR_CONV_PICK
+            const size_t flds = type == 0 ? (size_t)num_classes * 8 : 8;
+            if (flds > 48 * 1024) {
+                static bool attr[64][2][5] = {};
+                const int ti = fT == 1 ? 0 : fT == 2 ? 1 : fT == 4 ? 2 : fT == 8 ? 3 : 4;
+                if (!attr[v.device & 63][v.metric][ti]) {
+                    TWD_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+                    attr[v.device & 63][v.metric][ti] = true;
+                }
+            }
+            hipLaunchKernelGGL(fn, dim3(fG, nq), dim3(kFusedBlock), flds, v.stream, (const float4*)gal4, dp4, n, (int)tiles64, v.cls, qsrc, v.d,
+                               reduced_features_count, num_classes, type, threshold, cstate, dcls, dunrel, pinned ? (int32_t*)pin_res : (int32_t*)nullptr, kBatch,
+                               pinned ? pin_res + kBatch : (uint64_t*)nullptr, ticket, done_ctr);
+            TWD_HIP(hipGetLastError());
+            if (pinned) {
+                if ((rc = fir_gallery_wait_ticket_(g, pin_res + kBatch, ticket))) return rc;
+                std::memcpy(h_res, pin_res, sizeof(h_res));
+            } else {
+                TWD_HIP(hipMemcpyAsync(h_res, dres.p, sizeof(h_res), hipMemcpyDeviceToHost, v.stream));
+                TWD_HIP(hipStreamSynchronize(v.stream));
+            }
+            answered = true;
+            for (int i = 0; i < nq; ++i) answered = answered && h_res[kBatch + i] != 2;        // 2: the workgroups did not meet in time
+            if (!answered) {
+                TWD_HIP(hipStreamSynchronize(v.stream));
+                TWD_HIP(hipMemsetAsync(cst.p, 0, (size_t)kFusedMaxQueries * sizeof(ConvState) + 64, v.stream));      // whatever the launch left behind
+            }
+        }
+        if (answered) {
+        } else if (n == 0) {
             for (int i = 0; i < nq; ++i) { h_res[i] = -1; h_res[kBatch + i] = 1; }
         } else {
             // both stages are queued back to back -- the second one decides on the device which queries it concerns -- and

@@ -225,3 +225,79 @@ def test_proposed_twd_fused_beside_a_busy_device(fir, oracle):
         stop.set()
         t.join(timeout=60)
     assert not errors, errors
+
+
+def _conventional_all_forms(g, q, ncls, typ, th, fc=64):
+    out = []
+    for mode in (0, 1, 2):
+        with _FusedMode(mode):
+            out.append(tuple(np.asarray(x).tolist() for x in g.twd_conventional(q, ncls, typ, th, fc)))
+    return out
+
+
+@pytest.mark.parametrize("n,ncls,metric,class_major", [(70, 5, gc.L2, False), (3000, 37, gc.L2, True), (8192, 11, gc.L2, False), (20001, 40, gc.L2, True),
+                                                        (100000, 101, gc.L2, True), (5000, 23, gc.CHI2, False), (40000, 64, gc.CHI2, True)])
+def test_conventional_twd_as_one_launch_matches_the_oracle_and_the_other_forms(fir, oracle, n, ncls, metric, class_major):
+    """k_twd_conv_fused (both partial distances stay in registers, two meetings, secondBestDist from the workgroups' last local records)
+    against the oracle and the launch-per-stage forms: every type, thresholds on both sides of the reliability test, class-major
+    (the reference's order) and interleaved labels, 8 queries per call and one."""
+    rows, cls, q, _ = gc.twd_case(seed=41 + n % 13, n=n, d=256, n_classes=ncls)
+    if class_major:
+        cls = np.sort(cls)
+    if metric == gc.CHI2:
+        rows = np.abs(rows) + np.float32(1e-3)
+        q = np.abs(q) + np.float32(1e-3)
+    q = np.concatenate([q[:5], q[5:8] * np.float32(0.05) + rows[[1, n // 2, n - 1]] * np.float32(0.95)])
+    with fir.Gallery(rows, cls, metric, 0) as g:
+        for (typ, th) in gc.TWD_CONVENTIONAL + [(1, 0.0), (2, 0.5), (0, 0.9)]:
+            for fc in (64, 32) if n <= 20001 else (64,):
+                exp = [oracle.twd_conventional(rows, cls, qi, ncls, typ, th, fc, metric) for qi in q]
+                exp = ([e[0] for e in exp], [e[1] for e in exp])
+                for form, got in zip(("per-stage", "auto", "fused"), _conventional_all_forms(g, q, ncls, typ, th, fc)):
+                    assert got == exp, (form, typ, th, fc)
+                with _FusedMode(1):
+                    c1, u1 = g.twd_conventional(q[6:7], ncls, typ, th, fc)
+                assert (int(c1[0]), int(u1[0])) == (exp[0][6], exp[1][6]), (typ, th, fc)
+
+
+def test_conventional_twd_fused_second_best_follows_the_scan_order(fir, oracle):
+    """secondBestDist is 'bestDist at the last class change of the record walk' (ImageTesting.cpp:123-125), not 'the best of the other
+    classes': rows in descending distance (every row is a new record, spread over many workgroups), duplicated rows far apart (equal
+    distances: the first one is the record), NaN rows, and a gallery in which nothing is below the 100000 start value."""
+    rows, cls, q, ncls = gc.twd_case(seed=17, n=30000, d=256, n_classes=9)
+    order = np.argsort(oracle.all_distances(rows, q[0], 0, 64, 0))[::-1].copy()
+    rows, cls = rows[order], cls[order]
+    rows[20000] = rows[100]
+    rows[20001] = rows[29999]
+    q = q[:4].copy()
+    q[1] = rows[29999] * np.float32(0.999)
+    rows2 = rows.copy()
+    rows2[7] = np.nan
+    rows2[25000, 3] = np.nan
+    for rr in (rows, rows2):
+        with fir.Gallery(rr, cls, gc.L2, 0) as g:
+            for typ, th in ((1, 1e-4), (1, 1e-3), (1, 1e-6), (2, 0.9), (2, 0.99), (2, 0.9999), (0, 0.24)):
+                exp = [oracle.twd_conventional(rr, cls, qi, ncls, typ, th, 64) for qi in q]
+                exp = ([e[0] for e in exp], [e[1] for e in exp])
+                for form, got in zip(("per-stage", "auto", "fused"), _conventional_all_forms(g, q, ncls, typ, th)):
+                    assert got == exp, (form, typ, th)
+    far = np.full((700, 256), 3.0e4, np.float32)
+    with fir.Gallery(far, np.arange(700, dtype=np.int32) % 7, gc.L2, 0) as g:
+        for typ, th in ((0, 0.24), (1, 0.003), (2, 0.7)):
+            forms = _conventional_all_forms(g, np.zeros((2, 256), np.float32), 7, typ, th)
+            assert forms[0] == forms[1] == forms[2], (typ, forms)
+
+
+def test_conventional_twd_fused_many_calls_in_a_row(fir, oracle):
+    """The fused form leaves its state words zero behind every call (atomic exchanges by the deciding workgroup): a few hundred
+    calls of changing type, batch and threshold against the oracle."""
+    rows, cls, q, ncls = gc.twd_case(seed=58, n=12000, d=256, n_classes=30)
+    rng = np.random.default_rng(6)
+    with fir.Gallery(rows, cls, gc.L2, 0) as g, _FusedMode(1):
+        for it in range(150):
+            typ, th = gc.TWD_CONVENTIONAL[it % len(gc.TWD_CONVENTIONAL)]
+            nq = 1 + it % 5
+            qq = q[rng.integers(0, len(q), nq)] * np.float32(0.5) + rows[rng.integers(0, len(rows), nq)] * np.float32(0.5)
+            c, u = g.twd_conventional(qq, ncls, typ, th, 64)
+            exp = [oracle.twd_conventional(rows, cls, qi, ncls, typ, th, 64) for qi in qq]
+            assert (list(c), list(u)) == ([e[0] for e in exp], [e[1] for e in exp]), (it, typ, th)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""One TWD call repeated (for `rocprofv3 --kernel-trace --stats`). usage: python tools/twd_probe.py [rows] [dim] [queries] [conv|prop|prop_all]
+"""One TWD call repeated (for `rocprofv3 --kernel-trace --stats`). usage: python tools/twd_probe.py [rows] [dim] [queries] [conv|conv1|conv2|prop|prop_all]   (conv = posteriors, conv1 = distance difference, conv2 = distance ratio)
 (prop: a query next to a gallery row, the loop ends after the first chunk; prop_all: fresh random queries, distances concentrated: no chunk leaves one class, all 8 chunks)"""
 import gc
 import os
@@ -26,7 +26,8 @@ if which == "prop_all":
     q = rng.random((qb, d), dtype=np.float32)
     q /= np.linalg.norm(q, axis=1, keepdims=True)
 g = fir.Gallery(rows, cls, 0, 0)
-fn = (lambda: g.twd_conventional(q, 101, 0, 0.24, 64)) if which == "conv" else (lambda: g.twd_proposed(q, 32, 0.7))
+ctype = {"conv": (0, 0.24), "conv1": (1, 0.003), "conv2": (2, 0.7)}.get(which)
+fn = (lambda: g.twd_conventional(q, 101, ctype[0], ctype[1], 64)) if ctype else (lambda: g.twd_proposed(q, 32, 0.7))
 for _ in range(5):
     fn()
 ts = []
@@ -35,7 +36,9 @@ for _ in range(100):
     fn()
     ts.append((time.perf_counter() - t0) * 1e6)
 extra = ""
-if which != "conv":
+if ctype:
+    extra = f"  unreliable {fn()[1].tolist()[:4]}  FIR_TWD_FUSED={os.environ.get('FIR_TWD_FUSED', '(auto)')}"
+else:
     extra = f"  chunks used {g.twd_proposed(q, 32, 0.7)[2].tolist()[:4]}  FIR_TWD_FUSED={os.environ.get('FIR_TWD_FUSED', '(auto)')}"
 print(f"{n}x{d} qb={qb} {which}: median {np.median(ts):.1f} us/call" + extra)
 g.close()
