@@ -518,6 +518,7 @@ struct FusedState {
     unsigned int ctr, done;
     unsigned long long pad;
     FusedSlot slot[kFusedMaxChunks];
+    unsigned long long flag[256];                   // per workgroup: the number of the last meeting it has been released from (fused_meet)
 };
 __device__ __forceinline__ unsigned long long ord64(double v) {
     const unsigned long long b = (unsigned long long)__double_as_longlong(v);
@@ -538,11 +539,51 @@ __device__ __forceinline__ unsigned int opaque_zero() {
     return z;
 }
 
+constexpr int kMeetDirect = 16;
+// One meeting of the `G` workgroups of a query. Thread 0 arrives (its posts have returned) with a returning add on `ctr`; the workgroup
+// whose add completes `target` arrivals RELEASES the others by raising flag[0 .. G) to `gen` (one wave, 64 words per instruction);
+// everybody else polls ITS OWN flag word -- with all of them polling the one counter the polls queue up behind each other at the memory
+// side (196 workgroups: a meeting took 8-9 us against 4-5 us with 6). `after_arrival` runs in wave 0 between the arrival and the wait
+// (requests that must not delay the arrival). The poll is bounded by wall time: false = the others did not come. Ends on a barrier.
+template <typename F>
+__device__ __forceinline__ bool fused_meet(unsigned int* ctr, unsigned long long* flags, int G, int b, unsigned int target, unsigned long long gen, bool wait,
+                                           int* fail_s, F&& after_arrival) {
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        unsigned int seen = 0;
+        if (lane == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            seen = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+        }
+        after_arrival();
+        const bool direct = G <= kMeetDirect;                          // few workgroups: they poll the counter itself (one hop less)
+        const int last = __shfl((int)(seen == target), 0, 64);
+        if (last) {
+            if (!direct)
+                for (int i = lane; i < G; i += 64) (void)__hip_atomic_fetch_max(&flags[i], gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (lane == 0 && wait) {
+            unsigned long long t0 = 0;
+            for (unsigned int polls = 1;; ++polls) {
+                if (direct ? __hip_atomic_fetch_max(ctr, opaque_zero(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target
+                           : __hip_atomic_fetch_max(&flags[b], (unsigned long long)opaque_zero(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= gen) break;
+                __builtin_amdgcn_s_sleep(1);
+                if ((polls & 15u) == 0u) {                              // (the clock is a scalar memory read: not on every poll)
+                    const unsigned long long now = wall_clock64();
+                    if (!t0) t0 = now;
+                    else if (now - t0 > kFusedPatienceTicks) { *fail_s = 1; break; }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    return *fail_s == 0;
+}
+
 template <int METRIC, int T>
 __global__ void __launch_bounds__(kFusedBlock) k_twd_prop_fused(const float4* __restrict__ gal4, int dp4, int n, int tiles,
                                                                  const int32_t* __restrict__ cls, const float* queries, int qstride,
                                                                  int reduced, int nchunks, double threshold /* 1/th */, FusedState* state,
-                                                                 int parity, int32_t* __restrict__ class_out,
+                                                                 int parity, unsigned long long gen_base, int32_t* __restrict__ class_out,
                                                                  int32_t* __restrict__ unreliable_out, int32_t* __restrict__ chunks_out,
                                                                  int32_t* host_res, int host_stride, uint64_t* host_ticket, uint64_t ticket) {
     constexpr int kWaves = kFusedBlock / 64;
@@ -581,6 +622,19 @@ __global__ void __launch_bounds__(kFusedBlock) k_twd_prop_fused(const float4* __
     __syncthreads();
     // distances of chunk c for the rows still alive, added to their sums; the workgroup's smallest sum (and its first row) to
     // thread 0, which returns ~orderable (0 = no row below 100000) and the row
+    // The first eight 16-byte pieces of the wave's first tile for the chunk AFTER the coming meeting are requested in front of that
+    // meeting (whether the tile will still have a row alive is only known behind it): they arrive while the workgroups wait for each other.
+    float4 pre[8];
+    bool have_pre = false;
+    auto prefetch = [&](int cn) {
+        have_pre = cn < nchunks && w < tiles;
+        if (have_pre) {
+            const float4* tp = gal4 + ((size_t)w * dp4 + (size_t)cn * r4) * 64 + lane;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (u < r4) pre[u] = tp[(size_t)u * 64];
+        }
+    };
     auto chunk = [&](int c, const float* qv, unsigned int& row_out) -> unsigned long long {
         double md = 100000.0;                                          // bestDist = 100000 per chunk (:225)
         int mrow = -1;
@@ -592,9 +646,14 @@ __global__ void __launch_bounds__(kFusedBlock) k_twd_prop_fused(const float4* __
             float acc = 0.0f;
             for (int k0 = 0; k0 < r4; k0 += 8) {
                 float4 g[8];
+                if (i == 0 && k0 == 0 && have_pre) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (k0 + u < r4) g[u] = tp[(size_t)(k0 + u) * 64];
+                    for (int u = 0; u < 8; ++u) g[u] = pre[u];
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (k0 + u < r4) g[u] = tp[(size_t)(k0 + u) * 64];
+                }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     if (k0 + u < r4) {
@@ -639,24 +698,11 @@ __global__ void __launch_bounds__(kFusedBlock) k_twd_prop_fused(const float4* __
     bool has_best = false;
     for (int c = 0;; ++c) {
         // ---- meeting c: every workgroup of the query has posted chunk c's minimum and chunk c - 1's survivors ----
-        if (threadIdx.x == 0) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this workgroup's posts have returned
-            const unsigned int target = (unsigned int)G * (unsigned int)(c + 1);
-            unsigned int seen = __hip_atomic_fetch_add(&S->ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-            if (c < nchunks || b == 0) {                               // (after the last chunk only workgroup 0 has anything left to do)
-                unsigned long long t0 = 0;
-                for (unsigned int polls = 1; seen < target; ++polls) {
-                    __builtin_amdgcn_s_sleep(1);
-                    seen = __hip_atomic_fetch_max(&S->ctr, opaque_zero(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if ((polls & 15u) == 0u && seen < target) {        // (the clock is a scalar memory read: not on every poll)
-                        const unsigned long long now = wall_clock64();
-                        if (!t0) t0 = now;
-                        else if (now - t0 > kFusedPatienceTicks) { fail_s = 1; break; }
-                    }
-                }
-            }
-        }
-        __syncthreads();
+        // (the requests for chunk c + 1 go out in front of the wait; in thread 0's wave behind its arrival, which they must not delay;
+        // after the last chunk only workgroup 0 has anything left to do)
+        if (wave != 0) prefetch(c + 1);
+        (void)fused_meet(&S->ctr, S->flag, G, b, (unsigned int)G * (unsigned int)(c + 1), gen_base + (unsigned long long)(c + 1), c < nchunks || b == 0, &fail_s,
+                         [&]() { prefetch(c + 1); });
         if (c == nchunks && b != 0) return;
         if (fail_s) { failed = 1; break; }
         if (threadIdx.x < 4) {
@@ -769,38 +815,16 @@ struct ConvState {
     unsigned long long key1, v2min, v2row;           // ~key_pack(d1, row); ~ord64(second-stage value); ~row
     unsigned long long slot_m[256], slot_l[256];     // per workgroup: ~orderable(min d1); ~orderable(d1 of its last local record of another class)
     unsigned long long gprob[kConvMaxClasses];       // bit patterns of the class posteriors (non-negative doubles order like integers)
+    unsigned long long flag[256];                    // fused_meet's release words: they only ever rise (the meeting numbers of a handle never repeat)
 };
 __device__ __forceinline__ unsigned long long xchg0(unsigned long long* p) {
     return __hip_atomic_exchange(p, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// One meeting of the `G` workgroups of a query (see k_twd_prop_fused): thread 0's posts have returned, it arrives and -- if `wait` --
-// polls until `target` arrivals; returns false when the others did not come in time. Ends on a workgroup barrier.
-__device__ __forceinline__ bool fused_meet(unsigned int* ctr, unsigned int target, bool wait, int* fail_s) {
-    if (threadIdx.x == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        unsigned int seen = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-        if (wait) {
-            unsigned long long t0 = 0;
-            for (unsigned int polls = 1; seen < target; ++polls) {
-                __builtin_amdgcn_s_sleep(1);
-                seen = __hip_atomic_fetch_max(ctr, opaque_zero(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((polls & 15u) == 0u && seen < target) {
-                    const unsigned long long now = wall_clock64();
-                    if (!t0) t0 = now;
-                    else if (now - t0 > kFusedPatienceTicks) { *fail_s = 1; break; }
-                }
-            }
-        }
-    }
-    __syncthreads();
-    return *fail_s == 0;
-}
-
 template <int METRIC, int T>
 __global__ void __launch_bounds__(kFusedBlock) k_twd_conv_fused(const float4* __restrict__ gal4, int dp4, int n, int tiles, const int32_t* __restrict__ cls,
                                                                  const float* queries, int qstride, int reduced, int num_classes, int type,
-                                                                 double threshold, ConvState* state, int32_t* __restrict__ class_out,
-                                                                 int32_t* __restrict__ unreliable_out, int32_t* host_res, int host_stride,
+                                                                 double threshold, ConvState* state, unsigned long long gen_base,
+                                                                 int32_t* __restrict__ class_out, int32_t* __restrict__ unreliable_out, int32_t* host_res, int host_stride,
                                                                  uint64_t* host_ticket, uint64_t ticket, unsigned int* done_ctr) {
     constexpr int kWaves = kFusedBlock / 64;
     extern __shared__ __attribute__((aligned(16))) unsigned long long probabs[];   // type 0: num_classes bit patterns
@@ -823,7 +847,7 @@ __global__ void __launch_bounds__(kFusedBlock) k_twd_conv_fused(const float4* __
         for (int c = threadIdx.x; c < num_classes; c += kFusedBlock) probabs[c] = 0ull;
     __syncthreads();
     // ---- both partial distances of this lane's rows (db_features.cpp:22-42 over [0, reduced) and [reduced, 256)) ----
-    const int r4 = reduced >> 2;
+    const int r4 = reduced >> 2, t4 = (kLastFeature - reduced) >> 2;
     const float f1 = (float)reduced, f2 = (float)(kLastFeature - reduced);
     float d1[T];
     double v2[T];
@@ -838,30 +862,33 @@ __global__ void __launch_bounds__(kFusedBlock) k_twd_conv_fused(const float4* __
         if (t >= tiles) continue;                                       // wave-uniform
         const float4* tp = gal4 + (size_t)t * dp4 * 64 + lane;
         float a1 = 0.0f, a2 = 0.0f;
-        // the row's 64 chunks of four features, eight at a time, the next eight already requested (a tile is ONE wave's serial work:
-        // what it waits for is memory latency); chunk c belongs to the first stage while c < r4 (wave-uniform)
-        float4 gc[8], gn[8];
+        // (eight 16-byte pieces per request group; keeping the next group in flight as well -- a register double buffer over the row's
+        // 64 pieces -- changed nothing at one tile per wave and cost 40 % at eight: the waves of a CU overlap each other's latency)
+        for (int k0 = 0; k0 < r4; k0 += 8) {
+            float4 g[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) gc[u] = tp[(size_t)u * 64];
-#pragma unroll
-        for (int k0 = 0; k0 < kLastFeature / 4; k0 += 8) {
-            if (k0 + 8 < kLastFeature / 4) {
-#pragma unroll
-                for (int u = 0; u < 8; ++u) gn[u] = tp[(size_t)(k0 + 8 + u) * 64];
-            }
+            for (int u = 0; u < 8; ++u) if (k0 + u < r4) g[u] = tp[(size_t)(k0 + u) * 64];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const float4 l = *(const float4*)(qs + 4 * (k0 + u));
                 if (k0 + u < r4) {
-                    a1 = fir::accum<METRIC>(a1, l.x, gc[u].x); a1 = fir::accum<METRIC>(a1, l.y, gc[u].y);
-                    a1 = fir::accum<METRIC>(a1, l.z, gc[u].z); a1 = fir::accum<METRIC>(a1, l.w, gc[u].w);
-                } else {
-                    a2 = fir::accum<METRIC>(a2, l.x, gc[u].x); a2 = fir::accum<METRIC>(a2, l.y, gc[u].y);
-                    a2 = fir::accum<METRIC>(a2, l.z, gc[u].z); a2 = fir::accum<METRIC>(a2, l.w, gc[u].w);
+                    const float4 l = *(const float4*)(qs + 4 * (k0 + u));
+                    a1 = fir::accum<METRIC>(a1, l.x, g[u].x); a1 = fir::accum<METRIC>(a1, l.y, g[u].y);
+                    a1 = fir::accum<METRIC>(a1, l.z, g[u].z); a1 = fir::accum<METRIC>(a1, l.w, g[u].w);
                 }
             }
+        }
+        for (int k0 = 0; k0 < t4; k0 += 8) {
+            float4 g[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) gc[u] = gn[u];
+            for (int u = 0; u < 8; ++u) if (k0 + u < t4) g[u] = tp[(size_t)(r4 + k0 + u) * 64];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (k0 + u < t4) {
+                    const float4 l = *(const float4*)(qs + 4 * (r4 + k0 + u));
+                    a2 = fir::accum<METRIC>(a2, l.x, g[u].x); a2 = fir::accum<METRIC>(a2, l.y, g[u].y);
+                    a2 = fir::accum<METRIC>(a2, l.z, g[u].z); a2 = fir::accum<METRIC>(a2, l.w, g[u].w);
+                }
+            }
         }
         if (row < n) {
             valid |= 1u << i;
@@ -924,7 +951,7 @@ __global__ void __launch_bounds__(kFusedBlock) k_twd_conv_fused(const float4* __
             if (probabs[c]) (void)atomic_max_read(&S->gprob[c], probabs[c]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // every thread's posterior posts have returned ...
     __syncthreads();                                                   // ... before thread 0 arrives for the workgroup
-    bool ok = fused_meet(&S->ctr, (unsigned int)G, true, &fail_s);
+    bool ok = fused_meet(&S->ctr, S->flag, G, b, (unsigned int)G, gen_base + 1ull, true, &fail_s, []() {});
     // ---- between the meetings: r*, C*; the last local record of another class; the second-stage row ----
     if (ok) {
         if (threadIdx.x < 2) got[threadIdx.x] = atomic_max_read(threadIdx.x == 0 ? &S->key1 : &S->v2min, (unsigned long long)opaque_zero());
@@ -977,7 +1004,7 @@ __global__ void __launch_bounds__(kFusedBlock) k_twd_conv_fused(const float4* __
             }
         }
         if (threadIdx.x == 0 && gk2 != 0ull && my_r2 != 0xFFFFFFFFu && ~my_k2 == gk2) (void)atomic_max_read(&S->v2row, ~(unsigned long long)my_r2);
-        ok = fused_meet(&S->ctr, 2u * (unsigned int)G, b == 0, &fail_s);
+        ok = fused_meet(&S->ctr, S->flag, G, b, 2u * (unsigned int)G, gen_base + 2ull, b == 0, &fail_s, []() {});
     }
     if (b != 0) return;
     // ---- behind the second meeting: workgroup 0 decides ----
@@ -1169,8 +1196,9 @@ int fir_twd_conventional(fir_gallery* g, const float* queries, int32_t qb, int32
             int dp4 = 0;
             if ((rc = fir_gallery_tiled_(g, &gal4, &dp4))) return twd_fail(rc, "no tiled gallery");
             const uint64_t ticket = pinned ? fir_gallery_next_ticket_(g) : 0;
-            typedef void (*conv_fn)(const float4*, int, int, int, const int32_t*, const float*, int, int, int, int, double, ConvState*, int32_t*, int32_t*, int32_t*,
-                                    int, uint64_t*, uint64_t, unsigned int*);
+            typedef void (*conv_fn)(const float4*, int, int, int, const int32_t*, const float*, int, int, int, int, double, ConvState*, unsigned long long, int32_t*,
+                                    int32_t*, int32_t*, int, uint64_t*, uint64_t, unsigned int*);
+            const unsigned long long gen_base = (unsigned long long)(fir_gallery_next_counter_(g, 1) + 1) << 7;      // meeting numbers that never repeat
             conv_fn fn = nullptr;
 #define FIR_CONV_PICK(M)                                                                                               \
     fn = fT == 1 ? k_twd_conv_fused<M, 1> : fT == 2 ? k_twd_conv_fused<M, 2> : fT == 4 ? k_twd_conv_fused<M, 4>        \
@@ -1187,7 +1215,7 @@ int fir_twd_conventional(fir_gallery* g, const float* queries, int32_t qb, int32
                 }
             }
             hipLaunchKernelGGL(fn, dim3(fG, nq), dim3(kFusedBlock), flds, v.stream, (const float4*)gal4, dp4, n, (int)tiles64, v.cls, qsrc, v.d,
-                               reduced_features_count, num_classes, type, threshold, cstate, dcls, dunrel, pinned ? (int32_t*)pin_res : (int32_t*)nullptr, kBatch,
+                               reduced_features_count, num_classes, type, threshold, cstate, gen_base, dcls, dunrel, pinned ? (int32_t*)pin_res : (int32_t*)nullptr, kBatch,
                                pinned ? pin_res + kBatch : (uint64_t*)nullptr, ticket, done_ctr);
             TWD_HIP(hipGetLastError());
             if (pinned) {
@@ -1323,10 +1351,12 @@ int fir_twd_proposed(fir_gallery* g, const float* queries, int32_t qb, int32_t r
                 const void* gal4 = nullptr;
                 int dp4 = 0;
                 if ((rc = fir_gallery_tiled_(g, &gal4, &dp4))) return twd_fail(rc, "no tiled gallery");
-                const int parity = (int)(fir_gallery_next_counter_(g, 0) & 1);
+                const uint64_t call_no = fir_gallery_next_counter_(g, 0);
+                const int parity = (int)(call_no & 1);
+                const unsigned long long gen_base = (unsigned long long)(call_no + 1) << 7;                        // meeting numbers that never repeat
                 const uint64_t ticket = pinned ? fir_gallery_next_ticket_(g) : 0;
-                typedef void (*fused_fn)(const float4*, int, int, int, const int32_t*, const float*, int, int, int, double, FusedState*, int, int32_t*,
-                                         int32_t*, int32_t*, int32_t*, int, uint64_t*, uint64_t);
+                typedef void (*fused_fn)(const float4*, int, int, int, const int32_t*, const float*, int, int, int, double, FusedState*, int, unsigned long long,
+                                         int32_t*, int32_t*, int32_t*, int32_t*, int, uint64_t*, uint64_t);
                 fused_fn fn = nullptr;
 #define FIR_FUSED_PICK(M)                                                                                              \
     fn = fT == 1 ? k_twd_prop_fused<M, 1> : fT == 2 ? k_twd_prop_fused<M, 2> : fT == 4 ? k_twd_prop_fused<M, 4>        \
@@ -1334,7 +1364,7 @@ int fir_twd_proposed(fir_gallery* g, const float* queries, int32_t qb, int32_t r
                 if (v.metric == 0) { FIR_FUSED_PICK(fir::kL2); } else { FIR_FUSED_PICK(fir::kChi2); }
 #undef FIR_FUSED_PICK
                 hipLaunchKernelGGL(fn, dim3(fG, nq), dim3(kFusedBlock), 0, v.stream, (const float4*)gal4, dp4, n, (int)tiles, v.cls, qsrc, v.d,
-                                   reduced_features_count, nchunks, 1.0 / threshold, fst.as<FusedState>(), parity, dcls, dunrel, dchunks,
+                                   reduced_features_count, nchunks, 1.0 / threshold, fst.as<FusedState>(), parity, gen_base, dcls, dunrel, dchunks,
                                    pinned ? (int32_t*)pin_res : (int32_t*)nullptr, kBatch, pinned ? pin_res + 2 * kBatch : (uint64_t*)nullptr, ticket);
                 TWD_HIP(hipGetLastError());
                 if (pinned) {
