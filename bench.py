@@ -697,6 +697,25 @@ def config2(fir, src, q, dev, ws, d):
             os.environ["FIR_TWD_FUSED"] = old_env
         twd["same_verdicts"] = all(twd[f"one_launch_{t}"][k] == twd[f"launch_per_chunk_{t}"][k] for t in ("near_row", "fresh_query") for k in ("class", "unreliable", "chunks_used"))
         out["twd_proposed_one_query"] = twd
+        # ... and the conventional classifier (ImageTesting.cpp:108-186): posteriors and distance difference, first stage over 64 features
+        conv = {}
+        for mode, name in (("1", "one_launch"), ("0", "launch_per_stage")):
+            os.environ["FIR_TWD_FUSED"] = mode
+            for typ, th, tag in ((0, 0.24, "posteriors"), (1, 0.003, "difference")):
+                for _ in range(5):
+                    res = gt.twd_conventional(q_far, 1000, typ, th, 64)
+                ts = []
+                for _ in range(40):
+                    t0 = time.perf_counter()
+                    res = gt.twd_conventional(q_far, 1000, typ, th, 64)
+                    ts.append(time.perf_counter() - t0)
+                conv[f"{name}_{tag}"] = {"us_per_call": float(np.median(ts)) * 1e6, "class": int(res[0][0]), "unreliable": int(res[1][0])}
+        if old_env is None:
+            os.environ.pop("FIR_TWD_FUSED", None)
+        else:
+            os.environ["FIR_TWD_FUSED"] = old_env
+        conv["same_verdicts"] = all(conv[f"one_launch_{t}"][k] == conv[f"launch_per_stage_{t}"][k] for t in ("posteriors", "difference") for k in ("class", "unreliable"))
+        out["twd_conventional_one_query"] = conv
         gt.close()
     except Exception as e:      # noqa: BLE001 -- a side measurement must not take the bench line down
         out["twd_proposed_one_query"] = {"error": repr(e)}
