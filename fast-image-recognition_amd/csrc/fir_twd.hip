@@ -1148,7 +1148,6 @@ int fir_twd_conventional(fir_gallery* g, const float* queries, int32_t qb, int32
     const int n = (int)v.n;
     const int batch = std::min(batch_for(n, 8), std::max(8, (qb + 7) / 8 * 8));
     TWD_SLOT(dq, 0, (size_t)batch * v.d * 4);
-    TWD_SLOT(d1, 1, (size_t)2 * batch * std::max(n, 1) * 4);    // [0, reduced) distances of the batch, then [reduced, 256)
     TWD_SLOT(dres, 3, (size_t)2 * kBatch * 4);                 // class[kBatch], unreliable[kBatch]
     int32_t* dcls = dres.as<int32_t>();
     int32_t* dunrel = dcls + kBatch;
@@ -1156,17 +1155,28 @@ int fir_twd_conventional(fir_gallery* g, const float* queries, int32_t qb, int32
     const int nseg = n > 4 * kSpan ? std::min(256, (n + 2 * kSpan - 1) / (2 * kSpan)) : 1;
     const int seg_rows = nseg > 1 ? ((n + nseg - 1) / nseg + kSpan - 1) / kSpan * kSpan : n;
     const int nseg_eff = nseg > 1 ? (n + seg_rows - 1) / seg_rows : 1;
-    TWD_SLOT(dpart, 7, (size_t)batch * nseg_eff * (sizeof(DI) * 2 + sizeof(S1Chg)) + (size_t)batch * num_classes * 8);
-    DI* part1 = dpart.as<DI>();
-    DI* part2 = part1 + (size_t)batch * nseg_eff;
-    S1Chg* chg = (S1Chg*)(part2 + (size_t)batch * nseg_eff);
-    unsigned long long* gprob = (unsigned long long*)(chg + (size_t)batch * nseg_eff);
+    // (the distance tables and segment records of the launch-per-stage form are taken from the handle's scratch when that form runs)
+    Slot d1, dpart;
+    DI *part1 = nullptr, *part2 = nullptr;
+    S1Chg* chg = nullptr;
+    unsigned long long* gprob = nullptr;
+    auto stage_scratch = [&]() -> int {
+        int rc2;
+        if ((rc2 = fir_gallery_scratch_(g, 1, std::max<size_t>((size_t)2 * batch * std::max(n, 1) * 4, 16), &d1.p))) return rc2;    // [0, reduced) distances of the batch, then [reduced, 256)
+        if ((rc2 = fir_gallery_scratch_(g, 7, std::max<size_t>((size_t)batch * nseg_eff * (sizeof(DI) * 2 + sizeof(S1Chg)) + (size_t)batch * num_classes * 8, 16), &dpart.p)))
+            return rc2;
+        part1 = dpart.as<DI>();
+        part2 = part1 + (size_t)batch * nseg_eff;
+        chg = (S1Chg*)(part2 + (size_t)batch * nseg_eff);
+        gprob = (unsigned long long*)(chg + (size_t)batch * nseg_eff);
+        return FIR_OK;
+    };
     // Few queries: ONE launch per internal batch (k_twd_conv_fused), as for the proposed classifier (FIR_TWD_FUSED).
     const char* fenv = std::getenv("FIR_TWD_FUSED");
     const int fmode = fenv ? std::atoi(fenv) : 1;
     const int64_t tiles64 = ((int64_t)n + 63) / 64;
     bool fused = fmode != 0 && n > 0 && (fmode == 2 || qb <= kFusedMaxQueries) && (v.metric == 0 || v.metric == 1) && reduced_features_count % 4 == 0 &&
-                 num_classes <= kConvMaxClasses;
+                 num_classes <= 4096;                                   // (the posteriors of a workgroup sit in LDS next to 6 KiB of static tables)
     const int fq = std::min(qb, kFusedMaxQueries);
     int fG = 0, fT = 0;
     if (fused) {
@@ -1205,15 +1215,7 @@ int fir_twd_conventional(fir_gallery* g, const float* queries, int32_t qb, int32
        : fT == 8 ? k_twd_conv_fused<M, 8> : k_twd_conv_fused<M, 16>
             if (v.metric == 0) { FIR_CONV_PICK(fir::kL2); } else { FIR_CONV_PICK(fir::kChi2); }
 #undef FIR_CONV_PICK
-            const size_t flds = type == 0 ? (size_t)num_classes * 8 : 8;
-            if (flds > 48 * 1024) {
-                static bool attr[64][2][5] = {};
-                const int ti = fT == 1 ? 0 : fT == 2 ? 1 : fT == 4 ? 2 : fT == 8 ? 3 : 4;
-                if (!attr[v.device & 63][v.metric][ti]) {
-                    TWD_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-                    attr[v.device & 63][v.metric][ti] = true;
-                }
-            }
+            const size_t flds = type == 0 ? (size_t)num_classes * 8 : 8;      // <= 32 KiB
             hipLaunchKernelGGL(fn, dim3(fG, nq), dim3(kFusedBlock), flds, v.stream, (const float4*)gal4, dp4, n, (int)tiles64, v.cls, qsrc, v.d,
                                reduced_features_count, num_classes, type, threshold, cstate, gen_base, dcls, dunrel, pinned ? (int32_t*)pin_res : (int32_t*)nullptr, kBatch,
                                pinned ? pin_res + kBatch : (uint64_t*)nullptr, ticket, done_ctr);
@@ -1236,6 +1238,7 @@ int fir_twd_conventional(fir_gallery* g, const float* queries, int32_t qb, int32
         } else if (n == 0) {
             for (int i = 0; i < nq; ++i) { h_res[i] = -1; h_res[kBatch + i] = 1; }
         } else {
+            if ((rc = stage_scratch())) return rc;
             // both stages are queued back to back -- the second one decides on the device which queries it concerns -- and
             // the verdicts come back with ONE copy and ONE synchronisation per batch
             // small batches: the kernels read the queries from pinned host memory and the verdicts come back through it, with
