@@ -160,3 +160,28 @@ def test_kl_nomination_scan_returns_the_exact_scans_keys(fir, oracle, monkeypatc
         gaps = np.diff(ed) > 4e-5 * np.abs(ed[1:])
         if gaps.all():
             assert np.array_equal(a5[0][i], ei)
+
+
+@pytest.mark.parametrize("metric", [1, 2])
+def test_nomination_scans_over_ranges_with_ragged_edges(fir, metric, monkeypatch):
+    """The chi-square (harmonic, two terms per reciprocal) and KL (entropy form) nomination scans over feature ranges whose ends are not
+    multiples of 4 (the edge features go through the one-term forms), a range inside one 4-feature chunk, and batches that fill one
+    tile of 8 queries, one and a half, and an odd number of tiles: the exact scan's keys, bit for bit."""
+    import synth
+
+    n, d = 66000, 96
+    rows = synth.make_gallery(83, n, d, metric)
+    q, _ = synth.make_queries(83, rows, 40, metric)
+    rows[:, 7] = 0
+    q[::3, 8] = 0
+    with fir.Gallery(rows, None, metric, 0) as g:
+        for (a, b) in ((5, 93), (0, 96), (33, 35), (3, 70)):
+            for nq in (8, 12, 40):
+                got1 = g.search_top1(q[:nq], a, b)
+                got5 = g.search_topk(q[:nq], 5, a, b)
+                monkeypatch.setenv("FIR_NO_CHI2_NOMINATION", "1")
+                exp1 = g.search_top1(q[:nq], a, b)
+                exp5 = g.search_topk(q[:nq], 5, a, b)
+                monkeypatch.delenv("FIR_NO_CHI2_NOMINATION")
+                assert np.array_equal(got1[0], exp1[0]) and np.array_equal(got1[1].view(np.uint32), exp1[1].view(np.uint32)), (a, b, nq)
+                assert np.array_equal(got5[0], exp5[0]) and np.array_equal(got5[1].view(np.uint32), exp5[1].view(np.uint32)), (a, b, nq)
