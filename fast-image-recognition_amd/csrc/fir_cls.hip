@@ -194,11 +194,10 @@ __global__ void __launch_bounds__(BLOCK, NT > 1 ? 2 : 4) k_cls_scan_lds(const do
 #pragma unroll
             for (int q = 0; q < 8; ++q) acc[h][q] = 0.0;
         // COUNT chunks (two features each) from chunk c on of this lane against one tile's eight queries; the LDS reads run one feature ahead
-        auto run = [&](double (&a)[8], const double2* lq, const double2* g, int c, auto count_tag) {
+        // (`cur` = the tile's query values of the NEXT feature to be used: carried from call to call, so that switching between the tiles
+        // of a read does not restart the read-ahead)
+        auto run = [&](double (&a)[8], double2 (&cur)[4], const double2* lq, const double2* g, int c, auto count_tag) {
             constexpr int COUNT = decltype(count_tag)::value;
-            double2 cur[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) cur[i] = lq[(c * 2) * 4 + i];
 #pragma unroll
             for (int u = 0; u < COUNT; ++u) {
                 const double gv[2] = {g[u].x, g[u].y};
@@ -228,20 +227,25 @@ __global__ void __launch_bounds__(BLOCK, NT > 1 ? 2 : 4) k_cls_scan_lds(const do
 #pragma unroll
             for (int u = 0; u < kClsU; ++u) g[u] = cls_ld_nt(p + (size_t)u * 64);
         }
+        double2 curq[NT][4];
+#pragma unroll
+        for (int h = 0; h < NT; ++h)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) curq[h][i] = lq0[(size_t)h * (n2 + 4) + i];
         for (int gi = 0; gi < ng; ++gi, c += kClsU) {
             double2 nxg[kClsU];
             const int gn = gi + 1 < ng ? gi + 1 : gi;                           // the last group re-reads itself (keeps the loop branch-free)
 #pragma unroll
             for (int u = 0; u < kClsU; ++u) nxg[u] = cls_ld_nt(p + (size_t)(gn * kClsU + u) * 64);
 #pragma unroll
-            for (int h = 0; h < NT; ++h) run(acc[h], lq0 + (size_t)h * (n2 + 4), g, c, std::integral_constant<int, kClsU>());
+            for (int h = 0; h < NT; ++h) run(acc[h], curq[h], lq0 + (size_t)h * (n2 + 4), g, c, std::integral_constant<int, kClsU>());
 #pragma unroll
             for (int u = 0; u < kClsU; ++u) g[u] = nxg[u];
         }
         for (; c < dp2; ++c) {
             const double2 gt = cls_ld_nt(p + (size_t)c * 64);
 #pragma unroll
-            for (int h = 0; h < NT; ++h) run(acc[h], lq0 + (size_t)h * (n2 + 4), &gt, c, std::integral_constant<int, 1>());
+            for (int h = 0; h < NT; ++h) run(acc[h], curq[h], lq0 + (size_t)h * (n2 + 4), &gt, c, std::integral_constant<int, 1>());
         }
         const int64_t row = (int64_t)t * kTileRows + lane;
         if (row < nt) {
