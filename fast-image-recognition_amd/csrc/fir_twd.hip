@@ -531,6 +531,13 @@ __device__ __forceinline__ double ord64_back(unsigned long long o) {
 __device__ __forceinline__ unsigned long long atomic_max_read(unsigned long long* p, unsigned long long v) {
     return __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// A post the other workgroups will read behind the next meeting: the RETURNING form -- once the value is back (every wave waits
+// with vmcnt(0) in front of its workgroup's arrival) the maximum has been taken where every XCD's atomics are. The returned values are
+// only parked in variables that are looked at behind the meeting: nothing waits for a single post.
+__device__ __forceinline__ void post_max(unsigned long long* p, unsigned long long v, unsigned long long& ret) {
+    ret = __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void keep_alive(unsigned long long a, unsigned long long b = 0, unsigned long long c = 0) { asm volatile("" ::"v"(a), "v"(b), "v"(c)); }
 // A zero the compiler cannot see: an atomic maximum with a KNOWN zero is turned into an sc1 load, and what is wanted here is the
 // value at the memory side.
 __device__ __forceinline__ unsigned int opaque_zero() {
@@ -691,9 +698,10 @@ __global__ void __launch_bounds__(kFusedBlock) k_twd_prop_fused(const float4* __
         row_out = br;
         return br == 0xFFFFFFFFu ? 0ull : ~bk;
     };
+    unsigned long long ret_a = 0, ret_b = 0;                            // (post_max)
     unsigned int my_row = 0xFFFFFFFFu;
     unsigned long long my_vmin = chunk(0, qs, my_row);
-    if (threadIdx.x == 0 && my_vmin) (void)atomic_max_read(&S->slot[0].vmin, my_vmin);      // (returning: it has been performed when the wait below ends)
+    if (threadIdx.x == 0 && my_vmin) post_max(&S->slot[0].vmin, my_vmin, ret_a);      // (returning: it has been performed when the wait below ends)
     int bestCls = -1, unreliable = 0, used = 0, failed = 0;
     bool has_best = false;
     for (int c = 0;; ++c) {
@@ -703,6 +711,7 @@ __global__ void __launch_bounds__(kFusedBlock) k_twd_prop_fused(const float4* __
         if (wave != 0) prefetch(c + 1);
         (void)fused_meet(&S->ctr, S->flag, G, b, (unsigned int)G * (unsigned int)(c + 1), gen_base + (unsigned long long)(c + 1), c < nchunks || b == 0, &fail_s,
                          [&]() { prefetch(c + 1); });
+        keep_alive(ret_a, ret_b);
         if (c == nchunks && b != 0) return;
         if (fail_s) { failed = 1; break; }
         if (threadIdx.x < 4) {
@@ -764,16 +773,16 @@ __global__ void __launch_bounds__(kFusedBlock) k_twd_prop_fused(const float4* __
                 anyw |= red_row[i];
             }
             if (threadIdx.x == 0) {
-                if (has_c && my_vmin == g_vmin) (void)atomic_max_read(&S->slot[c].best, ~(((unsigned long long)my_row << 32) | (unsigned int)cls[my_row]));
+                if (has_c && my_vmin == g_vmin) post_max(&S->slot[c].best, ~(((unsigned long long)my_row << 32) | (unsigned int)cls[my_row]), ret_b);
             } else if (anyw) {
-                if (threadIdx.x == 1) (void)atomic_max_read(&S->slot[c].cmin, ~((unsigned long long)mn + 1ull));
-                else (void)atomic_max_read(&S->slot[c].cmax, (unsigned long long)mx + 1ull);
+                if (threadIdx.x == 1) post_max(&S->slot[c].cmin, ~((unsigned long long)mn + 1ull), ret_b);
+                else post_max(&S->slot[c].cmax, (unsigned long long)mx + 1ull, ret_b);
             }
         }
         __syncthreads();
         if (c + 1 < nchunks) {
             my_vmin = chunk(c + 1, qs + (c + 1) * reduced, my_row);
-            if (threadIdx.x == 0 && my_vmin) (void)atomic_max_read(&S->slot[c + 1].vmin, my_vmin);
+            if (threadIdx.x == 0 && my_vmin) post_max(&S->slot[c + 1].vmin, my_vmin, ret_a);
         }
     }
     if (b != 0 || threadIdx.x != 0) return;
@@ -899,6 +908,7 @@ __global__ void __launch_bounds__(kFusedBlock) k_twd_conv_fused(const float4* __
         }
     }
     // ---- what the workgroup posts before the first meeting ----
+    unsigned long long ret_a = 0, ret_b = 0, ret_c = 0, ret_d = 0;      // (post_max)
     unsigned long long k1 = ~0ull;                                      // first minimum below 100000 (:123: strict '<' from bestDist = 100000)
     double m2d = 100000.0;                                              // second stage: bestDist = 100000 (:168)
     unsigned int m2r = 0xFFFFFFFFu;
@@ -942,16 +952,18 @@ __global__ void __launch_bounds__(kFusedBlock) k_twd_conv_fused(const float4* __
         my_m = red_f[i] < my_m ? red_f[i] : my_m;
     }
     if (threadIdx.x == 0) {
-        if (my_k1 != ~0ull) (void)atomic_max_read(&S->key1, ~my_k1);
-        if (my_r2 != 0xFFFFFFFFu) (void)atomic_max_read(&S->v2min, ~my_k2);
-        if (my_m < __builtin_huge_valf()) (void)atomic_max_read(&S->slot_m[b], ~(unsigned long long)fir::f32_orderable(my_m + 0.0f));
+        if (my_k1 != ~0ull) post_max(&S->key1, ~my_k1, ret_a);
+        if (my_r2 != 0xFFFFFFFFu) post_max(&S->v2min, ~my_k2, ret_b);
+        if (my_m < __builtin_huge_valf()) post_max(&S->slot_m[b], ~(unsigned long long)fir::f32_orderable(my_m + 0.0f), ret_c);
     }
     if (with_prob)
         for (int c = threadIdx.x; c < num_classes; c += kFusedBlock)
-            if (probabs[c]) (void)atomic_max_read(&S->gprob[c], probabs[c]);
+            if (probabs[c]) post_max(&S->gprob[c], probabs[c], ret_d);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // every thread's posterior posts have returned ...
     __syncthreads();                                                   // ... before thread 0 arrives for the workgroup
     bool ok = fused_meet(&S->ctr, S->flag, G, b, (unsigned int)G, gen_base + 1ull, true, &fail_s, []() {});
+    keep_alive(ret_a, ret_b, ret_c);
+    keep_alive(ret_d);
     // ---- between the meetings: r*, C*; the last local record of another class; the second-stage row ----
     if (ok) {
         if (threadIdx.x < 2) got[threadIdx.x] = atomic_max_read(threadIdx.x == 0 ? &S->key1 : &S->v2min, (unsigned long long)opaque_zero());
@@ -1000,11 +1012,12 @@ __global__ void __launch_bounds__(kFusedBlock) k_twd_conv_fused(const float4* __
                 int have = 0;
                 float dl = 0.0f;
                 for (int w = 0; w < kWaves; ++w) if (red_i[w]) { have = 1; dl = red_g[w]; }      // the last wave that found one
-                if (have) (void)atomic_max_read(&S->slot_l[b], ~(unsigned long long)fir::f32_orderable(dl + 0.0f));
+                if (have) post_max(&S->slot_l[b], ~(unsigned long long)fir::f32_orderable(dl + 0.0f), ret_a);
             }
         }
-        if (threadIdx.x == 0 && gk2 != 0ull && my_r2 != 0xFFFFFFFFu && ~my_k2 == gk2) (void)atomic_max_read(&S->v2row, ~(unsigned long long)my_r2);
+        if (threadIdx.x == 0 && gk2 != 0ull && my_r2 != 0xFFFFFFFFu && ~my_k2 == gk2) post_max(&S->v2row, ~(unsigned long long)my_r2, ret_b);
         ok = fused_meet(&S->ctr, S->flag, G, b, 2u * (unsigned int)G, gen_base + 2ull, b == 0, &fail_s, []() {});
+        keep_alive(ret_a, ret_b);
     }
     if (b != 0) return;
     // ---- behind the second meeting: workgroup 0 decides ----
