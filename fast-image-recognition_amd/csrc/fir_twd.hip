@@ -871,8 +871,36 @@ __global__ void __launch_bounds__(kFusedBlock) k_twd_conv_fused(const float4* __
         if (t >= tiles) continue;                                       // wave-uniform
         const float4* tp = gal4 + (size_t)t * dp4 * 64 + lane;
         float a1 = 0.0f, a2 = 0.0f;
-        // (eight 16-byte pieces per request group; keeping the next group in flight as well -- a register double buffer over the row's
-        // 64 pieces -- changed nothing at one tile per wave and cost 40 % at eight: the waves of a CU overlap each other's latency)
+        if (T == 1 && (r4 & 7) == 0) {
+            // one tile per wave (with more, the tiles' request groups already overlap and the second register set only costs: 1M rows,
+            // T = 8: 232 -> 365 us) and reduced_features_count a multiple of 32 (the reference's 32 / 64 / 128): the row's 64 pieces as eight request groups in
+            // straight-line code, group g + 1 requested before group g is added up -- every wave of the chip asks for its 8 KiB at the same
+            // moment, so without the overlap a group costs a memory latency PLUS its share of the transfer (3.5 us per 12.8 MB at
+            // 100 000 rows). The first r4 / 8 groups belong to the first stage: `run` is handed to a1 at that border and starts again.
+            const int nb1 = r4 >> 3;
+            float run = 0.0f;
+            float4 ga[8], gb[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) ga[u] = tp[(size_t)u * 64];
+#pragma unroll
+            for (int bi = 0; bi < 8; ++bi) {
+                float4 (&cur)[8] = (bi & 1) ? gb : ga;
+                float4 (&nxt)[8] = (bi & 1) ? ga : gb;
+                if (bi + 1 < 8) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) nxt[u] = tp[(size_t)((bi + 1) * 8 + u) * 64];
+                }
+                a1 = bi == nb1 ? run : a1;
+                run = bi == nb1 ? 0.0f : run;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float4 l = *(const float4*)(qs + 4 * (bi * 8 + u));
+                    run = fir::accum<METRIC>(run, l.x, cur[u].x); run = fir::accum<METRIC>(run, l.y, cur[u].y);
+                    run = fir::accum<METRIC>(run, l.z, cur[u].z); run = fir::accum<METRIC>(run, l.w, cur[u].w);
+                }
+            }
+            a2 = run;
+        } else {
         for (int k0 = 0; k0 < r4; k0 += 8) {
             float4 g[8];
 #pragma unroll
@@ -898,6 +926,7 @@ __global__ void __launch_bounds__(kFusedBlock) k_twd_conv_fused(const float4* __
                     a2 = fir::accum<METRIC>(a2, l.z, g[u].z); a2 = fir::accum<METRIC>(a2, l.w, g[u].w);
                 }
             }
+        }
         }
         if (row < n) {
             valid |= 1u << i;
