@@ -1853,8 +1853,16 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
         const size_t per_query = m->precision == FIR_GEMM_F16 ? (size_t)(m->sample_rows + 31) / 32 : (size_t)m->sample_rows;
         GEMM_HIP(hipMalloc((void**)&m->sample, (size_t)kPasses * kQT * per_query * sizeof(float)));
     }
+    // A super-batch's preparation (query packing, the top-K sample pass) runs on the MAIN stream right in front of its full passes: alone on
+    // the chip it is 25 us (top-K: + 0.3 ms of sample passes); on the side stream, "under" the previous super-batch's full passes, its small
+    // kernels only got the CUs a full-pass workgroup had just left and slowed those passes down (1M x 512, 32 768 queries per call: top-1
+    // 1.253 -> 1.296 M q/s, top-5 1.018 -> 1.071 M; FIR_GEMM_SERIAL_PREP=0 is the old placement). Host-pointer calls keep the side stream:
+    // there the preparation waits for the super-batch's upload, which is what overlaps the passes.
+    const char* sp_env = std::getenv("FIR_GEMM_SERIAL_PREP");
+    const bool serial_prep = !(sp_env && std::atoi(sp_env) == 0) && !h_queries;
     auto prep = [&](int sb) -> int {
-        hipStream_t ps = m->side;
+        hipStream_t ps = serial_prep ? st : m->side;
+        if (serial_prep && sb >= 2) GEMM_HIP(hipStreamWaitEvent(st, m->rerank_done[sb & 1], 0));      // the re-rank of sb - 2 read this buffer
         const int q0 = sb * sbq;
         const int nq = std::min(sbq, qb - q0);
         if (h_queries) {
@@ -1947,7 +1955,8 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
         const int np = (nq + kQT - 1) / kQT;
         const int b = sb & 1;
         const float* dq = d_queries + (size_t)q0 * qs;
-        if (sb + 1 < nsb && (rcp = prep(sb + 1))) return rcp;
+        if (serial_prep) { if (sb >= 1 && (rcp = prep(sb))) return rcp; }
+        else if (sb + 1 < nsb && (rcp = prep(sb + 1))) return rcp;
         const bool adaptive = adaptive_for(nq);
         GEMM_HIP(hipStreamWaitEvent(st, m->prep_done[b], 0));
         // ---- the full pass(es) over the gallery: the launch fir_profile_read times and fir_gallery_last_dispatch names ----
