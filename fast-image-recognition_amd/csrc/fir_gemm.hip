@@ -660,8 +660,12 @@ __global__ void __launch_bounds__(256) k_gemm_pack_gallery_f16(const float4* __r
 // qinv = 1 / (qmul * gallery scale), which turns the MFMA result back into q.g. Queries past nq: all zero.
 // A query whose scale would leave [2^-100, 2^100], or with a non-finite value, gets qinv = NaN: every proxy is then NaN,
 // nothing is certified and the exact scan answers it.
+// counts != NULL: the query's candidate count is cleared here too (instead of a memset of its own); win != NULL: ... and the adaptive
+// pass's window and start value are set (k_gemm_adapt_init's two lines): two launches less in front of every super-batch.
 __global__ void __launch_bounds__(64) k_gemm_qprep_f16(const float* __restrict__ q, int nq, int d, int gallery_exp, float* __restrict__ qnorm,
-                                                        float* __restrict__ qmul, float* __restrict__ qinv, int qstride) {
+                                                        float* __restrict__ qmul, float* __restrict__ qinv, int qstride, int* __restrict__ counts = nullptr,
+                                                        float* __restrict__ win = nullptr, unsigned int* __restrict__ t_bits = nullptr,
+                                                        const float* __restrict__ gnorm_max_p = nullptr, float e_rel = 0.f) {
     const int qi = blockIdx.x;
     float s = 0.f, m = 0.f;
     bool bad = false;
@@ -684,9 +688,19 @@ __global__ void __launch_bounds__(64) k_gemm_qprep_f16(const float* __restrict__
         int sh = m > 0.f ? 14 - ex : 0;                    // m * 2^sh in [2^13, 2^14)
         if (sh < -100 || sh > 100 || gallery_exp < -100 || gallery_exp > 100) bad = true;
         // bad: the proxies of this query are NaN and say nothing about any row -- a NaN norm keeps the certificate from holding
-        qnorm[qi] = (bad && qi < nq) ? __builtin_nanf("") : s;
+        const float qn = (bad && qi < nq) ? __builtin_nanf("") : s;
+        qnorm[qi] = qn;
         qmul[qi] = bad ? 0.f : ldexpf(1.0f, sh);
         qinv[qi] = qi >= nq ? 0.f : bad ? __builtin_nanf("") : ldexpf(1.0f, -sh - gallery_exp);
+        if (counts) counts[qi] = 0;
+        if (win) {                                                   // (k_gemm_adapt_init)
+            if (qi >= nq) { win[qi] = 0.f; t_bits[qi] = 0u; }
+            else {
+                const float w = 2.5f * e_rel * (qn + gnorm_max_p[0]);
+                win[qi] = w + fabsf(w) * 1e-6f + 1e-30f;
+                t_bits[qi] = 0x7F800000u;
+            }
+        }
     }
 }
 
@@ -1875,8 +1889,11 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
         const float* dq = d_queries + (size_t)q0 * qs;
         if (m->precision == FIR_GEMM_F16) {
             const int pairs = (np + 1) / 2;                      // 128 queries per gallery read; a half-filled pair is zero-padded
-            hipLaunchKernelGGL(k_gemm_qprep_f16, dim3(pairs * 2 * kQT), dim3(64), 0, ps, dq, nq, d, m->gallery_exp, m->qnorm[b], m->qmul[b], m->qinv[b], qs);
-            GEMM_HIP(hipMemsetAsync(m->counts[b], 0, (size_t)pairs * 2 * kQT * sizeof(int), ps));
+            // (the candidate counts are cleared and, for the adaptive pass, its per-query state is set by the same launch)
+            const bool adaptive_prep = adaptive_for(nq);
+            hipLaunchKernelGGL(k_gemm_qprep_f16, dim3(pairs * 2 * kQT), dim3(64), 0, ps, dq, nq, d, m->gallery_exp, m->qnorm[b], m->qmul[b], m->qinv[b], qs,
+                               m->counts[b], adaptive_prep ? m->awin[b] : (float*)nullptr, adaptive_prep ? m->aT[b] : (unsigned int*)nullptr,
+                               (const float*)m->gmax, e_rel);
             if (m->mfma16)
                 hipLaunchKernelGGL(k_gemm_pack_queries_f16x, dim3((4 * m->dk16 * 64 + 255) / 256, pairs), dim3(256), 0, ps, dq, nq, d, m->dk16, m->qmul[b],
                                    m->qbf[b], qs);
@@ -1886,7 +1903,7 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
             const bool adaptive = adaptive_for(nq);
             if (adaptive) {
                 // no sample pass: the full pass finds its threshold on the way (k_gemm_proxy_f16x<3, *>)
-                hipLaunchKernelGGL(k_gemm_adapt_init, dim3((pairs * 2 * kQT + 255) / 256), dim3(256), 0, ps, m->awin[b], m->aT[b], pairs * 2 * kQT, nq, m->qnorm[b], m->gmax, e_rel);
+                // (k_gemm_qprep_f16 has set the windows and start values)
             } else if (rt_flow) {
                 // the smallest proxy of a row sample per query (register-tile kernel over rows [0, rt_sample_rows)), tau = that + one window
                 GEMM_HIP(hipMemsetD32Async((hipDeviceptr_t)m->smin[b], (int)0xFF800000u, sub_stride ? (size_t)kRtSubsets * sub_stride : (size_t)pairs * 2 * kQT, ps));
