@@ -10,9 +10,12 @@ KEY_NONE = 0xFFFFFFFFFFFFFFFF
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
+_LIB_FILE = "libfir_amd.so"       # __graft_entry__.load_package(audit=True) points its own copy of this module at libfir_amd_audit.so
+
+
 def lib_path():
     # FIR_AMD_LIB: an alternative build of the same library (kernel-variant experiments in tools/)
-    return os.environ.get("FIR_AMD_LIB") or os.path.join(_HERE, "libfir_amd.so")
+    return os.environ.get("FIR_AMD_LIB") or os.path.join(_HERE, _LIB_FILE)
 
 
 class FirError(RuntimeError):
@@ -73,6 +76,7 @@ SYMBOLS = [
     ("fir_gemm_search_topk_keys_dev", C.c_int, [_vp, _vp, C.c_int32, C.c_int32, _vp, _vp]),
     ("fir_gemm_search_few_keys_dev", C.c_int, [_vp, _vp, C.c_int32, _vp, _vp]),
     ("fir_gemm_stats", C.c_int, [_vp, _i64p, _i64p]),
+    ("fir_gemm_stats_ex", C.c_int, [_vp, _i64p]),
     ("fir_dem_pivot_table", C.c_int, [_vp, C.c_int32, C.c_int32, _vp, _vp, _vp, _i32p]),
     ("fir_dem_create", C.c_int, [_vp, C.c_int32, C.c_int32, C.POINTER(_vp)]),
     ("fir_dem_destroy", C.c_int, [_vp]),
@@ -110,6 +114,7 @@ SYMBOLS = [
     ("fir_cls_profile_enable", C.c_int, [_vp, C.c_int32]),
     ("fir_cls_profile_read", C.c_int, [_vp, _vp, C.c_int32, _i32p, C.POINTER(C.c_double), C.c_char_p, C.c_int32]),
     ("fir_gallery_mfma_stats", C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    ("fir_gallery_mfma_stats_ex", C.c_int, [_vp, C.POINTER(C.c_int64)]),
     ("fir_gallery_memory_bytes", C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("fir_gallery_set_shadow_copies", C.c_int, [_vp, C.c_int32]),
 ]
@@ -186,7 +191,8 @@ def keys_unpack(keys):
 class DispatchInfo(C.Structure):
     _fields_ = [("struct_bytes", C.c_int32), ("path", C.c_int32), ("kernel", C.c_char * 160), ("launches", C.c_int32), ("grid_x", C.c_int32),
                 ("grid_y", C.c_int32), ("block", C.c_int32), ("lds_bytes", C.c_int32), ("vgprs", C.c_int32), ("queries_per_pass", C.c_int32),
-                ("bytes_per_launch", C.c_double), ("flops_per_launch", C.c_double), ("warmup_calls_left", C.c_int32), ("reserved", C.c_int32)]
+                ("bytes_per_launch", C.c_double), ("flops_per_launch", C.c_double), ("warmup_calls_left", C.c_int32), ("reserved", C.c_int32),
+                ("knobs", C.c_char * 160)]
 
 
 SHADOW_NONE, SHADOW_FP16, SHADOW_ALL = 0, 1, 2
@@ -246,9 +252,10 @@ class Gallery:
         _check(lib().fir_gallery_set_shadow_copies(self._h, mode))
 
     def mfma_stats(self):
-        a, b = C.c_int64(), C.c_int64()
-        _check(lib().fir_gallery_mfma_stats(self._h, C.byref(a), C.byref(b)))
-        return {"passes": a.value, "fallback_queries": b.value}
+        """passes queued; queries whose first certificate did not hold (second matrix-core pass); queries the exact device scan answered"""
+        o = (C.c_int64 * 3)()
+        _check(lib().fir_gallery_mfma_stats_ex(self._h, o))
+        return {"passes": o[0], "second_pass_queries": o[1], "fallback_queries": o[2]}
 
     def memory_bytes(self):
         t, f, r, sc = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
@@ -366,7 +373,8 @@ class Gallery:
         _check(lib().fir_gallery_last_dispatch(self._h, C.byref(o)))
         return {"path": "mfma" if o.path == 1 else "scan", "kernel": o.kernel.decode(), "launches": o.launches, "grid": [o.grid_x, o.grid_y],
                 "block": o.block, "lds_bytes": o.lds_bytes, "vgprs": o.vgprs, "queries_per_pass": o.queries_per_pass,
-                "bytes_per_launch": o.bytes_per_launch, "flops_per_launch": o.flops_per_launch, "warmup_calls_left": o.warmup_calls_left}
+                "bytes_per_launch": o.bytes_per_launch, "flops_per_launch": o.flops_per_launch, "warmup_calls_left": o.warmup_calls_left,
+                "knobs": o.knobs.decode()}
 
 
 COMM_ID_BYTES = 128
@@ -541,9 +549,9 @@ class GemmSearch:
         _check(lib().fir_gemm_search_topk_keys_dev(self._h, _vp(q_ptr), qb, k, _vp(keys_ptr), _vp(stream) if stream else None))
 
     def stats(self):
-        a, b = C.c_int64(), C.c_int64()
-        _check(lib().fir_gemm_stats(self._h, C.byref(a), C.byref(b)))
-        return {"passes": a.value, "fallback_queries": b.value}
+        o = (C.c_int64 * 3)()
+        _check(lib().fir_gemm_stats_ex(self._h, o))
+        return {"passes": o[0], "second_pass_queries": o[1], "fallback_queries": o[2]}
 
 
 class Dem:

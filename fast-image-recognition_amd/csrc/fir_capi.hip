@@ -8,8 +8,11 @@
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
+#include <string>
 #include <vector>
 
 #include "../../include/fir_amd.h"
@@ -551,7 +554,7 @@ int topk_lists_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t s
     // re-ranked with the reference's arithmetic before the K smallest are taken: the same keys as the exact scan, about twice
     // as fast. Every row whose reference distance is <= the unwidened threshold is appended (approx <= exact (1 + eps)), and
     // the K-th smallest reference distance is <= that threshold (K sample rows are), so the K best are all in the list.
-    const bool no_nominate = std::getenv("FIR_NO_CHI2_NOMINATION") != nullptr;      // experiments
+    const bool no_nominate = fir_knob_("FIR_NO_CHI2_NOMINATION") != nullptr;      // experiments
     const bool nominate = g->metric == kChi2 && g->gallery_plain && !no_nominate && (size_t)g->d * sizeof(float) <= 48 * 1024;
     // KL over a plain-range gallery, the entropy form: KL = ln2 (Lq + Lg - E), Lq = sum(l log2 l + l), Lg the same over the row (both
     // added up in double once per query / per row), E = sum_k s_k log2 s_k with s_k = l_k + r_k the only sum the scan runs: a packed
@@ -572,12 +575,12 @@ int topk_lists_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t s
     // terms adds nf u / 2, the two plain sums nf u each, the reference's own chain (nf + 3) u of chi2 <= sum(l) + sum(r):
     //   |harmonic form - reference| <= B = (3 nf + 19) 2^-24 (sum(l) + max_rows sum(r)) / nf.
     // The threshold is widened by 1.5 B (k_query_sums_widen): every row whose reference distance is within the unwidened one is appended.
-    const char* form_env = std::getenv("FIR_CHI2_NOMINATION");                                   // experiments / tests: 1 = kChi2Approx
+    const char* form_env = fir_knob_("FIR_CHI2_NOMINATION");                                   // experiments / tests: 1 = kChi2Approx
     const int chi2_form = form_env ? std::atoi(form_env) : 2;
     const bool harm = nominate && chi2_form == 2;
     const float tau_scale = nominate && !harm ? 1.0f + 1.5f * (2.0f * (float)(end - start) + 16.0f) * 5.9604645e-8f : 1.0f;
     // the two cheap nomination forms take two tiles of 8 queries per gallery read (k_nominate): whole pairs of tiles
-    const int nh = (harm || klent) && !std::getenv("FIR_NOMINATE_ONE_TILE") ? 2 : 1;
+    const int nh = (harm || klent) && !fir_knob_("FIR_NOMINATE_ONE_TILE") ? 2 : 1;
     const int qpad = (qb + 8 * nh - 1) / (8 * nh) * (8 * nh);
     void *p_skeys = nullptr, *p_small = nullptr, *p_lists = nullptr;
     int rc;
@@ -1074,14 +1077,23 @@ int fir_gallery_set_large_batch_mfma(fir_gallery* g, int32_t min_queries) {
     return FIR_OK;
 }
 
-int fir_gallery_mfma_stats(fir_gallery* g, int64_t* passes, int64_t* fallback_queries) {
-    if (!g) return fail(FIR_ERR_ARG, "gallery is NULL");
-    int64_t p = 0, f = 0, a = 0, b = 0;
-    if (g->gemm && fir_gemm_stats(g->gemm, &a, &b) == FIR_OK) { p += a; f += b; }
+int fir_gallery_mfma_stats_ex(fir_gallery* g, int64_t out[3]) {
+    if (!g || !out) return fail(FIR_ERR_ARG, "NULL argument");
+    int64_t o[3];
+    out[0] = out[1] = out[2] = 0;
+    if (g->gemm && fir_gemm_stats_ex(g->gemm, o) == FIR_OK) { out[0] += o[0]; out[1] += o[1]; out[2] += o[2]; }
     for (auto& ps : g->gemm_prefix)
-        if (ps.m && fir_gemm_stats(ps.m, &a, &b) == FIR_OK) { p += a; f += b; }
-    if (passes) *passes = p;
-    if (fallback_queries) *fallback_queries = f;
+        if (ps.m && fir_gemm_stats_ex(ps.m, o) == FIR_OK) { out[0] += o[0]; out[1] += o[1]; out[2] += o[2]; }
+    // (states dropped since -- fir_gallery_set_large_batch_mfma(g, 0) frees them -- took their counters along)
+    return FIR_OK;
+}
+
+int fir_gallery_mfma_stats(fir_gallery* g, int64_t* passes, int64_t* fallback_queries) {
+    int64_t o[3];
+    const int rc = fir_gallery_mfma_stats_ex(g, o);
+    if (rc) return rc;
+    if (passes) *passes = o[0];
+    if (fallback_queries) *fallback_queries = o[2];
     return FIR_OK;
 }
 
@@ -1093,7 +1105,8 @@ int fir_gallery_memory_bytes(fir_gallery* g, int64_t* tiled, int64_t* fp16_fragm
         if (ps.m) { fir_gemm_memory_bytes_(ps.m, &a, &b, &c); fr += a; rm += b; sc += c; }
     sc += (int64_t)(g->qt_cap * sizeof(float) + g->dq_cap * sizeof(float) + g->dkeys_cap * sizeof(uint64_t) + g->part_cap * sizeof(uint64_t) +
                     g->dout_cap * sizeof(float) + g->didx_cap * sizeof(int32_t));
-    for (size_t i = 0; i < 16; ++i) sc += (int64_t)g->scratch_cap[i];
+    for (size_t i = 0; i < 24; ++i) sc += (int64_t)g->scratch_cap[i];
+    sc += (int64_t)(g->rowsum_cap * sizeof(float));
     if (tiled) *tiled = (int64_t)g->tiles * fir::kTileRows * (int64_t)((g->d + 3) / 4) * 16 + (g->cls ? (int64_t)g->n * 4 : 0);
     if (fp16_fragments) *fp16_fragments = fr;
     if (rowmajor_shadow) *rowmajor_shadow = rm;
@@ -1206,15 +1219,25 @@ int try_mfma(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start, 
     fir_gemm* m = nullptr;
     const int rc = g->n < kAutoMfmaRows ? ensure_gemm(g, end, &m, &g->small_hits, 3) : ensure_gemm(g, end, &m);
     if (rc) return rc;
-    if (h_queries) return fir_gemm_search_staged_(m, h_queries, (float*)d_queries, qb, 1, d_keys, st);
-    return fir_gemm_search_top1_keys_dev(m, d_queries, qb, d_keys, st);
+    const int rcs = h_queries ? fir_gemm_search_staged_(m, h_queries, (float*)d_queries, qb, 1, d_keys, st)
+                              : fir_gemm_search_top1_keys_dev(m, d_queries, qb, d_keys, st);
+    if (rcs == FIR_ERR_NOMEM && g->large_batch_min < 0) {       // no room for this call's candidate lists: the exact scan answers (automatic mode)
+        (void)hipGetLastError();
+        return 1;
+    }
+    return rcs;
 }
 int try_mfma_topk(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start, int32_t end, int32_t k, uint64_t* d_keys, hipStream_t st) {
     if (k < 2 || !wants_mfma(g, qb, start, end)) return 1;       // K = 1 callers use the top-1 entry points
     fir_gemm* m = nullptr;
     const int rc = g->n < kAutoMfmaRows ? ensure_gemm(g, end, &m, &g->small_hits, 3) : ensure_gemm(g, end, &m);
     if (rc) return rc;
-    return fir_gemm_search_topk_keys_dev(m, d_queries, qb, k, d_keys, st);
+    const int rcs = fir_gemm_search_topk_keys_dev(m, d_queries, qb, k, d_keys, st);
+    if (rcs == FIR_ERR_NOMEM && g->large_batch_min < 0) {
+        (void)hipGetLastError();
+        return 1;
+    }
+    return rcs;
 }
 }  // namespace
 
@@ -1289,12 +1312,36 @@ void fir_gallery_note_dispatch_(fir_gallery* g, const void* fn, const char* name
     note_dispatch(g, fn, name, first ? 0 : 1, gx, gy, block, dyn_lds, qpp, bytes, flops, 1);
 }
 
+namespace {
+std::mutex g_knob_mu;
+std::vector<std::string> g_knobs;        // names of the set FIR_* variables the library has looked at, in order of first use
+void knobs_list_(char* out, size_t cap) {
+    std::lock_guard<std::mutex> lk(g_knob_mu);
+    size_t used = 0;
+    out[0] = 0;
+    for (const std::string& k : g_knobs) {
+        if (used + k.size() + 6 >= cap) { std::snprintf(out + used, cap - used, "..."); return; }
+        used += (size_t)std::snprintf(out + used, cap - used, "%s%s", used ? " " : "", k.c_str());
+    }
+}
+}  // namespace
+
+extern "C" const char* fir_knob_(const char* name) {
+    const char* v = std::getenv(name);
+    if (v) {
+        std::lock_guard<std::mutex> lk(g_knob_mu);
+        if (std::find(g_knobs.begin(), g_knobs.end(), name) == g_knobs.end()) g_knobs.emplace_back(name);
+    }
+    return v;
+}
+
 int fir_gallery_last_dispatch(fir_gallery* g, fir_dispatch_info* out) {
     if (!g || !out) return fail(FIR_ERR_ARG, "NULL argument");
     if (out->struct_bytes < 8 || out->struct_bytes > (int32_t)sizeof(fir_dispatch_info)) return fail(FIR_ERR_ARG, "fir_dispatch_info.struct_bytes = %d", out->struct_bytes);
     const int32_t nb = out->struct_bytes;
     fir_dispatch_info tmp = g->last;
     tmp.warmup_calls_left = g->warm_left;
+    knobs_list_(tmp.knobs, sizeof tmp.knobs);
     tmp.struct_bytes = nb;
     std::memcpy(out, &tmp, (size_t)nb);
     return FIR_OK;
@@ -1335,7 +1382,7 @@ int wait_ticket(fir_gallery* g, volatile uint64_t* flag, uint64_t ticket) {
 // re-arms the device key, and the host spins on the ticket (falling back to hipStreamSynchronize after 2 ms).
 // 3 030 x 1536: 34 instead of 40 us per call (profiles/r01_sweep_notes.md). Returns 1 when the shape does not qualify.
 int top1_one_query(fir_gallery* g, const float* pinned_query, int32_t start, int32_t end, uint64_t* pinned_key) {
-    static const bool off = std::getenv("FIR_NO_ONE_QUERY") != nullptr;      // experiments
+    static const bool off = fir_knob_("FIR_NO_ONE_QUERY") != nullptr;      // experiments
     // up to 256 tiles (16 384 rows): every workgroup of this form ends on a device-wide fence before it is counted, and beyond
     // ~90 workgroups those fences cost more than the two extra launches of the general path (12 000 x 512: 25.5 against
     // 28.1 us; 24 000: 32.8 / 32.2; 50 000: 44.4 / 35.4)

@@ -782,7 +782,7 @@ int cls_scan(fir_cls* c, const double* queries, int32_t qb) {
         if ((rc = cls_grow(c->qn, c->qn_cap, (size_t)ntile * kk * 8))) return rc;
         hipLaunchKernelGGL(k_cls_prep_query_tiles, dim3((unsigned)(((size_t)ntile * kk * 8 + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, dq, qb, c->d,
                            c->dp2, c->avg, c->qn);
-        const bool one_tile = std::getenv("FIR_CLS_ONE_TILE") != nullptr;
+        const bool one_tile = fir_knob_("FIR_CLS_ONE_TILE") != nullptr;
         const bool two = ntile >= 2 && 2 * lds_tile <= 150 * 1024 && !one_tile;
         if (two) {
             static bool attr_set[64] = {};                     // (per device: the attribute belongs to the device's copy of the code object)

@@ -1059,6 +1059,8 @@ __global__ void __launch_bounds__(256) k_gemm_tau(const float* __restrict__ samp
     }
 }
 
+#include "fir_gemm_fb.h"
+
 // Per query: every appended entry that could still be the nearest row is re-ranked with the reference's arithmetic, then
 // the certificate. One wave per query. out_key[q] = exact packed key; ok[q] = 1 when the certificate holds.
 // Each proxy is within E d of its row's true |g|^2 - 2 q.g, so a row whose proxy exceeds the smallest proxy p1 by more than
@@ -1070,8 +1072,16 @@ __global__ void __launch_bounds__(64) k_gemm_rerank(const unsigned long long* __
                                                      const float* __restrict__ tau, const float4* __restrict__ gal4,
                                                      const float* __restrict__ queries, const float* __restrict__ qnorm,
                                                      const float* __restrict__ gnorm_max_p, int64_t n, int d, int dp4, int64_t row_offset, float e_rel,
-                                                     int ngroup, unsigned long long* __restrict__ out_key, int* __restrict__ ok, int qstride, const float4* __restrict__ rowmajor) {
+                                                     int ngroup, unsigned long long* __restrict__ out_key, int* __restrict__ ok, int qstride, const float4* __restrict__ rowmajor,
+                                                     const RerankFb fb) {
+    // q: the query's scratch slot (lists, counts, tau, qnorm); qo: its place in queries / out_key / ok -- the same for a super-batch's
+    // own re-rank, the query's index in the call for a second-chance round (fir_gemm_fb.h)
     const int q = blockIdx.x, lane = threadIdx.x;
+    int qo = q;
+    if (fb.qmap) {
+        if (q >= fb.state[0] - fb.live_off) return;               // (uniform per workgroup)
+        qo = fb.qmap[q];
+    }
     const int cnt = counts[q];
     const int have = cnt < kListCap ? cnt : kListCap;
     const unsigned long long* L = lists + (size_t)q * kListCap;
@@ -1091,7 +1101,7 @@ __global__ void __launch_bounds__(64) k_gemm_rerank(const unsigned long long* __
     const float p1 = kmin != kKeyNone ? fir::f32_from_orderable((uint32_t)(kmin >> 32)) : __builtin_huge_valf();
     float win = p1 + 2.0f * E * (float)d;
     win += fabsf(win) * 1e-6f;
-    const float* qv = queries + (size_t)q * qstride;
+    const float* qv = queries + (size_t)qo * qstride;
     const int d4 = (d + 3) >> 2;                                  // float4 chunks of the compared features (a prefix of the row when d < its length)
     unsigned long long best = kKeyNone;
     float p_out = __builtin_huge_valf();            // smallest proxy NOT re-ranked
@@ -1156,7 +1166,7 @@ __global__ void __launch_bounds__(64) k_gemm_rerank(const unsigned long long* __
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) p_out = fminf(p_out, __shfl_xor(p_out, off, 64));
     if (lane == 0) {
-        out_key[q] = best;
+        out_key[qo] = best;
         // Certificate. Every row NOT re-ranked has a proxy >= p_excl: the smallest list entry outside the window, or tau
         // for rows that were never appended. Its reference distance is then >= (|q|^2 + p_excl)/d - E.
         bool certified = false;
@@ -1168,7 +1178,17 @@ __global__ void __launch_bounds__(64) k_gemm_rerank(const unsigned long long* __
             certified = lower > bd;                 // false for NaN
             if (n <= reranked) certified = true;    // every row was re-ranked
         }
-        ok[q] = certified ? 1 : 0;
+        ok[qo] = certified ? 1 : 0;
+        if (!certified && fb.list && !fb.qmap) {
+            // a second pass may append below min(this pass's bound, smallest stored proxy + one window): at or above the smallest proxy of
+            // ALL rows + the window (a stored proxy is some row's), so that list will hold every possible winner. NaN bounds stay NaN
+            // (nothing is appended, nothing certified: the exact scan answers).
+            const float w = 2.5f * e_rel * (qn + gmax);
+            const float c = p1 + (w + fabsf(w) * 1e-6f + 1e-30f);
+            const float t = tau[q];
+            fb.tau2[fb.q_base + q] = c < t ? c : t;
+            fb.list[atomicAdd(&fb.state[0], 1)] = fb.q_base + q;
+        }
     }
 }
 
@@ -1265,8 +1285,13 @@ __global__ void __launch_bounds__(64) k_gemm_rerank_topk(const unsigned long lon
                                                           const float* __restrict__ queries, const float* __restrict__ qnorm,
                                                           const float* __restrict__ gnorm_max_p, int64_t n, int d, int dp4, int64_t row_offset,
                                                           float e_rel, int ngroup, int k, unsigned long long* __restrict__ out_key,
-                                                          int* __restrict__ ok, int qstride, const float4* __restrict__ rowmajor) {
-    const int q = blockIdx.x, lane = threadIdx.x;
+                                                          int* __restrict__ ok, int qstride, const float4* __restrict__ rowmajor, const RerankFb fb) {
+    const int q = blockIdx.x, lane = threadIdx.x;                 // (q, qo: as k_gemm_rerank)
+    int qo = q;
+    if (fb.qmap) {
+        if (q >= fb.state[0] - fb.live_off) return;
+        qo = fb.qmap[q];
+    }
     const int cnt = counts[q];
     const int have = cnt < kListCap ? cnt : kListCap;
     const unsigned long long* L = lists + (size_t)q * kListCap;
@@ -1290,7 +1315,7 @@ __global__ void __launch_bounds__(64) k_gemm_rerank_topk(const unsigned long lon
     const float pk = found == k ? fir::f32_from_orderable((uint32_t)(kth >> 32)) : __builtin_huge_valf();   // a short list is re-ranked whole
     float win = pk + 2.0f * E * (float)d;
     win += fabsf(win) * 1e-6f;
-    const float* qv = queries + (size_t)q * qstride;
+    const float* qv = queries + (size_t)qo * qstride;
     const int d4 = (d + 3) >> 2;                                  // float4 chunks of the compared features (a prefix of the row when d < its length)
     unsigned long long best[kTopKMax];
 #pragma unroll
@@ -1362,7 +1387,7 @@ __global__ void __launch_bounds__(64) k_gemm_rerank_topk(const unsigned long lon
     unsigned long long kth_exact = kKeyNone;
     for (int r = 0; r < k; ++r) {
         const unsigned long long m = fir::wave_min_u64(best[0]);
-        if (lane == 0) out_key[(size_t)q * k + r] = m;
+        if (lane == 0) out_key[(size_t)qo * k + r] = m;
         kth_exact = m;
         if (m != kKeyNone && best[0] == m) {                            // exactly one lane holds it
 #pragma unroll
@@ -1381,7 +1406,15 @@ __global__ void __launch_bounds__(64) k_gemm_rerank_topk(const unsigned long lon
             certified = lower > bd;                 // false for NaN
             if (n <= reranked) certified = true;    // every row was re-ranked
         }
-        ok[q] = certified ? 1 : 0;
+        ok[qo] = certified ? 1 : 0;
+        if (!certified && fb.list && !fb.qmap) {
+            // (as k_gemm_rerank, hung on the K-th smallest stored proxy: the K-th smallest proxy of ALL rows is at or below it)
+            const float w = 2.5f * e_rel * (qn + gmax);
+            const float c = pk + (w + fabsf(w) * 1e-6f + 1e-30f);
+            const float t = tau[q];
+            fb.tau2[fb.q_base + q] = c < t ? c : t;
+            fb.list[atomicAdd(&fb.state[0], 1)] = fb.q_base + q;
+        }
     }
 }
 
@@ -1483,9 +1516,18 @@ struct fir_gemm {
     hipEvent_t copy_done[2] = {nullptr, nullptr};
     int* ok = nullptr; size_t ok_cap = 0;  // certificate flags of one call
     int sample_rows = 0;
-    float* fbq = nullptr;                 // fallback queries (device)
-    unsigned long long* fbkeys = nullptr;
-    int64_t passes = 0, fallbacks = 0;
+    // uncertified queries, handled on the device in stream order (fir_gemm_fb.h)
+    int* fb_state = nullptr;              // int[8]: count, count2, -, -, running totals (2 x 64 bit)
+    int* fb_list = nullptr;               // [ok_cap] queries the first certificate did not hold for
+    int* fb_list2 = nullptr;              // [ok_cap] ... still uncertified after the second-chance rounds
+    float* fb_tau2 = nullptr;             // [ok_cap] the bound a second pass may append below
+    float* sc_qnorm = nullptr; float* sc_qmul = nullptr; float* sc_qinv = nullptr; float* sc_tau = nullptr;   // one pair's scratch of a second-chance round
+    int* sc_counts = nullptr;
+    unsigned long long* sc_lists = nullptr;
+    uint4* sc_qbf = nullptr;
+    size_t fb_lds = 0;                    // dynamic LDS of k_gemm_exact_fb
+    int fb_grid = 0;
+    int64_t passes = 0;
     int rerank_group = kRerankGroup;      // candidate rows the re-rank stages in LDS at a time
     int streamed = -1;                    // fp16: query slabs through the LDS double buffer (-1: when the tile does not fit, d > 512)
     bool wide = true;                     // bf16: pairs of passes through k_gemm_proxy_bf16_wide (FIR_GEMM_WIDE=0 turns it off)
@@ -1552,7 +1594,8 @@ void fir_gemm_memory_bytes_(const fir_gemm* m, int64_t* fragments, int64_t* rowm
     sc += 2 * (m->precision == FIR_GEMM_F32 ? (int64_t)kPasses * (kQT / 32) * m->dq8 * 1024
                                             : (int64_t)kPasses * (kQT / 32) * m->dk16 * (m->precision == FIR_GEMM_BF16_SPLIT ? 2048 : 1024));   // query fragments
     sc += 2 * (int64_t)kPasses * kQT * 4 * 4 + 2 * (int64_t)kRtSubsets * kPasses * kQT * 4;      // per-query scalars, subset minima
-    sc += (int64_t)m->ok_cap * 4 + (int64_t)kQT * m->v.d * 4 + (int64_t)kQT * kTopKMax * 8;
+    sc += (int64_t)m->ok_cap * 16 + 32;                                                           // certificate flags, the two lists of uncertified queries, their bounds
+    if (m->sc_lists) sc += (int64_t)kScQueries * kListCap * 8 + (int64_t)4 * m->dk16 * 1024 + (int64_t)kScQueries * 20;   // one pair's second-chance scratch
     if (m->proxies) sc += (int64_t)m->proxies_nq * np * 4;
     if (fragments) *fragments = fr;
     if (rowmajor) *rowmajor = rm;
@@ -1579,7 +1622,7 @@ int fir_gemm_create_range_ex_(fir_gallery* g, int32_t precision, int32_t end_pos
         delete m;
         return gemm_fail(FIR_ERR_ARG, "feature prefix [0,%d) of %d: multiples of 16 inside the row, fp16 form only", end_pos, dd);
     }
-    if (const char* w = std::getenv("FIR_GEMM_WIDE")) m->wide = std::atoi(w) != 0;   // experiments: 0 = one pass per gallery read
+    if (const char* w = fir_knob_("FIR_GEMM_WIDE")) m->wide = std::atoi(w) != 0;   // experiments: 0 = one pass per gallery read
     m->dq8 = (m->feat + 31) / 32 * 4;     // feature groups of 8, padded to a multiple of 4 groups (zeros)
     m->dk16 = (m->feat + 127) / 128 * 8;  // k-blocks of 16, padded to a multiple of 8 (the paired-pass kernel's double-buffer unit)
     if (precision == FIR_GEMM_F16) m->dk16 = (m->feat + 16 * kRing - 1) / (16 * kRing) * kRing;   // ... to whole double-buffer units
@@ -1612,10 +1655,29 @@ int fir_gemm_create_range_ex_(fir_gallery* g, int32_t precision, int32_t end_pos
     for (int b = 0; b < 2 && e == hipSuccess; ++b) e = hipEventCreateWithFlags(&m->copy_done[b], hipEventDisableTiming);
     m->sample_rows = (int)std::min<int64_t>(np, std::max<int64_t>(kMinSampleRows, np / 64));
     m->rt_sample_rows = (int)std::min<int64_t>(np, std::max<int64_t>(kMinSampleRows, np / 32));    // n/16 .. n/48 measured: 1.022 / 1.038 / 1.028 M queries/s at 1M x 512
-    if (const char* w = std::getenv("FIR_GEMM_SAMPLE_DIV"))      // experiments
+    if (const char* w = fir_knob_("FIR_GEMM_SAMPLE_DIV"))      // experiments
         m->rt_sample_rows = (int)std::min<int64_t>(np, std::max<int64_t>(kMinSampleRows, np / std::max(1, std::atoi(w))));
-    if (e == hipSuccess) e = hipMalloc((void**)&m->fbq, (size_t)kQT * m->v.d * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc((void**)&m->fbkeys, (size_t)kQT * kTopKMax * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void**)&m->fb_state, 8 * sizeof(int));
+    if (e == hipSuccess) e = hipMemset(m->fb_state, 0, 8 * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void**)&m->sc_qnorm, kScQueries * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&m->sc_qmul, kScQueries * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&m->sc_qinv, kScQueries * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&m->sc_tau, kScQueries * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&m->sc_counts, kScQueries * sizeof(int));
+    if (e == hipSuccess && precision == FIR_GEMM_F16) e = hipMalloc((void**)&m->sc_lists, (size_t)kScQueries * kListCap * sizeof(unsigned long long));
+    if (e == hipSuccess && precision == FIR_GEMM_F16) e = hipMalloc((void**)&m->sc_qbf, (size_t)4 * m->dk16 * 64 * sizeof(uint4));
+    {   // the exact device scan of the uncertified rest keeps eight queries in LDS
+        m->fb_lds = (size_t)m->dp4 * 4 * 8 * sizeof(float);
+        if (m->fb_lds > kRerankLdsMax) {
+            const int dd = m->v.d;
+            fir_gemm_destroy(m);
+            return gemm_fail(FIR_ERR_ARG, "rows of %d features are too long for the matrix-core path's exact fallback", dd);
+        }
+        if (e == hipSuccess && m->fb_lds > 48 * 1024)
+            e = hipFuncSetAttribute((const void*)k_gemm_exact_fb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRerankLdsMax);
+        const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (size_t)(160 * 1024) / std::max<size_t>(m->fb_lds, 1)));
+        m->fb_grid = std::max(1, m->v.cus) * per_cu;
+    }
     const int lds_bytes = precision == FIR_GEMM_F32 ? (kQT / 32) * std::min(m->dq8, kSlab8) * 64 * (int)sizeof(float4)
                                                     : (kQT / 32) * std::min(m->dk16, kSlab16) * 128 * (int)sizeof(uint4);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
@@ -1626,7 +1688,7 @@ int fir_gemm_create_range_ex_(fir_gallery* g, int32_t precision, int32_t end_pos
     {   // the re-rank keeps the query and up to kRerankGroup candidate rows in LDS
         const size_t row_bytes = (size_t)(m->dp4 + 1) * sizeof(float4);
         size_t want_group = kRerankGroup;
-        if (const char* w = std::getenv("FIR_GEMM_RERANK_GROUP")) want_group = (size_t)std::max(1, std::min(64, std::atoi(w)));      // experiments
+        if (const char* w = fir_knob_("FIR_GEMM_RERANK_GROUP")) want_group = (size_t)std::max(1, std::min(64, std::atoi(w)));      // experiments
         m->rerank_group = (int)std::min<size_t>(want_group, kRerankLdsMax / row_bytes > 1 ? kRerankLdsMax / row_bytes - 1 : 0);
         if (m->rerank_group < 1) { delete m; return gemm_fail(FIR_ERR_ARG, "rows of %d features are too long for the matrix-core path's re-rank", m->v.d); }
         if (e == hipSuccess && (size_t)(m->rerank_group + 1) * row_bytes > 48 * 1024)
@@ -1647,19 +1709,21 @@ int fir_gemm_create_range_ex_(fir_gallery* g, int32_t precision, int32_t end_pos
     FIR_X_ATTR(3, 0, 0) FIR_X_ATTR(3, 0, 1) FIR_X_ATTR(3, 1, 0) FIR_X_ATTR(3, 1, 1)
 #undef FIR_X_ATTR
     m->mfma16 = precision == FIR_GEMM_F16;
-    if (const char* w = std::getenv("FIR_GEMM_MFMA16")) m->mfma16 = std::atoi(w) != 0 && precision == FIR_GEMM_F16;
-    if (const char* w = std::getenv("FIR_GEMM_STAGGER")) m->stagger = std::atoi(w);     // 1 = half a unit, 2 = half a row block at 512 features
-    if (const char* w = std::getenv("FIR_GEMM_PRIO")) m->prio = std::atoi(w) != 0;
-    if (const char* w = std::getenv("FIR_GEMM_NO_BLOCK_BOUND")) m->no_block_bound = std::atoi(w) != 0;
-    if (const char* w = std::getenv("FIR_GEMM_DBG_SKIP")) m->dbg_skip = std::atoi(w) & 31;     // timing experiments only: the answers are wrong
-    if (const char* w = std::getenv("FIR_GEMM_EREL_SCALE")) m->erel_scale = (float)std::atof(w);
-    if (const char* w = std::getenv("FIR_GEMM_ADAPTIVE")) m->adaptive = std::atoi(w);
-    if (const char* w = std::getenv("FIR_GEMM_SHARE_STREAMED")) m->share_streamed = std::max(1, std::min(16, std::atoi(w)));
-    if (const char* w = std::getenv("FIR_GEMM_SHARE")) m->share_max = std::max(0, std::min(16, std::atoi(w)));
+    if (const char* w = fir_knob_("FIR_GEMM_MFMA16")) m->mfma16 = std::atoi(w) != 0 && precision == FIR_GEMM_F16;
+    if (const char* w = fir_knob_("FIR_GEMM_STAGGER")) m->stagger = std::atoi(w);     // 1 = half a unit, 2 = half a row block at 512 features
+    if (const char* w = fir_knob_("FIR_GEMM_PRIO")) m->prio = std::atoi(w) != 0;
+    if (const char* w = fir_knob_("FIR_GEMM_NO_BLOCK_BOUND")) m->no_block_bound = std::atoi(w) != 0;
+#ifdef FIR_AUDIT      // knobs that change answers: the audit build only (libfir_amd_audit.so; fir_internal.h)
+    if (const char* w = fir_knob_("FIR_GEMM_DBG_SKIP")) m->dbg_skip = std::atoi(w) & 31;     // timing experiments only: the answers are wrong
+    if (const char* w = fir_knob_("FIR_GEMM_EREL_SCALE")) m->erel_scale = (float)std::atof(w);
+#endif
+    if (const char* w = fir_knob_("FIR_GEMM_ADAPTIVE")) m->adaptive = std::atoi(w);
+    if (const char* w = fir_knob_("FIR_GEMM_SHARE_STREAMED")) m->share_streamed = std::max(1, std::min(16, std::atoi(w)));
+    if (const char* w = fir_knob_("FIR_GEMM_SHARE")) m->share_max = std::max(0, std::min(16, std::atoi(w)));
     // the 16-row kernels always run the smallest-proxy sample flow with its XCD-shared launches: one workgroup per CU, CUs in eights
     if (m->mfma16 && !(m->share_max > 0 && (m->v.cus & 7) == 0 && m->v.cus >= 8)) m->mfma16 = 0;
-    if (const char* w = std::getenv("FIR_GEMM_REGTILE")) m->regtile = std::atoi(w);
-    if (const char* w = std::getenv("FIR_GEMM_STREAMED")) m->streamed = std::atoi(w);   // experiments: 0 / 1 force the form, -1 = by row length
+    if (const char* w = fir_knob_("FIR_GEMM_REGTILE")) m->regtile = std::atoi(w);
+    if (const char* w = fir_knob_("FIR_GEMM_STREAMED")) m->streamed = std::atoi(w);   // experiments: 0 / 1 force the form, -1 = by row length
     if (e == hipSuccess && m->v.n > 0) {
         // row norms come from the f32 packer (run on a one-group scratch when only the bf16 fragments are kept)
         if (precision == FIR_GEMM_BF16_SPLIT) {
@@ -1701,7 +1765,7 @@ int fir_gemm_create_range_ex_(fir_gallery* g, int32_t precision, int32_t end_pos
             const size_t want = (size_t)m->v.n * d4 * sizeof(float4);
             size_t free_b = 0, total_b = 0;
             int mode = rowmajor_mode;
-            if (const char* w = std::getenv("FIR_GEMM_ROWMAJOR")) { if (mode < 0) mode = std::atoi(w); }
+            if (const char* w = fir_knob_("FIR_GEMM_ROWMAJOR")) { if (mode < 0) mode = std::atoi(w); }
             const bool room = hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b >= 4 * want;
             if (mode != 0 && (room || mode > 0) && hipMalloc((void**)&m->rowmajor, want) == hipSuccess) {
                 const int64_t tiles = (m->v.n + 63) / 64;
@@ -1740,23 +1804,92 @@ int fir_gemm_destroy(fir_gemm* m) {
     }
     if (m->queries_ready) (void)hipEventDestroy(m->queries_ready);
     (void)hipFree(m->gm); (void)hipFree(m->gb); (void)hipFree(m->gh); (void)hipFree(m->rowmajor); (void)hipFree(m->proxies); (void)hipFree(m->gnorm); (void)hipFree(m->gmax); (void)hipFree(m->sample); (void)hipFree(m->ok);
-    (void)hipFree(m->fbq); (void)hipFree(m->fbkeys);
+    (void)hipFree(m->fb_state); (void)hipFree(m->fb_list); (void)hipFree(m->fb_list2); (void)hipFree(m->fb_tau2);
+    (void)hipFree(m->sc_qnorm); (void)hipFree(m->sc_qmul); (void)hipFree(m->sc_qinv); (void)hipFree(m->sc_tau); (void)hipFree(m->sc_counts);
+    (void)hipFree(m->sc_lists); (void)hipFree(m->sc_qbf);
         if (m->copy) { (void)hipStreamSynchronize(m->copy); (void)hipStreamDestroy(m->copy); }
     for (int b = 0; b < 2; ++b) if (m->copy_done[b]) (void)hipEventDestroy(m->copy_done[b]);
     delete m;
     return FIR_OK;
 }
 
-int fir_gemm_stats(const fir_gemm* m, int64_t* passes, int64_t* fallback_queries) {
-    if (!m) return gemm_fail(FIR_ERR_ARG, "NULL argument");
-    if (passes) *passes = m->passes;
-    if (fallback_queries) *fallback_queries = m->fallbacks;
+// out[0] = 64-query passes queued so far, out[1] = queries whose first certificate did not hold (they took a second matrix-core
+// pass or, beyond its rounds, went straight to the exact device scan), out[2] = queries the exact device scan answered. The two
+// counters live on the device (fir_gemm_fb.h): this call waits for the device's work and reads them.
+int fir_gemm_stats_ex(const fir_gemm* m, int64_t out[3]) {
+    if (!m || !out) return gemm_fail(FIR_ERR_ARG, "NULL argument");
+    GEMM_HIP(hipSetDevice(m->v.device));
+    GEMM_HIP(hipDeviceSynchronize());
+    unsigned long long tot[2] = {0, 0};
+    GEMM_HIP(hipMemcpy(tot, m->fb_state + 4, sizeof tot, hipMemcpyDeviceToHost));
+    out[0] = m->passes;
+    out[1] = (int64_t)tot[0];
+    out[2] = (int64_t)tot[1];
     return FIR_OK;
 }
 
-// d_queries / d_keys: device pointers. All passes are queued first; the certificates of the whole batch are read
-// back with ONE stream synchronisation, then the uncertified queries (if any) go through the exact scan.
+int fir_gemm_stats(const fir_gemm* m, int64_t* passes, int64_t* fallback_queries) {
+    int64_t o[3];
+    const int rc = fir_gemm_stats_ex(m, o);
+    if (rc) return rc;
+    if (passes) *passes = o[0];
+    if (fallback_queries) *fallback_queries = o[2];
+    return FIR_OK;
+}
+
 }  // extern "C"
+
+// Everything a call still owes its uncertified queries, queued on `st` behind the last re-rank (fir_gemm_fb.h): second-chance rounds
+// (sc_rounds > 0: the 16-row fp16 flow only), the collection of what is left, the exact device scan (K launches for the K nearest).
+static int gemm_finish_(fir_gemm* m, const float* d_queries, int k, uint64_t* d_keys, hipStream_t st, float e_rel, int sc_rounds) {
+    const int d = m->feat, qs = m->v.d;
+    const int64_t n = m->v.n;
+    const bool streamed = m->dk16 > kSlabH || m->streamed > 0;
+    const size_t rr_lds = (size_t)(m->rerank_group + 1) * (m->dp4 + 1) * sizeof(float4);
+    for (int r = 0; r < sc_rounds; ++r) {
+        const int off = r * kScQueries;
+        hipLaunchKernelGGL(k_gemm_sc_prep, dim3(kScQueries), dim3(64), 0, st, d_queries, d, qs, m->gallery_exp, (const int*)m->fb_state, (const int*)m->fb_list, off,
+                           (const float*)m->fb_tau2, m->sc_qnorm, m->sc_qmul, m->sc_qinv, m->sc_tau, m->sc_counts);
+        hipLaunchKernelGGL(k_gemm_pack_queries_f16x, dim3((4 * m->dk16 * 64 + 255) / 256, 1), dim3(256), 0, st, d_queries, kScQueries, d, m->dk16, (const float*)m->sc_qmul,
+                           m->sc_qbf, qs, (const int*)m->fb_list + off, (const int*)m->fb_state, off);
+        // one pair over all CUs (share = 1: 256 row ranges), the gallery stream read once (nt)
+        hipLaunchKernelGGL(pick_x(1, streamed, (m->dk16 / kRing) & 1), dim3(m->v.cus, 1), dim3(kGemmBlock), kHalfLds, st, m->gh, m->gnorm, m->sc_qbf, (const float*)m->sc_qinv, n,
+                           (int64_t)0, n, m->dk16, (const float*)m->sc_tau, m->sc_lists, m->sc_counts, (float*)nullptr, 0, 1, 1 | (m->no_block_bound ? 64 : 0), 1,
+                           (unsigned int*)m->fb_state, off);
+        const RerankFb fb = {m->fb_state, nullptr, nullptr, 0, (const int*)m->fb_list + off, off};
+        if (k == 1)
+            hipLaunchKernelGGL(k_gemm_rerank, dim3(kScQueries), dim3(64), rr_lds, st, m->sc_lists, m->sc_counts, m->sc_tau, m->gal4, d_queries, m->sc_qnorm, m->gmax, n, d,
+                               m->dp4, m->v.row_offset, e_rel, m->rerank_group, (unsigned long long*)d_keys, m->ok, qs, m->rowmajor, fb);
+        else
+            hipLaunchKernelGGL(k_gemm_rerank_topk, dim3(kScQueries), dim3(64), rr_lds, st, m->sc_lists, m->sc_counts, m->sc_tau, m->gal4, d_queries, m->sc_qnorm, m->gmax, n,
+                               d, m->dp4, m->v.row_offset, e_rel, m->rerank_group, k, (unsigned long long*)d_keys, m->ok, qs, m->rowmajor, fb);
+    }
+    hipLaunchKernelGGL(k_gemm_fb_collect, dim3(1), dim3(256), 0, st, m->fb_state, (const int*)m->fb_list, (const int*)m->ok, m->fb_list2, (unsigned long long*)d_keys, k);
+    for (int r = 0; r < k; ++r)
+        hipLaunchKernelGGL(k_gemm_exact_fb, dim3(m->fb_grid), dim3(256), m->fb_lds, st, m->gal4, n, m->dp4, d, m->v.row_offset, d_queries, qs, (const int*)m->fb_state,
+                           (const int*)m->fb_list2, (unsigned long long*)d_keys, k, r);
+    GEMM_HIP(hipGetLastError());
+    return FIR_OK;
+}
+
+// the per-call buffers of the uncertified-query lists (and the certificate flags), grown to the largest call seen
+static int gemm_fb_reserve_(fir_gemm* m, int32_t qb) {
+    if ((size_t)qb <= m->ok_cap) return FIR_OK;
+    GEMM_HIP(hipDeviceSynchronize());                        // (an earlier call's kernels may still read the old ones)
+    (void)hipFree(m->ok); (void)hipFree(m->fb_list); (void)hipFree(m->fb_list2); (void)hipFree(m->fb_tau2);
+    m->ok = nullptr; m->fb_list = nullptr; m->fb_list2 = nullptr; m->fb_tau2 = nullptr;
+    m->ok_cap = 0;
+    const size_t cap = (size_t)std::max(qb, 1024);
+    GEMM_HIP(hipMalloc((void**)&m->ok, cap * sizeof(int)));
+    GEMM_HIP(hipMalloc((void**)&m->fb_list, cap * sizeof(int)));
+    GEMM_HIP(hipMalloc((void**)&m->fb_list2, cap * sizeof(int)));
+    GEMM_HIP(hipMalloc((void**)&m->fb_tau2, cap * sizeof(float)));
+    m->ok_cap = cap;
+    return FIR_OK;
+}
+
+// d_queries / d_keys: device pointers. Everything is queued on `stream` (and the handle's side streams, joined before the call
+// returns control of `stream`): no host synchronisation -- the keys are final in stream order.
 
 // The K nearest rows of every query, K = 1 (fir_gemm_search_top1_keys_dev) or 2..kTopKMax (fir_gemm_search_topk_keys_dev):
 // d_keys[q * k + r], ascending.
@@ -1776,13 +1909,11 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
     if (n == 0)
         return k == 1 ? fir_search_top1_exact_keys_dev_(m->g, d_queries, qb, 0, d, d_keys, st)
                       : fir_search_topk_exact_keys_dev_(m->g, d_queries, qb, d, k, d_keys, st);
-    if ((size_t)qb > m->ok_cap) {
-        if (m->ok) GEMM_HIP(hipFree(m->ok));
-        m->ok = nullptr;
-        m->ok_cap = 0;
-        GEMM_HIP(hipMalloc((void**)&m->ok, (size_t)std::max(qb, 1024) * sizeof(int)));
-        m->ok_cap = (size_t)std::max(qb, 1024);
+    {
+        const int rcr = gemm_fb_reserve_(m, qb);
+        if (rcr) return rcr;
     }
+    GEMM_HIP(hipMemsetAsync(m->fb_state, 0, 2 * sizeof(int), st));       // this call's two list lengths
     const size_t lds = m->precision == FIR_GEMM_F32 ? (size_t)(kQT / 32) * std::min(m->dq8, kSlab8) * 64 * sizeof(float4)
                                                     : (size_t)(kQT / 32) * std::min(m->dk16, kSlab16) * 128 * sizeof(uint4);
     // fp16: both operands rounded to 11 bits -> |q~.g~ - q.g| <= (2^-10 + 2^-22) sum|q_k g_k| + the sub-normal tails
@@ -1800,7 +1931,7 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
     // super-batch: between two super-batches the next one's preparation queues behind the previous one's re-rank, which runs squeezed
     // between the full pass's workgroups (100 000 x 512, 4 096 queries: ~65 us of bubble per boundary and a re-rank four times
     // slower than alone, for 110 us launches -- profiles/r03_small_call_timeline.txt)
-    const bool short_launches = (double)n * (double)d <= 1.5e8 && !std::getenv("FIR_GEMM_QUARTERS");
+    const bool short_launches = (double)n * (double)d <= 1.5e8 && !fir_knob_("FIR_GEMM_QUARTERS");
     const int sbq = short_launches ? std::min(kPasses * kQT, std::max(1024, (qb + 1023) / 1024 * 1024))
                                    : std::min(kPasses * kQT, std::max(1024, (qb / 4 + 1023) / 1024 * 1024));
     const int nsb = (qb + sbq - 1) / sbq;
@@ -1857,7 +1988,13 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
         const int64_t row_groups = ((n + 31) / 32 + kGemmBlock / 64 - 1) / (kGemmBlock / 64);
         return row_groups * P / std::max(grid, 1) >= 12;
     };
-    const int adapt_dbg = std::getenv("FIR_GEMM_ADAPT_DBG") ? (std::atoi(std::getenv("FIR_GEMM_ADAPT_DBG")) & 3) << 2 : 0;   // experiments: 1 = no refresh, 2 = no exchange
+#ifdef FIR_AUDIT
+    // 1 = no refresh, 2 = no exchange of the adaptive bound between workgroups (still sound: a looser bound appends more -- this is how
+    // the tests drive lists into overflow and the second-chance pass on benign data)
+    const int adapt_dbg = fir_knob_("FIR_GEMM_ADAPT_DBG") ? (std::atoi(fir_knob_("FIR_GEMM_ADAPT_DBG")) & 3) << 2 : 0;
+#else
+    const int adapt_dbg = 0;
+#endif
     const int sub_stride = k > 1 ? kPasses * kQT : 0;      // top-K: the sample as kRtSubsets subset minima per query (k_gemm_tau_kmin)
     // the full pass: both kernels run at ~1 KiB of LDS traffic per MFMA and within 7 % of each other (profiles/r02_gemm_kernel_choice.txt):
     // register tile ahead up to 256 features, LDS tile ahead at 512
@@ -1872,7 +2009,7 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
     // kernels only got the CUs a full-pass workgroup had just left and slowed those passes down (1M x 512, 32 768 queries per call: top-1
     // 1.253 -> 1.296 M q/s, top-5 1.018 -> 1.071 M; FIR_GEMM_SERIAL_PREP=0 is the old placement). Host-pointer calls keep the side stream:
     // there the preparation waits for the super-batch's upload, which is what overlaps the passes.
-    const char* sp_env = std::getenv("FIR_GEMM_SERIAL_PREP");
+    const char* sp_env = fir_knob_("FIR_GEMM_SERIAL_PREP");
     const bool serial_prep = !(sp_env && std::atoi(sp_env) == 0) && !h_queries;
     auto prep = [&](int sb) -> int {
         hipStream_t ps = serial_prep ? st : m->side;
@@ -2072,73 +2209,43 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
         // exact re-rank + certificate of this super-batch on the side stream, under the next one's full pass
         hipStream_t rs = m->side;
         GEMM_HIP(hipStreamWaitEvent(m->side, m->main_done[b], 0));
+        const RerankFb fb = {m->fb_state, m->fb_list, m->fb_tau2, q0, nullptr, 0};     // uncertified queries go on the call's list
         if (k == 1)
             hipLaunchKernelGGL(k_gemm_rerank, dim3(nq), dim3(64), (size_t)(m->rerank_group + 1) * (m->dp4 + 1) * sizeof(float4), rs, m->lists[b], m->counts[b],
                                m->tau[b], m->gal4, dq, m->qnorm[b], m->gmax, n, d, m->dp4, m->v.row_offset, e_rel, m->rerank_group,
-                               (unsigned long long*)d_keys + q0, m->ok + q0, qs, m->rowmajor);
+                               (unsigned long long*)d_keys + q0, m->ok + q0, qs, m->rowmajor, fb);
         else
             hipLaunchKernelGGL(k_gemm_rerank_topk, dim3(nq), dim3(64), (size_t)(m->rerank_group + 1) * (m->dp4 + 1) * sizeof(float4), rs, m->lists[b],
                                m->counts[b], m->tau[b], m->gal4, dq, m->qnorm[b], m->gmax, n, d, m->dp4, m->v.row_offset, e_rel, m->rerank_group, k,
-                               (unsigned long long*)d_keys + (size_t)q0 * k, m->ok + q0, qs, m->rowmajor);
+                               (unsigned long long*)d_keys + (size_t)q0 * k, m->ok + q0, qs, m->rowmajor, fb);
         GEMM_HIP(hipEventRecord(m->rerank_done[b], rs));
         m->passes += np;
     }
     GEMM_HIP(hipStreamWaitEvent(st, m->rerank_done[(nsb - 1) & 1], 0));   // join the side stream (it is in order: the last re-rank is the last thing on it)
     GEMM_HIP(hipGetLastError());
-    std::vector<int> h_ok((size_t)qb);
-    GEMM_HIP(hipMemcpyAsync(h_ok.data(), m->ok, (size_t)qb * sizeof(int), hipMemcpyDeviceToHost, st));
-    GEMM_HIP(hipStreamSynchronize(st));
-    if (std::getenv("FIR_GEMM_DEBUG_COUNTS")) {       // experiments: appended rows per query of the last super-batch
+#ifdef FIR_AUDIT
+    if (fir_knob_("FIR_GEMM_DEBUG_COUNTS")) {       // audit builds: appended rows per query of the last super-batch (synchronises)
+        GEMM_HIP(hipStreamSynchronize(st));
         const int nql = std::min(sbq, qb - (nsb - 1) * sbq);
-        std::vector<int> hc((size_t)nql);
+        std::vector<int> hc((size_t)nql), h_ok((size_t)nql);
         GEMM_HIP(hipMemcpy(hc.data(), m->counts[(nsb - 1) & 1], (size_t)nql * sizeof(int), hipMemcpyDeviceToHost));
+        GEMM_HIP(hipMemcpy(h_ok.data(), m->ok + (size_t)(nsb - 1) * sbq, (size_t)nql * sizeof(int), hipMemcpyDeviceToHost));
         long long sum = 0;
-        int mx = 0;
+        int mx = 0, bad = 0;
         for (int v : hc) { sum += v; mx = std::max(mx, v); }
+        for (int v : h_ok) bad += v ? 0 : 1;
         std::vector<float> ht((size_t)nql);
         GEMM_HIP(hipMemcpy(ht.data(), m->tau[(nsb - 1) & 1], (size_t)nql * sizeof(float), hipMemcpyDeviceToHost));
         double ts = 0;
         int ninf = 0;
         for (float v : ht) { if (v < 1e30f) ts += v; else ++ninf; }
-        std::fprintf(stderr, "fir_gemm: appended rows per query (last super-batch of %d): mean %.1f, max %d; tau: mean %.6f, %d not finite\n", nql, (double)sum / nql, mx,
-                     ts / std::max(1, nql - ninf), ninf);
-        // the uncertified queries of that super-batch: list length, bound, smallest proxy in the list
-        const int q0l = (nsb - 1) * sbq;
-        int shown = 0;
-        for (int i = 0; i < nql && shown < 8; ++i) {
-            if (h_ok[(size_t)(q0l + i)]) continue;
-            const int cnt = std::min(hc[(size_t)i], kListCap);
-            std::vector<unsigned long long> hl((size_t)std::max(cnt, 1));
-            if (cnt > 0) GEMM_HIP(hipMemcpy(hl.data(), m->lists[(nsb - 1) & 1] + (size_t)i * kListCap, (size_t)cnt * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-            unsigned long long mn = ~0ull;
-            for (int j = 0; j < cnt; ++j) mn = std::min(mn, hl[(size_t)j]);
-            uint32_t ob = (uint32_t)(mn >> 32);
-            uint32_t fb = (ob & 0x80000000u) ? (ob ^ 0x80000000u) : ~ob;
-            float pmin;
-            std::memcpy(&pmin, &fb, 4);
-            float hqn = 0.f;
-            GEMM_HIP(hipMemcpy(&hqn, m->qnorm[(nsb - 1) & 1] + i, 4, hipMemcpyDeviceToHost));
-            std::fprintf(stderr, "  uncertified query %d: %d appended, tau %.7f, smallest proxy in list %.7f (row %u), |q|^2 %.6f\n", q0l + i, hc[(size_t)i], ht[(size_t)i], pmin,
-                         (unsigned)(mn & 0xFFFFFFFFu), hqn);
-            ++shown;
-        }
+        std::fprintf(stderr, "fir_gemm: appended rows per query (last super-batch of %d): mean %.1f, max %d; tau: mean %.6f, %d not finite; %d uncertified\n", nql,
+                     (double)sum / nql, mx, ts / std::max(1, nql - ninf), ninf, bad);
     }
-    // uncertified queries: the exact streaming scan answers them, kQT at a time
-    std::vector<int> which;
-    for (int i = 0; i < qb; ++i)
-        if (!h_ok[(size_t)i]) which.push_back(i);
-    m->fallbacks += (int64_t)which.size();
-    for (size_t f0 = 0; f0 < which.size(); f0 += kQT) {
-        const int nf = (int)std::min<size_t>(kQT, which.size() - f0);
-        for (int i = 0; i < nf; ++i)
-            GEMM_HIP(hipMemcpyAsync(m->fbq + (size_t)i * qs, d_queries + (size_t)which[f0 + i] * qs, (size_t)qs * sizeof(float), hipMemcpyDeviceToDevice, st));
-        int rc = k == 1 ? fir_search_top1_exact_keys_dev_(m->g, m->fbq, nf, 0, d, (uint64_t*)m->fbkeys, st)
-                        : fir_search_topk_exact_keys_dev_(m->g, m->fbq, nf, d, k, (uint64_t*)m->fbkeys, st);
-        if (rc) return rc;
-        for (int i = 0; i < nf; ++i)
-            GEMM_HIP(hipMemcpyAsync(d_keys + (size_t)which[f0 + i] * k, m->fbkeys + (size_t)i * k, (size_t)k * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
-    }
-    return FIR_OK;
+#endif
+    // uncertified queries: a second matrix-core pass with the tightest bound the first one can justify, then the exact device scan
+    const int sc_rounds = x_flow ? std::min(kScRounds, (qb + kScQueries - 1) / kScQueries) : 0;
+    return gemm_finish_(m, d_queries, k, d_keys, st, e_rel, sc_rounds);
 }
 
 extern "C" {
@@ -2182,12 +2289,11 @@ int fir_gemm_search_few_keys_dev(fir_gemm* m, const float* d_queries, int32_t qb
         }
         m->lists_cap = 2 * kQT;
     }
-    if (m->ok_cap < 1024) {
-        if (m->ok) GEMM_HIP(hipFree(m->ok));
-        m->ok = nullptr;
-        GEMM_HIP(hipMalloc((void**)&m->ok, 1024 * sizeof(int)));
-        m->ok_cap = 1024;
+    {
+        const int rcr = gemm_fb_reserve_(m, qb);
+        if (rcr) return rcr;
     }
+    GEMM_HIP(hipMemsetAsync(m->fb_state, 0, 2 * sizeof(int), st));
     const float e_rel = m->erel_scale * (8.0f * (float)d * 5.9604645e-8f + 9.765625e-4f * 1.0625f);     // as gemm_search (one fp16 term)
     const int b = 0;
     hipLaunchKernelGGL(k_gemm_qprep_f16, dim3(2 * kQT), dim3(64), 0, st, d_queries, qb, d, m->gallery_exp, m->qnorm[b], m->qmul[b], m->qinv[b], qs);
@@ -2212,20 +2318,14 @@ int fir_gemm_search_few_keys_dev(fir_gemm* m, const float* d_queries, int32_t qb
                                2.0 * (double)n * d * nqt);
     hipLaunchKernelGGL(k_gemm_tau_min, dim3(1), dim3(256), 0, st, m->smin[b], m->tau[b], 2 * kQT, qb, m->qnorm[b], m->gmax, e_rel);
     hipLaunchKernelGGL(k_gemm_select, dim3((unsigned)std::min<int64_t>(1024, (n + 255) / 256), qb), dim3(256), 0, st, m->proxies, n, m->tau[b], m->lists[b], m->counts[b]);
+    const RerankFb fb = {m->fb_state, m->fb_list, m->fb_tau2, 0, nullptr, 0};
     hipLaunchKernelGGL(k_gemm_rerank, dim3(qb), dim3(64), (size_t)(m->rerank_group + 1) * (m->dp4 + 1) * sizeof(float4), st, m->lists[b], m->counts[b], m->tau[b], m->gal4,
-                       d_queries, m->qnorm[b], m->gmax, n, d, m->dp4, m->v.row_offset, e_rel, m->rerank_group, (unsigned long long*)d_keys, m->ok, qs, m->rowmajor);
+                       d_queries, m->qnorm[b], m->gmax, n, d, m->dp4, m->v.row_offset, e_rel, m->rerank_group, (unsigned long long*)d_keys, m->ok, qs, m->rowmajor, fb);
     GEMM_HIP(hipGetLastError());
-    int h_ok[8];
-    GEMM_HIP(hipMemcpyAsync(h_ok, m->ok, (size_t)qb * sizeof(int), hipMemcpyDeviceToHost, st));
-    GEMM_HIP(hipStreamSynchronize(st));
     m->passes += 1;
-    for (int i = 0; i < qb; ++i) {
-        if (h_ok[i]) continue;
-        ++m->fallbacks;
-        const int rc = fir_search_top1_exact_keys_dev_(m->g, d_queries + (size_t)i * qs, 1, 0, d, d_keys + i, st);
-        if (rc) return rc;
-    }
-    return FIR_OK;
+    // (the bound of this form already is the smallest proxy of ALL rows + one window: a second pass could not do better; what is
+    // not certified -- NaN operands, thousands of ties -- goes to the exact device scan, in stream order)
+    return gemm_finish_(m, d_queries, 1, d_keys, st, e_rel, 0);
 }
 
 // Host-pointer form for fir_search_top1 / fir_search_topk: h_queries -> d_stage (qb rows of the gallery's length) super-batch by

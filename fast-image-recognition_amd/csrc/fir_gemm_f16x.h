@@ -44,8 +44,15 @@ __global__ void __launch_bounds__(256) k_gemm_pack_gallery_f16x(const float4* __
 }
 
 // queries * qmul -> 16-row fragment order; blockIdx.y = pair of 64-query passes
+// qmap (a second-chance round, fir_gemm_fb.h): slot i of the one pair is query qmap[i] of the call, state[0] - live_off slots are live
 __global__ void __launch_bounds__(256) k_gemm_pack_queries_f16x(const float* q, int nq, int d, int dk16, const float* __restrict__ qmul, uint4* qh,
-                                                                 int qstride) {
+                                                                 int qstride, const int* __restrict__ qmap = nullptr, const int* __restrict__ state = nullptr,
+                                                                 int live_off = 0) {
+    if (qmap) {
+        nq = state[0] - live_off;
+        if (nq <= 0) return;
+        nq = nq < 2 * kQT ? nq : 2 * kQT;
+    }
     const int dk32 = dk16 >> 1;
     const int q_base = (int)blockIdx.y * 2 * kQT;
     qh += (size_t)blockIdx.y * 8 * dk32 * 64;
@@ -60,7 +67,7 @@ __global__ void __launch_bounds__(256) k_gemm_pack_queries_f16x(const float* q, 
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int k = 32 * kk + 8 * (l >> 4) + j;
-        const float x = (qi < nq && k < d) ? q[(size_t)qi * qstride + k] : 0.f;
+        const float x = (qi < nq && k < d) ? q[(size_t)(qmap ? qmap[qi] : qi) * qstride + k] : 0.f;
         v[j] = (_Float16)(x * mul);
     }
     uint4 u;
@@ -109,6 +116,9 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
                                                                     float* sample, int sample_rows, int share, int nt_flags,
                                                                     int rb_stride, unsigned int* smin, int sub_stride) {
     extern __shared__ __attribute__((aligned(16))) uint4 lqx[];
+    // MODE 1 as a second-chance round (fir_gemm_fb.h): `smin` is the list's length, `sub_stride` the part of it earlier rounds took --
+    // nothing left for this round: every workgroup returns at once (a kernel boundary lies between the writers and this load)
+    if (MODE == 1 && smin != nullptr && (int)smin[0] - sub_stride <= 0) return;
     const int nt = nt_flags & 1;
     __shared__ float tau_s[2 * kQT], qinv_s[2 * kQT];
     // MODE 1: appends are staged per workgroup in LDS (an LDS atomic counts in lgkmcnt and returns in ~100 cycles; a returning GLOBAL

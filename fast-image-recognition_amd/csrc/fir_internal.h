@@ -18,6 +18,11 @@ struct fir_gallery_view {
 };
 extern "C" int fir_gallery_view_(fir_gallery* g, fir_gallery_view* out);
 extern "C" void fir_set_last_error_(const char* msg);
+// Every environment knob the library honours goes through here: getenv(name), and a set one is remembered (once) in the list
+// fir_gallery_last_dispatch reports in fir_dispatch_info::knobs -- a stray variable in a production environment is visible.
+// The knobs that can change ANSWERS (FIR_GEMM_EREL_SCALE, FIR_GEMM_DBG_SKIP, FIR_GEMM_ADAPT_DBG, fir_shard_opts.fail_*) exist
+// only in the audit build (-DFIR_AUDIT, libfir_amd_audit.so: what the tests that need them load); the shipped library ignores them.
+extern "C" const char* fir_knob_(const char* name);
 extern "C" int fir_gallery_tiled_(fir_gallery* g, const void** gal4, int* dp4);   // the tiled f32 gallery (fir_kernels.h layout)
 
 // Device scratch owned by the gallery handle: `slot` in [0, 24), grown on demand, kept until the gallery is destroyed

@@ -657,6 +657,11 @@ int read_opts(const fir_shard_opts* opts, fir_shard_opts* o) {
     if (!o->comm_id) { o->nprocs = 1; o->proc_rank = 0; }
     if (o->shards_per_device > 64) return sh_fail(FIR_ERR_ARG, "shards_per_device = %d", o->shards_per_device);
     if (o->nprocs < 1 || o->proc_rank < 0 || o->proc_rank >= o->nprocs) return sh_fail(FIR_ERR_ARG, "process %d of %d", o->proc_rank, o->nprocs);
+#ifndef FIR_AUDIT
+    // the failure-injection hooks exist in the audit build only (libfir_amd_audit.so): the shipped library refuses them loudly
+    if (o->fail_shard != 0 || o->fail_step != 0)
+        return sh_fail(FIR_ERR_ARG, "fir_shard_opts.fail_shard / fail_step are test hooks of the audit build (libfir_amd_audit.so); this library has none");
+#endif
     return FIR_OK;
 }
 
@@ -1048,6 +1053,10 @@ int fir_gallery_create_sharded_ex(const float* rows, int64_t n, int32_t d, const
     if (spd > 64) return sh_fail(FIR_ERR_ARG, "shards_per_device = %d", spd);
     if (nprocs < 1 || proc < 0 || proc >= nprocs) return sh_fail(FIR_ERR_ARG, "process %d of %d", proc, nprocs);
     if (o.rows_on_device && ndev != 1) return sh_fail(FIR_ERR_ARG, "device-resident rows need a one-entry device list (they live on one device)");
+#ifndef FIR_AUDIT
+    if (o.fail_shard != 0 || o.fail_step != 0)       // (as read_opts: the hooks exist in the audit build only)
+        return sh_fail(FIR_ERR_ARG, "fir_shard_opts.fail_shard / fail_step are test hooks of the audit build (libfir_amd_audit.so); this library has none");
+#endif
     if (o.first_global_row < 0 || o.first_global_row + n >= ((int64_t)1 << 31)) return sh_fail(FIR_ERR_ARG, "rows [%lld, +%lld) do not fit 32-bit indices", (long long)o.first_global_row, (long long)n);
     for (int i = 0; i < ndev; ++i)
         for (int j = 0; j < i; ++j)

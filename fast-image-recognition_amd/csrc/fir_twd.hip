@@ -1214,7 +1214,7 @@ int fir_twd_conventional(fir_gallery* g, const float* queries, int32_t qb, int32
         return FIR_OK;
     };
     // Few queries: ONE launch per internal batch (k_twd_conv_fused), as for the proposed classifier (FIR_TWD_FUSED).
-    const char* fenv = std::getenv("FIR_TWD_FUSED");
+    const char* fenv = fir_knob_("FIR_TWD_FUSED");
     const int fmode = fenv ? std::atoi(fenv) : 1;
     const int64_t tiles64 = ((int64_t)n + 63) / 64;
     bool fused = fmode != 0 && n > 0 && (fmode == 2 || qb <= kFusedMaxQueries) && (v.metric == 0 || v.metric == 1) && reduced_features_count % 4 == 0 &&
@@ -1352,7 +1352,7 @@ int fir_twd_proposed(fir_gallery* g, const float* queries, int32_t qb, int32_t r
         return twd_fail(FIR_ERR_ARG, "reduced_features_count=%d must divide %d", reduced_features_count, kLastFeature);
     const int nchunks = kLastFeature / reduced_features_count;
     // Few queries: ONE launch per internal batch (k_twd_prop_fused). FIR_TWD_FUSED=0 never, 2 = whatever the batch (tests).
-    const char* fenv = std::getenv("FIR_TWD_FUSED");
+    const char* fenv = fir_knob_("FIR_TWD_FUSED");
     const int fmode = fenv ? std::atoi(fenv) : 1;
     const int64_t tiles = ((int64_t)n + 63) / 64;
     bool fused = fmode != 0 && n > 0 && (fmode == 2 || qb <= kFusedMaxQueries) && (v.metric == 0 || v.metric == 1) &&

@@ -277,11 +277,18 @@ int fir_gemm_search_topk_keys_dev(fir_gemm* m, const float* d_queries, int32_t q
  * bytes; identical keys). min_queries > 0: the caller's threshold instead (any gallery size); 0: never, frees the copy
  * (the exact streaming scan answers everything); < 0: back to the default. */
 int fir_gallery_set_large_batch_mfma(fir_gallery* g, int32_t min_queries);
-/* passes = 64-query GEMM passes run so far, fallback_queries = queries answered by the exact scan instead. */
+/* passes = 64-query GEMM passes queued so far, fallback_queries = queries answered by the exact device scan instead (results
+ * identical either way). Uncertified queries are dealt with on the device, in stream order (a second matrix-core pass with the
+ * tightest bound the first one justifies, then the exact scan): the search calls never synchronise; this call waits for the
+ * device and reads the counters. */
 int fir_gemm_stats(const fir_gemm* m, int64_t* passes, int64_t* fallback_queries);
+/* out[0] = passes, out[1] = queries whose FIRST certificate did not hold (list overflow, window reaching the bound, NaN),
+ * out[2] = queries the exact device scan answered (= fallback_queries above). */
+int fir_gemm_stats_ex(const fir_gemm* m, int64_t out[3]);
 /* The same counters for the matrix-core states a gallery's AUTOMATIC dispatch has built (whole rows and feature prefixes),
  * summed: fallback_queries = queries it could not certify and sent through the exact scan (results identical either way). */
 int fir_gallery_mfma_stats(fir_gallery* g, int64_t* passes, int64_t* fallback_queries);
+int fir_gallery_mfma_stats_ex(fir_gallery* g, int64_t out[3]);
 /* HBM held by a gallery handle, in bytes: the tiled f32 rows (+ labels), the fp16 fragment copies the automatic dispatch has
  * made (0.5 x the rows each; one per feature prefix in use), the row-major f32 shadow copies the exact re-rank gathers from
  * (1 x the rows; made only when four times their size was free), and all other scratch. Any pointer may be NULL. */
@@ -317,7 +324,8 @@ typedef struct fir_shard_opts {
     int64_t total_rows;         /* fir_cls_create_sharded with comm_id: training rows over ALL processes (PNN divisor); 0 = n */
     int32_t timeout_ms;         /* bound of every wait behind a collective (0: 120 000). When it passes, or RCCL reports an
                                  * asynchronous error, the communicator is aborted and the call returns FIR_ERR_COMM          */
-    int32_t fail_shard;         /* test hook: 1-based index of the local shard whose step fails with FIR_ERR_NOMEM (0: none)  */
+    int32_t fail_shard;         /* AUDIT BUILD ONLY (libfir_amd_audit.so, -DFIR_AUDIT; the shipped library returns FIR_ERR_ARG for a
+                                 * non-zero value): 1-based index of the local shard whose step fails with FIR_ERR_NOMEM (0: none)   */
     int32_t fail_step;          /* ... 1: its scan, after the buffers were agreed on; 2: the buffer growth of its device      */
     int32_t reserved2;
 } fir_shard_opts;
@@ -402,6 +410,9 @@ typedef struct fir_dispatch_info {
                                * state is built only for a gallery that keeps getting such calls; > 0 = this call was one of the
                                * first few and took the scan, this many more will; 0 = steady state */
     int32_t reserved;
+    char knobs[160];          /* the FIR_* environment knobs this PROCESS has honoured so far, space separated ("" = none; a trailing
+                               * "..." = more than fit). Experiment switches only: none of them changes an answer in the shipped library
+                               * (the audit knobs that can are compiled into libfir_amd_audit.so alone, which also lists them here) */
 } fir_dispatch_info;
 int fir_gallery_last_dispatch(fir_gallery* g, fir_dispatch_info* out);
 

@@ -21,6 +21,14 @@ def fir():
 
 
 @pytest.fixture(scope="session")
+def fir_audit():
+    """The same package over libfir_amd_audit.so (-DFIR_AUDIT): the only build with the knobs that can change answers."""
+    import __graft_entry__ as ge
+
+    return ge.load_package(audit=True)
+
+
+@pytest.fixture(scope="session")
 def oracle():
     import oracle_lib
 

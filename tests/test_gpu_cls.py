@@ -251,18 +251,18 @@ def test_knn_vote_over_training_row_shards_inside_the_library(fir, oracle):
 
 
 @pytest.mark.parametrize("step", [1, 2])
-def test_a_failing_training_set_shard_fails_pnn_and_knn_instead_of_blocking(fir, oracle, step):
+def test_a_failing_training_set_shard_fails_pnn_and_knn_instead_of_blocking(fir, fir_audit, oracle, step):
     """The sharded classifiers' failure semantics (include/fir_amd.h): shard 2 of 5 fails its step; PNN (status element behind
     the ncclSum payload) and kNN (behind the gathered tables) return its error, the handle is closed, a fresh one works."""
     n, d, ncls = 3000, 64, 13
     tr, tcls, q = _big_training_set(n, d, ncls, 6)
     _, _, avg, _ = oracle.train_stats(tr)
     for call in (lambda s: s.pnn_predict(q), lambda s: s.knn_predict(q, 3)):
-        with fir.ShardedClsModel(tr, tcls, ncls, avg, devices=[0], shards_per_device=5, fail_shard=3, fail_step=step, timeout_ms=20000) as s:
-            with pytest.raises(fir.FirError) as e:
+        with fir_audit.ShardedClsModel(tr, tcls, ncls, avg, devices=[0], shards_per_device=5, fail_shard=3, fail_step=step, timeout_ms=20000) as s:
+            with pytest.raises(fir_audit.FirError) as e:
                 call(s)
             assert e.value.code == -3, (e.value.code, str(e.value))
-            with pytest.raises(fir.FirError) as e2:
+            with pytest.raises(fir_audit.FirError) as e2:
                 s.pnn_predict(q)
             assert e2.value.code == -5
     with fir.ClsModel(tr, tcls, ncls, avg, 0) as m:

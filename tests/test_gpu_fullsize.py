@@ -222,11 +222,25 @@ def test_config5_1m_x_1280_matrix_core_path_equals_the_scan(fir, oracle, precisi
         got = k2.cpu().numpy().view(np.uint64)
         fb = gm.stats()["fallback_queries"]
         gm.close()
+        small = {}
         if precision == 2:                              # and the default dispatch is this path
             g.set_large_batch_mfma(-1)
             auto = keys_of(fir, g, q, st)
             assert g.last_dispatch()["path"] == "mfma" and np.array_equal(auto, scan)
+            # small batches of config 5 on benign data -- 8 and 32 queries, ten calls each through the default
+            # dispatch: every certificate holds at the first pass (no second pass, no exact scan) and the keys are the scan's
+            for sq in (8, 32):
+                ks = torch.empty(sq, device="cuda", dtype=torch.int64)
+                s0 = g.mfma_stats()
+                for _ in range(10):
+                    g.search_top1_keys_dev(q[128:].data_ptr(), sq, ks.data_ptr(), stream=st.cuda_stream)
+                    st.synchronize()
+                    assert np.array_equal(ks.cpu().numpy().view(np.uint64), scan[128:128 + sq])
+                s1 = g.mfma_stats()
+                small[sq] = (g.last_dispatch()["path"], s1["second_pass_queries"] - s0["second_pass_queries"], s1["fallback_queries"] - s0["fallback_queries"])
         g.close()
+    for sq, (path, second, exact) in small.items():
+        assert path == "mfma" and second == 0 and exact == 0, (sq, path, second, exact)
     assert np.array_equal(got, scan)
     assert fb <= qb // 8, fb                           # the certificate holds for (nearly) every query: the path is not the scan in disguise
     idx, dist = fir.keys_unpack(scan)

@@ -22,8 +22,33 @@ def run_both(fir, rows, q, precision=2):
             m.search_top1_keys_dev(tq.data_ptr(), q.shape[0], keys.data_ptr())
             torch.cuda.synchronize()
             st = m.stats()
+            st["kernel"] = g.last_dispatch()["kernel"]
         idx, dist = fir.keys_unpack(keys.cpu().numpy().view(np.uint64))
     return (idx, dist), (eidx, edist), st
+
+
+@pytest.fixture(params=["default", "sample-flow", "adaptive-always"])
+def flow(request, monkeypatch):
+    """the hard inputs below must reach BOTH threshold flows of the 16-row fp16 kernels, whatever the shape-based
+    choice (adaptive_for, fir_gemm.hip) would have been: FIR_GEMM_ADAPTIVE=0 is the sample flow (k_gemm_proxy_f16x<2, *> +
+    <1, *>), 2 forces the in-flight threshold (<3, *>) at any shape. Both flows are sound: the knob changes no answer."""
+    if request.param == "sample-flow":
+        monkeypatch.setenv("FIR_GEMM_ADAPTIVE", "0")
+    elif request.param == "adaptive-always":
+        monkeypatch.setenv("FIR_GEMM_ADAPTIVE", "2")
+    return request.param
+
+
+def check_flow(flow, precision, st):
+    """the kernel that ran is the one the parametrisation asked for (fp16 form only: the other precisions have one flow)"""
+    if precision != 2:
+        if flow != "default":
+            pytest.skip("the f32 / bf16 forms have one threshold flow")
+        return
+    if flow == "adaptive-always":
+        assert "f16x<3," in st["kernel"], st["kernel"]
+    elif flow == "sample-flow":
+        assert "f16x<1," in st["kernel"], st["kernel"]
 
 
 @pytest.mark.parametrize("seed,n,d,qb", [(1, 5000, 512, 70), (2, 40000, 512, 64), (3, 1000, 256, 5), (4, 333, 100, 130), (5, 7, 64, 3), (6, 70000, 128, 200), (7, 3000, 1280, 70), (8, 900, 1536, 9), (9, 2000, 520, 33)])
@@ -59,23 +84,29 @@ def test_paired_passes_all_shapes(fir, n, d, qb):
 
 @pytest.mark.parametrize("scale", [1e-20, 1e-6, 30.0, 1e15, 1e19])
 @pytest.mark.parametrize("precision", [0, 1, 2])
-def test_extreme_magnitudes_fall_back_to_the_same_answers(fir, scale, precision):
+def test_extreme_magnitudes_fall_back_to_the_same_answers(fir, scale, precision, flow):
     """Inputs far from unit norm: products in the denormal range, distances beyond the 100000 cut-off, squares that
     overflow. Whatever the proxies become, the certificate or the fallback returns the exact scan's keys."""
     rows = (synth.make_gallery(55, 6000, 128, 0) * np.float32(scale)).astype(np.float32)
     q = (synth.make_queries(55, rows / np.float32(scale), 70, 0)[0] * np.float32(scale)).astype(np.float32)
+    if precision != 2 and flow != "default":
+        pytest.skip("the f32 / bf16 forms have one threshold flow")
     (idx, dist), (eidx, edist), st = run_both(fir, rows, q, precision)
+    check_flow(flow, precision, st)
     assert np.array_equal(idx, eidx)
     assert np.array_equal(dist.view(np.uint32), edist.view(np.uint32))
 
 
 @pytest.mark.parametrize("precision", [0, 1, 2])
-def test_gemm_adversarial_near_ties_and_duplicates(fir, oracle, precision):
+@pytest.mark.parametrize("qb", [12, 200])
+def test_gemm_adversarial_near_ties_and_duplicates(fir, oracle, precision, flow, qb):
     """20 rows within a few ulps of the best, exact duplicates of the best, a NaN row and unnormalised rows: every row
     inside the rounding window of the best proxy is re-ranked exactly, so the lowest row of a tie wins as in the scan."""
     n, d = 30000, 512
+    if precision != 2 and flow != "default":
+        pytest.skip("the f32 / bf16 forms have one threshold flow")
     rows = synth.make_gallery(9, n, d, 0)
-    q, pick = synth.make_queries(9, rows, 12, 0)
+    q, pick = synth.make_queries(9, rows, qb, 0)              # (200: a full pair of 64-query passes and a half-filled one)
     base = rows[777].copy()
     for j in range(20):                       # near-duplicates of one row, spread over the gallery
         v = base.copy()
@@ -89,7 +120,10 @@ def test_gemm_adversarial_near_ties_and_duplicates(fir, oracle, precision):
     rows[100] = np.nan
     rows[200] *= np.float32(50.0)             # a long row: |g|^2 enters the proxy and the error bound
     q[3] = rows[200]
+    if qb > 128:
+        q[130], q[131], q[199] = base, rows[4242], rows[200]     # the same hard queries in the half-filled pair
     (idx, dist), (eidx, edist), st = run_both(fir, rows, q, precision)
+    check_flow(flow, precision, st)
     assert np.array_equal(idx, eidx)
     assert np.array_equal(dist.view(np.uint32), edist.view(np.uint32))
     assert idx[2] == 5 and dist[2] == 0
@@ -148,9 +182,12 @@ def test_fp16_term_wide_dynamic_range_and_mixed_scales(fir):
 
 
 @pytest.mark.parametrize("precision", [0, 1, 2])
-def test_more_ties_than_the_candidate_list_holds(fir, precision):
+def test_more_ties_than_the_candidate_list_holds(fir, precision, flow):
     """5000 copies of one row: more entries below tau than a query's candidate list (4096) can take. The overflow is
-    detected, the certificate refuses and the exact scan answers -- the lowest copy."""
+    detected, the certificate refuses, the second pass (fp16 form) overflows as well -- the ties are all inside one window of
+    the best -- and the exact device scan answers: the lowest copy."""
+    if precision != 2 and flow != "default":
+        pytest.skip("the f32 / bf16 forms have one threshold flow")
     n, d = 9000, 128
     rows = synth.make_gallery(77, n, d, 0)
     rows[2000:7000] = rows[10]
@@ -158,15 +195,16 @@ def test_more_ties_than_the_candidate_list_holds(fir, precision):
     q[0] = rows[10]
     q[1] = rows[10] * np.float32(1.001)
     (idx, dist), (eidx, edist), st = run_both(fir, rows, q, precision)
+    check_flow(flow, precision, st)
     assert np.array_equal(idx, eidx)
     assert np.array_equal(dist.view(np.uint32), edist.view(np.uint32))
     assert idx[0] == 10 and dist[0] == 0
-    assert st["fallback_queries"] >= 1
+    assert st["fallback_queries"] >= 1 and st["second_pass_queries"] >= st["fallback_queries"]
 
 
 @pytest.mark.parametrize("precision", [1, 2])
 @pytest.mark.parametrize("spread", [0.3, 0.05, 0.005])
-def test_clustered_gallery_like_identities(fir, precision, spread):
+def test_clustered_gallery_like_identities(fir, precision, spread, flow):
     """A gallery of 600 identities x 40 images (each image = the identity's centre + noise of the given relative size), queries
     drawn the same way: dozens of rows sit within the proxy's rounding window of the best one. They are all re-ranked
     exactly, so the keys equal the scan's, and with a window re-rank only a handful of queries may need the exact scan."""
@@ -177,7 +215,10 @@ def test_clustered_gallery_like_identities(fir, precision, spread):
     rows = synth.normalise(rows, 0)
     who = rng.integers(0, ids, qb)
     q = synth.normalise(centres[who] * (1 + spread * (rng.random((qb, d), dtype=np.float32) - 0.5)), 0)
+    if precision != 2 and flow != "default":
+        pytest.skip("the f32 / bf16 forms have one threshold flow")
     (idx, dist), (eidx, edist), st = run_both(fir, rows, q, precision)
+    check_flow(flow, precision, st)
     assert np.array_equal(idx, eidx)
     assert np.array_equal(dist.view(np.uint32), edist.view(np.uint32))
     assert np.all(idx // per == who)                      # the nearest image belongs to the query's identity
@@ -519,7 +560,7 @@ def _coherent_rounding_fixture(n_random=6000, d=512, seed=91):
     return rows, q, ia, ib
 
 
-def test_the_certificate_bound_is_needed_and_a_shrunken_one_is_caught(fir, oracle, monkeypatch):
+def test_the_certificate_bound_is_needed_and_a_shrunken_one_is_caught(fir, fir_audit, oracle, monkeypatch):
     """the suite must be able to SEE an unsound error bound. With the bound as derived the
     coherent-rounding near-tie is answered exactly (both rows are inside the rounding window, both are re-ranked, the reference's
     first minimum wins); with FIR_GEMM_EREL_SCALE=0.25 -- an audit knob that multiplies the certificate's E -- row A falls out of
@@ -530,20 +571,117 @@ def test_the_certificate_bound_is_needed_and_a_shrunken_one_is_caught(fir, oracl
     dev = torch.device("cuda", 0)
     tq = torch.from_numpy(q).to(dev)
     keys = torch.empty(q.shape[0], dtype=torch.int64, device=dev)
-    with fir.Gallery(rows, None, 0, 0) as g:
-        g.set_large_batch_mfma(0)
-        eidx, edist = g.search_top1(q)
-        assert eidx[0] == ia and edist[0] == 0.0 and (eidx[0], edist[0]) == oracle.recognize_bf(rows, q[0], 0, d, 0)
-        got = {}
-        for scale in ("1", "0.25"):
-            monkeypatch.setenv("FIR_GEMM_EREL_SCALE", scale)
-            with fir.GemmSearch(g, 2) as m:
-                m.search_top1_keys_dev(tq.data_ptr(), q.shape[0], keys.data_ptr())
-                torch.cuda.synchronize()
-                got[scale] = (fir.keys_unpack(keys.cpu().numpy().view(np.uint64)), m.stats()["fallback_queries"])
-        monkeypatch.delenv("FIR_GEMM_EREL_SCALE")
-    (idx, dist), fb = got["1"]
-    assert np.array_equal(idx, eidx) and np.array_equal(dist.view(np.uint32), edist.view(np.uint32)) and fb <= 2
-    (idx_s, dist_s), fb_s = got["0.25"]
+    got = {}
+    # the audit build (libfir_amd_audit.so) honours the knob; the shipped library must not -- a stray variable cannot break the keys
+    for lib_name, pkg in (("audit", fir_audit), ("shipped", fir)):
+        with pkg.Gallery(rows, None, 0, 0) as g:
+            g.set_large_batch_mfma(0)
+            eidx, edist = g.search_top1(q)
+            assert eidx[0] == ia and edist[0] == 0.0 and (eidx[0], edist[0]) == oracle.recognize_bf(rows, q[0], 0, d, 0)
+            for scale in ("1", "0.25"):
+                monkeypatch.setenv("FIR_GEMM_EREL_SCALE", scale)
+                with pkg.GemmSearch(g, 2) as m:
+                    m.search_top1_keys_dev(tq.data_ptr(), q.shape[0], keys.data_ptr())
+                    torch.cuda.synchronize()
+                    got[lib_name, scale] = (pkg.keys_unpack(keys.cpu().numpy().view(np.uint64)), m.stats()["fallback_queries"])
+                    knobs = g.last_dispatch().get("knobs", "")
+                    assert ("FIR_GEMM_EREL_SCALE" in knobs) == (lib_name == "audit"), knobs     # whatever is honoured is reported
+            monkeypatch.delenv("FIR_GEMM_EREL_SCALE")
+    for key in (("audit", "1"), ("shipped", "1"), ("shipped", "0.25")):
+        (idx, dist), fb = got[key]
+        assert np.array_equal(idx, eidx) and np.array_equal(dist.view(np.uint32), edist.view(np.uint32)) and fb <= 2, key
+    (idx_s, dist_s), fb_s = got["audit", "0.25"]
     # the wrong row, certified (no fall-back to the exact scan for it): the shrunken bound is unsound and it shows
     assert idx_s[0] == ib and dist_s[0] > 0.0 and fb_s <= 2, (idx_s[0], dist_s[0], fb_s)
+
+
+def _identity_gallery(n_ids, per, d, seed, dev):
+    """class-ordered rows = identity centre x (1 +- 2.5 %), unit length: what the reference's galleries look like"""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    centres = torch.rand((n_ids, d), generator=g, device=dev)
+    rows = centres.repeat_interleave(per, dim=0) * (1 + 0.05 * (torch.rand((n_ids * per, d), generator=g, device=dev) - 0.5))
+    return (rows / rows.norm(dim=1, keepdim=True)).contiguous(), centres
+
+
+@pytest.mark.parametrize("k", [1, 5])
+def test_a_loose_first_bound_costs_a_second_pass_not_the_exact_scan(fir, monkeypatch, k):
+    """an overflowing candidate list must be cheap. 25 000 identities x 40 class-ordered rows and a row sample
+    cut down to 8 192 rows (FIR_GEMM_SAMPLE_DIV) with the sample flow (FIR_GEMM_ADAPTIVE=0; the K-nearest form always samples): the
+    strided sample misses the query's identity, every row of every identity nearer than the nearest SAMPLED one passes the first
+    bound and many lists overflow their 4 096 entries. Those queries take the second matrix-core pass with
+    min(first bound, smallest stored proxy + one window) -- on the device, in stream order -- and come back certified: nothing
+    reaches the exact device scan, and the keys are the exact scan's."""
+    dev = torch.device("cuda", 0)
+    n_ids, per, d, qb = 25000, 40, 128, 384
+    rows, centres = _identity_gallery(n_ids, per, d, 77, dev)
+    gq = torch.Generator(device=dev)
+    gq.manual_seed(78)
+    who = torch.randint(0, n_ids, (qb,), generator=gq, device=dev)
+    q = centres[who] * (1 + 0.05 * (torch.rand((qb, d), generator=gq, device=dev) - 0.5))
+    q = (q / q.norm(dim=1, keepdim=True)).contiguous()
+    torch.cuda.synchronize()                               # (the library's streams do not wait for torch's)
+    monkeypatch.setenv("FIR_GEMM_ADAPTIVE", "0")
+    monkeypatch.setenv("FIR_GEMM_SAMPLE_DIV", "1000000")
+    ke = torch.empty(qb * k, dtype=torch.int64, device=dev)
+    km = torch.empty(qb * k, dtype=torch.int64, device=dev)
+    with fir.Gallery(dev_ptr=rows.data_ptr(), n=n_ids * per, d=d, metric=0, device=0) as g:
+        g.set_large_batch_mfma(0)
+        if k == 1:
+            g.search_top1_keys_dev(q.data_ptr(), qb, ke.data_ptr())
+        else:
+            g.search_topk_keys_dev(q.data_ptr(), qb, k, ke.data_ptr())
+        torch.cuda.synchronize()
+        with fir.GemmSearch(g, 2) as m:
+            if k == 1:
+                m.search_top1_keys_dev(q.data_ptr(), qb, km.data_ptr())
+            else:
+                m.search_topk_keys_dev(q.data_ptr(), qb, k, km.data_ptr())
+            torch.cuda.synchronize()
+            st = m.stats()
+            assert "FIR_GEMM_SAMPLE_DIV" in g.last_dispatch()["knobs"]
+    assert torch.equal(ke, km)
+    idx, _ = fir.keys_unpack(km.cpu().numpy().view(np.uint64))
+    assert np.all(idx.reshape(qb, k)[:, 0] // per == who.cpu().numpy())
+    assert st["second_pass_queries"] >= 8, st             # the first bound WAS loose ...
+    assert st["fallback_queries"] == 0, st                # ... and the second pass answered all of them
+
+
+def test_the_device_pointer_call_returns_before_its_kernels_have_run(fir):
+    """no host synchronisation inside fir_search_top1_keys_dev on the matrix-core path -- the certified /
+    uncertified split, the second pass and the exact scan of the rest are all queued on the caller's stream. Two calls are
+    enqueued back to back; when the second one returns the stream still has work (the first call's 8 192-query pass alone is
+    tens of milliseconds at 300 000 x 512), and a NaN query -- which no certificate holds for -- is answered in stream order."""
+    dev = torch.device("cuda", 0)
+    n, d, qb = 300_000, 512, 8192
+    g0 = torch.Generator(device=dev)
+    g0.manual_seed(5)
+    rows = torch.rand((n, d), generator=g0, device=dev)
+    rows = (rows / rows.norm(dim=1, keepdim=True)).contiguous()
+    q = torch.rand((qb, d), generator=g0, device=dev)
+    q = (q / q.norm(dim=1, keepdim=True)).contiguous()
+    q[5, 7] = float("nan")
+    q[6] = rows[1234]
+    torch.cuda.synchronize()                               # (the library's streams do not wait for torch's)
+    k1 = torch.empty(qb, dtype=torch.int64, device=dev)
+    k2 = torch.empty(qb, dtype=torch.int64, device=dev)
+    ke = torch.empty(qb, dtype=torch.int64, device=dev)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        with fir.Gallery(dev_ptr=rows.data_ptr(), n=n, d=d, metric=0, device=0, stream=st.cuda_stream) as g:
+            g.search_top1_keys_dev(q.data_ptr(), qb, k1.data_ptr(), stream=st.cuda_stream)      # (builds the fp16 copy: synchronises once)
+            st.synchronize()
+            assert g.last_dispatch()["path"] == "mfma"
+            g.search_top1_keys_dev(q.data_ptr(), qb, k1.data_ptr(), stream=st.cuda_stream)
+            g.search_top1_keys_dev(q.data_ptr(), qb, k2.data_ptr(), stream=st.cuda_stream)
+            still_running = not st.query()
+            st.synchronize()
+            stats = g.mfma_stats()
+            g.set_large_batch_mfma(0)
+            g.search_top1_keys_dev(q.data_ptr(), qb, ke.data_ptr(), stream=st.cuda_stream)
+            st.synchronize()
+    assert still_running, "the calls returned only after their work was done: something synchronised"
+    assert torch.equal(k1, ke) and torch.equal(k2, ke)
+    idx, _ = fir.keys_unpack(k1.cpu().numpy().view(np.uint64))
+    assert idx[5] == -1 and idx[6] == 1234
+    assert 3 <= stats["fallback_queries"] <= 6, stats     # the NaN query of each of the three calls went to the exact device scan

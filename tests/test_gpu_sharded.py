@@ -131,7 +131,7 @@ def test_argument_errors(fir):
 
 
 @pytest.mark.parametrize("step", [1, 2])
-def test_a_failing_shard_fails_the_call_on_every_entry_point_and_never_blocks(fir, oracle, step):
+def test_a_failing_shard_fails_the_call_on_every_entry_point_and_never_blocks(fir, fir_audit, oracle, step):
     """Failure semantics (include/fir_amd.h, 'Failure semantics of every sharded handle'; the reference's "-1, never block",
     ann.cpp:113-126): shard 3 of 8 is made to fail -- its scan after the buffers were agreed on (step 1: the rank still enters
     the exchange, with FIR_KEY_NONE keys and a poisoned status element) or its device's buffer growth (step 2: the one-int
@@ -143,14 +143,18 @@ def test_a_failing_shard_fails_the_call_on_every_entry_point_and_never_blocks(fi
     q, _ = synth.make_queries(57, rows, 11, L2)
     calls = [lambda s: s.search_top1(q), lambda s: s.search_topk(q, 5), lambda s: s.classify_top1(q)]
     for call in calls:
-        with fir.ShardedGallery(rows, labels, fir.METRIC_L2, devices=[0], shards_per_device=8, fail_shard=4, fail_step=step, timeout_ms=20000) as s:
-            with pytest.raises(fir.FirError) as e:
+        # (the injection hooks live in the audit build only: libfir_amd_audit.so)
+        with fir_audit.ShardedGallery(rows, labels, fir.METRIC_L2, devices=[0], shards_per_device=8, fail_shard=4, fail_step=step, timeout_ms=20000) as s:
+            with pytest.raises(fir_audit.FirError) as e:
                 call(s)
             assert e.value.code == -3, (e.value.code, str(e.value))            # FIR_ERR_NOMEM, the injected error
             for again in calls:                                               # closed: no collective is attempted any more
-                with pytest.raises(fir.FirError) as e2:
+                with pytest.raises(fir_audit.FirError) as e2:
                     again(s)
                 assert e2.value.code == -5                                    # FIR_ERR_STATE
+    with pytest.raises(fir.FirError) as e3:                                   # the shipped library has no such hook and says so
+        fir.ShardedGallery(rows, labels, fir.METRIC_L2, devices=[0], shards_per_device=8, fail_shard=4, fail_step=step)
+    assert e3.value.code == -1
     with fir.ShardedGallery(rows, labels, fir.METRIC_L2, devices=[0], shards_per_device=8) as s:     # a fresh handle works
         idx, dist = s.search_top1(q)
         cls, _, _ = s.classify_top1(q)
@@ -159,7 +163,7 @@ def test_a_failing_shard_fails_the_call_on_every_entry_point_and_never_blocks(fi
     assert np.array_equal(cls, np.where(eidx >= 0, labels[np.maximum(eidx, 0)], -1))
 
 
-def test_a_failing_shard_in_the_asynchronous_device_pointer_call(fir):
+def test_a_failing_shard_in_the_asynchronous_device_pointer_call(fir, fir_audit):
     """fir_sharded_search_top1_keys_dev returns before the exchange has run: the failing rank gets its error from the call, the
     exchange still happens (nobody is left waiting in it), and fir_sharded_sync reports the closed handle."""
     torch = pytest.importorskip("torch")
@@ -169,11 +173,11 @@ def test_a_failing_shard_in_the_asynchronous_device_pointer_call(fir):
     q, _ = synth.make_queries(58, rows, qb, L2)
     rt, qt = torch.from_numpy(rows).to(dev), torch.from_numpy(q).to(dev)
     keys = torch.empty(qb, device=dev, dtype=torch.int64)
-    with fir.ShardedGallery(dev_ptr=rt.data_ptr(), n=n, d=d, metric=fir.METRIC_L2, devices=[0], shards_per_device=4, fail_shard=2, fail_step=1) as s:
-        with pytest.raises(fir.FirError) as e:
+    with fir_audit.ShardedGallery(dev_ptr=rt.data_ptr(), n=n, d=d, metric=fir.METRIC_L2, devices=[0], shards_per_device=4, fail_shard=2, fail_step=1) as s:
+        with pytest.raises(fir_audit.FirError) as e:
             s.search_top1_keys_dev(qt.data_ptr(), qb, keys.data_ptr())
         assert e.value.code == -3
-        with pytest.raises(fir.FirError) as e2:
+        with pytest.raises(fir_audit.FirError) as e2:
             s.sync()
         assert e2.value.code == -5
     with fir.ShardedGallery(dev_ptr=rt.data_ptr(), n=n, d=d, metric=fir.METRIC_L2, devices=[0], shards_per_device=4) as s:
