@@ -77,6 +77,8 @@ SYMBOLS = [
     ("fir_gemm_search_few_keys_dev", C.c_int, [_vp, _vp, C.c_int32, _vp, _vp]),
     ("fir_gemm_stats", C.c_int, [_vp, _i64p, _i64p]),
     ("fir_gemm_stats_ex", C.c_int, [_vp, _i64p]),
+    ("fir_gemm_uncertified_notes", C.c_int, [_vp, _f32p, _i32p]),
+    ("fir_gallery_mfma_uncertified_notes", C.c_int, [_vp, _f32p, _i32p]),
     ("fir_dem_pivot_table", C.c_int, [_vp, C.c_int32, C.c_int32, _vp, _vp, _vp, _i32p]),
     ("fir_dem_create", C.c_int, [_vp, C.c_int32, C.c_int32, C.POINTER(_vp)]),
     ("fir_dem_destroy", C.c_int, [_vp]),
@@ -256,6 +258,12 @@ class Gallery:
         o = (C.c_int64 * 3)()
         _check(lib().fir_gallery_mfma_stats_ex(self._h, o))
         return {"passes": o[0], "second_pass_queries": o[1], "fallback_queries": o[2]}
+
+    def uncertified_notes(self):
+        """the first (up to 8) queries whose first certificate did not hold: [list entries asked for, bound, smallest stored proxy, |q|^2]"""
+        o, c = (C.c_float * 32)(), C.c_int32()
+        _check(lib().fir_gallery_mfma_uncertified_notes(self._h, o, C.byref(c)))
+        return [[float(o[4 * i + j]) for j in range(4)] for i in range(c.value)]
 
     def memory_bytes(self):
         t, f, r, sc = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()

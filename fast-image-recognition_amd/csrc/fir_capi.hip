@@ -1088,6 +1088,13 @@ int fir_gallery_mfma_stats_ex(fir_gallery* g, int64_t out[3]) {
     return FIR_OK;
 }
 
+int fir_gallery_mfma_uncertified_notes(fir_gallery* g, float out[32], int32_t* count) {
+    if (!g || !out || !count) return fail(FIR_ERR_ARG, "NULL argument");
+    *count = 0;
+    if (!g->gemm) return FIR_OK;
+    return fir_gemm_uncertified_notes(g->gemm, out, count);
+}
+
 int fir_gallery_mfma_stats(fir_gallery* g, int64_t* passes, int64_t* fallback_queries) {
     int64_t o[3];
     const int rc = fir_gallery_mfma_stats_ex(g, o);

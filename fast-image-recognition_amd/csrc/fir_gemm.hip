@@ -694,11 +694,13 @@ __global__ void __launch_bounds__(64) k_gemm_qprep_f16(const float* __restrict__
         qinv[qi] = qi >= nq ? 0.f : bad ? __builtin_nanf("") : ldexpf(1.0f, -sh - gallery_exp);
         if (counts) counts[qi] = 0;
         if (win) {                                                   // (k_gemm_adapt_init)
-            if (qi >= nq) { win[qi] = 0.f; t_bits[qi] = 0u; }
+            // (t_bits is the word the ranks exchange through memory-side atomics: it is only ever touched by atomics, so that no XCD's L2
+            // holds a line of it that an atomic could be served from)
+            if (qi >= nq) { win[qi] = 0.f; atomicExch(&t_bits[qi], 0u); }
             else {
                 const float w = 2.5f * e_rel * (qn + gnorm_max_p[0]);
                 win[qi] = w + fabsf(w) * 1e-6f + 1e-30f;
-                t_bits[qi] = 0x7F800000u;
+                atomicExch(&t_bits[qi], 0x7F800000u);
             }
         }
     }
@@ -1188,6 +1190,7 @@ __global__ void __launch_bounds__(64) k_gemm_rerank(const unsigned long long* __
             const float t = tau[q];
             fb.tau2[fb.q_base + q] = c < t ? c : t;
             fb.list[atomicAdd(&fb.state[0], 1)] = fb.q_base + q;
+            fb_note(fb.state, cnt, t, p1, qn);
         }
     }
 }
@@ -1414,6 +1417,7 @@ __global__ void __launch_bounds__(64) k_gemm_rerank_topk(const unsigned long lon
             const float t = tau[q];
             fb.tau2[fb.q_base + q] = c < t ? c : t;
             fb.list[atomicAdd(&fb.state[0], 1)] = fb.q_base + q;
+            fb_note(fb.state, cnt, t, pk, qn);
         }
     }
 }
@@ -1472,11 +1476,12 @@ __global__ void __launch_bounds__(256) k_gemm_adapt_init(float* __restrict__ win
     t_bits[q] = 0x7F800000u;
 }
 // ... and, after the pass, the bound the re-rank's certificate gets: every row that was not appended has a proxy >= tau
-__global__ void __launch_bounds__(256) k_gemm_adapt_final(const unsigned int* __restrict__ t_bits, const float* __restrict__ qnorm, float* __restrict__ tau,
+__global__ void __launch_bounds__(256) k_gemm_adapt_final(unsigned int* __restrict__ t_bits, const float* __restrict__ qnorm, float* __restrict__ tau,
                                                            int nq_total, int nq_valid) {
     const int q = blockIdx.x * 256 + threadIdx.x;
     if (q >= nq_total) return;
-    tau[q] = q < nq_valid ? __uint_as_float(t_bits[q]) - qnorm[q] : -__builtin_huge_valf();      // the same subtraction the kernel compares against
+    // (read by an atomic, like every other access to these words)
+    tau[q] = q < nq_valid ? __uint_as_float(atomicMin(&t_bits[q], 0xFFFFFFFFu)) - qnorm[q] : -__builtin_huge_valf();      // the same subtraction the kernel compares against
 }
 
 }  // namespace
@@ -1517,7 +1522,7 @@ struct fir_gemm {
     int* ok = nullptr; size_t ok_cap = 0;  // certificate flags of one call
     int sample_rows = 0;
     // uncertified queries, handled on the device in stream order (fir_gemm_fb.h)
-    int* fb_state = nullptr;              // int[8]: count, count2, -, -, running totals (2 x 64 bit)
+    int* fb_state = nullptr;              // int[kFbStateWords]: count, count2, notes taken, -, running totals (2 x 64 bit), the first uncertified queries' numbers (fir_gemm_fb.h)
     int* fb_list = nullptr;               // [ok_cap] queries the first certificate did not hold for
     int* fb_list2 = nullptr;              // [ok_cap] ... still uncertified after the second-chance rounds
     float* fb_tau2 = nullptr;             // [ok_cap] the bound a second pass may append below
@@ -1657,8 +1662,8 @@ int fir_gemm_create_range_ex_(fir_gallery* g, int32_t precision, int32_t end_pos
     m->rt_sample_rows = (int)std::min<int64_t>(np, std::max<int64_t>(kMinSampleRows, np / 32));    // n/16 .. n/48 measured: 1.022 / 1.038 / 1.028 M queries/s at 1M x 512
     if (const char* w = fir_knob_("FIR_GEMM_SAMPLE_DIV"))      // experiments
         m->rt_sample_rows = (int)std::min<int64_t>(np, std::max<int64_t>(kMinSampleRows, np / std::max(1, std::atoi(w))));
-    if (e == hipSuccess) e = hipMalloc((void**)&m->fb_state, 8 * sizeof(int));
-    if (e == hipSuccess) e = hipMemset(m->fb_state, 0, 8 * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void**)&m->fb_state, kFbStateWords * sizeof(int));
+    if (e == hipSuccess) e = hipMemset(m->fb_state, 0, kFbStateWords * sizeof(int));
     if (e == hipSuccess) e = hipMalloc((void**)&m->sc_qnorm, kScQueries * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&m->sc_qmul, kScQueries * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&m->sc_qinv, kScQueries * sizeof(float));
@@ -1825,6 +1830,22 @@ int fir_gemm_stats_ex(const fir_gemm* m, int64_t out[3]) {
     out[0] = m->passes;
     out[1] = (int64_t)tot[0];
     out[2] = (int64_t)tot[1];
+    return FIR_OK;
+}
+
+// What the first (up to 8) queries whose FIRST certificate did not hold looked like, since this state was created: per query four
+// floats -- entries its candidate list was asked to take (4096 fit), the bound the pass appended below (|g|^2 - 2 q.g units), the
+// smallest stored proxy (the K-th smallest for the K nearest), |q|^2. *count = how many of the 8 slots are filled. Diagnostics for
+// a benchmark line: a bound of +inf with a million entries is a pass that never found its threshold, a finite one with a few
+// thousand a threshold that stayed loose.
+int fir_gemm_uncertified_notes(const fir_gemm* m, float out[32], int32_t* count) {
+    if (!m || !out || !count) return gemm_fail(FIR_ERR_ARG, "NULL argument");
+    GEMM_HIP(hipSetDevice(m->v.device));
+    GEMM_HIP(hipDeviceSynchronize());
+    int h[kFbStateWords];
+    GEMM_HIP(hipMemcpy(h, m->fb_state, sizeof h, hipMemcpyDeviceToHost));
+    *count = h[2] < 8 ? h[2] : 8;
+    std::memcpy(out, h + 8, 32 * sizeof(float));
     return FIR_OK;
 }
 

@@ -347,6 +347,10 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
                         } else {
                             const int slot = atomicAdd(&counts[q], 1);
                             if (slot < kListCap) lists[(size_t)q * kListCap + slot] = key;
+                            // the list is full: this query is uncertified whatever else happens (fir_gemm_fb.h gives it a second pass), so the
+                            // workgroup stops appending for it -- a pass whose bound stays loose must not turn into millions of atomics on
+                            // one counter (~11 ns each: a whole gallery's worth is 11 ms). The next lowering of T writes tq_s again.
+                            else if (MODE == 3) tq_s[q] = -__builtin_huge_valf();
                         }
                     }
                 }

@@ -24,8 +24,19 @@
 constexpr int kScQueries = 2 * kQT;      // queries of one second-chance round (one pair of passes)
 constexpr int kScRounds = 4;             // second-chance rounds per call at most; the rest of a longer list goes to the exact scan
 
-// device words of one fir_gemm (int[8]): [0] count, [1] count2 -- cleared at the start of every call --, [4..5] and [6..7]: running
-// totals (64-bit) of queries that took a second pass / the exact device scan
+// device words of one fir_gemm (int[kFbStateWords]): [0] count, [1] count2 -- cleared at the start of every call --, [2] notes taken,
+// [4..5] and [6..7]: running totals (64-bit) of queries that took a second pass / the exact device scan, [8..39]: four floats for each
+// of the first eight uncertified queries of the state's life (fir_gemm_uncertified_notes)
+constexpr int kFbStateWords = 40;
+__device__ __forceinline__ void fb_note(int* state, int cnt, float bound, float smallest, float qn) {
+    if (state[2] < 8) {                                            // (racy on purpose: a cheap filter in front of the atomic)
+        const int i = atomicAdd(&state[2], 1);
+        if (i < 8) {
+            float* o = (float*)(state + 8) + 4 * i;
+            o[0] = (float)cnt; o[1] = bound; o[2] = smallest; o[3] = qn;
+        }
+    }
+}
 struct RerankFb {
     int* state;          // GemmFb words
     int* list;           // first pass: uncertified queries are appended here (index within the call)

@@ -285,6 +285,11 @@ int fir_gemm_stats(const fir_gemm* m, int64_t* passes, int64_t* fallback_queries
 /* out[0] = passes, out[1] = queries whose FIRST certificate did not hold (list overflow, window reaching the bound, NaN),
  * out[2] = queries the exact device scan answered (= fallback_queries above). */
 int fir_gemm_stats_ex(const fir_gemm* m, int64_t out[3]);
+/* Diagnostics: the first (up to 8) queries of this state's life whose first certificate did not hold -- per query four floats:
+ * entries its candidate list was asked to take (4096 fit), the bound the pass appended below, the smallest stored proxy (K-th
+ * smallest for the K nearest), |q|^2. *count = filled slots. Waits for the device. */
+int fir_gemm_uncertified_notes(const fir_gemm* m, float out[32], int32_t* count);
+int fir_gallery_mfma_uncertified_notes(fir_gallery* g, float out[32], int32_t* count);   /* ... of the automatic dispatch's whole-row state */
 /* The same counters for the matrix-core states a gallery's AUTOMATIC dispatch has built (whole rows and feature prefixes),
  * summed: fallback_queries = queries it could not certify and sent through the exact scan (results identical either way). */
 int fir_gallery_mfma_stats(fir_gallery* g, int64_t* passes, int64_t* fallback_queries);
