@@ -358,12 +358,14 @@ def main():
             p.profile_enable(True)
         if m.sh is not None:
             m.sh.profile_enable(True)
-        fb0 = sum(p.mfma_stats()["fallback_queries"] for p in m.parts)
+        st0 = [p.mfma_stats() for p in m.parts]
         t0 = time.perf_counter()
         for _ in range(steps):
             m.step(q, qb, keys)
         fence()
         elapsed = max_over_ranks(time.perf_counter() - t0)
+        if m.sh is not None:
+            m.sh.sync()                      # the asynchronous calls' sticky status: a peer's failure during the loop surfaces here, not never
         kernel_ms = np.concatenate([p.profile_read()[0] for p in m.parts]) if m.parts else np.zeros(0)
         exch_ms = m.sh.profile_read() if m.sh is not None else np.zeros(0)
         for p in m.parts:
@@ -371,7 +373,10 @@ def main():
         if m.sh is not None:
             m.sh.profile_enable(False)
         disp = m.g.last_dispatch()
-        disp["fallback_queries"] = sum(p.mfma_stats()["fallback_queries"] for p in m.parts) - fb0     # queries of the timed steps the certificate sent to the exact scan
+        st1 = [p.mfma_stats() for p in m.parts]
+        # queries of the timed steps whose first certificate did not hold (second matrix-core pass) / that the exact device scan answered
+        disp["second_pass_queries"] = sum(b["second_pass_queries"] - a["second_pass_queries"] for a, b in zip(st0, st1))
+        disp["fallback_queries"] = sum(b["fallback_queries"] - a["fallback_queries"] for a, b in zip(st0, st1))
         return elapsed, kernel_ms, exch_ms, disp
 
     n, qb = args.rows, args.batch
@@ -491,7 +496,7 @@ def main():
                 "path_note": "fp16 MFMA (one term, power-of-two-scaled operands, 128 queries per gallery read) nominates rows, the reference's f32 arithmetic re-ranks every row "
                              "inside the rounding window, a rounding-error certificate proves the rest cannot win, uncertified queries go through the exact scan" if hd["path"] == "mfma" else "exact streaming scan",
                 "identical_keys_to_exact_scan": identical,
-                "fallback_queries_in_timed_steps": hd.get("fallback_queries"),
+                "fallback_queries_in_timed_steps": hd.get("fallback_queries"), "second_pass_queries_in_timed_steps": hd.get("second_pass_queries"),
                 "hbm_bytes_held": mem_report,
                 "planted_queries_found": planted_ok,
                 "row_sharding": f"{world} rank(s) x {args.shards_per_device} shard(s), {m_n} rows on this rank",

@@ -181,7 +181,15 @@ scan_fn pick_fast(int epi, int qb, int metric, int start, int end, int dp4, size
     if (need <= kMaxQueryTileLds) {                        // above 64 KiB the launch opts in (run_pass)
         if (lds_bytes) *lds_bytes = need;
         if (qb == 8) return (scan_fn)k_scan_l2_lds<1, FIR_FAST_U, FIR_FAST_WPS>;
-        return (scan_fn)k_scan_l2_lds<2, FIR_FAST_U, FIR_FAST_WPS>;
+        // 16 queries per read: two rows per lane (fir_kernels.h, l2_chunk_lds). FIR_SCAN16_FORM (experiments): 0 = one row per lane (rounds 1-3)
+        static const int form16 = fir_knob_("FIR_SCAN16_FORM") ? std::atoi(fir_knob_("FIR_SCAN16_FORM")) : 1;
+        switch (form16) {
+            case 0: return (scan_fn)k_scan_l2_lds<2, FIR_FAST_U, FIR_FAST_WPS>;
+            case 2: return (scan_fn)k_scan_l2_lds<2, 8, 3, false, 2>;
+            case 3: return (scan_fn)k_scan_l2_lds<2, 4, 3, false, 2>;
+            case 4: return (scan_fn)k_scan_l2_lds<2, 2, 4, false, 2>;
+            default: return (scan_fn)k_scan_l2_lds<2, 4, 4, false, 2>;
+        }
     }
 #endif
     if (qb == 8) return (scan_fn)k_scan_l2_fast<1, FIR_FAST_U, FIR_FAST_WPS>;

@@ -163,9 +163,14 @@ __device__ __forceinline__ double2 cls_ld_nt(const double2* p) {
 // the vector pipes become the bound and a query costs about half the time. Every load group is used for the tiles in turn, each
 // with its own sums; per (row, query) the operations and their order are unchanged.
 // BLOCK = threads per workgroup.
-template <int kClsU, int NT, int BLOCK = kBlock>
-__global__ void __launch_bounds__(BLOCK, NT > 1 ? 2 : 4) k_cls_scan_lds(const double2* __restrict__ gal2, const double* __restrict__ qn_tiles, int64_t nt,
-                                                                          int tiles, int dp2, int waves, int nq_total, double* __restrict__ sums_base) {
+// R = tiles of 64 training rows per wave and step (a lane owns R rows): every LDS read of a query value then serves R rows. With one row
+// per lane a feature of one query tile is four broadcast ds_read_b128 against 24 f64 operations -- at two tiles per read the CU's LDS
+// pipe is two thirds busy when the vector pipes are full, and with only two waves per SIMD the reads' latency under that load shows
+// (profiles/r04_k3_*.txt); two rows per lane halve the LDS traffic per operation and double the work behind every read.
+// WPS = waves per SIMD the launch bounds ask for (registers: 512 / WPS per lane).
+template <int kClsU, int NT, int BLOCK = kBlock, int R = 1, int WPS = (NT > 1 ? 2 : 4)>
+__global__ void __launch_bounds__(BLOCK, WPS) k_cls_scan_lds(const double2* __restrict__ gal2, const double* __restrict__ qn_tiles, int64_t nt,
+                                                                            int tiles, int dp2, int waves, int nq_total, double* __restrict__ sums_base) {
     extern __shared__ __attribute__((aligned(16))) double2 lqd[];          // per tile: [(feature k) * 4 + i] = queries 2i, 2i + 1 of feature k
     const int lane = threadIdx.x & 63;
     const int gw = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
@@ -186,21 +191,28 @@ __global__ void __launch_bounds__(BLOCK, NT > 1 ? 2 : 4) k_cls_scan_lds(const do
     int zero_v;
     asm volatile("v_mov_b32 %0, 0" : "=v"(zero_v));
     const double2* lq0 = lqd + zero_v;
-    for (int t = gw; t < tiles; t += waves) {
-        const double2* p = gal2 + (size_t)t * dp2 * 64 + lane;
-        double acc[NT][8];
+    const int tsteps = (tiles + R - 1) / R;                                // a wave's step: R consecutive tiles (the last one may repeat the last tile)
+    for (int ts = gw; ts < tsteps; ts += waves) {
+        const double2* p[R];
 #pragma unroll
-        for (int h = 0; h < NT; ++h)
+        for (int r = 0; r < R; ++r) {
+            const int t = ts * R + r < tiles ? ts * R + r : tiles - 1;
+            p[r] = gal2 + (size_t)t * dp2 * 64 + lane;
+        }
+        double acc[R][NT][8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) acc[h][q] = 0.0;
-        // COUNT chunks (two features each) from chunk c on of this lane against one tile's eight queries; the LDS reads run one feature ahead
-        // (`cur` = the tile's query values of the NEXT feature to be used: carried from call to call, so that switching between the tiles
-        // of a read does not restart the read-ahead)
-        auto run = [&](double (&a)[8], double2 (&cur)[4], const double2* lq, const double2* g, int c, auto count_tag) {
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int h = 0; h < NT; ++h)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc[r][h][q] = 0.0;
+        // COUNT chunks (two features each) from chunk c on of this lane's R rows against one tile's eight queries; the LDS reads run one feature
+        // ahead (`cur` = the tile's query values of the NEXT feature to be used: carried from call to call, so that switching between the tiles
+        // of a read does not restart the read-ahead). Per (row, query) the operations and their order are the reference's whatever R and NT are.
+        auto run = [&](int h, double2 (&cur)[4], const double2* lq, const double2 (&g)[R][kClsU], int c, auto count_tag) {
             constexpr int COUNT = decltype(count_tag)::value;
 #pragma unroll
             for (int u = 0; u < COUNT; ++u) {
-                const double gv[2] = {g[u].x, g[u].y};
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     double2 nx[4];
@@ -208,11 +220,15 @@ __global__ void __launch_bounds__(BLOCK, NT > 1 ? 2 : 4) k_cls_scan_lds(const do
 #pragma unroll
                     for (int i = 0; i < 4; ++i) nx[i] = lq[k1 * 4 + i];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const double d0 = gv[j] - cur[i].x;                         // classification.cpp:132-137
-                        const double d1 = gv[j] - cur[i].y;
-                        a[2 * i] = a[2 * i] + d0 * d0;                              // :141
-                        a[2 * i + 1] = a[2 * i + 1] + d1 * d1;
+                    for (int r = 0; r < R; ++r) {
+                        const double gv = j == 0 ? g[r][u].x : g[r][u].y;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const double d0 = gv - cur[i].x;                        // classification.cpp:132-137
+                            const double d1 = gv - cur[i].y;
+                            acc[r][h][2 * i] = acc[r][h][2 * i] + d0 * d0;          // :141
+                            acc[r][h][2 * i + 1] = acc[r][h][2 * i + 1] + d1 * d1;
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -222,10 +238,12 @@ __global__ void __launch_bounds__(BLOCK, NT > 1 ? 2 : 4) k_cls_scan_lds(const do
         };
         int c = 0;
         const int ng = dp2 / kClsU;
-        double2 g[kClsU];
+        double2 g[R][kClsU];
         if (ng > 0) {
 #pragma unroll
-            for (int u = 0; u < kClsU; ++u) g[u] = cls_ld_nt(p + (size_t)u * 64);
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int u = 0; u < kClsU; ++u) g[r][u] = cls_ld_nt(p[r] + (size_t)u * 64);
         }
         double2 curq[NT][4];
 #pragma unroll
@@ -233,30 +251,40 @@ __global__ void __launch_bounds__(BLOCK, NT > 1 ? 2 : 4) k_cls_scan_lds(const do
 #pragma unroll
             for (int i = 0; i < 4; ++i) curq[h][i] = lq0[(size_t)h * (n2 + 4) + i];
         for (int gi = 0; gi < ng; ++gi, c += kClsU) {
-            double2 nxg[kClsU];
+            double2 nxg[R][kClsU];
             const int gn = gi + 1 < ng ? gi + 1 : gi;                           // the last group re-reads itself (keeps the loop branch-free)
 #pragma unroll
-            for (int u = 0; u < kClsU; ++u) nxg[u] = cls_ld_nt(p + (size_t)(gn * kClsU + u) * 64);
+            for (int r = 0; r < R; ++r)
 #pragma unroll
-            for (int h = 0; h < NT; ++h) run(acc[h], curq[h], lq0 + (size_t)h * (n2 + 4), g, c, std::integral_constant<int, kClsU>());
+                for (int u = 0; u < kClsU; ++u) nxg[r][u] = cls_ld_nt(p[r] + (size_t)(gn * kClsU + u) * 64);
 #pragma unroll
-            for (int u = 0; u < kClsU; ++u) g[u] = nxg[u];
+            for (int h = 0; h < NT; ++h) run(h, curq[h], lq0 + (size_t)h * (n2 + 4), g, c, std::integral_constant<int, kClsU>());
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int u = 0; u < kClsU; ++u) g[r][u] = nxg[r][u];
         }
         for (; c < dp2; ++c) {
-            const double2 gt = cls_ld_nt(p + (size_t)c * 64);
+            double2 gt[R][kClsU];
 #pragma unroll
-            for (int h = 0; h < NT; ++h) run(acc[h], curq[h], lq0 + (size_t)h * (n2 + 4), &gt, c, std::integral_constant<int, 1>());
+            for (int r = 0; r < R; ++r) gt[r][0] = cls_ld_nt(p[r] + (size_t)c * 64);
+#pragma unroll
+            for (int h = 0; h < NT; ++h) run(h, curq[h], lq0 + (size_t)h * (n2 + 4), gt, c, std::integral_constant<int, 1>());
         }
-        const int64_t row = (int64_t)t * kTileRows + lane;
-        if (row < nt) {
 #pragma unroll
-            for (int h = 0; h < NT; ++h) {
-                const int q0 = (tile0 + h) * 8;
-                const int nq = nq_total - q0 < 8 ? nq_total - q0 : 8;
-                double* sums = sums_base + (size_t)q0 * nt;
+        for (int r = 0; r < R; ++r) {
+            const int t = ts * R + r;
+            const int64_t row = (int64_t)t * kTileRows + lane;
+            if (t < tiles && row < nt) {
 #pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    if (q < nq) sums[(size_t)q * nt + row] = acc[h][q];
+                for (int h = 0; h < NT; ++h) {
+                    const int q0 = (tile0 + h) * 8;
+                    const int nq = nq_total - q0 < 8 ? nq_total - q0 : 8;
+                    double* sums = sums_base + (size_t)q0 * nt;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        if (q < nq) sums[(size_t)q * nt + row] = acc[r][h][q];
+                }
             }
         }
     }
@@ -783,32 +811,69 @@ int cls_scan(fir_cls* c, const double* queries, int32_t qb) {
         hipLaunchKernelGGL(k_cls_prep_query_tiles, dim3((unsigned)(((size_t)ntile * kk * 8 + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, dq, qb, c->d,
                            c->dp2, c->avg, c->qn);
         const bool one_tile = fir_knob_("FIR_CLS_ONE_TILE") != nullptr;
-        const bool two = ntile >= 2 && 2 * lds_tile <= 150 * 1024 && !one_tile;
-        if (two) {
+        if (const char* form = fir_knob_("FIR_CLS_FORM")) {
+            // experiments (profiles/r04_k3_*.txt): "NT,R,U,BLOCK,WPS" = query tiles per read, rows per lane, double2 in flight per row, threads per
+            // workgroup, waves per SIMD of the launch bounds -- one of the instantiations below; the sums are the same bits in every form
+            int fnt = 2, fr = 1, fu = 8, fb = 256, fw = 2;
+            std::sscanf(form, "%d,%d,%d,%d,%d", &fnt, &fr, &fu, &fb, &fw);
+            typedef void (*scan_fn)(const double2*, const double*, int64_t, int, int, int, int, double*);
+            scan_fn fn = nullptr;
+            const char* nm = "?";
+#define FIR_CLS_PICK(NT_, R_, U_, B_, W_) if (fnt == NT_ && fr == R_ && fu == U_ && fb == B_ && fw == W_) { fn = k_cls_scan_lds<U_, NT_, B_, R_, W_>; nm = "fir::k_cls_scan_lds<" #U_ ", " #NT_ ", " #B_ ", " #R_ ", " #W_ ">"; }
+            FIR_CLS_PICK(2, 1, 8, 256, 2) FIR_CLS_PICK(2, 2, 4, 256, 2) FIR_CLS_PICK(2, 2, 8, 256, 2) FIR_CLS_PICK(2, 2, 4, 512, 2) FIR_CLS_PICK(2, 1, 4, 512, 4)
+            FIR_CLS_PICK(3, 1, 8, 512, 2) FIR_CLS_PICK(3, 2, 4, 512, 2) FIR_CLS_PICK(4, 1, 8, 512, 2) FIR_CLS_PICK(4, 2, 4, 512, 2) FIR_CLS_PICK(4, 1, 4, 512, 2)
+            FIR_CLS_PICK(2, 4, 2, 256, 2) FIR_CLS_PICK(2, 2, 2, 256, 2) FIR_CLS_PICK(4, 2, 2, 512, 2)
+#undef FIR_CLS_PICK
+            if (fn && (size_t)fnt * lds_tile <= 150 * 1024) {
+                CLS_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+                const int wpc = fw * 4;                                          // waves per CU the launch bounds (and LDS) allow
+                const int64_t tsteps = (c->tiles + fr - 1) / fr;
+                const int wvf = (int)std::min<int64_t>(std::max<int64_t>((tsteps + fb / 64 - 1) / (fb / 64) * (fb / 64), fb / 64), (int64_t)c->cus * wpc);
+                for (int t0 = 0; t0 < ntile; t0 += 64) {
+                    const int tn = std::min(64, ntile - t0);
+                    cls_prof(c, 0, 0.0, nullptr);
+                    hipLaunchKernelGGL(fn, dim3(wvf / (fb / 64), (tn + fnt - 1) / fnt), dim3(fb), (size_t)fnt * lds_tile, c->stream, c->gal2, c->qn + (size_t)t0 * kk * 8, c->nt,
+                                       (int)c->tiles, c->dp2, wvf, qb - t0 * 8, c->sums + (size_t)t0 * 8 * c->nt);
+                    cls_prof(c, 1, (double)((tn + fnt - 1) / fnt) * ((double)c->tiles * 64.0 * c->dp2 * 16.0) + (double)tn * ((double)kk * 64.0 + 8.0 * 8.0 * (double)c->nt), nm);
+                }
+                CLS_HIP(hipGetLastError());
+                return FIR_OK;
+            }
+        }
+        // Forms by tiles of eight queries per read of the training rows (profiles/r04_k3_forms.txt; 1M x 512, 64 queries, kernel ms per call):
+        // one tile, one row per lane 5.7 (HBM-bound, 0.72 of the peak); two tiles 4.16 (round 3); two tiles, two rows per lane 3.90; four
+        // tiles, two rows per lane 3.74 -- the f64 vector pipes are then 85-90 % busy at the 1.7 GHz the chip holds under this load
+        // (profiles/r04_rocprofv3_pmc_k3.json): that, not the 2.4 GHz issue rate, is the roof. Two rows per lane: every broadcast LDS read of a
+        // query value serves two rows (the LDS pipe was two thirds busy at the vector pipes' full rate). A call is cut into groups of 4, 2, 1
+        // tiles so that no group computes padding tiles.
+        typedef void (*scan_fn)(const double2*, const double*, int64_t, int, int, int, int, double*);
+        struct Form { scan_fn fn; int nt, r, block, wpc; const char* name; };
+        const Form f4 = {k_cls_scan_lds<2, 4, 512, 2, 2>, 4, 2, 512, 8, "fir::k_cls_scan_lds<2, 4, 512, 2, 2>"};
+        const Form f2 = {k_cls_scan_lds<4, 2, 256, 2, 2>, 2, 2, 256, 8, "fir::k_cls_scan_lds<4, 2, 256, 2, 2>"};
+        const Form f1 = {k_cls_scan_lds<8, 1>, 1, 1, 256, 16, "fir::k_cls_scan_lds<8, 1>"};
+        {
             static bool attr_set[64] = {};                     // (per device: the attribute belongs to the device's copy of the code object)
             const int dv = c->device & 63;
             if (!attr_set[dv]) {
-                CLS_HIP(hipFuncSetAttribute((const void*)k_cls_scan_lds<8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+                CLS_HIP(hipFuncSetAttribute((const void*)f4.fn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+                CLS_HIP(hipFuncSetAttribute((const void*)f2.fn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
                 attr_set[dv] = true;
             }
         }
-        // waves per SIMD by launch bounds (one tile per read: four; two tiles: two, 66 KiB of LDS per workgroup at d = 512). Measured at
-        // 1M x 512, eight passes per launch (profiles/r03_k3_sweep.txt): 16 / 12 / 8 waves per CU 5.65 / 5.78 / 5.95 ms with one tile per read
-        // (two tiles: 384-thread workgroups -- three waves per SIMD instead of two -- measured slower, 12.1 / 12.9 against 13.5 / 14.6 k q/s)
-        const int wv = (int)std::min<int64_t>(std::max<int64_t>((c->tiles + 3) / 4 * 4, 4), (int64_t)c->cus * (two ? 8 : 16));
-        const int per = two ? 2 : 1;
-        for (int t0 = 0; t0 < ntile; t0 += 64) {
-            const int tn = std::min(64, ntile - t0);
+        for (int t0 = 0; t0 < ntile;) {
+            const int rem = ntile - t0;
+            const Form& f = (rem >= 4 && 4 * lds_tile <= 150 * 1024 && !one_tile) ? f4 : (rem >= 2 && 2 * lds_tile <= 150 * 1024 && !one_tile) ? f2 : f1;
+            const int groups = std::min(rem / f.nt, 64 / f.nt);                   // at most 64 tiles per launch (blockIdx.y = group of nt tiles)
+            const int tn = groups * f.nt;
+            const int wpb = f.block / 64;
+            const int64_t tsteps = (c->tiles + f.r - 1) / f.r;
+            const int wv = (int)std::min<int64_t>(std::max<int64_t>((tsteps + wpb - 1) / wpb * wpb, wpb), (int64_t)c->cus * f.wpc);
             cls_prof(c, 0, 0.0, nullptr);
-            if (two)
-                hipLaunchKernelGGL((k_cls_scan_lds<8, 2>), dim3(wv / 4, (tn + 1) / 2), dim3(kBlock), 2 * lds_tile, c->stream, c->gal2, c->qn + (size_t)t0 * kk * 8, c->nt,
-                                   (int)c->tiles, c->dp2, wv, qb - t0 * 8, c->sums + (size_t)t0 * 8 * c->nt);
-            else
-                hipLaunchKernelGGL((k_cls_scan_lds<8, 1>), dim3(wv / 4, tn), dim3(kBlock), lds_tile, c->stream, c->gal2, c->qn + (size_t)t0 * kk * 8, c->nt,
-                                   (int)c->tiles, c->dp2, wv, qb - t0 * 8, c->sums + (size_t)t0 * 8 * c->nt);
-            // algorithmic bytes of the launch: every read of the training rows serves `per` tiles of eight queries (+ the query tiles, + the sums written)
-            cls_prof(c, 1, (double)((tn + per - 1) / per) * ((double)c->tiles * 64.0 * c->dp2 * 16.0) + (double)tn * ((double)kk * 64.0 + 8.0 * 8.0 * (double)c->nt),
-                     two ? "fir::k_cls_scan_lds<8, 2>" : "fir::k_cls_scan_lds<8, 1>");
+            hipLaunchKernelGGL(f.fn, dim3(wv / wpb, groups), dim3(f.block), (size_t)f.nt * lds_tile, c->stream, c->gal2, c->qn + (size_t)t0 * kk * 8, c->nt, (int)c->tiles,
+                               c->dp2, wv, std::min(qb - t0 * 8, tn * 8), c->sums + (size_t)t0 * 8 * c->nt);
+            // algorithmic bytes of the launch: every read of the training rows serves nt tiles of eight queries (+ the query tiles, + the sums written)
+            cls_prof(c, 1, (double)groups * ((double)c->tiles * 64.0 * c->dp2 * 16.0) + (double)tn * ((double)kk * 64.0 + 8.0 * 8.0 * (double)c->nt), f.name);
+            t0 += tn;
         }
         CLS_HIP(hipGetLastError());
         return FIR_OK;

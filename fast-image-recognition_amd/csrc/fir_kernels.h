@@ -745,9 +745,13 @@ __device__ __forceinline__ void lds_unit(f2 (&s)[4], const float4* lq, int k, in
 // One chunk (4 features) of one lane against 8*NB queries; the LDS reads run one unit (one
 // feature x 8 queries) ahead of the VALU work: cur = this unit's query values on entry, the next
 // unit's on exit (past the last feature: the zeroed slack chunk).
-template <int NB>
-__device__ __forceinline__ void l2_chunk_lds(f2 (&acc)[NB][4], const float4 g, f2 (&cur)[4], const float4* lq, int c) {
-    const f2 gp[2] = {f2{g.x, g.y}, f2{g.z, g.w}};
+// R rows per lane (R consecutive tiles per wave and step): every unit's two LDS reads then serve R rows -- at 16 queries per read of
+// the gallery the CU's LDS pipe is two thirds busy when the vector pipes run at their full rate (profiles/r04_scan16_forms.txt).
+template <int NB, int R = 1>
+__device__ __forceinline__ void l2_chunk_lds(f2 (&acc)[R][NB][4], const float4 (&g)[R], f2 (&cur)[4], const float4* lq, int c) {
+    f2 gp[R][2];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { gp[r][0] = f2{g[r].x, g[r].y}; gp[r][1] = f2{g[r].z, g[r].w}; }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
 #pragma unroll
@@ -756,8 +760,11 @@ __device__ __forceinline__ void l2_chunk_lds(f2 (&acc)[NB][4], const float4 g, f
             const int nb = b + 1 < NB ? b + 1 : 0;
             const int nk = c * 4 + j + (b + 1 < NB ? 0 : 1);
             lds_unit<NB>(nx, lq, nk, nb);
-            if (j & 1) l2_feat8_v<1>(acc[b], gp[j >> 1], cur);
-            else l2_feat8_v<0>(acc[b], gp[j >> 1], cur);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (j & 1) l2_feat8_v<1>(acc[r][b], gp[r][j >> 1], cur);
+                else l2_feat8_v<0>(acc[r][b], gp[r][j >> 1], cur);
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 4; ++i) cur[i] = nx[i];
@@ -769,7 +776,7 @@ __device__ __forceinline__ void l2_chunk_lds(f2 (&acc)[NB][4], const float4 g, f
 // APPEND = true: instead of a running first minimum, every row whose distance is <= tau[query] is appended (packed key) to
 // that query's candidate list: the distances are the exact ones, so the K nearest rows are the K smallest keys of a list
 // whose threshold came from a row sample (fir_capi.hip, topk_dev) -- the top-K scan at the speed of the top-1 scan.
-template <int NB, int U, int WPS, bool APPEND = false>
+template <int NB, int U, int WPS, bool APPEND = false, int R = 1>
 __global__ void __launch_bounds__(kBlock, WPS) k_scan_l2_lds(const ScanArgs a) {
     constexpr int QB = 8 * NB;
     extern __shared__ __attribute__((aligned(16))) float4 lq[];
@@ -801,72 +808,105 @@ __global__ void __launch_bounds__(kBlock, WPS) k_scan_l2_lds(const ScanArgs a) {
     }
     int32_t* counts = APPEND ? a.counts + (size_t)blockIdx.y * QB : nullptr;
 
-    for (int t = gw; t < a.tiles; t += a.waves) {
+    // a wave's step: R consecutive tiles, a lane owns row `lane` of each (ascending: the running first minimum stays the reference's);
+    // the last step may repeat the last tile (its rows are not looked at twice: the epilogue checks the tile index)
+    const int tsteps = (a.tiles + R - 1) / R;
+    for (int ts = gw; ts < tsteps; ts += a.waves) {
+        const float4* p[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int t = ts * R + r < a.tiles ? ts * R + r : a.tiles - 1;
 #ifdef FIR_DEBUG_TILEMOD   // timing experiments only: every tile reads one of the first few (cache-resident stream)
-        const float4* p = a.gal4 + ((size_t)(t % FIR_DEBUG_TILEMOD) * a.dp4 + c_lo) * 64 + lane;
+            p[r] = a.gal4 + ((size_t)(t % FIR_DEBUG_TILEMOD) * a.dp4 + c_lo) * 64 + lane;
 #else
-        const float4* p = a.gal4 + ((size_t)t * a.dp4 + c_lo) * 64 + lane;
+            p[r] = a.gal4 + ((size_t)t * a.dp4 + c_lo) * 64 + lane;
 #endif
-        f2 acc[NB][4];
+        }
+        f2 acc[R][NB][4];
 #pragma unroll
-        for (int b = 0; b < NB; ++b)
+        for (int r = 0; r < R; ++r)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[b][i] = f2{0.0f, 0.0f};
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[r][b][i] = f2{0.0f, 0.0f};
         f2 cur[4];
         lds_unit<NB>(cur, lqv, c_lo * 4, 0);
 
         int c = c_lo;
 #if FIR_PIPE == 0
         for (; c + U <= c_hi; c += U) {
-            float4 g[U];
-            ld_gallery_group<U>(g, p + (size_t)(c - c_lo) * 64, a.nt != 0);
+            float4 g[R][U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) l2_chunk_lds<NB>(acc, g[u], cur, lqv, c + u);
+            for (int r = 0; r < R; ++r) ld_gallery_group<U>(g[r], p[r] + (size_t)(c - c_lo) * 64, a.nt != 0);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float4 gu[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) gu[r] = g[r][u];
+                l2_chunk_lds<NB, R>(acc, gu, cur, lqv, c + u);
+            }
         }
 #else
         // register double buffer: the next group's loads are in flight while this group is consumed
         {
             const int ng = (c_hi - c_lo) / U;
-            float4 g[U];
+            float4 g[R][U];
             if (ng > 0) {
-                ld_gallery_group<U>(g, p, a.nt != 0);
+#pragma unroll
+                for (int r = 0; r < R; ++r) ld_gallery_group<U>(g[r], p[r], a.nt != 0);
             }
             for (int gi = 0; gi < ng; ++gi, c += U) {
-                float4 nxg[U];
+                float4 nxg[R][U];
                 const int gn = gi + 1 < ng ? gi + 1 : gi;   // the last group re-reads itself (L2 hit; keeps the loop branch-free)
-                ld_gallery_group<U>(nxg, p + (size_t)(gn * U) * 64, a.nt != 0);
 #pragma unroll
-                for (int u = 0; u < U; ++u) l2_chunk_lds<NB>(acc, g[u], cur, lqv, c + u);
+                for (int r = 0; r < R; ++r) ld_gallery_group<U>(nxg[r], p[r] + (size_t)(gn * U) * 64, a.nt != 0);
 #pragma unroll
-                for (int u = 0; u < U; ++u) g[u] = nxg[u];
+                for (int u = 0; u < U; ++u) {
+                    float4 gu[R];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) gu[r] = g[r][u];
+                    l2_chunk_lds<NB, R>(acc, gu, cur, lqv, c + u);
+                }
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int u = 0; u < U; ++u) g[r][u] = nxg[r][u];
             }
         }
 #endif
-        for (; c < c_hi; ++c)
-            l2_chunk_lds<NB>(acc, ld_gallery(p + (size_t)(c - c_lo) * 64, a.nt != 0), cur, lqv, c);
+        for (; c < c_hi; ++c) {
+            float4 gu[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) gu[r] = ld_gallery(p[r] + (size_t)(c - c_lo) * 64, a.nt != 0);
+            l2_chunk_lds<NB, R>(acc, gu, cur, lqv, c);
+        }
 
-        const int64_t row = (int64_t)t * kTileRows + lane;
-        if (row < a.n) {
 #pragma unroll
-            for (int b = 0; b < NB; ++b)
+        for (int r = 0; r < R; ++r) {
+            const int t = ts * R + r;
+            const int64_t row = (int64_t)t * kTileRows + lane;
+            if (t < a.tiles && row < a.n) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float d0 = acc[b][i].x / fcount, d1 = acc[b][i].y / fcount;   // db_features.cpp:40
-                    const int q0 = b * 8 + 2 * i;
-                    if constexpr (APPEND) {
-                        if (d0 <= best_d[q0]) {
-                            const int slot = atomicAdd(&counts[q0], 1);
-                            if (slot < a.k) keys[(size_t)q0 * a.k + slot] = key_pack(d0, (uint32_t)(row + a.row_offset));
+                for (int b = 0; b < NB; ++b)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float d0 = acc[r][b][i].x / fcount, d1 = acc[r][b][i].y / fcount;   // db_features.cpp:40
+                        const int q0 = b * 8 + 2 * i;
+                        if constexpr (APPEND) {
+                            if (d0 <= best_d[q0]) {
+                                const int slot = atomicAdd(&counts[q0], 1);
+                                if (slot < a.k) keys[(size_t)q0 * a.k + slot] = key_pack(d0, (uint32_t)(row + a.row_offset));
+                            }
+                            if (d1 <= best_d[q0 + 1]) {
+                                const int slot = atomicAdd(&counts[q0 + 1], 1);
+                                if (slot < a.k) keys[(size_t)(q0 + 1) * a.k + slot] = key_pack(d1, (uint32_t)(row + a.row_offset));
+                            }
+                        } else {
+                            if (d0 < best_d[q0]) { best_d[q0] = d0; best_i[q0] = (int32_t)row; }           // db_features.cpp:329-332
+                            if (d1 < best_d[q0 + 1]) { best_d[q0 + 1] = d1; best_i[q0 + 1] = (int32_t)row; }
                         }
-                        if (d1 <= best_d[q0 + 1]) {
-                            const int slot = atomicAdd(&counts[q0 + 1], 1);
-                            if (slot < a.k) keys[(size_t)(q0 + 1) * a.k + slot] = key_pack(d1, (uint32_t)(row + a.row_offset));
-                        }
-                    } else {
-                        if (d0 < best_d[q0]) { best_d[q0] = d0; best_i[q0] = (int32_t)row; }           // db_features.cpp:329-332
-                        if (d1 < best_d[q0 + 1]) { best_d[q0 + 1] = d1; best_i[q0 + 1] = (int32_t)row; }
                     }
-                }
+            }
         }
     }
     if constexpr (APPEND) return;

@@ -193,7 +193,11 @@ struct DevCtx {
     std::vector<hipEvent_t> evs;                          // pairs around the RCCL calls (profiling, device slot 0)
     size_t ev_used = 0;
     int32_t* status = nullptr;                            // device: [0] the agreed-growth word, [1] sticky status of the asynchronous calls
-    int32_t* h_status = nullptr;                          // pinned host: [0] what this rank contributes, [1] what came back, [2] sticky read-back
+    int32_t* h_status = nullptr;                          // pinned host: [0] what this rank contributes, [1] what came back, [2] sticky read-back,
+                                                          // [3] the sticky status as the device mirrors it (k_shard_note_status), [4..5] a double (fir_cls_sharded)
+    int32_t* d_hsticky = nullptr;                         // device address of h_status[3]
+    hipEvent_t async_done = nullptr;                      // behind the last asynchronous device-pointer call, on the stream it ran on
+    bool async_pending = false;                           // ... whose status nobody has looked at yet
 };
 
 // What the ranks of a handle have to agree on to stay out of each other's way (see "Failure semantics" above).
@@ -256,6 +260,27 @@ int wait_stream(DevCtx& dc, hipStream_t st, Health& hl) {
     }
 }
 
+// ... and the same for an event (the asynchronous device-pointer call runs on the CALLER's stream: its completion is an event
+// recorded there, not the state of the handle's own stream)
+int wait_event(DevCtx& dc, hipEvent_t ev, Health& hl) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int spins = 0;; ++spins) {
+        const hipError_t q = hipEventQuery(ev);
+        if (q == hipSuccess) return FIR_OK;
+        if (q != hipErrorNotReady) { (void)hipGetLastError(); return comm_dead(dc, hl, FIR_ERR_HIP, hipGetErrorString(q)); }
+        if (dc.comm && (spins & 63) == 63) {
+            ncclResult_t ar = ncclSuccess;
+            if (ncclCommGetAsyncError(dc.comm, &ar) == ncclSuccess && ar != ncclSuccess && ar != ncclInProgress)
+                return comm_dead(dc, hl, FIR_ERR_COMM, ncclGetErrorString(ar));
+        }
+        if (spins > 2000) {
+            if (std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() > hl.timeout_ms)
+                return comm_dead(dc, hl, FIR_ERR_COMM, "an asynchronous call's exchange did not complete within the time-out (a peer is gone or never entered it)");
+            std::this_thread::sleep_for(std::chrono::microseconds(20));
+        }
+    }
+}
+
 // Every rank contributes its local status (FIR_OK or a negative FIR_ERR_*); all of them get the minimum.
 int agree(DevCtx& dc, hipStream_t st, Health& hl, int local_rc, int* agreed) {
     if (!dc.comm) return sh_fail(FIR_ERR_STATE, "sharded handle: no communicator");
@@ -296,15 +321,17 @@ __global__ void k_shard_set_u64(uint64_t* p, uint64_t v) { *p = v; }
 __global__ void k_shard_set_i32(int32_t* p, int32_t v) { *p = v; }
 __global__ void k_shard_set_f64(double* p, double v) { *p = v; }
 // sticky[0] = min(sticky[0], status of the exchange just finished) -- the asynchronous device-pointer call's record
-__global__ void k_shard_note_status(const uint64_t* __restrict__ st, int32_t* __restrict__ sticky) {
+// ... mirrored into pinned host memory, where the next call (or fir_sharded_sync) reads it without a copy of its own
+__global__ void k_shard_note_status(const uint64_t* __restrict__ st, int32_t* __restrict__ sticky, int32_t* __restrict__ host_sticky) {
     const uint64_t v = *st;
     const int32_t c = v == kKeyNone ? 0 : (int32_t)(int64_t)v - 1000;
-    if (c < *sticky) *sticky = c;
+    if (c < *sticky) { *sticky = c; *host_sticky = c; }
 }
 
 }  // namespace
 
 struct fir_sharded {
+    int exchanges_done = 0;          // (audit build's fail_step = 3)
     int d = 0, metric = 0;
     int64_t n_local = 0, first_row = 0;
     int ndev = 0, spd = 1, nranks = 1, rank0 = 0;
@@ -444,6 +471,12 @@ int exchange_keys(fir_sharded* h, int slot, int32_t qb, int32_t k, hipStream_t s
             hipLaunchKernelGGL(k_shard_merge_topk, dim3((qb + 63) / 64), dim3(64), 0, st, dc.gath, h->nranks, qb, k, keys, per + 1, keys + per);
     }
     if (nr != ncclSuccess) return comm_dead(dc, h->health, FIR_ERR_COMM, ncclGetErrorString(nr));
+#ifdef FIR_AUDIT
+    // fail_step = 3 (audit build): from the handle's SECOND exchange on the status element comes BACK poisoned, as if a peer's scan had
+    // failed -- this rank's own work is fine (the first call of a handle grows its buffers in the agreed, blocking step: a test of the
+    // asynchronous path needs one clean call in front)
+    if (inject_here(h, dc, 3) && h->exchanges_done++ >= 1) hipLaunchKernelGGL(k_shard_set_u64, dim3(1), dim3(1), 0, st, keys + per, status_key(FIR_ERR_NOMEM));
+#endif
     if (prof && dc.ev_used + 2 <= dc.evs.size()) {
         (void)hipEventRecord(dc.evs[dc.ev_used + 1], st);
         dc.ev_used += 2;
@@ -572,8 +605,12 @@ int setup_devices(std::vector<DevCtx>& devs, const int32_t* devices, int ndev, i
         SH_HIP(hipSetDevice(dc.device));
         SH_HIP(hipMalloc((void**)&dc.status, 4 * sizeof(int32_t)));
         SH_HIP(hipMemset(dc.status, 0, 4 * sizeof(int32_t)));
-        SH_HIP(hipHostMalloc((void**)&dc.h_status, 8 * sizeof(int32_t), hipHostMallocPortable));
+        SH_HIP(hipHostMalloc((void**)&dc.h_status, 8 * sizeof(int32_t), hipHostMallocPortable | hipHostMallocMapped));
         std::memset(dc.h_status, 0, 8 * sizeof(int32_t));
+        void* dp = nullptr;
+        SH_HIP(hipHostGetDevicePointer(&dp, dc.h_status, 0));
+        dc.d_hsticky = (int32_t*)dp + 3;
+        SH_HIP(hipEventCreateWithFlags(&dc.async_done, hipEventDisableTiming));
     }
     // RCCL writes its version banner to STDOUT when a process's FIRST communicator comes up. The callers of this library print
     // results there (the reference's harnesses, whose output must stay diffable): for that one creation -- serialised by a
@@ -629,6 +666,7 @@ void teardown_devices(std::vector<DevCtx>& devs, bool dead) {
         if (dc.comm) { if (dead) (void)ncclCommAbort(dc.comm); else (void)ncclCommDestroy(dc.comm); }
         (void)hipFree(dc.status);
         if (dc.h_status) (void)hipHostFree(dc.h_status);
+        if (dc.async_done) (void)hipEventDestroy(dc.async_done);
         (void)hipFree(dc.dq); (void)hipFree(dc.parts); (void)hipFree(dc.keys); (void)hipFree(dc.gath); (void)hipFree(dc.cls);
         for (hipEvent_t e : dc.evs) (void)hipEventDestroy(e);
         if (dc.stream) (void)hipStreamDestroy(dc.stream);
@@ -1166,6 +1204,14 @@ int fir_sharded_search_top1_keys_dev(fir_sharded* h, const float* d_queries, int
     DevCtx& dc = h->devs[0];
     SH_HIP(hipSetDevice(dc.device));
     hipStream_t st = stream ? (hipStream_t)stream : dc.stream;
+    // What the previous asynchronous call found, if it is through (no waiting here): a peer's failure closes the handle BEFORE this rank
+    // enqueues another collective that the failed peer -- dead since that call -- will never enter. A previous call that is still in
+    // flight is the caller's to order (fir_amd.h: fir_sharded_sync between asynchronous calls whose failure must not be outrun).
+    if (dc.async_pending && hipEventQuery(dc.async_done) == hipSuccess) {
+        dc.async_pending = false;
+        if (dc.h_status[3] < 0) { h->health.dead = true; h->health.dead_code = dc.h_status[3]; return peer_failed(dc.h_status[3]); }
+    }
+    (void)hipGetLastError();
     const CallBuffers nb = call_buffers(h, dc, qb, 1, false, false);
     if ((rc = grow_agreed(dc, st, h->health, call_grows(dc, nb), inject_here(h, dc, 2), [&]() -> int { return call_alloc(dc, nb); }))) return rc;
     // every rank enters the exchange; one whose scans failed sends FIR_KEY_NONE keys and a poisoned status element, returns its
@@ -1174,8 +1220,10 @@ int fir_sharded_search_top1_keys_dev(fir_sharded* h, const float* d_queries, int
     char mine[512] = "";
     if (local) { strncpy(mine, fir_last_error(), sizeof(mine) - 1); (void)hipGetLastError(); }
     if ((rc = exchange_keys(h, 0, qb, 1, st, local))) return rc;
-    hipLaunchKernelGGL(k_shard_note_status, dim3(1), dim3(1), 0, st, dc.keys + qb, dc.status + 1);
+    hipLaunchKernelGGL(k_shard_note_status, dim3(1), dim3(1), 0, st, dc.keys + qb, dc.status + 1, dc.d_hsticky);
     (void)hipMemcpyAsync(d_keys, dc.keys, (size_t)qb * sizeof(uint64_t), hipMemcpyDeviceToDevice, st);
+    (void)hipEventRecord(dc.async_done, st);           // what fir_sharded_sync (and the next call's look at the status) waits for: `st` may be the caller's stream
+    dc.async_pending = true;
     if (local) { h->health.dead = true; h->health.dead_code = local; fir_set_last_error_(mine); return local; }
     SH_HIP(hipGetLastError());
     return FIR_OK;
@@ -1186,11 +1234,17 @@ int fir_sharded_sync(fir_sharded* h) {
     if (h->health.dead) return dead_handle(h->health);
     for (DevCtx& dc : h->devs) {
         SH_HIP(hipSetDevice(dc.device));
-        int rc = wait_stream(dc, dc.stream, h->health);
-        if (rc) return rc;
-        // the asynchronous calls' record: the worst status any exchange since the last sync came back with
-        SH_HIP(hipMemcpy(dc.h_status + 2, dc.status + 1, sizeof(int32_t), hipMemcpyDeviceToHost));
-        if (dc.h_status[2] < 0) { h->health.dead = true; h->health.dead_code = dc.h_status[2]; return peer_failed(dc.h_status[2]); }
+        int rc;
+        // the last asynchronous call ran on whatever stream its caller named: its completion is the event recorded behind it, waited for
+        // with the same bound as every other wait behind a collective (the handle's own stream says nothing about it)
+        if (dc.async_pending && (rc = wait_event(dc, dc.async_done, h->health))) return rc;
+        dc.async_pending = false;
+        if ((rc = wait_stream(dc, dc.stream, h->health))) return rc;
+        // the asynchronous calls' record: the worst status any exchange since the last sync came back with (device word and its host mirror)
+        SH_HIP(hipMemcpyAsync(dc.h_status + 2, dc.status + 1, sizeof(int32_t), hipMemcpyDeviceToHost, dc.stream));
+        if ((rc = wait_stream(dc, dc.stream, h->health))) return rc;
+        const int32_t worst = std::min(dc.h_status[2], dc.h_status[3]);
+        if (worst < 0) { h->health.dead = true; h->health.dead_code = worst; return peer_failed(worst); }
     }
     return FIR_OK;
 }

@@ -331,7 +331,8 @@ typedef struct fir_shard_opts {
                                  * asynchronous error, the communicator is aborted and the call returns FIR_ERR_COMM          */
     int32_t fail_shard;         /* AUDIT BUILD ONLY (libfir_amd_audit.so, -DFIR_AUDIT; the shipped library returns FIR_ERR_ARG for a
                                  * non-zero value): 1-based index of the local shard whose step fails with FIR_ERR_NOMEM (0: none)   */
-    int32_t fail_step;          /* ... 1: its scan, after the buffers were agreed on; 2: the buffer growth of its device      */
+    int32_t fail_step;          /* ... 1: its scan, after the buffers were agreed on; 2: the buffer growth of its device; 3: from the
+                                 * handle's second exchange on the status element comes back poisoned, as if a PEER's scan had failed */
     int32_t reserved2;
 } fir_shard_opts;
 /* Failure semantics of every sharded handle (the reference's convention is "-1, never block", ann.cpp:113-126): a call in which
@@ -364,9 +365,17 @@ int fir_sharded_search_topk(fir_sharded* h, const float* queries, int32_t qb, in
 int fir_sharded_classify_top1(fir_sharded* h, const float* queries, int32_t qb, int32_t start_pos, int32_t end_pos,
                               int32_t* class_out, int32_t* idx, float* dist);
 /* One process per GPU (one-entry device list): device pointers on that GPU, asynchronous on `stream`
- * (NULL = the handle's); d_keys[qb] <- the reduced keys, identical on every rank. */
+ * (NULL = the handle's); d_keys[qb] <- the reduced keys, identical on every rank.
+ * A rank whose own scans fail gets its error from the call; its peers learn of it from the status element that travels
+ * behind the keys: it lands in a sticky word that (a) the NEXT call on the handle looks at on entry, if the previous call's
+ * work is through by then, and (b) fir_sharded_sync waits for -- on the stream the call actually ran on, with the handle's
+ * time-out -- and reports. A peer that failed skips every later collective, so a caller that must never outrun a failure
+ * calls fir_sharded_sync between asynchronous calls (or at least before it relies on the keys); without it the second of two
+ * back-to-back calls can enqueue a collective the failed peer never enters, which then ends at the time-out of the next sync. */
 int fir_sharded_search_top1_keys_dev(fir_sharded* h, const float* d_queries, int32_t qb, int32_t start_pos,
                                      int32_t end_pos, uint64_t* d_keys, void* stream);
+/* Waits (bounded by timeout_ms) for everything the handle has queued, the asynchronous calls on their callers' streams included,
+ * and returns the worst status any of their exchanges came back with (FIR_OK, or the peer's error: the handle is then closed). */
 int fir_sharded_sync(fir_sharded* h);
 
 /* PNNClassifier::predict_bf (classification.cpp:188-226) over training rows split across GPUs: every shard sums

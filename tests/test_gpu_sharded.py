@@ -187,3 +187,43 @@ def test_a_failing_shard_in_the_asynchronous_device_pointer_call(fir, fir_audit)
         idx0, _ = g.search_top1(q)
     idx, _ = fir.keys_unpack(keys.cpu().numpy().view(np.uint64))
     assert np.array_equal(idx, idx0)
+
+
+def test_a_peers_failure_reaches_the_asynchronous_caller_whatever_stream_it_used(fir_audit):
+    """the asynchronous device-pointer call may run on the CALLER's stream; fir_sharded_sync must wait for THAT
+    work (an event recorded behind the call, with the handle's time-out) before it reads the sticky status, and the next call looks
+    at the status on entry. fail_step = 3 (audit build) poisons the status element that comes back from the handle's second exchange
+    on -- this rank's own scan is fine, it is a peer that 'failed': the call itself succeeds, the sync reports FIR_ERR_NOMEM and
+    closes the handle; with a sleeping kernel in front of the call on the caller's stream the sync still waits for it."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda", 0)
+    n, d, qb = 6000, 64, 16
+    rows = synth.make_gallery(59, n, d, L2)
+    q, _ = synth.make_queries(59, rows, qb, L2)
+    rt, qt = torch.from_numpy(rows).to(dev), torch.from_numpy(q).to(dev)
+    keys = torch.empty(qb, device=dev, dtype=torch.int64)
+    torch.cuda.synchronize()
+    mine = torch.cuda.Stream()                              # a non-blocking stream of the caller's own
+    opts = dict(dev_ptr=rt.data_ptr(), n=n, d=d, metric=fir_audit.METRIC_L2, devices=[0], shards_per_device=4, fail_shard=2, fail_step=3, timeout_ms=20000)
+    with fir_audit.ShardedGallery(**opts) as s:
+        s.search_top1_keys_dev(qt.data_ptr(), qb, keys.data_ptr(), stream=mine.cuda_stream)      # clean (and it grows the buffers: blocking)
+        s.sync()
+        with torch.cuda.stream(mine):
+            torch.cuda._sleep(400_000_000)                  # ~0.2 s of work in front of the call on the caller's stream
+            s.search_top1_keys_dev(qt.data_ptr(), qb, keys.data_ptr(), stream=mine.cuda_stream)  # succeeds: nothing of THIS rank failed
+        assert not mine.query()                             # (the call did not wait)
+        with pytest.raises(fir_audit.FirError) as e:
+            s.sync()
+        assert e.value.code == -3, (e.value.code, str(e.value))   # the peer's error, found on the caller's stream
+        assert mine.query()                                 # the sync waited for the caller's stream's work
+        with pytest.raises(fir_audit.FirError) as e2:       # closed
+            s.search_top1_keys_dev(qt.data_ptr(), qb, keys.data_ptr(), stream=mine.cuda_stream)
+        assert e2.value.code == -5
+    # and without a sync in between: the next call finds the status on entry once the poisoned call's work is through
+    with fir_audit.ShardedGallery(**opts) as s:
+        s.search_top1_keys_dev(qt.data_ptr(), qb, keys.data_ptr(), stream=mine.cuda_stream)
+        s.search_top1_keys_dev(qt.data_ptr(), qb, keys.data_ptr(), stream=mine.cuda_stream)      # the poisoned exchange
+        mine.synchronize()
+        with pytest.raises(fir_audit.FirError) as e3:
+            s.search_top1_keys_dev(qt.data_ptr(), qb, keys.data_ptr(), stream=mine.cuda_stream)
+        assert e3.value.code == -3
