@@ -182,13 +182,15 @@ scan_fn pick_fast(int epi, int qb, int metric, int start, int end, int dp4, size
         if (lds_bytes) *lds_bytes = need;
         if (qb == 8) return (scan_fn)k_scan_l2_lds<1, FIR_FAST_U, FIR_FAST_WPS>;
         // 16 queries per read: two rows per lane (fir_kernels.h, l2_chunk_lds). FIR_SCAN16_FORM (experiments): 0 = one row per lane (rounds 1-3)
-        static const int form16 = fir_knob_("FIR_SCAN16_FORM") ? std::atoi(fir_knob_("FIR_SCAN16_FORM")) : 1;
+        static const int form16 = fir_knob_("FIR_SCAN16_FORM") ? std::atoi(fir_knob_("FIR_SCAN16_FORM")) : 3;
         switch (form16) {
+            // (profiles/r04_scan16_forms.txt: 1M x 512 32.3 k q/s -> 33.2-33.5 k with two rows per lane whatever U / waves per SIMD; the vector
+            // pipes are the bound at the clock the chip holds, not the LDS reads)
             case 0: return (scan_fn)k_scan_l2_lds<2, FIR_FAST_U, FIR_FAST_WPS>;
+            case 1: return (scan_fn)k_scan_l2_lds<2, 4, 4, false, 2>;
             case 2: return (scan_fn)k_scan_l2_lds<2, 8, 3, false, 2>;
-            case 3: return (scan_fn)k_scan_l2_lds<2, 4, 3, false, 2>;
             case 4: return (scan_fn)k_scan_l2_lds<2, 2, 4, false, 2>;
-            default: return (scan_fn)k_scan_l2_lds<2, 4, 4, false, 2>;
+            default: return (scan_fn)k_scan_l2_lds<2, 4, 3, false, 2>;
         }
     }
 #endif
