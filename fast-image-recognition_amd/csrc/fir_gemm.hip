@@ -665,7 +665,7 @@ __global__ void __launch_bounds__(256) k_gemm_pack_gallery_f16(const float4* __r
 __global__ void __launch_bounds__(64) k_gemm_qprep_f16(const float* __restrict__ q, int nq, int d, int gallery_exp, float* __restrict__ qnorm,
                                                         float* __restrict__ qmul, float* __restrict__ qinv, int qstride, int* __restrict__ counts = nullptr,
                                                         float* __restrict__ win = nullptr, unsigned int* __restrict__ t_bits = nullptr,
-                                                        const float* __restrict__ gnorm_max_p = nullptr, float e_rel = 0.f) {
+                                                        const float* __restrict__ gnorm_max_p = nullptr, float e_rel = 0.f, int nslot = 0) {
     const int qi = blockIdx.x;
     float s = 0.f, m = 0.f;
     bool bad = false;
@@ -696,12 +696,15 @@ __global__ void __launch_bounds__(64) k_gemm_qprep_f16(const float* __restrict__
         if (win) {                                                   // (k_gemm_adapt_init)
             // (t_bits is the word the ranks exchange through memory-side atomics: it is only ever touched by atomics, so that no XCD's L2
             // holds a line of it that an atomic could be served from)
-            if (qi >= nq) { win[qi] = 0.f; atomicExch(&t_bits[qi], 0u); }
+            // nslot > 0 (the K nearest rows, k_gemm_proxy_f16x<4, *>): eight slot words per query
+            const unsigned int start = qi >= nq ? 0u : 0x7F800000u;
+            if (qi >= nq) win[qi] = 0.f;
             else {
                 const float w = 2.5f * e_rel * (qn + gnorm_max_p[0]);
                 win[qi] = w + fabsf(w) * 1e-6f + 1e-30f;
-                atomicExch(&t_bits[qi], 0x7F800000u);
             }
+            if (nslot > 0) { for (int sl = 0; sl < 8; ++sl) atomicExch(&t_bits[(size_t)qi * 8 + sl], start); }
+            else atomicExch(&t_bits[qi], start);
         }
     }
 }
@@ -1477,11 +1480,22 @@ __global__ void __launch_bounds__(256) k_gemm_adapt_init(float* __restrict__ win
 }
 // ... and, after the pass, the bound the re-rank's certificate gets: every row that was not appended has a proxy >= tau
 __global__ void __launch_bounds__(256) k_gemm_adapt_final(unsigned int* __restrict__ t_bits, const float* __restrict__ qnorm, float* __restrict__ tau,
-                                                           int nq_total, int nq_valid) {
+                                                           int nq_total, int nq_valid, int nslot = 0) {
     const int q = blockIdx.x * 256 + threadIdx.x;
     if (q >= nq_total) return;
     // (read by an atomic, like every other access to these words)
-    tau[q] = q < nq_valid ? __uint_as_float(atomicMin(&t_bits[q], 0xFFFFFFFFu)) - qnorm[q] : -__builtin_huge_valf();      // the same subtraction the kernel compares against
+    unsigned int t;
+    if (nslot > 0) {                                  // the K nearest rows: the K-th smallest of the eight slot values (K = nslot)
+        unsigned int v[8];
+        for (int sl = 0; sl < 8; ++sl) v[sl] = atomicMin(&t_bits[(size_t)q * 8 + sl], 0xFFFFFFFFu);
+        t = 0xFFFFFFFFu;
+        for (int i = 0; i < 8; ++i) {
+            int rank = 0;
+            for (int j = 0; j < 8; ++j) rank += (v[j] < v[i] || (v[j] == v[i] && j < i)) ? 1 : 0;
+            if (rank == nslot - 1) t = v[i];
+        }
+    } else t = atomicMin(&t_bits[q], 0xFFFFFFFFu);
+    tau[q] = q < nq_valid ? __uint_as_float(t) - qnorm[q] : -__builtin_huge_valf();      // the same subtraction the kernel compares against
 }
 
 }  // namespace
@@ -1541,6 +1555,7 @@ struct fir_gemm {
     int regtile = -1;                     // fp16 full pass through the register-tile kernel: -1 = where it measured faster (rows up to 256 features), 0 / 1 = never / wherever it exists (FIR_GEMM_REGTILE)                  // fp16 full pass: query fragments in registers, gallery through the LDS-DMA ring (FIR_GEMM_REGTILE=0: the LDS-tile kernel)
     int mfma16 = 0;                       // fp16: both operands in the 16-row fragment order, every pass on v_mfma_f32_16x16x32_f16 (fir_gemm_f16x.h): the default since it was
                                           // measured against the 32x32x16 kernels at the same wave tile (profiles/r03_mfma_shape_ab.txt); FIR_GEMM_MFMA16=0 brings those back
+    int adaptive_topk = 1;                // ... and for the K nearest rows (k_gemm_proxy_f16x<4, *>: K slot minima per query); FIR_GEMM_ADAPTIVE_TOPK=0: the sample flow
     int adaptive = 1;                     // 16-row top-1 flow: the append threshold is found during the full pass (k_gemm_proxy_f16x<3, *>), no sample pass
                                           // (profiles/r03_adaptive_threshold.txt); FIR_GEMM_ADAPTIVE=0: the sample flow
     float* awin[2] = {nullptr, nullptr};  // ... its per-query windows
@@ -1575,9 +1590,11 @@ static fir_x_fn pick_x(int mode, bool streamed, bool odd, int dbg = 0) {
     }
     if (mode == 1) return streamed ? (odd ? k_gemm_proxy_f16x<1, 1, 1> : k_gemm_proxy_f16x<1, 1, 0>) : (odd ? k_gemm_proxy_f16x<1, 0, 1> : k_gemm_proxy_f16x<1, 0, 0>);
     if (mode == 3) return streamed ? (odd ? k_gemm_proxy_f16x<3, 1, 1> : k_gemm_proxy_f16x<3, 1, 0>) : (odd ? k_gemm_proxy_f16x<3, 0, 1> : k_gemm_proxy_f16x<3, 0, 0>);
+    if (mode == 4) return streamed ? (odd ? k_gemm_proxy_f16x<4, 1, 1> : k_gemm_proxy_f16x<4, 1, 0>) : (odd ? k_gemm_proxy_f16x<4, 0, 1> : k_gemm_proxy_f16x<4, 0, 0>);
     return streamed ? (odd ? k_gemm_proxy_f16x<2, 1, 1> : k_gemm_proxy_f16x<2, 1, 0>) : (odd ? k_gemm_proxy_f16x<2, 0, 1> : k_gemm_proxy_f16x<2, 0, 0>);
 }
-static const char* name_x(bool streamed, bool odd, bool adaptive = false) {
+static const char* name_x(bool streamed, bool odd, bool adaptive = false, bool slots = false) {
+    if (adaptive && slots) return streamed ? (odd ? "fir::k_gemm_proxy_f16x<4, 1, 1>" : "fir::k_gemm_proxy_f16x<4, 1, 0>") : (odd ? "fir::k_gemm_proxy_f16x<4, 0, 1>" : "fir::k_gemm_proxy_f16x<4, 0, 0>");
     if (adaptive) return streamed ? (odd ? "fir::k_gemm_proxy_f16x<3, 1, 1>" : "fir::k_gemm_proxy_f16x<3, 1, 0>") : (odd ? "fir::k_gemm_proxy_f16x<3, 0, 1>" : "fir::k_gemm_proxy_f16x<3, 0, 0>");
     return streamed ? (odd ? "fir::k_gemm_proxy_f16x<1, 1, 1>" : "fir::k_gemm_proxy_f16x<1, 1, 0>") : (odd ? "fir::k_gemm_proxy_f16x<1, 0, 1>" : "fir::k_gemm_proxy_f16x<1, 0, 0>");
 }
@@ -1649,7 +1666,7 @@ int fir_gemm_create_range_ex_(fir_gallery* g, int32_t precision, int32_t end_pos
         if (e == hipSuccess) e = hipMalloc((void**)&m->smin[b], (size_t)kRtSubsets * kPasses * kQT * sizeof(unsigned int));   // top-K: one minimum per subset
         if (e == hipSuccess) e = hipMalloc((void**)&m->tau[b], kPasses * kQT * sizeof(float));
         if (e == hipSuccess) e = hipMalloc((void**)&m->awin[b], kPasses * kQT * sizeof(float));
-        if (e == hipSuccess) e = hipMalloc((void**)&m->aT[b], kPasses * kQT * sizeof(unsigned int));
+        if (e == hipSuccess) e = hipMalloc((void**)&m->aT[b], (size_t)8 * kPasses * kQT * sizeof(unsigned int));     // (x 8: the K slot words of the K-nearest form)
         if (e == hipSuccess) e = hipEventCreateWithFlags(&m->main_done[b], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&m->rerank_done[b], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&m->prep_done[b], hipEventDisableTiming);
@@ -1712,6 +1729,7 @@ int fir_gemm_create_range_ex_(fir_gallery* g, int32_t precision, int32_t end_pos
 #define FIR_X_ATTR(M, S, O) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_proxy_f16x<M, S, O>, hipFuncAttributeMaxDynamicSharedMemorySize, kHalfLds);
     FIR_X_ATTR(1, 0, 0) FIR_X_ATTR(1, 0, 1) FIR_X_ATTR(1, 1, 0) FIR_X_ATTR(1, 1, 1) FIR_X_ATTR(2, 0, 0) FIR_X_ATTR(2, 0, 1) FIR_X_ATTR(2, 1, 0) FIR_X_ATTR(2, 1, 1)
     FIR_X_ATTR(3, 0, 0) FIR_X_ATTR(3, 0, 1) FIR_X_ATTR(3, 1, 0) FIR_X_ATTR(3, 1, 1)
+    FIR_X_ATTR(4, 0, 0) FIR_X_ATTR(4, 0, 1) FIR_X_ATTR(4, 1, 0) FIR_X_ATTR(4, 1, 1)
 #undef FIR_X_ATTR
     m->mfma16 = precision == FIR_GEMM_F16;
     if (const char* w = fir_knob_("FIR_GEMM_MFMA16")) m->mfma16 = std::atoi(w) != 0 && precision == FIR_GEMM_F16;
@@ -1723,6 +1741,7 @@ int fir_gemm_create_range_ex_(fir_gallery* g, int32_t precision, int32_t end_pos
     if (const char* w = fir_knob_("FIR_GEMM_EREL_SCALE")) m->erel_scale = (float)std::atof(w);
 #endif
     if (const char* w = fir_knob_("FIR_GEMM_ADAPTIVE")) m->adaptive = std::atoi(w);
+    if (const char* w = fir_knob_("FIR_GEMM_ADAPTIVE_TOPK")) m->adaptive_topk = std::atoi(w) != 0;
     if (const char* w = fir_knob_("FIR_GEMM_SHARE_STREAMED")) m->share_streamed = std::max(1, std::min(16, std::atoi(w)));
     if (const char* w = fir_knob_("FIR_GEMM_SHARE")) m->share_max = std::max(0, std::min(16, std::atoi(w)));
     // the 16-row kernels always run the smallest-proxy sample flow with its XCD-shared launches: one workgroup per CU, CUs in eights
@@ -2000,7 +2019,7 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
     // it ends -- 1 000-2 400 appended rows per query measured at 100k x 512 with 256 queries, against ~20 through the sample
     // flow, 13 % fewer queries/s -- so such super-batches keep the sample flow.
     auto adaptive_for = [&](int nq_sb) -> bool {
-        if (!(x_flow && k == 1 && m->adaptive > 0)) return false;
+        if (!(x_flow && m->adaptive > 0 && (k == 1 || m->adaptive_topk))) return false;
         if (m->adaptive > 1) return true;                                   // FIR_GEMM_ADAPTIVE=2: always
         const int pairs_sb = ((nq_sb + kQT - 1) / kQT + 1) / 2;
         const bool str = m->dk16 > kSlabH || m->streamed > 0;
@@ -2051,7 +2070,7 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
             const bool adaptive_prep = adaptive_for(nq);
             hipLaunchKernelGGL(k_gemm_qprep_f16, dim3(pairs * 2 * kQT), dim3(64), 0, ps, dq, nq, d, m->gallery_exp, m->qnorm[b], m->qmul[b], m->qinv[b], qs,
                                m->counts[b], adaptive_prep ? m->awin[b] : (float*)nullptr, adaptive_prep ? m->aT[b] : (unsigned int*)nullptr,
-                               (const float*)m->gmax, e_rel);
+                               (const float*)m->gmax, e_rel, k > 1 ? k : 0);
             if (m->mfma16)
                 hipLaunchKernelGGL(k_gemm_pack_queries_f16x, dim3((4 * m->dk16 * 64 + 255) / 256, pairs), dim3(256), 0, ps, dq, nq, d, m->dk16, m->qmul[b],
                                    m->qbf[b], qs);
@@ -2172,9 +2191,10 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
                     used_rt = true;
                     used_rt_lds = rt_lds;
                 } else if (adaptive)
-                    hipLaunchKernelGGL(pick_x(3, streamed, (m->dk16 / kRing) & 1, m->dbg_skip), g1, dim3(kGemmBlock), kHalfLds, st, m->gh, m->gnorm, m->qbf[b] + qo * 4 * m->dk16 * 64,
+                    hipLaunchKernelGGL(pick_x(k > 1 ? 4 : 3, streamed, (m->dk16 / kRing) & 1, k > 1 ? 0 : m->dbg_skip), g1, dim3(kGemmBlock), kHalfLds, st, m->gh, m->gnorm, m->qbf[b] + qo * 4 * m->dk16 * 64,
                                        m->qinv[b] + qo * 2 * kQT, n, (int64_t)0, n, m->dk16, m->awin[b] + qo * 2 * kQT, m->lists[b] + qo * 2 * kQT * kListCap,
-                                       m->counts[b] + qo * 2 * kQT, m->qnorm[b] + qo * 2 * kQT, sample_rows, share, nt | adapt_dbg | (m->stagger ? 2 : 0) | (m->stagger > 1 ? 32 : 0) | (m->prio ? 16 : 0) | (m->no_block_bound ? 64 : 0), 1, m->aT[b] + qo * 2 * kQT, 0);
+                                       m->counts[b] + qo * 2 * kQT, m->qnorm[b] + qo * 2 * kQT, sample_rows, share, nt | adapt_dbg | (m->stagger ? 2 : 0) | (m->stagger > 1 ? 32 : 0) | (m->prio ? 16 : 0) | (m->no_block_bound ? 64 : 0), 1,
+                                       m->aT[b] + qo * 2 * kQT * (k > 1 ? 8 : 1), k > 1 ? k : 0);
                 else if (m->mfma16)
                     hipLaunchKernelGGL(pick_x(1, streamed, (m->dk16 / kRing) & 1), g1, dim3(kGemmBlock), kHalfLds, st, m->gh, m->gnorm, m->qbf[b] + qo * 4 * m->dk16 * 64,
                                        m->qinv[b] + qo * 2 * kQT, n, (int64_t)0, n, m->dk16, m->tau[b] + qo * 2 * kQT, m->lists[b] + qo * 2 * kQT * kListCap,
@@ -2196,9 +2216,9 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
                 const void* fp = (const void*)rt_main;
                 fir_gallery_note_dispatch_(m->g, fp, nm, sb == 0, grid, nlaunch, 512, used_rt_lds, 128 * p_first, bytes, flops);
             } else
-            fir_gallery_note_dispatch_(m->g, m->mfma16 ? (const void*)pick_x(adaptive ? 3 : 1, streamed, (m->dk16 / kRing) & 1)
+            fir_gallery_note_dispatch_(m->g, m->mfma16 ? (const void*)pick_x(adaptive ? (k > 1 ? 4 : 3) : 1, streamed, (m->dk16 / kRing) & 1)
                                                        : (streamed ? (const void*)k_gemm_proxy_f16<1, 1> : (const void*)k_gemm_proxy_f16<1, 0>),
-                                       m->mfma16 ? name_x(streamed, (m->dk16 / kRing) & 1, adaptive)
+                                       m->mfma16 ? name_x(streamed, (m->dk16 / kRing) & 1, adaptive, k > 1)
                                                  : (streamed ? "fir::k_gemm_proxy_f16<1, 1>" : "fir::k_gemm_proxy_f16<1, 0>"), sb == 0, grid, m->share_max > 0 ? nlaunch : pairs, kGemmBlock, kHalfLds,
                                        m->share_max > 0 ? 128 * p_first : 128, bytes, flops);
         } else if (m->precision == FIR_GEMM_F32) {
@@ -2224,7 +2244,7 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
         }
         if (adaptive) {
             const int pairs_a = (np + 1) / 2;
-            hipLaunchKernelGGL(k_gemm_adapt_final, dim3((pairs_a * 2 * kQT + 255) / 256), dim3(256), 0, st, m->aT[b], m->qnorm[b], m->tau[b], pairs_a * 2 * kQT, nq);
+            hipLaunchKernelGGL(k_gemm_adapt_final, dim3((pairs_a * 2 * kQT + 255) / 256), dim3(256), 0, st, m->aT[b], m->qnorm[b], m->tau[b], pairs_a * 2 * kQT, nq, k > 1 ? k : 0);
         }
         GEMM_HIP(hipEventRecord(m->main_done[b], st));
         // exact re-rank + certificate of this super-batch on the side stream, under the next one's full pass

@@ -124,14 +124,38 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
     // MODE 1: appends are staged per workgroup in LDS (an LDS atomic counts in lgkmcnt and returns in ~100 cycles; a returning GLOBAL
     // atomic sits in the in-order vmcnt queue behind the prefetched gallery loads -- every append drained the wave's stream) and
     // flushed to the global lists once, at the end; a query that fills its kXStage slots appends directly (rare, correct)
-    constexpr bool kAppend = MODE == 1 || MODE == 3;
+    // MODE 4: MODE 3 for the K nearest rows (K = sub_stride, 2..8). Per query EIGHT slot minima over disjoint row sets (row block rb
+    // belongs to slot rb mod 8): the K smallest slot minima belong to K distinct rows, so T = (the K-th smallest slot minimum + |q|^2) +
+    // window bounds the K-th smallest proxy of all rows from above -- what the K-nearest re-rank's certificate needs (k_gemm_rerank_topk:
+    // window hung on the K-th smallest proxy of the list). Every slot only falls, so T only falls, and the MODE 3 argument carries over
+    // word for word. The slots live in LDS (slot_s, as the float bits of (slot minimum + |q|^2) + window, >= 0) and in `smin` (8 words
+    // per query), exchanged by the same atomics on the same schedule; the hot path still compares against one bound per query (tq_s / tqr).
+    constexpr bool kAdapt = MODE == 3 || MODE == 4;
+    constexpr bool kSlots = MODE == 4;
+    const int kth = kSlots ? sub_stride : 1;
+    // the K-th smallest of a query's eight slot words (rank by value, then slot: every word gets a distinct rank)
+    auto kth_of_slots = [&](const unsigned int* sl) -> unsigned int {
+        unsigned int v[8], res = 0xFFFFFFFFu;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = sl[i];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            int rank = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) rank += (v[j] < v[i] || (v[j] == v[i] && j < i)) ? 1 : 0;
+            res = rank == kth - 1 ? v[i] : res;
+        }
+        return res;
+    };
+    constexpr bool kAppend = MODE == 1 || kAdapt;
     __shared__ unsigned long long skeys[kAppend ? 2 * kQT * kXStage : 1];
     __shared__ int scnt[kAppend ? 2 * kQT : 1];
-    __shared__ float qn_s[MODE == 3 ? 2 * kQT : 1], win_s[MODE == 3 ? 2 * kQT : 1];
+    __shared__ float qn_s[kAdapt ? 2 * kQT : 1], win_s[kAdapt ? 2 * kQT : 1];
+    __shared__ unsigned int slot_s[kSlots ? 2 * kQT * 8 : 1];
     // MODE 3: tq_s = T - |q|^2 as the hot path compares it, rewritten by whoever lowers T (tau_s holds T itself). A racing store may leave
     // the value of an OLDER (larger) T: harmless -- any T the pass ever held is >= the final one, so whatever fails the test against
     // it has a proxy >= fl(T_final - |q|^2), the bound the certificate is given
-    __shared__ float tq_s[MODE == 3 ? 2 * kQT : 1];
+    __shared__ float tq_s[kAdapt ? 2 * kQT : 1];
     int pair_of_wg = (int)blockIdx.y;
     int64_t rg_first = blockIdx.x, rg_step = gridDim.x, rg_last = -1;
     int range = (int)blockIdx.x;
@@ -156,16 +180,21 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
         counts += pr * 2 * kQT;
         if (MODE == 0) sample += pr * 2 * kQT * ((sample_rows + 31) / 32);
         if (MODE == 2 || MODE == 3) smin += pr * 2 * kQT;
-        if (MODE == 3) sample += pr * 2 * kQT;
+        if (MODE == 4) smin += pr * 2 * kQT * 8;
+        if (kAdapt) sample += pr * 2 * kQT;
     }
     const int64_t rbs = MODE == 2 ? rb_stride : 1;                        // gallery row blocks per row block of the pass
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wpb = blockDim.x >> 6;
     if (threadIdx.x < 2 * kQT) {
+        if (kSlots) {
+            for (int sl = 0; sl < 8; ++sl) slot_s[threadIdx.x * 8 + sl] = atomicMin(&smin[threadIdx.x * 8 + sl], 0xFFFFFFFFu);
+            tau_s[threadIdx.x] = __uint_as_float(kth_of_slots(&slot_s[threadIdx.x * 8]));
+        } else
         tau_s[threadIdx.x] = MODE == 1 ? tau[threadIdx.x] : MODE == 3 ? __uint_as_float(atomicMin(&smin[threadIdx.x], 0xFFFFFFFFu)) : 0.f;    // (MODE 3: an atomic, see the refresh below)
         qinv_s[threadIdx.x] = qinv[threadIdx.x];
         if (kAppend) scnt[threadIdx.x] = 0;
-        if (MODE == 3) {
+        if (kAdapt) {
             qn_s[threadIdx.x] = sample[threadIdx.x];
             win_s[threadIdx.x] = tau[threadIdx.x];
             tq_s[threadIdx.x] = tau_s[threadIdx.x] - qn_s[threadIdx.x];
@@ -256,10 +285,33 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
 #pragma unroll
         for (int jb = 0; jb < 8; ++jb) {
             m2r[jb] = 2.0f * qinv_s[jb * 16 + (lane & 15)];
-            tqr[jb] = MODE == 3 ? tq_s[jb * 16 + (lane & 15)] : tau_s[jb * 16 + (lane & 15)];
+            tqr[jb] = kAdapt ? tq_s[jb * 16 + (lane & 15)] : tau_s[jb * 16 + (lane & 15)];
         }
     }
-    bool warm = MODE == 3;                           // MODE 3: the first row block is walked twice (see above)
+    bool warm = kAdapt;                              // MODE 3 / 4: the first row block is walked twice (see above)
+    // MODE 4: the K-th smallest slot value as the new T of query q (a value read a moment ago is >= the slot's current one, so this is a bound)
+    auto slots_to_T = [&](int q) {
+        const unsigned int tk = kth_of_slots(&slot_s[q * 8]);
+        if (tk < atomicMin((unsigned int*)&tau_s[q], tk)) tq_s[q] = __uint_as_float(tk) - qn_s[q];
+    };
+    // a new smallest proxy `mn` of row block rbq for query q: T falls, here and (through `smin`) for everybody else
+    auto lower_T = [&](int q, int64_t rbq, float mn) {
+        const float tn = fmaxf((mn + qn_s[q]) + win_s[q], 0.f);
+        if (!kSlots) {
+            if (tn < tau_s[q]) {
+                if (__float_as_uint(tn) < atomicMin((unsigned int*)&tau_s[q], __float_as_uint(tn))) tq_s[q] = tn - qn_s[q];
+                atomicMin(&smin[q], __float_as_uint(tn));
+            }
+        } else {
+            const int sl = (int)(rbq & 7);
+            if (tn < __uint_as_float(slot_s[q * 8 + sl])) {
+                if (__float_as_uint(tn) < atomicMin(&slot_s[q * 8 + sl], __float_as_uint(tn))) {
+                    atomicMin(&smin[q * 8 + sl], __float_as_uint(tn));
+                    slots_to_T(q);
+                }
+            }
+        }
+    };
     bool exchange = false;
     int blk_no = 0;
     int64_t rg_next = rg;
@@ -272,14 +324,23 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
         const bool active = rbp < rb_end;
         const int64_t rgn = rg_next;
         const uint4* a_nxt = FIR_X_BLOCK(rgn < rg_end ? rgn : rg);
-        if (MODE == 3) {
+        if (kAdapt) {
             if (exchange) {                               // (uniform over the workgroup: every wave walks the same rg sequence)
                 // the workgroup's warm-up minima go out, everybody else's come in
                 __syncthreads();
                 if (threadIdx.x < 2 * kQT) {
+                    if (kSlots) {
+                        for (int sl = 0; sl < 8; ++sl) {
+                            const unsigned int mine = slot_s[threadIdx.x * 8 + sl];
+                            const unsigned int old = (nt_flags & 8) ? mine : atomicMin(&smin[threadIdx.x * 8 + sl], mine);
+                            slot_s[threadIdx.x * 8 + sl] = old < mine ? old : mine;
+                        }
+                        tau_s[threadIdx.x] = __uint_as_float(kth_of_slots(&slot_s[threadIdx.x * 8]));
+                    } else {
                     const unsigned int mine = __float_as_uint(tau_s[threadIdx.x]);
                     const unsigned int old = (nt_flags & 8) ? mine : atomicMin(&smin[threadIdx.x], mine);
                     tau_s[threadIdx.x] = __uint_as_float(old < mine ? old : mine);
+                    }
                     tq_s[threadIdx.x] = tau_s[threadIdx.x] - qn_s[threadIdx.x];
                 }
                 __syncthreads();
@@ -296,9 +357,19 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
                     int zl;                                   // (an opaque zero: keeps the addresses from being hoisted out of the row loop and spilled)
                     asm volatile("v_mov_b32 %0, 0" : "=v"(zl));
                     const int ql = 16 * wave + lane + zl;
+                    if (kSlots) {
+                        bool fell = false;
+                        for (int sl = 0; sl < 8; ++sl) {
+                            const unsigned int mine = slot_s[ql * 8 + sl];
+                            const unsigned int old = atomicMin(&smin[ql * 8 + sl], mine);
+                            if (old < mine) { atomicMin(&slot_s[ql * 8 + sl], old); fell = true; }
+                        }
+                        if (fell) slots_to_T(ql);
+                    } else {
                     const unsigned int mine = __float_as_uint(tau_s[ql]);
                     const unsigned int old = atomicMin(&smin[ql], mine);
                     if (old < mine && old < atomicMin((unsigned int*)&tau_s[ql], old)) tq_s[ql] = __uint_as_float(old) - qn_s[ql];
+                    }
                 }
             }
             ++blk_no;
@@ -315,7 +386,7 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
             // (kDefer: the lane's scale and bound come from registers -- an LDS read here would wait, in order, behind the query
             // fragments just requested for the next step; a bound that is a row block old is a larger one: it appends more, never less)
             const float m2 = kDefer ? m2r[jb] : 2.0f * qinv_s[q];
-            const float tq = kDefer ? tqr[jb] : MODE == 3 ? tq_s[q] : tau_s[q];
+            const float tq = kDefer ? tqr[jb] : kAdapt ? tq_s[q] : tau_s[q];
             if (!(nt_flags & 64)) {
                 // with m2 > 0, fl(gmin - m2 amax) <= fl(gn_r - m2 acc_r) for every row r of the lane (gmin <= gn_r, amax >= acc_r, rounding is
                 // monotone): `lb >= tq` proves that no row of the block is appended -- seven instructions instead of sixteen. NaN sums never
@@ -350,17 +421,11 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
                             // the list is full: this query is uncertified whatever else happens (fir_gemm_fb.h gives it a second pass), so the
                             // workgroup stops appending for it -- a pass whose bound stays loose must not turn into millions of atomics on
                             // one counter (~11 ns each: a whole gallery's worth is 11 ms). The next lowering of T writes tq_s again.
-                            else if (MODE == 3) tq_s[q] = -__builtin_huge_valf();
+                            else if (kAdapt) tq_s[q] = -__builtin_huge_valf();
                         }
                     }
                 }
-                if (MODE == 3) {
-                    const float tn = fmaxf((mn + qn_s[q]) + win_s[q], 0.f);
-                    if (tn < tau_s[q]) {                                // a new smallest proxy: T falls, here and for everybody else
-                        if (__float_as_uint(tn) < atomicMin((unsigned int*)&tau_s[q], __float_as_uint(tn))) tq_s[q] = tn - qn_s[q];
-                        atomicMin(&smin[q], __float_as_uint(tn));
-                    }
-                }
+                if (kAdapt) lower_T(q, rbq, mn);
             }
         };
         auto unit = [&](uint4 (&C)[kRing], uint4 (&N)[kRing], int h, auto first_tag) {
@@ -444,10 +509,10 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
         if (!active) continue;
         if (full_block) {
             const float gmin = fminf(fminf(fminf(gns[0].x, gns[0].y), fminf(gns[0].z, gns[0].w)), fminf(fminf(gns[1].x, gns[1].y), fminf(gns[1].z, gns[1].w)));
-            if (kAppend && !(MODE == 3 && warm_it)) {
+            if (kAppend && !(kAdapt && warm_it)) {
                 if (kDefer) {
                     pend = true;                                             // checked in the next row block's first step (or behind the loop)
-                    if (MODE == 3) {
+                    if (kAdapt) {
 #pragma unroll
                         for (int jb = 0; jb < 8; ++jb) tqr[jb] = tq_s[jb * 16 + (lane & 15)];
                     }
@@ -476,13 +541,17 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
                         mn = fminf(mn, pv[4 * s + reg]);                   // NaN never enters, like k_gemm_tau's ordering
                     }
                 }
-                if (MODE == 3 && warm_it) {
+                if (kAdapt && warm_it) {
                     // observe only: the smallest proxy of the block's 32 rows lowers T (LDS; the workgroup exchanges with `smin` afterwards)
                     float o = __shfl_xor(mn, 16, 64);
                     mn = o < mn ? o : mn;
                     o = __shfl_xor(mn, 32, 64);
                     mn = o < mn ? o : mn;
                     const float tn = fmaxf((mn + qn_s[q]) + win_s[q], 0.f);     // (NaN operands: fmaxf gives 0 only if both are NaN; a NaN tn fails the test below)
+                    if (kSlots) {
+                        const int sl = (int)(rb & 7);                           // (the exchange behind the warm-up turns the slots into T)
+                        if (lane < 16 && tn < __uint_as_float(slot_s[q * 8 + sl])) atomicMin(&slot_s[q * 8 + sl], __float_as_uint(tn));
+                    } else
                     if (lane < 16 && tn < tau_s[q]) atomicMin((unsigned int*)&tau_s[q], __float_as_uint(tn));
                 } else if (MODE == 2 && !sub_stride) {
                     smallest[jb] = fminf(smallest[jb], mn);
@@ -502,7 +571,7 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
         for (int jb = 0; jb < 8; ++jb) {
             const int q = jb * 16 + (lane & 15);
             const float m2 = 2.0f * qinv_s[q];
-            const float tq = MODE == 3 ? (warm_it ? -__builtin_huge_valf() : tq_s[q]) : tau_s[q];      // (a warm-up walk appends nothing)
+            const float tq = kAdapt ? (warm_it ? -__builtin_huge_valf() : tq_s[q]) : tau_s[q];      // (a warm-up walk appends nothing)
             float mn = __builtin_huge_valf();
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -520,7 +589,7 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
             }
             if (MODE == 2 && !sub_stride) {
                 smallest[jb] = fminf(smallest[jb], mn);
-            } else if (MODE != 1 && MODE != 3) {
+            } else if (MODE != 1 && !kAdapt) {
                 float o = __shfl_xor(mn, 16, 64);
                 mn = o < mn ? o : mn;
                 o = __shfl_xor(mn, 32, 64);
@@ -536,7 +605,7 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
         auto last_jb = [&](int jb) {
             const int q = jb * 16 + (lane & 15);
             const float m2 = 2.0f * qinv_s[q];
-            const float tq = MODE == 3 ? tq_s[q] : tau_s[q];
+            const float tq = kAdapt ? tq_s[q] : tau_s[q];
             const float gnv[8] = {pg[0].x, pg[0].y, pg[0].z, pg[0].w, pg[1].x, pg[1].y, pg[1].z, pg[1].w};
             float pv[8];
             float mn = __builtin_huge_valf();
@@ -560,13 +629,7 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
                         }
                     }
                 }
-                if (MODE == 3) {
-                    const float tn = fmaxf((mn + qn_s[q]) + win_s[q], 0.f);
-                    if (tn < tau_s[q]) {
-                        atomicMin((unsigned int*)&tau_s[q], __float_as_uint(tn));
-                        atomicMin(&smin[q], __float_as_uint(tn));
-                    }
-                }
+                if (kAdapt) lower_T(q, p_rb, mn);
             }
         };
 #pragma unroll
