@@ -2026,7 +2026,9 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
         int P = 1;
         while (P * 2 <= pairs_sb && P * 2 <= (str ? std::min(m->share_max, m->share_streamed) : m->share_max)) P *= 2;
         const int64_t row_groups = ((n + 31) / 32 + kGemmBlock / 64 - 1) / (kGemmBlock / 64);
-        return row_groups * P / std::max(grid, 1) >= 12;
+        // (the K-nearest form's eight slots per query fill more slowly: 256 queries against 1M x 512 measured 479 k q/s against the sample
+        // flow's 514 k, 4 096 queries 1.02 M against 0.92 M -- profiles/r04_topk_slots.txt)
+        return row_groups * P / std::max(grid, 1) >= (k > 1 ? 100 : 12);
     };
 #ifdef FIR_AUDIT
     // 1 = no refresh, 2 = no exchange of the adaptive bound between workgroups (still sound: a looser bound appends more -- this is how
