@@ -392,6 +392,25 @@ def main():
     elapsed, k_ms, x_ms, disp = timed_loop(m, q, qb, keys, args.steps, args.warmup)
     keys_default = keys.clone()
     head = {"elapsed": elapsed, "kernel_ms": k_ms, "exch_ms": x_ms, "disp": disp}
+    # "t_batch includes H2D of queries and D2H of results; report kernel-only too" -- the same step through the HOST-pointer entry
+    # point (fir_search_top1: what the reference's call takes, db_features.cpp:319): queries from pinned host memory, indices and distances back
+    # to host arrays, inside the timed region. `value` stays the device-resident rate.
+    host_rate = None
+    if world == 1 and not args.pmc_child and m.sh is None:
+        qh = q.cpu().pin_memory().numpy()
+        hsteps = max(2, args.steps // 5)
+        hidx, _ = m.g.search_top1(qh)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(hsteps):
+            hidx, hdist = m.g.search_top1(qh)
+        hdt = time.perf_counter() - t0
+        kidx, kdist = fir.keys_unpack(keys_default.cpu().numpy().view(np.uint64))
+        host_rate = {"value_host_pointers": qb * hsteps / hdt, "unit": "queries/s", "steps": hsteps, "ms_per_step": hdt / hsteps * 1e3,
+                     "bytes_up_per_step": int(qb) * d * 4, "bytes_down_per_step": int(qb) * 8,
+                     "identical_to_the_device_pointer_call": bool(np.array_equal(hidx, kidx) and np.array_equal(hdist.view(np.uint32), kdist.view(np.uint32))),
+                     "what": "fir_search_top1 (host pointers): H2D of the queries super-batch by super-batch under the passes before, D2H of indices and distances, all inside the timed region"}
+        del qh
     mem_report = m.g.memory_bytes()            # fir_gallery_memory_bytes: the tiled rows and what the default dispatch added to them
 
     # ---- the exact streaming scan, matrix-core path off: the metric's HBM clause ----
@@ -421,8 +440,10 @@ def main():
     also = None
     cfg2 = None
     k3 = None
+    small = None
     if world == 1 and not args.no_extras and not args.pmc_child:
         xb = min(args.extra_batch, qb)
+        small = small_batches(fir, m.g, q, dev, work_stream)
         also = other_scans(fir, m.g, q[:xb], keys_default[:xb], dev, work_stream, n, d)
         k3 = k3_classifiers(fir, dev, args)
         if small_src is not None:
@@ -479,6 +500,7 @@ def main():
         out = {
             "metric": "query-vectors/sec brute-force L2 top-1, 1Mx512 gallery",
             "value": qb * args.steps / head["elapsed"],
+            "value_host_pointers": host_rate["value_host_pointers"] if host_rate else None,
             "unit": "queries/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -498,6 +520,8 @@ def main():
                 "identical_keys_to_exact_scan": identical,
                 "fallback_queries_in_timed_steps": hd.get("fallback_queries"), "second_pass_queries_in_timed_steps": hd.get("second_pass_queries"),
                 "hbm_bytes_held": mem_report,
+                "host_pointer_step": host_rate,
+                "small_batches_1mx512": small,
                 "planted_queries_found": planted_ok,
                 "row_sharding": f"{world} rank(s) x {args.shards_per_device} shard(s), {m_n} rows on this rank",
                 "key_exchange": ("RCCL ncclAllReduce(ncclMin, ncclUint64) issued by libfir_amd.so (fir_sharded_search_top1_keys_dev)" if m.in_library_rccl
@@ -518,8 +542,8 @@ def main():
             "config5": cfg5,
         }
         if also:
-            out["roofline_chi2"] = also.pop("roofline_chi2", None)
-            out["roofline_kl"] = also.pop("roofline_kl", None)
+            for kname in ("roofline_chi2", "roofline_kl", "roofline_chi2_exact", "roofline_kl_exact"):
+                out[kname] = also.pop(kname, None)
         if cpu is not None:
             out["cpu_baseline"] = cpu["reference"]
             out["cpu_all"] = cpu["all"]
@@ -546,6 +570,43 @@ def rate(fn, nq, reps):
 # 8-cycle v_rcp_f32 = 11.0; KL 24.9 + 2.96 for v_rcp + 2 v_log = 27.9. The s_nop hazard padding the compiler adds (1.7 / 5.7
 # per element) is not counted: it is part of what keeps the achieved rate below the peak.
 CHI2_SLOTS, KL_SLOTS = 11.0, 27.9
+# ... and of the nomination scans (csrc/fir_kernels.h, TileAcc::chunk<kChi2Harm / kKLEnt>; DESIGN section 4 "chi-square and KL nomination")
+NOM_SLOTS = {"chi2": 2.25, "kl": 3.0}
+NOM_MODEL = {"chi2": "harmonic form, two terms per reciprocal: per pair of features and pair of queries four packed adds / multiplies, two v_rcp_f32 (two issue slots each) and one packed fma "
+                     "= 2.25 issue slots per (row, feature, query)",
+             "kl": "entropy form: per feature and pair of queries a packed add, two v_log_f32 (two issue slots each) and a packed fma = 3.0 issue slots per (row, feature, query)"}
+NOM_CLOCK_NOTE = {"chi2": "rocprofv3 --pmc pass of this kernel (profiles/r04_rocprofv3_pmc_chi2_nominate.json): 20.75 M cycles per 256-query launch of ~10.9 ms = 1.90 GHz sustained, "
+                          "SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x kernel cycles) = 0.956: the vector pipes are 96 % busy at the clock the chip holds; `frac` prices it at 2.4 GHz",
+                  "kl": "same kernel family as the chi-square nomination scan (profiles/r04_rocprofv3_pmc_chi2_nominate.json: vector pipes 96 % busy at the 1.9 GHz the chip sustains); `frac` prices it at 2.4 GHz"}
+
+
+def small_batches(fir, g, q, dev, ws):
+    """The headline gallery (1M x 512) at small batches: exact scan, forced matrix cores, default dispatch; queries whose first certificate did not hold
+    (they take a second matrix-core pass on the device) and queries the exact device scan had to answer, per call. VERDICT r3 item 1."""
+    stream = ws.cuda_stream
+    out = {}
+    with torch.cuda.stream(ws):
+        for sq in (8, 32, 256):
+            ks = torch.empty(sq, device=dev, dtype=torch.int64)
+            km = torch.empty(sq, device=dev, dtype=torch.int64)
+            kd = torch.empty(sq, device=dev, dtype=torch.int64)
+            g.set_large_batch_mfma(0)
+            r_scan = rate(lambda: g.search_top1_keys_dev(q.data_ptr(), sq, ks.data_ptr(), stream=stream), sq, 5)
+            g.set_large_batch_mfma(1)
+            r_mfma = rate(lambda: g.search_top1_keys_dev(q.data_ptr(), sq, km.data_ptr(), stream=stream), sq, 10)
+            g.set_large_batch_mfma(-1)
+            g.search_top1_keys_dev(q.data_ptr(), sq, kd.data_ptr(), stream=stream)
+            st0 = g.mfma_stats()
+            r_def = rate(lambda: g.search_top1_keys_dev(q.data_ptr(), sq, kd.data_ptr(), stream=stream), sq, 10)
+            st1 = g.mfma_stats()
+            dd = g.last_dispatch()
+            out[str(sq)] = {"exact_scan_queries_per_s": r_scan, "matrix_core_queries_per_s": r_mfma, "default_dispatch_queries_per_s": r_def,
+                            "default_over_best_of_the_two_forms": r_def / max(r_scan, r_mfma), "default_dispatch_path": dd["path"], "default_dispatch_kernel": dd["kernel"],
+                            "identical_keys": bool(torch.equal(ks, km)) and bool(torch.equal(ks, kd)),
+                            "second_pass_queries_per_call": (st1["second_pass_queries"] - st0["second_pass_queries"]) / 11.0,
+                            "fallback_queries_per_call": (st1["fallback_queries"] - st0["fallback_queries"]) / 11.0}
+        g.set_large_batch_mfma(-1)
+    return out
 
 
 def other_scans(fir, g, q, keys, dev, ws, n, d):
@@ -598,7 +659,12 @@ def other_scans(fir, g, q, keys, dev, ws, n, d):
             q256 = q[:256].clamp_min(0.0)
             q256 = torch.where(q256 < 1e-4 / 13.0, torch.zeros_like(q256), q256).contiguous()
             k256 = torch.empty(256, device=dev, dtype=torch.int64)
+            g.profile_enable(True)
+            g.profile_read()
             r1d = rate(lambda: g.search_top1_keys_dev(q256.data_ptr(), 256, k256.data_ptr(), stream=stream), 256, 2)
+            ms_nom, _ = g.profile_read()
+            g.profile_enable(False)
+            dsp_nom = g.last_dispatch()
             k256_5 = torch.empty((256, 5), device=dev, dtype=torch.int64)
             r5d = rate(lambda: g.search_topk_keys_dev(q256.data_ptr(), 256, 5, k256_5.data_ptr(), stream=stream), 256, 2)
             also[f"{name}_top1_default_dispatch_queries_per_s_batch256"] = r1d
@@ -615,7 +681,20 @@ def other_scans(fir, g, q, keys, dev, ws, n, d):
             per_pass_ms /= passes
             elems_per_pass = float(n) * d * qpp
             wave_instr_per_s = elems_per_pass / 64.0 * slots / (per_pass_ms * 1e-3) if per_pass_ms == per_pass_ms else float("nan")
-            also[f"roofline_{name}"] = {"bound": "valu", "model": f"{slots} VALU issue slots per (row, feature, query) element in the plain-range form (counted in the compiled loop, bench.py), "
+            # what the default dispatch runs for a 256-query batch: the NOMINATION scan (k_nominate, 16 queries per read of the gallery) + the exact re-rank
+            # of the appended rows; its launch is timed by the library's HIP events (one launch = grid_y reads)
+            nslots = NOM_SLOTS[name]
+            reads = max(1, dsp_nom["grid"][1])
+            ms_read = float(np.mean(ms_nom)) / reads if len(ms_nom) else float("nan")
+            nom_rate = float(n) * d * dsp_nom["queries_per_pass"] / 64.0 * nslots / (ms_read * 1e-3) if ms_read == ms_read else float("nan")
+            also[f"roofline_{name}"] = {"bound": "valu", "kernel": dsp_nom["kernel"], "what": "the nomination scan the default dispatch runs (cheap metric, threshold widened by its error bound, exact re-rank of the appended rows)",
+                                       "model": NOM_MODEL[name] + "; peak = 256 CUs x 4 SIMDs x one wave64 instruction per 4 cycles at the 2.4 GHz maximum clock",
+                                       "achieved": nom_rate / 1e9, "peak": PEAK_VALU_WAVE_INSTR_PER_S / 1e9, "unit": "G wave-instructions/s", "frac": nom_rate / PEAK_VALU_WAVE_INSTR_PER_S,
+                                       "kernel_ms_per_launch": float(np.mean(ms_nom)) if len(ms_nom) else None, "gallery_reads_per_launch": reads, "kernel_ms_per_read": ms_read,
+                                       "queries_per_read": dsp_nom["queries_per_pass"], "launches_timed": int(len(ms_nom)), "gallery_GBps": n * d * 4.0 / (ms_read * 1e-3) / 1e9,
+                                       "frac_of_hbm_peak": n * d * 4.0 / (ms_read * 1e-3) / 1e9 / 8000.0, "vgprs": dsp_nom["vgprs"], "queries_per_s_whole_call": r1d,
+                                       "sustained_clock_note": NOM_CLOCK_NOTE[name]}
+            also[f"roofline_{name}_exact"] = {"bound": "valu", "model": f"{slots} VALU issue slots per (row, feature, query) element in the plain-range form (counted in the compiled loop, bench.py), "
                                                                     "peak = 256 CUs x 4 SIMDs x one wave64 instruction per 4 cycles at 2.4 GHz",
                                        "achieved": wave_instr_per_s / 1e9, "peak": PEAK_VALU_WAVE_INSTR_PER_S / 1e9, "unit": "G wave-instructions/s",
                                        "frac": wave_instr_per_s / PEAK_VALU_WAVE_INSTR_PER_S, "kernel": dsp["kernel"] + " (launched next to its plain-range twin; the one that applies runs)",
@@ -778,6 +857,36 @@ def k3_classifiers(fir, dev, args, qb=64):
                                                       "frac": winst / (avg * 1e-3) / 1e9 / 614.4},
                                         "achieved": nbytes / (avg * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": nbytes / (avg * 1e-3) / 1e9 / 8000.0,
                                         "kernel_time_share_of_call": float(np.sum(ms)) / (dt * 3 * 1e3)}
+    # kNN batches through the matrix cores (csrc/fir_gemm_f64.h): fp16 fragments of the centred rows nominate, float64 re-ranks,
+    # the certificate covers the rest, the vote runs over the nominated rows; what is not settled takes the exact scan. 4 096 queries per call.
+    kq = 4096
+    pickk = torch.randint(0, ncls, (kq,), generator=g, device=dev)
+    qk = (centres[pickk] + 0.004 * torch.randn((kq, d), generator=g, device=dev, dtype=torch.float64)).cpu().numpy()
+    m.set_knn_mfma(0)
+    exact_cls = {kk: m.knn_predict(qk[:64], kk) for kk in (1, 3)}
+    m.set_knn_mfma(-1)
+    for kk in (1, 3):
+        res = m.knn_predict(qk, kk)
+        m.profile_read()
+        s0 = m.knn_stats()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            res = m.knn_predict(qk, kk)
+        dt = (time.perf_counter() - t0) / 3
+        ms, _, _ = m.profile_read()
+        s1 = m.knn_stats()
+        dsp = m.last_dispatch()
+        blk = {"queries_per_call": kq, "queries_per_s": kq / dt, "ms_per_call": dt * 1e3, "kernel": dsp["kernel"],
+               "matrix_core_queries_per_call": (s1["matrix_core_queries"] - s0["matrix_core_queries"]) / 3.0,
+               "exact_scan_queries_per_call": (s1["exact_scan_queries_of_them"] - s0["exact_scan_queries_of_them"]) / 3.0,
+               "classes_equal_the_exact_scans_on_64": bool(np.array_equal(res[:64], exact_cls[kk])),
+               "class_of_the_planted_centre_found": float(np.mean(res == pickk.cpu().numpy()))}
+        if len(ms) and dsp["flops_per_launch"] > 0:
+            kms = float(np.min(ms))                        # (the timed event pair brackets the FIRST full-pass launch of each call)
+            blk["roofline_mfma"] = {"bound": "mfma", "kernel": dsp["kernel"], "kernel_ms_first_launch": kms, "flops_per_launch": dsp["flops_per_launch"],
+                                    "achieved_tflops": dsp["flops_per_launch"] / (kms * 1e-3) / 1e12, "peak_tflops": PEAK_MFMA_F16_TFLOPS,
+                                    "frac_of_mfma_peak": dsp["flops_per_launch"] / (kms * 1e-3) / 1e12 / PEAK_MFMA_F16_TFLOPS}
+        out[f"knn{kk}_matrix_cores"] = blk
     m.close()
     return out
 

@@ -67,6 +67,9 @@ SYMBOLS = [
     ("fir_cls_pnn_predict", C.c_int, [_vp, _vp, C.c_int32, C.c_double, _vp, _vp]),
     ("fir_cls_pnn_predict_seq", C.c_int, [_vp, _vp, C.c_int32, C.c_double, _vp, _vp]),
     ("fir_cls_knn_predict", C.c_int, [_vp, _vp, C.c_int32, C.c_int32, _vp]),
+    ("fir_cls_set_knn_mfma", C.c_int, [_vp, C.c_int32]),
+    ("fir_cls_knn_stats", C.c_int, [_vp, _i64p, _i64p]),
+    ("fir_cls_last_dispatch", C.c_int, [_vp, C.c_char_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("fir_cls_knn_class_nearest", C.c_int, [_vp, _vp, C.c_int32, C.c_int32, _vp]),
     ("fir_gemm_create", C.c_int, [_vp, C.POINTER(_vp)]),
     ("fir_gemm_create_ex", C.c_int, [_vp, C.c_int32, C.POINTER(_vp)]),
@@ -722,6 +725,20 @@ class ClsModel:
         chunks = np.empty(q.shape[0], np.int32)
         _check(lib().fir_cls_pnn_predict_seq(self._h, pq, q.shape[0], var, best.ctypes.data_as(_vp), chunks.ctypes.data_as(_vp)))
         return best, chunks
+
+    def set_knn_mfma(self, min_queries):
+        _check(lib().fir_cls_set_knn_mfma(self._h, min_queries))
+
+    def knn_stats(self):
+        a, b = C.c_int64(), C.c_int64()
+        _check(lib().fir_cls_knn_stats(self._h, C.byref(a), C.byref(b)))
+        return {"matrix_core_queries": a.value, "exact_scan_queries_of_them": b.value}
+
+    def last_dispatch(self):
+        buf = C.create_string_buffer(96)
+        nb, fl = C.c_double(), C.c_double()
+        _check(lib().fir_cls_last_dispatch(self._h, buf, 96, C.byref(nb), C.byref(fl)))
+        return {"kernel": buf.value.decode(), "bytes_per_launch": nb.value, "flops_per_launch": fl.value}
 
     def knn_class_nearest(self, queries, k):
         """[qb, num_classes, k] smallest mean distances per class among the rows held (sharded kNN vote)."""

@@ -622,6 +622,10 @@ int topk_lists_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t s
     //    largest of the k distances is a threshold at least k rows pass; about 2.3 * n * k / rows_sampled rows will
     const int64_t want_rows = std::max<int64_t>(16384, (int64_t)g->n * k / 256);
     const int64_t group_tiles = std::max<int64_t>(1, std::min<int64_t>(g->tiles / k, (want_rows / k + kTileRows - 1) / kTileRows));
+    // (the row samples are not what a profile of this call is about: the events and the dispatch record belong to the append scan below)
+    const bool was_profiling = g->profiling, was_quiet = g->quiet;
+    g->profiling = false;
+    g->quiet = true;
     if (k > 1 && g->metric != kL2) {
         // chi-square / KL: the K samples in ONE launch -- sample tile t belongs to group t mod K, a wave reports into its group's keys
         // (K launches of group_tiles tiles each leave most of the chip idle: a tile is one wave's serial work)
@@ -641,6 +645,8 @@ int topk_lists_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t s
     }
     g->tiles_limit = 0;
     g->tile_begin = 0;
+    g->profiling = was_profiling;
+    g->quiet = was_quiet;
     if (rc) return rc;
     FIR_HIP(hipMemsetAsync(flag, 0, 4, st));
     hipLaunchKernelGGL(k_topk_tau, dim3((qpad + 63) / 64), dim3(64), 0, st, skeys, qb, qpad, k, tau, counts, flag, tau_scale);
@@ -667,6 +673,12 @@ int topk_lists_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t s
                            : g->metric == kChi2 ? (scan_fn)k_scan<8, kChi2InRange, kU, kEpiAppend, kKMax, kWpsPlain>
                            : g->metric == kKL ? (scan_fn)k_scan<8, kKLInRange, kU, kEpiAppend, kKMax, kWpsPlain> : nullptr;   // see run_pass
     if (nh == 2) fn = klent ? (scan_fn)k_nominate<kKLEnt, 2, kU, kWpsPlain> : (scan_fn)k_nominate<kChi2Harm, 2, kU, kWpsPlain>;
+    char fn_name[96];
+    if (nh == 2) std::snprintf(fn_name, sizeof fn_name, "fir::k_nominate<%d, 2, %d, %d>", klent ? (int)kKLEnt : (int)kChi2Harm, kU, kWpsPlain);
+    else if (fast) std::snprintf(fn_name, sizeof fn_name, "fir::k_scan_l2_lds<1, %d, %d, true>", FIR_FAST_U, FIR_FAST_WPS);
+    else std::snprintf(fn_name, sizeof fn_name, "fir::k_scan<8, %d, %d, %d, %d, %d>", klent ? (int)kKLEnt : harm ? (int)kChi2Harm : nominate ? (int)kChi2Approx : g->metric, kU,
+                       (int)kEpiAppend, kKMax, (nominate || klent) ? kWpsPlain : kWps);
+    int launches_noted = 0;
     int max_waves = max_waves_for(g, fn, lds_bytes);
     if (fn_plain) max_waves = std::min(max_waves, max_waves_for(g, fn_plain, lds_bytes));
     const int waves = g->waves_req > 0 ? std::min(g->waves_req, max_waves) : pick_waves(g->tiles, max_waves, g->cus * 4);
@@ -698,8 +710,15 @@ int topk_lists_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t s
         a.flag = flag;
         a.sg = g->rowsum;
         a.sq = harm || klent ? sq + q0 : nullptr;
+        // algorithmic bytes of the launch: one read of the compared features per nh tiles of eight queries, the query tiles, the appended keys aside
+        const double launch_bytes = (double)(ny / nh) * ((double)g->n * (end - start) * 4.0) + (double)ny * ((double)(end - start) * 32.0 + 64.0);
+        if (!g->quiet && (rc = fir_gallery_profile_begin_(g, st))) return rc;
         hipLaunchKernelGGL(fn, dim3(waves / 4, ny / nh), dim3(kBlock), lds_bytes, st, a);
         if (fn_plain) hipLaunchKernelGGL(fn_plain, dim3(waves / 4, ny), dim3(kBlock), lds_bytes, st, a);
+        if (!g->quiet) {
+            if ((rc = fir_gallery_profile_end_(g, st, launch_bytes))) return rc;
+            note_dispatch(g, (const void*)fn, fn_name, launches_noted++, waves / 4, ny / nh, kBlock, lds_bytes, 8 * nh, launch_bytes, 0.0, 0);
+        }
     }
     // 3. (nomination) the reference's distance of every appended row, keys rewritten in place
     if (klent)

@@ -681,7 +681,17 @@ struct fir_cls {
     std::vector<hipEvent_t> ev;
     size_t ev_used = 0;
     double last_bytes = 0.0;          // algorithmic bytes of the last timed launch
+    double last_flops = 0.0;          // ... its dot-product flops when it was a matrix-core pass (kNN batches), else 0
     char last_kernel[64] = "";
+    // large kNN batches: the matrix cores nominate, float64 re-ranks, the exact scan takes what is not settled (fir_gemm_f64.h)
+    fir_gemm* mm = nullptr;           // created on the first such call
+    bool mm_failed = false;           // ... or not (rows too long, no memory): the exact scan answers
+    int mm_mode = -1;                 // fir_cls_set_knn_mfma: -1 automatic (>= kKnnMfmaQueries queries against a training set streamed from HBM), 0 never, > 0 from that many queries on
+    double* qc = nullptr; size_t qc_cap = 0;          // centred queries, row-major
+    int32_t* knn_rows = nullptr; size_t knn_rows_cap = 0;
+    double* knn_dist = nullptr; size_t knn_dist_cap = 0;
+    int32_t* knn_ok = nullptr; size_t knn_ok_cap = 0;
+    int64_t mm_queries = 0, mm_unsettled = 0;         // queries that went through the matrix cores / of them sent on to the exact scan
 };
 
 extern "C" void fir_set_last_error_(const char* msg);   // fir_capi.hip: feeds fir_last_error()
@@ -1012,6 +1022,8 @@ int fir_cls_destroy(fir_cls* c) {
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     (void)hipFree(c->gal2); (void)hipFree(c->avg); (void)hipFree(c->class_off); (void)hipFree(c->dq); (void)hipFree(c->qn);
     (void)hipFree(c->sums); (void)hipFree(c->scores); (void)hipFree(c->best);
+    if (c->mm) (void)fir_gemm_destroy(c->mm);
+    (void)hipFree(c->qc); (void)hipFree(c->knn_rows); (void)hipFree(c->knn_dist); (void)hipFree(c->knn_ok);
     if (c->pin) (void)hipHostFree(c->pin);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1176,15 +1188,107 @@ int fir_cls_pnn_predict_seq(fir_cls* c, const double* queries, int32_t qb, doubl
     return FIR_OK;
 }
 
+}  // extern "C"
+
+namespace {
+constexpr int kKnnMfmaQueries = 128;       // automatic mode: kNN batches from this size on take the matrix cores (training sets streamed from HBM)
+
+// qc[i][k] = q[i][k] - avg[k]: the query side of normalize() (classification.cpp:103-105, :135), row-major
+__global__ void __launch_bounds__(kBlock) k_cls_center_queries(const double* __restrict__ q, int64_t count, int d, const double* __restrict__ avg, double* __restrict__ qc) {
+    const int64_t o = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (o < count) qc[o] = q[o] - avg[o % d];
+}
+
+// The vote over a query's K' nearest rows (ascending, exact float64 distances; fir_gemm_f64.h): classification.cpp:154-160 walks the
+// sorted rows and stops at the first class with K votes. best[q] <- that class when the walk ends inside the K' rows, the certificate
+// holds and no two of the rows looked at (nor the deciding row and its successor) have EQUAL distances -- the reference's std::sort
+// leaves the order of equal distances open, and the exact path has its own rule for them --, else -1: the exact scan answers.
+__global__ void __launch_bounds__(kBlock) k_cls_knn_vote(const int32_t* __restrict__ rows, const double* __restrict__ dist, const int32_t* __restrict__ ok, int nq, int kp, int k,
+                                                          const int32_t* __restrict__ class_off, int num_classes, int32_t* __restrict__ best) {
+    const int q = blockIdx.x * kBlock + threadIdx.x;
+    if (q >= nq) return;
+    int res = -1;
+    if (ok[q]) {
+        int cls[8];
+        for (int j = 0; j < kp; ++j) {
+            const int r = rows[(size_t)q * kp + j];
+            if (r < 0) break;
+            if (j > 0 && dist[(size_t)q * kp + j] == dist[(size_t)q * kp + j - 1]) break;          // equal distances: not ours to order
+            int lo = 0, hi = num_classes;                                                         // class_off[lo] <= r < class_off[hi]
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (class_off[mid] <= r) lo = mid; else hi = mid; }
+            cls[j] = lo;
+            int votes = 0;
+            for (int i = 0; i <= j; ++i) votes += cls[i] == lo ? 1 : 0;
+            if (votes >= k) {
+                // (the successor of the deciding row: inside the K' rows it is known; past them the certificate says nothing ties with the K'-th)
+                const bool tie_next = j + 1 < kp && rows[(size_t)q * kp + j + 1] >= 0 && dist[(size_t)q * kp + j + 1] == dist[(size_t)q * kp + j];
+                if (!tie_next) res = lo;
+                break;
+            }
+        }
+    }
+    best[q] = res;
+}
+
+// kNN through the matrix cores for the queries of one call (qb <= cls_batch): 0 = best_class filled for every query, 1 = not taken (the
+// exact path answers the call), < 0 = error.
+int cls_knn_mfma(fir_cls* c, const double* queries, int32_t qb, int32_t k, int32_t* best_class);
+}  // namespace
+
+extern "C" {
+
+int fir_cls_set_knn_mfma(fir_cls* c, int32_t min_queries) {
+    if (!c) return cls_fail(FIR_ERR_ARG, "NULL argument");
+    c->mm_mode = min_queries < 0 ? -1 : min_queries;
+    if (min_queries == 0 && c->mm) { (void)fir_gemm_destroy(c->mm); c->mm = nullptr; }
+    c->mm_failed = false;
+    return FIR_OK;
+}
+
+int fir_cls_knn_stats(fir_cls* c, int64_t* matrix_core_queries, int64_t* exact_scan_queries_of_them) {
+    if (!c) return cls_fail(FIR_ERR_ARG, "NULL argument");
+    if (matrix_core_queries) *matrix_core_queries = c->mm_queries;
+    if (exact_scan_queries_of_them) *exact_scan_queries_of_them = c->mm_unsettled;
+    return FIR_OK;
+}
+
+int fir_cls_last_dispatch(fir_cls* c, char* kernel, int32_t kernel_cap, double* bytes_per_launch, double* flops_per_launch) {
+    if (!c) return cls_fail(FIR_ERR_ARG, "NULL argument");
+    if (kernel && kernel_cap > 0) std::snprintf(kernel, (size_t)kernel_cap, "%s", c->last_kernel);
+    if (bytes_per_launch) *bytes_per_launch = c->last_bytes;
+    if (flops_per_launch) *flops_per_launch = c->last_flops;
+    return FIR_OK;
+}
+
+static int cls_knn_exact(fir_cls* c, const double* queries, int32_t qb, int32_t k, int32_t* best_class);
+
 int fir_cls_knn_predict(fir_cls* c, const double* queries, int32_t qb, int32_t k, int32_t* best_class) {
     if (!c || !best_class || (qb > 0 && !queries)) return cls_fail(FIR_ERR_ARG, "NULL argument");
     if (qb < 0) return cls_fail(FIR_ERR_ARG, "qb < 0");
     if (k < 1 || k > kKMax) return cls_fail(FIR_ERR_ARG, "k=%d outside [1,%d]", k, kKMax);
     if (qb == 0) return FIR_OK;
+    // Large batches against a training set that streams from HBM: the matrix cores nominate the K' nearest rows, float64 re-ranks them,
+    // the vote is taken over those; what that does not settle falls through to the exact scan below (fir_gemm_f64.h). Same classes.
+    const bool big = (double)c->tiles * 64.0 * c->dp2 * 16.0 > 256.0 * 1024 * 1024;
+    const bool want = c->mm_mode > 0 ? qb >= c->mm_mode : (c->mm_mode < 0 && big && qb >= kKnnMfmaQueries);
+    if (want && !c->mm_failed && c->nt > 0) {
+        const int32_t b = std::min<int32_t>(65536, std::max<int32_t>(cls_batch(c), 8192));
+        bool all = true;
+        for (int32_t q0 = 0; q0 < qb && all; q0 += b) {
+            const int rc0 = cls_knn_mfma(c, queries + (size_t)q0 * c->d, std::min(b, qb - q0), k, best_class + q0);
+            if (rc0 < 0) return rc0;
+            if (rc0 == 1) { if (q0 != 0) return cls_fail(FIR_ERR_STATE, "the matrix-core kNN path stopped in the middle of a call"); all = false; }
+        }
+        if (all) return FIR_OK;
+    }
+    return cls_knn_exact(c, queries, qb, k, best_class);
+}
+
+static int cls_knn_exact(fir_cls* c, const double* queries, int32_t qb, int32_t k, int32_t* best_class) {
     if (qb > cls_batch(c)) {
         const int32_t b = cls_batch(c);
         for (int32_t q0 = 0; q0 < qb; q0 += b) {
-            const int rc0 = fir_cls_knn_predict(c, queries + (size_t)q0 * c->d, std::min(b, qb - q0), k, best_class + q0);
+            const int rc0 = cls_knn_exact(c, queries + (size_t)q0 * c->d, std::min(b, qb - q0), k, best_class + q0);
             if (rc0) return rc0;
         }
         return FIR_OK;
@@ -1209,6 +1313,83 @@ int fir_cls_knn_predict(fir_cls* c, const double* queries, int32_t qb, int32_t k
     if (small) std::memcpy(best_class, dbest, (size_t)qb * sizeof(int32_t));
     return FIR_OK;
 }
+
+}  // extern "C"
+
+namespace {
+int cls_knn_mfma(fir_cls* c, const double* queries, int32_t qb, int32_t k, int32_t* best_class) {
+    CLS_HIP(hipSetDevice(c->device));
+    if (!c->mm) {
+        const int rc = fir_gemm_create_f64_(c->device, c->cus, c->stream, c->gal2, c->nt, c->d, c->dp2, &c->mm);
+        if (rc) {
+            c->mm = nullptr;
+            if (c->mm_mode > 0 || (rc != FIR_ERR_ARG && rc != FIR_ERR_NOMEM)) return rc;     // asked for explicitly, or a real failure
+            (void)hipGetLastError();
+            c->mm_failed = true;                                                             // automatic: this shape (or this much HBM) stays with the exact scan
+            return 1;
+        }
+    }
+    const int kp = k == 1 ? 1 : 8;           // rows nominated per query: the walk of kNN-K ends inside the 8 nearest rows unless the classes are very mixed
+    int rc;
+    if ((rc = cls_grow(c->dq, c->dq_cap, (size_t)qb * c->d))) return rc;
+    if ((rc = cls_grow(c->qc, c->qc_cap, (size_t)qb * c->d))) return rc;
+    if ((rc = cls_grow(c->knn_rows, c->knn_rows_cap, (size_t)qb * 8))) return rc;
+    if ((rc = cls_grow(c->knn_dist, c->knn_dist_cap, (size_t)qb * 8))) return rc;
+    if ((rc = cls_grow(c->knn_ok, c->knn_ok_cap, (size_t)qb))) return rc;
+    if ((rc = cls_grow(c->best, c->best_cap, (size_t)qb))) return rc;
+    CLS_HIP(hipMemcpyAsync(c->dq, queries, (size_t)qb * c->d * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    const int64_t count = (int64_t)qb * c->d;
+    hipLaunchKernelGGL(k_cls_center_queries, dim3((unsigned)((count + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, c->dq, count, c->d, c->avg, c->qc);
+    hipEvent_t* evp = nullptr;
+    if (c->profiling) {
+        if (c->ev_used + 2 > c->ev.size())
+            for (int i = 0; i < 64; ++i) {
+                hipEvent_t e;
+                if (hipEventCreate(&e) != hipSuccess) break;
+                c->ev.push_back(e);
+            }
+        if (c->ev_used + 2 <= c->ev.size()) evp = &c->ev[c->ev_used];
+    }
+    const char* kname = nullptr;
+    double flops = 0.0;
+    if ((rc = fir_gemm_knn_f64_(c->mm, c->qc, qb, kp, c->knn_rows, c->knn_dist, c->knn_ok, c->stream, &kname, &flops, evp))) return rc;
+    if (evp) {
+        c->ev_used += 2;
+        c->last_bytes = 0.0;
+        c->last_flops = flops;
+        if (kname) std::snprintf(c->last_kernel, sizeof c->last_kernel, "%s", kname);
+    }
+    hipLaunchKernelGGL(k_cls_knn_vote, dim3((qb + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, c->knn_rows, c->knn_dist, c->knn_ok, qb, kp, k, c->class_off, c->num_classes,
+                       c->best);
+    CLS_HIP(hipGetLastError());
+    CLS_HIP(hipMemcpyAsync(best_class, c->best, (size_t)qb * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    CLS_HIP(hipStreamSynchronize(c->stream));
+    c->mm_queries += qb;
+    // what the K' rows did not settle: the exact scan (classification.cpp's own loop over every row), a tile of queries at a time
+    std::vector<int32_t> which;
+    for (int32_t i = 0; i < qb; ++i)
+        if (best_class[i] < 0) which.push_back(i);
+    if (!which.empty()) {
+        c->mm_unsettled += (int64_t)which.size();
+        std::vector<double> sub(which.size() * (size_t)c->d);
+        for (size_t i = 0; i < which.size(); ++i) std::memcpy(&sub[i * (size_t)c->d], queries + (size_t)which[i] * c->d, (size_t)c->d * sizeof(double));
+        std::vector<int32_t> cls(which.size());
+        char keep[sizeof c->last_kernel];
+        std::memcpy(keep, c->last_kernel, sizeof keep);
+        const double keep_flops = c->last_flops;
+        if ((rc = cls_knn_exact(c, sub.data(), (int32_t)which.size(), k, cls.data()))) return rc;
+        for (size_t i = 0; i < which.size(); ++i) best_class[which[i]] = cls[i];
+        if (evp) {                                       // the call's dominant kernel stays the matrix-core pass
+            std::memcpy(c->last_kernel, keep, sizeof keep);
+            c->last_flops = keep_flops;
+            c->last_bytes = 0.0;
+        }
+    }
+    return 0;
+}
+}  // namespace
+
+extern "C" {
 
 int fir_cls_knn_class_nearest(fir_cls* c, const double* queries, int32_t qb, int32_t k, double* nearest) {
     if (!c || !nearest || (qb > 0 && !queries)) return cls_fail(FIR_ERR_ARG, "NULL argument");

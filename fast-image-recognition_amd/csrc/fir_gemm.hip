@@ -1555,6 +1555,8 @@ struct fir_gemm {
     int regtile = -1;                     // fp16 full pass through the register-tile kernel: -1 = where it measured faster (rows up to 256 features), 0 / 1 = never / wherever it exists (FIR_GEMM_REGTILE)                  // fp16 full pass: query fragments in registers, gallery through the LDS-DMA ring (FIR_GEMM_REGTILE=0: the LDS-tile kernel)
     int mfma16 = 0;                       // fp16: both operands in the 16-row fragment order, every pass on v_mfma_f32_16x16x32_f16 (fir_gemm_f16x.h): the default since it was
                                           // measured against the 32x32x16 kernels at the same wave tile (profiles/r03_mfma_shape_ab.txt); FIR_GEMM_MFMA16=0 brings those back
+    bool f64 = false;                     // the nomination state of a float64 training set owned by fir_cls.hip (fir_gemm_f64.h)
+    const double2* gal2 = nullptr; int dp2 = 0;
     int adaptive_topk = 1;                // ... and for the K nearest rows (k_gemm_proxy_f16x<4, *>: K slot minima per query); FIR_GEMM_ADAPTIVE_TOPK=0: the sample flow
     int adaptive = 1;                     // 16-row top-1 flow: the append threshold is found during the full pass (k_gemm_proxy_f16x<3, *>), no sample pass
                                           // (profiles/r03_adaptive_threshold.txt); FIR_GEMM_ADAPTIVE=0: the sample flow
@@ -1818,7 +1820,7 @@ int fir_gemm_create_range_ex_(fir_gallery* g, int32_t precision, int32_t end_pos
 int fir_gemm_destroy(fir_gemm* m) {
     if (!m) return FIR_OK;
     (void)hipSetDevice(m->v.device);
-    (void)hipStreamSynchronize(m->v.stream);
+    if (m->v.stream || !m->f64) (void)hipStreamSynchronize(m->v.stream);
     if (m->side) { (void)hipStreamSynchronize(m->side); (void)hipStreamDestroy(m->side); }
     for (int b = 0; b < 2; ++b) {
         (void)hipFree(m->qm[b]); (void)hipFree(m->qbf[b]); (void)hipFree(m->qnorm[b]); (void)hipFree(m->qmul[b]); (void)hipFree(m->qinv[b]); (void)hipFree(m->smin[b]); (void)hipFree(m->tau[b]); (void)hipFree(m->awin[b]); (void)hipFree(m->aT[b]); (void)hipFree(m->lists[b]); (void)hipFree(m->counts[b]);
@@ -2379,3 +2381,5 @@ int fir_gemm_search_staged_(fir_gemm* m, const float* h_queries, float* d_stage,
 }
 
 }  // extern "C"
+
+#include "fir_gemm_f64.h"

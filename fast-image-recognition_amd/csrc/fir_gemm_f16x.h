@@ -124,8 +124,10 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
     // MODE 1: appends are staged per workgroup in LDS (an LDS atomic counts in lgkmcnt and returns in ~100 cycles; a returning GLOBAL
     // atomic sits in the in-order vmcnt queue behind the prefetched gallery loads -- every append drained the wave's stream) and
     // flushed to the global lists once, at the end; a query that fills its kXStage slots appends directly (rare, correct)
-    // MODE 4: MODE 3 for the K nearest rows (K = sub_stride, 2..8). Per query EIGHT slot minima over disjoint row sets (row block rb
-    // belongs to slot rb mod 8): the K smallest slot minima belong to K distinct rows, so T = (the K-th smallest slot minimum + |q|^2) +
+    // MODE 4: MODE 3 for the K nearest rows (K = sub_stride, 2..8). Per query EIGHT slot minima over disjoint row sets -- slot i = the rows a
+    // lane holds in position i of its eight (rows 16 (i >> 2) + 4 (lane >> 4) + (i & 3) of every row block): four rows of EVERY block feed
+    // every slot, so a cluster of a few dozen near rows fills all eight at once (slots by row block left the slots of a class-ordered
+    // training set to different classes: profiles/r04_knn_matrix_cores.txt) -- the K smallest slot minima belong to K distinct rows, so T = (the K-th smallest slot minimum + |q|^2) +
     // window bounds the K-th smallest proxy of all rows from above -- what the K-nearest re-rank's certificate needs (k_gemm_rerank_topk:
     // window hung on the K-th smallest proxy of the list). Every slot only falls, so T only falls, and the MODE 3 argument carries over
     // word for word. The slots live in LDS (slot_s, as the float bits of (slot minimum + |q|^2) + window, >= 0) and in `smin` (8 words
@@ -294,22 +296,27 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
         const unsigned int tk = kth_of_slots(&slot_s[q * 8]);
         if (tk < atomicMin((unsigned int*)&tau_s[q], tk)) tq_s[q] = __uint_as_float(tk) - qn_s[q];
     };
-    // a new smallest proxy `mn` of row block rbq for query q: T falls, here and (through `smin`) for everybody else
-    auto lower_T = [&](int q, int64_t rbq, float mn) {
-        const float tn = fmaxf((mn + qn_s[q]) + win_s[q], 0.f);
+    // a new smallest proxy `mn` (= the smallest of the lane's eight proxies pv) for query q: T falls, here and (through `smin`) for everybody else
+    auto lower_T = [&](int q, const float (&pv)[8], float mn) {
         if (!kSlots) {
+            const float tn = fmaxf((mn + qn_s[q]) + win_s[q], 0.f);
             if (tn < tau_s[q]) {
                 if (__float_as_uint(tn) < atomicMin((unsigned int*)&tau_s[q], __float_as_uint(tn))) tq_s[q] = tn - qn_s[q];
                 atomicMin(&smin[q], __float_as_uint(tn));
             }
         } else {
-            const int sl = (int)(rbq & 7);
-            if (tn < __uint_as_float(slot_s[q * 8 + sl])) {
-                if (__float_as_uint(tn) < atomicMin(&slot_s[q * 8 + sl], __float_as_uint(tn))) {
-                    atomicMin(&smin[q * 8 + sl], __float_as_uint(tn));
-                    slots_to_T(q);
+            bool fell = false;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float tn = fmaxf((pv[i] + qn_s[q]) + win_s[q], 0.f);        // (a NaN proxy: fmaxf gives 0 + ... no: NaN + x = NaN, fmaxf(NaN, 0) = 0 -- kept out by the test on pv[i] itself)
+                if (pv[i] == pv[i] && tn < __uint_as_float(slot_s[q * 8 + i])) {
+                    if (__float_as_uint(tn) < atomicMin(&slot_s[q * 8 + i], __float_as_uint(tn))) {
+                        atomicMin(&smin[q * 8 + i], __float_as_uint(tn));
+                        fell = true;
+                    }
                 }
             }
+            if (fell) slots_to_T(q);
         }
     };
     bool exchange = false;
@@ -377,8 +384,8 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
         }
         float4 gns[2];                               // squared norms of rows 16 s + 4 (lane >> 4) + 0..3 of the block
         const bool full_block = active && rbp * 32 >= row_begin && rbp * 32 + 32 <= row_end && rb * 32 + 32 <= n && (MODE != 0 || rb * 32 + 32 <= sample_rows);
-        // MODE 2, sub_stride: sixteen row ranges x four waves = kRtSubsets disjoint subsets (more ranges wrap around: unions of disjoint sets)
-        unsigned int* smin_blk = MODE == 2 ? smin + (size_t)(((range & 15) << 2) + (wave & 3)) * sub_stride : nullptr;
+        // MODE 2, sub_stride: eight positions x eight waves = kRtSubsets disjoint subsets of the sampled rows (below)
+        unsigned int* smin_blk = MODE == 2 ? smin + (size_t)(wave & 7) * sub_stride : nullptr;       // (position 0's subset of this wave)
         // one query block of a full row block `rbq` against the bound (the append forms, not the warm-up walk); g0 / g1 / gminq = the
         // block's row norms and their minimum
         auto check_jb = [&](int jb, int64_t rbq, const float4 g0, const float4 g1, float gminq) {
@@ -425,7 +432,7 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
                         }
                     }
                 }
-                if (kAdapt) lower_T(q, rbq, mn);
+                if (kAdapt) lower_T(q, pv, mn);
             }
         };
         auto unit = [&](uint4 (&C)[kRing], uint4 (&N)[kRing], int h, auto first_tag) {
@@ -541,27 +548,41 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
                         mn = fminf(mn, pv[4 * s + reg]);                   // NaN never enters, like k_gemm_tau's ordering
                     }
                 }
-                if (kAdapt && warm_it) {
+                if (kSlots && warm_it) {
+                    // observe only: every lane's eight proxies lower their slots (LDS; the exchange behind the warm-up turns the slots into T)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float tn = fmaxf((pv[i] + qn_s[q]) + win_s[q], 0.f);
+                        if (pv[i] == pv[i] && tn < __uint_as_float(slot_s[q * 8 + i])) atomicMin(&slot_s[q * 8 + i], __float_as_uint(tn));
+                    }
+                } else if (kAdapt && warm_it) {
                     // observe only: the smallest proxy of the block's 32 rows lowers T (LDS; the workgroup exchanges with `smin` afterwards)
                     float o = __shfl_xor(mn, 16, 64);
                     mn = o < mn ? o : mn;
                     o = __shfl_xor(mn, 32, 64);
                     mn = o < mn ? o : mn;
                     const float tn = fmaxf((mn + qn_s[q]) + win_s[q], 0.f);     // (NaN operands: fmaxf gives 0 only if both are NaN; a NaN tn fails the test below)
-                    if (kSlots) {
-                        const int sl = (int)(rb & 7);                           // (the exchange behind the warm-up turns the slots into T)
-                        if (lane < 16 && tn < __uint_as_float(slot_s[q * 8 + sl])) atomicMin(&slot_s[q * 8 + sl], __float_as_uint(tn));
-                    } else
                     if (lane < 16 && tn < tau_s[q]) atomicMin((unsigned int*)&tau_s[q], __float_as_uint(tn));
                 } else if (MODE == 2 && !sub_stride) {
                     smallest[jb] = fminf(smallest[jb], mn);
+                } else if (MODE == 2) {
+                    // the K-nearest sample: kRtSubsets = 8 positions (of a lane's eight rows) x 8 waves disjoint subsets -- every sampled row
+                    // block feeds eight of them (a class of a few dozen rows then shows in eight subsets, not in one)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        float v = pv[i] == pv[i] ? pv[i] : __builtin_huge_valf();
+                        float o = __shfl_xor(v, 16, 64);
+                        v = o < v ? o : v;
+                        o = __shfl_xor(v, 32, 64);
+                        v = o < v ? o : v;
+                        if (lane < 16 && v < __builtin_huge_valf()) atomicMin(&smin[(size_t)(i * 8 + (wave & 7)) * sub_stride + q], fir::f32_orderable(v));
+                    }
                 } else {
                     float o = __shfl_xor(mn, 16, 64);
                     mn = o < mn ? o : mn;
                     o = __shfl_xor(mn, 32, 64);
                     mn = o < mn ? o : mn;
                     if (MODE == 0) { if (lane < 16) sample[(size_t)(rb - rb_begin) * (2 * kQT) + q] = mn; }
-                    else if (lane < 16 && mn < __builtin_huge_valf()) atomicMin(&smin_blk[q], fir::f32_orderable(mn));
                 }
             }
             continue;
@@ -595,7 +616,7 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
                 o = __shfl_xor(mn, 32, 64);
                 mn = o < mn ? o : mn;
                 if (MODE == 0) { if (lane < 16) sample[(size_t)(rb - rb_begin) * (2 * kQT) + q] = mn; }
-                else if (lane < 16 && mn < __builtin_huge_valf()) atomicMin(&smin_blk[q], fir::f32_orderable(mn));
+                else if (lane < 16 && mn < __builtin_huge_valf()) atomicMin(&smin_blk[q], fir::f32_orderable(mn));     // (a straddling block: one subset takes its minimum)
             }
         }
     }
@@ -629,7 +650,7 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
                         }
                     }
                 }
-                if (kAdapt) lower_T(q, p_rb, mn);
+                if (kAdapt) lower_T(q, pv, mn);
             }
         };
 #pragma unroll

@@ -84,3 +84,9 @@ extern "C" void fir_gemm_memory_bytes_(const fir_gemm* m, int64_t* fragments, in
 struct fir_cls;
 extern "C" int fir_cls_pnn_scores_dev_(fir_cls* c, const double* queries, int32_t qb, double var, double** d_scores, void** stream, int32_t* max_batch);
 extern "C" int fir_cls_knn_nearest_dev_(fir_cls* c, const double* queries, int32_t qb, int32_t k, double** d_lists, void** stream, int32_t* max_batch);
+
+// fir_gemm_f64.h: the matrix-core nomination over a float64 training set (tiled layout of fir_cls.hip), for large kNN batches
+extern "C" int fir_gemm_create_f64_(int device, int cus, void* stream, const void* gal2, int64_t nt, int d, int dp2, fir_gemm** out);
+extern "C" int fir_gemm_knn_f64_(fir_gemm* m, const double* d_qc, int32_t qb, int32_t kp, int32_t* d_rows, double* d_dist, int32_t* d_ok, void* stream,
+                                 const char** kernel_name, double* flops_per_launch, hipEvent_t* ev_pair);
+extern "C" int fir_gemm_destroy(fir_gemm* m);

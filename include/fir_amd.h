@@ -180,8 +180,21 @@ int fir_cls_pnn_predict(fir_cls* c, const double* queries, int32_t qb, double va
  * chunks_out[qb] (may be NULL) <- chunks used. */
 int fir_cls_pnn_predict_seq(fir_cls* c, const double* queries, int32_t qb, double var, int32_t* best_class, int32_t* chunks_out);
 /* KNNClassifier::predict, classification.cpp:116-170: rows sorted by mean distance vote for their
- * class until one class has k votes. 1 <= k <= 8. best_class[qb]. */
+ * class until one class has k votes. 1 <= k <= 8. best_class[qb].
+ * Batches of >= 128 queries against a training set that streams from HBM (> 256 MiB of rows) go through the matrix cores: an fp16
+ * copy of the centred rows nominates the nearest rows (one for k = 1, eight for k > 1), the reference's float64 arithmetic re-ranks
+ * them and a rounding-error certificate proves that no other row can be among them; the vote is taken over those rows. A query that
+ * is not certified, whose eight rows do not settle the vote, or with equal distances among them goes through the exact scan of every
+ * row as before: the classes are the exact scan's either way. Costs the fp16 copy (nt * d * 2 bytes), made on first use. */
 int fir_cls_knn_predict(fir_cls* c, const double* queries, int32_t qb, int32_t k, int32_t* best_class);
+/* min_queries > 0: kNN batches of at least that many queries take the matrix cores whatever the training set's size; 0: never (frees
+ * the fp16 copy); < 0: back to the automatic choice above. */
+int fir_cls_set_knn_mfma(fir_cls* c, int32_t min_queries);
+/* queries that took the matrix-core path so far, and how many of them the exact scan answered after all */
+int fir_cls_knn_stats(fir_cls* c, int64_t* matrix_core_queries, int64_t* exact_scan_queries_of_them);
+/* the dominant kernel of the most recent PROFILED launch (fir_cls_profile_enable): name, algorithmic bytes (scans), dot-product flops
+ * (matrix-core passes: 2 * rows * d * queries of the launch) */
+int fir_cls_last_dispatch(fir_cls* c, char* kernel, int32_t kernel_cap, double* bytes_per_launch, double* flops_per_launch);
 /* The part of that vote a row shard can do alone: nearest[qb][num_classes][k] <- the k smallest mean distances of every
  * class among the rows held, ascending, DBL_MAX where the class has fewer. The class that first collects k votes in the
  * globally sorted order is the one whose k-th nearest member is nearest, so ranks exchange these lists, keep the k

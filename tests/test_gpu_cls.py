@@ -272,3 +272,109 @@ def test_a_failing_training_set_shard_fails_pnn_and_knn_instead_of_blocking(fir,
         b, _ = s.pnn_predict(q)
         kk = s.knn_predict(q, 3)
     assert np.array_equal(kk, k0) and (b == b0).mean() > 0.9
+
+
+def _mixed_training_set(n, d, ncls, seed, spread):
+    """Class-major float64 rows whose classes overlap (centre + spread x noise): the nearest rows of a query belong to several classes"""
+    rng = np.random.default_rng(seed)
+    centres = rng.random((ncls, d))
+    tcls = np.sort(rng.integers(0, ncls, n)).astype(np.int32)
+    tr = centres[tcls] + spread * rng.standard_normal((n, d))
+    return tr, tcls, centres, rng
+
+
+@pytest.mark.parametrize("k", [1, 3, 5])
+@pytest.mark.parametrize("spread", [0.004, 0.3])
+def test_knn_batches_through_the_matrix_cores_give_the_exact_scans_classes(fir, oracle, k, spread):
+    """VERDICT r3 item 3 (row a12): KNNClassifier::predict (classification.cpp:116-170) for a batch -- fp16 fragments of the centred
+    float64 rows nominate, the reference's float64 arithmetic re-ranks, the certificate covers the rest, the vote runs over the K'
+    nearest rows; what that does not settle takes the exact scan. Forced on (fir_cls_set_knn_mfma) for a 40 000 x 96 training set:
+    well separated classes (every vote settles inside the nominated rows) and heavily overlapping ones (many walks need more than
+    eight rows: those queries fall through), exact duplicates across classes (equal distances: never ours to order), a query that IS
+    a training row, a NaN query. Classes = the exact scan's for every query, = the oracle's on a sample."""
+    n, d, ncls, qb = 40_000, 96, 23, 300
+    tr, tcls, centres, rng = _mixed_training_set(n, d, ncls, 31, spread)
+    tr[n - 7] = tr[11]                                    # the same row in the first and in the last class: equal distances
+    tr[n // 2] = tr[11]
+    q = centres[rng.integers(0, ncls, qb)] + spread * rng.standard_normal((qb, d))
+    q[0] = tr[11]
+    q[1] = tr[777]
+    q[2, 5] = np.nan
+    q[3] = 0.5 * (tr[100] + tr[n - 100])                  # halfway between two classes
+    _, _, avg, _ = oracle.train_stats(tr)
+    with fir.ClsModel(tr, tcls, ncls, avg, 0) as m:
+        m.set_knn_mfma(0)
+        exact = m.knn_predict(q, k)
+        m.set_knn_mfma(1)
+        got = m.knn_predict(q, k)
+        st = m.knn_stats()
+        again = m.knn_predict(q[:130], k)                 # a second, smaller batch on the same state (a half-filled pair)
+    assert np.array_equal(got, exact)
+    assert np.array_equal(again, exact[:130])
+    assert st["matrix_core_queries"] == qb
+    if spread < 0.01:
+        assert st["exact_scan_queries_of_them"] <= 8, st  # the duplicates, the NaN query, the halfway query at most
+    for i in (1, 3, 7, 150, 299):
+        assert got[i] == oracle.knn_predict(tr, tcls, avg, ncls, q[i], k)[0], i
+
+
+def test_knn_matrix_core_certificate_is_needed_and_a_shrunken_bound_is_caught(fir, fir_audit, oracle, monkeypatch):
+    """The audit of test_gpu_gemm.py::test_the_certificate_bound_is_needed... for the float64 classifier: a coherent-rounding near-tie
+    (every component of row A rounds DOWN to fp16, every component of row B UP: B's proxy is lower than A's by 0.77 of the rounding
+    window although A is the query itself) between rows of two classes, avg = 0 so that the centred rows are the rows. With the bound
+    as derived kNN-1 returns A's class; with FIR_GEMM_EREL_SCALE=0.25 -- honoured by the audit build only -- A falls out of the
+    window, B is certified and the WRONG class comes back: the suite can see an unsound bound on this path too."""
+    rng = np.random.default_rng(91)
+    n, d, ncls = 6000, 512, 2
+    tr = rng.random((n, d))
+    a = np.full(d, 1.0 + 0.499 * 2.0 ** -10)
+    b = np.full(d, 1.0 + 0.501 * 2.0 ** -10)
+    ia, ib = n // 3, 2 * n // 3 + 5
+    tr[ia], tr[ib] = a, b
+    tcls = (np.arange(n) >= n // 2).astype(np.int32)      # class 0: the first half (A), class 1: the second (B)
+    q = np.vstack([a] + [tr[i] * 0.999 for i in (7, 99, 1234)] + [rng.random(d) for _ in range(124)])
+    avg = np.zeros(d)
+    got = {}
+    for lib_name, pkg in (("audit", fir_audit), ("shipped", fir)):
+        for scale in ("1", "0.25"):
+            monkeypatch.setenv("FIR_GEMM_EREL_SCALE", scale)
+            with pkg.ClsModel(tr, tcls, ncls, avg, 0) as m:
+                m.set_knn_mfma(1)
+                got[lib_name, scale] = (m.knn_predict(q, 1), m.knn_stats())
+        monkeypatch.delenv("FIR_GEMM_EREL_SCALE")
+    with fir.ClsModel(tr, tcls, ncls, avg, 0) as m:
+        m.set_knn_mfma(0)
+        exact = m.knn_predict(q, 1)
+    assert exact[0] == 0 == oracle.knn_predict(tr, tcls, avg, ncls, q[0], 1)[0]
+    for key in (("audit", "1"), ("shipped", "1"), ("shipped", "0.25")):
+        assert np.array_equal(got[key][0], exact), key
+    wrong, st = got["audit", "0.25"]
+    assert wrong[0] == 1 and st["exact_scan_queries_of_them"] <= 2, (wrong[0], st)     # B's class, certified: the shrunken bound is unsound and it shows
+
+
+def test_knn_at_scale_takes_the_matrix_cores_by_default(fir, oracle):
+    """300 000 x 256 float64 rows (614 MB: streams from HBM), 1 024 queries: the default dispatch nominates through the matrix cores
+    (fir_cls_last_dispatch names the pass), kNN-1 / kNN-3 classes equal the exact scan's, (nearly) nothing falls through."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda", 0)
+    n, d, ncls, qb = 300_000, 256, 300, 1024
+    g = torch.Generator(device=dev)
+    g.manual_seed(4)
+    centres = torch.rand((ncls, d), generator=g, device=dev, dtype=torch.float64)
+    tcls = (torch.arange(n, device=dev) * ncls // n).to(torch.int64)
+    tr = centres[tcls] + 0.05 * torch.randn((n, d), generator=g, device=dev, dtype=torch.float64)
+    avg = tr.mean(dim=0).cpu().numpy()
+    pick = torch.randint(0, ncls, (qb,), generator=g, device=dev)
+    q = (centres[pick] + 0.05 * torch.randn((qb, d), generator=g, device=dev, dtype=torch.float64)).cpu().numpy()
+    torch.cuda.synchronize()
+    with fir.ClsModel(None, tcls.to(torch.int32).cpu().numpy(), ncls, avg, 0, dev_ptr=tr.data_ptr(), nt=n, d=d) as m:
+        m.profile_enable(True)
+        k1, k3 = m.knn_predict(q, 1), m.knn_predict(q, 3)
+        disp = m.last_dispatch()
+        st = m.knn_stats()
+        m.set_knn_mfma(0)
+        e1, e3 = m.knn_predict(q[:256], 1), m.knn_predict(q[:256], 3)
+    assert "k_gemm_proxy_f16x" in disp["kernel"] and disp["flops_per_launch"] > 0, disp
+    assert np.array_equal(k1[:256], e1) and np.array_equal(k3[:256], e3)
+    assert np.mean(k1 == pick.cpu().numpy()) > 0.99
+    assert st["matrix_core_queries"] == 2 * qb and st["exact_scan_queries_of_them"] <= qb // 16, st
