@@ -956,6 +956,9 @@ def config5(args, fir, dev, ws):
         g.profile_enable(False)
         dd = g.last_dispatch()
         mem = g.memory_bytes()
+        # diagnostics: the first (up to 8) queries of the last state's life whose FIRST certificate did not hold -- [list entries asked for (4096 fit),
+        # the bound the pass appended below, the smallest stored proxy, |q|^2]; empty = every certificate held at the first pass
+        out["first_uncertified_queries"] = g.uncertified_notes()
         g.close()
     if len(ms) and dd["path"] == "mfma":
         avg = float(np.mean(ms))

@@ -477,7 +477,7 @@ int top1_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t start, 
     // chi-square batches over a large plain-range gallery: nomination scan + exact re-rank (topk_lists_dev with K = 1), the same
     // keys at about twice the rate; it synchronises `st` once (it has to know that no list overflowed) and leaves the call to the
     // exact scan below when it cannot answer (operands outside the plain range, list overflow)
-    if ((g->metric == kChi2 || g->metric == kKL) && g->gallery_plain && g->tiles_limit == 0 && !g->quiet && !g->profiling && qb >= 8 && g->n >= 65536 &&
+    if ((g->metric == kChi2 || g->metric == kKL) && g->gallery_plain && g->tiles_limit == 0 && !g->quiet && qb >= 8 && g->n >= 65536 &&
         g->qpp == 0) {
         int rc0 = FIR_OK;
         for (int q0 = 0; q0 < qb && rc0 == FIR_OK; q0 += 1024)       // candidate lists are 32 KiB per query: bounded scratch for any qb

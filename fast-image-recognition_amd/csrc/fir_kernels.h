@@ -959,13 +959,13 @@ __global__ void k_topk_tau(const uint64_t* __restrict__ gkeys, int nq, int nq_pa
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nq_pad) return;
     counts[q] = 0;
-    if (q >= nq) { tau[q] = -1.0f; return; }
+    if (q >= nq) { tau[q] = -__builtin_huge_valf(); return; }       // (-inf: no distance is at or below it -- a KL value can round to a small negative number, -1 could not tell)
     uint64_t worst = 0;
     for (int i = 0; i < K; ++i) {
         const uint64_t key = gkeys[(size_t)i * nq + q];
         worst = key > worst ? key : worst;
     }
-    if (worst == kKeyNone) { tau[q] = -1.0f; atomicOr(flag, 1); return; }
+    if (worst == kKeyNone) { tau[q] = -__builtin_huge_valf(); atomicOr(flag, 1); return; }
     // scale > 1: the append scan that follows uses a cheaper metric whose value is within (scale - 1) of the reference's
     tau[q] = f32_from_orderable((uint32_t)(worst >> 32)) * scale;
 }
@@ -1160,7 +1160,7 @@ __global__ void __launch_bounds__(64) k_query_entropy_widen(const float* __restr
     for (int off = 32; off >= 1; off >>= 1) { s += __shfl_xor(s, off, 64); e += __shfl_xor(e, off, 64); }
     if (threadIdx.x == 0) {
         sq[qi] = (float)e;
-        if (qi < nq && tau[qi] >= 0.0f) tau[qi] += 1.5f * coef * (s + __uint_as_float(smax[0]));
+        if (qi < nq && tau[qi] > -__builtin_huge_valf()) tau[qi] += 1.5f * coef * (s + __uint_as_float(smax[0]));    // (every sampled threshold is widened, a slightly negative one too: ADVICE r3)
     }
 }
 // sq[q] = sum of query q over [start, end); tau[q] += 1.5 * B, B = coef * (sq[q] + smax) the bound on |harmonic form - reference|
@@ -1175,7 +1175,7 @@ __global__ void __launch_bounds__(64) k_query_sums_widen(const float* __restrict
     for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
     if (threadIdx.x == 0) {
         sq[qi] = s;
-        if (qi < nq && tau[qi] >= 0.0f) tau[qi] += 1.5f * coef * (s + __uint_as_float(smax[0]));
+        if (qi < nq && tau[qi] > -__builtin_huge_valf()) tau[qi] += 1.5f * coef * (s + __uint_as_float(smax[0]));    // (every sampled threshold is widened, a slightly negative one too: ADVICE r3)
     }
 }
 

@@ -510,7 +510,10 @@ __global__ void k_twd_prop_finish(int nq, int nchunks, int nseg, const DI* __res
 constexpr int kFusedBlock = 512;
 constexpr int kFusedMaxChunks = 64;
 constexpr int kFusedMaxQueries = 8;
-constexpr unsigned long long kFusedPatienceTicks = 25000000ull;     // wall_clock64() runs at 100 MHz: 0.25 s
+// A meeting takes ~5 us when every workgroup is resident (profiles/r03_twd_fused_latency.txt); the launch is only made when the occupancy
+// query says the whole grid fits the device at once (fused_grid_fits), so a workgroup that has not arrived after 5 ms is one that another
+// stream's kernels keep off the chip: the call then costs a fall-back to the launch-per-chunk form, not a quarter of a second.
+constexpr unsigned long long kFusedPatienceTicks = 500000ull;       // wall_clock64() runs at 100 MHz: 5 ms
 struct FusedSlot {
     unsigned long long vmin, best, cmin, cmax;    // ~orderable(min sum); ~((row << 32) | class); ~(ord(class) + 1); ord(class) + 1
 };
@@ -1176,6 +1179,17 @@ __global__ void __launch_bounds__(256) k_twd_publish(const int32_t* __restrict__
 
 extern "C" {
 
+// The hand-rolled grid meetings of the fused kernels need every workgroup of the launch resident at the same time: checked against the
+// occupancy query before the launch (MI355X_MICROARCH.md: the API can read one block per CU high near register-file edges, so one block of
+// margin is kept whenever more than one per CU is counted on), and bounded by kFusedPatienceTicks inside the kernel whatever else runs.
+static bool fused_grid_fits(const void* fn, int block, size_t dyn_lds, int workgroups, int cus) {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, block, dyn_lds) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (per_cu < 1) return false;
+    const int safe = per_cu > 1 ? per_cu - 1 : 1;
+    return workgroups <= safe * std::max(cus, 1);
+}
+
 int fir_twd_conventional(fir_gallery* g, const float* queries, int32_t qb, int32_t num_classes, int32_t type, double threshold,
                          int32_t reduced_features_count, int32_t* class_out, int32_t* unreliable_out) {
     fir_gallery_view v;
@@ -1229,6 +1243,15 @@ int fir_twd_conventional(fir_gallery* g, const float* queries, int32_t qb, int32
         // every query of a fused launch reads the rows for itself: beyond one tile per wave that costs more than the launches it saves
         // (100 000 x 512, 8 queries: 146 against 96 us), so several queries go this way only while every wave has a single tile
         if (!fT || (fq > 1 && fT > 1)) fused = false;
+        if (fused) {      // every workgroup of the launch must be resident at once: the occupancy query decides, not an assumption
+            const void* f16 = v.metric == 0 ? (fT == 1 ? (const void*)k_twd_conv_fused<fir::kL2, 1> : fT == 2 ? (const void*)k_twd_conv_fused<fir::kL2, 2>
+                                                     : fT == 4 ? (const void*)k_twd_conv_fused<fir::kL2, 4> : fT == 8 ? (const void*)k_twd_conv_fused<fir::kL2, 8>
+                                                                                                                      : (const void*)k_twd_conv_fused<fir::kL2, 16>)
+                                            : (fT == 1 ? (const void*)k_twd_conv_fused<fir::kChi2, 1> : fT == 2 ? (const void*)k_twd_conv_fused<fir::kChi2, 2>
+                                                     : fT == 4 ? (const void*)k_twd_conv_fused<fir::kChi2, 4> : fT == 8 ? (const void*)k_twd_conv_fused<fir::kChi2, 8>
+                                                                                                                        : (const void*)k_twd_conv_fused<fir::kChi2, 16>);
+            if (!fused_grid_fits(f16, kFusedBlock, type == 0 ? (size_t)num_classes * 8 : 8, fG * fq, v.cus)) fused = false;
+        }
     }
     const int fbatch = fused ? kFusedMaxQueries : batch;
     for (int q0 = 0; q0 < qb; q0 += fbatch) {
@@ -1365,6 +1388,15 @@ int fir_twd_proposed(fir_gallery* g, const float* queries, int32_t qb, int32_t r
         const int64_t need = (tiles + (int64_t)fG * 8 - 1) / ((int64_t)fG * 8);
         fT = need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : need <= 8 ? 8 : need <= 16 ? 16 : 0;
         if (!fT) fused = false;
+        if (fused) {      // every workgroup of the launch must be resident at once: the occupancy query decides, not an assumption
+            const void* f16 = v.metric == 0 ? (fT == 1 ? (const void*)k_twd_prop_fused<fir::kL2, 1> : fT == 2 ? (const void*)k_twd_prop_fused<fir::kL2, 2>
+                                                     : fT == 4 ? (const void*)k_twd_prop_fused<fir::kL2, 4> : fT == 8 ? (const void*)k_twd_prop_fused<fir::kL2, 8>
+                                                                                                                      : (const void*)k_twd_prop_fused<fir::kL2, 16>)
+                                            : (fT == 1 ? (const void*)k_twd_prop_fused<fir::kChi2, 1> : fT == 2 ? (const void*)k_twd_prop_fused<fir::kChi2, 2>
+                                                     : fT == 4 ? (const void*)k_twd_prop_fused<fir::kChi2, 4> : fT == 8 ? (const void*)k_twd_prop_fused<fir::kChi2, 8>
+                                                                                                                        : (const void*)k_twd_prop_fused<fir::kChi2, 16>);
+            if (!fused_grid_fits(f16, kFusedBlock, 0, fG * fq, v.cus)) fused = false;
+        }
     }
     const int batch = fused ? 8 : std::min(batch_for(n, (size_t)nchunks * 4 + 9, (size_t)1 << 30), std::max(8, (qb + 7) / 8 * 8));
     TWD_SLOT(dq, 0, (size_t)batch * v.d * 4);

@@ -131,6 +131,12 @@ def test_kl_nomination_scan_returns_the_exact_scans_keys(fir, oracle, monkeypatc
     rows[5000] = rows[4000]
     rows[5000, 7] = np.nextafter(rows[5000, 7], np.float32(1))     # near-tie one ulp apart
     q[3] = 0.5 * (rows[4000] + rows[123])
+    # a query that is a one-ulp neighbour of two gallery rows -- its KL value l log(2l/s) + r log(2r/s) cancels to a tiny number
+    # that can round below zero, and so can a sampled threshold: it must be widened like any other (the "no threshold" sentinel is -inf)
+    rows[6000] = rows[6100]
+    rows[6000, 3] = np.nextafter(rows[6000, 3], np.float32(0))
+    q[4] = rows[6100]
+    q[4, 3] = np.nextafter(q[4, 3], np.float32(1))
     with fir.Gallery(rows, None, fir.METRIC_KL, 0) as g:
         a1 = g.search_top1(q)                         # default dispatch: nomination
         a5 = g.search_topk(q, 5)
