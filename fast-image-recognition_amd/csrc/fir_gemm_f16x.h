@@ -190,7 +190,11 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
     const int wpb = blockDim.x >> 6;
     if (threadIdx.x < 2 * kQT) {
         if (kSlots) {
-            for (int sl = 0; sl < 8; ++sl) slot_s[threadIdx.x * 8 + sl] = atomicMin(&smin[threadIdx.x * 8 + sl], 0xFFFFFFFFu);
+            unsigned int v8[8];
+#pragma unroll
+            for (int sl = 0; sl < 8; ++sl) v8[sl] = atomicMin(&smin[threadIdx.x * 8 + sl], 0xFFFFFFFFu);
+#pragma unroll
+            for (int sl = 0; sl < 8; ++sl) slot_s[threadIdx.x * 8 + sl] = v8[sl];
             tau_s[threadIdx.x] = __uint_as_float(kth_of_slots(&slot_s[threadIdx.x * 8]));
         } else
         tau_s[threadIdx.x] = MODE == 1 ? tau[threadIdx.x] : MODE == 3 ? __uint_as_float(atomicMin(&smin[threadIdx.x], 0xFFFFFFFFu)) : 0.f;    // (MODE 3: an atomic, see the refresh below)
@@ -337,11 +341,13 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
                 __syncthreads();
                 if (threadIdx.x < 2 * kQT) {
                     if (kSlots) {
-                        for (int sl = 0; sl < 8; ++sl) {
-                            const unsigned int mine = slot_s[threadIdx.x * 8 + sl];
-                            const unsigned int old = (nt_flags & 8) ? mine : atomicMin(&smin[threadIdx.x * 8 + sl], mine);
-                            slot_s[threadIdx.x * 8 + sl] = old < mine ? old : mine;
-                        }
+                        unsigned int mine[8], old[8];
+#pragma unroll
+                        for (int sl = 0; sl < 8; ++sl) mine[sl] = slot_s[threadIdx.x * 8 + sl];
+#pragma unroll
+                        for (int sl = 0; sl < 8; ++sl) old[sl] = (nt_flags & 8) ? mine[sl] : atomicMin(&smin[threadIdx.x * 8 + sl], mine[sl]);
+#pragma unroll
+                        for (int sl = 0; sl < 8; ++sl) slot_s[threadIdx.x * 8 + sl] = old[sl] < mine[sl] ? old[sl] : mine[sl];
                         tau_s[threadIdx.x] = __uint_as_float(kth_of_slots(&slot_s[threadIdx.x * 8]));
                     } else {
                     const unsigned int mine = __float_as_uint(tau_s[threadIdx.x]);
@@ -365,12 +371,16 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
                     asm volatile("v_mov_b32 %0, 0" : "=v"(zl));
                     const int ql = 16 * wave + lane + zl;
                     if (kSlots) {
+                        // (all eight round trips in flight together: one after the other they cost a refresh eight memory latencies)
+                        unsigned int mine[8], old[8];
+#pragma unroll
+                        for (int sl = 0; sl < 8; ++sl) mine[sl] = slot_s[ql * 8 + sl];
+#pragma unroll
+                        for (int sl = 0; sl < 8; ++sl) old[sl] = atomicMin(&smin[ql * 8 + sl], mine[sl]);
                         bool fell = false;
-                        for (int sl = 0; sl < 8; ++sl) {
-                            const unsigned int mine = slot_s[ql * 8 + sl];
-                            const unsigned int old = atomicMin(&smin[ql * 8 + sl], mine);
-                            if (old < mine) { atomicMin(&slot_s[ql * 8 + sl], old); fell = true; }
-                        }
+#pragma unroll
+                        for (int sl = 0; sl < 8; ++sl)
+                            if (old[sl] < mine[sl]) { atomicMin(&slot_s[ql * 8 + sl], old[sl]); fell = true; }
                         if (fell) slots_to_T(ql);
                     } else {
                     const unsigned int mine = __float_as_uint(tau_s[ql]);
