@@ -6,7 +6,7 @@
 // cores answered, and it made a loose append threshold expensive: a list that overflows (kListCap rows below the threshold)
 // cost a host round trip plus ~0.35 ms of exact scan per 8 queries. Now:
 //
-//   1. the re-rank kernels append every uncertified query to `list` (GemmFb::count) together with the bound a SECOND pass
+//   1. the re-rank kernels append every uncertified query to `list` (its length: state[0]) together with the bound a SECOND pass
 //      may use for it: tau2 = min(first bound, smallest stored proxy + one window) -- at or above (smallest proxy of ALL rows
 //      + window), so the second list holds every possible winner, and as tight as the first pass can know (for the adaptive
 //      flow the first bound already is exactly that);
@@ -14,7 +14,7 @@
 //      kernel k_gemm_proxy_f16x<1, *> with tau2, every CU on the one pair) and the same re-rank + certificate; every kernel of
 //      a round returns at its first instruction when the list has nothing for it, so the usual call pays a few empty launches;
 //   3. what is still uncertified (NaN / infinite operands, more exact ties than a list holds) is collected again
-//      (GemmFb::count2) and answered by k_gemm_exact_fb: the reference's own arithmetic over all rows, 8 queries per read of the
+//      (state[1]) and answered by k_gemm_exact_fb: the reference's own arithmetic over all rows, 8 queries per read of the
 //      tiled f32 gallery, looping on the device over however many queries there are; K rounds for the K nearest rows.
 //
 // No host synchronisation anywhere: the keys are final in stream order. The counters are running totals the statistics
@@ -38,7 +38,7 @@ __device__ __forceinline__ void fb_note(int* state, int cnt, float bound, float 
     }
 }
 struct RerankFb {
-    int* state;          // GemmFb words
+    int* state;          // the state words above
     int* list;           // first pass: uncertified queries are appended here (index within the call)
     float* tau2;         // first pass: [query of the call] the bound the second-chance pass appends below
     int q_base;          // first pass: index within the call of block 0's query

@@ -26,6 +26,19 @@ def test_library_exports_every_declared_symbol(fir):
     assert bound == set(names), (bound ^ set(names))
 
 
+def test_the_audit_build_is_the_same_abi_and_the_shipped_library_has_no_audit_knobs(fir, fir_audit):
+    """libfir_amd_audit.so (-DFIR_AUDIT) exports the same symbols; the strings of the knobs that can change answers exist in the audit
+    library only -- a stray environment variable cannot reach them in the product."""
+    A = ctypes.CDLL(fir_audit.lib_path())
+    for n in declared_symbols():
+        assert hasattr(A, n), n
+    assert fir_audit.lib_path() != fir.lib_path() and fir_audit.lib_path().endswith("libfir_amd_audit.so")
+    shipped = open(fir.lib_path(), "rb").read()
+    audit = open(fir_audit.lib_path(), "rb").read()
+    for knob in (b"FIR_GEMM_EREL_SCALE", b"FIR_GEMM_DBG_SKIP", b"FIR_GEMM_ADAPT_DBG", b"FIR_GEMM_DEBUG_COUNTS"):
+        assert knob in audit and knob not in shipped, knob
+
+
 def test_no_torch_or_oracle_in_the_product_library(fir):
     out = os.popen(f"ldd {fir.lib_path()}").read()
     assert "libamdhip64" in out
