@@ -1272,7 +1272,7 @@ int fir_cls_knn_predict(fir_cls* c, const double* queries, int32_t qb, int32_t k
     const bool big = (double)c->tiles * 64.0 * c->dp2 * 16.0 > 256.0 * 1024 * 1024;
     const bool want = c->mm_mode > 0 ? qb >= c->mm_mode : (c->mm_mode < 0 && big && qb >= kKnnMfmaQueries);
     if (want && !c->mm_failed && c->nt > 0) {
-        const int32_t b = std::min<int32_t>(65536, std::max<int32_t>(cls_batch(c), 8192));
+        const int32_t b = 16384;                   // queries per internal batch of the matrix-core path (its scratch: two copies of the queries, 8 rows + distances per query)
         bool all = true;
         for (int32_t q0 = 0; q0 < qb && all; q0 += b) {
             const int rc0 = cls_knn_mfma(c, queries + (size_t)q0 * c->d, std::min(b, qb - q0), k, best_class + q0);

@@ -645,6 +645,18 @@ def test_a_loose_first_bound_costs_a_second_pass_not_the_exact_scan(fir, monkeyp
     assert np.all(idx.reshape(qb, k)[:, 0] // per == who.cpu().numpy())
     assert st["second_pass_queries"] >= 8, st             # the first bound WAS loose ...
     assert st["fallback_queries"] == 0, st                # ... and the second pass answered all of them
+    if k == 1:
+        # the same through the HOST-pointer entry point (queries staged super-batch by super-batch) and the gallery's own dispatch
+        qh = q.cpu().numpy()
+        with fir.Gallery(dev_ptr=rows.data_ptr(), n=n_ids * per, d=d, metric=0, device=0) as g:
+            g.set_large_batch_mfma(1)
+            hidx, hdist = g.search_top1(qh)
+            sth = g.mfma_stats()
+            notes = g.uncertified_notes()
+        eidx, edist = fir.keys_unpack(ke.cpu().numpy().view(np.uint64))
+        assert np.array_equal(hidx, eidx) and np.array_equal(hdist.view(np.uint32), edist.view(np.uint32))
+        assert sth["second_pass_queries"] >= 8 and sth["fallback_queries"] == 0, sth
+        assert len(notes) >= 1 and notes[0][0] > 4096 and np.isfinite(notes[0][1]), notes     # the diagnostics say: list overflow under a finite bound
 
 
 def test_the_device_pointer_call_returns_before_its_kernels_have_run(fir):
