@@ -424,25 +424,33 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
                 mn = fminf(mn, pv[i]);                                   // NaN never enters, like k_gemm_tau's ordering
             }
             if (mn < tq) {
+                // The rare path works on its OWN copy of the query index, made here from the hardware's lane count: every address below
+                // (scnt, skeys, the slots, the lists) is then computed where it is used. From `q` itself the compiler hoisted eight sets
+                // of them out of the row loop, spilled them, and reloaded them here -- a scratch load and an s_waitcnt vmcnt(0) per
+                // appended row, i.e. every append waited for the gallery prefetch in flight (~1.2 us per event:
+                // profiles/r04_append_path.txt).
+                int lz;                                               // the lane index, from the hardware: no register of the hot loop is read
+                asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lz));
+                const int qr = jb * 16 + (lz & 15);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     if (pv[i] < tq) {
-                        const int64_t row = rbq * 32 + 16 * (i >> 2) + 4 * (lane >> 4) + (i & 3);
+                        const int64_t row = rbq * 32 + 16 * (i >> 2) + 4 * (lz >> 4) + (i & 3);
                         const unsigned long long key = fir::key_pack(pv[i], (uint32_t)row);
-                        const int st = atomicAdd(&scnt[q], 1);
+                        const int st = atomicAdd(&scnt[qr], 1);
                         if (st < kXStage) {
-                            skeys[q * kXStage + st] = key;
+                            skeys[qr * kXStage + st] = key;
                         } else {
-                            const int slot = atomicAdd(&counts[q], 1);
-                            if (slot < kListCap) lists[(size_t)q * kListCap + slot] = key;
+                            const int slot = atomicAdd(&counts[qr], 1);
+                            if (slot < kListCap) lists[(size_t)qr * kListCap + slot] = key;
                             // the list is full: this query is uncertified whatever else happens (fir_gemm_fb.h gives it a second pass), so the
                             // workgroup stops appending for it -- a pass whose bound stays loose must not turn into millions of atomics on
                             // one counter (~11 ns each: a whole gallery's worth is 11 ms). The next lowering of T writes tq_s again.
-                            else if (kAdapt) tq_s[q] = -__builtin_huge_valf();
+                            else if (kAdapt) tq_s[qr] = -__builtin_huge_valf();
                         }
                     }
                 }
-                if (kAdapt) lower_T(q, pv, mn);
+                if (kAdapt) lower_T(qr, pv, mn);
             }
         };
         auto unit = [&](uint4 (&C)[kRing], uint4 (&N)[kRing], int h, auto first_tag) {
@@ -462,9 +470,14 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
                 }
             }
             if (h == units - 1 && full_block) {
-                const float4* gp = (const float4*)(gnorm + rb * 32 + 4 * (lane >> 4));
-                gns[0] = gp[0];
-                gns[1] = gp[4];
+                // (wave-uniform base + a lane offset made here: hoisted out of the row loop, `gnorm + 4 (lane >> 4)` is a 64-bit register
+                // pair per lane that the K-nearest form spilled -- a scratch reload and an s_waitcnt vmcnt(0) in every row block)
+                unsigned int zl;
+                asm volatile("v_mov_b32 %0, 0" : "=v"(zl));
+                const float* gb = gnorm + rb * 32;
+                const unsigned int off = 4u * ((unsigned int)lane >> 4) + zl;
+                gns[0] = *(const float4*)(gb + off);
+                gns[1] = *(const float4*)(gb + off + 16);
             }
             const uint4* bq_after = STREAMED ? lqx + lane + (size_t)((ring_c + 1) & 3) * 4 * kRing * 64
                                              : lqx + lane + (size_t)((h + 1 < units ? h + 1 : 0) % kUnitsPerSlab) * kRing * 4 * 64;
