@@ -137,9 +137,9 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
     const int kth = kSlots ? sub_stride : 1;
     // the K-th smallest of a query's eight slot words (rank by value, then slot: every word gets a distinct rank)
     auto kth_of_slots = [&](const unsigned int* sl) -> unsigned int {
-        unsigned int v[8], res = 0xFFFFFFFFu;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = sl[i];
+        const uint4 lo = *(const uint4*)sl, hi = *(const uint4*)(sl + 4);          // (sl is 32-byte aligned: a query's eight words)
+        const unsigned int v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        unsigned int res = 0xFFFFFFFFu;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             int rank = 0;
@@ -153,7 +153,7 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
     __shared__ unsigned long long skeys[kAppend ? 2 * kQT * kXStage : 1];
     __shared__ int scnt[kAppend ? 2 * kQT : 1];
     __shared__ float qn_s[kAdapt ? 2 * kQT : 1], win_s[kAdapt ? 2 * kQT : 1];
-    __shared__ unsigned int slot_s[kSlots ? 2 * kQT * 8 : 1];
+    __shared__ __attribute__((aligned(16))) unsigned int slot_s[kSlots ? 2 * kQT * 8 : 8];
     // MODE 3: tq_s = T - |q|^2 as the hot path compares it, rewritten by whoever lowers T (tau_s holds T itself). A racing store may leave
     // the value of an OLDER (larger) T: harmless -- any T the pass ever held is >= the final one, so whatever fails the test against
     // it has a proxy >= fl(T_final - |q|^2), the bound the certificate is given
@@ -309,15 +309,20 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
                 atomicMin(&smin[q], __float_as_uint(tn));
             }
         } else {
+            // (the eight slot words in ONE round trip to the LDS, as two 16-byte reads: read one by one between the conditional atomics
+            // they cost an append event eight round trips in a row. A slot another wave lowers in between is compared against its
+            // older, larger value: one atomic more, the same minimum.)
+            const uint4 s_lo = *(const uint4*)&slot_s[q * 8], s_hi = *(const uint4*)&slot_s[q * 8 + 4];
+            const unsigned int have[8] = {s_lo.x, s_lo.y, s_lo.z, s_lo.w, s_hi.x, s_hi.y, s_hi.z, s_hi.w};
+            const float qn = qn_s[q], win = win_s[q];
             bool fell = false;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const float tn = fmaxf((pv[i] + qn_s[q]) + win_s[q], 0.f);        // (a NaN proxy: fmaxf gives 0 + ... no: NaN + x = NaN, fmaxf(NaN, 0) = 0 -- kept out by the test on pv[i] itself)
-                if (pv[i] == pv[i] && tn < __uint_as_float(slot_s[q * 8 + i])) {
-                    if (__float_as_uint(tn) < atomicMin(&slot_s[q * 8 + i], __float_as_uint(tn))) {
-                        atomicMin(&smin[q * 8 + i], __float_as_uint(tn));
-                        fell = true;
-                    }
+                const float tn = fmaxf((pv[i] + qn) + win, 0.f);        // (a NaN proxy: fmaxf(NaN, 0) = 0 -- kept out by the test on pv[i] itself)
+                if (pv[i] == pv[i] && tn < __uint_as_float(have[i])) {
+                    atomicMin(&slot_s[q * 8 + i], __float_as_uint(tn));
+                    atomicMin(&smin[q * 8 + i], __float_as_uint(tn));
+                    fell = true;
                 }
             }
             if (fell) slots_to_T(q);
