@@ -594,7 +594,7 @@ int topk_lists_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t s
     const int qpad = (qb + 8 * nh - 1) / (8 * nh) * (8 * nh);
     void *p_skeys = nullptr, *p_small = nullptr, *p_lists = nullptr;
     int rc;
-    if ((rc = fir_gallery_scratch_(g, 12, (size_t)qb * k * 8, &p_skeys))) return rc;
+    if ((rc = fir_gallery_scratch_(g, 12, (size_t)qpad * k * 8, &p_skeys))) return rc;
     if ((rc = fir_gallery_scratch_(g, 13, (size_t)qpad * 8 + 16, &p_small))) return rc;
     if ((rc = fir_gallery_scratch_(g, 14, (size_t)qpad * kListCap * 8, &p_lists))) return rc;
     uint64_t* skeys = (uint64_t*)p_skeys;
@@ -626,7 +626,62 @@ int topk_lists_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t s
     const bool was_profiling = g->profiling, was_quiet = g->quiet;
     g->profiling = false;
     g->quiet = true;
-    if (k > 1 && g->metric != kL2) {
+    FIR_HIP(hipMemsetAsync(flag, 0, 4, st));
+    // chi-square / KL nomination: the row samples run the NOMINATION metric too (2.25 / 3 issue slots per element instead of the
+    // exact metric's 11 / ~35: the samples were 0.9 of a 256-query call's 12.3 ms). A sampled minimum is then within B of the
+    // reference's value of that row, so at least K rows have a reference distance <= max_i(sample_i) + B, and the append scan
+    // (the same metric) has to take everything <= max_i(sample_i) + 2 B: the thresholds are widened by 2.5 B instead of 1.5 B.
+    const bool approx_samples = (harm || klent) && !fir_knob_("FIR_EXACT_SAMPLES");
+    const int kk_q = g->dp4 * 4;
+    const int sample_stride = approx_samples ? qpad : qb;                  // keys of sample group i: skeys[i * sample_stride + q]
+    bool tiles_ready = false;                                              // the query tiles are already in g->qt, in the nomination form
+    if (approx_samples) {
+        const float nf = (float)(end - start);
+        const float coef = harm ? (3.0f * nf + 19.0f) * 5.9604645e-8f / nf
+                                : (0.6932f * (26.1f * (64.0f + nf / 32.0f) + 150.0f) + 2.0f * nf + 8.0f) * 5.9604645e-8f / nf;
+        // the per-query sums first (thresholds at -inf: nothing to widen yet)
+        FIR_HIP(hipMemsetD32Async((hipDeviceptr_t)tau, (int)0xFF800000u, (size_t)qpad, st));
+        hipLaunchKernelGGL(harm ? k_query_sums_widen : k_query_entropy_widen, dim3(qpad), dim3(64), 0, st, d_queries, qb, g->d, start, end, sq, tau,
+                           (const unsigned int*)(g->rowsum + g->n), coef);
+        // every query tile of the call, once, in the form both scans read
+        hipLaunchKernelGGL(k_transpose_queries, dim3((unsigned)(((int64_t)kk_q * qpad + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, d_queries, qb, g->d,
+                           g->dp4, 8, g->qt, (uint64_t*)nullptr, 0, g->range, next_serial(g), harm ? 1 : 2);
+        tiles_ready = true;
+        FIR_HIP(hipMemsetAsync(skeys, 0xFF, (size_t)qpad * k * 8, st));
+        const scan_fn sfn = harm ? (scan_fn)k_scan<8, kChi2Harm, kU, kEpiTop1, kKMax, kWpsPlain> : (scan_fn)k_scan<8, kKLEnt, kU, kEpiTop1, kKMax, kWpsPlain>;
+        const int64_t tiles = std::min<int64_t>(group_tiles * k, g->tiles);
+        int waves = pick_waves(tiles, max_waves_for(g, sfn, 0), g->cus * 4);
+        if (k > 1) waves = std::max(4 * k, waves / (4 * k) * (4 * k));                  // a wave's tiles all belong to one group
+        ScanArgs a{};
+        a.groups = k > 1 ? k : 0;
+        a.group_stride = sample_stride;
+        a.qt = g->qt;
+        a.gal4 = g->gal4;
+        a.row_offset = g->row_offset;
+        a.n = std::min<int64_t>(g->n, tiles * kTileRows);
+        a.tiles = (int32_t)tiles;
+        a.dp4 = g->dp4;
+        a.start = start;
+        a.end = end;
+        a.waves = waves;
+        a.keys = skeys;
+        a.nq = 8;
+        a.qt_stride = (int64_t)kk_q * 8;
+        a.nt = 0;
+        a.range = g->range;
+        a.serial = g->q_serial;
+        a.flag = flag;
+        a.sg = g->rowsum;
+        a.sq = sq;
+        for (int y0 = 0; y0 < qpad / 8; y0 += g->max_tiles_per_launch) {
+            const int ny = std::min(g->max_tiles_per_launch, qpad / 8 - y0);
+            ScanArgs b = a;
+            b.qt = g->qt + (size_t)y0 * 8 * kk_q;
+            b.keys = skeys + (size_t)y0 * 8;
+            b.sq = sq + (size_t)y0 * 8;
+            hipLaunchKernelGGL(sfn, dim3(waves / 4, ny), dim3(kBlock), 0, st, b);
+        }
+    } else if (k > 1 && g->metric != kL2) {
         // chi-square / KL: the K samples in ONE launch -- sample tile t belongs to group t mod K, a wave reports into its group's keys
         // (K launches of group_tiles tiles each leave most of the chip idle: a tile is one wave's serial work)
         FIR_HIP(hipMemsetAsync(skeys, 0xFF, (size_t)qb * k * 8, st));
@@ -648,17 +703,18 @@ int topk_lists_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t s
     g->profiling = was_profiling;
     g->quiet = was_quiet;
     if (rc) return rc;
-    FIR_HIP(hipMemsetAsync(flag, 0, 4, st));
-    hipLaunchKernelGGL(k_topk_tau, dim3((qpad + 63) / 64), dim3(64), 0, st, skeys, qb, qpad, k, tau, counts, flag, tau_scale);
+    hipLaunchKernelGGL(k_topk_tau, dim3((qpad + 63) / 64), dim3(64), 0, st, skeys, qb, qpad, k, tau, counts, flag, tau_scale, sample_stride);
+    // (1.5 B over an exact sample; 2.5 B over a sample in the nomination metric -- the kernels multiply by 1.5)
+    const float widen = approx_samples ? 1.67f : 1.0f;
     if (harm) {
         const float nf = (float)(end - start);
         hipLaunchKernelGGL(k_query_sums_widen, dim3(qpad), dim3(64), 0, st, d_queries, qb, g->d, start, end, sq, tau, (const unsigned int*)(g->rowsum + g->n),
-                           (3.0f * nf + 19.0f) * 5.9604645e-8f / nf);
+                           widen * (3.0f * nf + 19.0f) * 5.9604645e-8f / nf);
     }
     if (klent) {
         const float nf = (float)(end - start);
         hipLaunchKernelGGL(k_query_entropy_widen, dim3(qpad), dim3(64), 0, st, d_queries, qb, g->d, start, end, sq, tau, (const unsigned int*)(g->rowsum + g->n),
-                           (0.6932f * (26.1f * (64.0f + nf / 32.0f) + 150.0f) + 2.0f * nf + 8.0f) * 5.9604645e-8f / nf);
+                           widen * (0.6932f * (26.1f * (64.0f + nf / 32.0f) + 150.0f) + 2.0f * nf + 8.0f) * 5.9604645e-8f / nf);
     }
     // 2. the append scan over the whole gallery: 8 queries per tile, every tile of the call in one launch (blockIdx.y)
     const int kk = g->dp4 * 4;
@@ -687,8 +743,9 @@ int topk_lists_dev(fir_gallery* g, const float* d_queries, int32_t qb, int32_t s
         const int ny = std::min(tiles_per_launch, (qpad - q0) / 8);
         const int live = std::max(0, std::min(qb - q0, ny * 8));
         float* qt = g->qt + (size_t)q0 * kk;
-        hipLaunchKernelGGL(k_transpose_queries, dim3((unsigned)(((int64_t)kk * 8 * ny + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
-                           d_queries + (size_t)q0 * g->d, live, g->d, g->dp4, 8, qt, (uint64_t*)nullptr, 0, g->range, next_serial(g), harm ? 1 : klent ? 2 : 0);
+        if (!tiles_ready)
+            hipLaunchKernelGGL(k_transpose_queries, dim3((unsigned)(((int64_t)kk * 8 * ny + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
+                               d_queries + (size_t)q0 * g->d, live, g->d, g->dp4, 8, qt, (uint64_t*)nullptr, 0, g->range, next_serial(g), harm ? 1 : klent ? 2 : 0);
         ScanArgs a{};
         a.range = g->range;
         a.serial = g->q_serial;

@@ -955,14 +955,15 @@ __global__ void __launch_bounds__(kBlock) k_topk_merge(const uint64_t* part, int
 // A group without any row below 100000 raises the flag (the caller then uses the register-list scan). Padding queries
 // [nq, nq_pad) get a threshold nothing reaches.
 __global__ void k_topk_tau(const uint64_t* __restrict__ gkeys, int nq, int nq_pad, int K, float* __restrict__ tau, int32_t* __restrict__ counts,
-                           int32_t* __restrict__ flag, float scale = 1.0f) {
+                           int32_t* __restrict__ flag, float scale = 1.0f, int stride = 0) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nq_pad) return;
+    if (stride == 0) stride = nq;                                    // keys of sample group i: gkeys[i * stride + q]
     counts[q] = 0;
     if (q >= nq) { tau[q] = -__builtin_huge_valf(); return; }       // (-inf: no distance is at or below it -- a KL value can round to a small negative number, -1 could not tell)
     uint64_t worst = 0;
     for (int i = 0; i < K; ++i) {
-        const uint64_t key = gkeys[(size_t)i * nq + q];
+        const uint64_t key = gkeys[(size_t)i * stride + q];
         worst = key > worst ? key : worst;
     }
     if (worst == kKeyNone) { tau[q] = -__builtin_huge_valf(); atomicOr(flag, 1); return; }

@@ -57,6 +57,14 @@ def main():
         r1 = rate(lambda: g.search_top1_keys_dev(q.data_ptr(), a.qb, k1.data_ptr()), a.qb)
         r5 = rate(lambda: g.search_topk_keys_dev(q.data_ptr(), a.qb, 5, k5.data_ptr()), a.qb)
         print(f"{name} top-1 {r1:9.0f} q/s   top-5 {r5:9.0f} q/s   identical keys: {bool(torch.equal(k1, ref1))} / {bool(torch.equal(k5, ref5))}", flush=True)
+    # the row samples in the exact metric (round 4's first half) against the nomination metric (default since), interleaved
+    for rnd in range(2):
+        for env, name in (("1", "exact samples    "), (None, "nomination-form samples")):
+            if env: os.environ["FIR_EXACT_SAMPLES"] = env
+            else: os.environ.pop("FIR_EXACT_SAMPLES", None)
+            r1 = rate(lambda: g.search_top1_keys_dev(q.data_ptr(), a.qb, k1.data_ptr()), a.qb)
+            r5 = rate(lambda: g.search_topk_keys_dev(q.data_ptr(), a.qb, 5, k5.data_ptr()), a.qb)
+            print(f"{name} top-1 {r1:9.0f} q/s   top-5 {r5:9.0f} q/s   identical keys: {bool(torch.equal(k1, ref1))} / {bool(torch.equal(k5, ref5))}", flush=True)
     g.close()
 
 
