@@ -191,3 +191,47 @@ def test_nomination_scans_over_ranges_with_ragged_edges(fir, metric, monkeypatch
                 monkeypatch.delenv("FIR_NO_CHI2_NOMINATION")
                 assert np.array_equal(got1[0], exp1[0]) and np.array_equal(got1[1].view(np.uint32), exp1[1].view(np.uint32)), (a, b, nq)
                 assert np.array_equal(got5[0], exp5[0]) and np.array_equal(got5[1].view(np.uint32), exp5[1].view(np.uint32)), (a, b, nq)
+
+
+@pytest.mark.parametrize("metric", [1, 2])
+def test_thresholds_from_nomination_metric_samples_lose_no_row(fir, metric, monkeypatch):
+    """Since round 4 the row samples that give the append scan its threshold run the nomination metric themselves (fir_capi.hip:
+    topk_lists_dev, approx_samples): a sampled minimum is only within B of the reference's value, so the threshold is widened by
+    2.5 B. The tight case: the query's nearest rows lie INSIDE the sampled rows (the first 16 384), so the threshold is as low as
+    it can get, and rows outside the sample tie with them exactly or sit one ulp on either side -- every one of them has to be
+    appended, and the ties have to resolve by row as the exact scan resolves them. FIR_EXACT_SAMPLES=1 (the exact metric's
+    samples, 1.5 B) must give the same keys."""
+    import synth
+
+    n, d, qb = 70000, 128, 24
+    rows = synth.make_gallery(97, n, d, metric)
+    q = np.empty((qb, d), np.float32)
+    for i in range(qb):
+        src = 40 * i + 3                                           # inside the sample of every group (tile t belongs to group t mod K)
+        q[i] = rows[src] * (1 + 0.01 * np.cos(np.arange(d) + i)).astype(np.float32)
+        q[i] /= q[i].sum()
+        rows[20000 + 7 * i] = rows[src]                            # an exact copy outside the sample: the tie goes to the earlier row
+        up = rows[src].copy()
+        up[i % d] = np.nextafter(up[i % d], np.float32(1))
+        rows[40000 + 11 * i] = up                                  # one ulp away in one feature, outside the sample
+        dn = rows[src].copy()
+        dn[(i + 1) % d] = np.nextafter(dn[(i + 1) % d], np.float32(0))
+        rows[60000 + 13 * i] = dn
+    with fir.Gallery(rows, None, metric, 0) as g:
+        a1 = g.search_top1(q)
+        a5 = g.search_topk(q, 5)
+        assert "k_nominate" in g.last_dispatch()["kernel"]
+        monkeypatch.setenv("FIR_EXACT_SAMPLES", "1")
+        x1 = g.search_top1(q)
+        x5 = g.search_topk(q, 5)
+        monkeypatch.delenv("FIR_EXACT_SAMPLES")
+        monkeypatch.setenv("FIR_NO_CHI2_NOMINATION", "1")
+        e1 = g.search_top1(q)
+        e5 = g.search_topk(q, 5)
+        monkeypatch.delenv("FIR_NO_CHI2_NOMINATION")
+    for got1, got5 in ((a1, a5), (x1, x5)):
+        assert np.array_equal(got1[0], e1[0]) and np.array_equal(got1[1].view(np.uint32), e1[1].view(np.uint32))
+        assert np.array_equal(got5[0], e5[0]) and np.array_equal(got5[1].view(np.uint32), e5[1].view(np.uint32))
+    # the four planted rows of every query are its four nearest, whatever their order
+    for i in range(qb):
+        assert {40 * i + 3, 20000 + 7 * i, 40000 + 11 * i, 60000 + 13 * i} <= set(int(v) for v in e5[0][i])
