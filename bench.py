@@ -45,6 +45,20 @@ import __graft_entry__ as ge  # noqa: E402
 
 CHUNK_ROWS = 15625      # generation granule: 64 chunks make the 1M-row gallery, any 1/2/4/8 sharding is whole chunks
 PEAK_MFMA_F16_TFLOPS = 2500.0      # dense fp16 / bf16 MFMA peak, MI355X_MICROARCH.md
+L2_TO_CU_GBPS = (66.0, 73.0)        # what one CU takes from its XCD's L2, rows served from L2, ~72 KiB in flight (MI355X_MICROARCH.md, "Indexed rows: gather into LDS")
+N_CUS = 256
+
+
+def l2_to_cu(n_rows, d, queries_per_launch, kernel_ms):
+    """The gallery stream of a matrix-core launch priced against the L2 -> CU path ("what bounds the 16-row kernels"):
+    every fp16 fragment is read once by each of the queries_per_launch / 128 workgroups that hold a 128-query tile (one of them from HBM,
+    the others from the XCD's L2); rows longer than 512 features re-stream the query slabs as well, half as many bytes again."""
+    dk = (d + 31) // 32 * 32
+    tiles = queries_per_launch / 128.0
+    stream = tiles * n_rows * dk * 2.0 * (1.5 if dk > 512 else 1.0)
+    per_cu = stream / (kernel_ms * 1e-3) / 1e9 / N_CUS
+    return {"bytes_per_launch_through_l1": stream, "GBps_per_cu": per_cu, "ceiling_GBps_per_cu": list(L2_TO_CU_GBPS),
+            "frac_of_ceiling": per_cu / L2_TO_CU_GBPS[0], "bytes_per_mfma": 128 * (1.5 if dk > 512 else 1.0)}
 PEAK_VALU_WAVE_INSTR_PER_S = 256 * 4 * 2.4e9 / 4.0   # one wave64 VALU instruction per 4 cycles per SIMD (profiles/r01_ubench_valu_issue_rate.txt)
 
 
@@ -496,7 +510,8 @@ def main():
                              "note": f"fp16 gallery fragments leave HBM once per {hd['queries_per_pass']} queries (the pairs of a launch walk the same rows together and share the stream through L2)",
                              "flops_per_launch": hd["flops_per_launch"], "achieved_tflops": tf, "peak_tflops": PEAK_MFMA_F16_TFLOPS, "frac_of_mfma_peak": tf / PEAK_MFMA_F16_TFLOPS,
                              "stream_GBps": gbs, "peak_GBps": peak_gbs, "frac_of_hbm_peak": gbs / peak_gbs, "traffic": traffic.get("mfma"),
-                             "kernel_time_share_of_step": float(np.sum(head["kernel_ms"])) / (head["elapsed"] * 1e3) if world == 1 else None, **h_blk}
+                             "kernel_time_share_of_step": float(np.sum(head["kernel_ms"])) / (head["elapsed"] * 1e3) if world == 1 else None,
+                             "l2_to_cu": l2_to_cu(row_hi - row_lo, d, hd["queries_per_pass"], h_avg), **h_blk}
         out = {
             "metric": "query-vectors/sec brute-force L2 top-1, 1Mx512 gallery",
             "value": qb * args.steps / head["elapsed"],
@@ -969,6 +984,7 @@ def config5(args, fir, dev, ws):
                                 "kernel_avg_ms": avg, "launches_timed": int(len(ms)), "grid": dd["grid"], "block": dd["block"],
                                 "lds_bytes_per_workgroup": dd["lds_bytes"], "vgprs": dd["vgprs"], "queries_per_gallery_read": dd["queries_per_pass"],
                                 "bytes_per_launch": dd["bytes_per_launch"], "queries_per_s_whole_call": qb / dt,
+                                "l2_to_cu": l2_to_cu(n, d, dd["queries_per_pass"], avg),
                                 "kernel_time_share_of_call": float(np.sum(ms)) / (dt * reps * 1e3)}
     out["crossover_query_batch"] = crossover          # the smallest measured batch at which the matrix-core form beats the exact scan
     out["identical_keys_at_every_batch"] = ident_all
