@@ -1569,6 +1569,7 @@ struct fir_gemm {
     int prio = 0;                         // mfma16 experiment: s_setprio 2 around the MFMA phase of a row block (FIR_GEMM_PRIO)
     int stagger = 0;                      // mfma16 experiment: the second wave of every SIMD starts half a unit late (FIR_GEMM_STAGGER)
     int share_streamed = 8;               // ... of them when the query slabs are streamed (FIR_GEMM_SHARE_STREAMED)
+    int few_blocks = 1;                   // calls of <= 32 queries multiply against the live query blocks only (FIR_GEMM_FEW_BLOCKS=0: the whole tile, for A/B runs)
     int share_max = 16;                   // fp16: up to this many pairs of passes (x 128 queries) read the gallery together in one launch (FIR_GEMM_SHARE; 0 = the old one-pair-at-a-time grid)
 };
 
@@ -1577,7 +1578,11 @@ struct fir_gemm {
 // the 16-row kernels by (mode, query slabs streamed, odd number of units per row block)
 typedef void (*fir_x_fn)(const uint4*, const float*, const uint4*, const float*, int64_t, int64_t, int64_t, int, const float*, unsigned long long*, int*, float*,
                          int, int, int, int, unsigned int*, int);
-static fir_x_fn pick_x(int mode, bool streamed, bool odd, int dbg = 0) {
+static fir_x_fn pick_x(int mode, bool streamed, bool odd, int dbg = 0, int njb = 8) {
+    if (njb < 8 && mode == 3 && !odd && !dbg) {        // a call of <= 16 / <= 32 queries (top-1, threshold found on the way)
+        if (njb == 1) return streamed ? k_gemm_proxy_f16x<3, 1, 0, 0, 1> : k_gemm_proxy_f16x<3, 0, 0, 0, 1>;
+        if (njb == 2) return streamed ? k_gemm_proxy_f16x<3, 1, 0, 0, 2> : k_gemm_proxy_f16x<3, 0, 0, 0, 2>;
+    }
     if (dbg && mode == 3 && !streamed && !odd) {       // timing experiments (FIR_GEMM_DBG_SKIP): wrong answers
         switch (dbg & 31) {
             case 1: return k_gemm_proxy_f16x<3, 0, 0, 1>;
@@ -1595,7 +1600,11 @@ static fir_x_fn pick_x(int mode, bool streamed, bool odd, int dbg = 0) {
     if (mode == 4) return streamed ? (odd ? k_gemm_proxy_f16x<4, 1, 1> : k_gemm_proxy_f16x<4, 1, 0>) : (odd ? k_gemm_proxy_f16x<4, 0, 1> : k_gemm_proxy_f16x<4, 0, 0>);
     return streamed ? (odd ? k_gemm_proxy_f16x<2, 1, 1> : k_gemm_proxy_f16x<2, 1, 0>) : (odd ? k_gemm_proxy_f16x<2, 0, 1> : k_gemm_proxy_f16x<2, 0, 0>);
 }
-static const char* name_x(bool streamed, bool odd, bool adaptive = false, bool slots = false) {
+static const char* name_x(bool streamed, bool odd, bool adaptive = false, bool slots = false, int njb = 8) {
+    if (njb < 8 && adaptive && !slots && !odd) {
+        if (njb == 1) return streamed ? "fir::k_gemm_proxy_f16x<3, 1, 0, 0, 1>" : "fir::k_gemm_proxy_f16x<3, 0, 0, 0, 1>";
+        if (njb == 2) return streamed ? "fir::k_gemm_proxy_f16x<3, 1, 0, 0, 2>" : "fir::k_gemm_proxy_f16x<3, 0, 0, 0, 2>";
+    }
     if (adaptive && slots) return streamed ? (odd ? "fir::k_gemm_proxy_f16x<4, 1, 1>" : "fir::k_gemm_proxy_f16x<4, 1, 0>") : (odd ? "fir::k_gemm_proxy_f16x<4, 0, 1>" : "fir::k_gemm_proxy_f16x<4, 0, 0>");
     if (adaptive) return streamed ? (odd ? "fir::k_gemm_proxy_f16x<3, 1, 1>" : "fir::k_gemm_proxy_f16x<3, 1, 0>") : (odd ? "fir::k_gemm_proxy_f16x<3, 0, 1>" : "fir::k_gemm_proxy_f16x<3, 0, 0>");
     return streamed ? (odd ? "fir::k_gemm_proxy_f16x<1, 1, 1>" : "fir::k_gemm_proxy_f16x<1, 1, 0>") : (odd ? "fir::k_gemm_proxy_f16x<1, 0, 1>" : "fir::k_gemm_proxy_f16x<1, 0, 0>");
@@ -1745,6 +1754,7 @@ int fir_gemm_create_range_ex_(fir_gallery* g, int32_t precision, int32_t end_pos
     if (const char* w = fir_knob_("FIR_GEMM_ADAPTIVE")) m->adaptive = std::atoi(w);
     if (const char* w = fir_knob_("FIR_GEMM_ADAPTIVE_TOPK")) m->adaptive_topk = std::atoi(w) != 0;
     if (const char* w = fir_knob_("FIR_GEMM_SHARE_STREAMED")) m->share_streamed = std::max(1, std::min(16, std::atoi(w)));
+    if (const char* w = fir_knob_("FIR_GEMM_FEW_BLOCKS")) m->few_blocks = std::atoi(w) != 0;
     if (const char* w = fir_knob_("FIR_GEMM_SHARE")) m->share_max = std::max(0, std::min(16, std::atoi(w)));
     // the 16-row kernels always run the smallest-proxy sample flow with its XCD-shared launches: one workgroup per CU, CUs in eights
     if (m->mfma16 && !(m->share_max > 0 && (m->v.cus & 7) == 0 && m->v.cus >= 8)) m->mfma16 = 0;
@@ -1999,8 +2009,15 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
     // the preparation of super-batch i+1 (query norms / scales / fragments, the sample pass, tau) and the exact re-rank +
     // certificate of super-batch i, both under super-batch i's (or i+1's) full pass. Order on `side`:
     // prep(0) prep(1) rerank(0) prep(2) rerank(1) ... -- prep(i+2) reuses the scratch set rerank(i) has just finished with.
-    GEMM_HIP(hipEventRecord(m->queries_ready, st));
-    GEMM_HIP(hipStreamWaitEvent(m->side, m->queries_ready, 0));
+    // (a call of ONE super-batch whose preparation runs on `st` has nothing to put under anything: its re-rank follows its pass on `st`
+    // as well -- every hop to the side stream and back is 10-12 us of a 300-us call)
+    const char* sp_env = fir_knob_("FIR_GEMM_SERIAL_PREP");
+    const bool serial_prep = !(sp_env && std::atoi(sp_env) == 0) && !h_queries;        // (see the note on prep() below)
+    const bool one_stream = nsb == 1 && serial_prep && !fir_knob_("FIR_GEMM_TWO_STREAMS");
+    if (!one_stream) {
+        GEMM_HIP(hipEventRecord(m->queries_ready, st));
+        GEMM_HIP(hipStreamWaitEvent(m->side, m->queries_ready, 0));
+    }
     // the register-tile flow (fir_gemm_regtile.h) for fp16 galleries whose rows fit the compute waves' registers
     typedef void (*rt_fn)(const uint4*, const float*, const uint4*, const float*, int64_t, int64_t, int, const float*, unsigned long long*, int*, unsigned int*, int, int, int);
     rt_fn rt_main = nullptr, rt_sample = nullptr;
@@ -2053,8 +2070,6 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
     // kernels only got the CUs a full-pass workgroup had just left and slowed those passes down (1M x 512, 32 768 queries per call: top-1
     // 1.253 -> 1.296 M q/s, top-5 1.018 -> 1.071 M; FIR_GEMM_SERIAL_PREP=0 is the old placement). Host-pointer calls keep the side stream:
     // there the preparation waits for the super-batch's upload, which is what overlaps the passes.
-    const char* sp_env = fir_knob_("FIR_GEMM_SERIAL_PREP");
-    const bool serial_prep = !(sp_env && std::atoi(sp_env) == 0) && !h_queries;
     auto prep = [&](int sb) -> int {
         hipStream_t ps = serial_prep ? st : m->side;
         if (serial_prep && sb >= 2) GEMM_HIP(hipStreamWaitEvent(st, m->rerank_done[sb & 1], 0));      // the re-rank of sb - 2 read this buffer
@@ -2160,6 +2175,8 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
         // ---- the full pass(es) over the gallery: the launch fir_profile_read times and fir_gallery_last_dispatch names ----
         if (m->precision == FIR_GEMM_F16) {
             const int pairs = (np + 1) / 2;
+            // (a super-batch of at most 16 / 32 queries: one / two query blocks of the tile are live -- the pass multiplies against those only)
+            const int njb = (k == 1 && adaptive && m->mfma16 && !m->dbg_skip && !((m->dk16 / kRing) & 1) && m->few_blocks) ? (nq <= 16 ? 1 : nq <= 32 ? 2 : 8) : 8;
             const bool streamed = m->mfma16 ? (m->dk16 > kSlabH || m->streamed > 0) : (m->streamed >= 0 ? m->streamed != 0 : m->dk16 > kSlabH);
             const int64_t rblocks = (n + 31) / 32;
             // rows longer than the LDS tile (query slabs streamed per unit): 16 readers of one range drift apart, 8 measured better
@@ -2195,7 +2212,7 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
                     used_rt = true;
                     used_rt_lds = rt_lds;
                 } else if (adaptive)
-                    hipLaunchKernelGGL(pick_x(k > 1 ? 4 : 3, streamed, (m->dk16 / kRing) & 1, k > 1 ? 0 : m->dbg_skip), g1, dim3(kGemmBlock), kHalfLds, st, m->gh, m->gnorm, m->qbf[b] + qo * 4 * m->dk16 * 64,
+                    hipLaunchKernelGGL(pick_x(k > 1 ? 4 : 3, streamed, (m->dk16 / kRing) & 1, k > 1 ? 0 : m->dbg_skip, njb), g1, dim3(kGemmBlock), kHalfLds, st, m->gh, m->gnorm, m->qbf[b] + qo * 4 * m->dk16 * 64,
                                        m->qinv[b] + qo * 2 * kQT, n, (int64_t)0, n, m->dk16, m->awin[b] + qo * 2 * kQT, m->lists[b] + qo * 2 * kQT * kListCap,
                                        m->counts[b] + qo * 2 * kQT, m->qnorm[b] + qo * 2 * kQT, sample_rows, share, nt | adapt_dbg | (m->stagger ? 2 : 0) | (m->stagger > 1 ? 32 : 0) | (m->prio ? 16 : 0) | (m->no_block_bound ? 64 : 0), 1,
                                        m->aT[b] + qo * 2 * kQT * (k > 1 ? 8 : 1), k > 1 ? k : 0);
@@ -2220,9 +2237,9 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
                 const void* fp = (const void*)rt_main;
                 fir_gallery_note_dispatch_(m->g, fp, nm, sb == 0, grid, nlaunch, 512, used_rt_lds, 128 * p_first, bytes, flops);
             } else
-            fir_gallery_note_dispatch_(m->g, m->mfma16 ? (const void*)pick_x(adaptive ? (k > 1 ? 4 : 3) : 1, streamed, (m->dk16 / kRing) & 1)
+            fir_gallery_note_dispatch_(m->g, m->mfma16 ? (const void*)pick_x(adaptive ? (k > 1 ? 4 : 3) : 1, streamed, (m->dk16 / kRing) & 1, 0, njb)
                                                        : (streamed ? (const void*)k_gemm_proxy_f16<1, 1> : (const void*)k_gemm_proxy_f16<1, 0>),
-                                       m->mfma16 ? name_x(streamed, (m->dk16 / kRing) & 1, adaptive, k > 1)
+                                       m->mfma16 ? name_x(streamed, (m->dk16 / kRing) & 1, adaptive, k > 1, njb)
                                                  : (streamed ? "fir::k_gemm_proxy_f16<1, 1>" : "fir::k_gemm_proxy_f16<1, 0>"), sb == 0, grid, m->share_max > 0 ? nlaunch : pairs, kGemmBlock, kHalfLds,
                                        m->share_max > 0 ? 128 * p_first : 128, bytes, flops);
         } else if (m->precision == FIR_GEMM_F32) {
@@ -2252,8 +2269,8 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
         }
         GEMM_HIP(hipEventRecord(m->main_done[b], st));
         // exact re-rank + certificate of this super-batch on the side stream, under the next one's full pass
-        hipStream_t rs = m->side;
-        GEMM_HIP(hipStreamWaitEvent(m->side, m->main_done[b], 0));
+        hipStream_t rs = one_stream ? st : m->side;
+        if (!one_stream) GEMM_HIP(hipStreamWaitEvent(m->side, m->main_done[b], 0));
         const RerankFb fb = {m->fb_state, m->fb_list, m->fb_tau2, q0, nullptr, 0};     // uncertified queries go on the call's list
         if (k == 1)
             hipLaunchKernelGGL(k_gemm_rerank, dim3(nq), dim3(64), (size_t)(m->rerank_group + 1) * (m->dp4 + 1) * sizeof(float4), rs, m->lists[b], m->counts[b],
@@ -2266,7 +2283,7 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
         GEMM_HIP(hipEventRecord(m->rerank_done[b], rs));
         m->passes += np;
     }
-    GEMM_HIP(hipStreamWaitEvent(st, m->rerank_done[(nsb - 1) & 1], 0));   // join the side stream (it is in order: the last re-rank is the last thing on it)
+    if (!one_stream) GEMM_HIP(hipStreamWaitEvent(st, m->rerank_done[(nsb - 1) & 1], 0));   // join the side stream (it is in order: the last re-rank is the last thing on it)
     GEMM_HIP(hipGetLastError());
 #ifdef FIR_AUDIT
     if (fir_knob_("FIR_GEMM_DEBUG_COUNTS")) {       // audit builds: appended rows per query of the last super-batch (synchronises)
@@ -2289,7 +2306,9 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
     }
 #endif
     // uncertified queries: a second matrix-core pass with the tightest bound the first one can justify, then the exact device scan
-    const int sc_rounds = x_flow ? std::min(kScRounds, (qb + kScQueries - 1) / kScQueries) : 0;
+    // (calls of at most 32 queries skip the second-chance rounds: the exact device scan reads the gallery once per eight queries, about what
+    // one more matrix-core pass costs, and four launches fewer are 20 us of such a call)
+    const int sc_rounds = x_flow && qb > 32 ? std::min(kScRounds, (qb + kScQueries - 1) / kScQueries) : 0;
     return gemm_finish_(m, d_queries, k, d_keys, st, e_rel, sc_rounds);
 }
 

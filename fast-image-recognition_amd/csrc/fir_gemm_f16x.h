@@ -106,10 +106,13 @@ __global__ void __launch_bounds__(256) k_gemm_pack_queries_f16x(const float* q, 
 // throw-away MFMAs first, so that partners do not reach their epilogues and their end-of-unit waits together. Bit 0: the
 // gallery stream is read once per launch (non-temporal loads).
 constexpr int kXStage = 16;             // staged appends per query and workgroup
+// NJB: query blocks of 16 the wave multiplies against (8 = the whole 128-query tile). A call of at most 16 / 32 queries fills one / two
+// blocks; with NJB = 1 / 2 the pass does an eighth / a quarter of the MFMAs and LDS reads and is what such a call should be: one read
+// of the fp16 fragments at the rate the memory system gives (the tile's layout in LDS and in `qh` is unchanged).
 // DBG (timing experiments only, FIR_GEMM_DBG_SKIP; own instantiations so that the production kernels' register allocation is not
 // touched -- as runtime flags the two tests made the row loop spill): bit 0 = no epilogue, bit 1 = no gallery stream, bit 2 = no
 // re-read of the query fragments. The answers of such a kernel are wrong.
-template <int MODE, int STREAMED, int ODD, int DBG = 0>
+template <int MODE, int STREAMED, int ODD, int DBG = 0, int NJB = 8>
 __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* __restrict__ gh, const float* __restrict__ gnorm, const uint4* qh,
                                                                     const float* __restrict__ qinv, int64_t n, int64_t row_begin, int64_t row_end,
                                                                     int dk16, const float* tau, unsigned long long* lists, int* counts,
@@ -259,19 +262,19 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
         }
         __syncthreads();
     }
-    float smallest[8];                               // MODE 2: running minima of this lane's eight queries
+    float smallest[NJB];                             // MODE 2: running minima of this lane's NJB queries
 #pragma unroll
-    for (int j = 0; j < 8; ++j) smallest[j] = __builtin_huge_valf();
-    uint4 B[8];                                      // the fragments of the first step of the first unit (slot 0 / the resident tile's start)
+    for (int j = 0; j < NJB; ++j) smallest[j] = __builtin_huge_valf();
+    uint4 B[NJB];                                    // the fragments of the first step of the first unit (slot 0 / the resident tile's start)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) B[j] = lqx[lane + j * 64];
-    if ((nt_flags & 2) && resident && wave >= wpb / 2) {
+    for (int j = 0; j < NJB; ++j) B[j] = lqx[lane + j * 64];
+    if (NJB == 8 && (nt_flags & 2) && resident && wave >= wpb / 2) {
         // half a unit of MFMAs whose result goes nowhere the kernel's outputs are computed from: it only delays this wave
         f32x4 junk = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < 32; ++r) junk = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_f16x8(B[r & 7]), as_f16x8(B[(r + 1) & 7]), junk, 0, 0, 0);
+        for (int r = 0; r < 32; ++r) junk = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_f16x8(B[r & (NJB - 1)]), as_f16x8(B[(r + 1) & (NJB - 1)]), junk, 0, 0, 0);
         if (nt_flags & 32)                               // (FIR_GEMM_STAGGER=2: half a row block at 512 features instead of half a unit)
-            for (int r = 0; r < 96; ++r) junk = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_f16x8(B[r & 7]), as_f16x8(B[(r + 1) & 7]), junk, 0, 0, 0);
+            for (int r = 0; r < 96; ++r) junk = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_f16x8(B[r & (NJB - 1)]), as_f16x8(B[(r + 1) & (NJB - 1)]), junk, 0, 0, 0);
         asm volatile("" ::"v"(junk));
     }
     // The append forms DEFER a full row block's epilogue into the next row block's first step: the first step's MFMAs start the sums
@@ -281,15 +284,15 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
     // alone, waits for its own LDS reads (profiles/r03_gemm_time_decomposition.txt: the epilogue cost 0.18 of 1.56 ms). DBG & 8: the
     // epilogue where it was, for A/B runs.
     constexpr bool kDefer = kAppend && !(DBG & 8) && !(DBG & 1);
-    f32x4 acc[2][8];                                 // (first written by the MFMAs of a row block's first step, against a zero C operand)
+    f32x4 acc[2][NJB];                               // (first written by the MFMAs of a row block's first step, against a zero C operand)
     bool pend = false;                               // a full row block's checks are still owed
     int64_t p_rb = 0;
     float4 pg[2] = {};
     float p_gmin = 0.f;
-    float m2r[kDefer ? 8 : 1], tqr[kDefer ? 8 : 1];  // per query block of this lane: 2 / scale, and the bound as of the last row block's end
+    float m2r[kDefer ? NJB : 1], tqr[kDefer ? NJB : 1];  // per query block of this lane: 2 / scale, and the bound as of the last row block's end
     if (kDefer) {
 #pragma unroll
-        for (int jb = 0; jb < 8; ++jb) {
+        for (int jb = 0; jb < NJB; ++jb) {
             m2r[jb] = 2.0f * qinv_s[jb * 16 + (lane & 15)];
             tqr[jb] = kAdapt ? tq_s[jb * 16 + (lane & 15)] : tau_s[jb * 16 + (lane & 15)];
         }
@@ -363,7 +366,7 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
                 }
                 __syncthreads();
                 exchange = false;
-            } else if (!warm_it && wave < 8 && !(nt_flags & 4)) {
+            } else if (!warm_it && wave < NJB && !(nt_flags & 4)) {
                 // What the other workgroups have reached since. Only ATOMICS read `smin`: they execute at the memory side, so what they
                 // return is the value every XCD's updates have been folded into -- a load, even an sc1 one, can be served by a line this
                 // XCD's L2 took in earlier (measured: whole XCDs' workgroups never saw the others' bounds and appended 16 rows each per
@@ -491,7 +494,7 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
                 const uint4* bn = t + 1 < 4 ? bq + (size_t)(t + 1) * 8 * 64 : bq_after;
                 const f16x8 a0 = as_f16x8(C[2 * t]), a1 = as_f16x8(C[2 * t + 1]);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
+                for (int j = 0; j < NJB; ++j) {
                     if (kDefer && kFirst && t == 0) {
                         if (pend) check_jb(j, p_rb, pg[0], pg[1], p_gmin);      // the previous row block's sums of query block j, about to be overwritten
                     }
@@ -538,7 +541,7 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
         if (nt_flags & 16) __builtin_amdgcn_s_setprio(0);
         if (DBG & 1) {                   // (no epilogue: the sums are only kept alive)
 #pragma unroll
-            for (int jb = 0; jb < 8; ++jb) asm volatile("" ::"v"(acc[0][jb]), "v"(acc[1][jb]));
+            for (int jb = 0; jb < NJB; ++jb) asm volatile("" ::"v"(acc[0][jb]), "v"(acc[1][jb]));
             continue;
         }
         if (!active) continue;
@@ -549,7 +552,7 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
                     pend = true;                                             // checked in the next row block's first step (or behind the loop)
                     if (kAdapt) {
 #pragma unroll
-                        for (int jb = 0; jb < 8; ++jb) tqr[jb] = tq_s[jb * 16 + (lane & 15)];
+                        for (int jb = 0; jb < NJB; ++jb) tqr[jb] = tq_s[jb * 16 + (lane & 15)];
                     }
                     p_rb = rb;
                     pg[0] = gns[0];
@@ -557,12 +560,12 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
                     p_gmin = gmin;
                 } else {
 #pragma unroll
-                    for (int jb = 0; jb < 8; ++jb) check_jb(jb, rb, gns[0], gns[1], gmin);
+                    for (int jb = 0; jb < NJB; ++jb) check_jb(jb, rb, gns[0], gns[1], gmin);
                 }
                 continue;
             }
 #pragma unroll
-            for (int jb = 0; jb < 8; ++jb) {
+            for (int jb = 0; jb < NJB; ++jb) {
                 const int q = jb * 16 + (lane & 15);
                 const float m2 = 2.0f * qinv_s[q];
                 float pv[8];
@@ -617,7 +620,7 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
         }
         // a block that straddles the end of the rows (or of the sample): row by row
 #pragma unroll
-        for (int jb = 0; jb < 8; ++jb) {
+        for (int jb = 0; jb < NJB; ++jb) {
             const int q = jb * 16 + (lane & 15);
             const float m2 = 2.0f * qinv_s[q];
             const float tq = kAdapt ? (warm_it ? -__builtin_huge_valf() : tq_s[q]) : tau_s[q];      // (a warm-up walk appends nothing)
@@ -682,7 +685,7 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
             }
         };
 #pragma unroll
-        for (int jb = 0; jb < 8; ++jb) last_jb(jb);
+        for (int jb = 0; jb < NJB; ++jb) last_jb(jb);
     }
     if (kAppend) {
         __syncthreads();                             // every wave's staged appends are in
@@ -698,7 +701,7 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
     }
     if (MODE == 2 && !sub_stride) {
 #pragma unroll
-        for (int jb = 0; jb < 8; ++jb) {
+        for (int jb = 0; jb < NJB; ++jb) {
             float v = smallest[jb];
             v = fminf(v, __shfl_xor(v, 16, 64));
             v = fminf(v, __shfl_xor(v, 32, 64));
