@@ -2176,8 +2176,10 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
         if (m->precision == FIR_GEMM_F16) {
             const int pairs = (np + 1) / 2;
             // (a super-batch of at most 16 / 32 queries: one / two query blocks of the tile are live -- the pass multiplies against those only)
-            const int njb = (k == 1 && adaptive && m->mfma16 && !m->dbg_skip && !((m->dk16 / kRing) & 1) && m->few_blocks) ? (nq <= 16 ? 1 : nq <= 32 ? 2 : 8) : 8;
             const bool streamed = m->mfma16 ? (m->dk16 > kSlabH || m->streamed > 0) : (m->streamed >= 0 ? m->streamed != 0 : m->dk16 > kSlabH);
+            // (whole, even numbers of the form's units per row: eight pieces streamed, sixteen resident)
+            const bool njb_shape = streamed ? !((m->dk16 / kRing) & 1) : (m->dk16 % (4 * kRing)) == 0;
+            const int njb = (k == 1 && adaptive && m->mfma16 && !m->dbg_skip && njb_shape && m->few_blocks) ? (nq <= 16 ? 1 : nq <= 32 ? 2 : 8) : 8;
             const int64_t rblocks = (n + 31) / 32;
             // rows longer than the LDS tile (query slabs streamed per unit): 16 readers of one range drift apart, 8 measured better
             const int share_cap = m->share_max > 0 ? (streamed ? std::min(m->share_max, m->share_streamed) : m->share_max) : 16;

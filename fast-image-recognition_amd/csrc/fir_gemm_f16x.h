@@ -92,9 +92,9 @@ __global__ void __launch_bounds__(256) k_gemm_pack_queries_f16x(const float* q, 
 // (profiles/r03_adaptive_threshold.txt). A row is appended when its proxy is below tq = T - |q|^2 AT THAT MOMENT. T only ever
 // falls, so whatever was not appended has a proxy >= fl(T_final - |q|^2) =: tau, which k_gemm_adapt_final hands to the
 // re-rank's certificate; and every row within the window of the smallest proxy of ALL rows IS appended (its proxy is below
-// every T the pass ever held). With T = +inf at the start the first row block of a wave would append all its rows: every
-// wave therefore walks its first row block twice -- once only lowering T (then the workgroup exchanges T with `smin`), then
-// for real (1 extra row block in ~120). Here `tau` carries the windows, `sample` the |q|^2, `smin` the global T.
+// every T the pass ever held). With T = +inf at the start the first row block of a wave would append all its rows: its sums
+// are therefore looked at twice -- once only lowering T (then the workgroup exchanges T with `smin`), then, still in the
+// registers, for real. Here `tau` carries the windows, `sample` the |q|^2, `smin` the global T.
 // MODE 1: the full pass, every row below tau is appended; MODE 2: the sample of the smallest-proxy flow -- row blocks
 // 0, rb_stride, 2 rb_stride, ... of the gallery ((row_end - row_begin) / 32 of them, spread over all of it: the reference's
 // galleries are ordered by class), smin[q] <- the smallest proxy seen (fir::f32_orderable bits, atomicMin, caller presets +inf);
@@ -211,7 +211,11 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
     }
     const int64_t rb_begin = row_begin / 32, rb_end = (row_end + 31) / 32;
     const int64_t nrg = (rb_end - rb_begin + wpb - 1) / wpb;
-    const int units = dk16 / kRing;
+    // a unit of the few-block forms is SIXTEEN gallery pieces (eight steps): such a pass is one read of the fragments and nothing else, and
+    // what it reads at is set by the bytes a wave keeps in flight -- 16 KiB instead of 8 (registers are not scarce with one or two
+    // query blocks). Resident tiles only (the streamed ring's slots and its vmcnt(12) are sized for eight pieces).
+    constexpr int RING = (!STREAMED && NJB < 8) ? 2 * kRing : kRing;
+    const int units = dk16 / RING;
     const int64_t rg_end = rg_last >= 0 ? rg_last : nrg;
     int64_t rg = rg_first;
     if (rg >= rg_end) return;                        // uniform per workgroup
@@ -220,10 +224,10 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
     // one 32-bit lane offset register instead of a 64-bit address per pointer)
 #define FIR_X_BLOCK(RG) (gh + (size_t)(((rb_begin + (RG) * wpb + wave) < rb_end ? (rb_begin + (RG) * wpb + wave) : rb_end - 1) * rbs) * dk16 * 64)
     const uint4* a_cur = FIR_X_BLOCK(rg);
-    uint4 cur[kRing], nxt[kRing];
+    uint4 cur[RING], nxt[RING];
 #pragma unroll
-    for (int u = 0; u < kRing; ++u) cur[u] = FIR_X_LD(a_cur + (size_t)u * 64 + lane);
-    constexpr int kUnitsPerSlab = kSlabH / kRing;                         // units of the LDS-resident tile (512 features)
+    for (int u = 0; u < RING; ++u) cur[u] = FIR_X_LD(a_cur + (size_t)u * 64 + lane);
+    constexpr int kUnitsPerSlab = kSlabH / RING;                         // units of the LDS-resident tile (512 features)
     const bool resident = !STREAMED;                                      // (the caller streams whatever does not fit: dk16 > kSlabH)
     // STREAMED (rows longer than the 512 features whose 128-query tile fits LDS): the query fragments go through a ring of FOUR
     // 32-KiB LDS slots of one unit (four steps x eight query blocks) each. Units are numbered c = 0, 1, 2, ... over the whole walk of
@@ -240,7 +244,7 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
     const uint32_t lds_base = (uint32_t)(uintptr_t)(void __attribute__((address_space(3)))*)lqx;
     auto request_piece = [&](int hq, int slot, int i) {              // piece i of this wave: (step i, query block `wave`) of slab hq
         const uint4* src = qh + ((size_t)wave * dk32 + (size_t)hq * 4 + i) * 64 + lane;
-        const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)slot * (4 * kRing * 1024) + (uint32_t)(i * 8 + wave) * 1024);
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)slot * (4 * RING * 1024) + (uint32_t)(i * 8 + wave) * 1024);
         asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(src) : "memory");
     };
     int ring_c = 0, hq3 = 0;                         // unit counter of the walk; slab index of unit ring_c + 3
@@ -297,7 +301,7 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
             tqr[jb] = kAdapt ? tq_s[jb * 16 + (lane & 15)] : tau_s[jb * 16 + (lane & 15)];
         }
     }
-    bool warm = kAdapt;                              // MODE 3 / 4: the first row block is walked twice (see above)
+    bool warm = kAdapt;                              // MODE 3 / 4: the first row block's sums are looked at twice (below)
     // MODE 4: the K-th smallest slot value as the new T of query q (a value read a moment ago is >= the slot's current one, so this is a bound)
     auto slots_to_T = [&](int q) {
         const unsigned int tk = kth_of_slots(&slot_s[q * 8]);
@@ -331,42 +335,43 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
             if (fell) slots_to_T(q);
         }
     };
-    bool exchange = false;
+    // the workgroup's first-row-block minima go out, everybody else's come in (uniform over the workgroup: every wave's first row block
+    // is its warm-up block)
+    auto exchange_T = [&]() {
+            // the workgroup's warm-up minima go out, everybody else's come in
+        __syncthreads();
+        if (threadIdx.x < 2 * kQT) {
+            if (kSlots) {
+                unsigned int mine[8], old[8];
+#pragma unroll
+                for (int sl = 0; sl < 8; ++sl) mine[sl] = slot_s[threadIdx.x * 8 + sl];
+#pragma unroll
+                for (int sl = 0; sl < 8; ++sl) old[sl] = (nt_flags & 8) ? mine[sl] : atomicMin(&smin[threadIdx.x * 8 + sl], mine[sl]);
+#pragma unroll
+                for (int sl = 0; sl < 8; ++sl) slot_s[threadIdx.x * 8 + sl] = old[sl] < mine[sl] ? old[sl] : mine[sl];
+                tau_s[threadIdx.x] = __uint_as_float(kth_of_slots(&slot_s[threadIdx.x * 8]));
+            } else {
+            const unsigned int mine = __float_as_uint(tau_s[threadIdx.x]);
+            const unsigned int old = (nt_flags & 8) ? mine : atomicMin(&smin[threadIdx.x], mine);
+            tau_s[threadIdx.x] = __uint_as_float(old < mine ? old : mine);
+            }
+            tq_s[threadIdx.x] = tau_s[threadIdx.x] - qn_s[threadIdx.x];
+        }
+        __syncthreads();
+    };
     int blk_no = 0;
     int64_t rg_next = rg;
     for (; rg < rg_end; rg = rg_next) {
-        const bool warm_it = warm;
+        const bool warm_it = warm;                        // this wave's first row block: T is still what it was preset to
         warm = false;
-        rg_next = warm_it ? rg : rg + rg_step;
+        rg_next = rg + rg_step;
         const int64_t rbp = rb_begin + rg * wpb + wave;   // row block of the pass ...
         const int64_t rb = rbp * rbs;                     // ... and of the gallery
         const bool active = rbp < rb_end;
         const int64_t rgn = rg_next;
         const uint4* a_nxt = FIR_X_BLOCK(rgn < rg_end ? rgn : rg);
         if (kAdapt) {
-            if (exchange) {                               // (uniform over the workgroup: every wave walks the same rg sequence)
-                // the workgroup's warm-up minima go out, everybody else's come in
-                __syncthreads();
-                if (threadIdx.x < 2 * kQT) {
-                    if (kSlots) {
-                        unsigned int mine[8], old[8];
-#pragma unroll
-                        for (int sl = 0; sl < 8; ++sl) mine[sl] = slot_s[threadIdx.x * 8 + sl];
-#pragma unroll
-                        for (int sl = 0; sl < 8; ++sl) old[sl] = (nt_flags & 8) ? mine[sl] : atomicMin(&smin[threadIdx.x * 8 + sl], mine[sl]);
-#pragma unroll
-                        for (int sl = 0; sl < 8; ++sl) slot_s[threadIdx.x * 8 + sl] = old[sl] < mine[sl] ? old[sl] : mine[sl];
-                        tau_s[threadIdx.x] = __uint_as_float(kth_of_slots(&slot_s[threadIdx.x * 8]));
-                    } else {
-                    const unsigned int mine = __float_as_uint(tau_s[threadIdx.x]);
-                    const unsigned int old = (nt_flags & 8) ? mine : atomicMin(&smin[threadIdx.x], mine);
-                    tau_s[threadIdx.x] = __uint_as_float(old < mine ? old : mine);
-                    }
-                    tq_s[threadIdx.x] = tau_s[threadIdx.x] - qn_s[threadIdx.x];
-                }
-                __syncthreads();
-                exchange = false;
-            } else if (!warm_it && wave < NJB && !(nt_flags & 4)) {
+            if (!warm_it && wave < NJB && !(nt_flags & 4)) {
                 // What the other workgroups have reached since. Only ATOMICS read `smin`: they execute at the memory side, so what they
                 // return is the value every XCD's updates have been folded into -- a load, even an sc1 one, can be served by a line this
                 // XCD's L2 took in earlier (measured: whole XCDs' workgroups never saw the others' bounds and appended 16 rows each per
@@ -398,7 +403,6 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
                 }
             }
             ++blk_no;
-            if (warm_it) exchange = true;
         }
         float4 gns[2];                               // squared norms of rows 16 s + 4 (lane >> 4) + 0..3 of the block
         const bool full_block = active && rbp * 32 >= row_begin && rbp * 32 + 32 <= row_end && rb * 32 + 32 <= n && (MODE != 0 || rb * 32 + 32 <= sample_rows);
@@ -461,20 +465,20 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
                 if (kAdapt) lower_T(qr, pv, mn);
             }
         };
-        auto unit = [&](uint4 (&C)[kRing], uint4 (&N)[kRing], int h, auto first_tag) {
+        auto unit = [&](uint4 (&C)[RING], uint4 (&N)[RING], int h, auto first_tag) {
             constexpr bool kFirst = decltype(first_tag)::value;      // the first unit of the row block: its first step starts the sums
-            const uint4* src = h + 1 < units ? a_cur + (size_t)(h + 1) * kRing * 64 : a_nxt;
-            const uint4* bq = STREAMED ? lqx + lane + (size_t)(ring_c & 3) * 4 * kRing * 64 : lqx + lane + (size_t)(h % kUnitsPerSlab) * kRing * 4 * 64;
+            const uint4* src = h + 1 < units ? a_cur + (size_t)(h + 1) * RING * 64 : a_nxt;
+            const uint4* bq = STREAMED ? lqx + lane + (size_t)(ring_c & 3) * 4 * RING * 64 : lqx + lane + (size_t)(h % kUnitsPerSlab) * RING * 4 * 64;
             // The next unit's eight gallery pieces are requested in one burst in front of the unit. (DBG & 16, measured and not kept: two per
             // step, behind the fourth and the eighth pair of MFMAs -- every piece still exactly one unit before its use -- ran 6 % slower at
             // 512 features and 5 % at 256: profiles/r03_gemm_time_decomposition.txt.)
             if (!(DBG & 16) && !(DBG & 2)) {
                 if (nt) {
 #pragma unroll
-                    for (int u = 0; u < kRing; ++u) N[u] = ld_nt(src + (size_t)u * 64 + lane);
+                    for (int u = 0; u < RING; ++u) N[u] = ld_nt(src + (size_t)u * 64 + lane);
                 } else {
 #pragma unroll
-                    for (int u = 0; u < kRing; ++u) N[u] = src[(size_t)u * 64 + lane];
+                    for (int u = 0; u < RING; ++u) N[u] = src[(size_t)u * 64 + lane];
                 }
             }
             if (h == units - 1 && full_block) {
@@ -487,11 +491,11 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
                 gns[0] = *(const float4*)(gb + off);
                 gns[1] = *(const float4*)(gb + off + 16);
             }
-            const uint4* bq_after = STREAMED ? lqx + lane + (size_t)((ring_c + 1) & 3) * 4 * kRing * 64
-                                             : lqx + lane + (size_t)((h + 1 < units ? h + 1 : 0) % kUnitsPerSlab) * kRing * 4 * 64;
+            const uint4* bq_after = STREAMED ? lqx + lane + (size_t)((ring_c + 1) & 3) * 4 * RING * 64
+                                             : lqx + lane + (size_t)((h + 1 < units ? h + 1 : 0) % kUnitsPerSlab) * RING * 4 * 64;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const uint4* bn = t + 1 < 4 ? bq + (size_t)(t + 1) * 8 * 64 : bq_after;
+            for (int t = 0; t < RING / 2; ++t) {
+                const uint4* bn = t + 1 < RING / 2 ? bq + (size_t)(t + 1) * 8 * 64 : bq_after;
                 const f16x8 a0 = as_f16x8(C[2 * t]), a1 = as_f16x8(C[2 * t + 1]);
 #pragma unroll
                 for (int j = 0; j < NJB; ++j) {
@@ -535,7 +539,7 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
                 unit(cur, nxt, h + 1, std::false_type());
             }
 #pragma unroll
-            for (int u = 0; u < kRing; ++u) cur[u] = nxt[u];         // an odd number of units: the next row block's first unit sits in nxt
+            for (int u = 0; u < RING; ++u) cur[u] = nxt[u];         // an odd number of units: the next row block's first unit sits in nxt
         }
         a_cur = a_nxt;
         if (nt_flags & 16) __builtin_amdgcn_s_setprio(0);
@@ -544,10 +548,50 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
             for (int jb = 0; jb < NJB; ++jb) asm volatile("" ::"v"(acc[0][jb]), "v"(acc[1][jb]));
             continue;
         }
+        if (kAdapt && warm_it) {
+            // This wave's first row block, T still at its preset: the sums are looked at twice. First only to lower T (LDS) -- then the
+            // workgroup exchanges with `smin` -- then, still in their registers, for the block's checks like any other block's. (Until
+            // round 4 the block was WALKED twice: one row block in ~120 of a large launch, one in 15 of a one-pair launch over 1M rows.)
+            if (active && full_block) {
+#pragma unroll
+                for (int jb = 0; jb < NJB; ++jb) {
+                    const int q = jb * 16 + (lane & 15);
+                    const float m2 = 2.0f * qinv_s[q];
+                    float pv[8];
+                    float mn = __builtin_huge_valf();
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const float gnv[4] = {gns[s].x, gns[s].y, gns[s].z, gns[s].w};
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) {
+                            pv[4 * s + reg] = __builtin_fmaf(-m2, acc[s][jb][reg], gnv[reg]);
+                            mn = fminf(mn, pv[4 * s + reg]);                   // NaN never enters, like k_gemm_tau's ordering
+                        }
+                    }
+                    if (kSlots) {
+                        // every lane's eight proxies lower their slots (LDS; the exchange turns the slots into T)
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const float tn = fmaxf((pv[i] + qn_s[q]) + win_s[q], 0.f);
+                            if (pv[i] == pv[i] && tn < __uint_as_float(slot_s[q * 8 + i])) atomicMin(&slot_s[q * 8 + i], __float_as_uint(tn));
+                        }
+                    } else {
+                        // the smallest proxy of the block's 32 rows lowers T (LDS)
+                        float o = __shfl_xor(mn, 16, 64);
+                        mn = o < mn ? o : mn;
+                        o = __shfl_xor(mn, 32, 64);
+                        mn = o < mn ? o : mn;
+                        const float tn = fmaxf((mn + qn_s[q]) + win_s[q], 0.f);     // (NaN operands: fmaxf gives 0 only if both are NaN; a NaN tn fails the test below)
+                        if (lane < 16 && tn < tau_s[q]) atomicMin((unsigned int*)&tau_s[q], __float_as_uint(tn));
+                    }
+                }
+            }
+            exchange_T();
+        }
         if (!active) continue;
         if (full_block) {
             const float gmin = fminf(fminf(fminf(gns[0].x, gns[0].y), fminf(gns[0].z, gns[0].w)), fminf(fminf(gns[1].x, gns[1].y), fminf(gns[1].z, gns[1].w)));
-            if (kAppend && !(kAdapt && warm_it)) {
+            if (kAppend) {
                 if (kDefer) {
                     pend = true;                                             // checked in the next row block's first step (or behind the loop)
                     if (kAdapt) {
@@ -579,22 +623,7 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
                         mn = fminf(mn, pv[4 * s + reg]);                   // NaN never enters, like k_gemm_tau's ordering
                     }
                 }
-                if (kSlots && warm_it) {
-                    // observe only: every lane's eight proxies lower their slots (LDS; the exchange behind the warm-up turns the slots into T)
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const float tn = fmaxf((pv[i] + qn_s[q]) + win_s[q], 0.f);
-                        if (pv[i] == pv[i] && tn < __uint_as_float(slot_s[q * 8 + i])) atomicMin(&slot_s[q * 8 + i], __float_as_uint(tn));
-                    }
-                } else if (kAdapt && warm_it) {
-                    // observe only: the smallest proxy of the block's 32 rows lowers T (LDS; the workgroup exchanges with `smin` afterwards)
-                    float o = __shfl_xor(mn, 16, 64);
-                    mn = o < mn ? o : mn;
-                    o = __shfl_xor(mn, 32, 64);
-                    mn = o < mn ? o : mn;
-                    const float tn = fmaxf((mn + qn_s[q]) + win_s[q], 0.f);     // (NaN operands: fmaxf gives 0 only if both are NaN; a NaN tn fails the test below)
-                    if (lane < 16 && tn < tau_s[q]) atomicMin((unsigned int*)&tau_s[q], __float_as_uint(tn));
-                } else if (MODE == 2 && !sub_stride) {
+                if (MODE == 2 && !sub_stride) {
                     smallest[jb] = fminf(smallest[jb], mn);
                 } else if (MODE == 2) {
                     // the K-nearest sample: kRtSubsets = 8 positions (of a lane's eight rows) x 8 waves disjoint subsets -- every sampled row
@@ -623,7 +652,7 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
         for (int jb = 0; jb < NJB; ++jb) {
             const int q = jb * 16 + (lane & 15);
             const float m2 = 2.0f * qinv_s[q];
-            const float tq = kAdapt ? (warm_it ? -__builtin_huge_valf() : tq_s[q]) : tau_s[q];      // (a warm-up walk appends nothing)
+            const float tq = kAdapt ? tq_s[q] : tau_s[q];
             float mn = __builtin_huge_valf();
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
