@@ -260,7 +260,7 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
         __syncthreads();
     } else {
         // LDS image: step-major, the eight query blocks of a step side by side -- (kk * 8 + jb) * 1 KiB
-        for (int i = threadIdx.x; i < 8 * dk32 * 64; i += blockDim.x) {
+        for (int i = threadIdx.x; i < NJB * dk32 * 64; i += blockDim.x) {                   // (the live query blocks: NJB of the tile's eight)
             const int jb = i / (dk32 * 64), r = i - jb * dk32 * 64;
             lqx[(size_t)((r >> 6) * 8 + jb) * 64 + (r & 63)] = qh[(size_t)jb * dk32 * 64 + r];
         }
