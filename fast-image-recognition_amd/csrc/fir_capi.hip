@@ -300,11 +300,11 @@ bool wants_mfma(const fir_gallery* g, int32_t qb, int32_t start, int32_t end) {
     if (qb >= kAutoMfmaQueries || (qb >= 32 && mb >= 128.0)) return true;
     if (qb < 2 || mb < 300.0) return false;
     // 2..31 queries over rows streamed from HBM: the scan takes one pass per power-of-two group of up to 8 queries (3 queries: 2 + 1,
-    // 7: 4 + 2 + 1), ~10 us + 0.185 us per MB each (397 us for 8 queries, 1016 us for 7 at 1M x 512); the matrix-core call ~125 us +
-    // 0.105 us per MB for anything up to 128 queries (347 us there)
+    // 7: 4 + 2 + 1), ~15 us + 0.16 us per MB each (1M x 512, 2 048 MB: 340 us for 1, 2, 4 or 8 queries, three times that for 7); the
+    // matrix-core call, since round 4 (live query blocks only, one stream, the first row block summed once: profiles/r04_small_calls.txt),
+    // ~75 us + 0.095 us per MB for anything up to 32 queries (1M x 512: 265 us; 1M x 1280: 575 us), ~125 us + 0.105 us per MB up to 128
     const int passes = qb / 8 + __builtin_popcount((unsigned)qb & 7u);
-    if (passes == 1 && qb < 8) return false;                   // 2 or 4 queries: one narrow pass (349 / 353 us), a tie -- the scan needs no fp16 copy
-    return 125.0 + 0.105 * mb < passes * (10.0 + 0.185 * mb);
+    return (qb <= 32 ? 75.0 + 0.095 * mb : 125.0 + 0.105 * mb) < passes * (15.0 + 0.16 * mb);
 }
 
 // ONE query against rows far beyond the caches (automatic mode only): the nomination scan over the fp16 copy
