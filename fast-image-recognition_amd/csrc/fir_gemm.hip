@@ -665,8 +665,15 @@ __global__ void __launch_bounds__(256) k_gemm_pack_gallery_f16(const float4* __r
 __global__ void __launch_bounds__(64) k_gemm_qprep_f16(const float* __restrict__ q, int nq, int d, int gallery_exp, float* __restrict__ qnorm,
                                                         float* __restrict__ qmul, float* __restrict__ qinv, int qstride, int* __restrict__ counts = nullptr,
                                                         float* __restrict__ win = nullptr, unsigned int* __restrict__ t_bits = nullptr,
-                                                        const float* __restrict__ gnorm_max_p = nullptr, float e_rel = 0.f, int nslot = 0) {
+                                                        const float* __restrict__ gnorm_max_p = nullptr, float e_rel = 0.f, int nslot = 0,
+                                                        unsigned int* __restrict__ smin_init = nullptr, int* __restrict__ fb_state = nullptr) {
+    // smin_init / fb_state (the few-query path): the words three hipMemsetAsync calls used to preset -- each a launch of its own in front of a
+    // 250-us call
     const int qi = blockIdx.x;
+    if (threadIdx.x == 0) {
+        if (smin_init) smin_init[qi] = 0xFF800000u;
+        if (fb_state && qi == 0) { fb_state[0] = 0; fb_state[1] = 0; }
+    }
     float s = 0.f, m = 0.f;
     bool bad = false;
     if (qi < nq)
@@ -1965,7 +1972,8 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
         const int rcr = gemm_fb_reserve_(m, qb);
         if (rcr) return rcr;
     }
-    GEMM_HIP(hipMemsetAsync(m->fb_state, 0, 2 * sizeof(int), st));       // this call's two list lengths
+    // this call's two list lengths (the fp16 forms clear them in the first super-batch's query preparation: one launch less per call)
+    if (m->precision != FIR_GEMM_F16) GEMM_HIP(hipMemsetAsync(m->fb_state, 0, 2 * sizeof(int), st));
     const size_t lds = m->precision == FIR_GEMM_F32 ? (size_t)(kQT / 32) * std::min(m->dq8, kSlab8) * 64 * sizeof(float4)
                                                     : (size_t)(kQT / 32) * std::min(m->dk16, kSlab16) * 128 * sizeof(uint4);
     // fp16: both operands rounded to 11 bits -> |q~.g~ - q.g| <= (2^-10 + 2^-22) sum|q_k g_k| + the sub-normal tails
@@ -2089,7 +2097,7 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
             const bool adaptive_prep = adaptive_for(nq);
             hipLaunchKernelGGL(k_gemm_qprep_f16, dim3(pairs * 2 * kQT), dim3(64), 0, ps, dq, nq, d, m->gallery_exp, m->qnorm[b], m->qmul[b], m->qinv[b], qs,
                                m->counts[b], adaptive_prep ? m->awin[b] : (float*)nullptr, adaptive_prep ? m->aT[b] : (unsigned int*)nullptr,
-                               (const float*)m->gmax, e_rel, k > 1 ? k : 0);
+                               (const float*)m->gmax, e_rel, k > 1 ? k : 0, (unsigned int*)nullptr, sb == 0 ? m->fb_state : (int*)nullptr);
             if (m->mfma16)
                 hipLaunchKernelGGL(k_gemm_pack_queries_f16x, dim3((4 * m->dk16 * 64 + 255) / 256, pairs), dim3(256), 0, ps, dq, nq, d, m->dk16, m->qmul[b],
                                    m->qbf[b], qs);
@@ -2359,14 +2367,12 @@ int fir_gemm_search_few_keys_dev(fir_gemm* m, const float* d_queries, int32_t qb
         const int rcr = gemm_fb_reserve_(m, qb);
         if (rcr) return rcr;
     }
-    GEMM_HIP(hipMemsetAsync(m->fb_state, 0, 2 * sizeof(int), st));
     const float e_rel = m->erel_scale * (8.0f * (float)d * 5.9604645e-8f + 9.765625e-4f * 1.0625f);     // as gemm_search (one fp16 term)
     const int b = 0;
-    hipLaunchKernelGGL(k_gemm_qprep_f16, dim3(2 * kQT), dim3(64), 0, st, d_queries, qb, d, m->gallery_exp, m->qnorm[b], m->qmul[b], m->qinv[b], qs);
-    GEMM_HIP(hipMemsetAsync(m->counts[b], 0, 2 * kQT * sizeof(int), st));
+    hipLaunchKernelGGL(k_gemm_qprep_f16, dim3(2 * kQT), dim3(64), 0, st, d_queries, qb, d, m->gallery_exp, m->qnorm[b], m->qmul[b], m->qinv[b], qs, m->counts[b],
+                       (float*)nullptr, (unsigned int*)nullptr, (const float*)nullptr, 0.f, 0, m->smin[b], m->fb_state);
     if (m->mfma16) hipLaunchKernelGGL(k_gemm_pack_queries_f16x, dim3((4 * m->dk16 * 64 + 255) / 256, 1), dim3(256), 0, st, d_queries, qb, d, m->dk16, m->qmul[b], m->qbf[b], qs);
     else hipLaunchKernelGGL(k_gemm_pack_queries_f16, dim3((4 * m->dk16 * 64 + 255) / 256, 1), dim3(256), 0, st, d_queries, qb, d, m->dk16, m->qmul[b], m->qbf[b], qs);
-    GEMM_HIP(hipMemsetD32Async((hipDeviceptr_t)m->smin[b], (int)0xFF800000u, 2 * kQT, st));
     const dim3 grid((unsigned)std::min<int64_t>((int64_t)m->v.cus * 8, ((n + 31) / 32 + 3) / 4));
     const size_t lds = (size_t)m->dk16 * 2 * nqt * sizeof(uint4);
 #define FIR_FEW(NQ) do { if (m->mfma16) hipLaunchKernelGGL(k_gemm_scan_f16x<NQ>, grid, dim3(256), lds, st, m->gh, m->gnorm, m->qbf[b], m->qinv[b], n, m->dk16, m->proxies, m->smin[b]); \
