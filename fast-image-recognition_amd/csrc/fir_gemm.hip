@@ -1591,12 +1591,16 @@ static fir_x_fn pick_x(int mode, bool streamed, bool odd, int dbg = 0, int njb =
         if (njb == 2) return streamed ? k_gemm_proxy_f16x<3, 1, 0, 0, 2> : k_gemm_proxy_f16x<3, 0, 0, 0, 2>;
     }
     if (dbg && mode == 3 && !streamed && !odd) {       // timing experiments (FIR_GEMM_DBG_SKIP): wrong answers
-        switch (dbg & 31) {
+        switch (dbg & 127) {
             case 1: return k_gemm_proxy_f16x<3, 0, 0, 1>;
             case 2: return k_gemm_proxy_f16x<3, 0, 0, 2>;
             case 3: return k_gemm_proxy_f16x<3, 0, 0, 3>;
             case 5: return k_gemm_proxy_f16x<3, 0, 0, 5>;
             case 7: return k_gemm_proxy_f16x<3, 0, 0, 7>;
+            case 64: return k_gemm_proxy_f16x<3, 0, 0, 64>;     // (not a wrong-answer form: the gallery pieces one behind each MFMA pair of a unit's first step)
+            case 33: return k_gemm_proxy_f16x<3, 0, 0, 33>;     // no MFMAs, no epilogue: the gallery stream + the query-fragment re-reads
+            case 37: return k_gemm_proxy_f16x<3, 0, 0, 37>;     // ... the gallery stream alone
+            case 35: return k_gemm_proxy_f16x<3, 0, 0, 35>;     // ... the query-fragment re-reads alone
             case 16: return k_gemm_proxy_f16x<3, 0, 0, 16>;     // (not a wrong-answer form either: the gallery pieces of a unit requested two per step instead of in one burst)
             case 8: return k_gemm_proxy_f16x<3, 0, 0, 8>;       // (not a wrong-answer form: the epilogue behind its own row block, for A/B runs)
             default: break;
@@ -1755,7 +1759,7 @@ int fir_gemm_create_range_ex_(fir_gallery* g, int32_t precision, int32_t end_pos
     if (const char* w = fir_knob_("FIR_GEMM_PRIO")) m->prio = std::atoi(w) != 0;
     if (const char* w = fir_knob_("FIR_GEMM_NO_BLOCK_BOUND")) m->no_block_bound = std::atoi(w) != 0;
 #ifdef FIR_AUDIT      // knobs that change answers: the audit build only (libfir_amd_audit.so; fir_internal.h)
-    if (const char* w = fir_knob_("FIR_GEMM_DBG_SKIP")) m->dbg_skip = std::atoi(w) & 31;     // timing experiments only: the answers are wrong
+    if (const char* w = fir_knob_("FIR_GEMM_DBG_SKIP")) m->dbg_skip = std::atoi(w) & 127;     // timing experiments only: the answers are wrong
     if (const char* w = fir_knob_("FIR_GEMM_EREL_SCALE")) m->erel_scale = (float)std::atof(w);
 #endif
     if (const char* w = fir_knob_("FIR_GEMM_ADAPTIVE")) m->adaptive = std::atoi(w);

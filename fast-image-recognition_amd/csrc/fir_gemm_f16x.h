@@ -111,7 +111,7 @@ constexpr int kXStage = 16;             // staged appends per query and workgrou
 // of the fp16 fragments at the rate the memory system gives (the tile's layout in LDS and in `qh` is unchanged).
 // DBG (timing experiments only, FIR_GEMM_DBG_SKIP; own instantiations so that the production kernels' register allocation is not
 // touched -- as runtime flags the two tests made the row loop spill): bit 0 = no epilogue, bit 1 = no gallery stream, bit 2 = no
-// re-read of the query fragments. The answers of such a kernel are wrong.
+// re-read of the query fragments, bit 5 = no MFMAs. The answers of such a kernel are wrong.
 template <int MODE, int STREAMED, int ODD, int DBG = 0, int NJB = 8>
 __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* __restrict__ gh, const float* __restrict__ gnorm, const uint4* qh,
                                                                     const float* __restrict__ qinv, int64_t n, int64_t row_begin, int64_t row_end,
@@ -472,7 +472,7 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
             // The next unit's eight gallery pieces are requested in one burst in front of the unit. (DBG & 16, measured and not kept: two per
             // step, behind the fourth and the eighth pair of MFMAs -- every piece still exactly one unit before its use -- ran 6 % slower at
             // 512 features and 5 % at 256: profiles/r03_gemm_time_decomposition.txt.)
-            if (!(DBG & 16) && !(DBG & 2)) {
+            if (!(DBG & 16) && !(DBG & 2) && !(DBG & 64)) {
                 if (nt) {
 #pragma unroll
                     for (int u = 0; u < RING; ++u) N[u] = ld_nt(src + (size_t)u * 64 + lane);
@@ -504,9 +504,17 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
                     }
                     const f16x8 b = as_f16x8(B[j]);
                     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-                    acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b, kFirst && t == 0 ? zero : acc[0][j], 0, 0, 0);
-                    acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b, kFirst && t == 0 ? zero : acc[1][j], 0, 0, 0);
+                    if (!(DBG & 32)) {
+                        acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b, kFirst && t == 0 ? zero : acc[0][j], 0, 0, 0);
+                        acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b, kFirst && t == 0 ? zero : acc[1][j], 0, 0, 0);
+                    } else {                                      // (DBG & 32: no MFMAs -- the operands are only kept alive: what the two streams cost by themselves)
+                        asm volatile("" ::"v"(a0), "v"(a1), "v"(b));
+                        if (kFirst && t == 0) { acc[0][j] = zero; acc[1][j] = zero; }
+                    }
                     if (!(DBG & 4)) B[j] = bn[j * 64];
+                    if ((DBG & 64) && t == 0 && RING == 8) {     // (DBG & 64: the next unit's pieces one at a time, behind each MFMA pair of the unit's first step)
+                        N[j] = nt ? ld_nt(src + (size_t)j * 64 + lane) : src[(size_t)j * 64 + lane];
+                    }
                     if ((DBG & 16) && !(DBG & 2) && (j == 3 || j == 7)) {
                         const int u = 2 * t + (j == 7 ? 1 : 0);
                         N[u] = nt ? ld_nt(src + (size_t)u * 64 + lane) : src[(size_t)u * 64 + lane];
