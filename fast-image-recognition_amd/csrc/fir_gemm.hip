@@ -1571,6 +1571,7 @@ struct fir_gemm {
     unsigned int* aT[2] = {nullptr, nullptr};   // ... and the ranks' shared T (float bits)
     float erel_scale = 1.0f;              // AUDIT KNOB, never set in production: the certificate's relative error bound is multiplied by this (FIR_GEMM_EREL_SCALE);
                                           // tests/test_gpu_gemm.py shows that a bound shrunk to a quarter returns a wrong row on a crafted near-tie, i.e. that the suite can see an unsound bound
+    int dbg_block = kGemmBlock;           // timing experiments (audit build, FIR_GEMM_DBG_BLOCK=256): the resident adaptive pass with four waves per workgroup = ONE wave per SIMD
     int dbg_skip = 0;                     // timing experiments: bit 0 = no epilogue, bit 1 = no gallery stream, bit 2 = no query-fragment re-reads (FIR_GEMM_DBG_SKIP; wrong answers)
     int no_block_bound = 0;               // A/B: the append forms compute all eight proxies of every query block (FIR_GEMM_NO_BLOCK_BOUND)
     int prio = 0;                         // mfma16 experiment: s_setprio 2 around the MFMA phase of a row block (FIR_GEMM_PRIO)
@@ -1759,7 +1760,8 @@ int fir_gemm_create_range_ex_(fir_gallery* g, int32_t precision, int32_t end_pos
     if (const char* w = fir_knob_("FIR_GEMM_PRIO")) m->prio = std::atoi(w) != 0;
     if (const char* w = fir_knob_("FIR_GEMM_NO_BLOCK_BOUND")) m->no_block_bound = std::atoi(w) != 0;
 #ifdef FIR_AUDIT      // knobs that change answers: the audit build only (libfir_amd_audit.so; fir_internal.h)
-    if (const char* w = fir_knob_("FIR_GEMM_DBG_SKIP")) m->dbg_skip = std::atoi(w) & 127;     // timing experiments only: the answers are wrong
+    if (const char* w = fir_knob_("FIR_GEMM_DBG_SKIP")) m->dbg_skip = std::atoi(w) & 127;
+    if (const char* w = fir_knob_("FIR_GEMM_DBG_BLOCK")) m->dbg_block = std::atoi(w) == 256 ? 256 : kGemmBlock;     // timing experiments only: the answers are wrong
     if (const char* w = fir_knob_("FIR_GEMM_EREL_SCALE")) m->erel_scale = (float)std::atof(w);
 #endif
     if (const char* w = fir_knob_("FIR_GEMM_ADAPTIVE")) m->adaptive = std::atoi(w);
@@ -2226,7 +2228,7 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
                     used_rt = true;
                     used_rt_lds = rt_lds;
                 } else if (adaptive)
-                    hipLaunchKernelGGL(pick_x(k > 1 ? 4 : 3, streamed, (m->dk16 / kRing) & 1, k > 1 ? 0 : m->dbg_skip, njb), g1, dim3(kGemmBlock), kHalfLds, st, m->gh, m->gnorm, m->qbf[b] + qo * 4 * m->dk16 * 64,
+                    hipLaunchKernelGGL(pick_x(k > 1 ? 4 : 3, streamed, (m->dk16 / kRing) & 1, k > 1 ? 0 : m->dbg_skip, njb), g1, dim3(streamed ? kGemmBlock : m->dbg_block), kHalfLds, st, m->gh, m->gnorm, m->qbf[b] + qo * 4 * m->dk16 * 64,
                                        m->qinv[b] + qo * 2 * kQT, n, (int64_t)0, n, m->dk16, m->awin[b] + qo * 2 * kQT, m->lists[b] + qo * 2 * kQT * kListCap,
                                        m->counts[b] + qo * 2 * kQT, m->qnorm[b] + qo * 2 * kQT, sample_rows, share, nt | adapt_dbg | (m->stagger ? 2 : 0) | (m->stagger > 1 ? 32 : 0) | (m->prio ? 16 : 0) | (m->no_block_bound ? 64 : 0), 1,
                                        m->aT[b] + qo * 2 * kQT * (k > 1 ? 8 : 1), k > 1 ? k : 0);
