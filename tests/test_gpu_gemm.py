@@ -411,7 +411,9 @@ def test_default_dispatch_takes_small_batches_on_large_galleries(fir):
     dev = torch.device("cuda", 0)
     d = 512
     for n, qb, want in ((70_000, 32, "mfma"), (70_000, 16, "scan"), (400_000, 16, "mfma"), (400_000, 8, "scan"), (400_000, 7, "mfma"),
-                        (1_000_000, 8, "mfma"), (1_000_000, 3, "mfma"), (1_000_000, 4, "mfma"), (1_000_000, 2, "mfma")):
+                        (1_000_000, 8, "mfma"), (1_000_000, 3, "mfma"), (1_000_000, 4, "mfma"), (1_000_000, 2, "mfma"),
+                        # the few-block forms' edges: 16 queries fill one query block, 17 start the second, 32 fill it, 33 take the whole tile
+                        (1_000_000, 16, "mfma"), (1_000_000, 17, "mfma"), (1_000_000, 32, "mfma"), (1_000_000, 33, "mfma")):
         x = torch.rand((n, d), device=dev)
         x = (x / x.norm(dim=1, keepdim=True)).contiguous()
         q = (x[:: n // qb][:qb] * 0.97 + x[1: qb + 1] * 0.03).contiguous()
@@ -421,6 +423,9 @@ def test_default_dispatch_takes_small_batches_on_large_galleries(fir):
         g.search_top1_keys_dev(q.data_ptr(), qb, k1.data_ptr())
         g.sync()
         assert g.last_dispatch()["path"] == want, (n, qb)
+        if n == 1_000_000 and want == "mfma":
+            kern = g.last_dispatch()["kernel"]
+            assert ("f16x<3, 0, 0, 0, 1>" in kern) == (qb <= 16) and ("f16x<3, 0, 0, 0, 2>" in kern) == (16 < qb <= 32), (qb, kern)
         g.set_large_batch_mfma(0)
         g.search_top1_keys_dev(q.data_ptr(), qb, k2.data_ptr())
         g.sync()
