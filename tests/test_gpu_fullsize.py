@@ -305,3 +305,40 @@ def test_config4_10m_x_512_as_eight_shards_through_the_library_exchange(fir, ora
         assert np.float32(dist[i]).view(np.uint32) == np.float32(exp).view(np.uint32), i
     del x
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("qb", [8, 4096])
+def test_power_of_two_scaling_and_row_reversal_at_1m(fir, qb):
+    """Two size-independent properties of the whole 1M x 512 path (matrix-core nomination, exact re-rank, certificate), no oracle needed:
+    (1) gallery and queries both multiplied by 2^e: every squared difference scales by 4^e exactly, so the same rows come back with the
+    distance's exponent shifted by 2e and the same mantissa bits -- for e = 5 and e = -7 (the fp16 fragments are cut with power-of-two
+    scales per gallery and per query: this walks their exponent arithmetic); (2) the gallery's rows in reverse order: row i becomes row
+    n - 1 - i with the same distance bits (random rows: no ties)."""
+    n, d = 1_000_000, 512
+    x = make_gallery(n, d, 4242)
+    gq = torch.Generator(device="cuda")
+    gq.manual_seed(99)
+    q = torch.rand((qb, d), generator=gq, device="cuda")
+    q[::2] = x[(torch.arange(qb, device="cuda")[::2] * 977 + 5) % n] * 0.98 + q[::2] * 0.02
+    q = (q / q.norm(dim=1, keepdim=True)).contiguous()
+    st = torch.cuda.Stream()
+    torch.cuda.synchronize()
+
+    def run(rows, queries):
+        with fir.Gallery(dev_ptr=rows.data_ptr(), n=n, d=d, metric=0, device=0, stream=st.cuda_stream) as g:
+            keys = keys_of(fir, g, queries, st)
+            assert g.last_dispatch()["path"] == "mfma"
+        return fir.keys_unpack(keys)
+
+    i0, d0 = run(x, q)
+    for e in (5, -7):
+        xs, qs = (x * 2.0 ** e).contiguous(), (q * 2.0 ** e).contiguous()
+        torch.cuda.synchronize()
+        ie, de = run(xs, qs)
+        assert np.array_equal(ie, i0)
+        assert np.array_equal(de.view(np.uint32), (d0 * np.float32(4.0 ** e)).view(np.uint32))
+        del xs, qs
+    xr = torch.flip(x, dims=[0]).contiguous()
+    torch.cuda.synchronize()
+    ir, dr = run(xr, q)
+    assert np.array_equal(ir, n - 1 - i0) and np.array_equal(dr.view(np.uint32), d0.view(np.uint32))
