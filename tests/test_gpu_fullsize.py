@@ -342,3 +342,48 @@ def test_power_of_two_scaling_and_row_reversal_at_1m(fir, qb):
     torch.cuda.synchronize()
     ir, dr = run(xr, q)
     assert np.array_equal(ir, n - 1 - i0) and np.array_equal(dr.view(np.uint32), d0.view(np.uint32))
+
+
+@pytest.mark.parametrize("metric", [1, 2])
+def test_chi2_kl_scale_with_their_operands_at_1m(fir, metric):
+    """chi-square and KL are homogeneous of degree one: gallery and queries both multiplied by 2^e give the same rows (top-1 and top-5)
+    and every distance times 2^e exactly -- (l - r)^2 / (l + r) and l log(2l / s) pick the factor up once, the quotients inside do not
+    see it. The nomination forms (harmonic sums / entropies, thresholds widened by bounds relative to sum(l) + max sum(r)) are NOT
+    scale-free in what they add up, so this walks their widening at other magnitudes; 40 queries take the nomination scan."""
+    n, d, k, qb = 1_000_000, 512, 5, 40
+    x = make_gallery(n, d, 778)
+    x = x * x.norm(dim=1, keepdim=True)
+    x = (x / x.sum(dim=1, keepdim=True)).contiguous()
+    gq = torch.Generator(device="cuda")
+    gq.manual_seed(6)
+    fresh = torch.rand((qb, d), generator=gq, device="cuda")
+    fresh = torch.where(fresh < 1e-4, torch.zeros_like(fresh), fresh)
+    q = fresh / fresh.sum(dim=1, keepdim=True)
+    q[::2] = x[(torch.arange(qb, device="cuda")[::2] * 7919 + 3) % n] * 0.97 + q[::2] * 0.03
+    q = q.contiguous()
+    st = torch.cuda.Stream()
+    torch.cuda.synchronize()
+
+    def run(rows, queries):
+        with fir.Gallery(dev_ptr=rows.data_ptr(), n=n, d=d, metric=metric, device=0, stream=st.cuda_stream) as g:
+            k1 = keys_of(fir, g, queries, st)
+            assert "k_nominate" in g.last_dispatch()["kernel"]
+            kk = torch.empty((qb, k), device="cuda", dtype=torch.int64)
+            g.search_topk_keys_dev(queries.data_ptr(), qb, k, kk.data_ptr(), stream=st.cuda_stream)
+            st.synchronize()
+        i1, d1 = fir.keys_unpack(k1)
+        i5, d5 = fir.keys_unpack(kk.cpu().numpy().view(np.uint64).reshape(-1))
+        return i1, d1, i5, d5
+
+    base = run(x, q)
+    assert np.array_equal(base[2].reshape(qb, k)[:, 0], base[0])
+    for e in (3, -3):
+        xs, qs = (x * 2.0 ** e).contiguous(), (q * 2.0 ** e).contiguous()
+        torch.cuda.synchronize()
+        got = run(xs, qs)
+        assert np.array_equal(got[0], base[0]) and np.array_equal(got[2], base[2])
+        assert np.array_equal(got[1].view(np.uint32), (base[1] * np.float32(2.0 ** e)).view(np.uint32))
+        assert np.array_equal(got[3].view(np.uint32), (base[3] * np.float32(2.0 ** e)).view(np.uint32))
+        del xs, qs
+    del x
+    torch.cuda.empty_cache()
