@@ -378,3 +378,39 @@ def test_knn_at_scale_takes_the_matrix_cores_by_default(fir, oracle):
     assert np.array_equal(k1[:256], e1) and np.array_equal(k3[:256], e3)
     assert np.mean(k1 == pick.cpu().numpy()) > 0.99
     assert st["matrix_core_queries"] == 2 * qb and st["exact_scan_queries_of_them"] <= qb // 16, st
+
+
+def test_knn_through_the_matrix_cores_is_scale_free(fir):
+    """Training rows, their average and the queries all multiplied by 2^e (exact in float64): every distance scales by 4^e, so kNN-1 and
+    kNN-3 classes are the same -- through the matrix-core path the centred rows' fp16 fragments are cut with a different power-of-two
+    scale and the certificate's window scales with them. e = 9 and e = -11 against e = 0, which is checked against the exact scan."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda", 0)
+    n, d, ncls, qb = 300_000, 256, 300, 512
+    g = torch.Generator(device=dev)
+    g.manual_seed(41)
+    centres = torch.rand((ncls, d), generator=g, device=dev, dtype=torch.float64)
+    tcls = (torch.arange(n, device=dev) * ncls // n).to(torch.int64)
+    tr = centres[tcls] + 0.05 * torch.randn((n, d), generator=g, device=dev, dtype=torch.float64)
+    pick = torch.randint(0, ncls, (qb,), generator=g, device=dev)
+    q = centres[pick] + 0.05 * torch.randn((qb, d), generator=g, device=dev, dtype=torch.float64)
+    cls32 = tcls.to(torch.int32).cpu().numpy()
+    res = {}
+    for e in (0, 9, -11):
+        trs = (tr * 2.0 ** e).contiguous()
+        avg = trs.mean(dim=0).cpu().numpy() if e == 0 else res["avg0"] * 2.0 ** e
+        if e == 0:
+            res["avg0"] = avg
+        qs = (q * 2.0 ** e).cpu().numpy()
+        torch.cuda.synchronize()
+        with fir.ClsModel(None, cls32, ncls, avg, 0, dev_ptr=trs.data_ptr(), nt=n, d=d) as m:
+            k1, k3 = m.knn_predict(qs, 1), m.knn_predict(qs, 3)
+            st = m.knn_stats()
+            assert st["matrix_core_queries"] == 2 * qb and st["exact_scan_queries_of_them"] <= qb // 8, st
+            if e == 0:
+                m.set_knn_mfma(0)
+                assert np.array_equal(k1[:128], m.knn_predict(qs[:128], 1)) and np.array_equal(k3[:128], m.knn_predict(qs[:128], 3))
+        res[e] = (k1, k3)
+        del trs
+    for e in (9, -11):
+        assert np.array_equal(res[e][0], res[0][0]) and np.array_equal(res[e][1], res[0][1]), e
