@@ -703,3 +703,50 @@ def test_the_device_pointer_call_returns_before_its_kernels_have_run(fir):
     idx, _ = fir.keys_unpack(k1.cpu().numpy().view(np.uint64))
     assert idx[5] == -1 and idx[6] == 1234
     assert 3 <= stats["fallback_queries"] <= 6, stats     # the NaN query of each of the three calls went to the exact device scan
+
+
+@pytest.mark.parametrize("qb", [5, 16, 24])
+def test_small_calls_with_hard_queries_at_1m(fir, qb):
+    """The few-block forms of the matrix-core pass (k_gemm_proxy_f16x<3, 0, 0, 0, 1 | 2>: a call of at most 16 / 32 queries multiplies
+    against its live query blocks only, its first row block is summed once, and what it cannot certify goes straight to the exact
+    device scan) with the queries that make trouble: a NaN component, an infinite one, an all-zero query, an exact copy of a row that
+    has a duplicate further down (the lower row wins), a query one ulp from a row, a query midway between two rows. Keys = the exact
+    scan's, several calls in a row (state carried between calls would show)."""
+    dev = torch.device("cuda", 0)
+    n, d = 1_000_000, 512
+    g0 = torch.Generator(device=dev)
+    g0.manual_seed(77 + qb)
+    x = torch.rand((n, d), generator=g0, device=dev)
+    x = (x / x.norm(dim=1, keepdim=True)).contiguous()
+    x[900_001] = x[4321]                                       # duplicate further down
+    q = torch.rand((qb, d), generator=g0, device=dev)
+    q = (q / q.norm(dim=1, keepdim=True)).contiguous()
+    q[0, 3] = float("nan")
+    q[1, 5] = float("inf")
+    q[2] = 0.0
+    q[3] = x[4321]
+    q[4] = x[777_777]
+    q[4, 9] = torch.nextafter(q[4, 9], torch.tensor(2.0, device=dev))
+    if qb > 5:
+        q[5] = 0.5 * (x[10] + x[999_990])
+    torch.cuda.synchronize()
+    st = torch.cuda.Stream()
+    ka = torch.empty(qb, dtype=torch.int64, device=dev)
+    ke = torch.empty(qb, dtype=torch.int64, device=dev)
+    with torch.cuda.stream(st):
+        with fir.Gallery(dev_ptr=x.data_ptr(), n=n, d=d, metric=0, device=0, stream=st.cuda_stream) as g:
+            g.set_large_batch_mfma(0)
+            g.search_top1_keys_dev(q.data_ptr(), qb, ke.data_ptr(), stream=st.cuda_stream)
+            st.synchronize()
+            g.set_large_batch_mfma(-1)
+            for call in range(4):
+                ka.fill_(-7)
+                g.search_top1_keys_dev(q.data_ptr(), qb, ka.data_ptr(), stream=st.cuda_stream)
+                st.synchronize()
+                kern = g.last_dispatch()["kernel"]
+                assert ("f16x<3, 0, 0, 0, 1>" in kern) if qb <= 16 else ("f16x<3, 0, 0, 0, 2>" in kern), kern
+                assert torch.equal(ka, ke), (call, qb)
+            stats = g.mfma_stats()
+    idx, dist = fir.keys_unpack(ke.cpu().numpy().view(np.uint64))
+    assert idx[0] == -1 and idx[3] == 4321 and dist[3] == 0 and idx[4] == 777_777
+    assert stats["second_pass_queries"] >= 4 and stats["fallback_queries"] >= 4, stats      # the NaN query of every call: no second-chance round below 33 queries, the exact device scan
