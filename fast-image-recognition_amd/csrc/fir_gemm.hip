@@ -1592,12 +1592,14 @@ static fir_x_fn pick_x(int mode, bool streamed, bool odd, int dbg = 0, int njb =
         if (njb == 2) return streamed ? k_gemm_proxy_f16x<3, 1, 0, 0, 2> : k_gemm_proxy_f16x<3, 0, 0, 0, 2>;
     }
     if (dbg && mode == 3 && !streamed && !odd) {       // timing experiments (FIR_GEMM_DBG_SKIP): wrong answers
-        switch (dbg & 127) {
+        switch (dbg & 1023) {
             case 1: return k_gemm_proxy_f16x<3, 0, 0, 1>;
             case 2: return k_gemm_proxy_f16x<3, 0, 0, 2>;
             case 3: return k_gemm_proxy_f16x<3, 0, 0, 3>;
             case 5: return k_gemm_proxy_f16x<3, 0, 0, 5>;
             case 7: return k_gemm_proxy_f16x<3, 0, 0, 7>;
+            case 512: return k_gemm_proxy_f16x<3, 0, 0, 512>;   // (not a wrong-answer form: the L2 touch two units ahead by one workgroup in sixteen)
+            case 256: return k_gemm_proxy_f16x<3, 0, 0, 256>;   // (not a wrong-answer form: timestamps of workgroup 0's load bursts, FIR_GEMM_DUMP_PHASES)
             case 64: return k_gemm_proxy_f16x<3, 0, 0, 64>;     // (not a wrong-answer form: the gallery pieces one behind each MFMA pair of a unit's first step)
             case 33: return k_gemm_proxy_f16x<3, 0, 0, 33>;     // no MFMAs, no epilogue: the gallery stream + the query-fragment re-reads
             case 37: return k_gemm_proxy_f16x<3, 0, 0, 37>;     // ... the gallery stream alone
@@ -1760,7 +1762,7 @@ int fir_gemm_create_range_ex_(fir_gallery* g, int32_t precision, int32_t end_pos
     if (const char* w = fir_knob_("FIR_GEMM_PRIO")) m->prio = std::atoi(w) != 0;
     if (const char* w = fir_knob_("FIR_GEMM_NO_BLOCK_BOUND")) m->no_block_bound = std::atoi(w) != 0;
 #ifdef FIR_AUDIT      // knobs that change answers: the audit build only (libfir_amd_audit.so; fir_internal.h)
-    if (const char* w = fir_knob_("FIR_GEMM_DBG_SKIP")) m->dbg_skip = std::atoi(w) & 127;
+    if (const char* w = fir_knob_("FIR_GEMM_DBG_SKIP")) m->dbg_skip = std::atoi(w) & 1023;
     if (const char* w = fir_knob_("FIR_GEMM_DBG_BLOCK")) m->dbg_block = std::atoi(w) == 256 ? 256 : kGemmBlock;     // timing experiments only: the answers are wrong
     if (const char* w = fir_knob_("FIR_GEMM_EREL_SCALE")) m->erel_scale = (float)std::atof(w);
 #endif
@@ -2302,6 +2304,16 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
     if (!one_stream) GEMM_HIP(hipStreamWaitEvent(st, m->rerank_done[(nsb - 1) & 1], 0));   // join the side stream (it is in order: the last re-rank is the last thing on it)
     GEMM_HIP(hipGetLastError());
 #ifdef FIR_AUDIT
+    if (const char* path = fir_knob_("FIR_GEMM_DUMP_PHASES")) {     // audit builds, with FIR_GEMM_DBG_SKIP=256: the load-burst timestamps of the last super-batch's first pair
+        GEMM_HIP(hipStreamSynchronize(st));
+        std::vector<unsigned long long> h(8 * 256);
+        GEMM_HIP(hipMemcpy(h.data(), m->lists[(nsb - 1) & 1] + (size_t)(2 * kQT - 1) * kListCap + 2048, h.size() * 8, hipMemcpyDeviceToHost));
+        if (FILE* f = std::fopen(path, "w")) {
+            for (int w = 0; w < 8; ++w)
+                for (int u = 0; u < 240; ++u) std::fprintf(f, "%d %d %llu %llu\n", w, u, h[(size_t)w * 256 + u] >> 20, h[(size_t)w * 256 + u] & 0xFFFFFull);
+            std::fclose(f);
+        }
+    }
     if (fir_knob_("FIR_GEMM_DEBUG_COUNTS")) {       // audit builds: appended rows per query of the last super-batch (synchronises)
         GEMM_HIP(hipStreamSynchronize(st));
         const int nql = std::min(sbq, qb - (nsb - 1) * sbq);

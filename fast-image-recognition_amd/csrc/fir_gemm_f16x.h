@@ -360,6 +360,8 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
         __syncthreads();
     };
     int blk_no = 0;
+    int dbg_units = 0;                               // (DBG & 256: units walked so far)
+    int touch_e = 0, touch_o = 0;                    // (DBG & 512)
     int64_t rg_next = rg;
     for (; rg < rg_end; rg = rg_next) {
         const bool warm_it = warm;                        // this wave's first row block: T is still what it was preset to
@@ -472,6 +474,8 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
             // The next unit's eight gallery pieces are requested in one burst in front of the unit. (DBG & 16, measured and not kept: two per
             // step, behind the fourth and the eighth pair of MFMAs -- every piece still exactly one unit before its use -- ran 6 % slower at
             // 512 features and 5 % at 256: profiles/r03_gemm_time_decomposition.txt.)
+            unsigned long long t_burst0 = 0;
+            if (DBG & 256) t_burst0 = __builtin_amdgcn_s_memtime();
             if (!(DBG & 16) && !(DBG & 2) && !(DBG & 64)) {
                 if (nt) {
 #pragma unroll
@@ -480,6 +484,26 @@ __global__ void __launch_bounds__(kGemmBlock, 1) k_gemm_proxy_f16x(const uint4* 
 #pragma unroll
                     for (int u = 0; u < RING; ++u) N[u] = src[(size_t)u * 64 + lane];
                 }
+            }
+            if ((DBG & 512) && pair_of_wg == 0) {
+                // (experiment, audit build: ONE of the workgroups that share a row range asks for the unit after next -- one dword per 128-byte
+                // line, 64 lines = the unit's 8 KiB -- so that the fragments are in the XCD's L2 when the sixteen readers' bursts come for them;
+                // the value is looked at two units later, by the next unit of the same parity)
+                const uint4* tgt = h + 2 < units ? a_cur + (size_t)(h + 2) * RING * 64 : a_nxt + (size_t)(h + 2 - units) * RING * 64;
+                int& tch = (h & 1) ? touch_o : touch_e;
+                asm volatile("" ::"v"(tch));
+                tch = *(const int*)(tgt + (size_t)lane * 8);
+            }
+            if (DBG & 256) {
+                // (timing probe, audit build: when this wave started issuing the unit's eight loads and when the last of them had been issued --
+                // s_memtime is a scalar instruction: it issues in order behind them -- for the first 240 units of workgroup 0's waves, kept in the
+                // unused tail of the pair's last candidate list: profiles/r04_wave_phases.txt)
+                const unsigned long long t_burst1 = __builtin_amdgcn_s_memtime();
+                if (blockIdx.x == 0 && dbg_units < 240 && lane == 0) {
+                    unsigned long long* dst = lists + (size_t)(2 * kQT - 1) * kListCap + 2048 + (size_t)wave * 256;
+                    dst[dbg_units] = (t_burst0 << 20) | ((t_burst1 - t_burst0) & 0xFFFFFull);
+                }
+                ++dbg_units;
             }
             if (h == units - 1 && full_block) {
                 // (wave-uniform base + a lane offset made here: hoisted out of the row loop, `gnorm + 4 (lane >> 4)` is a 64-bit register
