@@ -1591,6 +1591,7 @@ static fir_x_fn pick_x(int mode, bool streamed, bool odd, int dbg = 0, int njb =
         if (njb == 1) return streamed ? k_gemm_proxy_f16x<3, 1, 0, 0, 1> : k_gemm_proxy_f16x<3, 0, 0, 0, 1>;
         if (njb == 2) return streamed ? k_gemm_proxy_f16x<3, 1, 0, 0, 2> : k_gemm_proxy_f16x<3, 0, 0, 0, 2>;
     }
+#ifdef FIR_AUDIT      // (the timing forms are instantiated in the audit build only: the shipped library cannot select them)
     if (dbg && mode == 3 && !streamed && !odd) {       // timing experiments (FIR_GEMM_DBG_SKIP): wrong answers
         switch (dbg & 1023) {
             case 1: return k_gemm_proxy_f16x<3, 0, 0, 1>;
@@ -1609,6 +1610,7 @@ static fir_x_fn pick_x(int mode, bool streamed, bool odd, int dbg = 0, int njb =
             default: break;
         }
     }
+#endif
     if (mode == 1) return streamed ? (odd ? k_gemm_proxy_f16x<1, 1, 1> : k_gemm_proxy_f16x<1, 1, 0>) : (odd ? k_gemm_proxy_f16x<1, 0, 1> : k_gemm_proxy_f16x<1, 0, 0>);
     if (mode == 3) return streamed ? (odd ? k_gemm_proxy_f16x<3, 1, 1> : k_gemm_proxy_f16x<3, 1, 0>) : (odd ? k_gemm_proxy_f16x<3, 0, 1> : k_gemm_proxy_f16x<3, 0, 0>);
     if (mode == 4) return streamed ? (odd ? k_gemm_proxy_f16x<4, 1, 1> : k_gemm_proxy_f16x<4, 1, 0>) : (odd ? k_gemm_proxy_f16x<4, 0, 1> : k_gemm_proxy_f16x<4, 0, 0>);
