@@ -288,7 +288,10 @@ bool wants_mfma(const fir_gallery* g, int32_t qb, int32_t start, int32_t end) {
         // of the device the gallery lives on, the fixed terms -- launches, synchronisation -- do not)
         const double mbs = (double)g->n * (double)end * 4.0 / 1.0e6 * (256.0 / std::max(g->cus, 1));
         const bool streamed = end > 512;
-        const double mfma_us = (streamed ? 225.0 : 125.0) + (double)((qb + 127) / 128) * (streamed ? 0.12 : 0.06) * mbs;
+        // (round 4: every super-batch finds its threshold on the way and small calls stay on one stream -- the matrix-core call's fixed part
+        // fell from ~125 / 225 us to ~100 / 170 us: 8 192 x 512, 128 / 256 / 1 024 queries 103 / 100 / 115 us, 65 536 x 512 98 / 99 / 162,
+        // 8 192 x 1280 148 / 200 / 231, 65 536 x 1280 172 / 234 / 446: profiles/r04_adaptive_cutoff.txt)
+        const double mfma_us = (streamed ? 170.0 : 100.0) + (double)((qb + 127) / 128) * (streamed ? 0.12 : 0.06) * mbs;
         const double scan_us = 40.0 + (double)((qb + 15) / 16) * (2.0 + 0.25 * mbs);
         return mfma_us * 1.15 < scan_us;
     }

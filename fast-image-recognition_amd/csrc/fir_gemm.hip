@@ -2050,11 +2050,13 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
     // the same flow on the 16-row fragment order: k_gemm_proxy_f16x<2, *> is its sample pass, for any row length
     const bool x_flow = m->precision == FIR_GEMM_F16 && m->mfma16 && m->share_max > 0 && (grid & 7) == 0 && grid >= 8;
     const bool rt_flow = rt_main != nullptr || x_flow;
-    // The adaptive threshold needs every workgroup to see enough rows for the bounds to travel: with the rows of a pair cut into
-    // (CUs / pairs per launch) ranges, that is (row groups) * (pairs per launch) / CUs row groups per workgroup. Below a dozen (a
-    // cache-resident gallery, or one pair over 256 ranges of 100 000 rows) every workgroup is still in its loose early phase when
-    // it ends -- 1 000-2 400 appended rows per query measured at 100k x 512 with 256 queries, against ~20 through the sample
-    // flow, 13 % fewer queries/s -- so such super-batches keep the sample flow.
+    // Which super-batches find their threshold on the way. Until round 4's second half the answer depended on how many row groups a
+    // workgroup sees ((row groups) * (pairs per launch) / CUs: below a dozen the bound is still loose when the workgroup ends, 1 000-2 400
+    // appended rows per query at 100k x 512 with 256 queries) and such super-batches kept the sample flow. Since an appended row no longer
+    // waits for the gallery prefetch and a wave's first row block is summed once, the pass on the way is never slower for top-1 and
+    // 10-23 % faster wherever the sample flow used to run (8 192 .. 700 000 rows x 128 .. 4 096 queries, no second pass anywhere:
+    // profiles/r04_adaptive_cutoff.txt): top-1 always takes it. The K-nearest form (eight slots per query fill more slowly) wins from eight
+    // pairs per launch on and on cache-sized galleries, and loses 3-35 % with one or two pairs over 100 000+ rows: those keep the sample flow.
     auto adaptive_for = [&](int nq_sb) -> bool {
         if (!(x_flow && m->adaptive > 0 && (k == 1 || m->adaptive_topk))) return false;
         if (m->adaptive > 1) return true;                                   // FIR_GEMM_ADAPTIVE=2: always
@@ -2065,7 +2067,8 @@ static int gemm_search(fir_gemm* m, const float* d_queries, int32_t qb, int k, u
         const int64_t row_groups = ((n + 31) / 32 + kGemmBlock / 64 - 1) / (kGemmBlock / 64);
         // (the K-nearest form's eight slots per query fill more slowly: 256 queries against 1M x 512 measured 479 k q/s against the sample
         // flow's 514 k, 4 096 queries 1.02 M against 0.92 M -- profiles/r04_topk_slots.txt)
-        return row_groups * P / std::max(grid, 1) >= (k > 1 ? 100 : 12);
+        if (k == 1) return true;
+        return P >= 8 || n <= 65536 || row_groups * P / std::max(grid, 1) >= 100;
     };
 #ifdef FIR_AUDIT
     // 1 = no refresh, 2 = no exchange of the adaptive bound between workgroups (still sound: a looser bound appends more -- this is how

@@ -500,7 +500,7 @@ def test_default_dispatch_on_cache_resident_galleries(fir, oracle):
     the matrix cores down to a few thousand rows -- from the fourth such call on: the state is not built for one-off calls --, small
     ones and the reference's own gallery size with a few hundred queries stay with the scan. Same keys either way, the oracle's on a
     sample."""
-    for n, d, qb, want in ((40000, 512, 128, "mfma"), (40000, 512, 32, "scan"), (16384, 512, 1024, "mfma"), (16384, 512, 128, "scan"),
+    for n, d, qb, want in ((40000, 512, 128, "mfma"), (40000, 512, 32, "scan"), (16384, 512, 1024, "mfma"), (16384, 512, 128, "mfma"), (8192, 512, 64, "scan"),
                            (3030, 1536, 256, "scan"), (3030, 1536, 2000, "mfma"), (1500, 512, 2000, "scan")):
         rows = synth.make_gallery(n % 89, n, d, 0)
         q, _ = synth.make_queries(n % 89, rows, qb, 0)
