@@ -409,7 +409,6 @@ extern "C" int fir_gemm_knn_f64_(fir_gemm* m, const double* d_qc, int32_t qb, in
         }
     }
     const int b = 0;
-    const int64_t row_groups = ((n + 31) / 32 + kGemmBlock / 64 - 1) / (kGemmBlock / 64);
     const int share_cap = streamed ? std::min(m->share_max, m->share_streamed) : m->share_max;
     const size_t rr_lds = (size_t)m->dp2 * sizeof(double2);
     bool first = true;
@@ -419,7 +418,9 @@ extern "C" int fir_gemm_knn_f64_(fir_gemm* m, const double* d_qc, int32_t qb, in
         const double* dq = d_qc + (size_t)q0 * d;
         int Pmax = 1;
         while (Pmax * 2 <= pairs && Pmax * 2 <= share_cap) Pmax *= 2;
-        const bool adaptive = m->adaptive > 0 && (kp == 1 || m->adaptive_topk) && (m->adaptive > 1 || row_groups * Pmax / std::max(grid, 1) >= (kp > 1 ? 100 : 12));
+        // (every super-batch: the pass starts from a threshold seeded by the row sample, so it is tight from its first row block on whatever the
+        // number of row groups a workgroup sees -- 128 queries per call over 1M x 512: 1.83 -> 1.45 ms; profiles/r04_adaptive_cutoff.txt)
+        const bool adaptive = m->adaptive > 0 && (kp == 1 || m->adaptive_topk);
         hipLaunchKernelGGL(k_gemm_qprep_f16_f64, dim3(pairs * 2 * kQT), dim3(64), 0, st, dq, nq, d, m->gallery_exp, m->qnorm[b], m->qmul[b], m->qinv[b], m->counts[b], m->awin[b],
                            adaptive ? m->aT[b] : (unsigned int*)nullptr, (const float*)m->gmax, e_rel, kp > 1 ? kp : 0);
         hipLaunchKernelGGL(k_gemm_pack_queries_f16x_f64, dim3((4 * m->dk16 * 64 + 255) / 256, pairs), dim3(256), 0, st, dq, nq, d, m->dk16, (const float*)m->qmul[b], m->qbf[b]);
